@@ -1,0 +1,116 @@
+"""ctypes binding of libghm.so (include/ghm.h).  There is no CPU fallback: if the library is
+missing, or a call fails, this raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libghm.so")
+
+
+class GhmError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """ghm_conv_desc"""
+    _fields_ = [("N", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("K", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+                ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("x_nstride", C.c_int64), ("y_nstride", C.c_int64)]
+
+
+_p, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_D = C.POINTER(ConvDesc)
+
+# name -> argtypes (return type is int unless listed in _SPECIAL)
+SIGNATURES = {
+    "ghm_device_count": [C.POINTER(_i32)],
+    "ghm_ctx_create": [_i32, C.POINTER(_p)],
+    "ghm_ctx_destroy": [_p],
+    "ghm_device_info": [_p, C.c_char_p, _i32, C.POINTER(_i32), C.POINTER(_i64)],
+    "ghm_alloc": [_p, C.c_size_t, C.POINTER(_p)],
+    "ghm_free": [_p, _p],
+    "ghm_h2d": [_p, _p, _p, C.c_size_t],
+    "ghm_d2h": [_p, _p, _p, C.c_size_t],
+    "ghm_d2d": [_p, _p, _p, C.c_size_t],
+    "ghm_memset_zero": [_p, _p, C.c_size_t],
+    "ghm_sync": [_p],
+    "ghm_capture_begin": [_p],
+    "ghm_capture_end": [_p, C.POINTER(_p)],
+    "ghm_graph_launch": [_p, _p],
+    "ghm_graph_destroy": [_p],
+    "ghm_timer_start": [_p, _i32],
+    "ghm_timer_stop": [_p, _i32],
+    "ghm_timer_elapsed_ms": [_p, _i32, C.POINTER(_f)],
+    "ghm_conv2d_fwd": [_p, _D, _p, _p, _p, _p, _i32, _f, _i32],
+    "ghm_conv2d_dgrad": [_p, _D, _p, _p, _p, _p, _i32, _f, _i32],
+    "ghm_conv2d_wgrad_workspace": [_D, C.POINTER(C.c_size_t)],
+    "ghm_conv2d_wgrad": [_p, _D, _p, _p, _p, _p, _i32],
+    "ghm_channel_sum": [_p, _p, _i32, _i32, _i32, _i64, _p, _i32],
+    "ghm_bn_stats": [_p, _p, _i32, _i32, _i32, _i64, _f, _p, _p, _p, _p, _f, _p],
+    "ghm_bn_apply": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _f],
+    "ghm_bn_backward": [_p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p,
+                        _i32, _f, _i32, _p],
+    "ghm_act_fwd": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _f],
+    "ghm_act_bwd": [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _f, _i32],
+    "ghm_maxpool2_fwd": [_p, _p, _p, _i32, _i32, _i32, _i32],
+    "ghm_maxpool2_bwd": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f],
+    "ghm_avgpool_fwd": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32],
+    "ghm_avgpool_bwd": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32],
+    "ghm_upsample_nearest2_fwd": [_p, _p, _i64, _p, _i32, _i32, _i32, _i32],
+    "ghm_upsample_nearest2_bwd": [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32],
+    "ghm_upsample_bilinear2_fwd": [_p, _p, _i64, _p, _i32, _i32, _i32, _i32],
+    "ghm_upsample_bilinear2_bwd": [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32],
+    "ghm_copy_view": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32],
+    "ghm_axpby": [_p, _f, _p, _f, _p, _i64],
+    "ghm_lsgan_loss": [_p, _p, _i64, _f, _p, _p, _f, _i32],
+    "ghm_bce_loss": [_p, _p, _i64, _f, _p, _p, _f, _i32],
+    "ghm_recon_loss": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _i64, _f, _i32],
+    "ghm_rmsprop": [_p, _p, _p, _p, _i64, _p, _f, _f, _f],
+    "ghm_adam": [_p, _p, _p, _p, _p, _i64, _p, _f, _f, _f, _f],
+    "ghm_adam_tick": [_p, _p],
+    "ghm_comm_unique_id": [C.POINTER(C.c_uint8 * 128)],
+    "ghm_comm_init": [_p, _i32, _i32, C.POINTER(C.c_uint8 * 128)],
+    "ghm_comm_destroy": [_p],
+    "ghm_allreduce_sum": [_p, _p, _i64],
+    "ghm_allreduce_max": [_p, _p, _i64],
+    "ghm_conv2d_variant": [_D, _i32, C.c_char_p, _i32],
+}
+_SPECIAL = {"ghm_last_error": ([], C.c_char_p), "ghm_bn_workspace": ([_i32], C.c_size_t)}
+
+_lib = None
+
+
+def load():
+    """dlopen libghm.so and type every export of include/ghm.h.  Raises GhmError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GhmError("%s not found: build it with `python gan_heightmaps_amd/csrc/build.py` "
+                       "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name, (args, res) in _SPECIAL.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().ghm_last_error()
+        raise GhmError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)
+
+
+def all_export_names():
+    return list(SIGNATURES) + list(_SPECIAL)

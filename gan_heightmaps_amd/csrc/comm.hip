@@ -1,0 +1,107 @@
+// Data-parallel gradient exchange: RCCL all-reduce over xGMI on the ctx stream.
+// librccl is loaded lazily (dlopen) so that single-GPU runs never touch it.  The reference has no
+// collective code at all; one process per GPU, gradients summed per net bucket.
+#include <dlfcn.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+
+// minimal RCCL surface (nccl.h ABI): ncclUniqueId is 128 opaque bytes
+typedef struct { char internal[128]; } rccl_uid;
+typedef void* rccl_comm;
+enum { RCCL_FLOAT32 = 7 };
+enum { RCCL_SUM = 0, RCCL_MAX = 2 };
+
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(rccl_uid*) = nullptr;
+    int (*CommInitRank)(rccl_comm*, int, rccl_uid, int) = nullptr;
+    int (*CommDestroy)(rccl_comm) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+RcclApi g_api;
+
+int load_rccl() {
+    if (g_api.handle) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+        g_api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (g_api.handle) break;
+    }
+    GHM_CHECK(g_api.handle != nullptr, "cannot dlopen librccl: %s", dlerror());
+#define RCCL_SYM(field, name)                                          \
+    *(void**)(&g_api.field) = dlsym(g_api.handle, name);               \
+    GHM_CHECK(g_api.field != nullptr, "librccl lacks symbol %s", name)
+    RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+    RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    RCCL_SYM(AllReduce, "ncclAllReduce");
+    RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RCCL_SYM
+    return 0;
+}
+
+#define GHM_RCCL(expr)                                                                        \
+    do {                                                                                      \
+        int _r = (expr);                                                                      \
+        if (_r != 0) {                                                                        \
+            ghm_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, g_api.GetErrorString(_r)); \
+            return -4;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int ghm_comm_unique_id(uint8_t id_out[128]) {
+    if (int e = load_rccl()) return e;
+    rccl_uid id;
+    GHM_RCCL(g_api.GetUniqueId(&id));
+    memcpy(id_out, id.internal, 128);
+    return 0;
+}
+
+int ghm_comm_init(ghm_ctx* ctx, int32_t rank, int32_t world, const uint8_t id[128]) {
+    if (int e = load_rccl()) return e;
+    GHM_CHECK(ctx->comm == nullptr, "communicator already initialised");
+    GHM_HIP(hipSetDevice(ctx->device));
+    rccl_uid uid;
+    memcpy(uid.internal, id, 128);
+    rccl_comm comm = nullptr;
+    GHM_RCCL(g_api.CommInitRank(&comm, world, uid, rank));
+    ctx->comm = comm;
+    ctx->rank = rank;
+    ctx->world = world;
+    return 0;
+}
+
+int ghm_comm_destroy(ghm_ctx* ctx) {
+    if (ctx->comm && g_api.handle) {
+        GHM_RCCL(g_api.CommDestroy((rccl_comm)ctx->comm));
+    }
+    ctx->comm = nullptr;
+    ctx->world = 1;
+    ctx->rank = 0;
+    return 0;
+}
+
+int ghm_allreduce_sum(ghm_ctx* ctx, float* buf, int64_t n) {
+    if (ctx->world == 1 && ctx->comm == nullptr) return 0;   // single process: the sum is the identity
+    GHM_CHECK(ctx->comm != nullptr, "ghm_allreduce_sum without ghm_comm_init");
+    GHM_RCCL(g_api.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT32, RCCL_SUM, (rccl_comm)ctx->comm, ctx->stream));
+    return 0;
+}
+
+int ghm_allreduce_max(ghm_ctx* ctx, float* buf, int64_t n) {
+    if (ctx->world == 1 && ctx->comm == nullptr) return 0;
+    GHM_CHECK(ctx->comm != nullptr, "ghm_allreduce_max without ghm_comm_init");
+    GHM_RCCL(g_api.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT32, RCCL_MAX, (rccl_comm)ctx->comm, ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// Internal helpers shared by the libghm.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/ghm.h"
+
+struct ghm_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+struct ghm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start[64] = {};
+    hipEvent_t ev_stop[64] = {};
+    void* comm = nullptr;          // ncclComm_t (RCCL), owned by comm.hip
+    int rank = 0, world = 1;
+    int num_cu = 256;
+    bool capturing = false;
+};
+
+void ghm_set_error(const char* fmt, ...);
+
+#define GHM_HIP(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            ghm_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return -1;                                                                      \
+        }                                                                                   \
+    } while (0)
+
+#define GHM_CHECK(cond, ...)                 \
+    do {                                     \
+        if (!(cond)) {                       \
+            ghm_set_error(__VA_ARGS__);      \
+            return -2;                       \
+        }                                    \
+    } while (0)
+
+#define GHM_LAUNCH_CHECK() GHM_HIP(hipGetLastError())
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// activation and its derivative expressed through the OUTPUT (valid for all five kinds)
+__device__ __forceinline__ float ghm_act(float v, int act, float alpha) {
+    switch (act) {
+        case GHM_ACT_RELU: return v > 0.f ? v : 0.f;
+        case GHM_ACT_LRELU: return v > 0.f ? v : alpha * v;
+        case GHM_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        case GHM_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+__device__ __forceinline__ float ghm_dact_from_out(float y, int act, float alpha) {
+    switch (act) {
+        case GHM_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case GHM_ACT_LRELU: return y > 0.f ? 1.f : alpha;
+        case GHM_ACT_SIGMOID: return y * (1.f - y);
+        case GHM_ACT_TANH: return 1.f - y * y;
+        default: return 1.f;
+    }
+}

@@ -1,0 +1,712 @@
+// Implicit-GEMM convolution family for gfx950 (MI355X), fp32 in / fp32 accumulate on the matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32, 157 TFLOP/s peak -- MI355X_MICROARCH.md).
+//
+// One kernel template serves every "gather" convolution of the train step:
+//     out[n, r, (u*os+ou), (v*os+ov)] = act( bias[r] + sum_{t in taps} sum_{ch}
+//                                            A(t, ch, r) * in[n, ch, u*ss + di[t], v*ss + dj[t]] )
+//   forward conv (stride s):       os=1, ss=s, taps = all (a,b), di=a-pad,  A = wp[ch][tap][r]
+//   data gradient, stride 1:       os=1, ss=1, taps = all (a,b), di=pad-a,  A = wp[r][tap][ch]  (WT)
+//   data gradient, stride 2:       4 launches, one per output parity class (os=2), each with the taps
+//                                  whose parity matches; di = (ou+pad-a)/2                        (WT)
+//   Deconv2DLayer forward  = data-gradient form (+bias, +act); its data gradient = forward form.
+// GEMM view: rows = output channels r (MFMA "A" operand = weights), columns = output pixels (MFMA "B"
+// operand = gathered activations), so the accumulator fragment has lanes along pixels and the NCHW
+// stores / gathers are pixel-contiguous (coalesced 128 B per 32 lanes).  K index = tap-major,
+// channel-minor; a 16-deep K slab is staged through LDS (double-buffered, register-prefetched).
+//
+// The weight gradient is a second template: rows = (ch, tap) in packed order, columns = filters,
+// K = output pixels, split-K over pixel ranges with an fp32 partial reduce.
+//
+// Replaces Theano's CorrMM / GpuDnnConv{,GradW,GradI}.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MAX_TAPS 25
+
+struct IgemmArgs {
+    const float* in;
+    const float* wp;
+    const float* bias;
+    float* out;
+    int N, CH, Hin, Win;
+    long in_nstride;
+    int R, Hout, Wout;
+    long out_nstride;
+    int Hs, Ws;        // output sub-grid
+    int os, ou, ov;    // output position = u*os+ou
+    int ss;            // source stride
+    int T;             // taps in the weight layout (kh*kw)
+    int ntaps;         // taps used by this launch
+    int act;
+    float alpha;
+    int accumulate;
+    int di[MAX_TAPS], dj[MAX_TAPS], wi[MAX_TAPS];
+};
+
+// XCD-aware block remap: consecutive logical tiles (which share weights / halo pixels) land on the
+// same XCD's L2 (blocks are dispatched round-robin over the 8 XCDs). Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nb) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int BM, int BN, int WM, int WN, bool WT, bool FASTK>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+    constexpr int BK = 16;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int BROWS = 256 / BN, BLOADS = BK / BROWS;
+    constexpr int AV = BM / 4;                       // float4 per weight row (forward form)
+    constexpr int AROWS = 256 / AV;
+    constexpr int APASS = (BK + AROWS - 1) / AROWS;
+    constexpr int AT = BM / 16;                      // scalar loads per thread (WT form)
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+    float* As = smem;
+    float* Bs = smem + 2 * BK * LDA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntr = (a.R + BM - 1) / BM;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int r0 = (L % ntr) * BM;
+    const int p0 = (L / ntr) * BN;
+    const int hw_s = a.Hs * a.Ws;
+    const int P = a.N * hw_s;
+    const int HinWin = a.Hin * a.Win;
+    const int Ktot = a.ntaps * a.CH;
+    const int nslabs = (Ktot + BK - 1) / BK;
+
+    // ---- per-thread gather pixel ----
+    const int b_pix = tid % BN, b_row0 = tid / BN;
+    int sy0 = 0, sx0 = 0;
+    bool pvalid;
+    const float* inb = a.in;
+    {
+        const int p = p0 + b_pix;
+        pvalid = p < P;
+        const int pp = pvalid ? p : 0;
+        const int n = pp / hw_s, rem = pp - n * hw_s;
+        const int uu = rem / a.Ws, vv = rem - uu * a.Ws;
+        sy0 = uu * a.ss;
+        sx0 = vv * a.ss;
+        inb += (long)n * a.in_nstride;
+    }
+    const int a_c4 = tid % AV, a_row0 = tid / AV;    // forward-form weight loader
+    const int a_k = tid & 15, a_r0 = tid >> 4;       // WT-form weight loader
+    const bool rvec = (a.R & 3) == 0;
+
+    float breg[BLOADS];
+    float4 areg4[WT ? 1 : APASS];
+    float aregs[WT ? AT : 1];
+
+    auto load_slab = [&](int s) {
+        const int kk0 = s * BK;
+        if constexpr (FASTK) {
+            const int ti = kk0 / a.CH;               // uniform
+            const int ch0 = kk0 - ti * a.CH;
+            const int y = sy0 + a.di[ti], x = sx0 + a.dj[ti];
+            const bool ok = pvalid && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
+            const float* src = inb + (long)(ch0 + b_row0) * HinWin + (y * a.Win + x);
+#pragma unroll
+            for (int j = 0; j < BLOADS; ++j) breg[j] = ok ? src[(long)j * BROWS * HinWin] : 0.f;
+            const int tapw = a.wi[ti];
+            if constexpr (!WT) {
+#pragma unroll
+                for (int j = 0; j < APASS; ++j) {
+                    const int krow = a_row0 + j * AROWS;
+                    const int r = r0 + a_c4 * 4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (krow < BK) {
+                        const float* wrow = a.wp + ((long)(ch0 + krow) * a.T + tapw) * a.R;
+                        if (rvec) {
+                            if (r < a.R) v = *reinterpret_cast<const float4*>(wrow + r);
+                        } else {
+                            if (r + 0 < a.R) v.x = wrow[r + 0];
+                            if (r + 1 < a.R) v.y = wrow[r + 1];
+                            if (r + 2 < a.R) v.z = wrow[r + 2];
+                            if (r + 3 < a.R) v.w = wrow[r + 3];
+                        }
+                    }
+                    areg4[j] = v;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < AT; ++j) {
+                    const int r = r0 + a_r0 + j * 16;
+                    aregs[j] = (r < a.R) ? a.wp[((long)r * a.T + tapw) * a.CH + ch0 + a_k] : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < BLOADS; ++j) {
+                const int kk = kk0 + b_row0 + j * BROWS;
+                float v = 0.f;
+                if (kk < Ktot) {
+                    const int ti = kk / a.CH, ch = kk - ti * a.CH;
+                    const int y = sy0 + a.di[ti], x = sx0 + a.dj[ti];
+                    if (pvalid && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win)
+                        v = inb[(long)ch * HinWin + (y * a.Win + x)];
+                }
+                breg[j] = v;
+            }
+            if constexpr (!WT) {
+#pragma unroll
+                for (int j = 0; j < APASS; ++j) {
+                    const int krow = a_row0 + j * AROWS;
+                    const int kk = kk0 + krow;
+                    const int r = r0 + a_c4 * 4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (krow < BK && kk < Ktot) {
+                        const int ti = kk / a.CH, ch = kk - ti * a.CH;
+                        const float* wrow = a.wp + ((long)ch * a.T + a.wi[ti]) * a.R;
+                        if (r + 0 < a.R) v.x = wrow[r + 0];
+                        if (r + 1 < a.R) v.y = wrow[r + 1];
+                        if (r + 2 < a.R) v.z = wrow[r + 2];
+                        if (r + 3 < a.R) v.w = wrow[r + 3];
+                    }
+                    areg4[j] = v;
+                }
+            } else {
+                const int kk = kk0 + a_k;
+                const bool kv = kk < Ktot;
+                const int ti = kv ? kk / a.CH : 0, ch = kv ? kk - ti * a.CH : 0;
+                const int tapw = a.wi[ti];
+#pragma unroll
+                for (int j = 0; j < AT; ++j) {
+                    const int r = r0 + a_r0 + j * 16;
+                    aregs[j] = (kv && r < a.R) ? a.wp[((long)r * a.T + tapw) * a.CH + ch] : 0.f;
+                }
+            }
+        }
+    };
+
+    auto store_slab = [&](int buf) {
+        float* Ab = As + buf * BK * LDA;
+        float* Bb = Bs + buf * BK * LDB;
+#pragma unroll
+        for (int j = 0; j < BLOADS; ++j) Bb[(b_row0 + j * BROWS) * LDB + b_pix] = breg[j];
+        if constexpr (!WT) {
+#pragma unroll
+            for (int j = 0; j < APASS; ++j) {
+                const int krow = a_row0 + j * AROWS;
+                if (krow < BK) *reinterpret_cast<float4*>(Ab + krow * LDA + a_c4 * 4) = areg4[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < AT; ++j) Ab[a_k * LDA + a_r0 + j * 16] = aregs[j];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+
+    const int frag_k = lane >> 5, frag_i = lane & 31;
+    for (int s = 0; s < nslabs; ++s) {
+        const int buf = s & 1;
+        const bool more = (s + 1) < nslabs;
+        if (more) load_slab(s + 1);
+        const float* Ab = As + buf * BK * LDA + wm * (BM / WM) + frag_i;
+        const float* Bb = Bs + buf * BK * LDB + wn * (BN / WN) + frag_i;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ab[(ks * 2 + frag_k) * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bb[(ks * 2 + frag_k) * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lanes along pixels (D column = lane&31), rows = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int HWout = a.Hout * a.Wout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int p = p0 + wn * (BN / WN) + j * 32 + frag_i;
+        if (p >= P) continue;
+        const int n = p / hw_s, rem = p - n * hw_s;
+        const int uu = rem / a.Ws, vv = rem - uu * a.Ws;
+        float* ob = a.out + (long)n * a.out_nstride + (long)(uu * a.os + a.ou) * a.Wout + (vv * a.os + a.ov);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = r0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * frag_k;
+                if (r < a.R) {
+                    float v = acc[i][j][e];
+                    if (a.bias) v += a.bias[r];
+                    float* o = ob + (long)r * HWout;
+                    if (a.accumulate) v += *o;
+                    *o = ghm_act(v, a.act, a.alpha);
+                }
+            }
+        }
+    }
+}
+
+// Direct (VALU) form of the same gather convolution for R <= 4 output channels (g_out, d_out, pd_out,
+// dconv9, and the data gradients of the 1- and 4-channel first layers): one thread per output pixel.
+template <bool WT>
+__global__ __launch_bounds__(256) void direct_smallr_kernel(const IgemmArgs a) {
+    const int hw_s = a.Hs * a.Ws;
+    const long P = (long)a.N * hw_s;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int n = (int)(p / hw_s), rem = (int)(p - (long)n * hw_s);
+    const int uu = rem / a.Ws, vv = rem - uu * a.Ws;
+    const float* inb = a.in + (long)n * a.in_nstride;
+    const int HinWin = a.Hin * a.Win;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < a.ntaps; ++t) {
+        const int y = uu * a.ss + a.di[t], x = vv * a.ss + a.dj[t];
+        const bool ok = (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
+        const float* src = inb + (y * a.Win + x);
+        const int tapw = a.wi[t];
+#pragma unroll 4
+        for (int ch = 0; ch < a.CH; ++ch) {
+            const float v = ok ? src[(long)ch * HinWin] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < a.R) {
+                    const float w = WT ? a.wp[((long)r * a.T + tapw) * a.CH + ch]
+                                       : a.wp[((long)ch * a.T + tapw) * a.R + r];
+                    acc[r] = fmaf(v, w, acc[r]);
+                }
+            }
+        }
+    }
+    float* ob = a.out + (long)n * a.out_nstride + (long)(uu * a.os + a.ou) * a.Wout + (vv * a.os + a.ov);
+    const int HWout = a.Hout * a.Wout;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r < a.R) {
+            float v = acc[r];
+            if (a.bias) v += a.bias[r];
+            float* o = ob + (long)r * HWout;
+            if (a.accumulate) v += *o;
+            *o = ghm_act(v, a.act, a.alpha);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    float* out;
+    int N, C, H, W;
+    long x_nstride;
+    int K, Ho, Wo;
+    long y_nstride;
+    int kh, kw, stride, pad;
+    int CT;               // C * kh * kw rows
+    int P;                // N * Ho * Wo
+    int slabs_per_split;  // 32-pixel slabs per z-slice
+    long split_stride;    // elements between partial slices (0 when writing dwp directly)
+    int accumulate;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    constexpr int BKP = 32;
+    constexpr int LDA = BM + 1, LDB = BN + 1;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int AL = BM / 8, BL = BN / 8;
+    __shared__ __attribute__((aligned(16))) float smem[BKP * (LDA + LDB) + 2 * BM];   // single LDS stage,
+    float* As = smem;                                                               // next slab lives in registers
+    float* Bs = smem + BKP * LDA;
+    int* rowoff = reinterpret_cast<int*>(smem + BKP * (LDA + LDB));
+    int* rowdij = rowoff + BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int T = a.kh * a.kw;
+    const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
+
+    for (int row = tid; row < BM; row += 256) {
+        const int g = m0 + row;
+        if (g < a.CT) {
+            const int c = g / T, tap = g - c * T;
+            const int ta = tap / a.kw, tb = tap - ta * a.kw;
+            rowoff[row] = c * HW;
+            rowdij[row] = ((ta - a.pad) << 16) | ((tb - a.pad) & 0xffff);
+        } else {
+            rowoff[row] = -1;
+            rowdij[row] = 0;
+        }
+    }
+    __syncthreads();
+
+    const int lp = tid & 31, lg = tid >> 5;
+    const int total_slabs = (a.P + BKP - 1) / BKP;
+    const int s_begin = blockIdx.z * a.slabs_per_split;
+    const int s_end = min(s_begin + a.slabs_per_split, total_slabs);
+
+    float areg[AL], breg[BL];
+    auto load_slab = [&](int s) {
+        const int p = s * BKP + lp;
+        const bool pv = p < a.P;
+        const int pp = pv ? p : 0;
+        const int n = pp / HoWo, rem = pp - n * HoWo;
+        const int i = rem / a.Wo, j = rem - i * a.Wo;
+        const int sy = i * a.stride, sx = j * a.stride;
+        const float* xb = a.x + (long)n * a.x_nstride;
+        const float* yb = a.dy + (long)n * a.y_nstride + rem;
+#pragma unroll
+        for (int q = 0; q < AL; ++q) {
+            const int row = lg + q * 8;
+            const int off = rowoff[row], dij = rowdij[row];
+            const int y = sy + (dij >> 16), x = sx + (int)(short)(dij & 0xffff);
+            const bool ok = pv && off >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            areg[q] = ok ? xb[off + y * a.W + x] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < BL; ++q) {
+            const int co = n0 + lg + q * 8;
+            breg[q] = (pv && co < a.K) ? yb[(long)co * HoWo] : 0.f;
+        }
+    };
+    auto store_slab = [&]() {
+        float* Ab = As + lp * LDA;
+        float* Bb = Bs + lp * LDB;
+#pragma unroll
+        for (int q = 0; q < AL; ++q) Ab[lg + q * 8] = areg[q];
+#pragma unroll
+        for (int q = 0; q < BL; ++q) Bb[lg + q * 8] = breg[q];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frag_k = lane >> 5, frag_i = lane & 31;
+    if (s_begin < s_end) load_slab(s_begin);
+    for (int s = s_begin; s < s_end; ++s) {
+        store_slab();
+        __syncthreads();
+        if ((s + 1) < s_end) load_slab(s + 1);      // global loads fly under the MFMAs below
+        const float* Ab = As + wm * (BM / WM) + frag_i;
+        const float* Bb = Bs + wn * (BN / WN) + frag_i;
+#pragma unroll
+        for (int ks = 0; ks < BKP / 2; ++ks) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ab[(ks * 2 + frag_k) * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bb[(ks * 2 + frag_k) * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float* ob = a.out + (long)blockIdx.z * a.split_stride;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (BN / WN) + j * 32 + frag_i;
+        if (col >= a.K) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * frag_k;
+                if (row < a.CT) {
+                    float* o = ob + (long)row * a.K + col;
+                    float v = acc[i][j][e];
+                    if (a.accumulate) v += *o;
+                    *o = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ void reduce_splits_kernel(const float* __restrict__ part, int S, long n, long split_stride,
+                                     float* __restrict__ out, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[(long)k * split_stride + i];
+    if (accumulate) s += out[i];
+    out[i] = s;
+}
+
+// per-channel sum over (n, hw): bias gradients
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, int N, int HW, long nstride,
+                                                          float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* p = x + (long)n * nstride + (long)c * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = (accumulate ? out[c] : 0.f) + red[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: variant choice and launch
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Variant {
+    int bm, bn;
+};
+
+Variant pick_variant(int R, long P, int num_cu) {
+    int bm = R >= 96 ? 128 : (R >= 48 ? 64 : 32);
+    int big, small;
+    if (bm == 128) { big = 128; small = 64; }
+    else if (bm == 64) { big = 256; small = 64; }
+    else { big = 256; small = 128; }
+    const long ntr = (R + bm - 1) / bm;
+    const long blocks_big = ntr * ((P + big - 1) / big);
+    int bn = (blocks_big >= 2L * num_cu) ? big : small;
+    if (const char* f = getenv("GHM_FORCE_TILE")) {     // test knob: exercise both pixel-tile widths
+        if (f[0] == 'b') bn = big;
+        if (f[0] == 's') bn = small;
+    }
+    return {bm, bn};
+}
+
+template <bool WT>
+int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a) {
+    const long P = (long)a.N * a.Hs * a.Ws;
+    if (P == 0 || a.R == 0) return 0;
+    if (a.R <= 4) {
+        hipLaunchKernelGGL((direct_smallr_kernel<WT>), dim3(ceil_div(P, 256)), dim3(256), 0, ctx->stream, a);
+        GHM_LAUNCH_CHECK();
+        return 0;
+    }
+    const Variant v = pick_variant(a.R, P, ctx->num_cu);
+    const bool fast = (a.CH % 16) == 0;
+    const int grid = ceil_div(a.R, v.bm) * ceil_div(P, v.bn);
+#define GHM_IGEMM_CASE(BM_, BN_, WM_, WN_)                                                             \
+    if (v.bm == BM_ && v.bn == BN_) {                                                                  \
+        if (fast)                                                                                      \
+            hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, WT, true>), dim3(grid), dim3(256), 0, \
+                               ctx->stream, a);                                                        \
+        else                                                                                           \
+            hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, WT, false>), dim3(grid), dim3(256), 0, \
+                               ctx->stream, a);                                                        \
+        GHM_LAUNCH_CHECK();                                                                            \
+        return 0;                                                                                      \
+    }
+    GHM_IGEMM_CASE(128, 128, 2, 2)
+    GHM_IGEMM_CASE(128, 64, 2, 2)
+    GHM_IGEMM_CASE(64, 256, 1, 4)
+    GHM_IGEMM_CASE(64, 64, 2, 2)
+    GHM_IGEMM_CASE(32, 256, 1, 4)
+    GHM_IGEMM_CASE(32, 128, 1, 4)
+#undef GHM_IGEMM_CASE
+    ghm_set_error("no igemm variant for bm=%d bn=%d", v.bm, v.bn);
+    return -3;
+}
+
+int check_desc(const ghm_conv_desc* d) {
+    GHM_CHECK(d->kh * d->kw <= MAX_TAPS, "filter %dx%d exceeds %d taps", d->kh, d->kw, MAX_TAPS);
+    GHM_CHECK(d->stride == 1 || d->stride == 2, "stride %d unsupported", d->stride);
+    GHM_CHECK(d->Ho == (d->H + 2 * d->pad - d->kh) / d->stride + 1 &&
+                  d->Wo == (d->W + 2 * d->pad - d->kw) / d->stride + 1,
+              "inconsistent conv geometry H=%d W=%d k=%dx%d s=%d p=%d -> %dx%d", d->H, d->W, d->kh, d->kw,
+              d->stride, d->pad, d->Ho, d->Wo);
+    GHM_CHECK(d->x_nstride >= (int64_t)d->C * d->H * d->W && d->y_nstride >= (int64_t)d->K * d->Ho * d->Wo,
+              "sample strides smaller than the tensors");
+    return 0;
+}
+
+struct WVariant {
+    int bm, bn, splits, slabs_per_split;
+};
+
+WVariant pick_wgrad(const ghm_conv_desc* d, int num_cu) {
+    const int CT = d->C * d->kh * d->kw;
+    WVariant v;
+    v.bm = CT >= 96 ? 128 : 32;
+    v.bn = d->K >= 96 ? 128 : (d->K >= 48 ? 64 : 32);
+    if (v.bm == 32) v.bn = 128;
+    const long tiles = (long)ceil_div(CT, v.bm) * ceil_div(d->K, v.bn);
+    const long P = (long)d->N * d->Ho * d->Wo;
+    const long slabs = (P + 31) / 32;
+    long want = (4L * num_cu + tiles - 1) / tiles;      // aim for ~4 blocks per CU
+    long max_by_work = slabs / 8 > 0 ? slabs / 8 : 1;   // at least 8 slabs per split
+    long S = want < max_by_work ? want : max_by_work;
+    if (S < 1) S = 1;
+    if (S > 1024) S = 1024;
+    v.slabs_per_split = (int)((slabs + S - 1) / S);
+    v.splits = (int)((slabs + v.slabs_per_split - 1) / v.slabs_per_split);
+    return v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ghm_conv2d_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,
+                   float* y, int32_t act, float alpha, int32_t accumulate) {
+    if (int e = check_desc(d)) return e;
+    GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = x; a.wp = wp; a.bias = bias; a.out = y;
+    a.N = d->N; a.CH = d->C; a.Hin = d->H; a.Win = d->W; a.in_nstride = d->x_nstride;
+    a.R = d->K; a.Hout = d->Ho; a.Wout = d->Wo; a.out_nstride = d->y_nstride;
+    a.Hs = d->Ho; a.Ws = d->Wo; a.os = 1; a.ou = 0; a.ov = 0; a.ss = d->stride;
+    a.T = d->kh * d->kw; a.ntaps = a.T;
+    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
+    for (int ta = 0; ta < d->kh; ++ta)
+        for (int tb = 0; tb < d->kw; ++tb) {
+            const int t = ta * d->kw + tb;
+            a.di[t] = ta - d->pad; a.dj[t] = tb - d->pad; a.wi[t] = t;
+        }
+    return launch_igemm<false>(ctx, a);
+}
+
+int ghm_conv2d_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const float* wp, const float* bias,
+                     float* dx, int32_t act, float alpha, int32_t accumulate) {
+    if (int e = check_desc(d)) return e;
+    GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    const int s = d->stride;
+    for (int pu = 0; pu < s; ++pu) {
+        for (int pv = 0; pv < s; ++pv) {
+            IgemmArgs a;
+            memset(&a, 0, sizeof(a));
+            a.in = dy; a.wp = wp; a.bias = bias; a.out = dx;
+            a.N = d->N; a.CH = d->K; a.Hin = d->Ho; a.Win = d->Wo; a.in_nstride = d->y_nstride;
+            a.R = d->C; a.Hout = d->H; a.Wout = d->W; a.out_nstride = d->x_nstride;
+            a.Hs = (d->H - pu + s - 1) / s; a.Ws = (d->W - pv + s - 1) / s;
+            a.os = s; a.ou = pu; a.ov = pv; a.ss = 1;
+            a.T = d->kh * d->kw;
+            a.act = act; a.alpha = alpha; a.accumulate = accumulate;
+            int nt = 0;
+            for (int ta = 0; ta < d->kh; ++ta) {
+                if (((pu + d->pad - ta) % s + s) % s != 0) continue;
+                for (int tb = 0; tb < d->kw; ++tb) {
+                    if (((pv + d->pad - tb) % s + s) % s != 0) continue;
+                    // exact division: numerator is a multiple of s (may be negative)
+                    a.di[nt] = (pu + d->pad - ta) / s; a.dj[nt] = (pv + d->pad - tb) / s;
+                    a.wi[nt] = ta * d->kw + tb;
+                    ++nt;
+                }
+            }
+            a.ntaps = nt;
+            if (a.Hs <= 0 || a.Ws <= 0) continue;
+            if (int e = launch_igemm<true>(ctx, a)) return e;
+        }
+    }
+    return 0;
+}
+
+int ghm_conv2d_wgrad_workspace(const ghm_conv_desc* d, size_t* bytes) {
+    // upper bound independent of the CU count (splits <= 1024)
+    const WVariant v = pick_wgrad(d, 256);
+    const size_t n = (size_t)d->C * d->kh * d->kw * d->K;
+    *bytes = (v.splits > 1 ? (size_t)v.splits * n * sizeof(float) : 16);
+    return 0;
+}
+
+int ghm_conv2d_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* dy, float* dwp,
+                     void* workspace, int32_t accumulate) {
+    if (int e = check_desc(d)) return e;
+    const WVariant v = pick_wgrad(d, 256);
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.dy = dy;
+    a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.x_nstride = d->x_nstride;
+    a.K = d->K; a.Ho = d->Ho; a.Wo = d->Wo; a.y_nstride = d->y_nstride;
+    a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
+    a.CT = d->C * d->kh * d->kw;
+    a.P = d->N * d->Ho * d->Wo;
+    a.slabs_per_split = v.slabs_per_split;
+    const long n = (long)a.CT * a.K;
+    if (v.splits > 1) {
+        GHM_CHECK(workspace != nullptr, "wgrad needs a workspace for %d splits", v.splits);
+        a.out = (float*)workspace; a.split_stride = n; a.accumulate = 0;
+    } else {
+        a.out = dwp; a.split_stride = 0; a.accumulate = accumulate;
+    }
+    dim3 grid(ceil_div(a.CT, v.bm), ceil_div(a.K, v.bn), v.splits);
+#define GHM_WGRAD_CASE(BM_, BN_, WM_, WN_)                                                          \
+    if (v.bm == BM_ && v.bn == BN_) {                                                               \
+        hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, WM_, WN_>), grid, dim3(256), 0, ctx->stream, a); \
+        GHM_LAUNCH_CHECK();                                                                         \
+    } else
+    GHM_WGRAD_CASE(128, 128, 2, 2)
+    GHM_WGRAD_CASE(128, 64, 4, 1)
+    GHM_WGRAD_CASE(128, 32, 4, 1)
+    GHM_WGRAD_CASE(32, 128, 1, 4) {
+        ghm_set_error("no wgrad variant for bm=%d bn=%d", v.bm, v.bn);
+        return -3;
+    }
+#undef GHM_WGRAD_CASE
+    if (v.splits > 1) {
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream,
+                           (const float*)workspace, v.splits, n, n, dwp, accumulate);
+        GHM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int ghm_channel_sum(ghm_ctx* ctx, const float* x, int32_t N, int32_t C, int32_t HW, int64_t nstride, float* out,
+                    int32_t accumulate) {
+    if (C == 0) return 0;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, ctx->stream, x, N, HW, (long)nstride, out,
+                       accumulate);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t out_len) {
+    if (kind == 2) {
+        const WVariant v = pick_wgrad(d, 256);
+        snprintf(out, out_len, "wgrad_kernel<%d,%d> splits=%d", v.bm, v.bn, v.splits);
+    } else {
+        const int R = kind == 0 ? d->K : d->C;
+        const long P = kind == 0 ? (long)d->N * d->Ho * d->Wo : (long)d->N * d->H * d->W / (d->stride * d->stride);
+        if (R <= 4) {
+            snprintf(out, out_len, "direct_smallr_kernel");
+        } else {
+            const Variant v = pick_variant(R, P, 256);
+            snprintf(out, out_len, "igemm_kernel<%d,%d,%s>", v.bm, v.bn, kind == 0 ? "fwd" : "wt");
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+// Context, device memory, stream, HIP-graph capture and event timers of libghm.so.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+
+void ghm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char* ghm_last_error(void) { return g_err; }
+
+int ghm_device_count(int32_t* n) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        c = 0;
+        (void)hipGetLastError();
+    }
+    *n = c;
+    return 0;
+}
+
+int ghm_ctx_create(int32_t device, ghm_ctx** out) {
+    GHM_HIP(hipSetDevice(device));
+    ghm_ctx* c = new ghm_ctx();
+    c->device = device;
+    GHM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    GHM_HIP(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount;
+    *out = c;
+    return 0;
+}
+
+int ghm_ctx_destroy(ghm_ctx* ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->comm) ghm_comm_destroy(ctx);
+    for (int i = 0; i < 64; ++i) {
+        if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
+        if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
+    }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int ghm_device_info(ghm_ctx* ctx, char* name, int32_t name_len, int32_t* num_cu, int64_t* hbm_bytes) {
+    hipDeviceProp_t prop;
+    GHM_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len > 0) {
+        snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (num_cu) *num_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return 0;
+}
+
+int ghm_alloc(ghm_ctx* ctx, size_t bytes, void** out) {
+    GHM_CHECK(!ctx->capturing, "ghm_alloc inside graph capture");
+    GHM_HIP(hipSetDevice(ctx->device));
+    if (bytes == 0) bytes = 16;
+    GHM_HIP(hipMalloc(out, bytes));
+    return 0;
+}
+
+int ghm_free(ghm_ctx* ctx, void* ptr) {
+    GHM_CHECK(!ctx->capturing, "ghm_free inside graph capture");
+    GHM_HIP(hipSetDevice(ctx->device));
+    GHM_HIP(hipFree(ptr));
+    return 0;
+}
+
+int ghm_h2d(ghm_ctx* ctx, void* dst, const void* src_host, size_t bytes) {
+    GHM_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    // pageable host memory: the runtime stages it, but keep the host buffer's lifetime simple
+    if (!ctx->capturing) GHM_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ghm_d2h(ghm_ctx* ctx, void* dst_host, const void* src, size_t bytes) {
+    GHM_CHECK(!ctx->capturing, "ghm_d2h inside graph capture");
+    GHM_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GHM_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ghm_d2d(ghm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    GHM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+int ghm_memset_zero(ghm_ctx* ctx, void* dst, size_t bytes) {
+    GHM_HIP(hipMemsetAsync(dst, 0, bytes, ctx->stream));
+    return 0;
+}
+
+int ghm_sync(ghm_ctx* ctx) {
+    GHM_CHECK(!ctx->capturing, "ghm_sync inside graph capture");
+    GHM_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ghm_capture_begin(ghm_ctx* ctx) {
+    GHM_CHECK(!ctx->capturing, "nested capture");
+    GHM_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return 0;
+}
+
+int ghm_capture_end(ghm_ctx* ctx, ghm_graph** out) {
+    GHM_CHECK(ctx->capturing, "capture_end without capture_begin");
+    ctx->capturing = false;
+    ghm_graph* g = new ghm_graph();
+    hipError_t e = hipStreamEndCapture(ctx->stream, &g->graph);
+    if (e != hipSuccess) {
+        delete g;
+        ghm_set_error("hipStreamEndCapture -> %s", hipGetErrorString(e));
+        return -1;
+    }
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g->graph);
+        delete g;
+        ghm_set_error("hipGraphInstantiate -> %s", hipGetErrorString(e));
+        return -1;
+    }
+    *out = g;
+    return 0;
+}
+
+int ghm_graph_launch(ghm_ctx* ctx, ghm_graph* g) {
+    GHM_HIP(hipGraphLaunch(g->exec, ctx->stream));
+    return 0;
+}
+
+int ghm_graph_destroy(ghm_graph* g) {
+    if (!g) return 0;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return 0;
+}
+
+int ghm_timer_start(ghm_ctx* ctx, int32_t slot) {
+    GHM_CHECK(slot >= 0 && slot < 64, "timer slot out of range");
+    if (!ctx->ev_start[slot]) {
+        GHM_HIP(hipEventCreate(&ctx->ev_start[slot]));
+        GHM_HIP(hipEventCreate(&ctx->ev_stop[slot]));
+    }
+    GHM_HIP(hipEventRecord(ctx->ev_start[slot], ctx->stream));
+    return 0;
+}
+
+int ghm_timer_stop(ghm_ctx* ctx, int32_t slot) {
+    GHM_CHECK(slot >= 0 && slot < 64 && ctx->ev_stop[slot], "timer slot not started");
+    GHM_HIP(hipEventRecord(ctx->ev_stop[slot], ctx->stream));
+    return 0;
+}
+
+int ghm_timer_elapsed_ms(ghm_ctx* ctx, int32_t slot, float* ms) {
+    GHM_CHECK(slot >= 0 && slot < 64 && ctx->ev_stop[slot], "timer slot not started");
+    GHM_HIP(hipEventSynchronize(ctx->ev_stop[slot]));
+    GHM_HIP(hipEventElapsedTime(ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,711 @@
+// HBM-bound wavefront kernels of the train step: BatchNorm (stats / apply / backward), activations,
+// pooling, nearest and Theano-bilinear 2x resampling, strided copies, losses and the optimisers.
+// All tensors are fp32 [N, C, HW] views with an explicit sample stride; lanes run along HW (NCHW
+// contiguous), 16 B per lane where the geometry allows.
+//
+// Replaces Theano Elemwise / Pool / GpuDnnBatchNorm-free BN graph / lasagne.updates expressions
+// (SURVEY.md section 2.2 "Loss / optimizer sites" and "Backward sites").
+#include "common.h"
+
+namespace {
+
+struct View {
+    int N, C, HW;
+};
+
+// index helper: one thread handles VEC consecutive hw elements of one (n, c) row
+template <int VEC>
+__device__ __forceinline__ bool decode(const View v, long& n, long& c, long& i) {
+    const long per_row = v.HW / VEC;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)v.N * v.C * per_row;
+    if (idx >= total) return false;
+    const long row = idx / per_row;
+    i = (idx - row * per_row) * VEC;
+    n = row / v.C;
+    c = row - n * v.C;
+    return true;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+inline int grid_for(const View v, int vec) { return ceil_div((long)v.N * v.C * (v.HW / vec), 256); }
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm
+// ---------------------------------------------------------------------------------------------
+constexpr int BN_MAX_SPLIT = 64;
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    // wave reduce then LDS across the 4 waves
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// grid (S, C): partial sum / sum of squares in fp64
+__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, int N, int HW, long nstride,
+                                                        int S, double* __restrict__ ws) {
+    const int c = blockIdx.y, s = blockIdx.x;
+    const long total = (long)N * HW;
+    const long chunk = (total + S - 1) / S;
+    const long lo = s * chunk, hi = min(lo + chunk, total);
+    double a = 0.0, b = 0.0;
+    for (long e = lo + threadIdx.x; e < hi; e += 256) {
+        const long n = e / HW, i = e - n * HW;
+        const float v = x[n * nstride + (long)c * HW + i];
+        a += v;
+        b += (double)v * v;
+    }
+    __shared__ double red[4];
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        ws[((long)c * BN_MAX_SPLIT + s) * 2 + 0] = a;
+        ws[((long)c * BN_MAX_SPLIT + s) * 2 + 1] = b;
+    }
+}
+
+__global__ void bn_stats_final(const double* __restrict__ ws, int C, int S, double count, float eps,
+                               float* __restrict__ mean, float* __restrict__ inv, float* run_mean, float* run_inv,
+                               float ra) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < S; ++s) {
+        a += ws[((long)c * BN_MAX_SPLIT + s) * 2 + 0];
+        b += ws[((long)c * BN_MAX_SPLIT + s) * 2 + 1];
+    }
+    const double mu = a / count;
+    double var = b / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float m = (float)mu;
+    const float iv = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = m;
+    inv[c] = iv;
+    if (run_mean) {
+        run_mean[c] = (1.f - ra) * run_mean[c] + ra * m;
+        run_inv[c] = (1.f - ra) * run_inv[c] + ra * iv;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long xs, float* __restrict__ y,
+                                                       long ys, View v, const float* __restrict__ mean,
+                                                       const float* __restrict__ inv, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int act, float alpha) {
+    long n, c, i;
+    if (!decode<VEC>(v, n, c, i)) return;
+    const float sc = gamma[c] * inv[c];
+    const float sh = beta[c] - mean[c] * sc;
+    const float* xp = x + n * xs + c * v.HW + i;
+    float* yp = y + n * ys + c * v.HW + i;
+    if constexpr (VEC == 4) {
+        float4 t = *reinterpret_cast<const float4*>(xp);
+        t.x = ghm_act(fmaf(t.x, sc, sh), act, alpha);
+        t.y = ghm_act(fmaf(t.y, sc, sh), act, alpha);
+        t.z = ghm_act(fmaf(t.z, sc, sh), act, alpha);
+        t.w = ghm_act(fmaf(t.w, sc, sh), act, alpha);
+        *reinterpret_cast<float4*>(yp) = t;
+    } else {
+        *yp = ghm_act(fmaf(*xp, sc, sh), act, alpha);
+    }
+}
+
+// grid (S, C): partial sums of dz and dz*xhat, dz = dout * act'(y)
+__global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ dout, long ds, const float* __restrict__ y,
+                                                      long ys, const float* __restrict__ x, long xs, int N, int HW, int S,
+                                                      const float* __restrict__ mean, const float* __restrict__ inv,
+                                                      int act, float alpha, double* __restrict__ ws) {
+    const int c = blockIdx.y, s = blockIdx.x;
+    const long total = (long)N * HW;
+    const long chunk = (total + S - 1) / S;
+    const long lo = s * chunk, hi = min(lo + chunk, total);
+    const float m = mean[c], iv = inv[c];
+    double a = 0.0, b = 0.0;
+    for (long e = lo + threadIdx.x; e < hi; e += 256) {
+        const long n = e / HW, i = e - n * HW;
+        const long o = (long)c * HW + i;
+        const float dz = dout[n * ds + o] * ghm_dact_from_out(y[n * ys + o], act, alpha);
+        const float xh = (x[n * xs + o] - m) * iv;
+        a += dz;
+        b += (double)dz * xh;
+    }
+    __shared__ double red[4];
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        ws[((long)c * BN_MAX_SPLIT + s) * 2 + 0] = a;
+        ws[((long)c * BN_MAX_SPLIT + s) * 2 + 1] = b;
+    }
+}
+
+__global__ void bn_bwd_final(const double* __restrict__ ws, int C, int S, float* __restrict__ sums, float* dgamma,
+                             float* dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < S; ++s) {
+        a += ws[((long)c * BN_MAX_SPLIT + s) * 2 + 0];
+        b += ws[((long)c * BN_MAX_SPLIT + s) * 2 + 1];
+    }
+    sums[2 * c + 0] = (float)a;
+    sums[2 * c + 1] = (float)b;
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)a;
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)b;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ dout, long ds, const float* __restrict__ y,
+                                                    long ys, const float* __restrict__ x, long xs, float* __restrict__ dx,
+                                                    long dxs, View v, const float* __restrict__ mean,
+                                                    const float* __restrict__ inv, const float* __restrict__ gamma,
+                                                    const float* __restrict__ sums, float inv_count, int act,
+                                                    float alpha) {
+    long n, c, i;
+    if (!decode<VEC>(v, n, c, i)) return;
+    const float m = mean[c], iv = inv[c], g = gamma[c] * iv;
+    const float mb = sums[2 * c] * inv_count, mg = sums[2 * c + 1] * inv_count;
+    const long o = c * v.HW + i;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const float dz = dout[n * ds + o + k] * ghm_dact_from_out(y[n * ys + o + k], act, alpha);
+        const float xh = (x[n * xs + o + k] - m) * iv;
+        dx[n * dxs + o + k] = g * (dz - mb - xh * mg);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// activations, copies
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, long xs, float* __restrict__ y, long ys,
+                                                      View v, int act, float alpha) {
+    long n, c, i;
+    if (!decode<VEC>(v, n, c, i)) return;
+    const float* xp = x + n * xs + c * v.HW + i;
+    float* yp = y + n * ys + c * v.HW + i;
+    if constexpr (VEC == 4) {
+        float4 t = *reinterpret_cast<const float4*>(xp);
+        t.x = ghm_act(t.x, act, alpha);
+        t.y = ghm_act(t.y, act, alpha);
+        t.z = ghm_act(t.z, act, alpha);
+        t.w = ghm_act(t.w, act, alpha);
+        *reinterpret_cast<float4*>(yp) = t;
+    } else {
+        *yp = ghm_act(*xp, act, alpha);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dout, long ds, const float* __restrict__ y,
+                                                      long ys, float* __restrict__ dx, long dxs, View v, int act,
+                                                      float alpha, int accumulate) {
+    long n, c, i;
+    if (!decode<VEC>(v, n, c, i)) return;
+    const long o = c * v.HW + i;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        float g = dout[n * ds + o + k] * ghm_dact_from_out(y[n * ys + o + k], act, alpha);
+        float* p = dx + n * dxs + o + k;
+        if (accumulate) g += *p;
+        *p = g;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void copy_view_kernel(const float* __restrict__ x, long xs, float* __restrict__ y,
+                                                        long ys, View v, int accumulate) {
+    long n, c, i;
+    if (!decode<VEC>(v, n, c, i)) return;
+    const long o = c * v.HW + i;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        float g = x[n * xs + o + k];
+        float* p = y + n * ys + o + k;
+        if (accumulate) g += *p;
+        *p = g;
+    }
+}
+
+__global__ void axpby_kernel(float a, const float* __restrict__ x, float b, float* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a * x[i] + (b != 0.f ? b * y[i] : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pooling / resampling: one thread per OUTPUT-side 2x2 cell (or per coarse pixel)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long planes,
+                                                           int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= planes * Ho * Wo) return;
+    const long pl = idx / (Ho * Wo);
+    const int rem = (int)(idx - pl * Ho * Wo), i = rem / Wo, j = rem - i * Wo;
+    const float* p = x + pl * H * W + (long)(2 * i) * W + 2 * j;
+    const float2 a = *reinterpret_cast<const float2*>(p);
+    const float2 b = *reinterpret_cast<const float2*>(p + W);
+    y[idx] = fmaxf(fmaxf(a.x, a.y), fmaxf(b.x, b.y));
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, float* __restrict__ dx,
+                                                           long planes, int H, int W, int act, float alpha) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= planes * Ho * Wo) return;
+    const long pl = idx / (Ho * Wo);
+    const int rem = (int)(idx - pl * Ho * Wo), i = rem / Wo, j = rem - i * Wo;
+    const long o = pl * H * W + (long)(2 * i) * W + 2 * j;
+    const float m = y[idx], g = dy[idx];
+    const float2 a = *reinterpret_cast<const float2*>(x + o);
+    const float2 b = *reinterpret_cast<const float2*>(x + o + W);
+    float2 ra, rb;
+    ra.x = (a.x == m) ? g * ghm_dact_from_out(a.x, act, alpha) : 0.f;
+    ra.y = (a.y == m) ? g * ghm_dact_from_out(a.y, act, alpha) : 0.f;
+    rb.x = (b.x == m) ? g * ghm_dact_from_out(b.x, act, alpha) : 0.f;
+    rb.y = (b.y == m) ? g * ghm_dact_from_out(b.y, act, alpha) : 0.f;
+    *reinterpret_cast<float2*>(dx + o) = ra;
+    *reinterpret_cast<float2*>(dx + o + W) = rb;
+}
+
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long planes,
+                                                          int H, int W, int p) {
+    const int Ho = H / p, Wo = W / p;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= planes * Ho * Wo) return;
+    const long pl = idx / (Ho * Wo);
+    const int rem = (int)(idx - pl * Ho * Wo), i = rem / Wo, j = rem - i * Wo;
+    float s = 0.f;
+    for (int a = 0; a < p; ++a)
+        for (int b = 0; b < p; ++b) s += x[pl * H * W + (long)(i * p + a) * W + j * p + b];
+    y[idx] = s / (float)(p * p);
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long planes,
+                                                          int H, int W, int p) {
+    const int Ho = H / p, Wo = W / p;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= planes * H * W) return;
+    const long pl = idx / (H * W);
+    const int rem = (int)(idx - pl * H * W), u = rem / W, v = rem - u * W;
+    const int i = u / p, j = v / p;
+    dx[idx] = (i < Ho && j < Wo) ? dy[pl * Ho * Wo + i * Wo + j] / (float)(p * p) : 0.f;
+}
+
+// nearest 2x: thread per input pixel writes a 2x2 block
+__global__ __launch_bounds__(256) void up_nearest_fwd_kernel(const float* __restrict__ x, long xs, float* __restrict__ y,
+                                                             int N, int C, int H, int W) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long hw = (long)H * W;
+    if (idx >= (long)N * C * hw) return;
+    const long pl = idx / hw;
+    const int rem = (int)(idx - pl * hw), i = rem / W, j = rem - i * W;
+    const long n = pl / C, c = pl - n * C;
+    const float v = x[n * xs + c * hw + rem];
+    float* o = y + pl * 4 * hw + (long)(2 * i) * (2 * W) + 2 * j;
+    const float2 vv = make_float2(v, v);
+    *reinterpret_cast<float2*>(o) = vv;
+    *reinterpret_cast<float2*>(o + 2 * W) = vv;
+}
+
+__global__ __launch_bounds__(256) void up_nearest_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long dxs,
+                                                             int N, int C, int H, int W, int accumulate) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long hw = (long)H * W;
+    if (idx >= (long)N * C * hw) return;
+    const long pl = idx / hw;
+    const int rem = (int)(idx - pl * hw), i = rem / W, j = rem - i * W;
+    const long n = pl / C, c = pl - n * C;
+    const float* g = dy + pl * 4 * hw + (long)(2 * i) * (2 * W) + 2 * j;
+    const float2 a = *reinterpret_cast<const float2*>(g);
+    const float2 b = *reinterpret_cast<const float2*>(g + 2 * W);
+    float s = (a.x + a.y) + (b.x + b.y);
+    float* p = dx + n * dxs + c * hw + rem;
+    if (accumulate) s += *p;
+    *p = s;
+}
+
+// Theano bilinear 2x (ratio 2): out[2m] = x[m]; out[2m+1] = (x[m] + x[min(m+1,n-1)])/2, separable.
+__global__ __launch_bounds__(256) void up_bilinear_fwd_kernel(const float* __restrict__ x, long xs, float* __restrict__ y,
+                                                              int N, int C, int H, int W) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long hw = (long)H * W;
+    if (idx >= (long)N * C * hw) return;
+    const long pl = idx / hw;
+    const int rem = (int)(idx - pl * hw), i = rem / W, j = rem - i * W;
+    const long n = pl / C, c = pl - n * C;
+    const float* xp = x + n * xs + c * hw;
+    const int i1 = min(i + 1, H - 1), j1 = min(j + 1, W - 1);
+    const float v00 = xp[i * W + j], v01 = xp[i * W + j1], v10 = xp[i1 * W + j], v11 = xp[i1 * W + j1];
+    float* o = y + pl * 4 * hw + (long)(2 * i) * (2 * W) + 2 * j;
+    const float r0 = 0.5f * (v00 + v01);
+    const float c0 = 0.5f * (v00 + v10), c1 = 0.5f * (v01 + v11);
+    *reinterpret_cast<float2*>(o) = make_float2(v00, r0);
+    *reinterpret_cast<float2*>(o + 2 * W) = make_float2(c0, 0.5f * (c0 + c1));
+}
+
+// adjoint: dx[m] = g[2m] + g[2m+1]/2 + (m>=1 ? g[2m-1]/2 : 0) + (m==n-1 ? g[2n-1]/2 : 0), per axis
+__device__ __forceinline__ float bil_row(const float* g, int W2, int j, int W) {
+    // horizontal adjoint at fine row pointer g (length W2 = 2W), coarse column j
+    float s = g[2 * j] + 0.5f * g[2 * j + 1];
+    if (j >= 1) s += 0.5f * g[2 * j - 1];
+    if (j == W - 1) s += 0.5f * g[2 * W - 1];
+    return s;
+}
+__global__ __launch_bounds__(256) void up_bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long dxs,
+                                                              int N, int C, int H, int W, int accumulate) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long hw = (long)H * W;
+    if (idx >= (long)N * C * hw) return;
+    const long pl = idx / hw;
+    const int rem = (int)(idx - pl * hw), i = rem / W, j = rem - i * W;
+    const long n = pl / C, c = pl - n * C;
+    const int W2 = 2 * W;
+    const float* g = dy + pl * 4 * hw;
+    float s = bil_row(g + (long)(2 * i) * W2, W2, j, W) + 0.5f * bil_row(g + (long)(2 * i + 1) * W2, W2, j, W);
+    if (i >= 1) s += 0.5f * bil_row(g + (long)(2 * i - 1) * W2, W2, j, W);
+    if (i == H - 1) s += 0.5f * bil_row(g + (long)(2 * H - 1) * W2, W2, j, W);
+    float* p = dx + n * dxs + c * hw + rem;
+    if (accumulate) s += *p;
+    *p = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// losses: single-pass grid-stride with fp64 block partials + one atomic per block
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scalar_loss_kernel(const float* __restrict__ d, long n, float target, int kind,
+                                                          float* __restrict__ grad, float gscale, float* loss_out) {
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = d[i];
+        if (kind == 0) {
+            const float e = v - target;
+            acc += (double)e * e;
+            if (grad) grad[i] = gscale * 2.f * e / (float)n;
+        } else {
+            acc += -(double)(target * logf(v) + (1.f - target) * logf(1.f - v));
+            if (grad) grad[i] = gscale * (-(target / v) + (1.f - target) / (1.f - v)) / (float)n;
+        }
+    }
+    __shared__ double red[4];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(loss_out, (float)(acc / (double)n));
+}
+
+__global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict__ a, long as, const float* __restrict__ b,
+                                                         long bs, View v, int l2, float* __restrict__ grad, long gs,
+                                                         float gscale, int accumulate, float* loss_out) {
+    const long chw = (long)v.C * v.HW, total = (long)v.N * chw;
+    double acc = 0.0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long n = e / chw, o = e - n * chw;
+        const float dlt = a[n * as + o] - b[n * bs + o];
+        float g;
+        if (l2) {
+            acc += (double)dlt * dlt;
+            g = 2.f * dlt;
+        } else {
+            acc += fabsf(dlt);
+            g = (dlt > 0.f) ? 1.f : (dlt < 0.f ? -1.f : 0.f);
+        }
+        if (grad) {
+            float* p = grad + n * gs + o;
+            const float w = gscale * g / (float)total;
+            *p = accumulate ? *p + w : w;
+        }
+    }
+    __shared__ double red[4];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(loss_out, (float)(acc / (double)total));
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimisers (lasagne.updates.rmsprop / adam)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ acc, long n, const float* __restrict__ hyper,
+                                                      float rho, float eps, float gscale) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float lr = hyper[0];
+    if (i + 3 < n) {
+        float4 pv = *reinterpret_cast<float4*>(p + i);
+        float4 gv = *reinterpret_cast<const float4*>(g + i);
+        float4 av = *reinterpret_cast<float4*>(acc + i);
+        gv.x *= gscale; gv.y *= gscale; gv.z *= gscale; gv.w *= gscale;
+        av.x = rho * av.x + (1.f - rho) * gv.x * gv.x;
+        av.y = rho * av.y + (1.f - rho) * gv.y * gv.y;
+        av.z = rho * av.z + (1.f - rho) * gv.z * gv.z;
+        av.w = rho * av.w + (1.f - rho) * gv.w * gv.w;
+        pv.x -= lr * gv.x / sqrtf(av.x + eps);
+        pv.y -= lr * gv.y / sqrtf(av.y + eps);
+        pv.z -= lr * gv.z / sqrtf(av.z + eps);
+        pv.w -= lr * gv.w / sqrtf(av.w + eps);
+        *reinterpret_cast<float4*>(p + i) = pv;
+        *reinterpret_cast<float4*>(acc + i) = av;
+    } else {
+        for (long k = i; k < n; ++k) {
+            const float gg = g[k] * gscale;
+            const float a2 = rho * acc[k] + (1.f - rho) * gg * gg;
+            acc[k] = a2;
+            p[k] -= lr * gg / sqrtf(a2 + eps);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, const float* __restrict__ hyper, float b1,
+                                                   float b2, float eps, float gscale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float lr = hyper[0], t = hyper[1] + 1.f;     // t_prev + 1
+    const float a_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+    const float gg = g[i] * gscale;
+    const float mn = b1 * m[i] + (1.f - b1) * gg;
+    const float vn = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mn;
+    v[i] = vn;
+    p[i] -= a_t * mn / (sqrtf(vn) + eps);
+}
+
+__global__ void adam_tick_kernel(float* hyper) { hyper[1] += 1.f; }
+
+template <typename... Args>
+inline bool vec_ok(int HW, Args... strides_or_ptr_ok) {
+    return (HW % 4 == 0) && (... && strides_or_ptr_ok);
+}
+
+}  // namespace
+
+#define EW_GRID(total) dim3(ceil_div((long)(total), 256)), dim3(256), 0, ctx->stream
+
+extern "C" {
+
+size_t ghm_bn_workspace(int32_t C) { return (size_t)C * BN_MAX_SPLIT * 2 * sizeof(double) + (size_t)C * 2 * sizeof(float); }
+
+static int bn_split(int C, long count) {
+    long S = (1024 + C - 1) / C;
+    long maxs = count / 2048;
+    if (maxs < 1) maxs = 1;
+    if (S > maxs) S = maxs;
+    if (S > BN_MAX_SPLIT) S = BN_MAX_SPLIT;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+
+int ghm_bn_stats(ghm_ctx* ctx, const float* x, int32_t N, int32_t C, int32_t HW, int64_t nstride, float eps, float* mean,
+                 float* inv, float* run_mean, float* run_inv, float run_alpha, void* ws) {
+    const long count = (long)N * HW;
+    const int S = bn_split(C, count);
+    hipLaunchKernelGGL(bn_stats_partial, dim3(S, C), dim3(256), 0, ctx->stream, x, N, HW, (long)nstride, S, (double*)ws);
+    GHM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_final, dim3(ceil_div(C, 256)), dim3(256), 0, ctx->stream, (const double*)ws, C, S,
+                       (double)count, eps, mean, inv, run_mean, run_inv, run_alpha);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_bn_apply(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t ys, int32_t N, int32_t C, int32_t HW,
+                 const float* mean, const float* inv, const float* gamma, const float* beta, int32_t act, float alpha) {
+    const View v{N, C, HW};
+    if (HW % 4 == 0 && xs % 4 == 0 && ys % 4 == 0 && aligned16(x) && aligned16(y)) {
+        hipLaunchKernelGGL((bn_apply_kernel<4>), EW_GRID((long)N * C * (HW / 4)), x, (long)xs, y, (long)ys, v, mean, inv,
+                           gamma, beta, act, alpha);
+    } else {
+        hipLaunchKernelGGL((bn_apply_kernel<1>), EW_GRID((long)N * C * HW), x, (long)xs, y, (long)ys, v, mean, inv, gamma,
+                           beta, act, alpha);
+    }
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_bn_backward(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y, int64_t ys, const float* x, int64_t xs,
+                    float* dx, int64_t dxs, int32_t N, int32_t C, int32_t HW, const float* mean, const float* inv,
+                    const float* gamma, float* dgamma, float* dbeta, int32_t act, float alpha, int32_t accumulate,
+                    void* ws) {
+    const long count = (long)N * HW;
+    const int S = bn_split(C, count);
+    double* wsd = (double*)ws;
+    float* sums = (float*)((char*)ws + (size_t)C * BN_MAX_SPLIT * 2 * sizeof(double));
+    hipLaunchKernelGGL(bn_bwd_partial, dim3(S, C), dim3(256), 0, ctx->stream, dout, (long)ds, y, (long)ys, x, (long)xs, N,
+                       HW, S, mean, inv, act, alpha, wsd);
+    GHM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_final, dim3(ceil_div(C, 256)), dim3(256), 0, ctx->stream, (const double*)wsd, C, S, sums,
+                       dgamma, dbeta, accumulate);
+    GHM_LAUNCH_CHECK();
+    const View v{N, C, HW};
+    if (HW % 4 == 0) {
+        hipLaunchKernelGGL((bn_bwd_apply<4>), EW_GRID((long)N * C * (HW / 4)), dout, (long)ds, y, (long)ys, x, (long)xs, dx,
+                           (long)dxs, v, mean, inv, gamma, sums, 1.f / (float)count, act, alpha);
+    } else {
+        hipLaunchKernelGGL((bn_bwd_apply<1>), EW_GRID((long)N * C * HW), dout, (long)ds, y, (long)ys, x, (long)xs, dx,
+                           (long)dxs, v, mean, inv, gamma, sums, 1.f / (float)count, act, alpha);
+    }
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_act_fwd(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t ys, int32_t N, int32_t C, int32_t HW,
+                int32_t act, float alpha) {
+    const View v{N, C, HW};
+    if (HW % 4 == 0 && xs % 4 == 0 && ys % 4 == 0 && aligned16(x) && aligned16(y)) {
+        hipLaunchKernelGGL((act_fwd_kernel<4>), EW_GRID((long)N * C * (HW / 4)), x, (long)xs, y, (long)ys, v, act, alpha);
+    } else {
+        hipLaunchKernelGGL((act_fwd_kernel<1>), EW_GRID((long)N * C * HW), x, (long)xs, y, (long)ys, v, act, alpha);
+    }
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_act_bwd(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y, int64_t ys, float* dx, int64_t dxs,
+                int32_t N, int32_t C, int32_t HW, int32_t act, float alpha, int32_t accumulate) {
+    const View v{N, C, HW};
+    if (HW % 4 == 0) {
+        hipLaunchKernelGGL((act_bwd_kernel<4>), EW_GRID((long)N * C * (HW / 4)), dout, (long)ds, y, (long)ys, dx, (long)dxs,
+                           v, act, alpha, accumulate);
+    } else {
+        hipLaunchKernelGGL((act_bwd_kernel<1>), EW_GRID((long)N * C * HW), dout, (long)ds, y, (long)ys, dx, (long)dxs, v,
+                           act, alpha, accumulate);
+    }
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_copy_view(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t ys, int32_t N, int32_t C, int32_t HW,
+                  int32_t accumulate) {
+    const View v{N, C, HW};
+    if (HW % 4 == 0) {
+        hipLaunchKernelGGL((copy_view_kernel<4>), EW_GRID((long)N * C * (HW / 4)), x, (long)xs, y, (long)ys, v, accumulate);
+    } else {
+        hipLaunchKernelGGL((copy_view_kernel<1>), EW_GRID((long)N * C * HW), x, (long)xs, y, (long)ys, v, accumulate);
+    }
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_axpby(ghm_ctx* ctx, float a, const float* x, float b, float* y, int64_t n) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(axpby_kernel, EW_GRID(n), a, x, b, y, (long)n);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_maxpool2_fwd(ghm_ctx* ctx, const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W) {
+    GHM_CHECK(H % 2 == 0 && W % 2 == 0, "maxpool2 needs even H, W (got %dx%d)", H, W);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, EW_GRID((long)N * C * (H / 2) * (W / 2)), x, y, (long)N * C, H, W);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_maxpool2_bwd(ghm_ctx* ctx, const float* x, const float* y, const float* dy, float* dx, int32_t N, int32_t C,
+                     int32_t H, int32_t W, int32_t act, float alpha) {
+    GHM_CHECK(H % 2 == 0 && W % 2 == 0, "maxpool2 needs even H, W (got %dx%d)", H, W);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, EW_GRID((long)N * C * (H / 2) * (W / 2)), x, y, dy, dx, (long)N * C, H, W, act,
+                       alpha);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_avgpool_fwd(ghm_ctx* ctx, const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t p) {
+    hipLaunchKernelGGL(avgpool_fwd_kernel, EW_GRID((long)N * C * (H / p) * (W / p)), x, y, (long)N * C, H, W, p);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_avgpool_bwd(ghm_ctx* ctx, const float* dy, float* dx, int32_t N, int32_t C, int32_t H, int32_t W, int32_t p) {
+    hipLaunchKernelGGL(avgpool_bwd_kernel, EW_GRID((long)N * C * H * W), dy, dx, (long)N * C, H, W, p);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_upsample_nearest2_fwd(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int32_t N, int32_t C, int32_t H,
+                              int32_t W) {
+    hipLaunchKernelGGL(up_nearest_fwd_kernel, EW_GRID((long)N * C * H * W), x, (long)xs, y, N, C, H, W);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_upsample_nearest2_bwd(ghm_ctx* ctx, const float* dy, float* dx, int64_t dxs, int32_t N, int32_t C, int32_t H,
+                              int32_t W, int32_t accumulate) {
+    hipLaunchKernelGGL(up_nearest_bwd_kernel, EW_GRID((long)N * C * H * W), dy, dx, (long)dxs, N, C, H, W, accumulate);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_upsample_bilinear2_fwd(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int32_t N, int32_t C, int32_t H,
+                               int32_t W) {
+    hipLaunchKernelGGL(up_bilinear_fwd_kernel, EW_GRID((long)N * C * H * W), x, (long)xs, y, N, C, H, W);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_upsample_bilinear2_bwd(ghm_ctx* ctx, const float* dy, float* dx, int64_t dxs, int32_t N, int32_t C, int32_t H,
+                               int32_t W, int32_t accumulate) {
+    hipLaunchKernelGGL(up_bilinear_bwd_kernel, EW_GRID((long)N * C * H * W), dy, dx, (long)dxs, N, C, H, W, accumulate);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+static int loss_grid(long n) {
+    long g = (n + 256 * 8 - 1) / (256 * 8);
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int ghm_lsgan_loss(ghm_ctx* ctx, const float* d, int64_t n, float target, float* loss_out, float* grad,
+                   float grad_scale, int32_t accumulate_loss) {
+    if (!accumulate_loss) GHM_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), ctx->stream));
+    hipLaunchKernelGGL(scalar_loss_kernel, dim3(loss_grid(n)), dim3(256), 0, ctx->stream, d, (long)n, target, 0, grad,
+                       grad_scale, loss_out);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_bce_loss(ghm_ctx* ctx, const float* p, int64_t n, float target, float* loss_out, float* grad, float grad_scale,
+                 int32_t accumulate_loss) {
+    if (!accumulate_loss) GHM_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), ctx->stream));
+    hipLaunchKernelGGL(scalar_loss_kernel, dim3(loss_grid(n)), dim3(256), 0, ctx->stream, p, (long)n, target, 1, grad,
+                       grad_scale, loss_out);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_recon_loss(ghm_ctx* ctx, const float* a, int64_t as, const float* b, int64_t bs, int32_t N, int32_t C, int32_t HW,
+                   int32_t l2, float* loss_out, float* grad, int64_t gs, float grad_scale, int32_t accumulate_grad) {
+    GHM_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), ctx->stream));
+    const View v{N, C, HW};
+    hipLaunchKernelGGL(recon_loss_kernel, dim3(loss_grid((long)N * C * HW)), dim3(256), 0, ctx->stream, a, (long)as, b,
+                       (long)bs, v, l2, grad, (long)gs, grad_scale, accumulate_grad, loss_out);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_rmsprop(ghm_ctx* ctx, float* p, const float* g, float* acc, int64_t n, const float* hyper, float rho, float eps,
+                float grad_scale) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(rmsprop_kernel, EW_GRID((n + 3) / 4), p, g, acc, (long)n, hyper, rho, eps, grad_scale);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_adam(ghm_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float b1, float b2,
+             float eps, float grad_scale) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(adam_kernel, EW_GRID(n), p, g, m, v, (long)n, hyper, b1, b2, eps, grad_scale);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_adam_tick(ghm_ctx* ctx, float* hyper) {
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, ctx->stream, hyper);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

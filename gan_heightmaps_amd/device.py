@@ -1,0 +1,332 @@
+"""Device context and tensors over libghm.so (thin, explicit; no torch)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ConvDesc, call
+
+ACT_CODES = {'linear': 0, 'relu': 1, 'lrelu': 2, 'sigmoid': 3, 'tanh': 4}
+
+
+def device_count():
+    n = C.c_int32(0)
+    call("ghm_device_count", C.byref(n))
+    return n.value
+
+
+class DevTensor:
+    """fp32 [N, C, H, W] view in HBM with an explicit sample stride (elements)."""
+    __slots__ = ("dev", "ptr", "shape", "nstride", "base")
+
+    def __init__(self, dev, ptr, shape, nstride=None, base=None):
+        self.dev = dev
+        self.ptr = int(ptr)
+        shape = tuple(int(s) for s in shape)
+        if len(shape) == 2:
+            shape = (shape[0], shape[1], 1, 1)
+        assert len(shape) == 4
+        self.shape = shape
+        self.nstride = int(nstride) if nstride is not None else shape[1] * shape[2] * shape[3]
+        self.base = base
+
+    N = property(lambda s: s.shape[0])
+    Cc = property(lambda s: s.shape[1])
+    H = property(lambda s: s.shape[2])
+    W = property(lambda s: s.shape[3])
+    HW = property(lambda s: s.shape[2] * s.shape[3])
+    size = property(lambda s: s.shape[0] * s.shape[1] * s.shape[2] * s.shape[3])
+    contiguous = property(lambda s: s.nstride == s.shape[1] * s.shape[2] * s.shape[3])
+
+    def channels(self, c0, c1):
+        """View of channels [c0, c1) (ConcatLayer axis=1 without a copy)."""
+        assert 0 <= c0 < c1 <= self.shape[1]
+        return DevTensor(self.dev, self.ptr + 4 * c0 * self.HW, (self.N, c1 - c0, self.H, self.W), self.nstride,
+                         self.base if self.base is not None else self)
+
+    def samples(self, n0, n1):
+        assert 0 <= n0 < n1 <= self.shape[0]
+        return DevTensor(self.dev, self.ptr + 4 * n0 * self.nstride, (n1 - n0,) + self.shape[1:], self.nstride,
+                         self.base if self.base is not None else self)
+
+    def reshape(self, shape):
+        assert self.contiguous
+        t = DevTensor(self.dev, self.ptr, shape, None, self.base if self.base is not None else self)
+        assert t.size == self.size
+        return t
+
+    def numpy(self):
+        n, c, h, w = self.shape
+        out = np.empty(self.shape, np.float32)
+        if self.contiguous:
+            self.dev.d2h(out, self.ptr, out.nbytes)
+        else:
+            for i in range(n):
+                self.dev.d2h(out[i], self.ptr + 4 * i * self.nstride, out[i].nbytes)
+        return out
+
+    def set(self, arr):
+        arr = np.ascontiguousarray(arr, np.float32).reshape(self.shape)
+        if self.contiguous:
+            self.dev.h2d(self.ptr, arr)
+        else:
+            for i in range(self.N):
+                self.dev.h2d(self.ptr + 4 * i * self.nstride, arr[i])
+        return self
+
+
+class Device:
+    def __init__(self, index=0):
+        _lib.load()
+        h = C.c_void_p()
+        call("ghm_ctx_create", int(index), C.byref(h))
+        self.h = h
+        self.index = index
+        self._allocs = {}
+        self.bytes_allocated = 0
+
+    # ---- memory ----
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        call("ghm_alloc", self.h, int(max(nbytes, 16)), C.byref(p))
+        self._allocs[p.value] = nbytes
+        self.bytes_allocated += nbytes
+        return p.value
+
+    def free(self, ptr):
+        if ptr in self._allocs:
+            self.bytes_allocated -= self._allocs.pop(ptr)
+            call("ghm_free", self.h, C.c_void_p(ptr))
+
+    def empty(self, shape):
+        shape = tuple(int(s) for s in shape)
+        n = int(np.prod(shape)) if len(shape) else 1
+        return DevTensor(self, self.alloc(4 * n), shape if len(shape) in (2, 4) else (1, n, 1, 1))
+
+    def zeros(self, shape):
+        t = self.empty(shape)
+        self.memset_zero(t.ptr, 4 * t.size)
+        return t
+
+    def tensor(self, arr):
+        arr = np.ascontiguousarray(arr, np.float32)
+        shape = arr.shape
+        if arr.ndim == 1:
+            shape = (1, arr.shape[0], 1, 1)
+        elif arr.ndim == 0:
+            shape = (1, 1, 1, 1)
+        elif arr.ndim == 3:
+            shape = (1,) + arr.shape
+        t = self.empty(shape)
+        self.h2d(t.ptr, arr)
+        return t
+
+    def h2d(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        call("ghm_h2d", self.h, C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes)
+
+    def d2h(self, arr, ptr, nbytes):
+        assert arr.flags['C_CONTIGUOUS']
+        call("ghm_d2h", self.h, arr.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), int(nbytes))
+
+    def d2d(self, dst, src, nbytes):
+        call("ghm_d2d", self.h, C.c_void_p(dst), C.c_void_p(src), int(nbytes))
+
+    def memset_zero(self, ptr, nbytes):
+        call("ghm_memset_zero", self.h, C.c_void_p(ptr), int(nbytes))
+
+    def sync(self):
+        call("ghm_sync", self.h)
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        cu, hbm = C.c_int32(), C.c_int64()
+        call("ghm_device_info", self.h, name, 256, C.byref(cu), C.byref(hbm))
+        return {"name": name.value.decode(), "num_cu": cu.value, "hbm_bytes": hbm.value}
+
+    # ---- graph capture / timers ----
+    def capture_begin(self):
+        call("ghm_capture_begin", self.h)
+
+    def capture_end(self):
+        g = C.c_void_p()
+        call("ghm_capture_end", self.h, C.byref(g))
+        return g
+
+    def graph_launch(self, g):
+        call("ghm_graph_launch", self.h, g)
+
+    def graph_destroy(self, g):
+        call("ghm_graph_destroy", g)
+
+    def timer_start(self, slot=0):
+        call("ghm_timer_start", self.h, slot)
+
+    def timer_stop(self, slot=0):
+        call("ghm_timer_stop", self.h, slot)
+
+    def timer_ms(self, slot=0):
+        ms = C.c_float()
+        call("ghm_timer_elapsed_ms", self.h, slot, C.byref(ms))
+        return ms.value
+
+    def close(self):
+        if self.h is not None:
+            for p in list(self._allocs):
+                self.free(p)
+            call("ghm_ctx_destroy", self.h)
+            self.h = None
+
+
+# ---- weight layout (include/ghm.h): wp[c][a*kw+b][k] = W[k][c][kh-1-a][kw-1-b] -------------------
+
+def pack_conv_w(W):
+    """lasagne Conv2DLayer W[K, C, kh, kw] (or Deconv2DLayer W[Cin=K, Cout=C, kh, kw]) -> packed [C, kh*kw, K]."""
+    K, Cc, kh, kw = W.shape
+    return np.ascontiguousarray(W[:, :, ::-1, ::-1].transpose(1, 2, 3, 0)).reshape(Cc, kh * kw, K).astype(np.float32)
+
+
+def unpack_conv_w(wp, K, Cc, kh, kw):
+    return np.ascontiguousarray(np.asarray(wp).reshape(Cc, kh, kw, K).transpose(3, 0, 1, 2)[:, :, ::-1, ::-1])
+
+
+def conv_desc(N, Cc, H, W, K, kh, kw, stride, pad, x_nstride=None, y_nstride=None):
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    return ConvDesc(N, Cc, H, W, K, Ho, Wo, kh, kw, stride, pad,
+                    x_nstride if x_nstride is not None else Cc * H * W,
+                    y_nstride if y_nstride is not None else K * Ho * Wo)
+
+
+def _vp(x):
+    if x is None:
+        return C.c_void_p(0)
+    if isinstance(x, DevTensor):
+        return C.c_void_p(x.ptr)
+    return C.c_void_p(int(x))
+
+
+class Ops:
+    """Python spellings of the C-ABI ops on DevTensors (each is one asynchronous call)."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.h = dev.h
+
+    def conv2d_fwd(self, d, x, wp, bias, y, act='linear', alpha=0.0, accumulate=False):
+        call("ghm_conv2d_fwd", self.h, C.byref(d), _vp(x), _vp(wp), _vp(bias), _vp(y), ACT_CODES[act], alpha,
+             int(accumulate))
+
+    def conv2d_dgrad(self, d, dy, wp, dx, bias=None, act='linear', alpha=0.0, accumulate=False):
+        call("ghm_conv2d_dgrad", self.h, C.byref(d), _vp(dy), _vp(wp), _vp(bias), _vp(dx), ACT_CODES[act], alpha,
+             int(accumulate))
+
+    def wgrad_workspace(self, d):
+        n = C.c_size_t()
+        call("ghm_conv2d_wgrad_workspace", C.byref(d), C.byref(n))
+        return n.value
+
+    def conv2d_wgrad(self, d, x, dy, dwp, ws, accumulate=False):
+        call("ghm_conv2d_wgrad", self.h, C.byref(d), _vp(x), _vp(dy), _vp(dwp), _vp(ws), int(accumulate))
+
+    def channel_sum(self, x, out, accumulate=False):
+        call("ghm_channel_sum", self.h, _vp(x), x.N, x.Cc, x.HW, x.nstride, _vp(out), int(accumulate))
+
+    def bn_workspace(self, Cc):
+        return _lib.load().ghm_bn_workspace(Cc)
+
+    def bn_stats(self, x, mean, inv, ws, run_mean=None, run_inv=None, eps=1e-4, run_alpha=0.1):
+        call("ghm_bn_stats", self.h, _vp(x), x.N, x.Cc, x.HW, x.nstride, eps, _vp(mean), _vp(inv), _vp(run_mean),
+             _vp(run_inv), run_alpha, _vp(ws))
+
+    def bn_apply(self, x, y, mean, inv, gamma, beta, act='linear', alpha=0.0):
+        call("ghm_bn_apply", self.h, _vp(x), x.nstride, _vp(y), y.nstride, x.N, x.Cc, x.HW, _vp(mean), _vp(inv),
+             _vp(gamma), _vp(beta), ACT_CODES[act], alpha)
+
+    def bn_backward(self, dout, y, x, dx, mean, inv, gamma, dgamma, dbeta, ws, act='linear', alpha=0.0,
+                    accumulate=False):
+        call("ghm_bn_backward", self.h, _vp(dout), dout.nstride, _vp(y), y.nstride, _vp(x), x.nstride, _vp(dx),
+             dx.nstride, x.N, x.Cc, x.HW, _vp(mean), _vp(inv), _vp(gamma), _vp(dgamma), _vp(dbeta), ACT_CODES[act],
+             alpha, int(accumulate), _vp(ws))
+
+    def act_fwd(self, x, y, act, alpha=0.0):
+        call("ghm_act_fwd", self.h, _vp(x), x.nstride, _vp(y), y.nstride, x.N, x.Cc, x.HW, ACT_CODES[act], alpha)
+
+    def act_bwd(self, dout, y, dx, act, alpha=0.0, accumulate=False):
+        call("ghm_act_bwd", self.h, _vp(dout), dout.nstride, _vp(y), y.nstride, _vp(dx), dx.nstride, y.N, y.Cc, y.HW,
+             ACT_CODES[act], alpha, int(accumulate))
+
+    def maxpool2_fwd(self, x, y):
+        assert x.contiguous and y.contiguous
+        call("ghm_maxpool2_fwd", self.h, _vp(x), _vp(y), x.N, x.Cc, x.H, x.W)
+
+    def maxpool2_bwd(self, x, y, dy, dx, act='linear', alpha=0.0):
+        assert x.contiguous and y.contiguous and dy.contiguous and dx.contiguous
+        call("ghm_maxpool2_bwd", self.h, _vp(x), _vp(y), _vp(dy), _vp(dx), x.N, x.Cc, x.H, x.W, ACT_CODES[act], alpha)
+
+    def avgpool_fwd(self, x, y, p):
+        assert x.contiguous and y.contiguous
+        call("ghm_avgpool_fwd", self.h, _vp(x), _vp(y), x.N, x.Cc, x.H, x.W, p)
+
+    def avgpool_bwd(self, dy, dx, p):
+        assert dy.contiguous and dx.contiguous
+        call("ghm_avgpool_bwd", self.h, _vp(dy), _vp(dx), dx.N, dx.Cc, dx.H, dx.W, p)
+
+    def upsample_nearest2_fwd(self, x, y):
+        assert y.contiguous
+        call("ghm_upsample_nearest2_fwd", self.h, _vp(x), x.nstride, _vp(y), x.N, x.Cc, x.H, x.W)
+
+    def upsample_nearest2_bwd(self, dy, dx, accumulate=False):
+        assert dy.contiguous
+        call("ghm_upsample_nearest2_bwd", self.h, _vp(dy), _vp(dx), dx.nstride, dx.N, dx.Cc, dx.H, dx.W,
+             int(accumulate))
+
+    def upsample_bilinear2_fwd(self, x, y):
+        assert y.contiguous
+        call("ghm_upsample_bilinear2_fwd", self.h, _vp(x), x.nstride, _vp(y), x.N, x.Cc, x.H, x.W)
+
+    def upsample_bilinear2_bwd(self, dy, dx, accumulate=False):
+        assert dy.contiguous
+        call("ghm_upsample_bilinear2_bwd", self.h, _vp(dy), _vp(dx), dx.nstride, dx.N, dx.Cc, dx.H, dx.W,
+             int(accumulate))
+
+    def copy_view(self, x, y, accumulate=False):
+        assert x.shape == y.shape
+        call("ghm_copy_view", self.h, _vp(x), x.nstride, _vp(y), y.nstride, x.N, x.Cc, x.HW, int(accumulate))
+
+    def axpby(self, a, x, b, y, n):
+        call("ghm_axpby", self.h, a, _vp(x), b, _vp(y), int(n))
+
+    def lsgan_loss(self, d, target, loss_out, grad=None, grad_scale=1.0, accumulate_loss=False):
+        assert d.contiguous
+        call("ghm_lsgan_loss", self.h, _vp(d), d.size, target, _vp(loss_out), _vp(grad), grad_scale,
+             int(accumulate_loss))
+
+    def bce_loss(self, d, target, loss_out, grad=None, grad_scale=1.0, accumulate_loss=False):
+        assert d.contiguous
+        call("ghm_bce_loss", self.h, _vp(d), d.size, target, _vp(loss_out), _vp(grad), grad_scale,
+             int(accumulate_loss))
+
+    def recon_loss(self, a, b, loss_out, grad=None, grad_scale=1.0, l2=False, accumulate_grad=False):
+        call("ghm_recon_loss", self.h, _vp(a), a.nstride, _vp(b), b.nstride, a.N, a.Cc, a.HW, int(l2), _vp(loss_out),
+             _vp(grad), grad.nstride if grad is not None else 0, grad_scale, int(accumulate_grad))
+
+    def rmsprop(self, p, g, acc, n, hyper, rho=0.9, eps=1e-6, grad_scale=1.0):
+        call("ghm_rmsprop", self.h, _vp(p), _vp(g), _vp(acc), int(n), _vp(hyper), rho, eps, grad_scale)
+
+    def adam(self, p, g, m, v, n, hyper, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
+        call("ghm_adam", self.h, _vp(p), _vp(g), _vp(m), _vp(v), int(n), _vp(hyper), b1, b2, eps, grad_scale)
+
+    def adam_tick(self, hyper):
+        call("ghm_adam_tick", self.h, _vp(hyper))
+
+    def allreduce_sum(self, buf, n):
+        call("ghm_allreduce_sum", self.h, _vp(buf), int(n))
+
+    def allreduce_max(self, buf, n):
+        call("ghm_allreduce_max", self.h, _vp(buf), int(n))
+
+    def conv_variant(self, d, kind):
+        out = C.create_string_buffer(128)
+        call("ghm_conv2d_variant", C.byref(d), kind, out, 128)
+        return out.value.decode()

@@ -1,0 +1,333 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against the numpy oracle.
+Tolerance: rel-L2 <= 1e-5 for fp32 ops (north_star bound is 1e-3; fp32 MFMA is an exact fmaf chain)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from gan_heightmaps_amd import device
+    if device.device_count() == 0:
+        pytest.fail("no HIP device visible: GPU tests must run on the MI355X box")
+    dev = device.Device(0)
+    yield dev, device.Ops(dev), device
+    dev.close()
+
+
+CONV_CASES = [
+    # N, C, H, W, K, k, s, pad
+    (2, 16, 12, 12, 32, 5, 1, 2),     # dcgan-style 5x5 same
+    (2, 32, 16, 16, 64, 3, 2, 1),     # unet encoder 3x3 s2
+    (1, 48, 9, 11, 40, 3, 1, 1),      # odd sizes, C%16==0, ragged K
+    (2, 5, 10, 10, 7, 3, 1, 1),       # slow-K path, ragged everything
+    (4, 1, 32, 32, 64, 5, 1, 2),      # first layer d_conv1 (C=1)
+    (2, 4, 32, 32, 64, 3, 2, 1),      # pd_conv1 (C=4, s2)
+    (2, 64, 16, 16, 1, 5, 1, 2),      # g_out (K=1: direct kernel)
+    (2, 32, 8, 8, 3, 3, 2, 1),        # small-R, stride 2
+    (3, 32, 2, 2, 48, 2, 1, 0),       # conv9: k2 valid 2x2 -> 1x1
+    (2, 128, 24, 24, 128, 3, 1, 1),   # 128-wide tiles
+    (1, 16, 7, 7, 16, 3, 2, 1),       # odd input with stride 2
+    (4, 1000, 1, 1, 96, 1, 1, 0),     # DenseLayer as 1x1 conv (1000 % 16 != 0)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile", ["big", "small"])
+def test_conv_fwd_dgrad_wgrad(gpu, case, tile):
+    dev, ops, D = gpu
+    os.environ["GHM_FORCE_TILE"] = tile
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(hash(case) % 2**31)
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    y_ref = O.conv2d_fwd(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), s, pad)
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    dx_ref, dW_ref, db_ref = O.conv2d_vjp(x.astype(np.float64), Wt.astype(np.float64), dy.astype(np.float64), s, pad)
+
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    xd, wd, bd = dev.tensor(x), dev.tensor(D.pack_conv_w(Wt).reshape(1, -1, 1, 1)), dev.tensor(b)
+    yd = dev.empty(y_ref.shape)
+    ops.conv2d_fwd(d, xd, wd, bd, yd)
+    assert rel(yd.numpy(), y_ref) < TOL
+    # fused epilogue
+    ops.conv2d_fwd(d, xd, wd, bd, yd, act='lrelu', alpha=0.2)
+    assert rel(yd.numpy(), O.lrelu_fwd(y_ref, 0.2)) < TOL
+    # dgrad (+ accumulate)
+    dyd, dxd = dev.tensor(dy), dev.empty(x.shape)
+    ops.conv2d_dgrad(d, dyd, wd, dxd)
+    assert rel(dxd.numpy(), dx_ref) < TOL
+    ops.conv2d_dgrad(d, dyd, wd, dxd, accumulate=True)
+    assert rel(dxd.numpy(), 2 * dx_ref) < TOL
+    # wgrad in packed layout
+    dwd = dev.zeros((1, C * k * k * K, 1, 1))
+    ws = dev.alloc(ops.wgrad_workspace(d))
+    ops.conv2d_wgrad(d, xd, dyd, dwd, ws)
+    dW = D.unpack_conv_w(dwd.numpy().ravel(), K, C, k, k)
+    assert rel(dW, dW_ref) < TOL
+    dbd = dev.empty((1, K, 1, 1))
+    ops.channel_sum(dyd, dbd)
+    assert rel(dbd.numpy().ravel(), db_ref) < TOL
+    os.environ.pop("GHM_FORCE_TILE")
+
+
+def test_wgrad_split_k_large(gpu):
+    """enough pixels to force split-K partials + reduce, and accumulate on top"""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = 2, 16, 96, 96, 32, 3, 1, 1
+    rng = np.random.RandomState(1)
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    dy = rng.randn(N, K, H, W).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    assert "splits=1" not in ops.conv_variant(d, 2)
+    ref = O.corr2d_bwd_weight(x.astype(np.float64), dy.astype(np.float64), s, pad, k, k)   # [K,C,a,b] unflipped
+    ref_packed = ref.transpose(1, 2, 3, 0).reshape(-1)
+    dwd = dev.zeros((1, C * k * k * K, 1, 1))
+    ws = dev.alloc(ops.wgrad_workspace(d))
+    xd, dyd = dev.tensor(x), dev.tensor(dy)
+    ops.conv2d_wgrad(d, xd, dyd, dwd, ws)
+    assert rel(dwd.numpy().ravel(), ref_packed) < TOL
+    ops.conv2d_wgrad(d, xd, dyd, dwd, ws, accumulate=True)
+    assert rel(dwd.numpy().ravel(), 2 * ref_packed) < TOL
+
+
+DECONV_CASES = [(2, 48, 1, 1, 32, 2, 1), (2, 32, 8, 8, 3, 2, 2), (1, 16, 5, 5, 24, 2, 2), (2, 16, 4, 4, 16, 3, 2)]
+
+
+@pytest.mark.parametrize("case", DECONV_CASES)
+def test_deconv_fwd_bwd(gpu, case):
+    """Deconv2DLayer = adjoint of the true convolution: forward runs the dgrad form, backward the forward form."""
+    dev, ops, D = gpu
+    N, Cin, h, w, Cout, k, s = case
+    rng = np.random.RandomState(7)
+    x = rng.randn(N, Cin, h, w).astype(np.float32)
+    Wt = (rng.randn(Cin, Cout, k, k) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.randn(Cout).astype(np.float32)
+    y_ref = O.deconv2d_fwd(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), s)
+    Hh, Ww = y_ref.shape[2:]
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    dx_ref, dW_ref, db_ref = O.deconv2d_vjp(x.astype(np.float64), Wt.astype(np.float64), dy.astype(np.float64), s)
+    # descriptor of the forward conv this layer is the adjoint of: input = deconv output
+    d = D.conv_desc(N, Cout, Hh, Ww, Cin, k, k, s, 0)
+    assert (d.Ho, d.Wo) == (h, w)
+    xd, wd, bd = dev.tensor(x), dev.tensor(D.pack_conv_w(Wt).reshape(1, -1, 1, 1)), dev.tensor(b)
+    yd = dev.empty(y_ref.shape)
+    ops.conv2d_dgrad(d, xd, wd, yd, bias=bd, act='tanh')
+    assert rel(yd.numpy(), np.tanh(y_ref)) < TOL
+    dyd, dxd = dev.tensor(dy), dev.empty(x.shape)
+    ops.conv2d_fwd(d, dyd, wd, None, dxd)
+    assert rel(dxd.numpy(), dx_ref) < TOL
+    dwd = dev.zeros((1, Cout * k * k * Cin, 1, 1))
+    ws = dev.alloc(ops.wgrad_workspace(d))
+    ops.conv2d_wgrad(d, dyd, xd, dwd, ws)
+    assert rel(D.unpack_conv_w(dwd.numpy().ravel(), Cin, Cout, k, k), dW_ref) < TOL
+
+
+def test_conv_on_channel_slice_views(gpu):
+    """ConcatLayer(axis=1) without copies: conv reads / writes channel slices of wider buffers."""
+    dev, ops, D = gpu
+    rng = np.random.RandomState(3)
+    N, C, H, K = 2, 16, 8, 32
+    big_in = rng.randn(N, C + 5, H, H).astype(np.float32)
+    Wt = rng.randn(K, C, 3, 3).astype(np.float32) * 0.1
+    b = rng.randn(K).astype(np.float32)
+    tin = dev.tensor(big_in)
+    tout = dev.zeros((N, K + 3, H, H))
+    xin, yout = tin.channels(5, 5 + C), tout.channels(3, 3 + K)
+    d = D.conv_desc(N, C, H, H, K, 3, 3, 1, 1, xin.nstride, yout.nstride)
+    ops.conv2d_fwd(d, xin, dev.tensor(D.pack_conv_w(Wt).reshape(1, -1, 1, 1)), dev.tensor(b), yout)
+    ref = O.conv2d_fwd(big_in[:, 5:].astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), 1, 1)
+    got = tout.numpy()
+    assert rel(got[:, 3:], ref) < TOL and np.all(got[:, :3] == 0)
+
+
+@pytest.mark.parametrize("shape", [(4, 24, 1, 1), (4, 8, 16, 16), (3, 5, 7, 9), (2, 64, 64, 64)])
+@pytest.mark.parametrize("act,alpha", [('lrelu', 0.2), ('linear', 0.0)])
+def test_batchnorm_fwd_bwd(gpu, shape, act, alpha):
+    dev, ops, D = gpu
+    rng = np.random.RandomState(5)
+    N, C, H, W = shape
+    x = (rng.randn(*shape) * 2 + 1).astype(np.float32)
+    beta, gamma = rng.randn(C).astype(np.float32), rng.rand(C).astype(np.float32) + 0.5
+    rm, ri = rng.randn(C).astype(np.float32), rng.rand(C).astype(np.float32) + 0.5
+    x64 = x.astype(np.float64)
+    z, mu, inv = O.bn_train_fwd(x64, beta.astype(np.float64), gamma.astype(np.float64))
+    y_ref = O.lrelu_fwd(z, alpha) if act == 'lrelu' else z
+    dout = rng.randn(*shape).astype(np.float32)
+    dz = O.lrelu_vjp(z, alpha, dout.astype(np.float64)) if act == 'lrelu' else dout.astype(np.float64)
+    dx_ref, dbeta_ref, dgamma_ref = O.bn_train_vjp(x64, gamma.astype(np.float64), mu, inv, dz)
+    rm_ref, ri_ref = O.bn_running_update(rm.astype(np.float64), ri.astype(np.float64), mu, inv)
+
+    ws = dev.alloc(ops.bn_workspace(C))
+    xd, yd = dev.tensor(x), dev.empty(shape)
+    md, ivd, rmd, rid = dev.empty((1, C, 1, 1)), dev.empty((1, C, 1, 1)), dev.tensor(rm), dev.tensor(ri)
+    gd, bd = dev.tensor(gamma), dev.tensor(beta)
+    ops.bn_stats(xd, md, ivd, ws, rmd, rid)
+    assert rel(md.numpy().ravel(), mu) < TOL and rel(ivd.numpy().ravel(), inv) < TOL
+    assert rel(rmd.numpy().ravel(), rm_ref) < TOL and rel(rid.numpy().ravel(), ri_ref) < TOL
+    ops.bn_apply(xd, yd, md, ivd, gd, bd, act, alpha)
+    assert rel(yd.numpy(), y_ref) < TOL
+    dxd, dgd, dbd = dev.empty(shape), dev.empty((1, C, 1, 1)), dev.empty((1, C, 1, 1))
+    ops.bn_backward(dev.tensor(dout), yd, xd, dxd, md, ivd, gd, dgd, dbd, ws, act, alpha)
+    assert rel(dbd.numpy().ravel(), dbeta_ref) < 1e-4
+    assert rel(dgd.numpy().ravel(), dgamma_ref) < 1e-4
+    assert rel(dxd.numpy(), dx_ref) < 1e-4
+    # deterministic path = apply with running stats
+    ops.bn_apply(xd, yd, rmd, rid, gd, bd, 'linear', 0.0)
+    assert rel(yd.numpy(), O.bn_infer_fwd(x64, beta, gamma, rm_ref, ri_ref)) < TOL
+
+
+def test_bn_bottleneck_batch4_single_pixel(gpu):
+    """the [4,512,1,1] U-Net bottleneck: statistics over 4 values per channel"""
+    dev, ops, D = gpu
+    rng = np.random.RandomState(11)
+    x = rng.randn(4, 512, 1, 1).astype(np.float32)
+    z, mu, inv = O.bn_train_fwd(x.astype(np.float64), np.zeros(512), np.ones(512))
+    ws = dev.alloc(ops.bn_workspace(512))
+    md, ivd = dev.empty((1, 512, 1, 1)), dev.empty((1, 512, 1, 1))
+    ops.bn_stats(dev.tensor(x), md, ivd, ws)
+    assert rel(ivd.numpy().ravel(), inv) < TOL
+
+
+def test_pool_upsample_act(gpu):
+    dev, ops, D = gpu
+    rng = np.random.RandomState(9)
+    x = rng.randn(2, 6, 16, 12).astype(np.float32)
+    xd = dev.tensor(x)
+    # maxpool + fused lrelu backward
+    a = O.lrelu_fwd(x.astype(np.float64), 0.2)
+    ad = dev.tensor(a)
+    pd_ = dev.empty((2, 6, 8, 6))
+    ops.maxpool2_fwd(ad, pd_)
+    p_ref = O.maxpool_fwd(a, 2)
+    assert rel(pd_.numpy(), p_ref) < TOL
+    g = rng.randn(*p_ref.shape).astype(np.float32)
+    dxd = dev.empty(x.shape)
+    ops.maxpool2_bwd(ad, pd_, dev.tensor(g), dxd, 'lrelu', 0.2)
+    ref = O.lrelu_vjp(x.astype(np.float64), 0.2, O.maxpool_vjp(a.astype(np.float32).astype(np.float64),
+                                                               p_ref.astype(np.float32).astype(np.float64), g, 2))
+    assert rel(dxd.numpy(), ref) < TOL
+    # avgpool
+    yd = dev.empty((2, 6, 4, 3))
+    ops.avgpool_fwd(xd, yd, 4)
+    assert rel(yd.numpy(), O.avgpool_fwd(x, 4)) < TOL
+    g = rng.randn(2, 6, 4, 3).astype(np.float32)
+    ops.avgpool_bwd(dev.tensor(g), dxd, 4)
+    assert rel(dxd.numpy(), O.avgpool_vjp(x.shape, g, 4)) < TOL
+    # nearest / bilinear up + adjoints (+accumulate)
+    ud = dev.empty((2, 6, 32, 24))
+    ops.upsample_nearest2_fwd(xd, ud)
+    assert np.array_equal(ud.numpy(), O.upscale_nearest_fwd(x))
+    g = rng.randn(2, 6, 32, 24).astype(np.float32)
+    gd = dev.tensor(g)
+    ops.upsample_nearest2_bwd(gd, dxd)
+    assert rel(dxd.numpy(), O.upscale_nearest_vjp(g.astype(np.float64))) < TOL
+    ops.upsample_bilinear2_fwd(xd, ud)
+    assert rel(ud.numpy(), O.bilinear_up2_fwd(x)) < TOL
+    ops.upsample_bilinear2_bwd(gd, dxd)
+    assert rel(dxd.numpy(), O.bilinear_up2_vjp(g.astype(np.float64))) < TOL
+    ops.upsample_bilinear2_bwd(gd, dxd, accumulate=True)
+    assert rel(dxd.numpy(), 2 * O.bilinear_up2_vjp(g.astype(np.float64))) < TOL
+    # 1x1 and 2x2 bilinear edge cases (U-Net 2x2 -> 4x4)
+    for hw in [(1, 1), (2, 2), (1, 3)]:
+        xs = rng.randn(2, 3, *hw).astype(np.float32)
+        us = dev.empty((2, 3, 2 * hw[0], 2 * hw[1]))
+        ops.upsample_bilinear2_fwd(dev.tensor(xs), us)
+        assert rel(us.numpy(), O.bilinear_theano_literal(xs.astype(np.float64))) < TOL
+    # activations fwd/bwd
+    for act, alpha, f, df in [('sigmoid', 0, O.sigmoid_fwd, O.sigmoid_vjp_from_out),
+                              ('tanh', 0, O.tanh_fwd, O.tanh_vjp_from_out)]:
+        yd2 = dev.empty(x.shape)
+        ops.act_fwd(xd, yd2, act, alpha)
+        y_ref = f(x.astype(np.float64))
+        assert rel(yd2.numpy(), y_ref) < TOL
+        g = rng.randn(*x.shape).astype(np.float32)
+        ops.act_bwd(dev.tensor(g), yd2, dxd, act, alpha)
+        assert rel(dxd.numpy(), df(y_ref, g)) < 1e-4
+
+
+def test_losses_and_optimizers(gpu):
+    dev, ops, D = gpu
+    rng = np.random.RandomState(2)
+    d = rng.randn(8, 1, 16, 16).astype(np.float32)
+    dd, gd, ld = dev.tensor(d), dev.empty(d.shape), dev.zeros((1, 1, 1, 1))
+    ops.lsgan_loss(dd, 1.0, ld, gd, 1.0)
+    loss, grad = O.squared_error_mean(d.astype(np.float64), 1.0)
+    assert abs(ld.numpy().item() - loss) < 1e-5 * abs(loss) and rel(gd.numpy(), grad) < TOL
+    ops.lsgan_loss(dd, 0.0, ld, None, 1.0, accumulate_loss=True)
+    assert abs(ld.numpy().item() - (loss + O.squared_error_mean(d.astype(np.float64), 0.0)[0])) < 1e-4
+    p = rng.rand(4, 1, 1, 1).astype(np.float32) * 0.8 + 0.1
+    pd_, gp = dev.tensor(p), dev.empty(p.shape)
+    ops.bce_loss(pd_, 1.0, ld, gp)
+    loss, grad = O.bce_mean(p.astype(np.float64), 1.0)
+    assert abs(ld.numpy().item() - loss) < 1e-5 and rel(gp.numpy(), grad) < TOL
+    a, b = rng.randn(2, 3, 16, 16).astype(np.float32), rng.randn(2, 3, 16, 16).astype(np.float32)
+    ad, bd_, ga = dev.tensor(a), dev.tensor(b), dev.zeros(a.shape)
+    ops.recon_loss(ad, bd_, ld, ga, 100.0)
+    loss, grad = O.l1_mean(a.astype(np.float64), b.astype(np.float64))
+    assert abs(ld.numpy().item() - loss) < 1e-5 and rel(ga.numpy(), 100 * grad) < TOL
+    ops.recon_loss(ad, bd_, ld, ga, 1.0, l2=True, accumulate_grad=True)
+    l2, g2 = O.l2_mean(a.astype(np.float64), b.astype(np.float64))
+    assert abs(ld.numpy().item() - l2) < 1e-5 and rel(ga.numpy(), 100 * grad + g2) < TOL
+    # optimisers on a flat buffer with a ragged tail
+    n = 1003
+    pp, gg = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+    acc = np.abs(rng.randn(n)).astype(np.float32)
+    pd2, gd2, ad2 = dev.tensor(pp), dev.tensor(gg), dev.tensor(acc)
+    hyper = dev.tensor(np.array([1e-2, 0.0], np.float32))
+    ops.rmsprop(pd2, gd2, ad2, n, hyper)
+    p_ref, a_ref = O.rmsprop_step(pp.astype(np.float64), gg.astype(np.float64), acc.astype(np.float64), 1e-2)
+    assert rel(pd2.numpy().ravel(), p_ref) < TOL and rel(ad2.numpy().ravel(), a_ref) < TOL
+    m, v = np.zeros(n), np.zeros(n)
+    md, vd, pd3 = dev.zeros((1, n, 1, 1)), dev.zeros((1, n, 1, 1)), dev.tensor(pp)
+    pcur, t = pp.astype(np.float64), 0
+    for _ in range(3):
+        ops.adam(pd3, gd2, md, vd, n, hyper)
+        ops.adam_tick(hyper)
+        pcur, m, v, t = O.adam_step(pcur, gg.astype(np.float64), m, v, t, 1e-2)
+    assert rel(pd3.numpy().ravel(), pcur) < TOL
+    assert hyper.numpy().ravel()[1] == 3.0
+
+
+def test_graph_capture_replay(gpu):
+    dev, ops, D = gpu
+    x = np.arange(64, dtype=np.float32)
+    xd, yd = dev.tensor(x), dev.zeros((1, 64, 1, 1))
+    dev.capture_begin()
+    ops.axpby(2.0, xd, 1.0, yd, 64)
+    g = dev.capture_end()
+    for _ in range(3):
+        dev.graph_launch(g)
+    dev.sync()
+    assert np.allclose(yd.numpy().ravel(), 6 * x)
+    dev.graph_destroy(g)
+
+
+def test_rccl_single_rank_allreduce(gpu):
+    """world=1 communicator: exercises dlopen(librccl), ncclCommInitRank and ncclAllReduce on the ctx stream."""
+    import ctypes as C
+    from gan_heightmaps_amd._lib import call
+    dev, ops, D = gpu
+    uid = (C.c_uint8 * 128)()
+    call("ghm_comm_unique_id", C.byref(uid))
+    call("ghm_comm_init", dev.h, 0, 1, C.byref(uid))
+    x = np.arange(1000, dtype=np.float32)
+    xd = dev.tensor(x)
+    ops.allreduce_sum(xd, 1000)
+    ops.allreduce_max(xd, 1000)
+    dev.sync()
+    assert np.array_equal(xd.numpy().ravel(), x)
+    call("ghm_comm_destroy", dev.h)
