@@ -1,0 +1,582 @@
+"""Lowering of lasagne-style layer graphs to libghm.so launches, with hand-derived backward.
+
+This replaces what Theano does for the reference at ``theano.function`` time
+(/root/reference/pix2pix.py:142-147): a layer graph becomes a static *program* -- a list of kernel
+launches over preallocated HBM buffers -- that is recorded once and then replayed (optionally as a
+captured HIP graph).  There is no autodiff: every node type has its backward written out here.
+
+Graph rewrites before placement (both exact):
+  * act(concat(a, b)) -> concat(act(a), act(b)) with sharing of an identical act(a) that already
+    exists (U-Net skips: architectures/p2p.py:202-203 applies leaky_rectify after the concat while the
+    encoder applies the same nonlinearity to the same tensor),
+  * a NonlinearityLayer whose producer is a conv / deconv / dense / BN node with no other consumer is
+    folded into the producer's epilogue.
+Placement: inputs of a ConcatLayer(axis=1) are written in place into channel slices of the concat
+buffer (sample stride = total channels * H * W), so concatenation costs no copy.
+"""
+import numpy as np
+
+from . import layers as L
+from .architectures.layers import BilinearUpsample2DLayer
+from .device import DevTensor, Ops, conv_desc, pack_conv_w, unpack_conv_w
+from .nonlinearities import linear
+
+ALIGN = 64      # elements; keeps every parameter 256-B aligned inside the flat buffers
+
+
+def _align(n):
+    return (n + ALIGN - 1) // ALIGN * ALIGN
+
+
+class ParamStore:
+    """All parameters of one network in three flat fp32 buffers: trainable values ``w``, their
+    gradients ``g`` (same layout) and non-trainable state ``s`` (BN mean / inv_std).  The flat layout
+    makes the optimiser one kernel and the data-parallel exchange one all-reduce per network."""
+
+    def __init__(self, dev, params):
+        self.dev = dev
+        self.params = list(params)
+        nt = ns = 0
+        for p in self.params:
+            n = int(np.prod(p.shape))
+            if 'trainable' in p.tags:
+                p.index = ('w', nt)
+                nt += _align(n)
+            else:
+                p.index = ('s', ns)
+                ns += _align(n)
+        self.n_train, self.n_state = nt, ns
+        self.w = dev.zeros((1, max(nt, 1), 1, 1))
+        self.g = dev.zeros((1, max(nt, 1), 1, 1))
+        self.s = dev.zeros((1, max(ns, 1), 1, 1))
+        self.opt_state = {}
+        for p in self.params:
+            p.store = self
+            self.upload(p)
+
+    def _view(self, base, p):
+        n = int(np.prod(p.shape))
+        return DevTensor(self.dev, base.ptr + 4 * p.index[1], (1, n, 1, 1), None, base)
+
+    def value(self, p):
+        return self._view(self.w if p.index[0] == 'w' else self.s, p)
+
+    def grad(self, p):
+        assert p.index[0] == 'w'
+        return self._view(self.g, p)
+
+    @staticmethod
+    def _to_device_layout(p, v):
+        if p.kind == 'conv_w':
+            return pack_conv_w(v).ravel()
+        return np.ascontiguousarray(v, np.float32).ravel()
+
+    @staticmethod
+    def _from_device_layout(p, flat):
+        if p.kind == 'conv_w':
+            K, C, kh, kw = p.shape
+            return unpack_conv_w(flat, K, C, kh, kw).astype(np.float32)
+        return flat.reshape(p.shape).copy()
+
+    def upload(self, p):
+        self.value(p).set(self._to_device_layout(p, p.value))
+
+    def download(self, p):
+        return self._from_device_layout(p, self.value(p).numpy().ravel())
+
+    def download_grad(self, p):
+        return self._from_device_layout(p, self.grad(p).numpy().ravel())
+
+
+# --------------------------------------------------------------------------------------------------
+# IR
+# --------------------------------------------------------------------------------------------------
+class Node:
+    def __init__(self, op, inputs, layer=None, **attrs):
+        self.op = op
+        self.inputs = list(inputs)
+        self.layer = layer
+        self.attrs = attrs
+        self.act = linear               # epilogue nonlinearity of conv / deconv / dense / bn / act nodes
+        self.consumers = []
+        self.shape = None
+        self.out = None
+        self.alias = None               # (concat node, channel offset)
+        self.aux = {}
+
+    def __repr__(self):
+        return "<%s %s act=%s>" % (self.op, self.shape, self.act.kind)
+
+
+def _build_ir(out_layer):
+    nodes, of = [], {}
+    for l in L.get_all_layers(out_layer):
+        if isinstance(l, L.InputLayer):
+            n = Node('input', [], l)
+        elif isinstance(l, L.DenseLayer):
+            n = Node('dense', [of[id(l.input_layer)]], l)
+            n.act = l.nonlinearity
+        elif isinstance(l, L.Conv2DLayer):
+            n = Node('conv', [of[id(l.input_layer)]], l)
+            n.act = l.nonlinearity
+        elif isinstance(l, L.TransposedConv2DLayer):
+            n = Node('deconv', [of[id(l.input_layer)]], l)
+            n.act = l.nonlinearity
+        elif isinstance(l, L.BatchNormLayer):
+            n = Node('bn', [of[id(l.input_layer)]], l)
+        elif isinstance(l, L.NonlinearityLayer):
+            if l.nonlinearity == linear:
+                of[id(l)] = of[id(l.input_layer)]
+                continue
+            n = Node('act', [of[id(l.input_layer)]], l)
+            n.act = l.nonlinearity
+        elif isinstance(l, L.ReshapeLayer):
+            n = Node('reshape', [of[id(l.input_layer)]], l)
+        elif isinstance(l, L.Upscale2DLayer):
+            n = Node('up_nearest', [of[id(l.input_layer)]], l)
+        elif isinstance(l, BilinearUpsample2DLayer):
+            n = Node('up_bilinear', [of[id(l.input_layer)]], l)
+        elif isinstance(l, L.Pool2DLayer):
+            if l.mode == 'max':
+                if l.pool_size != (2, 2):
+                    raise NotImplementedError("max pooling other than 2x2")
+                n = Node('maxpool', [of[id(l.input_layer)]], l)
+            else:
+                n = Node('avgpool', [of[id(l.input_layer)]], l, p=l.pool_size[0])
+        elif isinstance(l, L.ConcatLayer):
+            n = Node('concat', [of[id(i)] for i in l.input_layers], l)
+        elif isinstance(l, L.DropoutLayer):
+            if l.p > 0:
+                raise NotImplementedError("DropoutLayer(p>0) has no kernel yet (unused by test1_nobn_bilin_both)")
+            of[id(l)] = of[id(l.input_layer)]
+            continue
+        else:
+            raise NotImplementedError("no lowering for %r" % (l,))
+        of[id(l)] = n
+        nodes.append(n)
+    return nodes, of
+
+
+def _toposort(out_node):
+    order, seen = [], set()
+    stack = [(out_node, False)]
+    while stack:
+        n, done = stack.pop()
+        if done:
+            order.append(n)
+            continue
+        if id(n) in seen:
+            continue
+        seen.add(id(n))
+        stack.append((n, True))
+        for i in reversed(n.inputs):
+            if id(i) not in seen:
+                stack.append((i, False))
+    for n in order:
+        n.consumers = []
+    for n in order:
+        for i in n.inputs:
+            i.consumers.append(n)
+    return order
+
+
+def _replace(order, old, new):
+    for n in order:
+        n.inputs = [new if i is old else i for i in n.inputs]
+
+
+def _rewrite(out_node):
+    # R1: act(concat(..)) -> concat(act(..)..) with CSE
+    changed = True
+    while changed:
+        changed = False
+        order = _toposort(out_node)
+        for n in order:
+            if n.op == 'act' and n.inputs[0].op == 'concat' and len(n.inputs[0].consumers) == 1:
+                cat = n.inputs[0]
+                new_inputs = []
+                for a in cat.inputs:
+                    shared = [c for c in a.consumers if c.op == 'act' and c.act == n.act and c is not n]
+                    if shared:
+                        new_inputs.append(shared[0])
+                    else:
+                        m = Node('act', [a], n.layer)
+                        m.act = n.act
+                        new_inputs.append(m)
+                new_cat = Node('concat', new_inputs, cat.layer)
+                if n is out_node:
+                    out_node = new_cat
+                _replace(order, n, new_cat)
+                changed = True
+                break
+    # R2: fold a sole-consumer act into its producer's epilogue
+    changed = True
+    while changed:
+        changed = False
+        order = _toposort(out_node)
+        for n in order:
+            if n.op == 'act':
+                m = n.inputs[0]
+                if m.op in ('conv', 'deconv', 'dense', 'bn') and m.act == linear and len(m.consumers) == 1:
+                    m.act = n.act
+                    if n is out_node:
+                        out_node = m
+                    _replace(order, n, m)
+                    changed = True
+                    break
+    return out_node
+
+
+class NetPlan:
+    """One network lowered for a fixed batch size: buffers + emitters of forward/backward programs."""
+
+    def __init__(self, dev, ops, out_layer, batch, store, inputs=None, out_tensor=None, name="net"):
+        self.dev, self.ops, self.batch, self.store, self.name = dev, ops, batch, store, name
+        nodes, of = _build_ir(out_layer)
+        self.out_node = _rewrite(of[id(out_layer)])
+        self.order = _toposort(self.out_node)
+        self.node_of_layer = of
+        self.input_nodes = [n for n in self.order if n.op == 'input']
+        self._shapes()
+        self._place(inputs or {}, out_tensor)
+        self._scratch = {}
+        self.bn_ws = None
+        cmax = max([n.shape[1] for n in self.order if n.op == 'bn'] + [0])
+        if cmax:
+            self.bn_ws = dev.alloc(ops.bn_workspace(cmax))
+            self._bn_scratch = dev.empty((1, 2 * cmax, 1, 1))
+        self.wgrad_ws = None
+        self._wgrad_ws_bytes = 0
+
+    # ---- shapes and placement ----------------------------------------------------------------
+    def _shapes(self):
+        B = self.batch
+        for n in self.order:
+            if n.op == 'input':
+                s = n.layer.output_shape
+                n.shape = (B,) + tuple(s[1:]) if len(s) == 4 else (B, s[1], 1, 1)
+            elif n.op == 'reshape':
+                tgt = n.layer.shape
+                per = int(np.prod(n.inputs[0].shape[1:]))
+                rest = int(np.prod(tgt[1:]))
+                if rest != per:
+                    raise NotImplementedError("ReshapeLayer that changes the batch dimension")
+                n.shape = (B,) + tuple(tgt[1:]) if len(tgt) == 4 else (B, tgt[1], 1, 1)
+            elif n.op == 'concat':
+                s0 = n.inputs[0].shape
+                n.shape = (B, sum(i.shape[1] for i in n.inputs), s0[2], s0[3])
+            else:
+                ls = n.layer.get_output_shape_for((B,) + tuple(n.inputs[0].shape[1:])) \
+                    if n.op not in ('dense',) else (B, n.layer.num_units)
+                n.shape = tuple(ls) if len(ls) == 4 else (B, ls[1], 1, 1)
+
+    def _place(self, inputs, out_tensor):
+        for n in self.order:
+            if n.op == 'concat':
+                c0 = 0
+                for i in n.inputs:
+                    if i.alias is None and i.op in ('conv', 'deconv', 'dense', 'bn', 'act', 'input') and i.out is None:
+                        i.alias = (n, c0)
+                    c0 += i.shape[1]
+        if out_tensor is not None:
+            assert out_tensor.shape == self.out_node.shape, (out_tensor.shape, self.out_node.shape)
+            assert self.out_node.alias is None
+            self.out_node.out = out_tensor
+        for n in self.input_nodes:
+            if n.layer in inputs:
+                assert n.alias is None, "external tensor for an input that lives inside a concat buffer"
+                t = inputs[n.layer]
+                assert t.shape == n.shape, (t.shape, n.shape)
+                n.out = t
+
+        def get_out(n):
+            if n.out is not None:
+                return n.out
+            if n.alias is not None:
+                cat, c0 = n.alias
+                n.out = get_out(cat).channels(c0, c0 + n.shape[1])
+            elif n.op == 'reshape':
+                n.out = get_out(n.inputs[0]).reshape(n.shape)
+            else:
+                n.out = self.dev.empty(n.shape)
+            return n.out
+
+        for n in self.order:
+            get_out(n)
+            if n.op == 'bn':
+                C = n.shape[1]
+                n.aux['mean'] = self.dev.empty((1, C, 1, 1))
+                n.aux['inv'] = self.dev.empty((1, C, 1, 1))
+
+    def input_tensor(self, layer):
+        return self.node_of_layer[id(layer)].out
+
+    @property
+    def out(self):
+        return self.out_node.out
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    def _desc(self, n, x_t, y_t):
+        """conv descriptor of node n for tensors (conv-input-side x_t, conv-output-side y_t)."""
+        l = n.layer
+        if n.op == 'dense':
+            return conv_desc(x_t.N, x_t.Cc * x_t.HW, 1, 1, l.num_units, 1, 1, 1, 0, x_t.nstride, y_t.nstride)
+        k = l.filter_size
+        if n.op == 'conv':
+            return conv_desc(x_t.N, x_t.Cc, x_t.H, x_t.W, l.num_filters, k[0], k[1], l.stride[0], l.pad[0],
+                             x_t.nstride, y_t.nstride)
+        # deconv: descriptor of the conv it is the adjoint of (conv input = deconv OUTPUT = x_t here)
+        return conv_desc(x_t.N, x_t.Cc, x_t.H, x_t.W, y_t.Cc, k[0], k[1], l.stride[0], 0, x_t.nstride, y_t.nstride)
+
+    def _need_wgrad_ws(self, d):
+        b = self.ops.wgrad_workspace(d)
+        if b > self._wgrad_ws_bytes:
+            if self.wgrad_ws is not None:
+                self.dev.free(self.wgrad_ws)
+            self.wgrad_ws = self.dev.alloc(b)
+            self._wgrad_ws_bytes = b
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def emit_forward(self, prog, deterministic=False, update_running=True):
+        ops, st = self.ops, self.store
+        for n in self.order:
+            y = n.out
+            if n.op in ('input', 'reshape', 'concat'):
+                if n.op == 'concat':
+                    c0 = 0
+                    for i in n.inputs:
+                        if i.alias is None or i.alias[0] is not n:
+                            dst = y.channels(c0, c0 + i.shape[1])
+                            prog.append(("concat_copy", lambda a=i.out, b=dst: ops.copy_view(a, b)))
+                        c0 += i.shape[1]
+                continue
+            x = n.inputs[0].out
+            a = n.act
+            if n.op in ('conv', 'dense'):
+                d = self._desc(n, x, y)
+                w, b = st.value(n.layer.W), st.value(n.layer.b)
+                prog.append(("%s_fwd" % n.op, lambda d=d, x=x, w=w, b=b, y=y, a=a:
+                             ops.conv2d_fwd(d, x, w, b, y, a.kind, a.alpha)))
+            elif n.op == 'deconv':
+                d = self._desc(n, y, x)
+                w, b = st.value(n.layer.W), st.value(n.layer.b)
+                prog.append(("deconv_fwd", lambda d=d, x=x, w=w, b=b, y=y, a=a:
+                             ops.conv2d_dgrad(d, x, w, y, b, a.kind, a.alpha)))
+            elif n.op == 'bn':
+                l = n.layer
+                g, be = st.value(l.gamma), st.value(l.beta)
+                rm, ri = st.value(l.mean), st.value(l.inv_std)
+                if deterministic:
+                    prog.append(("bn_apply_det", lambda x=x, y=y, rm=rm, ri=ri, g=g, be=be, a=a:
+                                 ops.bn_apply(x, y, rm, ri, g, be, a.kind, a.alpha)))
+                else:
+                    m, iv = n.aux['mean'], n.aux['inv']
+                    upd = update_running
+                    prog.append(("bn_stats", lambda x=x, m=m, iv=iv, rm=rm, ri=ri, l=l, upd=upd:
+                                 ops.bn_stats(x, m, iv, self.bn_ws, rm if upd else None, ri if upd else None,
+                                              l.epsilon, l.alpha)))
+                    prog.append(("bn_apply", lambda x=x, y=y, m=m, iv=iv, g=g, be=be, a=a:
+                                 ops.bn_apply(x, y, m, iv, g, be, a.kind, a.alpha)))
+            elif n.op == 'act':
+                prog.append(("act_fwd", lambda x=x, y=y, a=a: ops.act_fwd(x, y, a.kind, a.alpha)))
+            elif n.op == 'up_nearest':
+                prog.append(("up_nearest_fwd", lambda x=x, y=y: ops.upsample_nearest2_fwd(x, y)))
+            elif n.op == 'up_bilinear':
+                prog.append(("up_bilinear_fwd", lambda x=x, y=y: ops.upsample_bilinear2_fwd(x, y)))
+            elif n.op == 'maxpool':
+                prog.append(("maxpool_fwd", lambda x=x, y=y: ops.maxpool2_fwd(x, y)))
+            elif n.op == 'avgpool':
+                prog.append(("avgpool_fwd", lambda x=x, y=y, p=n.attrs['p']: ops.avgpool_fwd(x, y, p)))
+            else:
+                raise NotImplementedError(n.op)
+
+    # ---- backward --------------------------------------------------------------------------------
+    def emit_backward(self, prog, seed, nslice=None, wgrad=True, input_grads=(), accumulate_wgrad=False, tag="bwd"):
+        """Append the backward program.  ``seed``: DevTensor holding dLoss/d(output) (it may be modified in
+        place).  ``nslice=(n0, n1)``: run on that sample range of the saved activations.  ``input_grads``:
+        InputLayers whose gradient is wanted.  Returns {InputLayer: DevTensor grad}."""
+        ops, st, dev = self.ops, self.store, self.dev
+        n0, n1 = nslice if nslice is not None else (0, self.batch)
+        nb = n1 - n0
+
+        def sl(t):
+            return t if nslice is None else t.samples(n0, n1)
+
+        want_in = {id(self.node_of_layer[id(l)]) for l in input_grads}
+        # which nodes need a gradient at all
+        req = {}
+        for n in self.order:
+            has_p = wgrad and n.op in ('conv', 'deconv', 'dense', 'bn')
+            req[id(n)] = has_p or any(req[id(i)] for i in n.inputs) or id(n) in want_in
+        grads, written = {}, set()
+        key = (tag, n0, n1)
+        cache = self._scratch.setdefault(key, {})
+
+        def grad_of(n):
+            """gradient buffer w.r.t. n.out (allocated once per (tag, slice))."""
+            if id(n) in grads:
+                return grads[id(n)]
+            if id(n) in cache:
+                g = cache[id(n)]
+            elif n.alias is not None:
+                cat, c0 = n.alias
+                g = grad_of(cat).channels(c0, c0 + n.shape[1])
+            else:
+                g = dev.empty((nb,) + tuple(n.shape[1:]))
+            cache[id(n)] = g
+            grads[id(n)] = g
+            return g
+
+        def mark_written(n):
+            written.add(id(n))
+            if n.op == 'concat':
+                for i in n.inputs:
+                    if i.alias is not None and i.alias[0] is n:
+                        if id(i) in written:
+                            raise NotImplementedError("gradient of a concat input written before the concat's own "
+                                                      "consumer ran (unsupported graph ordering)")
+                        mark_written(i)
+
+        def target(n):
+            """-> (grad tensor of n, accumulate flag) for a consumer about to write it."""
+            if n.alias is not None and id(n) not in written:
+                # a concat input's gradient slice is first written by the concat's own consumer
+                raise NotImplementedError("gradient of a ConcatLayer input written before the concat's consumer "
+                                          "ran (unsupported graph ordering)")
+            return grad_of(n), id(n) in written
+
+        grads[id(self.out_node)] = seed
+        written.add(id(self.out_node))
+        mark_written(self.out_node)
+
+        for n in reversed(self.order):
+            if id(n) not in written or not req[id(n)]:
+                continue
+            G = grad_of(n)
+            if n.op in ('input', 'concat'):
+                if n.op == 'concat':
+                    c0 = 0
+                    for i in n.inputs:
+                        if (i.alias is None or i.alias[0] is not n) and req[id(i)]:
+                            gi, acc = target(i)
+                            src = G.channels(c0, c0 + i.shape[1])
+                            prog.append(("concat_bwd_copy", lambda a=src, b=gi, acc=acc: ops.copy_view(a, b, acc)))
+                            mark_written(i)
+                        c0 += i.shape[1]
+                continue
+            xin = n.inputs[0]
+            x, y = sl(xin.out), sl(n.out)
+            a = n.act
+            need_dx = req[id(xin)]
+            if n.op in ('conv', 'deconv', 'dense'):
+                if a != linear and not n.aux.get(('grad_is_pre', key)):
+                    prog.append(("act_bwd", lambda G=G, y=y, a=a: ops.act_bwd(G, y, G, a.kind, a.alpha)))
+                l = n.layer
+                w = st.value(l.W)
+                if n.op == 'deconv':
+                    d = self._desc(n, G, x)          # conv input side = deconv output grad, output side = x
+                else:
+                    d = self._desc(n, x, G)
+                if wgrad:
+                    self._need_wgrad_ws(d)
+                    gw, gb = st.grad(l.W), st.grad(l.b)
+                    aw = accumulate_wgrad
+                    if n.op == 'deconv':
+                        prog.append(("deconv_wgrad", lambda d=d, G=G, x=x, gw=gw, aw=aw:
+                                     ops.conv2d_wgrad(d, G, x, gw, self.wgrad_ws, aw)))
+                    else:
+                        prog.append(("%s_wgrad" % n.op, lambda d=d, G=G, x=x, gw=gw, aw=aw:
+                                     ops.conv2d_wgrad(d, x, G, gw, self.wgrad_ws, aw)))
+                    prog.append(("bias_grad", lambda G=G, gb=gb, aw=aw: ops.channel_sum(G, gb, aw)))
+                if need_dx:
+                    gi, acc = target(xin)
+                    if n.op == 'deconv':
+                        d2 = self._desc(n, G, gi)
+                        prog.append(("deconv_dgrad", lambda d=d2, G=G, w=w, gi=gi, acc=acc:
+                                     ops.conv2d_fwd(d, G, w, None, gi, 'linear', 0.0, acc)))
+                    else:
+                        d2 = self._desc(n, gi, G)
+                        prog.append(("%s_dgrad" % n.op, lambda d=d2, G=G, w=w, gi=gi, acc=acc:
+                                     ops.conv2d_dgrad(d, G, w, gi, None, 'linear', 0.0, acc)))
+                    mark_written(xin)
+            elif n.op == 'bn':
+                l = n.layer
+                gam = st.value(l.gamma)
+                if wgrad:
+                    dg, db, aw = st.grad(l.gamma), st.grad(l.beta), accumulate_wgrad
+                else:
+                    C = n.shape[1]
+                    dg, db, aw = self._bn_scratch.channels(0, C), self._bn_scratch.channels(C, 2 * C), False
+                gi, acc = target(xin)
+                dst = gi
+                if acc:
+                    dst = dev.empty(gi.shape) if ('bn_tmp', id(n)) not in cache else cache[('bn_tmp', id(n))]
+                    cache[('bn_tmp', id(n))] = dst
+                m, iv = n.aux['mean'], n.aux['inv']
+                prog.append(("bn_bwd", lambda G=G, y=y, x=x, dst=dst, m=m, iv=iv, gam=gam, dg=dg, db=db, a=a, aw=aw:
+                             ops.bn_backward(G, y, x, dst, m, iv, gam, dg, db, self.bn_ws, a.kind, a.alpha, aw)))
+                if acc:
+                    prog.append(("bn_bwd_acc", lambda dst=dst, gi=gi: ops.copy_view(dst, gi, True)))
+                mark_written(xin)
+            elif n.op == 'act':
+                if need_dx:
+                    gi, acc = target(xin)
+                    prog.append(("act_bwd", lambda G=G, y=y, gi=gi, a=a, acc=acc:
+                                 ops.act_bwd(G, y, gi, a.kind, a.alpha, acc)))
+                    mark_written(xin)
+            elif n.op == 'reshape':
+                if need_dx:
+                    if id(xin) in grads or id(xin) in cache or xin.alias is not None:
+                        gi, acc = target(xin)
+                        prog.append(("reshape_bwd", lambda G=G, gi=gi, acc=acc:
+                                     ops.copy_view(G.reshape(gi.shape), gi, acc)))
+                    else:
+                        grads[id(xin)] = cache[id(xin)] = G.reshape((nb,) + tuple(xin.shape[1:]))
+                    mark_written(xin)
+            elif n.op in ('up_nearest', 'up_bilinear'):
+                if need_dx:
+                    gi, acc = target(xin)
+                    fn = ops.upsample_nearest2_bwd if n.op == 'up_nearest' else ops.upsample_bilinear2_bwd
+                    prog.append(("%s_bwd" % n.op, lambda G=G, gi=gi, acc=acc, fn=fn: fn(G, gi, acc)))
+                    mark_written(xin)
+            elif n.op == 'maxpool':
+                if need_dx:
+                    gi, acc = target(xin)
+                    if acc:
+                        raise NotImplementedError("maxpool input with several consumers")
+                    fa = linear
+                    if xin.op in ('conv', 'deconv', 'dense') and len(xin.consumers) == 1 and xin.act.kind in ('lrelu', 'relu'):
+                        # fold the producer's LeakyReLU/ReLU backward into the pooling scatter (mask from the output sign)
+                        fa = xin.act
+                        xin.aux[('grad_is_pre', key)] = True
+                    prog.append(("maxpool_bwd", lambda x=x, y=y, G=G, gi=gi, fa=fa:
+                                 ops.maxpool2_bwd(x, y, G, gi, fa.kind, fa.alpha)))
+                    mark_written(xin)
+            elif n.op == 'avgpool':
+                if need_dx:
+                    gi, acc = target(xin)
+                    if acc:
+                        raise NotImplementedError("avgpool input with several consumers")
+                    prog.append(("avgpool_bwd", lambda G=G, gi=gi, p=n.attrs['p']: ops.avgpool_bwd(G, gi, p)))
+                    mark_written(xin)
+            else:
+                raise NotImplementedError(n.op)
+        return {l: (grad_of(self.node_of_layer[id(l)]) if id(self.node_of_layer[id(l)]) in written else None)
+                for l in input_grads}
+
+
+def run_program(prog):
+    for _, fn in prog:
+        fn()
+
+
+def time_program(dev, prog, repeat=1):
+    """Per-entry HIP-event timing (synchronises per entry: for profiling, not for throughput)."""
+    out = []
+    for label, fn in prog:
+        dev.timer_start(1)
+        for _ in range(repeat):
+            fn()
+        dev.timer_stop(1)
+        out.append((label, dev.timer_ms(1) / repeat))
+    return out
