@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""Throughput of the gan-heightmaps train step on MI355X (BASELINE.json metric:
+"512px heightmap+texture train images/sec at 1/2/4/8 MI355X; % MFMA roofline").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one call of the compiled train_fn of experiment test1_nobn_bilin_both (DCGAN G+D and pix2pix
+U-Net+PatchGAN forward, four gradient roots, four RMSprop updates) on a synthetic 512x512 batch of 4 per GPU
+(weak scaling) that is resident in HBM before the timed region.  One process per GPU; gradients are summed
+with RCCL.  Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel, HIP events inside the
+timed region) and "cpu_baseline" (the numpy oracle on the host cores; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+JOINT_GFLOP_PER_IMG = 683.29           # algorithmic 2 x MACs of the joint train step
+
+
+def synthetic_batch(B, latent_dim, in_shp, seed):
+    """Z~U[0,1) (pix2pix.py:31,206); X = uint8/255 (util.py:34); Y = (uint8-127.5)/127.5 (util.py:35)."""
+    Z = np.random.RandomState(seed).rand(B, latent_dim).astype(np.float32)
+    X = np.random.RandomState(seed + 1).randint(0, 256, (B, 1, in_shp, in_shp)).astype(np.float32) / 255.0
+    Y = (np.random.RandomState(seed + 2).randint(0, 256, (B, 3, in_shp, in_shp)).astype(np.float32) - 127.5) / 127.5
+    return Z, X.astype(np.float32), Y.astype(np.float32)
+
+
+def cpu_baseline(sample_batch=1):
+    """The numpy oracle (kind "port": the reference's Theano CPU path cannot be installed here) on one joint
+    train step of the same 512x512 nets, fp32 im2col + OpenBLAS sgemm, all host cores."""
+    from oracle import step as ostep
+    cfg = ostep.default_cfg()
+    st = ostep.init_state(cfg, 0, np.float32)
+    Z, X, Y = ostep.synthetic_batch(sample_batch, cfg, 0)
+    t0 = time.time()
+    ostep.train_step(st, Z, X, Y, dtype=np.float32)
+    dt = time.time() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {"value": sample_batch / dt, "unit": "images/s", "cores": int(threads), "kind": "port",
+            "sample": "%d joint train step(s) (fwd + 4 gradient roots + RMSprop) of the same 512x512 "
+                      "test1_nobn_bilin_both nets at batch %d, numpy fp32 im2col+sgemm oracle, %.1f s"
+                      % (1, sample_batch, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=4)
+    ap.add_argument("--mode", default="both", choices=["both", "dcgan", "p2p"])
+    ap.add_argument("--graph", action="store_true", help="replay the step as a captured HIP graph (no per-kernel events)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="print a per-program-entry timing table to stderr")
+    args = ap.parse_args()
+
+    from gan_heightmaps_amd import device, dist
+    from gan_heightmaps_amd.experiments import make_model
+
+    rank, local_rank, world = dist.env_rank_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+    if device.device_count() == 0:
+        sys.exit("bench.py: no HIP device visible (there is no CPU fallback)")
+    dev = device.Device(local_rank)
+    comm = dist.Comm(dev, rank, world) if world > 1 else None
+    B = args.batch_per_gpu
+    backend = dict(device=dev, comm=comm, use_graph=args.graph, seed=0, verbose=False)
+    model = make_model('test1_nobn_bilin_both', **backend)
+    if args.mode != 'both':
+        # configs 2 / 3 of BASELINE.json: same nets, one stage trained
+        model.engine.train_mode = args.mode
+    eng = model.engine
+    Z, X, Y = synthetic_batch(B, 1000, 512, seed=1000 + rank)
+    b = eng.built(B)
+    eng._upload(b, Z, X, Y)                      # inputs resident in HBM before the timed region
+
+    for _ in range(args.warmup):
+        eng.enqueue_train(b)
+    dev.sync()
+
+    prog = (b.train_compute + (b.update if world == 1 else [])) if not args.graph else []
+    # ---- pick the dominant kernel from one instrumented (untimed) step ----
+    dominant, launches_per_step, flops_per_step = None, 0, 0.0
+    if prog:
+        from gan_heightmaps_amd.engine import time_program
+        table = time_program(dev, prog)
+        by_kernel = {}
+        for label, ms, meta in table:
+            k = meta["kernel"].split(" splits")[0] if meta else label
+            e = by_kernel.setdefault(k, [0.0, 0, 0.0])
+            e[0] += ms
+            e[1] += 1
+            e[2] += meta["flops"] if meta else 0.0
+        if world > 1:
+            for e in b.exchange + b.update:
+                e[1]()
+        if args.profile and rank == 0:
+            tot = sum(v[0] for v in by_kernel.values())
+            for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][0]):
+                print("%-44s %9.3f ms %5.1f%% n=%3d %8.1f GFLOP %6.1f TF/s" %
+                      (k, v[0], 100 * v[0] / tot, v[1], v[2] / 1e9, v[2] / 1e9 / max(v[0], 1e-9)), file=sys.stderr)
+            for label, ms, meta in sorted(table, key=lambda t: -t[1])[:40]:
+                print("  %-18s %8.3f ms %s %s" % (label, ms, meta["kernel"] if meta else "",
+                                                 meta["geom"] if meta else ""), file=sys.stderr)
+        dominant = max((k for k in by_kernel if by_kernel[k][2] > 0), key=lambda k: by_kernel[k][0])
+        launches_per_step = by_kernel[dominant][1]
+        flops_per_step = by_kernel[dominant][2]
+
+    def is_dom(e):
+        return len(e) > 2 and e[2] is not None and e[2]["kernel"].split(" splits")[0] == dominant
+
+    max_slots = 4000
+    inst_steps = min(args.steps, max_slots // max(launches_per_step, 1)) if dominant else 0
+
+    # ---- timed region ----
+    if comm is not None:
+        comm.barrier()
+    dev.sync()
+    t0 = time.perf_counter()
+    slot = 0
+    for s in range(args.steps):
+        if args.graph:
+            eng.enqueue_train(b)
+            continue
+        if s < inst_steps:
+            for e in b.train_compute:
+                if is_dom(e):
+                    dev.timer_start(slot)
+                    e[1]()
+                    dev.timer_stop(slot)
+                    slot += 1
+                else:
+                    e[1]()
+        else:
+            for e in b.train_compute:
+                e[1]()
+        for e in b.exchange:
+            e[1]()
+        for e in b.update:
+            e[1]()
+    dev.sync()
+    if comm is not None:
+        comm.barrier()
+    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        elapsed = comm.max_scalar(elapsed)
+    losses = eng._read_losses()
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = B * world * args.steps / elapsed
+    out = {
+        "metric": "512px heightmap+texture train images/sec", "value": round(value, 3), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "test1_nobn_bilin_both joint DCGAN+pix2pix train step (train_mode=%s), 512x512, "
+                               "batch %d per GPU, RMSprop lr 1e-4, LSGAN + 100*L1" % (args.mode, B),
+                   "global_batch": B * world, "in_shp": 512, "parallelism": "dp%d" % world,
+                   "hip_graph": bool(args.graph)},
+        "step_algorithmic_tflops": round(JOINT_GFLOP_PER_IMG * value / 1e3, 2) if args.mode == 'both' else None,
+        "step_frac_of_fp32_mfma_peak": round(JOINT_GFLOP_PER_IMG * value / world / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)
+        if args.mode == 'both' else None,
+        "losses": [float(x) for x in losses],
+    }
+    if dominant and slot:
+        tot_ms = sum(dev.timer_ms(i) for i in range(slot))
+        avg_ms = tot_ms / slot
+        flops_per_launch = flops_per_step / launches_per_step
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "kernel": dominant, "launches_per_step": launches_per_step,
+                           "avg_launch_ms": round(avg_ms, 4),
+                           "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3),
+                           "share_of_step_time": round(avg_ms * launches_per_step / ms_per_step, 3)}
+    else:
+        out["roofline"] = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
+    dev.close()
+
+
+if __name__ == "__main__":
+    main()

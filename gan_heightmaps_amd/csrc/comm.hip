@@ -27,7 +27,9 @@ RcclApi g_api;
 
 int load_rccl() {
     if (g_api.handle) return 0;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // the ROCm install this library was linked against first: a bare soname would resolve to whatever copy a host
+    // process has already mapped (e.g. the librccl bundled with a torch wheel, built against another HIP runtime)
+    const char* names[] = {"/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
     for (const char* n : names) {
         g_api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (g_api.handle) break;

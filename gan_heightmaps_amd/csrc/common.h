@@ -7,6 +7,8 @@
 
 #include "../../include/ghm.h"
 
+#define GHM_MAX_TIMERS 4096
+
 struct ghm_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -15,13 +17,18 @@ struct ghm_graph {
 struct ghm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start[64] = {};
-    hipEvent_t ev_stop[64] = {};
+    hipEvent_t ev_start[GHM_MAX_TIMERS] = {};
+    hipEvent_t ev_stop[GHM_MAX_TIMERS] = {};
     void* comm = nullptr;          // ncclComm_t (RCCL), owned by comm.hip
     int rank = 0, world = 1;
     int num_cu = 256;
     bool capturing = false;
+    void* scratch = nullptr;       // library-owned workspace (split-K partials, reduction partials)
+    size_t scratch_bytes = 0;
 };
+
+// grow-only workspace owned by the ctx; growing is illegal while a graph is being captured
+int ghm_scratch(ghm_ctx* ctx, size_t bytes, void** out);
 
 void ghm_set_error(const char* fmt, ...);
 

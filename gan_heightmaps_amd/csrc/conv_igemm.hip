@@ -44,6 +44,8 @@ struct IgemmArgs {
     int act;
     float alpha;
     int accumulate;
+    float* partial;        // split-K: raw accumulators go to partial[split][r][p] (no bias / act)
+    int slabs_per_split;   // K slabs per blockIdx.y slice
     int di[MAX_TAPS], dj[MAX_TAPS], wi[MAX_TAPS];
 };
 
@@ -210,14 +212,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    load_slab(0);
+    const int s_begin = blockIdx.y * a.slabs_per_split;
+    const int s_end = min(nslabs, s_begin + a.slabs_per_split);
+    load_slab(s_begin);
     store_slab(0);
     __syncthreads();
 
     const int frag_k = lane >> 5, frag_i = lane & 31;
-    for (int s = 0; s < nslabs; ++s) {
-        const int buf = s & 1;
-        const bool more = (s + 1) < nslabs;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        const bool more = (s + 1) < s_end;
         if (more) load_slab(s + 1);
         const float* Ab = As + buf * BK * LDA + wm * (BM / WM) + frag_i;
         const float* Bb = Bs + buf * BK * LDB + wn * (BN / WN) + frag_i;
@@ -239,6 +243,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     }
 
     // ---- epilogue: lanes along pixels (D column = lane&31), rows = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    if (a.partial) {
+        float* pb = a.partial + (long)blockIdx.y * a.R * P;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int p = p0 + wn * (BN / WN) + j * 32 + frag_i;
+            if (p >= P) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = r0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * frag_k;
+                    if (r < a.R) pb[(long)r * P + p] = acc[i][j][e];
+                }
+            }
+        }
+        return;
+    }
     const int HWout = a.Hout * a.Wout;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -300,6 +321,72 @@ __global__ __launch_bounds__(256) void direct_smallr_kernel(const IgemmArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         if (r < a.R) {
+            float v = acc[r];
+            if (a.bias) v += a.bias[r];
+            float* o = ob + (long)r * HWout;
+            if (a.accumulate) v += *o;
+            *o = ghm_act(v, a.act, a.alpha);
+        }
+    }
+}
+
+// split-K epilogue: sum the partial slices, then bias / accumulate / activation and the NCHW scatter
+__global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs a, int S) {
+    const int hw_s = a.Hs * a.Ws;
+    const long P = (long)a.N * hw_s;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P * a.R) return;
+    const int r = (int)(idx / P);
+    const long p = idx - (long)r * P;
+    float v = 0.f;
+    for (int k = 0; k < S; ++k) v += a.partial[((long)k * a.R + r) * P + p];
+    const int n = (int)(p / hw_s), rem = (int)(p - (long)n * hw_s);
+    const int uu = rem / a.Ws, vv = rem - uu * a.Ws;
+    float* o = a.out + (long)n * a.out_nstride + (long)r * a.Hout * a.Wout +
+               (long)(uu * a.os + a.ou) * a.Wout + (vv * a.os + a.ov);
+    if (a.bias) v += a.bias[r];
+    if (a.accumulate) v += *o;
+    *o = ghm_act(v, a.act, a.alpha);
+}
+
+// R <= 4 with few output pixels and a long reduction (d_out, pd_out): one WAVE per output pixel, the 64
+// lanes stride over the (tap, channel) reduction and combine with a wave reduction.
+template <bool WT>
+__global__ __launch_bounds__(256) void direct_smallr_wave_kernel(const IgemmArgs a) {
+    const int hw_s = a.Hs * a.Ws;
+    const long P = (long)a.N * hw_s;
+    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const int lane = threadIdx.x & 63;
+    const int n = (int)(p / hw_s), rem = (int)(p - (long)n * hw_s);
+    const int uu = rem / a.Ws, vv = rem - uu * a.Ws;
+    const float* inb = a.in + (long)n * a.in_nstride;
+    const int HinWin = a.Hin * a.Win;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < a.ntaps; ++t) {
+        const int y = uu * a.ss + a.di[t], x = vv * a.ss + a.dj[t];
+        if ((unsigned)y >= (unsigned)a.Hin || (unsigned)x >= (unsigned)a.Win) continue;   // wave-uniform
+        const float* src = inb + (y * a.Win + x);
+        const int tapw = a.wi[t];
+        for (int ch = lane; ch < a.CH; ch += 64) {
+            const float v = src[(long)ch * HinWin];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < a.R) {
+                    const float w = WT ? a.wp[((long)r * a.T + tapw) * a.CH + ch]
+                                       : a.wp[((long)ch * a.T + tapw) * a.R + r];
+                    acc[r] = fmaf(v, w, acc[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        for (int o = 32; o > 0; o >>= 1) acc[r] += __shfl_down(acc[r], o, 64);
+    if (lane == 0) {
+        float* ob = a.out + (long)n * a.out_nstride + (long)(uu * a.os + a.ou) * a.Wout + (vv * a.os + a.ov);
+        const int HWout = a.Hout * a.Wout;
+        for (int r = 0; r < a.R && r < 4; ++r) {
             float v = acc[r];
             if (a.bias) v += a.bias[r];
             float* o = ob + (long)r * HWout;
@@ -461,23 +548,39 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, int S, long
     out[i] = s;
 }
 
-// per-channel sum over (n, hw): bias gradients
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, int N, int HW, long nstride,
-                                                          float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x;
+// per-channel sum over (n, hw): bias gradients. grid (S, C) partials, then one thread per channel.
+__global__ __launch_bounds__(256) void channel_sum_partial(const float* __restrict__ x, int N, int HW, long nstride,
+                                                           int S, float* __restrict__ part) {
+    const int c = blockIdx.y, sidx = blockIdx.x;
+    const long total = (long)N * HW;
+    const long chunk = ((total + S - 1) / S + 3) & ~3L;
+    const long lo = sidx * chunk, hi = min(lo + chunk, total);
     float s = 0.f;
-    for (int n = 0; n < N; ++n) {
-        const float* p = x + (long)n * nstride + (long)c * HW;
-        for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    if ((HW & 3) == 0 && (nstride & 3) == 0) {
+        for (long e = lo + threadIdx.x * 4; e < hi; e += 1024) {
+            const long n = e / HW, i = e - n * HW;
+            const float4 v = *reinterpret_cast<const float4*>(x + n * nstride + (long)c * HW + i);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (long e = lo + threadIdx.x; e < hi; e += 256) {
+            const long n = e / HW, i = e - n * HW;
+            s += x[n * nstride + (long)c * HW + i];
+        }
     }
-    __shared__ float red[256];
-    red[threadIdx.x] = s;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[c] = (accumulate ? out[c] : 0.f) + red[0];
+    if (threadIdx.x == 0) part[(long)c * S + sidx] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void channel_sum_final(const float* __restrict__ part, int C, int S, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[(long)c * S + k];
+    out[c] = (accumulate ? out[c] : 0.f) + s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -506,26 +609,53 @@ Variant pick_variant(int R, long P, int num_cu) {
 }
 
 template <bool WT>
-int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a) {
+int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
+    IgemmArgs a = a_in;
     const long P = (long)a.N * a.Hs * a.Ws;
     if (P == 0 || a.R == 0) return 0;
+    a.partial = nullptr;
+    a.slabs_per_split = 1 << 30;
     if (a.R <= 4) {
-        hipLaunchKernelGGL((direct_smallr_kernel<WT>), dim3(ceil_div(P, 256)), dim3(256), 0, ctx->stream, a);
+        if (P <= 16384 && (long)a.ntaps * a.CH >= 256) {
+            hipLaunchKernelGGL((direct_smallr_wave_kernel<WT>), dim3(ceil_div(P, 4)), dim3(256), 0, ctx->stream, a);
+        } else {
+            hipLaunchKernelGGL((direct_smallr_kernel<WT>), dim3(ceil_div(P, 256)), dim3(256), 0, ctx->stream, a);
+        }
         GHM_LAUNCH_CHECK();
         return 0;
     }
     const Variant v = pick_variant(a.R, P, ctx->num_cu);
     const bool fast = (a.CH % 16) == 0;
     const int grid = ceil_div(a.R, v.bm) * ceil_div(P, v.bn);
+    // split-K over the (tap, channel) slabs when the output tiles alone cannot fill the chip
+    const int nslabs = ceil_div((long)a.ntaps * a.CH, 16);
+    int splits = 1;
+    if (grid < ctx->num_cu) {
+        splits = (2 * ctx->num_cu + grid - 1) / grid;
+        const int max_by_work = nslabs / 8 > 0 ? nslabs / 8 : 1;     // keep >= 8 slabs (128 k) per slice
+        if (splits > max_by_work) splits = max_by_work;
+    }
+    if (const char* f = getenv("GHM_FORCE_SPLITK")) splits = atoi(f) < nslabs ? atoi(f) : nslabs;
+    if (splits > 1) {
+        a.slabs_per_split = ceil_div(nslabs, splits);
+        splits = ceil_div(nslabs, a.slabs_per_split);
+        void* ws = nullptr;
+        if (int e = ghm_scratch(ctx, (size_t)splits * a.R * P * sizeof(float), &ws)) return e;
+        a.partial = (float*)ws;
+    }
+    const dim3 g(grid, splits);
 #define GHM_IGEMM_CASE(BM_, BN_, WM_, WN_)                                                             \
     if (v.bm == BM_ && v.bn == BN_) {                                                                  \
         if (fast)                                                                                      \
-            hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, WT, true>), dim3(grid), dim3(256), 0, \
-                               ctx->stream, a);                                                        \
+            hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, WT, true>), g, dim3(256), 0, ctx->stream, a);  \
         else                                                                                           \
-            hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, WT, false>), dim3(grid), dim3(256), 0, \
-                               ctx->stream, a);                                                        \
+            hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, WT, false>), g, dim3(256), 0, ctx->stream, a); \
         GHM_LAUNCH_CHECK();                                                                            \
+        if (splits > 1) {                                                                              \
+            hipLaunchKernelGGL(igemm_splitk_epilogue, dim3(ceil_div(P * a.R, 256)), dim3(256), 0, ctx->stream, a, \
+                               splits);                                                                \
+            GHM_LAUNCH_CHECK();                                                                        \
+        }                                                                                              \
         return 0;                                                                                      \
     }
     GHM_IGEMM_CASE(128, 128, 2, 2)
@@ -686,8 +816,19 @@ int ghm_conv2d_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const
 int ghm_channel_sum(ghm_ctx* ctx, const float* x, int32_t N, int32_t C, int32_t HW, int64_t nstride, float* out,
                     int32_t accumulate) {
     if (C == 0) return 0;
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, ctx->stream, x, N, HW, (long)nstride, out,
-                       accumulate);
+    const long total = (long)N * HW;
+    long S = (1024 + C - 1) / C;
+    long maxs = total / 4096;
+    if (maxs < 1) maxs = 1;
+    if (S > maxs) S = maxs;
+    if (S > 256) S = 256;
+    void* ws = nullptr;
+    if (int e = ghm_scratch(ctx, (size_t)C * S * sizeof(float), &ws)) return e;
+    hipLaunchKernelGGL(channel_sum_partial, dim3((int)S, C), dim3(256), 0, ctx->stream, x, N, HW, (long)nstride, (int)S,
+                       (float*)ws);
+    GHM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(channel_sum_final, dim3(ceil_div(C, 256)), dim3(256), 0, ctx->stream, (const float*)ws, C, (int)S,
+                       out, accumulate);
     GHM_LAUNCH_CHECK();
     return 0;
 }

@@ -13,6 +13,20 @@ void ghm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int ghm_scratch(ghm_ctx* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->scratch_bytes) {
+        GHM_CHECK(!ctx->capturing, "workspace would grow (%zu -> %zu bytes) inside graph capture: run the program "
+                  "eagerly once before capturing", ctx->scratch_bytes, bytes);
+        GHM_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) GHM_HIP(hipFree(ctx->scratch));
+        const size_t want = bytes + bytes / 4;
+        GHM_HIP(hipMalloc(&ctx->scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return 0;
+}
+
 extern "C" {
 
 const char* ghm_last_error(void) { return g_err; }
@@ -44,10 +58,11 @@ int ghm_ctx_destroy(ghm_ctx* ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     if (ctx->comm) ghm_comm_destroy(ctx);
-    for (int i = 0; i < 64; ++i) {
+    for (int i = 0; i < GHM_MAX_TIMERS; ++i) {
         if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
         if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
     }
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -151,7 +166,7 @@ int ghm_graph_destroy(ghm_graph* g) {
 }
 
 int ghm_timer_start(ghm_ctx* ctx, int32_t slot) {
-    GHM_CHECK(slot >= 0 && slot < 64, "timer slot out of range");
+    GHM_CHECK(slot >= 0 && slot < GHM_MAX_TIMERS, "timer slot out of range");
     if (!ctx->ev_start[slot]) {
         GHM_HIP(hipEventCreate(&ctx->ev_start[slot]));
         GHM_HIP(hipEventCreate(&ctx->ev_stop[slot]));
@@ -161,13 +176,13 @@ int ghm_timer_start(ghm_ctx* ctx, int32_t slot) {
 }
 
 int ghm_timer_stop(ghm_ctx* ctx, int32_t slot) {
-    GHM_CHECK(slot >= 0 && slot < 64 && ctx->ev_stop[slot], "timer slot not started");
+    GHM_CHECK(slot >= 0 && slot < GHM_MAX_TIMERS && ctx->ev_stop[slot], "timer slot not started");
     GHM_HIP(hipEventRecord(ctx->ev_stop[slot], ctx->stream));
     return 0;
 }
 
 int ghm_timer_elapsed_ms(ghm_ctx* ctx, int32_t slot, float* ms) {
-    GHM_CHECK(slot >= 0 && slot < 64 && ctx->ev_stop[slot], "timer slot not started");
+    GHM_CHECK(slot >= 0 && slot < GHM_MAX_TIMERS && ctx->ev_stop[slot], "timer slot not started");
     GHM_HIP(hipEventSynchronize(ctx->ev_stop[slot]));
     GHM_HIP(hipEventElapsedTime(ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
     return 0;

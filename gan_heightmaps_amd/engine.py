@@ -356,12 +356,12 @@ class NetPlan:
                 d = self._desc(n, x, y)
                 w, b = st.value(n.layer.W), st.value(n.layer.b)
                 prog.append(("%s_fwd" % n.op, lambda d=d, x=x, w=w, b=b, y=y, a=a:
-                             ops.conv2d_fwd(d, x, w, b, y, a.kind, a.alpha)))
+                             ops.conv2d_fwd(d, x, w, b, y, a.kind, a.alpha), conv_meta(ops, d, 0)))
             elif n.op == 'deconv':
                 d = self._desc(n, y, x)
                 w, b = st.value(n.layer.W), st.value(n.layer.b)
                 prog.append(("deconv_fwd", lambda d=d, x=x, w=w, b=b, y=y, a=a:
-                             ops.conv2d_dgrad(d, x, w, y, b, a.kind, a.alpha)))
+                             ops.conv2d_dgrad(d, x, w, y, b, a.kind, a.alpha), conv_meta(ops, d, 1)))
             elif n.op == 'bn':
                 l = n.layer
                 g, be = st.value(l.gamma), st.value(l.beta)
@@ -483,21 +483,21 @@ class NetPlan:
                     aw = accumulate_wgrad
                     if n.op == 'deconv':
                         prog.append(("deconv_wgrad", lambda d=d, G=G, x=x, gw=gw, aw=aw:
-                                     ops.conv2d_wgrad(d, G, x, gw, self.wgrad_ws, aw)))
+                                     ops.conv2d_wgrad(d, G, x, gw, self.wgrad_ws, aw), conv_meta(ops, d, 2)))
                     else:
                         prog.append(("%s_wgrad" % n.op, lambda d=d, G=G, x=x, gw=gw, aw=aw:
-                                     ops.conv2d_wgrad(d, x, G, gw, self.wgrad_ws, aw)))
+                                     ops.conv2d_wgrad(d, x, G, gw, self.wgrad_ws, aw), conv_meta(ops, d, 2)))
                     prog.append(("bias_grad", lambda G=G, gb=gb, aw=aw: ops.channel_sum(G, gb, aw)))
                 if need_dx:
                     gi, acc = target(xin)
                     if n.op == 'deconv':
                         d2 = self._desc(n, G, gi)
                         prog.append(("deconv_dgrad", lambda d=d2, G=G, w=w, gi=gi, acc=acc:
-                                     ops.conv2d_fwd(d, G, w, None, gi, 'linear', 0.0, acc)))
+                                     ops.conv2d_fwd(d, G, w, None, gi, 'linear', 0.0, acc), conv_meta(ops, d2, 0)))
                     else:
                         d2 = self._desc(n, gi, G)
                         prog.append(("%s_dgrad" % n.op, lambda d=d2, G=G, w=w, gi=gi, acc=acc:
-                                     ops.conv2d_dgrad(d, G, w, gi, None, 'linear', 0.0, acc)))
+                                     ops.conv2d_dgrad(d, G, w, gi, None, 'linear', 0.0, acc), conv_meta(ops, d2, 1)))
                     mark_written(xin)
             elif n.op == 'bn':
                 l = n.layer
@@ -565,18 +565,26 @@ class NetPlan:
                 for l in input_grads}
 
 
+def conv_meta(ops, d, kind):
+    """roofline metadata of one conv launch: kernel variant name and ALGORITHMIC flops (2 x MACs)."""
+    return {"kernel": ops.conv_variant(d, kind),
+            "flops": 2.0 * d.N * d.K * d.Ho * d.Wo * d.C * d.kh * d.kw,
+            "geom": "N%d C%d %dx%d K%d k%d s%d" % (d.N, d.C, d.H, d.W, d.K, d.kh, d.stride)}
+
+
 def run_program(prog):
-    for _, fn in prog:
-        fn()
+    for e in prog:
+        e[1]()
 
 
 def time_program(dev, prog, repeat=1):
     """Per-entry HIP-event timing (synchronises per entry: for profiling, not for throughput)."""
     out = []
-    for label, fn in prog:
+    for e in prog:
+        label, fn = e[0], e[1]
         dev.timer_start(1)
         for _ in range(repeat):
             fn()
         dev.timer_stop(1)
-        out.append((label, dev.timer_ms(1) / repeat))
+        out.append((label, dev.timer_ms(1) / repeat, e[2] if len(e) > 2 else None))
     return out

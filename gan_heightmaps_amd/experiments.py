@@ -1,0 +1,134 @@
+"""Experiment registry with the reference's entry points (/root/reference/experiments.py:22-131):
+``python experiments.py <experiment> <mode>``, experiments test1_nobn, test1_nobn_finetunep2p_bilin and
+test1_nobn_bilin_both, modes train / interp / gen.
+
+The HDF5 + Keras-augmentation iterator of the reference (util.py:10-62) is outside this round's scope
+(SURVEY.md 8 f1); ``get_iterators`` reads an ``.npz`` with xt/yt/xv/yv uint8 NHWC arrays when given one and
+otherwise serves seeded synthetic batches with the reference's value ranges.
+"""
+import os
+import sys
+
+import numpy as np
+
+from .architectures import dcgan, p2p
+from .nonlinearities import linear, tanh
+from .pix2pix import Pix2Pix
+from .updates import rmsprop, shared
+from .init import floatX
+
+
+class ArrayIterator:
+    """Infinite shuffled batch generator over uint8 NHWC arrays (util.py:20-42 without augmentation):
+    NHWC uint8 -> NCHW float32; A: /255 if grayscale else (x-127.5)/127.5; same for B."""
+
+    def __init__(self, X, Y, bs, is_a_grayscale, is_b_grayscale, seed=0):
+        assert X.shape[0] == Y.shape[0]
+        self.X, self.Y, self.bs, self.N = X, Y, bs, X.shape[0]
+        self.ga, self.gb = is_a_grayscale, is_b_grayscale
+        self.rng = np.random.RandomState(seed)
+        self._slices = []
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if not self._slices:
+            self._slices = [slice(b * self.bs, (b + 1) * self.bs) for b in range((self.N + self.bs - 1) // self.bs)]
+            self.rng.shuffle(self._slices)
+        sl = self._slices.pop(0)
+        x = self.X[sl].astype("float32").transpose(0, 3, 1, 2)
+        y = self.Y[sl].astype("float32").transpose(0, 3, 1, 2)
+        x = x / 255.0 if self.ga else (x - 127.5) / 127.5
+        y = y / 255.0 if self.gb else (y - 127.5) / 127.5
+        return np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32)
+
+    next = __next__
+
+
+def synthetic_arrays(n, in_shp, is_a_grayscale, is_b_grayscale, seed=0):
+    rng = np.random.RandomState(seed)
+    X = rng.randint(0, 256, (n, in_shp, in_shp, 1 if is_a_grayscale else 3)).astype(np.uint8)
+    Y = rng.randint(0, 256, (n, in_shp, in_shp, 1 if is_b_grayscale else 3)).astype(np.uint8)
+    return X, Y
+
+
+def get_iterators(dataset, batch_size, is_a_grayscale, is_b_grayscale, da=True, in_shp=512, n_synthetic=8):
+    if dataset is not None and os.path.exists(dataset) and dataset.endswith(".npz"):
+        d = np.load(dataset)
+        xt, yt, xv, yv = d['xt'], d['yt'], d['xv'], d['yv']
+    else:
+        if dataset is not None:
+            print("dataset %r not available: using synthetic 512x512 batches" % (dataset,), file=sys.stderr)
+        xt, yt = synthetic_arrays(n_synthetic, in_shp, is_a_grayscale, is_b_grayscale, 0)
+        xv, yv = xt, yt
+    return (ArrayIterator(xt, yt, batch_size, is_a_grayscale, is_b_grayscale),
+            ArrayIterator(xv, yv, batch_size, is_a_grayscale, is_b_grayscale))
+
+
+# kwargs of the three experiments (experiments.py:24-41, :63-79, :102-119)
+_COMMON = dict(
+    gen_fn_dcgan=dcgan.default_generator, disc_fn_dcgan=dcgan.default_discriminator,
+    gen_params_dcgan={'num_repeats': 0, 'div': [2, 2, 4, 4, 8, 8, 8]},
+    disc_params_dcgan={'num_repeats': 0, 'bn': False, 'nonlinearity': linear, 'div': [8, 4, 4, 4, 2, 2, 2]},
+    gen_fn_p2p=p2p.g_unet, disc_fn_p2p=p2p.discriminator,
+    disc_params_p2p={'nf': 64, 'bn': False, 'num_repeats': 0, 'act': linear, 'mul_factor': [1, 2, 4, 8]},
+    in_shp=512, latent_dim=1000, is_a_grayscale=True, is_b_grayscale=False, lsgan=True, opt=rmsprop)
+
+
+def make_model(name, **backend):
+    """Construct the Pix2Pix of experiment ``name``; ``backend`` = device / comm / use_graph / seed / verbose."""
+    kw = dict(_COMMON)
+    kw['opt_args'] = {'learning_rate': shared(floatX(1e-4))}
+    if name == 'test1_nobn':
+        kw['gen_params_p2p'] = {'nf': 64, 'act': tanh, 'num_repeats': 0}
+    elif name == 'test1_nobn_finetunep2p_bilin':
+        kw['gen_params_p2p'] = {'nf': 64, 'act': tanh, 'num_repeats': 0, 'bilinear_upsample': True}
+        kw['train_mode'] = 'p2p'
+    elif name == 'test1_nobn_bilin_both':
+        kw['gen_params_p2p'] = {'nf': 64, 'act': tanh, 'num_repeats': 0, 'bilinear_upsample': True}
+        kw['train_mode'] = 'both'
+    else:
+        raise KeyError(name)
+    kw.update(backend)
+    return Pix2Pix(**kw)
+
+
+DATASET = os.environ.get("GHM_DATASET", "/data/lisa/data/cbeckham/textures_v2_brown500.h5")
+
+
+def _run(name, out_name, mode, num_epochs=1000, **train_kw):
+    assert mode in ["train", "interp", "gen"]
+    model = make_model(name)
+    bs = 4
+    it_train, it_val = get_iterators(DATASET, bs, True, False, True)
+    if mode == "train":
+        model.train(it_train, it_val, batch_size=bs, num_epochs=num_epochs, out_dir="output/%s" % out_name,
+                    model_dir="models/%s" % out_name, **train_kw)
+    elif mode == "gen":
+        model.generate_gz(100, 10, "deleteme")
+    else:
+        raise NotImplementedError("interpolation utilities are outside this round's scope (SURVEY 8 f3)")
+    return model
+
+
+def test1_nobn(mode, **kw):
+    return _run('test1_nobn', "test1_repeatnod_fixp2p_nobn", mode, **kw)
+
+
+def test1_nobn_finetunep2p_bilin(mode, **kw):
+    return _run('test1_nobn_finetunep2p_bilin', "test1_repeatnod_fixp2p_nobn_finetunep2p_bilin", mode, **kw)
+
+
+def test1_nobn_bilin_both(mode, **kw):
+    return _run('test1_nobn_bilin_both', "test1_nobn_bilin_both_deleteme", mode, **kw)
+
+
+def main(argv):
+    fn = {'test1_nobn': test1_nobn, 'test1_nobn_finetunep2p_bilin': test1_nobn_finetunep2p_bilin,
+          'test1_nobn_bilin_both': test1_nobn_bilin_both}[argv[1]]
+    fn(argv[2])
+
+
+if __name__ == '__main__':
+    main(sys.argv)

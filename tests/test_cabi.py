@@ -1,0 +1,57 @@
+"""The C-ABI library loads and exports exactly what include/ghm.h declares (no compute calls: no GPU here)."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ghm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ghm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from gan_heightmaps_amd import _lib
+    assert sorted(_lib.all_export_names()) == declared_symbols()
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    # in a fresh interpreter without torch (torch wheels bundle their own HIP runtime)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from gan_heightmaps_amd import _lib\n"
+            "lib = _lib.load()\n"
+            "missing = [n for n in %r if not hasattr(lib, n)]\n"
+            "assert not missing, missing\n"
+            "import ctypes as C\n"
+            "n = C.c_int32(-1); assert lib.ghm_device_count(C.byref(n)) == 0 and n.value >= 0\n"
+            "assert lib.ghm_bn_workspace(8) > 0\n"
+            "print('ok', n.value)\n") % (ROOT, declared_symbols())
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.startswith("ok")
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from gan_heightmaps_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    import pytest
+    with pytest.raises(_lib.GhmError):
+        _lib.load()
+
+
+def test_conv_variant_and_workspace_queries_are_host_only():
+    from gan_heightmaps_amd import device as D
+    import ctypes as C
+    from gan_heightmaps_amd._lib import call
+    d = D.conv_desc(8, 64, 256, 256, 128, 5, 5, 1, 2)
+    out = C.create_string_buffer(128)
+    for kind, want in [(0, "igemm_kernel<128,128,fwd>"), (1, "igemm_kernel<64,256,wt>"), (2, "wgrad_kernel<128,128>")]:
+        call("ghm_conv2d_variant", C.byref(d), kind, out, 128)
+        assert out.value.decode().startswith(want), out.value
+    n = C.c_size_t()
+    call("ghm_conv2d_wgrad_workspace", C.byref(d), C.byref(n))
+    assert n.value >= 64 * 25 * 128 * 4

@@ -331,3 +331,30 @@ def test_rccl_single_rank_allreduce(gpu):
     dev.sync()
     assert np.array_equal(xd.numpy().ravel(), x)
     call("ghm_comm_destroy", dev.h)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 8, 8, 96, 3, 1, 1), (4, 256, 4, 4, 128, 5, 1, 2), (2, 48, 9, 9, 40, 3, 2, 1)])
+@pytest.mark.parametrize("splits", ["3", "1000"])
+def test_conv_split_k(gpu, case, splits):
+    """few output tiles + long reduction: K is split across blocks, partials reduced with bias/act/accumulate"""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(42)
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    y_ref = O.conv2d_fwd(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), s, pad)
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    dx_ref, _, _ = O.conv2d_vjp(x.astype(np.float64), Wt.astype(np.float64), dy.astype(np.float64), s, pad)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    xd, wd, bd = dev.tensor(x), dev.tensor(D.pack_conv_w(Wt).reshape(1, -1, 1, 1)), dev.tensor(b)
+    yd, dyd, dxd = dev.empty(y_ref.shape), dev.tensor(dy), dev.zeros(x.shape)
+    os.environ["GHM_FORCE_SPLITK"] = splits
+    try:
+        ops.conv2d_fwd(d, xd, wd, bd, yd, act='lrelu', alpha=0.01)
+        assert rel(yd.numpy(), O.lrelu_fwd(y_ref, 0.01)) < TOL
+        ops.conv2d_dgrad(d, dyd, wd, dxd)
+        ops.conv2d_dgrad(d, dyd, wd, dxd, accumulate=True)
+        assert rel(dxd.numpy(), 2 * dx_ref) < TOL
+    finally:
+        os.environ.pop("GHM_FORCE_SPLITK")
