@@ -46,6 +46,7 @@ struct IgemmArgs {
     int accumulate;
     float* partial;        // split-K: raw accumulators go to partial[split][r][p] (no bias / act)
     int slabs_per_split;   // K slabs per blockIdx.y slice
+    int debug;             // tuning only (GHM_ABLATE): 1 = skip global loads, 2 = also skip LDS stores
     int di[MAX_TAPS], dj[MAX_TAPS], wi[MAX_TAPS];
 };
 
@@ -58,7 +59,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
 }
 
 template <int BM, int BN, int WM, int WN, bool WT, bool FASTK>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 4 : 2) void igemm_kernel(const IgemmArgs a) {
     constexpr int BK = 16;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -100,61 +101,60 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     }
     const int a_c4 = tid % AV, a_row0 = tid / AV;    // forward-form weight loader
     const int a_k = tid & 15, a_r0 = tid >> 4;       // WT-form weight loader
-    const bool rvec = (a.R & 3) == 0;
 
     float breg[BLOADS];
     float4 areg4[WT ? 1 : APASS];
     float aregs[WT ? AT : 1];
+    unsigned bmask = 0, amask = 0;      // validity bits of the prefetched slab, applied when it is stored to LDS
 
+    // Loads are branch-free: an out-of-range element reads a clamped (valid) address and is zeroed by a
+    // select, so every load of a slab is issued back to back and waited for once, after the MFMAs.
     auto load_slab = [&](int s) {
         const int kk0 = s * BK;
-        if constexpr (FASTK) {
+        if constexpr (FASTK) {                       // CH % 16 == 0 (one tap per slab) and, forward form, R % 4 == 0
             const int ti = kk0 / a.CH;               // uniform
             const int ch0 = kk0 - ti * a.CH;
             const int y = sy0 + a.di[ti], x = sx0 + a.dj[ti];
             const bool ok = pvalid && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
-            const float* src = inb + (long)(ch0 + b_row0) * HinWin + (y * a.Win + x);
+            const float* src = inb + (ok ? (long)(ch0 + b_row0) * HinWin + (y * a.Win + x) : 0L);
+            const long cstep = ok ? (long)BROWS * HinWin : 0L;
 #pragma unroll
-            for (int j = 0; j < BLOADS; ++j) breg[j] = ok ? src[(long)j * BROWS * HinWin] : 0.f;
+            for (int j = 0; j < BLOADS; ++j) breg[j] = src[j * cstep];
+            bmask = ok ? 0xffffffffu : 0u;
+            amask = 0;
             const int tapw = a.wi[ti];
             if constexpr (!WT) {
 #pragma unroll
                 for (int j = 0; j < APASS; ++j) {
                     const int krow = a_row0 + j * AROWS;
                     const int r = r0 + a_c4 * 4;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (krow < BK) {
-                        const float* wrow = a.wp + ((long)(ch0 + krow) * a.T + tapw) * a.R;
-                        if (rvec) {
-                            if (r < a.R) v = *reinterpret_cast<const float4*>(wrow + r);
-                        } else {
-                            if (r + 0 < a.R) v.x = wrow[r + 0];
-                            if (r + 1 < a.R) v.y = wrow[r + 1];
-                            if (r + 2 < a.R) v.z = wrow[r + 2];
-                            if (r + 3 < a.R) v.w = wrow[r + 3];
-                        }
-                    }
-                    areg4[j] = v;
+                    const bool av = krow < BK && r < a.R;
+                    const float* wrow = a.wp + ((long)(ch0 + (av ? krow : 0)) * a.T + tapw) * a.R + (av ? r : 0);
+                    areg4[j] = *reinterpret_cast<const float4*>(wrow);
+                    amask |= (av ? 1u : 0u) << j;
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < AT; ++j) {
                     const int r = r0 + a_r0 + j * 16;
-                    aregs[j] = (r < a.R) ? a.wp[((long)r * a.T + tapw) * a.CH + ch0 + a_k] : 0.f;
+                    const bool av = r < a.R;
+                    aregs[j] = a.wp[((long)(av ? r : 0) * a.T + tapw) * a.CH + ch0 + a_k];
+                    amask |= (av ? 1u : 0u) << j;
                 }
             }
         } else {
+            bmask = 0;
+            amask = 0;
 #pragma unroll
             for (int j = 0; j < BLOADS; ++j) {
                 const int kk = kk0 + b_row0 + j * BROWS;
-                float v = 0.f;
-                if (kk < Ktot) {
-                    const int ti = kk / a.CH, ch = kk - ti * a.CH;
-                    const int y = sy0 + a.di[ti], x = sx0 + a.dj[ti];
-                    if (pvalid && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win)
-                        v = inb[(long)ch * HinWin + (y * a.Win + x)];
-                }
-                breg[j] = v;
+                const bool kv = kk < Ktot;
+                const int kc = kv ? kk : 0;
+                const int ti = kc / a.CH, ch = kc - ti * a.CH;
+                const int y = sy0 + a.di[ti], x = sx0 + a.dj[ti];
+                const bool ok = kv && pvalid && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
+                breg[j] = inb[ok ? (long)ch * HinWin + (y * a.Win + x) : 0L];
+                bmask |= (ok ? 1u : 0u) << j;
             }
             if constexpr (!WT) {
 #pragma unroll
@@ -162,26 +162,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
                     const int krow = a_row0 + j * AROWS;
                     const int kk = kk0 + krow;
                     const int r = r0 + a_c4 * 4;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (krow < BK && kk < Ktot) {
-                        const int ti = kk / a.CH, ch = kk - ti * a.CH;
-                        const float* wrow = a.wp + ((long)ch * a.T + a.wi[ti]) * a.R;
-                        if (r + 0 < a.R) v.x = wrow[r + 0];
-                        if (r + 1 < a.R) v.y = wrow[r + 1];
-                        if (r + 2 < a.R) v.z = wrow[r + 2];
-                        if (r + 3 < a.R) v.w = wrow[r + 3];
-                    }
+                    const bool kv = krow < BK && kk < Ktot;
+                    const int kc = kv ? kk : 0;
+                    const int ti = kc / a.CH, ch = kc - ti * a.CH;
+                    const float* wrow = a.wp + ((long)ch * a.T + a.wi[ti]) * a.R;
+                    float4 v;
+                    v.x = wrow[(kv && r + 0 < a.R) ? r + 0 : 0];
+                    v.y = wrow[(kv && r + 1 < a.R) ? r + 1 : 0];
+                    v.z = wrow[(kv && r + 2 < a.R) ? r + 2 : 0];
+                    v.w = wrow[(kv && r + 3 < a.R) ? r + 3 : 0];
                     areg4[j] = v;
+                    amask |= ((kv && r + 0 < a.R) ? 1u : 0u) << (4 * j + 0);
+                    amask |= ((kv && r + 1 < a.R) ? 1u : 0u) << (4 * j + 1);
+                    amask |= ((kv && r + 2 < a.R) ? 1u : 0u) << (4 * j + 2);
+                    amask |= ((kv && r + 3 < a.R) ? 1u : 0u) << (4 * j + 3);
                 }
             } else {
                 const int kk = kk0 + a_k;
                 const bool kv = kk < Ktot;
-                const int ti = kv ? kk / a.CH : 0, ch = kv ? kk - ti * a.CH : 0;
+                const int kc = kv ? kk : 0;
+                const int ti = kc / a.CH, ch = kc - ti * a.CH;
                 const int tapw = a.wi[ti];
 #pragma unroll
                 for (int j = 0; j < AT; ++j) {
                     const int r = r0 + a_r0 + j * 16;
-                    aregs[j] = (kv && r < a.R) ? a.wp[((long)r * a.T + tapw) * a.CH + ch] : 0.f;
+                    const bool av = kv && r < a.R;
+                    aregs[j] = a.wp[((long)(av ? r : 0) * a.T + tapw) * a.CH + ch];
+                    amask |= (av ? 1u : 0u) << j;
                 }
             }
         }
@@ -191,16 +198,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         float* Ab = As + buf * BK * LDA;
         float* Bb = Bs + buf * BK * LDB;
 #pragma unroll
-        for (int j = 0; j < BLOADS; ++j) Bb[(b_row0 + j * BROWS) * LDB + b_pix] = breg[j];
+        for (int j = 0; j < BLOADS; ++j)
+            Bb[(b_row0 + j * BROWS) * LDB + b_pix] = ((bmask >> j) & 1u) ? breg[j] : 0.f;
         if constexpr (!WT) {
 #pragma unroll
             for (int j = 0; j < APASS; ++j) {
                 const int krow = a_row0 + j * AROWS;
-                if (krow < BK) *reinterpret_cast<float4*>(Ab + krow * LDA + a_c4 * 4) = areg4[j];
+                float4 v = areg4[j];
+                if constexpr (FASTK) {
+                    if (!((amask >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    if (!((amask >> (4 * j + 0)) & 1u)) v.x = 0.f;
+                    if (!((amask >> (4 * j + 1)) & 1u)) v.y = 0.f;
+                    if (!((amask >> (4 * j + 2)) & 1u)) v.z = 0.f;
+                    if (!((amask >> (4 * j + 3)) & 1u)) v.w = 0.f;
+                }
+                if (krow < BK) *reinterpret_cast<float4*>(Ab + krow * LDA + a_c4 * 4) = v;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < AT; ++j) Ab[a_k * LDA + a_r0 + j * 16] = aregs[j];
+            for (int j = 0; j < AT; ++j) Ab[a_k * LDA + a_r0 + j * 16] = ((amask >> j) & 1u) ? aregs[j] : 0.f;
         }
     };
 
@@ -222,23 +239,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
         const bool more = (s + 1) < s_end;
-        if (more) load_slab(s + 1);
+        if (more && a.debug < 1) load_slab(s + 1);   // global loads of the next slab fly under the MFMAs
         const float* Ab = As + buf * BK * LDA + wm * (BM / WM) + frag_i;
         const float* Bb = Bs + buf * BK * LDB + wn * (BN / WN) + frag_i;
+        float af[2][TM], bf[2][TN];                  // fragment double buffer: LDS latency hides under MFMAs
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = Ab[frag_k * LDA + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = Bb[frag_k * LDB + j * 32];
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
-            float af[TM], bf[TN];
+            if (ks + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = Ab[(ks * 2 + frag_k) * LDA + i * 32];
+                for (int i = 0; i < TM; ++i) af[(ks + 1) & 1][i] = Ab[((ks + 1) * 2 + frag_k) * LDA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bb[(ks * 2 + frag_k) * LDB + j * 32];
+                for (int j = 0; j < TN; ++j) bf[(ks + 1) & 1][j] = Bb[((ks + 1) * 2 + frag_k) * LDB + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+            // the next slab goes to the OTHER LDS buffer half-way through, so its ds_writes (and the wait for
+            // the global loads) sit between MFMAs instead of in front of the barrier
+            if (ks == BK / 4 - 1 && more && a.debug < 2) store_slab(buf ^ 1);
         }
-        if (more) store_slab(buf ^ 1);
         __syncthreads();
     }
 
@@ -416,7 +441,7 @@ struct WgradArgs {
 };
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 2) void wgrad_kernel(const WgradArgs a) {
     constexpr int BKP = 32;
     constexpr int LDA = BM + 1, LDB = BN + 1;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -453,7 +478,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int s_end = min(s_begin + a.slabs_per_split, total_slabs);
 
     float areg[AL], breg[BL];
+    unsigned amask = 0, bmask = 0;
     auto load_slab = [&](int s) {
+        amask = 0;
+        bmask = 0;
         const int p = s * BKP + lp;
         const bool pv = p < a.P;
         const int pp = pv ? p : 0;
@@ -468,21 +496,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             const int off = rowoff[row], dij = rowdij[row];
             const int y = sy + (dij >> 16), x = sx + (int)(short)(dij & 0xffff);
             const bool ok = pv && off >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            areg[q] = ok ? xb[off + y * a.W + x] : 0.f;
+            areg[q] = xb[ok ? off + y * a.W + x : 0];
+            amask |= (ok ? 1u : 0u) << q;
         }
 #pragma unroll
         for (int q = 0; q < BL; ++q) {
             const int co = n0 + lg + q * 8;
-            breg[q] = (pv && co < a.K) ? yb[(long)co * HoWo] : 0.f;
+            const bool ok = pv && co < a.K;
+            breg[q] = yb[ok ? (long)co * HoWo : 0L];
+            bmask |= (ok ? 1u : 0u) << q;
         }
     };
     auto store_slab = [&]() {
         float* Ab = As + lp * LDA;
         float* Bb = Bs + lp * LDB;
 #pragma unroll
-        for (int q = 0; q < AL; ++q) Ab[lg + q * 8] = areg[q];
+        for (int q = 0; q < AL; ++q) Ab[lg + q * 8] = ((amask >> q) & 1u) ? areg[q] : 0.f;
 #pragma unroll
-        for (int q = 0; q < BL; ++q) Bb[lg + q * 8] = breg[q];
+        for (int q = 0; q < BL; ++q) Bb[lg + q * 8] = ((bmask >> q) & 1u) ? breg[q] : 0.f;
     };
 
     f32x16 acc[TM][TN];
@@ -583,6 +614,67 @@ __global__ void channel_sum_final(const float* __restrict__ part, int C, int S, 
     out[c] = (accumulate ? out[c] : 0.f) + s;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// "taps as GEMM rows" path for stride-1 convolutions with <= 4 channels on one side and many pixels
+// (g_out forward / weight gradient, data gradient of the 1-channel first layer).  A k x k convolution with
+// R output channels is a 1x1 convolution with R*k*k outputs (MFMA, rows = (tap, r)) followed by a
+// shift-and-add of the k*k planes; the weight gradient is the transposed construction (shift-expand the
+// output gradient into k*k planes, then a 1x1 weight-gradient GEMM).  The packed layout wp[c][tap][r]
+// already is the [C][taps*R] matrix these GEMMs need.
+// ------------------------------------------------------------------------------------------------
+struct ShiftArgs {
+    const float* src;      // planes [N, M*T, H, W]   (plane index = outer*T*inner ... see kernels)
+    float* dst;
+    const float* bias;
+    int N, R, T, H, W;     // R channels, T taps, plane size H x W
+    long dst_nstride;
+    int act;
+    float alpha;
+    int accumulate;
+    int tap_major;         // 1: plane = tap*R + r (forward)   0: plane = r*T + tap (data gradient)
+    int sign;              // +1: read at p + d (forward)      -1: read at p - d (data gradient)
+    int di[MAX_TAPS], dj[MAX_TAPS];
+};
+
+__global__ __launch_bounds__(256) void shift_add_kernel(const ShiftArgs a) {
+    const long hw = (long)a.H * a.W;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)a.N * a.R * hw) return;
+    const long nr = idx / hw;
+    const int rem = (int)(idx - nr * hw), y = rem / a.W, x = rem - y * a.W;
+    const int n = (int)(nr / a.R), r = (int)(nr - (long)n * a.R);
+    const float* sb = a.src + (long)n * a.R * a.T * hw;
+    float v = a.bias ? a.bias[r] : 0.f;
+    for (int t = 0; t < a.T; ++t) {
+        const int yy = y + a.sign * a.di[t], xx = x + a.sign * a.dj[t];
+        if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) {
+            const int plane = a.tap_major ? t * a.R + r : r * a.T + t;
+            v += sb[(long)plane * hw + (long)yy * a.W + xx];
+        }
+    }
+    float* o = a.dst + (long)n * a.dst_nstride + (long)r * hw + rem;
+    if (a.accumulate) v += *o;
+    *o = ghm_act(v, a.act, a.alpha);
+}
+
+// E[n, tap*K + k, p'] = dy[n, k, p' - d_tap]  (zero outside)
+__global__ __launch_bounds__(256) void shift_expand_kernel(const float* __restrict__ dy, long dy_nstride, float* __restrict__ E,
+                                                           int N, int K, int T, int H, int W, ShiftArgs taps) {
+    const long hw = (long)H * W;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)N * T * K * hw) return;
+    const long plane = idx / hw;
+    const int rem = (int)(idx - plane * hw), y = rem / W, x = rem - y * W;
+    const int n = (int)(plane / (T * K)), tk = (int)(plane - (long)n * T * K);
+    const int t = tk / K, k = tk - t * K;
+    const int yy = y - taps.di[t], xx = x - taps.dj[t];
+    float v = 0.f;
+    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+        v = dy[(long)n * dy_nstride + (long)k * hw + (long)yy * W + xx];
+    E[idx] = v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side: variant choice and launch
 // ------------------------------------------------------------------------------------------------
@@ -598,9 +690,9 @@ Variant pick_variant(int R, long P, int num_cu) {
     if (bm == 128) { big = 128; small = 64; }
     else if (bm == 64) { big = 256; small = 64; }
     else { big = 256; small = 128; }
-    const long ntr = (R + bm - 1) / bm;
-    const long blocks_big = ntr * ((P + big - 1) / big);
-    int bn = (blocks_big >= 2L * num_cu) ? big : small;
+    // the wide pixel tile is the efficient one (measured: 128x128 + split-K beats 128x64 whenever the layer has
+    // at least one full wide tile); the narrow tile only serves the 1x1 .. 8x8 maps
+    int bn = (P >= big) ? big : small;
     if (const char* f = getenv("GHM_FORCE_TILE")) {     // test knob: exercise both pixel-tile widths
         if (f[0] == 'b') bn = big;
         if (f[0] == 's') bn = small;
@@ -615,6 +707,7 @@ int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
     if (P == 0 || a.R == 0) return 0;
     a.partial = nullptr;
     a.slabs_per_split = 1 << 30;
+    if (const char* f = getenv("GHM_ABLATE")) a.debug = atoi(f);
     if (a.R <= 4) {
         if (P <= 16384 && (long)a.ntaps * a.CH >= 256) {
             hipLaunchKernelGGL((direct_smallr_wave_kernel<WT>), dim3(ceil_div(P, 4)), dim3(256), 0, ctx->stream, a);
@@ -625,13 +718,13 @@ int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
         return 0;
     }
     const Variant v = pick_variant(a.R, P, ctx->num_cu);
-    const bool fast = (a.CH % 16) == 0;
+    const bool fast = (a.CH % 16) == 0 && (WT || (a.R % 4) == 0);
     const int grid = ceil_div(a.R, v.bm) * ceil_div(P, v.bn);
     // split-K over the (tap, channel) slabs when the output tiles alone cannot fill the chip
     const int nslabs = ceil_div((long)a.ntaps * a.CH, 16);
     int splits = 1;
-    if (grid < ctx->num_cu) {
-        splits = (2 * ctx->num_cu + grid - 1) / grid;
+    if (grid < ctx->num_cu + ctx->num_cu / 2) {
+        splits = (4 * ctx->num_cu + grid - 1) / grid;                // aim at ~4 resident blocks per CU
         const int max_by_work = nslabs / 8 > 0 ? nslabs / 8 : 1;     // keep >= 8 slabs (128 k) per slice
         if (splits > max_by_work) splits = max_by_work;
     }
@@ -667,6 +760,33 @@ int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
 #undef GHM_IGEMM_CASE
     ghm_set_error("no igemm variant for bm=%d bn=%d", v.bm, v.bn);
     return -3;
+}
+
+
+// does this geometry take the taps-as-rows path?  (stride 1, 'same'-style geometry, many pixels)
+bool taps_as_rows(const ghm_conv_desc* d, int small_side) {
+    return small_side <= 4 && d->stride == 1 && d->Ho == d->H && d->Wo == d->W && d->kh * d->kw > 1 &&
+           (long)d->N * d->H * d->W >= 32768 && getenv("GHM_NO_TAPROWS") == nullptr;
+}
+
+void fill_taps(const ghm_conv_desc* d, ShiftArgs& sa) {
+    for (int ta = 0; ta < d->kh; ++ta)
+        for (int tb = 0; tb < d->kw; ++tb) {
+            sa.di[ta * d->kw + tb] = ta - d->pad;
+            sa.dj[ta * d->kw + tb] = tb - d->pad;
+        }
+}
+
+IgemmArgs pointwise_args(const float* in, long in_nstride, int N, int CH, int H, int W, const float* wp, int R,
+                         float* out) {
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.wp = wp; a.bias = nullptr; a.out = out;
+    a.N = N; a.CH = CH; a.Hin = H; a.Win = W; a.in_nstride = in_nstride;
+    a.R = R; a.Hout = H; a.Wout = W; a.out_nstride = (long)R * H * W;
+    a.Hs = H; a.Ws = W; a.os = 1; a.ss = 1; a.T = 1; a.ntaps = 1;
+    a.act = GHM_ACT_LINEAR;
+    return a;
 }
 
 int check_desc(const ghm_conv_desc* d) {
@@ -712,6 +832,25 @@ int ghm_conv2d_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const f
                    float* y, int32_t act, float alpha, int32_t accumulate) {
     if (int e = check_desc(d)) return e;
     GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    if (taps_as_rows(d, d->K)) {
+        const int T = d->kh * d->kw;
+        void* ws = nullptr;
+        const size_t tb = (size_t)d->N * T * d->K * d->H * d->W * sizeof(float);
+        if (int e = ghm_scratch(ctx, tb + (64u << 20), &ws)) return e;     // + room for split-K partials
+        float* Tbuf = (float*)((char*)ws + (64u << 20));
+        IgemmArgs g = pointwise_args(x, d->x_nstride, d->N, d->C, d->H, d->W, wp, T * d->K, Tbuf);
+        if (int e = launch_igemm<false>(ctx, g)) return e;
+        ShiftArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.src = Tbuf; sa.dst = y; sa.bias = bias; sa.N = d->N; sa.R = d->K; sa.T = T; sa.H = d->H; sa.W = d->W;
+        sa.dst_nstride = d->y_nstride; sa.act = act; sa.alpha = alpha; sa.accumulate = accumulate;
+        sa.tap_major = 1; sa.sign = 1;
+        fill_taps(d, sa);
+        hipLaunchKernelGGL(shift_add_kernel, dim3(ceil_div((long)d->N * d->K * d->H * d->W, 256)), dim3(256), 0,
+                           ctx->stream, sa);
+        GHM_LAUNCH_CHECK();
+        return 0;
+    }
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
     a.in = x; a.wp = wp; a.bias = bias; a.out = y;
@@ -732,6 +871,26 @@ int ghm_conv2d_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, cons
                      float* dx, int32_t act, float alpha, int32_t accumulate) {
     if (int e = check_desc(d)) return e;
     GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    if (taps_as_rows(d, d->C)) {
+        const int T = d->kh * d->kw;
+        void* ws = nullptr;
+        const size_t tb = (size_t)d->N * T * d->C * d->H * d->W * sizeof(float);
+        if (int e = ghm_scratch(ctx, tb + (64u << 20), &ws)) return e;
+        float* Tbuf = (float*)((char*)ws + (64u << 20));
+        // rows m = c*T + tap, reduce over the conv's filters: wp viewed as [m][K] is the WT-form layout with T=1
+        IgemmArgs g = pointwise_args(dy, d->y_nstride, d->N, d->K, d->H, d->W, wp, T * d->C, Tbuf);
+        if (int e = launch_igemm<true>(ctx, g)) return e;
+        ShiftArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.src = Tbuf; sa.dst = dx; sa.bias = bias; sa.N = d->N; sa.R = d->C; sa.T = T; sa.H = d->H; sa.W = d->W;
+        sa.dst_nstride = d->x_nstride; sa.act = act; sa.alpha = alpha; sa.accumulate = accumulate;
+        sa.tap_major = 0; sa.sign = -1;
+        fill_taps(d, sa);
+        hipLaunchKernelGGL(shift_add_kernel, dim3(ceil_div((long)d->N * d->C * d->H * d->W, 256)), dim3(256), 0,
+                           ctx->stream, sa);
+        GHM_LAUNCH_CHECK();
+        return 0;
+    }
     const int s = d->stride;
     for (int pu = 0; pu < s; ++pu) {
         for (int pv = 0; pv < s; ++pv) {
@@ -771,9 +930,8 @@ int ghm_conv2d_wgrad_workspace(const ghm_conv_desc* d, size_t* bytes) {
     return 0;
 }
 
-int ghm_conv2d_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* dy, float* dwp,
-                     void* workspace, int32_t accumulate) {
-    if (int e = check_desc(d)) return e;
+static int wgrad_impl(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* dy, float* dwp,
+                      void* workspace, int32_t accumulate) {
     const WVariant v = pick_wgrad(d, 256);
     WgradArgs a;
     memset(&a, 0, sizeof(a));
@@ -813,6 +971,34 @@ int ghm_conv2d_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const
     return 0;
 }
 
+int ghm_conv2d_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* dy, float* dwp,
+                     void* workspace, int32_t accumulate) {
+    if (int e = check_desc(d)) return e;
+    if (taps_as_rows(d, d->K)) {
+        // shift-expand dy into T*K planes over the input grid, then a 1x1 weight-gradient GEMM whose "filters"
+        // are (tap, k): its packed output [c][1][tap*K + k] IS dwp[c][tap][k]
+        const int T = d->kh * d->kw;
+        void* ws = nullptr;
+        const size_t eb = (size_t)d->N * T * d->K * d->H * d->W * sizeof(float);
+        if (int e = ghm_scratch(ctx, eb + (64u << 20), &ws)) return e;
+        float* E = (float*)((char*)ws + (64u << 20));
+        ShiftArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        fill_taps(d, sa);
+        hipLaunchKernelGGL(shift_expand_kernel, dim3(ceil_div((long)d->N * T * d->K * d->H * d->W, 256)), dim3(256), 0,
+                           ctx->stream, dy, (long)d->y_nstride, E, d->N, d->K, T, d->H, d->W, sa);
+        GHM_LAUNCH_CHECK();
+        ghm_conv_desc d2 = *d;
+        d2.K = T * d->K; d2.Ho = d->H; d2.Wo = d->W; d2.kh = d2.kw = 1; d2.stride = 1; d2.pad = 0;
+        d2.y_nstride = (int64_t)d2.K * d->H * d->W;
+        size_t need = 0;
+        ghm_conv2d_wgrad_workspace(&d2, &need);
+        GHM_CHECK(need <= (64u << 20), "taps-as-rows weight gradient needs %zu bytes of partials", need);
+        return wgrad_impl(ctx, &d2, x, E, dwp, ws, accumulate);
+    }
+    return wgrad_impl(ctx, d, x, dy, dwp, workspace, accumulate);
+}
+
 int ghm_channel_sum(ghm_ctx* ctx, const float* x, int32_t N, int32_t C, int32_t HW, int64_t nstride, float* out,
                     int32_t accumulate) {
     if (C == 0) return 0;
@@ -834,6 +1020,10 @@ int ghm_channel_sum(ghm_ctx* ctx, const float* x, int32_t N, int32_t C, int32_t 
 }
 
 int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t out_len) {
+    if (taps_as_rows(d, kind == 1 ? d->C : d->K)) {
+        snprintf(out, out_len, "taps_as_rows<%s>", kind == 0 ? "fwd" : (kind == 1 ? "dgrad" : "wgrad"));
+        return 0;
+    }
     if (kind == 2) {
         const WVariant v = pick_wgrad(d, 256);
         snprintf(out, out_len, "wgrad_kernel<%d,%d> splits=%d", v.bm, v.bn, v.splits);

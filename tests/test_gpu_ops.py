@@ -358,3 +358,40 @@ def test_conv_split_k(gpu, case, splits):
         assert rel(dxd.numpy(), 2 * dx_ref) < TOL
     finally:
         os.environ.pop("GHM_FORCE_SPLITK")
+
+
+@pytest.mark.parametrize("case", [(2, 16, 128, 128, 1, 5, 1, 2), (1, 8, 192, 192, 3, 3, 1, 1)])
+def test_taps_as_rows_path(gpu, case):
+    """stride-1 convs with <=4 channels on one side and many pixels (g_out, d_conv1 dgrad): 1x1 MFMA GEMM with
+    (tap, r) rows + shift-add; must agree with the oracle AND with the direct kernels it replaces"""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(17)
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    assert ops.conv_variant(d, 0).startswith("taps_as_rows") and ops.conv_variant(d, 2).startswith("taps_as_rows")
+    y_ref = O.conv2d_fwd(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), s, pad)
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    dx_ref, dW_ref, _ = O.conv2d_vjp(x.astype(np.float64), Wt.astype(np.float64), dy.astype(np.float64), s, pad)
+    xd, wd, bd = dev.tensor(x), dev.tensor(D.pack_conv_w(Wt).ravel()), dev.tensor(b)
+    yd = dev.empty(y_ref.shape)
+    ops.conv2d_fwd(d, xd, wd, bd, yd, act='sigmoid')
+    assert rel(yd.numpy(), O.sigmoid_fwd(y_ref)) < TOL
+    dyd = dev.tensor(dy)
+    dwd = dev.zeros((1, C * k * k * K, 1, 1))
+    ops.conv2d_wgrad(d, xd, dyd, dwd, dev.alloc(ops.wgrad_workspace(d)))
+    assert rel(D.unpack_conv_w(dwd.numpy().ravel(), K, C, k, k), dW_ref) < TOL
+    # the transposed role: a conv with few INPUT channels, data gradient
+    d2 = D.conv_desc(N, K, H, W, C, k, k, s, pad)
+    assert ops.conv_variant(d2, 1).startswith("taps_as_rows")
+    W2 = (rng.randn(C, K, k, k) / np.sqrt(K * k * k)).astype(np.float32)
+    g2 = rng.randn(N, C, H, W).astype(np.float32)
+    x2 = rng.randn(N, K, H, W).astype(np.float32)
+    dx2_ref, _, _ = O.conv2d_vjp(x2.astype(np.float64), W2.astype(np.float64), g2.astype(np.float64), s, pad)
+    dx2 = dev.zeros((N, K, H, W))
+    ops.conv2d_dgrad(d2, dev.tensor(g2), dev.tensor(D.pack_conv_w(W2).ravel()), dx2)
+    assert rel(dx2.numpy(), dx2_ref) < TOL
+    ops.conv2d_dgrad(d2, dev.tensor(g2), dev.tensor(D.pack_conv_w(W2).ravel()), dx2, accumulate=True)
+    assert rel(dx2.numpy(), 2 * dx2_ref) < TOL

@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Micro-benchmark of one convolution geometry through the C ABI (fwd / dgrad / wgrad), HIP-event timed.
+    python tools/conv_bench.py N C H W K k stride pad [--reps R] [--kinds fwd,dgrad,wgrad]
+Used for kernel tuning and for rocprofv3 --pmc runs on a single layer."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gan_heightmaps_amd import device as D  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("geom", type=int, nargs=8, help="N C H W K k stride pad")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    args = ap.parse_args()
+    N, C, H, W, K, k, s, pad = args.geom
+    dev = D.Device(0)
+    ops = D.Ops(dev)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    rng = np.random.RandomState(0)
+    x = dev.tensor(rng.randn(N, C, H, W).astype(np.float32))
+    y = dev.tensor(rng.randn(N, K, d.Ho, d.Wo).astype(np.float32))
+    w = dev.tensor((rng.randn(C * k * k * K) * 0.05).astype(np.float32))
+    b = dev.tensor(rng.randn(K).astype(np.float32))
+    dx = dev.empty((N, C, H, W))
+    dw = dev.zeros((1, C * k * k * K, 1, 1))
+    ws = dev.alloc(ops.wgrad_workspace(d))
+    flops = 2.0 * N * K * d.Ho * d.Wo * C * k * k
+    fns = {"fwd": lambda: ops.conv2d_fwd(d, x, w, b, y, 'lrelu', 0.2),
+           "dgrad": lambda: ops.conv2d_dgrad(d, y, w, dx),
+           "wgrad": lambda: ops.conv2d_wgrad(d, x, y, dw, ws)}
+    for i, kind in enumerate(args.kinds.split(",")):
+        fn = fns[kind]
+        for _ in range(3):
+            fn()
+        dev.sync()
+        dev.timer_start(0)
+        for _ in range(args.reps):
+            fn()
+        dev.timer_stop(0)
+        ms = dev.timer_ms(0) / args.reps
+        print("%-6s %-34s %8.3f ms  %7.1f TFLOP/s  (%.1f GFLOP)" %
+              (kind, ops.conv_variant(d, ["fwd", "dgrad", "wgrad"].index(kind)), ms, flops / ms / 1e9, flops / 1e9))
+    dev.close()
+
+
+if __name__ == "__main__":
+    main()
