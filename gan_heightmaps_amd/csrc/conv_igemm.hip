@@ -59,7 +59,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
 }
 
 template <int BM, int BN, int WM, int WN, bool WT, bool FASTK>
-__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 4 : 2) void igemm_kernel(const IgemmArgs a) {
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? (WT ? 3 : 4) : 2) void igemm_kernel(const IgemmArgs a) {
     constexpr int BK = 16;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -363,8 +363,18 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs a, 
     if (idx >= P * a.R) return;
     const int r = (int)(idx / P);
     const long p = idx - (long)r * P;
-    float v = 0.f;
-    for (int k = 0; k < S; ++k) v += a.partial[((long)k * a.R + r) * P + p];
+    const float* pp = a.partial + (long)r * P + p;
+    const long sstride = (long)a.R * P;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int k = 0;
+    for (; k + 3 < S; k += 4) {
+        v0 += pp[(long)(k + 0) * sstride];
+        v1 += pp[(long)(k + 1) * sstride];
+        v2 += pp[(long)(k + 2) * sstride];
+        v3 += pp[(long)(k + 3) * sstride];
+    }
+    for (; k < S; ++k) v0 += pp[(long)k * sstride];
+    float v = (v0 + v1) + (v2 + v3);
     const int n = (int)(p / hw_s), rem = (int)(p - (long)n * hw_s);
     const int uu = rem / a.Ws, vv = rem - uu * a.Ws;
     float* o = a.out + (long)n * a.out_nstride + (long)r * a.Hout * a.Wout +
@@ -569,14 +579,41 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 2) void wgrad_ker
     }
 }
 
-__global__ void reduce_splits_kernel(const float* __restrict__ part, int S, long n, long split_stride,
-                                     float* __restrict__ out, int accumulate) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// sum of S partial slices: 4 consecutive elements per thread (16-B loads), 4 slices in flight per thread
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ part, int S, long n, long split_stride,
+                                                            float* __restrict__ out, int accumulate) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += part[(long)k * split_stride + i];
-    if (accumulate) s += out[i];
-    out[i] = s;
+    if (i + 3 < n && (split_stride & 3) == 0) {
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+        int k = 0;
+        for (; k + 3 < S; k += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(part + (long)(k + 0) * split_stride + i);
+            const float4 b = *reinterpret_cast<const float4*>(part + (long)(k + 1) * split_stride + i);
+            const float4 c = *reinterpret_cast<const float4*>(part + (long)(k + 2) * split_stride + i);
+            const float4 d = *reinterpret_cast<const float4*>(part + (long)(k + 3) * split_stride + i);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+            s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+            s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+        }
+        for (; k < S; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(part + (long)k * split_stride + i);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+        float4 r = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y),
+                               (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+        float4* o = reinterpret_cast<float4*>(out + i);
+        if (accumulate) { const float4 t = *o; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+        *o = r;
+    } else {
+        for (long e = i; e < n && e < i + 4; ++e) {
+            float s = 0.f;
+            for (int k = 0; k < S; ++k) s += part[(long)k * split_stride + e];
+            if (accumulate) s += out[e];
+            out[e] = s;
+        }
+    }
 }
 
 // per-channel sum over (n, hw): bias gradients. grid (S, C) partials, then one thread per channel.
@@ -964,7 +1001,7 @@ static int wgrad_impl(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, cons
     }
 #undef GHM_WGRAD_CASE
     if (v.splits > 1) {
-        hipLaunchKernelGGL(reduce_splits_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3(ceil_div((n + 3) / 4, 256)), dim3(256), 0, ctx->stream,
                            (const float*)workspace, v.splits, n, n, dwp, accumulate);
         GHM_LAUNCH_CHECK();
     }
