@@ -445,21 +445,25 @@ struct WgradArgs {
     int kh, kw, stride, pad;
     int CT;               // C * kh * kw rows
     int P;                // N * Ho * Wo
-    int slabs_per_split;  // 32-pixel slabs per z-slice
+    int slabs_per_split;  // 16-pixel slabs per z-slice
     long split_stride;    // elements between partial slices (0 when writing dwp directly)
     int accumulate;
+    int debug;            // tuning only (GHM_ABLATE)
 };
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 2) void wgrad_kernel(const WgradArgs a) {
-    constexpr int BKP = 32;
-    constexpr int LDA = BM + 1, LDB = BN + 1;
+    // rows = (channel, tap) of the packed weight layout, columns = filters, K = output pixels in 16-pixel
+    // slabs; same pipeline as igemm_kernel: double-buffered LDS, register prefetch of the next slab, its LDS
+    // store half-way through the MFMAs, fragment double buffer, one barrier per slab.
+    constexpr int BKP = 16;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int AL = BM / 8, BL = BN / 8;
-    __shared__ __attribute__((aligned(16))) float smem[BKP * (LDA + LDB) + 2 * BM];   // single LDS stage,
-    float* As = smem;                                                               // next slab lives in registers
-    float* Bs = smem + BKP * LDA;
-    int* rowoff = reinterpret_cast<int*>(smem + BKP * (LDA + LDB));
+    constexpr int AL = BM / 16, BL = BN / 16;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BKP * (LDA + LDB) + 2 * BM];
+    float* As = smem;
+    float* Bs = smem + 2 * BKP * LDA;
+    int* rowoff = reinterpret_cast<int*>(smem + 2 * BKP * (LDA + LDB));
     int* rowdij = rowoff + BM;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -482,27 +486,34 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 2) void wgrad_ker
     }
     __syncthreads();
 
-    const int lp = tid & 31, lg = tid >> 5;
+    const int lp = tid & 15, lg = tid >> 4;
     const int total_slabs = (a.P + BKP - 1) / BKP;
     const int s_begin = blockIdx.z * a.slabs_per_split;
     const int s_end = min(s_begin + a.slabs_per_split, total_slabs);
 
+    // pixel cursor of the NEXT slab this thread loads: advanced by 16 pixels per slab without divisions
+    int pn, pi, pj;
+    long pcur = (long)s_begin * BKP + lp;
+    {
+        const long pp = pcur < a.P ? pcur : 0;
+        pn = (int)(pp / HoWo);
+        const int rem = (int)(pp - (long)pn * HoWo);
+        pi = rem / a.Wo;
+        pj = rem - pi * a.Wo;
+    }
+
     float areg[AL], breg[BL];
     unsigned amask = 0, bmask = 0;
-    auto load_slab = [&](int s) {
+    auto load_slab = [&]() {
         amask = 0;
         bmask = 0;
-        const int p = s * BKP + lp;
-        const bool pv = p < a.P;
-        const int pp = pv ? p : 0;
-        const int n = pp / HoWo, rem = pp - n * HoWo;
-        const int i = rem / a.Wo, j = rem - i * a.Wo;
-        const int sy = i * a.stride, sx = j * a.stride;
-        const float* xb = a.x + (long)n * a.x_nstride;
-        const float* yb = a.dy + (long)n * a.y_nstride + rem;
+        const bool pv = pcur < a.P;
+        const int sy = pi * a.stride, sx = pj * a.stride;
+        const float* xb = a.x + (long)pn * a.x_nstride;
+        const float* yb = a.dy + (long)pn * a.y_nstride + (pi * a.Wo + pj);
 #pragma unroll
         for (int q = 0; q < AL; ++q) {
-            const int row = lg + q * 8;
+            const int row = lg + q * 16;
             const int off = rowoff[row], dij = rowdij[row];
             const int y = sy + (dij >> 16), x = sx + (int)(short)(dij & 0xffff);
             const bool ok = pv && off >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
@@ -511,19 +522,30 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 2) void wgrad_ker
         }
 #pragma unroll
         for (int q = 0; q < BL; ++q) {
-            const int co = n0 + lg + q * 8;
+            const int co = n0 + lg + q * 16;
             const bool ok = pv && co < a.K;
             breg[q] = yb[ok ? (long)co * HoWo : 0L];
             bmask |= (ok ? 1u : 0u) << q;
         }
+        // advance the cursor by one slab
+        pcur += BKP;
+        pj += BKP;
+        while (pj >= a.Wo) {
+            pj -= a.Wo;
+            if (++pi >= a.Ho) {
+                pi = 0;
+                ++pn;
+            }
+        }
+        if (pcur >= a.P) { pn = 0; pi = 0; pj = 0; }
     };
-    auto store_slab = [&]() {
-        float* Ab = As + lp * LDA;
-        float* Bb = Bs + lp * LDB;
+    auto store_slab = [&](int buf) {
+        float* Ab = As + buf * BKP * LDA + lp * LDA;
+        float* Bb = Bs + buf * BKP * LDB + lp * LDB;
 #pragma unroll
-        for (int q = 0; q < AL; ++q) Ab[lg + q * 8] = ((amask >> q) & 1u) ? areg[q] : 0.f;
+        for (int q = 0; q < AL; ++q) Ab[lg + q * 16] = ((amask >> q) & 1u) ? areg[q] : 0.f;
 #pragma unroll
-        for (int q = 0; q < BL; ++q) Bb[lg + q * 8] = ((bmask >> q) & 1u) ? breg[q] : 0.f;
+        for (int q = 0; q < BL; ++q) Bb[lg + q * 16] = ((bmask >> q) & 1u) ? breg[q] : 0.f;
     };
 
     f32x16 acc[TM][TN];
@@ -535,25 +557,36 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 2) void wgrad_ker
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int frag_k = lane >> 5, frag_i = lane & 31;
-    if (s_begin < s_end) load_slab(s_begin);
+    if (s_begin < s_end) {
+        load_slab();
+        store_slab(0);
+    }
+    __syncthreads();
     for (int s = s_begin; s < s_end; ++s) {
-        store_slab();
-        __syncthreads();
-        if ((s + 1) < s_end) load_slab(s + 1);      // global loads fly under the MFMAs below
-        const float* Ab = As + wm * (BM / WM) + frag_i;
-        const float* Bb = Bs + wn * (BN / WN) + frag_i;
+        const int buf = (s - s_begin) & 1;
+        const bool more = (s + 1) < s_end;
+        if (more && a.debug < 1) load_slab();
+        const float* Ab = As + buf * BKP * LDA + wm * (BM / WM) + frag_i;
+        const float* Bb = Bs + buf * BKP * LDB + wn * (BN / WN) + frag_i;
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = Ab[frag_k * LDA + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = Bb[frag_k * LDB + j * 32];
 #pragma unroll
         for (int ks = 0; ks < BKP / 2; ++ks) {
-            float af[TM], bf[TN];
+            if (ks + 1 < BKP / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = Ab[(ks * 2 + frag_k) * LDA + i * 32];
+                for (int i = 0; i < TM; ++i) af[(ks + 1) & 1][i] = Ab[((ks + 1) * 2 + frag_k) * LDA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bb[(ks * 2 + frag_k) * LDB + j * 32];
+                for (int j = 0; j < TN; ++j) bf[(ks + 1) & 1][j] = Bb[((ks + 1) * 2 + frag_k) * LDB + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+            if (ks == BKP / 4 - 1 && more && a.debug < 2) store_slab(buf ^ 1);
         }
         __syncthreads();
     }
@@ -850,9 +883,9 @@ WVariant pick_wgrad(const ghm_conv_desc* d, int num_cu) {
     if (v.bm == 32) v.bn = 128;
     const long tiles = (long)ceil_div(CT, v.bm) * ceil_div(d->K, v.bn);
     const long P = (long)d->N * d->Ho * d->Wo;
-    const long slabs = (P + 31) / 32;
+    const long slabs = (P + 15) / 16;
     long want = (4L * num_cu + tiles - 1) / tiles;      // aim for ~4 blocks per CU
-    long max_by_work = slabs / 8 > 0 ? slabs / 8 : 1;   // at least 8 slabs per split
+    long max_by_work = slabs / 16 > 0 ? slabs / 16 : 1; // at least 16 slabs (256 pixels) per split
     long S = want < max_by_work ? want : max_by_work;
     if (S < 1) S = 1;
     if (S > 1024) S = 1024;
@@ -979,6 +1012,7 @@ static int wgrad_impl(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, cons
     a.CT = d->C * d->kh * d->kw;
     a.P = d->N * d->Ho * d->Wo;
     a.slabs_per_split = v.slabs_per_split;
+    if (const char* f = getenv("GHM_ABLATE")) a.debug = atoi(f);
     const long n = (long)a.CT * a.K;
     if (v.splits > 1) {
         GHM_CHECK(workspace != nullptr, "wgrad needs a workspace for %d splits", v.splits);
