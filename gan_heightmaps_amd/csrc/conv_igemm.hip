@@ -612,6 +612,193 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 2) void wgrad_ker
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient with an LDS-staged input PATCH (the im2col tile never exists in HBM or in registers):
+// for one 16-pixel slab of an output row, the block stages the CB-channel input patch it touches
+// (kh rows x (15*stride + kw) columns per channel) once, and every MFMA "A" fragment (rows = (channel, tap))
+// is read from the patch at base(lane) + pixel*stride, base = c*PS + a*PW + b.  PW % 32 == kw and
+// PS % 32 == kh*kw make the 32 lanes of a fragment read hit 32 different banks.  Compared with
+// wgrad_kernel this loads each input element once per slab instead of kh*kw times and needs no per-element
+// tap decode.  Requires Wo % 16 == 0 (every layer with Wo >= 16 in this workload).
+// ------------------------------------------------------------------------------------------------
+template <int KS, int ST, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(const WgradArgs a) {
+    constexpr int T = KS * KS;
+    constexpr int CB = 128 / T;                 // channels per row tile (5 for 5x5, 14 for 3x3)
+    constexpr int ROWS = CB * T;                // valid rows of the 128-row tile
+    constexpr int BM = 128, BKP = 16;
+    constexpr int PWN = 15 * ST + KS;           // patch columns actually needed
+    constexpr int PW = (KS == 5) ? 37 : 35;     // >= PWN and == KS (mod 32)
+    constexpr int PS = KS * PW;                 // == T (mod 32)
+    static_assert(PW >= PWN && PW % 32 == KS && PS % 32 == T % 32, "patch strides");
+    constexpr int PATCH = ((CB * PS + 3) / 4) * 4;
+    constexpr int NEL = CB * KS * PWN;          // patch elements to fetch per slab
+    constexpr int AL = (NEL + 255) / 256;
+    constexpr int LDB = BN + 4;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int BV = (BN + 63) / 64;          // float4 loads of the dy tile per thread (64 filters per pass)
+    __shared__ __attribute__((aligned(16))) float smem[2 * (PATCH + BKP * LDB)];
+    float* Ps = smem;
+    float* Bs = smem + 2 * PATCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int c0 = blockIdx.x * CB, n0 = blockIdx.y * BN;
+    const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
+    const int slabs_per_row = a.Wo / BKP;
+    const int total_slabs = a.N * a.Ho * slabs_per_row;
+    const int s_begin = blockIdx.z * a.slabs_per_split;
+    const int s_end = min(s_begin + a.slabs_per_split, total_slabs);
+
+    // ---- per-thread constants of the patch fetch ----
+    int el_lds[AL], el_choff[AL], el_dy[AL], el_dx[AL];
+#pragma unroll
+    for (int q = 0; q < AL; ++q) {
+        const int e = tid + q * 256;
+        const int c = e / (KS * PWN), r = e - c * (KS * PWN);
+        const int ta = r / PWN, col = r - ta * PWN;
+        const bool v = e < NEL && (c0 + c) < a.C;
+        el_lds[q] = c * PS + ta * PW + col;
+        el_choff[q] = v ? (c0 + c) * HW : -1;
+        el_dy[q] = ta - a.pad;
+        el_dx[q] = col - a.pad;
+        if (e >= NEL) el_lds[q] = -1;
+    }
+    // ---- per-thread constants of the dy tile fetch (float4 along pixels) ----
+    const int b_p4 = tid & 3, b_co = tid >> 2;           // 4 x float4 cover 16 pixels; 64 filters per pass
+    // ---- fragment bases ----
+    const int frag_k = lane >> 5, frag_i = lane & 31;
+    int abase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm * (BM / WM) + i * 32 + frag_i;
+        const int rr = row < ROWS ? row : 0;
+        const int c = rr / T, tap = rr - c * T;
+        abase[i] = c * PS + (tap / KS) * PW + (tap % KS) + frag_k * ST;
+    }
+
+    // slab cursor (uniform): image n, output row i, first column j0
+    int sn, si, sj;
+    {
+        const int row = s_begin / slabs_per_row;
+        sj = (s_begin - row * slabs_per_row) * BKP;
+        sn = row / a.Ho;
+        si = row - sn * a.Ho;
+    }
+
+    float areg[AL];
+    float4 breg[BV];
+    unsigned amask = 0;
+    auto load_slab = [&]() {
+        amask = 0;
+        const float* xb = a.x + (long)sn * a.x_nstride;
+        const int y0 = si * ST, x0 = sj * ST;
+#pragma unroll
+        for (int q = 0; q < AL; ++q) {
+            const int y = y0 + el_dy[q], x = x0 + el_dx[q];
+            const bool ok = el_choff[q] >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            areg[q] = xb[ok ? el_choff[q] + y * a.W + x : 0];
+            amask |= (ok ? 1u : 0u) << q;
+        }
+        const float* yb = a.dy + (long)sn * a.y_nstride + (si * a.Wo + sj) + b_p4 * 4;
+#pragma unroll
+        for (int q = 0; q < BV; ++q) {
+            const int co = n0 + b_co + q * 64;
+            breg[q] = *reinterpret_cast<const float4*>(yb + (long)((co < a.K && b_co + q * 64 < BN) ? co : 0) * HoWo);
+        }
+        sj += BKP;
+        if (sj >= a.Wo) {
+            sj = 0;
+            if (++si >= a.Ho) {
+                si = 0;
+                ++sn;
+            }
+        }
+        if (sn >= a.N) { sn = 0; si = 0; sj = 0; }      // past the end: keep addresses valid
+    };
+    auto store_slab = [&](int buf) {
+        float* Pb = Ps + buf * PATCH;
+        float* Bb = Bs + buf * BKP * LDB;
+#pragma unroll
+        for (int q = 0; q < AL; ++q)
+            if (el_lds[q] >= 0) Pb[el_lds[q]] = ((amask >> q) & 1u) ? areg[q] : 0.f;
+#pragma unroll
+        for (int q = 0; q < BV; ++q) {
+            const int col = b_co + q * 64;
+            if (col >= BN) continue;
+            const bool ok = (n0 + col) < a.K;
+            float* d = Bb + (b_p4 * 4) * LDB + col;
+            d[0 * LDB] = ok ? breg[q].x : 0.f;
+            d[1 * LDB] = ok ? breg[q].y : 0.f;
+            d[2 * LDB] = ok ? breg[q].z : 0.f;
+            d[3 * LDB] = ok ? breg[q].w : 0.f;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (s_begin < s_end) {
+        load_slab();
+        store_slab(0);
+    }
+    __syncthreads();
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        const bool more = (s + 1) < s_end;
+        if (more) load_slab();
+        const float* Pb = Ps + buf * PATCH;
+        const float* Bb = Bs + buf * BKP * LDB + wn * (BN / WN) + frag_i + frag_k * LDB;
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = Pb[abase[i]];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = Bb[j * 32];
+#pragma unroll
+        for (int ks = 0; ks < BKP / 2; ++ks) {
+            if (ks + 1 < BKP / 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[(ks + 1) & 1][i] = Pb[abase[i] + (ks + 1) * 2 * ST];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[(ks + 1) & 1][j] = Bb[(ks + 1) * 2 * LDB + j * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+            if (ks == BKP / 4 - 1 && more) store_slab(buf ^ 1);
+        }
+        __syncthreads();
+    }
+
+    float* ob = a.out + (long)blockIdx.z * a.split_stride;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (BN / WN) + j * 32 + frag_i;
+        if (col >= a.K) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rt = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * frag_k;
+                const int row = c0 * T + rt;
+                if (rt < ROWS && row < a.CT) {
+                    float* o = ob + (long)row * a.K + col;
+                    float v = acc[i][j][e];
+                    if (a.accumulate) v += *o;
+                    *o = v;
+                }
+            }
+        }
+    }
+}
+
 // sum of S partial slices: 4 consecutive elements per thread (16-B loads), 4 slices in flight per thread
 __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ part, int S, long n, long split_stride,
                                                             float* __restrict__ out, int accumulate) {
@@ -873,15 +1060,26 @@ int check_desc(const ghm_conv_desc* d) {
 
 struct WVariant {
     int bm, bn, splits, slabs_per_split;
+    int patch;   // 1: wgrad_patch_kernel (row tile = CB channels x taps)
+    int row_tiles;
 };
+
+bool wgrad_patch_ok(const ghm_conv_desc* d) {
+    const bool k_ok = (d->kh == 3 && d->kw == 3) || (d->kh == 5 && d->kw == 5 && d->stride == 1);
+    return k_ok && d->Wo % 16 == 0 && d->C * d->kh * d->kw >= 96 && d->K > 4 && d->pad <= d->kh &&
+           d->y_nstride % 4 == 0 && (d->Ho * d->Wo) % 4 == 0 && getenv("GHM_NO_PATCH") == nullptr;
+}
 
 WVariant pick_wgrad(const ghm_conv_desc* d, int num_cu) {
     const int CT = d->C * d->kh * d->kw;
     WVariant v;
-    v.bm = CT >= 96 ? 128 : 32;
+    v.patch = wgrad_patch_ok(d) ? 1 : 0;
+    v.bm = (CT >= 96 || v.patch) ? 128 : 32;
     v.bn = d->K >= 96 ? 128 : (d->K >= 48 ? 64 : 32);
     if (v.bm == 32) v.bn = 128;
-    const long tiles = (long)ceil_div(CT, v.bm) * ceil_div(d->K, v.bn);
+    const int T = d->kh * d->kw;
+    v.row_tiles = v.patch ? ceil_div(d->C, 128 / T) : ceil_div(CT, v.bm);
+    const long tiles = (long)v.row_tiles * ceil_div(d->K, v.bn);
     const long P = (long)d->N * d->Ho * d->Wo;
     const long slabs = (P + 15) / 16;
     long want = (4L * num_cu + tiles - 1) / tiles;      // aim for ~4 blocks per CU
@@ -1020,7 +1218,27 @@ static int wgrad_impl(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, cons
     } else {
         a.out = dwp; a.split_stride = 0; a.accumulate = accumulate;
     }
-    dim3 grid(ceil_div(a.CT, v.bm), ceil_div(a.K, v.bn), v.splits);
+    dim3 grid(v.row_tiles, ceil_div(a.K, v.bn), v.splits);
+    if (v.patch) {
+#define GHM_WPATCH_CASE(KS_, ST_, BN_, WM_, WN_)                                                              \
+    if (d->kh == KS_ && d->stride == ST_ && v.bn == BN_) {                                                    \
+        hipLaunchKernelGGL((wgrad_patch_kernel<KS_, ST_, BN_, WM_, WN_>), grid, dim3(256), 0, ctx->stream, a); \
+        GHM_LAUNCH_CHECK();                                                                                   \
+    } else
+        GHM_WPATCH_CASE(5, 1, 128, 2, 2)
+        GHM_WPATCH_CASE(5, 1, 64, 4, 1)
+        GHM_WPATCH_CASE(5, 1, 32, 4, 1)
+        GHM_WPATCH_CASE(3, 1, 128, 2, 2)
+        GHM_WPATCH_CASE(3, 1, 64, 4, 1)
+        GHM_WPATCH_CASE(3, 1, 32, 4, 1)
+        GHM_WPATCH_CASE(3, 2, 128, 2, 2)
+        GHM_WPATCH_CASE(3, 2, 64, 4, 1)
+        GHM_WPATCH_CASE(3, 2, 32, 4, 1) {
+            ghm_set_error("no wgrad_patch variant for k=%d s=%d bn=%d", d->kh, d->stride, v.bn);
+            return -3;
+        }
+#undef GHM_WPATCH_CASE
+    } else
 #define GHM_WGRAD_CASE(BM_, BN_, WM_, WN_)                                                          \
     if (v.bm == BM_ && v.bn == BN_) {                                                               \
         hipLaunchKernelGGL((wgrad_kernel<BM_, BN_, WM_, WN_>), grid, dim3(256), 0, ctx->stream, a); \
@@ -1097,7 +1315,7 @@ int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t 
     }
     if (kind == 2) {
         const WVariant v = pick_wgrad(d, 256);
-        snprintf(out, out_len, "wgrad_kernel<%d,%d> splits=%d", v.bm, v.bn, v.splits);
+        snprintf(out, out_len, "%s<%d,%d> splits=%d", v.patch ? "wgrad_patch_kernel" : "wgrad_kernel", v.bm, v.bn, v.splits);
     } else {
         const int R = kind == 0 ? d->K : d->C;
         const long P = kind == 0 ? (long)d->N * d->Ho * d->Wo : (long)d->N * d->H * d->W / (d->stride * d->stride);

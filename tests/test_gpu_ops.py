@@ -41,6 +41,13 @@ CONV_CASES = [
     (2, 128, 24, 24, 128, 3, 1, 1),   # 128-wide tiles
     (1, 16, 7, 7, 16, 3, 2, 1),       # odd input with stride 2
     (4, 1000, 1, 1, 96, 1, 1, 0),     # DenseLayer as 1x1 conv (1000 % 16 != 0)
+    # geometries that take the LDS-patch kernels (Wo % 16 == 0, C*k*k >= 96)
+    (2, 16, 32, 32, 128, 5, 1, 2),    # 5x5 s1, ragged channel tile (16 = 3*5 + 1)
+    (1, 40, 32, 48, 64, 3, 1, 1),     # 3x3 s1, rectangular, 64 filters
+    (2, 24, 64, 64, 48, 3, 2, 1),     # 3x3 s2 -> 32x32
+    (1, 12, 32, 32, 200, 5, 1, 2),    # ragged filter tile (200 = 128 + 72)
+    (2, 32, 32, 32, 96, 3, 2, 1),     # 3x3 s2 -> 16x16 (one slab per row)
+    (3, 20, 16, 16, 24, 3, 1, 1),     # narrow filter tile (24 -> BN=32)
 ]
 
 
