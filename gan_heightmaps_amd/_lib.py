@@ -44,6 +44,8 @@ SIGNATURES = {
     "ghm_timer_elapsed_ms": [_p, _i32, C.POINTER(_f)],
     "ghm_conv2d_fwd": [_p, _D, _p, _p, _p, _p, _i32, _f, _i32],
     "ghm_conv2d_dgrad": [_p, _D, _p, _p, _p, _p, _i32, _f, _i32],
+    "ghm_conv2d_transpose_weights": [_p, _D, _p, _p],
+    "ghm_conv2d_dgrad_t": [_p, _D, _p, _p, _p, _p, _i32, _f, _i32],
     "ghm_conv2d_wgrad_workspace": [_D, C.POINTER(C.c_size_t)],
     "ghm_conv2d_wgrad": [_p, _D, _p, _p, _p, _p, _i32],
     "ghm_channel_sum": [_p, _p, _i32, _i32, _i32, _i64, _p, _i32],

@@ -355,6 +355,217 @@ __global__ __launch_bounds__(256) void direct_smallr_kernel(const IgemmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stride-1 convolution with an LDS-staged input PATCH (forward form; the data gradient runs the same
+// kernel on the transposed weights, see ghm_conv2d_dgrad_t).  A block owns BM output channels x a 2-D tile
+// of RT rows x 32 columns of one image.  Per slab of CB = 2*CP input channels it stages
+//   - the weight rows wp[c][tap][r0..r0+BM) of those channels (a contiguous [CB*T][BM] copy), and
+//   - the input patch those pixels touch, (RT+KS-1) x (32+KS-1) per channel, ONCE (not once per tap),
+// and every MFMA B fragment (32 consecutive pixels of one row) is read from the patch at a compile-time
+// offset: k-step (cp, tap) pairs channel 2cp (lanes 0-31) with channel 2cp+1 (lanes 32-63) on the same tap.
+// The pixel tile is fixed for the block, so bounds masks and LDS offsets are loop invariants and a slab
+// costs pointer bumps only.
+// ------------------------------------------------------------------------------------------------
+struct PatchArgs {
+    const float* in;
+    const float* wp;       // [CH][T][R]
+    const float* bias;
+    float* out;
+    float* partial;
+    int N, CH, H, W;       // stride 1, output grid == input grid (pad + pad' = KS-1)
+    long in_nstride;
+    int R;
+    long out_nstride;
+    int pad;               // rows/cols of halo before the tile
+    int act;
+    float alpha;
+    int accumulate;
+    int slabs_per_split;
+};
+
+template <int KS, int BM, int RT, int WM, int WN, int CP>
+__global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
+    constexpr int T = KS * KS, CB = 2 * CP;
+    constexpr int BN = RT * 32;
+    constexpr int LDA = BM + 4;
+    constexpr int PH = RT + KS - 1, PWN = 32 + KS - 1, PW = PWN, PS = PH * PW;
+    constexpr int KR = CB * T;                      // weight rows per slab
+    constexpr int ASZ = KR * LDA, PSZ = ((CB * PS + 3) / 4) * 4;
+    constexpr int TM = BM / (WM * 32), TN = RT / WN;
+    constexpr int AV = BM / 4;                      // float4 per weight row
+    constexpr int AL = (KR * AV + 255) / 256;
+    constexpr int NEL = CB * PH * PWN;
+    constexpr int BL = (NEL + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                               // 2 x ASZ
+    float* Ps = smem + 2 * ASZ;                     // 2 x PSZ
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int frag_k = lane >> 5, frag_i = lane & 31;
+    // ---- block -> (r tile, image, tile row, tile column); r fastest so neighbours share the patch in L2
+    const int ntr = (a.R + BM - 1) / BM;
+    const int tiles_x = a.W / 32, tiles_y = a.H / RT;
+    int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int r0 = (L % ntr) * BM;
+    L /= ntr;
+    const int tx = L % tiles_x;
+    L /= tiles_x;
+    const int ty = L % tiles_y;
+    const int n = L / tiles_y;
+    const int y0 = ty * RT, x0 = tx * 32;
+    const int HW = a.H * a.W;
+    const int nslabs = a.CH / CB;
+    const int s_begin = blockIdx.y * a.slabs_per_split;
+    const int s_end = min(nslabs, s_begin + a.slabs_per_split);
+
+    // ---- loop-invariant fetch descriptors (element offsets relative to per-slab base pointers) ----
+    int a_off[AL], a_lds[AL];
+#pragma unroll
+    for (int q = 0; q < AL; ++q) {
+        const int e = tid + q * 256;
+        const int row = e / AV, c4 = e - row * AV;
+        const bool v = row < KR && (r0 + c4 * 4) < a.R;
+        a_lds[q] = v ? row * LDA + c4 * 4 : -1;
+        a_off[q] = v ? row * a.R + r0 + c4 * 4 : 0;
+    }
+    int p_off[BL], p_lds[BL];
+    unsigned pmask = 0;
+#pragma unroll
+    for (int q = 0; q < BL; ++q) {
+        const int e = tid + q * 256;
+        const int c = e / (PH * PWN), r = e - c * (PH * PWN);
+        const int py = r / PWN, px = r - py * PWN;
+        const int y = y0 + py - a.pad, x = x0 + px - a.pad;
+        const bool inr = e < NEL;
+        const bool ok = inr && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        p_lds[q] = inr ? c * PS + py * PW + px : -1;
+        p_off[q] = ok ? c * HW + y * a.W + x : 0;
+        pmask |= (ok ? 1u : 0u) << q;
+    }
+    const float* wbase = a.wp + (long)s_begin * KR * a.R;                         // uniform
+    const float* ibase = a.in + (long)n * a.in_nstride + (long)s_begin * CB * HW; // uniform
+    const long a_step = (long)KR * a.R, p_step = (long)CB * HW;
+
+    float areg[AL * 4];          // scalars, not float4[]: keeps the staging registers out of scratch
+    float breg[BL];
+    auto load_slab = [&]() {
+#pragma unroll
+        for (int q = 0; q < AL; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(wbase + a_off[q]);
+            areg[4 * q + 0] = t.x; areg[4 * q + 1] = t.y; areg[4 * q + 2] = t.z; areg[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int q = 0; q < BL; ++q) breg[q] = ibase[p_off[q]];
+        wbase += a_step;
+        ibase += p_step;
+    };
+    auto store_slab = [&](int buf) {
+        float* Ab = As + buf * ASZ;
+        float* Pb = Ps + buf * PSZ;
+#pragma unroll
+        for (int q = 0; q < AL; ++q)
+            if (a_lds[q] >= 0)
+                *reinterpret_cast<float4*>(Ab + a_lds[q]) =
+                    make_float4(areg[4 * q + 0], areg[4 * q + 1], areg[4 * q + 2], areg[4 * q + 3]);
+#pragma unroll
+        for (int q = 0; q < BL; ++q)
+            if (p_lds[q] >= 0) Pb[p_lds[q]] = ((pmask >> q) & 1u) ? breg[q] : 0.f;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (s_begin < s_end) {
+        load_slab();
+        store_slab(0);
+    }
+    __syncthreads();
+    // lane bases: A rows (frag_k selects the odd channel of the pair), patch (pixel column, row segment)
+    const int abase = frag_k * T * LDA + wm * (BM / WM) + frag_i;
+    const int pbase = frag_k * PS + (wn * TN) * PW + frag_i;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        const bool more = (s + 1) < s_end;
+        if (more) load_slab();
+        const float* Ab = As + buf * ASZ + abase;
+        const float* Pb = Ps + buf * PSZ + pbase;
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = Ab[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = Pb[j * PW];
+#pragma unroll
+        for (int ks = 0; ks < CP * T; ++ks) {
+            if (ks + 1 < CP * T) {
+                const int cp = (ks + 1) / T, tap = (ks + 1) % T;
+                const int aoff = (2 * cp * T + tap) * LDA;
+                const int poff = 2 * cp * PS + (tap / KS) * PW + (tap % KS);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[(ks + 1) & 1][i] = Ab[aoff + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[(ks + 1) & 1][j] = Pb[poff + j * PW];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+            if (ks == (CP * T) / 2 - 1 && more) store_slab(buf ^ 1);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    const long P = (long)a.N * HW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int y = y0 + wn * TN + j, x = x0 + frag_i;
+        const long pix = (long)n * HW + (long)y * a.W + x;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = r0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * frag_k;
+                if (r < a.R) {
+                    if (a.partial) {
+                        a.partial[((long)blockIdx.y * a.R + r) * P + pix] = acc[i][j][e];
+                    } else {
+                        float v = acc[i][j][e];
+                        if (a.bias) v += a.bias[r];
+                        float* o = a.out + (long)n * a.out_nstride + (long)r * HW + (long)y * a.W + x;
+                        if (a.accumulate) v += *o;
+                        *o = ghm_act(v, a.act, a.alpha);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// wpT[k][T-1-tap][c] = wp[c][tap][k]: packed weights of the adjoint convolution (data gradient as a forward conv)
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const float* __restrict__ wp, float* __restrict__ wpT,
+                                                                int C, int T, int K) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int c0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, k = k0 + tx;
+        tile[i][tx] = (c < C && k < K) ? wp[((long)c * T + tap) * K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int k = k0 + i, c = c0 + tx;
+        if (k < K && c < C) wpT[((long)k * T + (T - 1 - tap)) * C + c] = tile[tx][i];
+    }
+}
+
 // split-K epilogue: sum the partial slices, then bias / accumulate / activation and the NCHW scatter
 __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs a, int S) {
     const int hw_s = a.Hs * a.Ws;
@@ -1046,6 +1257,76 @@ IgemmArgs pointwise_args(const float* in, long in_nstride, int N, int CH, int H,
     return a;
 }
 
+
+// ---- patch-kernel dispatch (stride-1 forward form) ----
+struct PatchPlan {
+    bool ok;
+    int bm, rt, splits, slabs_per_split, grid;
+    size_t lds;
+};
+
+PatchPlan plan_patch(int N, int CH, int H, int W, int R, int ks, int num_cu) {
+    PatchPlan p;
+    p.ok = false;
+    if (!(ks == 3 || ks == 5) || getenv("GHM_NO_PATCH")) return p;
+    p.bm = R >= 96 ? 128 : 64;
+    p.rt = p.bm == 128 ? 4 : 8;
+    const int cb = ks == 5 ? 2 : 4;
+    if (R < 32 || (R & 3) || (W % 32) || (H % p.rt) || (CH % cb) || CH < 2 * cb) return p;
+    const int T = ks * ks;
+    const int lda = p.bm + 4, ph = p.rt + ks - 1, pw = 32 + ks - 1;
+    const int asz = cb * T * lda, psz = ((cb * ph * pw + 3) / 4) * 4;
+    p.lds = (size_t)2 * (asz + psz) * sizeof(float);
+    const int ntr = (R + p.bm - 1) / p.bm;
+    p.grid = ntr * (W / 32) * (H / p.rt) * N;
+    const int nslabs = CH / cb;
+    p.splits = 1;
+    if (p.grid < num_cu + num_cu / 2) {
+        p.splits = (4 * num_cu + p.grid - 1) / p.grid;
+        const int maxs = nslabs / 4 > 0 ? nslabs / 4 : 1;
+        if (p.splits > maxs) p.splits = maxs;
+    }
+    p.slabs_per_split = (nslabs + p.splits - 1) / p.splits;
+    p.splits = (nslabs + p.slabs_per_split - 1) / p.slabs_per_split;
+    p.ok = true;
+    return p;
+}
+
+int launch_patch(ghm_ctx* ctx, const PatchPlan& pl, PatchArgs a, int ks) {
+    a.slabs_per_split = pl.slabs_per_split;
+    a.partial = nullptr;
+    if (pl.splits > 1) {
+        void* ws = nullptr;
+        if (int e = ghm_scratch(ctx, (size_t)pl.splits * a.R * a.N * a.H * a.W * sizeof(float), &ws)) return e;
+        a.partial = (float*)ws;
+    }
+    const dim3 g(pl.grid, pl.splits);
+#define GHM_PATCH_CASE(KS_, BM_, RT_, WM_, WN_, CP_)                                                          \
+    if (ks == KS_ && pl.bm == BM_) {                                                                          \
+        hipLaunchKernelGGL((conv_patch_kernel<KS_, BM_, RT_, WM_, WN_, CP_>), g, dim3(256), pl.lds, ctx->stream, a); \
+        GHM_LAUNCH_CHECK();                                                                                   \
+    } else
+    GHM_PATCH_CASE(5, 128, 4, 2, 2, 1)
+    GHM_PATCH_CASE(5, 64, 8, 1, 4, 1)
+    GHM_PATCH_CASE(3, 128, 4, 2, 2, 2)
+    GHM_PATCH_CASE(3, 64, 8, 1, 4, 2) {
+        ghm_set_error("no conv_patch variant for k=%d bm=%d", ks, pl.bm);
+        return -3;
+    }
+#undef GHM_PATCH_CASE
+    if (pl.splits > 1) {
+        IgemmArgs e;
+        memset(&e, 0, sizeof(e));
+        e.partial = a.partial; e.out = a.out; e.bias = a.bias; e.N = a.N; e.R = a.R;
+        e.Hout = a.H; e.Wout = a.W; e.out_nstride = a.out_nstride; e.Hs = a.H; e.Ws = a.W; e.os = 1;
+        e.act = a.act; e.alpha = a.alpha; e.accumulate = a.accumulate;
+        hipLaunchKernelGGL(igemm_splitk_epilogue, dim3(ceil_div((long)a.N * a.H * a.W * a.R, 256)), dim3(256), 0,
+                           ctx->stream, e, pl.splits);
+        GHM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 int check_desc(const ghm_conv_desc* d) {
     GHM_CHECK(d->kh * d->kw <= MAX_TAPS, "filter %dx%d exceeds %d taps", d->kh, d->kw, MAX_TAPS);
     GHM_CHECK(d->stride == 1 || d->stride == 2, "stride %d unsupported", d->stride);
@@ -1119,6 +1400,18 @@ int ghm_conv2d_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const f
         GHM_LAUNCH_CHECK();
         return 0;
     }
+    if (d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W) {
+        const PatchPlan pl = plan_patch(d->N, d->C, d->H, d->W, d->K, d->kh, ctx->num_cu);
+        if (pl.ok) {
+            PatchArgs pa;
+            memset(&pa, 0, sizeof(pa));
+            pa.in = x; pa.wp = wp; pa.bias = bias; pa.out = y;
+            pa.N = d->N; pa.CH = d->C; pa.H = d->H; pa.W = d->W; pa.in_nstride = d->x_nstride;
+            pa.R = d->K; pa.out_nstride = d->y_nstride; pa.pad = d->pad;
+            pa.act = act; pa.alpha = alpha; pa.accumulate = accumulate;
+            return launch_patch(ctx, pl, pa, d->kh);
+        }
+    }
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
     a.in = x; a.wp = wp; a.bias = bias; a.out = y;
@@ -1188,6 +1481,50 @@ int ghm_conv2d_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, cons
         }
     }
     return 0;
+}
+
+int ghm_conv2d_transpose_weights(ghm_ctx* ctx, const ghm_conv_desc* d, const float* wp, float* wpT) {
+    const int T = d->kh * d->kw;
+    hipLaunchKernelGGL(transpose_weights_kernel, dim3(ceil_div(d->K, 32), ceil_div(d->C, 32), T), dim3(256), 0,
+                       ctx->stream, wp, wpT, d->C, T, d->K);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_conv2d_dgrad_t(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const float* wpT, const float* bias,
+                       float* dx, int32_t act, float alpha, int32_t accumulate) {
+    if (int e = check_desc(d)) return e;
+    GHM_CHECK(d->stride == 1, "ghm_conv2d_dgrad_t: stride-1 convolutions only (got %d)", d->stride);
+    GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    // the data gradient of a stride-1 conv is the forward conv K -> C with flipped taps (already folded into
+    // wpT by ghm_conv2d_transpose_weights) and padding k-1-pad
+    const int padT = d->kh - 1 - d->pad;
+    if (d->kh == d->kw && d->Ho == d->H && d->Wo == d->W) {
+        const PatchPlan pl = plan_patch(d->N, d->K, d->H, d->W, d->C, d->kh, ctx->num_cu);
+        if (pl.ok) {
+            PatchArgs pa;
+            memset(&pa, 0, sizeof(pa));
+            pa.in = dy; pa.wp = wpT; pa.bias = bias; pa.out = dx;
+            pa.N = d->N; pa.CH = d->K; pa.H = d->H; pa.W = d->W; pa.in_nstride = d->y_nstride;
+            pa.R = d->C; pa.out_nstride = d->x_nstride; pa.pad = padT;
+            pa.act = act; pa.alpha = alpha; pa.accumulate = accumulate;
+            return launch_patch(ctx, pl, pa, d->kh);
+        }
+    }
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = dy; a.wp = wpT; a.bias = bias; a.out = dx;
+    a.N = d->N; a.CH = d->K; a.Hin = d->Ho; a.Win = d->Wo; a.in_nstride = d->y_nstride;
+    a.R = d->C; a.Hout = d->H; a.Wout = d->W; a.out_nstride = d->x_nstride;
+    a.Hs = d->H; a.Ws = d->W; a.os = 1; a.ou = 0; a.ov = 0; a.ss = 1;
+    a.T = d->kh * d->kw; a.ntaps = a.T;
+    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
+    for (int ta = 0; ta < d->kh; ++ta)
+        for (int tb = 0; tb < d->kw; ++tb) {
+            const int t = ta * d->kw + tb;
+            a.di[t] = ta - padT; a.dj[t] = tb - padT; a.wi[t] = t;
+        }
+    return launch_igemm<false>(ctx, a);
 }
 
 int ghm_conv2d_wgrad_workspace(const ghm_conv_desc* d, size_t* bytes) {
@@ -1311,6 +1648,21 @@ int ghm_channel_sum(ghm_ctx* ctx, const float* x, int32_t N, int32_t C, int32_t 
 int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t out_len) {
     if (taps_as_rows(d, kind == 1 ? d->C : d->K)) {
         snprintf(out, out_len, "taps_as_rows<%s>", kind == 0 ? "fwd" : (kind == 1 ? "dgrad" : "wgrad"));
+        return 0;
+    }
+    if (kind == 0 && d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W) {
+        const PatchPlan pl = plan_patch(d->N, d->C, d->H, d->W, d->K, d->kh, 256);
+        if (pl.ok) {
+            snprintf(out, out_len, "conv_patch_kernel<%d,%d,%dx32> splits=%d", d->kh, pl.bm, pl.rt, pl.splits);
+            return 0;
+        }
+    }
+    if (kind == 3) {      // data gradient through transposed weights
+        const PatchPlan pl = plan_patch(d->N, d->K, d->H, d->W, d->C, d->kh, 256);
+        if (d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W && pl.ok)
+            snprintf(out, out_len, "conv_patch_kernel<%d,%d,%dx32> splits=%d", d->kh, pl.bm, pl.rt, pl.splits);
+        else
+            snprintf(out, out_len, "igemm_kernel<fwd on wT>");
         return 0;
     }
     if (kind == 2) {

@@ -221,6 +221,13 @@ class Ops:
         call("ghm_conv2d_dgrad", self.h, C.byref(d), _vp(dy), _vp(wp), _vp(bias), _vp(dx), ACT_CODES[act], alpha,
              int(accumulate))
 
+    def transpose_weights(self, d, wp, wpT):
+        call("ghm_conv2d_transpose_weights", self.h, C.byref(d), _vp(wp), _vp(wpT))
+
+    def conv2d_dgrad_t(self, d, dy, wpT, dx, bias=None, act='linear', alpha=0.0, accumulate=False):
+        call("ghm_conv2d_dgrad_t", self.h, C.byref(d), _vp(dy), _vp(wpT), _vp(bias), _vp(dx), ACT_CODES[act], alpha,
+             int(accumulate))
+
     def wgrad_workspace(self, d):
         n = C.c_size_t()
         call("ghm_conv2d_wgrad_workspace", C.byref(d), C.byref(n))

@@ -87,6 +87,15 @@ class ParamStore:
     def download_grad(self, p):
         return self._from_device_layout(p, self.grad(p).numpy().ravel())
 
+    def transposed(self, p):
+        """scratch for the transposed packed weights of a stride-1 conv (refreshed each step before its first
+        data-gradient use: ghm_conv2d_transpose_weights)"""
+        if not hasattr(self, '_wT'):
+            self._wT = {}
+        if id(p) not in self._wT:
+            self._wT[id(p)] = self.dev.empty((1, int(np.prod(p.shape)), 1, 1))
+        return self._wT[id(p)]
+
 
 # --------------------------------------------------------------------------------------------------
 # IR
@@ -391,13 +400,16 @@ class NetPlan:
                 raise NotImplementedError(n.op)
 
     # ---- backward --------------------------------------------------------------------------------
-    def emit_backward(self, prog, seed, nslice=None, wgrad=True, input_grads=(), accumulate_wgrad=False, tag="bwd"):
+    def emit_backward(self, prog, seed, nslice=None, wgrad=True, input_grads=(), accumulate_wgrad=False, tag="bwd",
+                      transposed=None):
         """Append the backward program.  ``seed``: DevTensor holding dLoss/d(output) (it may be modified in
         place).  ``nslice=(n0, n1)``: run on that sample range of the saved activations.  ``input_grads``:
         InputLayers whose gradient is wanted.  Returns {InputLayer: DevTensor grad}."""
         ops, st, dev = self.ops, self.store, self.dev
         n0, n1 = nslice if nslice is not None else (0, self.batch)
         nb = n1 - n0
+        if transposed is None:
+            transposed = set()      # weights already transposed earlier in this step's program
 
         def sl(t):
             return t if nslice is None else t.samples(n0, n1)
@@ -494,6 +506,15 @@ class NetPlan:
                         d2 = self._desc(n, G, gi)
                         prog.append(("deconv_dgrad", lambda d=d2, G=G, w=w, gi=gi, acc=acc:
                                      ops.conv2d_fwd(d, G, w, None, gi, 'linear', 0.0, acc), conv_meta(ops, d2, 0)))
+                    elif n.op == 'conv' and l.stride[0] == 1:
+                        # stride-1 data gradient = forward conv on the transposed weights (LDS-patch kernel)
+                        d2 = self._desc(n, gi, G)
+                        wT = st.transposed(l.W)
+                        if id(l.W) not in transposed:
+                            transposed.add(id(l.W))
+                            prog.append(("transpose_w", lambda d=d2, w=w, wT=wT: ops.transpose_weights(d, w, wT)))
+                        prog.append(("conv_dgrad", lambda d=d2, G=G, wT=wT, gi=gi, acc=acc:
+                                     ops.conv2d_dgrad_t(d, G, wT, gi, None, 'linear', 0.0, acc), conv_meta(ops, d2, 3)))
                     else:
                         d2 = self._desc(n, gi, G)
                         prog.append(("%s_dgrad" % n.op, lambda d=d2, G=G, w=w, gi=gi, acc=acc:

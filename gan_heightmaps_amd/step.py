@@ -133,19 +133,21 @@ class GanStep:
         losses(tr, True)
         do_dcgan = self.train_mode in ('both', 'dcgan')
         do_p2p = self.train_mode in ('both', 'p2p')
+        tdone = set()      # conv weights whose transposed copy is already fresh in this program
         if do_dcgan:
-            b.D.emit_backward(tr, b.seed_D, wgrad=True, tag="dloss")
+            b.D.emit_backward(tr, b.seed_D, wgrad=True, tag="dloss", transposed=tdone)
             gin = b.D.emit_backward(tr, b.seed_G, nslice=(B, 2 * B), wgrad=False, input_grads=[d_in_layer],
-                                    tag="gloss")
-            b.G.emit_backward(tr, gin[d_in_layer], wgrad=True)
+                                    tag="gloss", transposed=tdone)
+            b.G.emit_backward(tr, gin[d_in_layer], wgrad=True, transposed=tdone)
         if do_p2p:
-            b.P.emit_backward(tr, b.seed_PD, wgrad=True, tag="dloss")
-            gin = b.P.emit_backward(tr, b.seed_PG, nslice=(B, 2 * B), wgrad=False, input_grads=[i_b], tag="gloss")
+            b.P.emit_backward(tr, b.seed_PD, wgrad=True, tag="dloss", transposed=tdone)
+            gin = b.P.emit_backward(tr, b.seed_PG, nslice=(B, 2 * B), wgrad=False, input_grads=[i_b], tag="gloss",
+                                    transposed=tdone)
             gu = gin[i_b]
             # (:115-117) recon loss and alpha * d recon / d U(X) added to the adversarial gradient
             tr.append(("recon", lambda: ops.recon_loss(b.U.out, b.y, slot(3), gu, self.alpha,
                                                        self.reconstruction == 'l2', True)))
-            b.U.emit_backward(tr, gu, wgrad=True)
+            b.U.emit_backward(tr, gu, wgrad=True, transposed=tdone)
         else:
             tr.append(("recon", lambda: ops.recon_loss(b.U.out, b.y, slot(3), None, 1.0,
                                                        self.reconstruction == 'l2')))

@@ -48,6 +48,10 @@ CONV_CASES = [
     (1, 12, 32, 32, 200, 5, 1, 2),    # ragged filter tile (200 = 128 + 72)
     (2, 32, 32, 32, 96, 3, 2, 1),     # 3x3 s2 -> 16x16 (one slab per row)
     (3, 20, 16, 16, 24, 3, 1, 1),     # narrow filter tile (24 -> BN=32)
+    (2, 64, 32, 32, 128, 5, 1, 2),    # conv_patch_kernel 5x5, 128-row tile, both directions
+    (1, 32, 64, 64, 64, 5, 1, 2),     # conv_patch_kernel 5x5, 64-row tile (8x32 pixel tile)
+    (2, 48, 32, 64, 160, 3, 1, 1),    # conv_patch_kernel 3x3, ragged filter tile, rectangular
+    (1, 64, 32, 32, 64, 3, 1, 1),     # conv_patch_kernel 3x3, 64-row tile
 ]
 
 
@@ -79,6 +83,16 @@ def test_conv_fwd_dgrad_wgrad(gpu, case, tile):
     assert rel(dxd.numpy(), dx_ref) < TOL
     ops.conv2d_dgrad(d, dyd, wd, dxd, accumulate=True)
     assert rel(dxd.numpy(), 2 * dx_ref) < TOL
+    if s == 1:
+        # stride-1 data gradient as a forward conv on the transposed packed weights
+        wtd = dev.zeros((1, C * k * k * K, 1, 1))
+        ops.transpose_weights(d, wd, wtd)
+        wp_host = D.pack_conv_w(Wt)                                   # [C, T, K]
+        assert np.array_equal(wtd.numpy().ravel(), np.ascontiguousarray(wp_host[:, ::-1, :].transpose(2, 1, 0)).ravel())
+        ops.conv2d_dgrad_t(d, dyd, wtd, dxd)
+        assert rel(dxd.numpy(), dx_ref) < TOL
+        ops.conv2d_dgrad_t(d, dyd, wtd, dxd, accumulate=True)
+        assert rel(dxd.numpy(), 2 * dx_ref) < TOL
     # wgrad in packed layout
     dwd = dev.zeros((1, C * k * k * K, 1, 1))
     ws = dev.alloc(ops.wgrad_workspace(d))
