@@ -832,14 +832,14 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 2) void wgrad_ker
 // wgrad_kernel this loads each input element once per slab instead of kh*kw times and needs no per-element
 // tap decode.  Requires Wo % 16 == 0 (every layer with Wo >= 16 in this workload).
 // ------------------------------------------------------------------------------------------------
-template <int KS, int ST, int BN, int WM, int WN>
+template <int KS, int ST, int BN, int WM, int WN, int BKP>
 __global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(const WgradArgs a) {
     constexpr int T = KS * KS;
     constexpr int CB = 128 / T;                 // channels per row tile (5 for 5x5, 14 for 3x3)
     constexpr int ROWS = CB * T;                // valid rows of the 128-row tile
-    constexpr int BM = 128, BKP = 16;
-    constexpr int PWN = 15 * ST + KS;           // patch columns actually needed
-    constexpr int PW = (KS == 5) ? 37 : 35;     // >= PWN and == KS (mod 32)
+    constexpr int BM = 128;
+    constexpr int PWN = (BKP - 1) * ST + KS;    // patch columns actually needed
+    constexpr int PW = ((PWN - KS + 31) / 32) * 32 + KS;   // >= PWN and == KS (mod 32)
     constexpr int PS = KS * PW;                 // == T (mod 32)
     static_assert(PW >= PWN && PW % 32 == KS && PS % 32 == T % 32, "patch strides");
     constexpr int PATCH = ((CB * PS + 3) / 4) * 4;
@@ -847,7 +847,9 @@ __global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(c
     constexpr int AL = (NEL + 255) / 256;
     constexpr int LDB = BN + 4;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int BV = (BN + 63) / 64;          // float4 loads of the dy tile per thread (64 filters per pass)
+    constexpr int PV = BKP / 4;                 // float4 per filter row of the dy tile
+    constexpr int CPP = 256 / PV;               // filters covered per pass
+    constexpr int BV = (BN + CPP - 1) / CPP;    // float4 loads of the dy tile per thread
     __shared__ __attribute__((aligned(16))) float smem[2 * (PATCH + BKP * LDB)];
     float* Ps = smem;
     float* Bs = smem + 2 * PATCH;
@@ -876,7 +878,7 @@ __global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(c
         if (e >= NEL) el_lds[q] = -1;
     }
     // ---- per-thread constants of the dy tile fetch (float4 along pixels) ----
-    const int b_p4 = tid & 3, b_co = tid >> 2;           // 4 x float4 cover 16 pixels; 64 filters per pass
+    const int b_p4 = tid % PV, b_co = tid / PV;          // PV x float4 cover the slab's pixels
     // ---- fragment bases ----
     const int frag_k = lane >> 5, frag_i = lane & 31;
     int abase[TM];
@@ -914,8 +916,8 @@ __global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(c
         const float* yb = a.dy + (long)sn * a.y_nstride + (si * a.Wo + sj) + b_p4 * 4;
 #pragma unroll
         for (int q = 0; q < BV; ++q) {
-            const int co = n0 + b_co + q * 64;
-            breg[q] = *reinterpret_cast<const float4*>(yb + (long)((co < a.K && b_co + q * 64 < BN) ? co : 0) * HoWo);
+            const int co = n0 + b_co + q * CPP;
+            breg[q] = *reinterpret_cast<const float4*>(yb + (long)((co < a.K && b_co + q * CPP < BN) ? co : 0) * HoWo);
         }
         sj += BKP;
         if (sj >= a.Wo) {
@@ -935,7 +937,7 @@ __global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(c
             if (el_lds[q] >= 0) Pb[el_lds[q]] = ((amask >> q) & 1u) ? areg[q] : 0.f;
 #pragma unroll
         for (int q = 0; q < BV; ++q) {
-            const int col = b_co + q * 64;
+            const int col = b_co + q * CPP;
             if (col >= BN) continue;
             const bool ok = (n0 + col) < a.K;
             float* d = Bb + (b_p4 * 4) * LDB + col;
@@ -1343,6 +1345,7 @@ struct WVariant {
     int bm, bn, splits, slabs_per_split;
     int patch;   // 1: wgrad_patch_kernel (row tile = CB channels x taps)
     int row_tiles;
+    int bkp;     // pixels per slab
 };
 
 bool wgrad_patch_ok(const ghm_conv_desc* d) {
@@ -1362,9 +1365,10 @@ WVariant pick_wgrad(const ghm_conv_desc* d, int num_cu) {
     v.row_tiles = v.patch ? ceil_div(d->C, 128 / T) : ceil_div(CT, v.bm);
     const long tiles = (long)v.row_tiles * ceil_div(d->K, v.bn);
     const long P = (long)d->N * d->Ho * d->Wo;
-    const long slabs = (P + 15) / 16;
+    v.bkp = (v.patch && d->Wo % 32 == 0 && getenv("GHM_WGRAD_BKP16") == nullptr) ? 32 : 16;
+    const long slabs = (P + v.bkp - 1) / v.bkp;
     long want = (4L * num_cu + tiles - 1) / tiles;      // aim for ~4 blocks per CU
-    long max_by_work = slabs / 16 > 0 ? slabs / 16 : 1; // at least 16 slabs (256 pixels) per split
+    long max_by_work = slabs / (256 / v.bkp) > 0 ? slabs / (256 / v.bkp) : 1;   // at least 256 pixels per split
     long S = want < max_by_work ? want : max_by_work;
     if (S < 1) S = 1;
     if (S > 1024) S = 1024;
@@ -1559,7 +1563,10 @@ static int wgrad_impl(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, cons
     if (v.patch) {
 #define GHM_WPATCH_CASE(KS_, ST_, BN_, WM_, WN_)                                                              \
     if (d->kh == KS_ && d->stride == ST_ && v.bn == BN_) {                                                    \
-        hipLaunchKernelGGL((wgrad_patch_kernel<KS_, ST_, BN_, WM_, WN_>), grid, dim3(256), 0, ctx->stream, a); \
+        if (v.bkp == 32)                                                                                      \
+            hipLaunchKernelGGL((wgrad_patch_kernel<KS_, ST_, BN_, WM_, WN_, 32>), grid, dim3(256), 0, ctx->stream, a); \
+        else                                                                                                  \
+            hipLaunchKernelGGL((wgrad_patch_kernel<KS_, ST_, BN_, WM_, WN_, 16>), grid, dim3(256), 0, ctx->stream, a); \
         GHM_LAUNCH_CHECK();                                                                                   \
     } else
         GHM_WPATCH_CASE(5, 1, 128, 2, 2)
