@@ -1660,21 +1660,28 @@ int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t 
     if (kind == 0 && d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W) {
         const PatchPlan pl = plan_patch(d->N, d->C, d->H, d->W, d->K, d->kh, 256);
         if (pl.ok) {
-            snprintf(out, out_len, "conv_patch_kernel<%d,%d,%dx32> splits=%d", d->kh, pl.bm, pl.rt, pl.splits);
+            snprintf(out, out_len, "conv_patch_kernel<%d, %d, %d, %d, %d, %d> splits=%d", d->kh, pl.bm, pl.rt,
+                     pl.bm == 128 ? 2 : 1, pl.bm == 128 ? 2 : 4, d->kh == 5 ? 1 : 2, pl.splits);
             return 0;
         }
     }
     if (kind == 3) {      // data gradient through transposed weights
         const PatchPlan pl = plan_patch(d->N, d->K, d->H, d->W, d->C, d->kh, 256);
         if (d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W && pl.ok)
-            snprintf(out, out_len, "conv_patch_kernel<%d,%d,%dx32> splits=%d", d->kh, pl.bm, pl.rt, pl.splits);
+            snprintf(out, out_len, "conv_patch_kernel<%d, %d, %d, %d, %d, %d> splits=%d", d->kh, pl.bm, pl.rt,
+                     pl.bm == 128 ? 2 : 1, pl.bm == 128 ? 2 : 4, d->kh == 5 ? 1 : 2, pl.splits);
         else
             snprintf(out, out_len, "igemm_kernel<fwd on wT>");
         return 0;
     }
     if (kind == 2) {
         const WVariant v = pick_wgrad(d, 256);
-        snprintf(out, out_len, "%s<%d,%d> splits=%d", v.patch ? "wgrad_patch_kernel" : "wgrad_kernel", v.bm, v.bn, v.splits);
+        if (v.patch)
+            snprintf(out, out_len, "wgrad_patch_kernel<%d, %d, %d, %d, %d, %d> splits=%d", d->kh, d->stride, v.bn,
+                     v.bn == 128 ? 2 : 4, v.bn == 128 ? 2 : 1, v.bkp, v.splits);
+        else
+            snprintf(out, out_len, "wgrad_kernel<%d, %d, %d, %d> splits=%d", v.bm, v.bn, v.bm == 32 ? 1 : (v.bn == 128 ? 2 : 4),
+                     v.bm == 32 ? 4 : (v.bn == 128 ? 2 : 1), v.splits);
     } else {
         const int R = kind == 0 ? d->K : d->C;
         const long P = kind == 0 ? (long)d->N * d->Ho * d->Wo : (long)d->N * d->H * d->W / (d->stride * d->stride);

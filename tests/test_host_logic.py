@@ -85,7 +85,7 @@ def test_unet_lowering_rewrites_and_concat_in_place():
     run = []
     for e in bwd:
         e[1]()
-    acc_calls = [c for c in ops.calls if c[0] == 'conv2d_dgrad' and c[1][-1] is True]
+    acc_calls = [c for c in ops.calls if c[0] in ('conv2d_dgrad', 'conv2d_dgrad_t') and c[1][-1] is True]
     assert len(acc_calls) == 5      # conv2..conv5 and the 2x2 bottleneck conv accumulate into the 5 skip slices
 
 
