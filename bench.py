@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--mode", default="both", choices=["both", "dcgan", "p2p"])
     ap.add_argument("--graph", action="store_true", help="replay the step as a captured HIP graph (no per-kernel events)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-stream", action="store_true", help="run both GAN stages on a single HIP stream")
     ap.add_argument("--profile", action="store_true", help="print a per-program-entry timing table to stderr")
     args = ap.parse_args()
 
@@ -81,7 +82,7 @@ def main():
     dev = device.Device(local_rank)
     comm = dist.Comm(dev, rank, world) if world > 1 else None
     B = args.batch_per_gpu
-    backend = dict(device=dev, comm=comm, use_graph=args.graph, seed=0, verbose=False)
+    backend = dict(device=dev, comm=comm, use_graph=args.graph, seed=0, verbose=False, two_streams=not args.one_stream)
     model = make_model('test1_nobn_bilin_both', **backend)
     if args.mode != 'both':
         # configs 2 / 3 of BASELINE.json: same nets, one stage trained
@@ -93,14 +94,12 @@ def main():
 
     for _ in range(args.warmup):
         eng.enqueue_train(b)
-    dev.sync()
+    eng.sync()
 
-    prog = (b.train_compute + (b.update if world == 1 else [])) if not args.graph else []
     # ---- pick the dominant kernel from one instrumented (untimed) step ----
     dominant, launches_per_step, flops_per_step = None, 0, 0.0
-    if prog:
-        from gan_heightmaps_amd.engine import time_program
-        table = time_program(dev, prog)
+    if not args.graph:
+        table = eng.profile_train(B)
         by_kernel = {}
         for label, ms, meta in table:
             k = meta["kernel"].split(" splits")[0] if meta else label
@@ -108,9 +107,6 @@ def main():
             e[0] += ms
             e[1] += 1
             e[2] += meta["flops"] if meta else 0.0
-        if world > 1:
-            for e in b.exchange + b.update:
-                e[1]()
         if args.profile and rank == 0:
             tot = sum(v[0] for v in by_kernel.values())
             for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][0]):
@@ -128,40 +124,36 @@ def main():
 
     max_slots = 4000
     inst_steps = min(args.steps, max_slots // max(launches_per_step, 1)) if dominant else 0
+    slots = []          # (device, slot) of every bracketed launch of the dominant kernel
+
+    def wrap(lane, e):
+        if is_dom(e):
+            d = eng.devs[lane]
+            d.timer_start(len(slots))
+            e[1]()
+            d.timer_stop(len(slots))
+            slots.append(d)
+        else:
+            e[1]()
 
     # ---- timed region ----
     if comm is not None:
         comm.barrier()
-    dev.sync()
+    eng.sync()
     t0 = time.perf_counter()
-    slot = 0
     for s in range(args.steps):
         if args.graph:
             eng.enqueue_train(b)
-            continue
-        if s < inst_steps:
-            for e in b.train_compute:
-                if is_dom(e):
-                    dev.timer_start(slot)
-                    e[1]()
-                    dev.timer_stop(slot)
-                    slot += 1
-                else:
-                    e[1]()
         else:
-            for e in b.train_compute:
-                e[1]()
-        for e in b.exchange:
-            e[1]()
-        for e in b.update:
-            e[1]()
-    dev.sync()
+            eng.enqueue_train(b, wrap if s < inst_steps else (lambda lane, e: e[1]()))
+    eng.sync()
     if comm is not None:
         comm.barrier()
     elapsed = time.perf_counter() - t0
     if comm is not None:
         elapsed = comm.max_scalar(elapsed)
     losses = eng._read_losses()
+    slot = len(slots)
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = B * world * args.steps / elapsed
@@ -172,14 +164,14 @@ def main():
         "config": {"workload": "test1_nobn_bilin_both joint DCGAN+pix2pix train step (train_mode=%s), 512x512, "
                                "batch %d per GPU, RMSprop lr 1e-4, LSGAN + 100*L1" % (args.mode, B),
                    "global_batch": B * world, "in_shp": 512, "parallelism": "dp%d" % world,
-                   "hip_graph": bool(args.graph)},
+                   "hip_graph": bool(args.graph), "streams": 1 if eng.devs[0] is eng.devs[1] else 2},
         "step_algorithmic_tflops": round(JOINT_GFLOP_PER_IMG * value / 1e3, 2) if args.mode == 'both' else None,
         "step_frac_of_fp32_mfma_peak": round(JOINT_GFLOP_PER_IMG * value / world / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)
         if args.mode == 'both' else None,
         "losses": [float(x) for x in losses],
     }
     if dominant and slot:
-        tot_ms = sum(dev.timer_ms(i) for i in range(slot))
+        tot_ms = sum(d.timer_ms(i) for i, d in enumerate(slots))
         avg_ms = tot_ms / slot
         flops_per_launch = flops_per_step / launches_per_step
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
@@ -197,6 +189,9 @@ def main():
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
+    for d in set(eng.devs):
+        if d is not dev:
+            d.close()
     dev.close()
 
 

@@ -35,6 +35,7 @@ SIGNATURES = {
     "ghm_d2d": [_p, _p, _p, C.c_size_t],
     "ghm_memset_zero": [_p, _p, C.c_size_t],
     "ghm_sync": [_p],
+    "ghm_stream_wait": [_p, _p],
     "ghm_capture_begin": [_p],
     "ghm_capture_end": [_p, C.POINTER(_p)],
     "ghm_graph_launch": [_p, _p],

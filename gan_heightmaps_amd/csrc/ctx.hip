@@ -124,6 +124,17 @@ int ghm_sync(ghm_ctx* ctx) {
     return 0;
 }
 
+int ghm_stream_wait(ghm_ctx* ctx, ghm_ctx* other) {
+    // everything enqueued on ``ctx`` after this call runs after everything enqueued on ``other`` so far
+    GHM_CHECK(ctx->device == other->device, "ghm_stream_wait across devices");
+    hipEvent_t ev;
+    GHM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    GHM_HIP(hipEventRecord(ev, other->stream));
+    GHM_HIP(hipStreamWaitEvent(ctx->stream, ev, 0));
+    GHM_HIP(hipEventDestroy(ev));       // destruction is deferred by the runtime until the event has fired
+    return 0;
+}
+
 int ghm_capture_begin(ghm_ctx* ctx) {
     GHM_CHECK(!ctx->capturing, "nested capture");
     GHM_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));

@@ -138,6 +138,10 @@ class Device:
     def sync(self):
         call("ghm_sync", self.h)
 
+    def wait_for(self, other):
+        """later work on this context's stream waits for everything already enqueued on ``other``'s stream"""
+        call("ghm_stream_wait", self.h, other.h)
+
     def info(self):
         name = C.create_string_buffer(256)
         cu, hbm = C.c_int32(), C.c_int64()

@@ -115,19 +115,21 @@ def test_gan_step_program_structure_on_fake_device():
     orig = step_mod.Ops
     step_mod.Ops = RecordingOps
     try:
-        eng = GanStep(dev, G, Dn, U, P, 100, True, 'l1', spec, 'both', use_graph=False)
+        eng = GanStep(dev, G, Dn, U, P, 100, True, 'l1', spec, 'both', use_graph=False, two_streams=False)
         b = eng.built(4)
     finally:
         step_mod.Ops = orig
     # G writes straight into the fake half of D's input batch; U into channels 1..3 of the PatchGAN pair buffer
     assert b.G.out.ptr == b.d_in.ptr + 4 * 4 * 32 * 32 and b.D.batch == 8
     assert b.U.out.nstride == 4 * 32 * 32 and b.U.out.shape == (4, 3, 32, 32)
-    labels = [e[0] for e in b.train_compute]
-    assert labels.count('loss') == 6 and labels.count('recon') == 1
-    assert [e[0] for e in b.update] == ['rmsprop_dcgan_gen', 'rmsprop_dcgan_disc', 'rmsprop_p2p_gen', 'rmsprop_p2p_disc']
+    # one launch list per stream: [DCGAN stage, pix2pix stage]
+    la, lb = ([e[0] for e in lane] for lane in b.train_compute)
+    assert la.count('loss') == 3 and lb.count('loss') == 3 and lb.count('recon') == 1 and 'recon' not in la
+    assert [[e[0] for e in lane] for lane in b.update] == [['rmsprop_dcgan_gen', 'rmsprop_dcgan_disc'],
+                                                           ['rmsprop_p2p_gen', 'rmsprop_p2p_disc']]
     assert b.exchange == []
     # D is differentiated twice: once with weight gradients (2B batch), once data-gradient only (fake half)
-    d_wgrads = sum(1 for e in b.train_compute if e[0] == 'conv_wgrad')
+    d_wgrads = sum(1 for lane in b.train_compute for e in lane if e[0] == 'conv_wgrad')
     n_convs = sum(1 for net in (G, Dn, U, P["out"]) for l in L.get_all_layers(net)
                   if isinstance(l, L.Conv2DLayer))
     assert d_wgrads == n_convs
