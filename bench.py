@@ -118,6 +118,7 @@ def main():
         dominant = max((k for k in by_kernel if by_kernel[k][2] > 0), key=lambda k: by_kernel[k][0])
         launches_per_step = by_kernel[dominant][1]
         flops_per_step = by_kernel[dominant][2]
+        isolated_ms = by_kernel[dominant][0] / launches_per_step      # one kernel at a time, nothing else on the GPU
 
     def is_dom(e):
         return len(e) > 2 and e[2] is not None and e[2]["kernel"].split(" splits")[0] == dominant
@@ -172,11 +173,18 @@ def main():
     }
     if dominant and slot:
         tot_ms = sum(d.timer_ms(i) for i, d in enumerate(slots))
-        avg_ms = tot_ms / slot
+        avg_ms = tot_ms / slot                           # in the timed region (the other stream keeps running)
         flops_per_launch = flops_per_step / launches_per_step
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")      # written by tools/pmc_traffic.py
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get(dominant, {}).get("hbm_bytes_per_launch")
+        iso = flops_per_launch / (isolated_ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                           "concurrent_streams": 1 if eng.devs[0] is eng.devs[1] else 2,
+                           "achieved_isolated": round(iso, 2), "frac_isolated": round(iso / FP32_MFMA_PEAK_TFLOPS, 4),
                            "kernel": dominant, "launches_per_step": launches_per_step,
                            "avg_launch_ms": round(avg_ms, 4),
                            "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3),

@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(c
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
         const bool more = (s + 1) < s_end;
-        if (more) load_slab();
+        if (more && a.debug < 1) load_slab();
         const float* Pb = Ps + buf * PATCH;
         const float* Bb = Bs + buf * BKP * LDB + wn * (BN / WN) + frag_i + frag_k * LDB;
         float af[2][TM], bf[2][TN];
@@ -985,7 +985,7 @@ __global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(c
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
-            if (ks == BKP / 4 - 1 && more) store_slab(buf ^ 1);
+            if (ks == BKP / 4 - 1 && more && a.debug < 2) store_slab(buf ^ 1);
         }
         __syncthreads();
     }
@@ -1367,7 +1367,11 @@ WVariant pick_wgrad(const ghm_conv_desc* d, int num_cu) {
     const long P = (long)d->N * d->Ho * d->Wo;
     v.bkp = (v.patch && d->Wo % 32 == 0 && getenv("GHM_WGRAD_BKP16") == nullptr) ? 32 : 16;
     const long slabs = (P + v.bkp - 1) / v.bkp;
-    long want = (4L * num_cu + tiles - 1) / tiles;      // aim for ~4 blocks per CU
+    // one FULL round of resident blocks (a second, partly filled round costs up to 2x): blocks/CU is 3 for the
+    // 128-filter tile, 4 otherwise
+    const long slots = (long)num_cu * (v.bn >= 128 ? 3 : 4);
+    long want = slots / tiles;
+    if (const char* f = getenv("GHM_WGRAD_SPLITS")) want = atol(f);
     long max_by_work = slabs / (256 / v.bkp) > 0 ? slabs / (256 / v.bkp) : 1;   // at least 256 pixels per split
     long S = want < max_by_work ? want : max_by_work;
     if (S < 1) S = 1;

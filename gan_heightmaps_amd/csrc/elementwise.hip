@@ -99,19 +99,22 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ beta, int act, float alpha) {
     long n, c, i;
     if (!decode<VEC>(v, n, c, i)) return;
+    // (x - mean) * (gamma * inv) + beta, in this order: when the batch variance is ~0 (batch of 1, 1x1 maps) the
+    // subtraction cancels exactly like the reference expression does; folding mean into a pre-computed shift
+    // leaves a rounding residue that the next layers' 1/sqrt(eps) = 100 gains amplify
     const float sc = gamma[c] * inv[c];
-    const float sh = beta[c] - mean[c] * sc;
+    const float m = mean[c], be = beta[c];
     const float* xp = x + n * xs + c * v.HW + i;
     float* yp = y + n * ys + c * v.HW + i;
     if constexpr (VEC == 4) {
         float4 t = *reinterpret_cast<const float4*>(xp);
-        t.x = ghm_act(fmaf(t.x, sc, sh), act, alpha);
-        t.y = ghm_act(fmaf(t.y, sc, sh), act, alpha);
-        t.z = ghm_act(fmaf(t.z, sc, sh), act, alpha);
-        t.w = ghm_act(fmaf(t.w, sc, sh), act, alpha);
+        t.x = ghm_act(fmaf(t.x - m, sc, be), act, alpha);
+        t.y = ghm_act(fmaf(t.y - m, sc, be), act, alpha);
+        t.z = ghm_act(fmaf(t.z - m, sc, be), act, alpha);
+        t.w = ghm_act(fmaf(t.w - m, sc, be), act, alpha);
         *reinterpret_cast<float4*>(yp) = t;
     } else {
-        *yp = ghm_act(fmaf(*xp, sc, sh), act, alpha);
+        *yp = ghm_act(fmaf(*xp - m, sc, be), act, alpha);
     }
 }
 
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(256) void up_bilinear_bwd_kernel(const float* __res
 // losses: single-pass grid-stride with fp64 block partials + one atomic per block
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scalar_loss_kernel(const float* __restrict__ d, long n, float target, int kind,
-                                                          float* __restrict__ grad, float gscale, float* loss_out) {
+                                                          float* __restrict__ grad, float gscale, double* __restrict__ part) {
     double acc = 0.0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float v = d[i];
@@ -394,12 +397,19 @@ __global__ __launch_bounds__(256) void scalar_loss_kernel(const float* __restric
     }
     __shared__ double red[4];
     acc = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(loss_out, (float)(acc / (double)n));
+    if (threadIdx.x == 0) part[blockIdx.x] = acc / (double)n;
+}
+
+// fixed-order sum of the block partials: losses are bit-for-bit repeatable (no float atomics)
+__global__ void loss_final_kernel(const double* __restrict__ part, int nblocks, float* loss_out, int accumulate) {
+    double s = 0.0;
+    for (int i = 0; i < nblocks; ++i) s += part[i];
+    loss_out[0] = (accumulate ? loss_out[0] : 0.f) + (float)s;
 }
 
 __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict__ a, long as, const float* __restrict__ b,
                                                          long bs, View v, int l2, float* __restrict__ grad, long gs,
-                                                         float gscale, int accumulate, float* loss_out) {
+                                                         float gscale, int accumulate, double* __restrict__ part) {
     const long chw = (long)v.C * v.HW, total = (long)v.N * chw;
     double acc = 0.0;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -421,7 +431,7 @@ __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict
     }
     __shared__ double red[4];
     acc = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(loss_out, (float)(acc / (double)total));
+    if (threadIdx.x == 0) part[blockIdx.x] = acc / (double)total;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -658,30 +668,40 @@ static int loss_grid(long n) {
     return (int)g;
 }
 
-int ghm_lsgan_loss(ghm_ctx* ctx, const float* d, int64_t n, float target, float* loss_out, float* grad,
-                   float grad_scale, int32_t accumulate_loss) {
-    if (!accumulate_loss) GHM_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), ctx->stream));
-    hipLaunchKernelGGL(scalar_loss_kernel, dim3(loss_grid(n)), dim3(256), 0, ctx->stream, d, (long)n, target, 0, grad,
-                       grad_scale, loss_out);
+static int scalar_loss(ghm_ctx* ctx, const float* d, int64_t n, float target, int kind, float* loss_out, float* grad,
+                       float grad_scale, int32_t accumulate_loss) {
+    const int g = loss_grid(n);
+    void* ws = nullptr;
+    if (int e = ghm_scratch(ctx, (size_t)g * sizeof(double), &ws)) return e;
+    hipLaunchKernelGGL(scalar_loss_kernel, dim3(g), dim3(256), 0, ctx->stream, d, (long)n, target, kind, grad, grad_scale,
+                       (double*)ws);
+    GHM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1), 0, ctx->stream, (const double*)ws, g, loss_out,
+                       accumulate_loss);
     GHM_LAUNCH_CHECK();
     return 0;
+}
+
+int ghm_lsgan_loss(ghm_ctx* ctx, const float* d, int64_t n, float target, float* loss_out, float* grad,
+                   float grad_scale, int32_t accumulate_loss) {
+    return scalar_loss(ctx, d, n, target, 0, loss_out, grad, grad_scale, accumulate_loss);
 }
 
 int ghm_bce_loss(ghm_ctx* ctx, const float* p, int64_t n, float target, float* loss_out, float* grad, float grad_scale,
                  int32_t accumulate_loss) {
-    if (!accumulate_loss) GHM_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), ctx->stream));
-    hipLaunchKernelGGL(scalar_loss_kernel, dim3(loss_grid(n)), dim3(256), 0, ctx->stream, p, (long)n, target, 1, grad,
-                       grad_scale, loss_out);
-    GHM_LAUNCH_CHECK();
-    return 0;
+    return scalar_loss(ctx, p, n, target, 1, loss_out, grad, grad_scale, accumulate_loss);
 }
 
 int ghm_recon_loss(ghm_ctx* ctx, const float* a, int64_t as, const float* b, int64_t bs, int32_t N, int32_t C, int32_t HW,
                    int32_t l2, float* loss_out, float* grad, int64_t gs, float grad_scale, int32_t accumulate_grad) {
-    GHM_HIP(hipMemsetAsync(loss_out, 0, sizeof(float), ctx->stream));
     const View v{N, C, HW};
-    hipLaunchKernelGGL(recon_loss_kernel, dim3(loss_grid((long)N * C * HW)), dim3(256), 0, ctx->stream, a, (long)as, b,
-                       (long)bs, v, l2, grad, (long)gs, grad_scale, accumulate_grad, loss_out);
+    const int g = loss_grid((long)N * C * HW);
+    void* ws = nullptr;
+    if (int e = ghm_scratch(ctx, (size_t)g * sizeof(double), &ws)) return e;
+    hipLaunchKernelGGL(recon_loss_kernel, dim3(g), dim3(256), 0, ctx->stream, a, (long)as, b, (long)bs, v, l2, grad, (long)gs,
+                       grad_scale, accumulate_grad, (double*)ws);
+    GHM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1), 0, ctx->stream, (const double*)ws, g, loss_out, 0);
     GHM_LAUNCH_CHECK();
     return 0;
 }
