@@ -112,7 +112,7 @@ def main():
             for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][0]):
                 print("%-44s %9.3f ms %5.1f%% n=%3d %8.1f GFLOP %6.1f TF/s" %
                       (k, v[0], 100 * v[0] / tot, v[1], v[2] / 1e9, v[2] / 1e9 / max(v[0], 1e-9)), file=sys.stderr)
-            for label, ms, meta in sorted(table, key=lambda t: -t[1])[:40]:
+            for label, ms, meta in sorted(table, key=lambda t: -t[1])[:(400 if os.environ.get('GHM_PROFILE_ALL') else 40)]:
                 print("  %-18s %8.3f ms %s %s" % (label, ms, meta["kernel"] if meta else "",
                                                  meta["geom"] if meta else ""), file=sys.stderr)
         dominant = max((k for k in by_kernel if by_kernel[k][2] > 0), key=lambda k: by_kernel[k][0])

@@ -79,7 +79,8 @@ SIGNATURES = {
     "ghm_allreduce_max": [_p, _p, _i64],
     "ghm_conv2d_variant": [_D, _i32, C.c_char_p, _i32],
 }
-_SPECIAL = {"ghm_last_error": ([], C.c_char_p), "ghm_bn_workspace": ([_i32], C.c_size_t)}
+_SPECIAL = {"ghm_last_error": ([], C.c_char_p), "ghm_bn_workspace": ([_i32], C.c_size_t),
+            "ghm_dgrad_t_supported": ([_D], C.c_int)}
 
 _lib = None
 

@@ -372,7 +372,8 @@ struct PatchArgs {
     const float* bias;
     float* out;
     float* partial;
-    int N, CH, H, W;       // stride 1, output grid == input grid (pad + pad' = KS-1)
+    int N, CH, H, W;       // OUTPUT grid (tiles of RT x 32 output pixels)
+    int Hin, Win;          // input grid (== H, W for stride 1)
     long in_nstride;
     int R;
     long out_nstride;
@@ -383,12 +384,12 @@ struct PatchArgs {
     int slabs_per_split;
 };
 
-template <int KS, int BM, int RT, int WM, int WN, int CP>
+template <int KS, int BM, int RT, int WM, int WN, int CP, int ST>
 __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
     constexpr int T = KS * KS, CB = 2 * CP;
     constexpr int BN = RT * 32;
     constexpr int LDA = BM + 4;
-    constexpr int PH = RT + KS - 1, PWN = 32 + KS - 1, PW = PWN, PS = PH * PW;
+    constexpr int PH = (RT - 1) * ST + KS, PWN = 31 * ST + KS, PW = PWN, PS = PH * PW;
     constexpr int KR = CB * T;                      // weight rows per slab
     constexpr int ASZ = KR * LDA, PSZ = ((CB * PS + 3) / 4) * 4;
     constexpr int TM = BM / (WM * 32), TN = RT / WN;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
     const int ty = L % tiles_y;
     const int n = L / tiles_y;
     const int y0 = ty * RT, x0 = tx * 32;
-    const int HW = a.H * a.W;
+    const int HW = a.H * a.W, HWin = a.Hin * a.Win;
     const int nslabs = a.CH / CB;
     const int s_begin = blockIdx.y * a.slabs_per_split;
     const int s_end = min(nslabs, s_begin + a.slabs_per_split);
@@ -436,16 +437,16 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
         const int e = tid + q * 256;
         const int c = e / (PH * PWN), r = e - c * (PH * PWN);
         const int py = r / PWN, px = r - py * PWN;
-        const int y = y0 + py - a.pad, x = x0 + px - a.pad;
+        const int y = y0 * ST + py - a.pad, x = x0 * ST + px - a.pad;
         const bool inr = e < NEL;
-        const bool ok = inr && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        const bool ok = inr && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
         p_lds[q] = inr ? c * PS + py * PW + px : -1;
-        p_off[q] = ok ? c * HW + y * a.W + x : 0;
+        p_off[q] = ok ? c * HWin + y * a.Win + x : 0;
         pmask |= (ok ? 1u : 0u) << q;
     }
     const float* wbase = a.wp + (long)s_begin * KR * a.R;                         // uniform
-    const float* ibase = a.in + (long)n * a.in_nstride + (long)s_begin * CB * HW; // uniform
-    const long a_step = (long)KR * a.R, p_step = (long)CB * HW;
+    const float* ibase = a.in + (long)n * a.in_nstride + (long)s_begin * CB * HWin; // uniform
+    const long a_step = (long)KR * a.R, p_step = (long)CB * HWin;
 
     float areg[AL * 4];          // scalars, not float4[]: keeps the staging registers out of scratch
     float breg[BL];
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
     __syncthreads();
     // lane bases: A rows (frag_k selects the odd channel of the pair), patch (pixel column, row segment)
     const int abase = frag_k * T * LDA + wm * (BM / WM) + frag_i;
-    const int pbase = frag_k * PS + (wn * TN) * PW + frag_i;
+    const int pbase = frag_k * PS + (wn * TN * ST) * PW + frag_i * ST;
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
         const bool more = (s + 1) < s_end;
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = Ab[i * 32];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = Pb[j * PW];
+        for (int j = 0; j < TN; ++j) bf[0][j] = Pb[j * ST * PW];
 #pragma unroll
         for (int ks = 0; ks < CP * T; ++ks) {
             if (ks + 1 < CP * T) {
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[(ks + 1) & 1][i] = Ab[aoff + i * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[(ks + 1) & 1][j] = Pb[poff + j * PW];
+                for (int j = 0; j < TN; ++j) bf[(ks + 1) & 1][j] = Pb[poff + j * ST * PW];
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -539,6 +540,170 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
                         float v = acc[i][j][e];
                         if (a.bias) v += a.bias[r];
                         float* o = a.out + (long)n * a.out_nstride + (long)r * HW + (long)y * a.W + x;
+                        if (a.accumulate) v += *o;
+                        *o = ghm_act(v, a.act, a.alpha);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Data gradient of a 3x3 / stride-2 / pad-1 convolution (U-Net encoder, PatchGAN) with an LDS patch of dy.
+// dx[c, 2i+pu, 2j+pv] only receives the taps whose parity matches (1, 2, 2 or 4 of the 9), so the four
+// output parity classes are four small stride-1 gathers over the SAME dy patch.  One block computes all
+// four classes of BM channels x (2 x 32) class pixels (= 4 x 64 dx pixels): every k-step (channel pair,
+// tap) feeds exactly one class, so the 9 taps cost 9 MFMA k-steps -- no zero-insertion waste -- and the
+// dy patch (3 x 33 per channel) and the transposed weight rows are staged once for all classes.
+// a.in = dy [N, CH=K, Hc, Wc] (class grid = conv output grid), a.out = dx [N, R=C, 2Hc, 2Wc],
+// a.wp = wpT[k][8 - tap][c].
+// ------------------------------------------------------------------------------------------------
+template <int BM, int WM, int CP>
+__global__ __launch_bounds__(256, 2) void dgrad_s2_patch_kernel(const PatchArgs a) {
+    constexpr int T = 9, CB = 2 * CP, RT = 2, WN = 2;
+    constexpr int LDA = BM + 4;
+    constexpr int PH = RT + 1, PWN = 33, PW = 33, PS = PH * PW;
+    constexpr int KR = CB * T;
+    constexpr int ASZ = KR * LDA, PSZ = ((CB * PS + 3) / 4) * 4;
+    constexpr int TM = BM / (WM * 32);
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int AV = BM / 4;
+    constexpr int AL = (KR * AV + 255) / 256;
+    constexpr int NEL = CB * PH * PWN;
+    constexpr int BL = (NEL + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Ps = smem + 2 * ASZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int frag_k = lane >> 5, frag_i = lane & 31;
+    const int Hc = a.Hin, Wc = a.Win;                 // class grid == dy grid
+    const int ntr = (a.R + BM - 1) / BM;
+    const int tiles_x = Wc / 32, tiles_y = Hc / RT;
+    int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int r0 = (L % ntr) * BM;
+    L /= ntr;
+    const int tx = L % tiles_x;
+    L /= tiles_x;
+    const int ty = L % tiles_y;
+    const int n = L / tiles_y;
+    const int i0 = ty * RT, j0 = tx * 32;
+    const int HWc = Hc * Wc, HWx = a.H * a.W;
+    const int nslabs = a.CH / CB;
+    const int s_begin = blockIdx.y * a.slabs_per_split;
+    const int s_end = min(nslabs, s_begin + a.slabs_per_split);
+
+    int a_off[AL], a_lds[AL];
+#pragma unroll
+    for (int q = 0; q < AL; ++q) {
+        const int e = tid + q * 256;
+        const int row = e / AV, c4 = e - row * AV;
+        const bool v = row < KR && (r0 + c4 * 4) < a.R;
+        a_lds[q] = v ? row * LDA + c4 * 4 : -1;
+        a_off[q] = v ? row * a.R + r0 + c4 * 4 : 0;
+    }
+    int p_off[BL], p_lds[BL];
+    unsigned pmask = 0;
+#pragma unroll
+    for (int q = 0; q < BL; ++q) {
+        const int e = tid + q * 256;
+        const int c = e / (PH * PWN), r = e - c * (PH * PWN);
+        const int py = r / PWN, px = r - py * PWN;
+        const int y = i0 + py, x = j0 + px;
+        const bool inr = e < NEL;
+        const bool ok = inr && y < Hc && x < Wc;
+        p_lds[q] = inr ? c * PS + py * PW + px : -1;
+        p_off[q] = ok ? c * HWc + y * Wc + x : 0;
+        pmask |= (ok ? 1u : 0u) << q;
+    }
+    const float* wbase = a.wp + (long)s_begin * KR * a.R;
+    const float* ibase = a.in + (long)n * a.in_nstride + (long)s_begin * CB * HWc;
+    const long a_step = (long)KR * a.R, p_step = (long)CB * HWc;
+
+    float areg[AL * 4];
+    float breg[BL];
+    auto load_slab = [&]() {
+#pragma unroll
+        for (int q = 0; q < AL; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(wbase + a_off[q]);
+            areg[4 * q + 0] = t.x; areg[4 * q + 1] = t.y; areg[4 * q + 2] = t.z; areg[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int q = 0; q < BL; ++q) breg[q] = ibase[p_off[q]];
+        wbase += a_step;
+        ibase += p_step;
+    };
+    auto store_slab = [&](int buf) {
+        float* Ab = As + buf * ASZ;
+        float* Pb = Ps + buf * PSZ;
+#pragma unroll
+        for (int q = 0; q < AL; ++q)
+            if (a_lds[q] >= 0)
+                *reinterpret_cast<float4*>(Ab + a_lds[q]) =
+                    make_float4(areg[4 * q + 0], areg[4 * q + 1], areg[4 * q + 2], areg[4 * q + 3]);
+#pragma unroll
+        for (int q = 0; q < BL; ++q)
+            if (p_lds[q] >= 0) Pb[p_lds[q]] = ((pmask >> q) & 1u) ? breg[q] : 0.f;
+    };
+
+    f32x16 acc[4][TM];                              // [parity class pu*2+pv][row tile]
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[cl][i][e] = 0.f;
+
+    if (s_begin < s_end) {
+        load_slab();
+        store_slab(0);
+    }
+    __syncthreads();
+    const int abase = frag_k * T * LDA + wm * (BM / WM) + frag_i;
+    const int pbase = frag_k * PS + wn * PW + frag_i;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        const bool more = (s + 1) < s_end;
+        if (more) load_slab();
+        const float* Ab = As + buf * ASZ + abase;
+        const float* Pb = Ps + buf * PSZ + pbase;
+#pragma unroll
+        for (int ks = 0; ks < CP * T; ++ks) {
+            const int cp = ks / T, tw = ks % T;             // tw: tap index in wpT order = 8 - original tap
+            const int ta = (8 - tw) / 3, tb = (8 - tw) % 3;  // original (a, b)
+            const int pu = ta == 1 ? 0 : 1, pv = tb == 1 ? 0 : 1;
+            const int di = ta == 0 ? 1 : 0, dj = tb == 0 ? 1 : 0;
+            const float bf = Pb[2 * cp * PS + di * PW + dj];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float af = Ab[(2 * cp * T + tw) * LDA + i * 32];
+                acc[pu * 2 + pv][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[pu * 2 + pv][i], 0, 0, 0);
+            }
+            if (ks == (CP * T) / 2 - 1 && more) store_slab(buf ^ 1);
+        }
+        __syncthreads();
+    }
+
+    const long P = (long)a.N * HWx;
+    const int ic = i0 + wn, jc = j0 + frag_i;
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl) {
+        const int y = 2 * ic + (cl >> 1), x = 2 * jc + (cl & 1);
+        const long pix = (long)n * HWx + (long)y * a.W + x;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = r0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * frag_k;
+                if (r < a.R) {
+                    if (a.partial) {
+                        a.partial[((long)blockIdx.y * a.R + r) * P + pix] = acc[cl][i][e];
+                    } else {
+                        float v = acc[cl][i][e];
+                        if (a.bias) v += a.bias[r];
+                        float* o = a.out + (long)n * a.out_nstride + (long)r * HWx + (long)y * a.W + x;
                         if (a.accumulate) v += *o;
                         *o = ghm_act(v, a.act, a.alpha);
                     }
@@ -1267,16 +1432,18 @@ struct PatchPlan {
     size_t lds;
 };
 
-PatchPlan plan_patch(int N, int CH, int H, int W, int R, int ks, int num_cu) {
+PatchPlan plan_patch(int N, int CH, int H, int W, int R, int ks, int num_cu, int st = 1) {
+    // H, W: OUTPUT grid
     PatchPlan p;
     p.ok = false;
     if (!(ks == 3 || ks == 5) || getenv("GHM_NO_PATCH")) return p;
+    if (st == 2 && (ks != 3 || getenv("GHM_NO_PATCH_S2"))) return p;
     p.bm = R >= 96 ? 128 : 64;
     p.rt = p.bm == 128 ? 4 : 8;
     const int cb = ks == 5 ? 2 : 4;
     if (R < 32 || (R & 3) || (W % 32) || (H % p.rt) || (CH % cb) || CH < 2 * cb) return p;
     const int T = ks * ks;
-    const int lda = p.bm + 4, ph = p.rt + ks - 1, pw = 32 + ks - 1;
+    const int lda = p.bm + 4, ph = (p.rt - 1) * st + ks, pw = 31 * st + ks;
     const int asz = cb * T * lda, psz = ((cb * ph * pw + 3) / 4) * 4;
     p.lds = (size_t)2 * (asz + psz) * sizeof(float);
     const int ntr = (R + p.bm - 1) / p.bm;
@@ -1294,7 +1461,7 @@ PatchPlan plan_patch(int N, int CH, int H, int W, int R, int ks, int num_cu) {
     return p;
 }
 
-int launch_patch(ghm_ctx* ctx, const PatchPlan& pl, PatchArgs a, int ks) {
+int launch_patch(ghm_ctx* ctx, const PatchPlan& pl, PatchArgs a, int ks, int st = 1) {
     a.slabs_per_split = pl.slabs_per_split;
     a.partial = nullptr;
     if (pl.splits > 1) {
@@ -1303,15 +1470,17 @@ int launch_patch(ghm_ctx* ctx, const PatchPlan& pl, PatchArgs a, int ks) {
         a.partial = (float*)ws;
     }
     const dim3 g(pl.grid, pl.splits);
-#define GHM_PATCH_CASE(KS_, BM_, RT_, WM_, WN_, CP_)                                                          \
-    if (ks == KS_ && pl.bm == BM_) {                                                                          \
-        hipLaunchKernelGGL((conv_patch_kernel<KS_, BM_, RT_, WM_, WN_, CP_>), g, dim3(256), pl.lds, ctx->stream, a); \
+#define GHM_PATCH_CASE(KS_, BM_, RT_, WM_, WN_, CP_, ST_)                                                     \
+    if (ks == KS_ && pl.bm == BM_ && st == ST_) {                                                             \
+        hipLaunchKernelGGL((conv_patch_kernel<KS_, BM_, RT_, WM_, WN_, CP_, ST_>), g, dim3(256), pl.lds, ctx->stream, a); \
         GHM_LAUNCH_CHECK();                                                                                   \
     } else
-    GHM_PATCH_CASE(5, 128, 4, 2, 2, 1)
-    GHM_PATCH_CASE(5, 64, 8, 1, 4, 1)
-    GHM_PATCH_CASE(3, 128, 4, 2, 2, 2)
-    GHM_PATCH_CASE(3, 64, 8, 1, 4, 2) {
+    GHM_PATCH_CASE(5, 128, 4, 2, 2, 1, 1)
+    GHM_PATCH_CASE(5, 64, 8, 1, 4, 1, 1)
+    GHM_PATCH_CASE(3, 128, 4, 2, 2, 2, 1)
+    GHM_PATCH_CASE(3, 64, 8, 1, 4, 2, 1)
+    GHM_PATCH_CASE(3, 128, 4, 2, 2, 2, 2)
+    GHM_PATCH_CASE(3, 64, 8, 1, 4, 2, 2) {
         ghm_set_error("no conv_patch variant for k=%d bm=%d", ks, pl.bm);
         return -3;
     }
@@ -1408,16 +1577,18 @@ int ghm_conv2d_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const f
         GHM_LAUNCH_CHECK();
         return 0;
     }
-    if (d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W) {
-        const PatchPlan pl = plan_patch(d->N, d->C, d->H, d->W, d->K, d->kh, ctx->num_cu);
+    if (d->kh == d->kw && ((d->stride == 1 && d->Ho == d->H && d->Wo == d->W) ||
+                           (d->stride == 2 && d->Ho * 2 == d->H && d->Wo * 2 == d->W))) {
+        const PatchPlan pl = plan_patch(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, ctx->num_cu, d->stride);
         if (pl.ok) {
             PatchArgs pa;
             memset(&pa, 0, sizeof(pa));
             pa.in = x; pa.wp = wp; pa.bias = bias; pa.out = y;
-            pa.N = d->N; pa.CH = d->C; pa.H = d->H; pa.W = d->W; pa.in_nstride = d->x_nstride;
+            pa.N = d->N; pa.CH = d->C; pa.H = d->Ho; pa.W = d->Wo; pa.Hin = d->H; pa.Win = d->W;
+            pa.in_nstride = d->x_nstride;
             pa.R = d->K; pa.out_nstride = d->y_nstride; pa.pad = d->pad;
             pa.act = act; pa.alpha = alpha; pa.accumulate = accumulate;
-            return launch_patch(ctx, pl, pa, d->kh);
+            return launch_patch(ctx, pl, pa, d->kh, d->stride);
         }
     }
     IgemmArgs a;
@@ -1491,6 +1662,13 @@ int ghm_conv2d_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, cons
     return 0;
 }
 
+int ghm_dgrad_t_supported(const ghm_conv_desc* d) {
+    if (d->stride == 1) return 1;
+    return d->stride == 2 && d->kh == 3 && d->kw == 3 && d->pad == 1 && d->H == 2 * d->Ho && d->W == 2 * d->Wo &&
+           d->Wo % 32 == 0 && d->Ho % 2 == 0 && d->K % 4 == 0 && d->K >= 8 && d->C % 4 == 0 && d->C >= 32 &&
+           getenv("GHM_NO_PATCH_S2") == nullptr;
+}
+
 int ghm_conv2d_transpose_weights(ghm_ctx* ctx, const ghm_conv_desc* d, const float* wp, float* wpT) {
     const int T = d->kh * d->kw;
     hipLaunchKernelGGL(transpose_weights_kernel, dim3(ceil_div(d->K, 32), ceil_div(d->C, 32), T), dim3(256), 0,
@@ -1502,8 +1680,52 @@ int ghm_conv2d_transpose_weights(ghm_ctx* ctx, const ghm_conv_desc* d, const flo
 int ghm_conv2d_dgrad_t(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const float* wpT, const float* bias,
                        float* dx, int32_t act, float alpha, int32_t accumulate) {
     if (int e = check_desc(d)) return e;
-    GHM_CHECK(d->stride == 1, "ghm_conv2d_dgrad_t: stride-1 convolutions only (got %d)", d->stride);
     GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    if (d->stride == 2) {
+        GHM_CHECK(ghm_dgrad_t_supported(d), "ghm_conv2d_dgrad_t: this stride-2 geometry has no transposed-weight kernel");
+        PatchArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.in = dy; pa.wp = wpT; pa.bias = bias; pa.out = dx;
+        pa.N = d->N; pa.CH = d->K; pa.H = d->H; pa.W = d->W; pa.Hin = d->Ho; pa.Win = d->Wo;
+        pa.in_nstride = d->y_nstride; pa.R = d->C; pa.out_nstride = d->x_nstride; pa.pad = d->pad;
+        pa.act = act; pa.alpha = alpha; pa.accumulate = accumulate;
+        const int bm = d->C >= 96 ? 128 : 64;
+        constexpr int cb = 4;
+        const int ntr = (d->C + bm - 1) / bm;
+        const int grid = ntr * (d->Wo / 32) * (d->Ho / 2) * d->N;
+        const int nslabs = d->K / cb;
+        int splits = 1;
+        if (grid < ctx->num_cu + ctx->num_cu / 2) {
+            splits = (2 * ctx->num_cu + grid - 1) / grid;
+            const int maxs = nslabs / 4 > 0 ? nslabs / 4 : 1;
+            if (splits > maxs) splits = maxs;
+        }
+        pa.slabs_per_split = (nslabs + splits - 1) / splits;
+        splits = (nslabs + pa.slabs_per_split - 1) / pa.slabs_per_split;
+        if (splits > 1) {
+            void* ws = nullptr;
+            if (int e = ghm_scratch(ctx, (size_t)splits * pa.R * pa.N * pa.H * pa.W * sizeof(float), &ws)) return e;
+            pa.partial = (float*)ws;
+        }
+        const size_t lds = (size_t)2 * (cb * 9 * (bm + 4) + ((cb * 99 + 3) / 4) * 4) * sizeof(float);
+        const dim3 g(grid, splits);
+        if (bm == 128)
+            hipLaunchKernelGGL((dgrad_s2_patch_kernel<128, 2, 2>), g, dim3(256), lds, ctx->stream, pa);
+        else
+            hipLaunchKernelGGL((dgrad_s2_patch_kernel<64, 2, 2>), g, dim3(256), lds, ctx->stream, pa);
+        GHM_LAUNCH_CHECK();
+        if (splits > 1) {
+            IgemmArgs e;
+            memset(&e, 0, sizeof(e));
+            e.partial = pa.partial; e.out = dx; e.bias = bias; e.N = d->N; e.R = d->C;
+            e.Hout = d->H; e.Wout = d->W; e.out_nstride = d->x_nstride; e.Hs = d->H; e.Ws = d->W; e.os = 1;
+            e.act = act; e.alpha = alpha; e.accumulate = accumulate;
+            hipLaunchKernelGGL(igemm_splitk_epilogue, dim3(ceil_div((long)d->N * d->H * d->W * d->C, 256)), dim3(256), 0,
+                               ctx->stream, e, splits);
+            GHM_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     // the data gradient of a stride-1 conv is the forward conv K -> C with flipped taps (already folded into
     // wpT by ghm_conv2d_transpose_weights) and padding k-1-pad
     const int padT = d->kh - 1 - d->pad;
@@ -1513,7 +1735,8 @@ int ghm_conv2d_dgrad_t(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, co
             PatchArgs pa;
             memset(&pa, 0, sizeof(pa));
             pa.in = dy; pa.wp = wpT; pa.bias = bias; pa.out = dx;
-            pa.N = d->N; pa.CH = d->K; pa.H = d->H; pa.W = d->W; pa.in_nstride = d->y_nstride;
+            pa.N = d->N; pa.CH = d->K; pa.H = d->H; pa.W = d->W; pa.Hin = d->H; pa.Win = d->W;
+            pa.in_nstride = d->y_nstride;
             pa.R = d->C; pa.out_nstride = d->x_nstride; pa.pad = padT;
             pa.act = act; pa.alpha = alpha; pa.accumulate = accumulate;
             return launch_patch(ctx, pl, pa, d->kh);
@@ -1661,19 +1884,22 @@ int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t 
         snprintf(out, out_len, "taps_as_rows<%s>", kind == 0 ? "fwd" : (kind == 1 ? "dgrad" : "wgrad"));
         return 0;
     }
-    if (kind == 0 && d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W) {
-        const PatchPlan pl = plan_patch(d->N, d->C, d->H, d->W, d->K, d->kh, 256);
+    if (kind == 0 && d->kh == d->kw && ((d->stride == 1 && d->Ho == d->H && d->Wo == d->W) ||
+                                        (d->stride == 2 && d->Ho * 2 == d->H && d->Wo * 2 == d->W))) {
+        const PatchPlan pl = plan_patch(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 256, d->stride);
         if (pl.ok) {
-            snprintf(out, out_len, "conv_patch_kernel<%d, %d, %d, %d, %d, %d> splits=%d", d->kh, pl.bm, pl.rt,
-                     pl.bm == 128 ? 2 : 1, pl.bm == 128 ? 2 : 4, d->kh == 5 ? 1 : 2, pl.splits);
+            snprintf(out, out_len, "conv_patch_kernel<%d, %d, %d, %d, %d, %d, %d> splits=%d", d->kh, pl.bm, pl.rt,
+                     pl.bm == 128 ? 2 : 1, pl.bm == 128 ? 2 : 4, d->kh == 5 ? 1 : 2, d->stride, pl.splits);
             return 0;
         }
     }
     if (kind == 3) {      // data gradient through transposed weights
         const PatchPlan pl = plan_patch(d->N, d->K, d->H, d->W, d->C, d->kh, 256);
         if (d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W && pl.ok)
-            snprintf(out, out_len, "conv_patch_kernel<%d, %d, %d, %d, %d, %d> splits=%d", d->kh, pl.bm, pl.rt,
+            snprintf(out, out_len, "conv_patch_kernel<%d, %d, %d, %d, %d, %d, 1> splits=%d", d->kh, pl.bm, pl.rt,
                      pl.bm == 128 ? 2 : 1, pl.bm == 128 ? 2 : 4, d->kh == 5 ? 1 : 2, pl.splits);
+        else if (d->stride == 2)
+            snprintf(out, out_len, "dgrad_s2_patch_kernel<%d, 2, 2>", d->C >= 96 ? 128 : 64);
         else
             snprintf(out, out_len, "igemm_kernel<fwd on wT>");
         return 0;

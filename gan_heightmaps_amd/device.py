@@ -225,6 +225,9 @@ class Ops:
         call("ghm_conv2d_dgrad", self.h, C.byref(d), _vp(dy), _vp(wp), _vp(bias), _vp(dx), ACT_CODES[act], alpha,
              int(accumulate))
 
+    def dgrad_t_supported(self, d):
+        return bool(_lib.load().ghm_dgrad_t_supported(C.byref(d)))
+
     def transpose_weights(self, d, wp, wpT):
         call("ghm_conv2d_transpose_weights", self.h, C.byref(d), _vp(wp), _vp(wpT))
 

@@ -506,8 +506,8 @@ class NetPlan:
                         d2 = self._desc(n, G, gi)
                         prog.append(("deconv_dgrad", lambda d=d2, G=G, w=w, gi=gi, acc=acc:
                                      ops.conv2d_fwd(d, G, w, None, gi, 'linear', 0.0, acc), conv_meta(ops, d2, 0)))
-                    elif n.op == 'conv' and l.stride[0] == 1 and l.W.shape[1] > 4:
-                        # stride-1 data gradient = forward conv on the transposed weights (LDS-patch kernel)
+                    elif n.op == 'conv' and l.W.shape[1] > 4 and ops.dgrad_t_supported(self._desc(n, gi, G)):
+                        # data gradient as a forward-form conv on the transposed weights (LDS-patch kernels)
                         d2 = self._desc(n, gi, G)
                         wT = st.transposed(l.W)
                         if id(l.W) not in transposed:

@@ -52,6 +52,10 @@ CONV_CASES = [
     (1, 32, 64, 64, 64, 5, 1, 2),     # conv_patch_kernel 5x5, 64-row tile (8x32 pixel tile)
     (2, 48, 32, 64, 160, 3, 1, 1),    # conv_patch_kernel 3x3, ragged filter tile, rectangular
     (1, 64, 32, 32, 64, 3, 1, 1),     # conv_patch_kernel 3x3, 64-row tile
+    (2, 32, 64, 64, 128, 3, 2, 1),    # conv_patch_kernel 3x3 stride 2, 128-row tile (-> 32x32)
+    (1, 16, 64, 128, 64, 3, 2, 1),    # conv_patch_kernel 3x3 stride 2, 64-row tile, rectangular
+    (2, 128, 64, 64, 40, 3, 2, 1),    # dgrad_s2_patch_kernel, 128 dx channels, ragged filters (40 % 4 == 0)
+    (1, 48, 128, 64, 24, 3, 2, 1),    # dgrad_s2_patch_kernel, 64-row tile (48 channels), rectangular
 ]
 
 
@@ -83,8 +87,8 @@ def test_conv_fwd_dgrad_wgrad(gpu, case, tile):
     assert rel(dxd.numpy(), dx_ref) < TOL
     ops.conv2d_dgrad(d, dyd, wd, dxd, accumulate=True)
     assert rel(dxd.numpy(), 2 * dx_ref) < TOL
-    if s == 1:
-        # stride-1 data gradient as a forward conv on the transposed packed weights
+    if ops.dgrad_t_supported(d):
+        # data gradient as a forward-form conv on the transposed packed weights
         wtd = dev.zeros((1, C * k * k * K, 1, 1))
         ops.transpose_weights(d, wd, wtd)
         wp_host = D.pack_conv_w(Wt)                                   # [C, T, K]

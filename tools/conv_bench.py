@@ -31,7 +31,11 @@ def main():
     dw = dev.zeros((1, C * k * k * K, 1, 1))
     ws = dev.alloc(ops.wgrad_workspace(d))
     flops = 2.0 * N * K * d.Ho * d.Wo * C * k * k
+    wT = dev.empty((1, C * k * k * K, 1, 1))
+    if ops.dgrad_t_supported(d):
+        ops.transpose_weights(d, w, wT)
     fns = {"fwd": lambda: ops.conv2d_fwd(d, x, w, b, y, 'lrelu', 0.2),
+           "dgrad_t": lambda: ops.conv2d_dgrad_t(d, y, wT, dx),
            "dgrad": lambda: ops.conv2d_dgrad(d, y, w, dx),
            "wgrad": lambda: ops.conv2d_wgrad(d, x, y, dw, ws)}
     for i, kind in enumerate(args.kinds.split(",")):
@@ -45,7 +49,7 @@ def main():
         dev.timer_stop(0)
         ms = dev.timer_ms(0) / args.reps
         print("%-6s %-34s %8.3f ms  %7.1f TFLOP/s  (%.1f GFLOP)" %
-              (kind, ops.conv_variant(d, ["fwd", "dgrad", "wgrad"].index(kind)), ms, flops / ms / 1e9, flops / 1e9))
+              (kind, ops.conv_variant(d, ["fwd", "dgrad", "wgrad", "dgrad_t"].index(kind)), ms, flops / ms / 1e9, flops / 1e9))
     dev.close()
 
 
