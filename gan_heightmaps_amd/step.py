@@ -48,7 +48,7 @@ def _interleave(a, b):
 
 class GanStep:
     def __init__(self, dev, dcgan_gen, dcgan_disc, p2p_gen, p2p_disc, alpha, lsgan, reconstruction, opt_spec,
-                 train_mode='both', comm=None, use_graph=True, two_streams=True):
+                 train_mode='both', comm=None, use_graph=True, two_streams=True, force_exchange=False):
         self.dev = dev
         self.devs = [dev, Device(dev.index) if two_streams else dev]
         self.ops = [Ops(self.devs[0]), Ops(self.devs[1])]
@@ -59,6 +59,9 @@ class GanStep:
         self.opt_spec, self.train_mode = opt_spec, train_mode
         self.comm = comm
         self.world = comm.world if comm is not None else 1
+        # data-parallel code path (stream hand-over, RCCL all-reduce, updates on stream A) even with one rank:
+        # lets a single-GPU box exercise exactly what N ranks run
+        self.exchange = self.world > 1 or (force_exchange and comm is not None)
         self.use_graph = use_graph
         for k in ('dcgan_disc', 'p2p_disc'):
             if _has_bn(self.nets[k]):
@@ -185,7 +188,7 @@ class GanStep:
         # ---- exchange + update (:131-141) ----
         keys = (['dcgan_gen', 'dcgan_disc'] if do_dcgan else []) + (['p2p_gen', 'p2p_disc'] if do_p2p else [])
         b.exchange = []
-        if self.world > 1:
+        if self.exchange:
             # one communicator, on stream A: wait for the pix2pix stream, sum every bucket, update everything on
             # stream A, then let stream B continue behind it
             for k in keys:
@@ -197,7 +200,7 @@ class GanStep:
         b.update = [[], []]
         for k in keys:
             st, hy = self.stores[k], self.hyper[k]
-            lane = 0 if self.world > 1 else LANE_OF[k]
+            lane = 0 if self.exchange else LANE_OF[k]
             o = self.ops[lane]
             if self.opt_spec.kind == 'rmsprop':
                 b.update[lane].append(("rmsprop_" + k, lambda st=st, hy=hy, o=o: o.rmsprop(
@@ -274,7 +277,7 @@ class GanStep:
     def enqueue_train(self, b, wrap=None):
         """one train step on the data already resident in b.z / b.x / b.y (asynchronous)"""
         dA, dB = self.devs
-        if self.world > 1:
+        if self.exchange:
             self._run_lanes(b, 'train_compute', b.train_compute, wrap)
             if dB is not dA:
                 dA.wait_for(dB)
@@ -292,7 +295,7 @@ class GanStep:
         b = self.built(int(np.shape(X)[0]))
         self._upload(b, Z, X, Y)
         self._run_lanes(b, 'loss', b.loss_prog)
-        if self.world > 1:
+        if self.exchange:
             self.sync()
             self.ops[0].allreduce_sum(self.losses_dev, 8)
         return self._read_losses()
@@ -309,7 +312,7 @@ class GanStep:
                 e[1]()
                 dev.timer_stop(1)
                 out.append((e[0], dev.timer_ms(1), e[2] if len(e) > 2 else None))
-        if self.world > 1:
+        if self.exchange:
             self.sync()
             for e in b.exchange:
                 e[1]()

@@ -49,7 +49,7 @@ def test_conv_variant_and_workspace_queries_are_host_only():
     from gan_heightmaps_amd._lib import call
     d = D.conv_desc(8, 64, 256, 256, 128, 5, 5, 1, 2)
     out = C.create_string_buffer(128)
-    for kind, want in [(0, "conv_patch_kernel<5, 128, 4, 2, 2, 1, 1>"), (1, "igemm_kernel<64,256,wt>"),
+    for kind, want in [(0, "conv_patch_kernel<5, 64, 8, 1, 4, 1, 1>"), (1, "igemm_kernel<64,256,wt>"),
                        (2, "wgrad_patch_kernel<5, 1, 128, 2, 2, 32>"), (3, "conv_patch_kernel<5, 64, 8, 1, 4, 1, 1>")]:
         call("ghm_conv2d_variant", C.byref(d), kind, out, 128)
         assert out.value.decode().startswith(want), out.value
