@@ -499,7 +499,11 @@ class NetPlan:
                     else:
                         prog.append(("%s_wgrad" % n.op, lambda d=d, G=G, x=x, gw=gw, aw=aw:
                                      ops.conv2d_wgrad(d, x, G, gw, self.wgrad_ws, aw), conv_meta(ops, d, 2)))
-                    prog.append(("bias_grad", lambda G=G, gb=gb, aw=aw: ops.channel_sum(G, gb, aw)))
+                    # a bias that feeds a BatchNorm has an identically zero gradient (the BN backward output sums to
+                    # zero per channel): its slice of the zero-initialised gradient buffer is simply never written
+                    bn_fed = len(n.consumers) == 1 and n.consumers[0].op == 'bn' and n.act == linear
+                    if not bn_fed:
+                        prog.append(("bias_grad", lambda G=G, gb=gb, aw=aw: ops.channel_sum(G, gb, aw)))
                 if need_dx:
                     gi, acc = target(xin)
                     if n.op == 'deconv':
