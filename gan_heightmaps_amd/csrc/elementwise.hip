@@ -378,6 +378,57 @@ __global__ __launch_bounds__(256) void up_bilinear_bwd_kernel(const float* __res
     *p = s;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// input pipeline (/root/reference/util.py:28-40 + Keras ImageDataGenerator): one pass that turns a
+// uint8 NHWC batch into the normalised fp32 NCHW tensor the nets consume, resampled through a per-sample affine
+// map (rotation about the centre, then column / row flips) with nearest-neighbour lookup and 'reflect' borders
+// -- scipy.ndimage.affine_transform(order=0, mode='reflect') semantics, coordinates in fp64 with separate
+// roundings (no fma) so that the sampled indices agree with scipy.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double reflect_coord(double in, int len) {
+    if (len <= 1) return 0.0;
+    const long sz2 = 2L * len;
+    if (in < 0) {
+        if (in < -(double)sz2) in = (double)sz2 * (double)(long)(-in / (double)sz2) + in;
+        in = in < -(double)len ? in + (double)sz2 : (in > -1e-15 ? 1e-15 : -in) - 1.0;
+    } else if (in > (double)(len - 1)) {
+        in -= (double)sz2 * (double)(long)(in / (double)sz2);
+        if (in >= (double)len) in = (double)sz2 - in - 1.0;
+    }
+    return in;
+}
+
+// xf[n] = {m00, m01, off0, m10, m11, off1, hflip, vflip}
+__global__ __launch_bounds__(256) void image_batch_kernel(const unsigned char* __restrict__ src, int N, int H, int W, int C,
+                                                          const double* __restrict__ xf, int mode, float* __restrict__ dst,
+                                                          long dst_nstride) {
+    const long hw = (long)H * W;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)N * hw) return;
+    const int n = (int)(idx / hw), rem = (int)(idx - (long)n * hw);
+    const int i = rem / W, j = rem - i * W;
+    const double* m = xf + 8 * n;
+    const int ii = m[7] != 0.0 ? H - 1 - i : i;           // flips act on the transformed image
+    const int jj = m[6] != 0.0 ? W - 1 - j : j;
+    double cy = m[2], cx = m[5];
+    cy = __dadd_rn(cy, __dmul_rn((double)ii, m[0]));
+    cy = __dadd_rn(cy, __dmul_rn((double)jj, m[1]));
+    cx = __dadd_rn(cx, __dmul_rn((double)ii, m[3]));
+    cx = __dadd_rn(cx, __dmul_rn((double)jj, m[4]));
+    cy = reflect_coord(cy, H);
+    cx = reflect_coord(cx, W);
+    int sy = (int)floor(cy + 0.5), sx = (int)floor(cx + 0.5);
+    sy = min(max(sy, 0), H - 1);
+    sx = min(max(sx, 0), W - 1);
+    const unsigned char* sp = src + (((long)n * H + sy) * W + sx) * C;
+    float* dp = dst + (long)n * dst_nstride + rem;
+    for (int c = 0; c < C; ++c) {
+        const float v = (float)sp[c];
+        dp[(long)c * hw] = mode == 0 ? v / 255.0f : (v - 127.5f) / 127.5f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // losses: single-pass grid-stride with fp64 block partials + one atomic per block
 // ---------------------------------------------------------------------------------------------
@@ -702,6 +753,15 @@ int ghm_recon_loss(ghm_ctx* ctx, const float* a, int64_t as, const float* b, int
                        grad_scale, accumulate_grad, (double*)ws);
     GHM_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1), 0, ctx->stream, (const double*)ws, g, loss_out, 0);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_image_batch(ghm_ctx* ctx, const uint8_t* src_nhwc, int32_t N, int32_t H, int32_t W, int32_t C,
+                    const double* xform, int32_t tanh_range, float* dst, int64_t dst_nstride) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(image_batch_kernel, EW_GRID((long)N * H * W), src_nhwc, N, H, W, C, xform, tanh_range ? 1 : 0, dst,
+                       (long)dst_nstride);
     GHM_LAUNCH_CHECK();
     return 0;
 }

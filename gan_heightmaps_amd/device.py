@@ -311,6 +311,10 @@ class Ops:
     def axpby(self, a, x, b, y, n):
         call("ghm_axpby", self.h, a, _vp(x), b, _vp(y), int(n))
 
+    def image_batch(self, src_u8_ptr, N, H, W, Cc, xform_ptr, tanh_range, dst):
+        call("ghm_image_batch", self.h, C.c_void_p(int(src_u8_ptr)), N, H, W, Cc, C.c_void_p(int(xform_ptr)),
+             int(tanh_range), _vp(dst), dst.nstride)
+
     def lsgan_loss(self, d, target, loss_out, grad=None, grad_scale=1.0, accumulate_loss=False):
         assert d.contiguous
         call("ghm_lsgan_loss", self.h, _vp(d), d.size, target, _vp(loss_out), _vp(grad), grad_scale,

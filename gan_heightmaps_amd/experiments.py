@@ -53,7 +53,11 @@ def synthetic_arrays(n, in_shp, is_a_grayscale, is_b_grayscale, seed=0):
     return X, Y
 
 
-def get_iterators(dataset, batch_size, is_a_grayscale, is_b_grayscale, da=True, in_shp=512, n_synthetic=8):
+def get_iterators(dataset, batch_size, is_a_grayscale, is_b_grayscale, da=True, in_shp=512, n_synthetic=8, device=None):
+    """experiments.get_iterators (experiments.py:10-18): (it_train, it_val) over the xt/yt/xv/yv arrays of the
+    dataset, augmented with flips + 360-degree rotation + reflect fill when ``da``.  The reference opens an HDF5
+    file (h5py is not available here): an ``.npz`` with the same four keys is read instead, else synthetic data."""
+    from .data import Hdf5Iterator, ImageDataGenerator
     if dataset is not None and os.path.exists(dataset) and dataset.endswith(".npz"):
         d = np.load(dataset)
         xt, yt, xv, yv = d['xt'], d['yt'], d['xv'], d['yv']
@@ -62,8 +66,15 @@ def get_iterators(dataset, batch_size, is_a_grayscale, is_b_grayscale, da=True, 
             print("dataset %r not available: using synthetic 512x512 batches" % (dataset,), file=sys.stderr)
         xt, yt = synthetic_arrays(n_synthetic, in_shp, is_a_grayscale, is_b_grayscale, 0)
         xv, yv = xt, yt
-    return (ArrayIterator(xt, yt, batch_size, is_a_grayscale, is_b_grayscale),
-            ArrayIterator(xv, yv, batch_size, is_a_grayscale, is_b_grayscale))
+    if da:
+        imgen = ImageDataGenerator(horizontal_flip=True, vertical_flip=True, rotation_range=360, fill_mode="reflect")
+    else:
+        imgen = ImageDataGenerator()
+    it_train = Hdf5Iterator(xt, yt, batch_size, imgen, is_a_grayscale=is_a_grayscale, is_b_grayscale=is_b_grayscale,
+                            device=device)
+    it_val = Hdf5Iterator(xv, yv, batch_size, imgen, is_a_grayscale=is_a_grayscale, is_b_grayscale=is_b_grayscale,
+                          device=device)
+    return it_train, it_val
 
 
 # kwargs of the three experiments (experiments.py:24-41, :63-79, :102-119)

@@ -118,10 +118,15 @@ class Pix2Pix:
 
         def _loop(fn, itr, src):
             rec = [[] for _ in self.train_keys]
+            on_device = hasattr(src, 'next_into')          # gan_heightmaps_amd.data.Hdf5Iterator: batch stays in HBM
             for _ in range(itr.N // batch_size):
-                X_batch, Y_batch = _next(src)
-                Z_batch = floatX(self.sampler(X_batch.shape[0], self.latent_dim))
-                results = fn(Z_batch, X_batch, Y_batch)
+                if on_device:
+                    results = self.engine.run_from_iterator(
+                        src, lambda n: floatX(self.sampler(n, self.latent_dim)), train=fn is self.train_fn)
+                else:
+                    X_batch, Y_batch = _next(src)
+                    Z_batch = floatX(self.sampler(X_batch.shape[0], self.latent_dim))
+                    results = fn(Z_batch, X_batch, Y_batch)
                 for i, r in enumerate(results):
                     rec[i].append(r)
                 if quick_run:

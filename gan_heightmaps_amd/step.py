@@ -274,6 +274,24 @@ class GanStep:
         self.enqueue_train(b)
         return self._read_losses() if read_losses else None
 
+    def run_from_iterator(self, it, Z_sampler, train=True):
+        """One train_fn / loss_fn call whose (A, B) batch is produced on the device by a data.Hdf5Iterator
+        (uint8 upload + ghm_image_batch straight into the step's input buffers; no fp32 host batch)."""
+        n = it.peek_n()
+        b = self.built(n)
+        self.sync()
+        it.next_into(b.x, b.y)
+        b.z.set(np.ascontiguousarray(Z_sampler(n), np.float32))
+        self.sync()
+        if train:
+            self.enqueue_train(b)
+        else:
+            self._run_lanes(b, 'loss', b.loss_prog)
+            if self.exchange:
+                self.sync()
+                self.ops[0].allreduce_sum(self.losses_dev, 8)
+        return self._read_losses()
+
     def enqueue_train(self, b, wrap=None):
         """one train step on the data already resident in b.z / b.x / b.y (asynchronous)"""
         dA, dB = self.devs

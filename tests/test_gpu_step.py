@@ -198,3 +198,31 @@ def test_data_parallel_code_path_with_one_rank(dev):
                 assert np.array_equal(a, b)
     finally:
         comm.close()
+
+
+def test_train_loop_with_device_iterator(dev, tmp_path):
+    """Pix2Pix.train (pix2pix.py:187-275) end to end at small scale: device-side data iterator with augmentation,
+    CSV log with the reference's header, checkpoint every `save_every` epochs, quick_run."""
+    from gan_heightmaps_amd import data as D
+    cfg = ostep.default_cfg(**SMALL)
+    m = build_model(cfg, 7, dev)
+    rng = np.random.RandomState(0)
+    X = rng.randint(0, 256, (8, 32, 32, 1)).astype(np.uint8)
+    Y = rng.randint(0, 256, (8, 32, 32, 3)).astype(np.uint8)
+    imgen = D.ImageDataGenerator(horizontal_flip=True, vertical_flip=True, rotation_range=360, fill_mode="reflect")
+    it_t = D.Hdf5Iterator(X, Y, 4, imgen, True, False, device=dev)
+    it_v = D.Hdf5Iterator(X, Y, 4, imgen, True, False, device=dev)
+    out, models = str(tmp_path / "out"), str(tmp_path / "models")
+    m.train(it_t, it_v, batch_size=4, num_epochs=2, out_dir=out, model_dir=models, save_every=2)
+    lines = open(out + "/results.txt").read().strip().split("\n")
+    assert lines[0].split(",") == ["epoch"] + ["train_" + k for k in m.train_keys] + ["valid_" + k for k in m.train_keys] \
+        + ["lr", "time", "mode"]
+    assert len(lines) == 3 and lines[2].startswith("2,") and lines[2].endswith(",both")
+    vals = np.array([float(v) for v in lines[1].split(",")[1:11]])
+    assert np.all(np.isfinite(vals)) and np.all(vals > 0)
+    import os
+    assert os.path.exists(models + "/2.model")
+    m2 = build_model(cfg, 99, dev)
+    m2.load_model(models + "/2.model")
+    Zb, Xb, Yb = ostep.synthetic_batch(4, cfg, seed=1)
+    assert rel(m2.loss_fn(Zb, Xb, Yb), m.loss_fn(Zb, Xb, Yb)) < 1e-6
