@@ -17,6 +17,7 @@ from . import layers as L
 from .device import Device
 from .step import GanStep, TRAIN_KEYS
 from .updates import adam, shared, OptimizerSpec
+from .util import convert_to_rgb, imsave
 
 floatX = _init.floatX
 
@@ -171,48 +172,95 @@ class Pix2Pix:
                 self.save_model("%s/%i.model" % (model_dir, e + 1))
         f.close()
 
-    # ---- sampling helpers (pix2pix.py:276-326), PNG output through PIL when available ----------------------
+    # ---- sampling helpers (pix2pix.py:276-425): forward-only, PNG output through util.imsave (PIL) --------
     @staticmethod
-    def _save_png(path, img_chw_01):
-        try:
-            from PIL import Image
-        except ImportError:         # pragma: no cover
-            np.save(path + ".npy", img_chw_01)
-            return
-        a = np.clip(img_chw_01, 0, 1)
-        a = (a.transpose(1, 2, 0) * 255).astype(np.uint8)
-        if a.shape[2] == 1:
-            a = a[:, :, 0]
-        Image.fromarray(a).save(path)
+    def _next(itr):
+        return next(itr) if hasattr(itr, '__next__') else itr.next()
 
-    @staticmethod
-    def _to_01(img, is_grayscale):
-        """util.convert_to_rgb range handling: grayscale is already [0,1], colour is [-1,1]"""
-        return img if is_grayscale else (img + 1.0) / 2.0
-
-    def generate_atob(self, itr, num_batches, out_dir, deterministic=False):
-        os.makedirs(out_dir, exist_ok=True)
+    def generate_atob(self, itr, num_batches, out_dir, dont_predict=False, deterministic=True):
+        """pix2pix samples (pix2pix.py:276-305): for every element of ``num_batches`` batches write
+        ``<ctr>.a.png`` (the input A) and ``<ctr>.b.png`` (U(A), or the iterator's own B when
+        ``dont_predict``)."""
         fn = self.gen_fn_det if deterministic else self.gen_fn
+        os.makedirs(out_dir, exist_ok=True)
         ctr = 0
         for _ in range(num_batches):
-            this_x, this_y = next(itr) if hasattr(itr, '__next__') else itr.next()
-            pred = fn(this_x)
-            for i in range(pred.shape[0]):
-                a = self._to_01(this_x[i], self.is_a_grayscale)
-                b = self._to_01(pred[i], self.is_b_grayscale)
-                if a.shape[0] != b.shape[0]:
-                    a = np.repeat(a, 3, axis=0) if a.shape[0] == 1 else a
-                    b = np.repeat(b, 3, axis=0) if b.shape[0] == 1 else b
-                self._save_png("%s/%i.png" % (out_dir, ctr), np.concatenate([a, b], axis=2))
+            this_x, this_y = self._next(itr)
+            pred_y = this_y if dont_predict else fn(this_x)
+            for i in range(pred_y.shape[0]):
+                imsave("%s/%i.a.png" % (out_dir, ctr), convert_to_rgb(this_x[i], is_grayscale=self.is_a_grayscale))
+                imsave("%s/%i.b.png" % (out_dir, ctr), convert_to_rgb(pred_y[i], is_grayscale=self.is_b_grayscale))
                 ctr += 1
 
-    def generate_gz(self, num_examples, batch_size, out_dir, deterministic=False):
+    def generate_gz(self, num_examples, batch_size, out_dir, deterministic=True):
+        """DCGAN samples g(z) (pix2pix.py:306-326): one draw of ``sampler(num_examples, latent_dim)``,
+        ``num_examples // batch_size`` forward passes, ``<ctr>.png`` each."""
         os.makedirs(out_dir, exist_ok=True)
         fn = self.z_fn_det if deterministic else self.z_fn
+        z = floatX(self.sampler(num_examples, self.latent_dim))
         ctr = 0
-        for _ in range(max(num_examples // batch_size, 1)):
-            z = floatX(self.sampler(batch_size, self.latent_dim))
-            out = fn(z)
+        for b in range(num_examples // batch_size):
+            out = fn(z[b * batch_size:(b + 1) * batch_size])
             for i in range(out.shape[0]):
-                self._save_png("%s/%i.png" % (out_dir, ctr), self._to_01(out[i], self.is_a_grayscale))
+                imsave("%s/%i.png" % (out_dir, ctr), convert_to_rgb(out[i], is_grayscale=self.is_a_grayscale))
+                ctr += 1
+
+    def interpolation_grid(self, zsample1=None, zsample2=None, deterministic=True, mode='row'):
+        """The decoded interpolation of generate_interpolation as an array [rows, cols, H, W, 3]:
+        'row' = 1x6 with coefficients (0, .1, .3, .6, .9, 1), 'matrix' = 5x5 with linspace(0, 1, 25)
+        (pix2pix.py:344-368).  All coefficients go through the generator as ONE batch (the reference
+        runs 6 / 25 batch-1 calls; with deterministic BN the result per sample is the same)."""
+        assert mode in ['row', 'matrix']
+        fn = self.z_fn_det if deterministic else self.z_fn
+        if zsample1 is None:
+            zsample1 = floatX(self.sampler(1, self.latent_dim))[0]
+        if zsample2 is None:
+            zsample2 = floatX(self.sampler(1, self.latent_dim))[0]
+        zsample1, zsample2 = np.asarray(zsample1), np.asarray(zsample2)
+        if mode == 'row':
+            rows, cols, coefs = 1, 6, np.asarray([0.0, 0.1, 0.3, 0.6, 0.9, 1.0], zsample1.dtype)
+        else:
+            rows, cols, coefs = 5, 5, np.linspace(0, 1, 25).astype(zsample1.dtype)
+        z = (1 - coefs)[:, None] * zsample1[None] + coefs[:, None] * zsample2[None]
+        if deterministic:
+            out = fn(floatX(z))
+        else:       # batch statistics would couple the samples: keep the reference's batch-1 calls
+            out = np.concatenate([fn(floatX(z[i:i + 1])) for i in range(len(coefs))], axis=0)
+        grid = np.zeros((rows, cols, self.in_shp, self.in_shp, 3), dtype=zsample1.dtype)
+        for n in range(len(coefs)):
+            grid[n // cols][n % cols] = convert_to_rgb(out[n], is_grayscale=self.is_a_grayscale)
+        return grid
+
+    def generate_interpolation(self, out_name, zsample1=None, zsample2=None, deterministic=True, mode='row',
+                               figsize=(10, 10), cmap='gray'):
+        """Write the interpolation grid between two prior samples as one figure (pix2pix.py:328-369)."""
+        from . import image_grid
+        grid = self.interpolation_grid(zsample1, zsample2, deterministic, mode)
+        image_grid.write_image_grid(out_name, grid, figsize=figsize, cmap=cmap)
+
+    def generate_interpolation_clip(self, num_samples, batch_size, out_dir, deterministic=True, min_max_norm=False,
+                                    concat=False):
+        """Frames of a long interpolation z1 -> z2 -> ... -> zn, 25 steps per leg, each decoded to a heightmap
+        G(z) and textured by U(G(z)) (pix2pix.py:371-425).  The G -> U chain stays in HBM
+        (GanStep.generate_chain); ``a_%04d.png``/``b_%04d.png`` or ``concat_%04d.png`` per frame."""
+        os.makedirs(out_dir, exist_ok=True)
+        zs = floatX(self.sampler(num_samples, self.latent_dim))
+        coefs = np.linspace(0, 1, 25).astype(zs.dtype)
+        legs = [(1 - coefs)[:, None] * zs[i][None] + coefs[:, None] * zs[i + 1][None] for i in range(len(zs) - 1)]
+        all_z = np.concatenate(legs, axis=0).astype(zs.dtype) if legs else np.zeros((0, self.latent_dim), zs.dtype)
+        ctr = 0
+        for b in range(all_z.shape[0] // batch_size):
+            z_out, p2p_out = self.engine.generate_chain(all_z[b * batch_size:(b + 1) * batch_size], deterministic)
+            for i in range(z_out.shape[0]):
+                a_img = z_out[i]
+                if min_max_norm:
+                    a_img = (a_img - np.min(a_img)) / (np.max(a_img) - np.min(a_img))
+                a_img = convert_to_rgb(a_img, is_grayscale=self.is_a_grayscale)
+                b_img = convert_to_rgb(p2p_out[i], is_grayscale=self.is_b_grayscale)
+                d = '%04d' % ctr
+                if concat:
+                    imsave("%s/concat_%s.png" % (out_dir, d), np.concatenate([a_img, b_img], axis=1))
+                else:
+                    imsave("%s/a_%s.png" % (out_dir, d), a_img)
+                    imsave("%s/b_%s.png" % (out_dir, d), b_img)
                 ctr += 1

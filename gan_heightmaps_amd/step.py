@@ -356,3 +356,23 @@ class GanStep:
         for e in prog:
             e[1]()
         return plan.out.numpy()
+
+    def generate_chain(self, Z, deterministic=True):
+        """z -> G(z) -> U(G(z)) without leaving HBM (the z_fn -> gen_fn chain of generate_interpolation_clip,
+        /root/reference/pix2pix.py:384-393).  Returns (heightmaps, textures) as numpy arrays."""
+        Z = np.ascontiguousarray(Z, np.float32)
+        pg, prog_g = self._infer_plan('dcgan_gen', Z.shape[0], deterministic)
+        pu, prog_u = self._infer_plan('p2p_gen', Z.shape[0], deterministic)
+        self.sync()
+        pg.input_nodes[0].out.set(Z)
+        for e in prog_g:
+            e[1]()
+        lg, lu = LANE_OF['dcgan_gen'], LANE_OF['p2p_gen']
+        if self.devs[lu] is not self.devs[lg]:
+            self.devs[lu].wait_for(self.devs[lg])
+        self.ops[lu].copy_view(pg.out, pu.input_nodes[0].out)
+        for e in prog_u:
+            e[1]()
+        a = pg.out.numpy()
+        return a, pu.out.numpy()
+

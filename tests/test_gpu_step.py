@@ -226,3 +226,40 @@ def test_train_loop_with_device_iterator(dev, tmp_path):
     m2.load_model(models + "/2.model")
     Zb, Xb, Yb = ostep.synthetic_batch(4, cfg, seed=1)
     assert rel(m2.loss_fn(Zb, Xb, Yb), m.loss_fn(Zb, Xb, Yb)) < 1e-6
+
+
+def test_sampling_utilities_on_device(dev, tmp_path):
+    """f3 (pix2pix.py:276-425): the in-HBM G -> U chain equals z_fn_det followed by gen_fn_det bit for bit, one
+    batched interpolation pass equals the reference's batch-1 calls, and the frame files appear."""
+    from gan_heightmaps_amd import util
+    cfg = ostep.default_cfg(**SMALL)
+    model = build_model(cfg, 5, dev)
+    model.sampler = np.random.RandomState(9).rand
+    Z = np.random.RandomState(1).rand(5, cfg['latent_dim']).astype(np.float32)
+    a0 = model.z_fn_det(Z)
+    b0 = model.gen_fn_det(a0)
+    a1, b1 = model.engine.generate_chain(Z, deterministic=True)
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1)
+    # oracle: deterministic forward of both generators on the same state
+    state = ostep.init_state(cfg, 5, np.float32)
+    X = np.zeros((5, 1, 32, 32), np.float32)
+    fw = ostep.forward(state, Z, X, np.zeros((5, 3, 32, 32), np.float32), deterministic=True)
+    assert rel(a1, fw['gz'].v) < 1e-5
+    fw2 = ostep.forward(state, Z, np.asarray(fw['gz'].v, np.float32), np.zeros((5, 3, 32, 32), np.float32),
+                        deterministic=True)
+    assert rel(b1, fw2['ux'].v) < 1e-5
+    # non-deterministic chain: batch statistics in both nets (and running stats move, as z_fn/gen_fn do)
+    a2, b2 = model.engine.generate_chain(Z, deterministic=False)
+    assert a2.shape == a1.shape and b2.shape == b1.shape and np.isfinite(b2).all()
+    # batched interpolation == per-sample deterministic calls
+    z1, z2 = Z[0], Z[1]
+    grid = model.interpolation_grid(z1, z2, mode='row')
+    for n, c in enumerate([0.0, 0.1, 0.3, 0.6, 0.9, 1.0]):
+        c = np.float32(c)
+        one = model.z_fn_det(((1 - c) * z1 + c * z2)[None])
+        assert np.abs(grid[0, n] - util.convert_to_rgb(one[0], True)).max() < 1e-5
+    model.generate_interpolation_clip(2, 5, str(tmp_path / "clip"), concat=True)
+    assert len(list((tmp_path / "clip").iterdir())) == 25
+    assert util.imread(str(tmp_path / "clip" / "concat_0024.png")).shape == (32, 64, 3)
+    model.generate_gz(6, 3, str(tmp_path / "gz"))
+    assert len(list((tmp_path / "gz").iterdir())) == 6
