@@ -25,6 +25,7 @@ struct ghm_ctx {
     bool capturing = false;
     void* scratch = nullptr;       // library-owned workspace (split-K partials, reduction partials)
     size_t scratch_bytes = 0;
+    float* zeros = nullptr;        // 256 B of zeros: the source of padding elements for LDS-DMA row staging
 };
 
 // grow-only workspace owned by the ctx; growing is illegal while a graph is being captured
@@ -72,3 +73,15 @@ __device__ __forceinline__ float ghm_dact_from_out(float y, int act, float alpha
         default: return 1.f;
     }
 }
+
+// ---- conv_thin.hip: layers with <= 4 channels on one side and large maps (HBM-bound) ----
+bool thin_fanout_fwd_ok(const ghm_conv_desc* d, int act);   // the kernel's epilogue does linear / relu / lrelu
+int thin_fanout_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,
+                    float* y, int act, float alpha, int accumulate);
+bool thin_fanout_dgrad_ok(const ghm_conv_desc* d, int act);
+int thin_fanout_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const float* wp, const float* bias,
+                      float* dx, int act, float alpha, int accumulate);
+bool thin_fanin_s2_ok(const ghm_conv_desc* d, const float* dx);
+int thin_fanin_s2(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const float* wp, const float* bias,
+                  float* dx, int act, float alpha, int accumulate);
+

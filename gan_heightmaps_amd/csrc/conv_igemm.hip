@@ -1560,6 +1560,7 @@ int ghm_conv2d_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const f
                    float* y, int32_t act, float alpha, int32_t accumulate) {
     if (int e = check_desc(d)) return e;
     GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    if (d->C <= 4 && thin_fanout_fwd_ok(d, act)) return thin_fanout_fwd(ctx, d, x, wp, bias, y, act, alpha, accumulate);
     if (taps_as_rows(d, d->K)) {
         const int T = d->kh * d->kw;
         void* ws = nullptr;
@@ -1613,6 +1614,9 @@ int ghm_conv2d_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, cons
                      float* dx, int32_t act, float alpha, int32_t accumulate) {
     if (int e = check_desc(d)) return e;
     GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    if (d->K <= 4 && thin_fanout_dgrad_ok(d, act))
+        return thin_fanout_dgrad(ctx, d, dy, wp, bias, dx, act, alpha, accumulate);
+    if (thin_fanin_s2_ok(d, dx)) return thin_fanin_s2(ctx, d, dy, wp, bias, dx, act, alpha, accumulate);
     if (taps_as_rows(d, d->C)) {
         const int T = d->kh * d->kw;
         void* ws = nullptr;
@@ -1662,6 +1666,15 @@ int ghm_conv2d_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, cons
         }
     }
     return 0;
+}
+
+// stride-1 data gradient as a forward conv K -> C on the transposed weights: padding k-1-pad
+static ghm_conv_desc swapped_desc(const ghm_conv_desc* d) {
+    ghm_conv_desc s = *d;
+    s.C = d->K; s.K = d->C; s.H = d->Ho; s.W = d->Wo; s.Ho = d->H; s.Wo = d->W;
+    s.pad = d->kh - 1 - d->pad;
+    s.x_nstride = d->y_nstride; s.y_nstride = d->x_nstride;
+    return s;
 }
 
 int ghm_dgrad_t_supported(const ghm_conv_desc* d) {
@@ -1731,6 +1744,10 @@ int ghm_conv2d_dgrad_t(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, co
     // the data gradient of a stride-1 conv is the forward conv K -> C with flipped taps (already folded into
     // wpT by ghm_conv2d_transpose_weights) and padding k-1-pad
     const int padT = d->kh - 1 - d->pad;
+    if (d->K <= 4) {
+        const ghm_conv_desc sw = swapped_desc(d);
+        if (thin_fanout_fwd_ok(&sw, act)) return thin_fanout_fwd(ctx, &sw, dy, wpT, bias, dx, act, alpha, accumulate);
+    }
     if (d->kh == d->kw && d->Ho == d->H && d->Wo == d->W) {
         const PatchPlan pl = plan_patch(d->N, d->K, d->H, d->W, d->C, d->kh, ctx->num_cu);
         if (pl.ok) {
@@ -1882,6 +1899,25 @@ int ghm_channel_sum(ghm_ctx* ctx, const float* x, int32_t N, int32_t C, int32_t 
 }
 
 int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t out_len) {
+    if (kind == 0 && d->C <= 4 && thin_fanout_fwd_ok(d, GHM_ACT_LINEAR)) {
+        snprintf(out, out_len, "fanout_kernel<fwd>");
+        return 0;
+    }
+    if (kind == 1 && d->K <= 4 && thin_fanout_dgrad_ok(d, GHM_ACT_LINEAR)) {
+        snprintf(out, out_len, "fanout_kernel<dgrad>");
+        return 0;
+    }
+    if (kind == 1 && thin_fanin_s2_ok(d, nullptr)) {
+        snprintf(out, out_len, "fanin_s2_kernel<%d>", d->kh);
+        return 0;
+    }
+    if (kind == 3 && d->stride == 1 && d->K <= 4) {
+        const ghm_conv_desc sw = swapped_desc(d);
+        if (thin_fanout_fwd_ok(&sw, GHM_ACT_LINEAR)) {
+            snprintf(out, out_len, "fanout_kernel<dgrad_t>");
+            return 0;
+        }
+    }
     if (taps_as_rows(d, kind == 1 ? d->C : d->K)) {
         snprintf(out, out_len, "taps_as_rows<%s>", kind == 0 ? "fwd" : (kind == 1 ? "dgrad" : "wgrad"));
         return 0;

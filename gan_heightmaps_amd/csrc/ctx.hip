@@ -50,6 +50,8 @@ int ghm_ctx_create(int32_t device, ghm_ctx** out) {
     hipDeviceProp_t prop;
     GHM_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount;
+    GHM_HIP(hipMalloc((void**)&c->zeros, 256));
+    GHM_HIP(hipMemset(c->zeros, 0, 256));
     *out = c;
     return 0;
 }
@@ -63,6 +65,7 @@ int ghm_ctx_destroy(ghm_ctx* ctx) {
         if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
     }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->zeros) (void)hipFree(ctx->zeros);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;

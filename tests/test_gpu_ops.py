@@ -62,8 +62,57 @@ CONV_CASES = [
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("tile", ["big", "small"])
 def test_conv_fwd_dgrad_wgrad(gpu, case, tile):
-    dev, ops, D = gpu
     os.environ["GHM_FORCE_TILE"] = tile
+    try:
+        _check_conv(gpu, case)
+    finally:
+        os.environ.pop("GHM_FORCE_TILE")
+
+
+# first / last layers at full resolution: <= 4 channels on one side, large maps (conv_thin.hip)
+THIN_CASES = [
+    # N, C, H, W, K, k, s, pad        fwd / dgrad / dgrad_t variants expected
+    ((2, 1, 128, 128, 64, 5, 1, 2), ("fanout_kernel<fwd>", None, None)),             # d_conv1
+    ((2, 4, 256, 256, 64, 3, 2, 1), ("fanout_kernel<fwd>", "fanin_s2_kernel<3>", None)),   # pd_conv1
+    ((2, 1, 256, 256, 64, 3, 2, 1), ("fanout_kernel<fwd>", "fanin_s2_kernel<3>", None)),   # unet conv1
+    ((2, 3, 256, 256, 128, 2, 2, 0), ("fanout_kernel<fwd>", "fanin_s2_kernel<2>", None)),  # final Deconv2DLayer
+    ((2, 64, 128, 128, 1, 5, 1, 2), (None, "fanout_kernel<dgrad>", "fanout_kernel<dgrad_t>")),   # g_out
+    ((1, 64, 128, 256, 3, 3, 1, 1), (None, "fanout_kernel<dgrad>", "fanout_kernel<dgrad_t>")),   # 3 filters, 27 rows
+    ((2, 3, 128, 256, 64, 3, 1, 1), ("fanout_kernel<fwd>", None, None)),             # 3 channels x 9 taps, rectangular
+    ((2, 3, 128, 256, 48, 3, 1, 1), ("igemm_kernel<64,256,fwd>", None, None)),       # ragged filters: general kernel
+]
+
+
+@pytest.mark.parametrize("case,variants", THIN_CASES)
+def test_thin_layer_kernels(gpu, case, variants):
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    for kind, want in zip((0, 1, 3), variants):
+        if want is not None:
+            assert ops.conv_variant(d, kind) == want
+    _check_conv(gpu, case)
+    # and they agree with the general kernels they replace
+    rng = np.random.RandomState(3)
+    x = dev.tensor(rng.randn(N, C, H, W).astype(np.float32))
+    dy = dev.tensor(rng.randn(N, K, d.Ho, d.Wo).astype(np.float32))
+    w = dev.tensor((rng.randn(C * k * k * K) / np.sqrt(C * k * k)).astype(np.float32))
+    b = dev.tensor(rng.randn(K).astype(np.float32))
+    y1, y2 = dev.empty((N, K, d.Ho, d.Wo)), dev.empty((N, K, d.Ho, d.Wo))
+    dx1, dx2 = dev.empty((N, C, H, W)), dev.empty((N, C, H, W))
+    ops.conv2d_fwd(d, x, w, b, y1, act='tanh')
+    ops.conv2d_dgrad(d, dy, w, dx1)
+    os.environ["GHM_NO_THIN"] = "1"
+    try:
+        ops.conv2d_fwd(d, x, w, b, y2, act='tanh')
+        ops.conv2d_dgrad(d, dy, w, dx2)
+    finally:
+        os.environ.pop("GHM_NO_THIN")
+    assert rel(y1.numpy(), y2.numpy()) < 1e-5 and rel(dx1.numpy(), dx2.numpy()) < 1e-5
+
+
+def _check_conv(gpu, case):
+    dev, ops, D = gpu
     N, C, H, W, K, k, s, pad = case
     rng = np.random.RandomState(hash(case) % 2**31)
     x = rng.randn(N, C, H, W).astype(np.float32)
@@ -106,7 +155,6 @@ def test_conv_fwd_dgrad_wgrad(gpu, case, tile):
     dbd = dev.empty((1, K, 1, 1))
     ops.channel_sum(dyd, dbd)
     assert rel(dbd.numpy().ravel(), db_ref) < TOL
-    os.environ.pop("GHM_FORCE_TILE")
 
 
 def test_wgrad_split_k_large(gpu):
