@@ -1554,6 +1554,13 @@ WVariant pick_wgrad(const ghm_conv_desc* d, int num_cu) {
 
 }  // namespace
 
+int ghm_reduce_splits(ghm_ctx* ctx, const float* part, int S, long n, long split_stride, float* out, int accumulate) {
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(ceil_div((n + 3) / 4, 256)), dim3(256), 0, ctx->stream, part, S, n,
+                       split_stride, out, accumulate);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" {
 
 int ghm_conv2d_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,
@@ -1853,6 +1860,7 @@ static int wgrad_impl(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, cons
 int ghm_conv2d_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* dy, float* dwp,
                      void* workspace, int32_t accumulate) {
     if (int e = check_desc(d)) return e;
+    if (thin_wgrad_ok(d, x, dy)) return thin_wgrad(ctx, d, x, dy, dwp, accumulate);
     if (taps_as_rows(d, d->K)) {
         // shift-expand dy into T*K planes over the input grid, then a 1x1 weight-gradient GEMM whose "filters"
         // are (tap, k): its packed output [c][1][tap*K + k] IS dwp[c][tap][k]
@@ -1909,6 +1917,10 @@ int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t 
     }
     if (kind == 1 && thin_fanin_s2_ok(d, nullptr)) {
         snprintf(out, out_len, "fanin_s2_kernel<%d>", d->kh);
+        return 0;
+    }
+    if (kind == 2 && thin_wgrad_ok(d, nullptr, nullptr)) {
+        snprintf(out, out_len, "thin_wgrad_kernel<%d>", d->C <= 4 ? d->K : d->C);
         return 0;
     }
     if (kind == 3 && d->stride == 1 && d->K <= 4) {

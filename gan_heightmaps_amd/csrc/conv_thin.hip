@@ -479,3 +479,327 @@ int thin_fanin_s2(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const f
     ghm_set_error("fanin_s2: no variant for k=%d C=%d", d->kh, d->C);
     return -3;
 }
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient of a thin layer:  G[b][q] = sum_{n, p} big[n, b, p] * thin[n, ch(q), p*ss + (di, dj)(q)]
+//   thin-in  conv (C <= 4): big = dy (K channels on the output grid), thin = x, dwp[(c*T+t)*K + k] = G[k][(c,t)]
+//   thin-out conv (K <= 4, stride 1, 'same'): big = x, thin = dy with the taps negated,
+//                                             dwp[(c*T+t)*K + k] = G[c][(k,t)]
+// MFMA: rows = big channels, columns = q, reduction = pixels.  The reduction index must be the MFMA k index,
+// i.e. lanes along CHANNELS for the A operand, while HBM wants lanes along pixels -- so the big tensor goes
+// through LDS: a loader wave (wave 8) DMAs [CB channels] x [PXC pixels] tiles with 16-byte
+// global_load_lds (2-4 channel rows per instruction), XOR-swizzling the 16-byte slot on the SOURCE address so
+// that the 32 lanes of an A-fragment read (32 channels, same pixels) hit 32 different slots; the thin rows
+// are staged as in fanout_kernel by a second loader wave (wave 9; their 4-byte DMAs would otherwise clog the
+// 64-entry vmcnt window of the tile loader).  The tile loader runs two tiles ahead with counted vmcnt (DMAs complete in
+// order), the eight MFMA waves each reduce an eighth of the tile's pixels into their own accumulators, and
+// the block combines them once at the end (fixed order) into its slice of the split-K partial buffer.
+// Algorithmic HBM bytes: the big tensor once.
+// ------------------------------------------------------------------------------------------------
+struct ThinWgradArgs {
+    const float* big;
+    const float* thin;
+    const float* zeros;
+    float* part;              // [gridDim.x][n_out]
+    int N, CB, Hb, Wb;        // big: CB channels on an Hb x Wb grid
+    long big_nstride;
+    int CS, Hin, Win;         // thin: CS channels on an Hin x Win grid
+    long thin_nstride;
+    int ss, Q;
+    int n_out;
+    long o_bs;                // output index = b*o_bs + oq[q]
+    int dimin, djmin, KR, LW;
+    int loff[THIN_MAX_Q], oq[THIN_MAX_Q];
+    int ch[THIN_MAX_Q], di[THIN_MAX_Q], dj[THIN_MAX_Q];
+};
+
+template <int N_>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+template <int RB, int CBQ>
+__global__ __launch_bounds__(640) void thin_wgrad_kernel(const ThinWgradArgs a) {
+    constexpr int CB = RB * 32;
+    constexpr int PXC = 256 / RB;             // pixels per tile: 128 (64 channels) or 64 (128 channels)
+    constexpr int SPR = PXC / 4;              // 16-byte slots per channel row
+    constexpr int RPU = 64 / SPR;             // channel rows per DMA instruction
+    constexpr int TILE = CB * PXC;            // floats
+    constexpr int NDMA = TILE / 256;          // DMA instructions per tile (32)
+    constexpr int PXW = PXC / 8;              // pixels per MFMA wave
+    constexpr int SPH = PXW / 2;              // k-steps per wave and tile
+#ifdef GHM_NOSWZ
+    constexpr int SWZ = 0;
+#else
+    constexpr int SWZ = SPR - 1;
+#endif
+    static_assert(NDMA == 32 && SPH % 4 == 0, "tile geometry");
+    extern __shared__ float lds[];
+    float* tiles = lds;                       // [3][TILE]
+    float* trows = lds + 3 * TILE;            // [2][CS*KR*LW]
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, l = lane & 31;
+    const int rowsz = a.CS * a.KR * a.LW;
+    const int NR = a.N * a.Hb;                // big rows
+    const int NC = a.Wb / PXC;                // tiles per row
+    const int HWb = a.Hb * a.Wb, HWin = a.Hin * a.Win;
+    const int G = gridDim.x;
+
+    auto stage_thin = [&](int r, float* dst) {
+        const int n = r / a.Hb, u = r - n * a.Hb;
+        const float* img = a.thin + (long)n * a.thin_nstride;
+        for (int ck = 0; ck < a.CS * a.KR; ++ck) {
+            const int c = ck / a.KR, kr = ck - c * a.KR;
+            const int y = u * a.ss + a.dimin + kr;
+            const bool rowok = (unsigned)y < (unsigned)a.Hin;
+            const float* src = img + (long)c * HWin + (rowok ? y : 0) * a.Win + a.djmin;
+            float* d = dst + ck * a.LW;
+            for (int x0 = 0; x0 < a.LW; x0 += 64) {
+                const int xin = x0 + lane + a.djmin;
+                const bool ok = rowok && (unsigned)xin < (unsigned)a.Win;
+                const float* g = ok ? src + (x0 + lane) : a.zeros;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(d + x0), 4, 0, 0);
+            }
+        }
+    };
+    auto stage_big = [&](int r, int c, float* dst) {
+        const int n = r / a.Hb, u = r - n * a.Hb;
+        // wave-uniform base (scalar) + 32-bit per-lane byte offset
+        const char* src = reinterpret_cast<const char*>(a.big + (long)n * a.big_nstride + (long)u * a.Wb + c * PXC);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));      // recompute the 32 lane offsets per tile instead of keeping them in VGPRs
+        const int rin = ln / SPR, slot = ln % SPR;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int b = i * RPU + rin;
+            const unsigned boff = ((unsigned)b * (unsigned)HWb + 4u * (slot ^ (b & SWZ))) * 4u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + boff),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+        }
+    };
+
+    // stage sequence of this block: rows r0, r0+G, ...; NC tiles per row
+    const int r0 = blockIdx.x;
+    const int nrows = (NR - r0 + G - 1) / G;
+    const int NT = nrows * NC;
+    if (wv == 9) {
+        stage_thin(r0, trows);
+        wait_vmcnt<0>();
+    }
+    if (wv == 8) {
+        stage_big(r0, 0, tiles);
+        if (NT > 1) {
+            stage_big(r0 + (1 / NC) * G, 1 % NC, tiles + TILE);      // NC >= 2: tile 1 is in the same row
+            wait_vmcnt<NDMA>();
+        } else {
+            wait_vmcnt<0>();
+        }
+    }
+    __syncthreads();
+
+    int offq[CBQ];
+#pragma unroll
+    for (int cb = 0; cb < CBQ; ++cb) {
+        const int q = cb * 32 + l;
+        offq[cb] = q < a.Q ? a.loff[q] : 0;       // dead columns read a finite word and are never written out
+    }
+    f32x16 acc[RB][CBQ];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CBQ; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rb][cb][e] = 0.f;
+
+    int t = 0;
+    for (int ir = 0; ir < nrows; ++ir) {
+        const float* trow = trows + (ir & 1) * rowsz;
+        for (int c = 0; c < NC; ++c, ++t) {
+            if (wv == 9) {
+                // thin rows of the next image row: issued at its predecessor's first tile, landed by its last
+                if (c == 0 && ir + 1 < nrows) stage_thin(r0 + (ir + 1) * G, trows + ((ir + 1) & 1) * rowsz);
+                if (c == NC - 1) wait_vmcnt<0>();
+            } else if (wv == 8) {
+                // issue tile t+2; tile t+1 must have landed.  DMAs complete in order: leaving at most as many
+                // outstanding as tile t+2 issued means tile t+1 is in LDS.
+                const int t2 = t + 2;
+                if (t2 < NT) {
+                    const int ir2 = t2 / NC, c2 = t2 - ir2 * NC;
+                    stage_big(r0 + ir2 * G, c2, tiles + (t2 % 3) * TILE);
+                    wait_vmcnt<NDMA>();
+                } else {
+                    wait_vmcnt<0>();
+                }
+            } else {
+                const float* tile = tiles + (t % 3) * TILE;
+                const int px0 = wv * PXW + SPH * h;                      // this lane's first pixel in the tile
+                const float* bsrc = trow + (c * PXC + px0) * a.ss;
+#pragma unroll
+                for (int m = 0; m < SPH / 4; ++m) {
+                    float4 av[RB];
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) {
+                        const int b = rb * 32 + l;
+                        av[rb] = *reinterpret_cast<const float4*>(tile + b * PXC + 4 * ((px0 / 4 + m) ^ (b & SWZ)));
+                    }
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        float bv[CBQ];
+#pragma unroll
+                        for (int cb = 0; cb < CBQ; ++cb) bv[cb] = bsrc[offq[cb] + (4 * m + s4) * a.ss];
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) {
+                            const float aval = s4 == 0 ? av[rb].x : (s4 == 1 ? av[rb].y : (s4 == 2 ? av[rb].z : av[rb].w));
+#pragma unroll
+                            for (int cb = 0; cb < CBQ; ++cb)
+                                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bv[cb], acc[rb][cb], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+        }
+    }
+
+    // combine the eight waves (fixed order): waves 4-7 -> 0-3, 2-3 -> 0-1, 1 -> 0; register images are lane-linear
+    __syncthreads();
+    float* red = lds;
+    constexpr int IMG = RB * CBQ * 16 * 64;       // floats per wave image
+#pragma unroll
+    for (int half = 4; half >= 1; half >>= 1) {
+        if (wv >= half && wv < 2 * half) {
+            float* dst = red + (wv - half) * IMG;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < CBQ; ++cb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dst[((rb * CBQ + cb) * 16 + e) * 64 + lane] = acc[rb][cb][e];
+        }
+        __syncthreads();
+        if (wv < half) {
+            const float* src = red + wv * IMG;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < CBQ; ++cb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[rb][cb][e] += src[((rb * CBQ + cb) * 16 + e) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wv == 0) {
+        float* out = a.part + (long)blockIdx.x * a.n_out;
+#pragma unroll
+        for (int cb = 0; cb < CBQ; ++cb) {
+            const int q = cb * 32 + l;
+            if (q < a.Q) {
+                const int oq = a.oq[q];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int b = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        out[b * a.o_bs + oq] = acc[rb][cb][e];
+                    }
+            }
+        }
+    }
+}
+
+static bool thin_wgrad_geometry_ok(int big_ch, int thin_ch, int kh, int kw, int stride, int Hb, int Wb, int N) {
+    const int q = thin_ch * kh * kw;
+    if (!(big_ch == 64 || (big_ch == 128 && q <= 32)) || q > THIN_MAX_Q) return false;
+    const int pxc = big_ch == 64 ? 128 : 64;
+    if (Wb % pxc != 0 || Wb / pxc < 2 || (long)N * Hb * Wb < 32768) return false;
+    const int LW = (((Wb - 1) * stride + kw) + 63) & ~63;
+    const size_t lds = (size_t)(3 * big_ch * pxc + 2 * thin_ch * kh * LW) * sizeof(float);
+    return lds <= 158 * 1024;
+}
+
+// which side is thin?  0 = neither, 1 = input channels (C <= 4), 2 = filters (K <= 4)
+static int thin_wgrad_side(const ghm_conv_desc* d, const float* x, const float* dy) {
+    if (!thin_enabled()) return 0;
+    if (d->C <= 4 && d->K > 4 && thin_wgrad_geometry_ok(d->K, d->C, d->kh, d->kw, d->stride, d->Ho, d->Wo, d->N) &&
+        ((uintptr_t)dy % 16 == 0) && d->y_nstride % 4 == 0 && (d->Ho * d->Wo) % 4 == 0)
+        return 1;
+    if (d->K <= 4 && d->C > 4 && d->stride == 1 && d->Ho == d->H && d->Wo == d->W &&
+        thin_wgrad_geometry_ok(d->C, d->K, d->kh, d->kw, 1, d->H, d->W, d->N) && ((uintptr_t)x % 16 == 0) &&
+        d->x_nstride % 4 == 0 && (d->H * d->W) % 4 == 0)
+        return 2;
+    return 0;
+}
+
+bool thin_wgrad_ok(const ghm_conv_desc* d, const float* x, const float* dy) { return thin_wgrad_side(d, x, dy) != 0; }
+
+int thin_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* dy, float* dwp, int accumulate) {
+    const int side = thin_wgrad_side(d, x, dy);
+    GHM_CHECK(side != 0, "thin_wgrad: geometry not supported");
+    ThinWgradArgs a;
+    memset(&a, 0, sizeof(a));
+    const int T = d->kh * d->kw;
+    a.zeros = ctx->zeros;
+    a.N = d->N;
+    a.n_out = d->C * T * d->K;
+    if (side == 1) {
+        a.big = dy; a.CB = d->K; a.Hb = d->Ho; a.Wb = d->Wo; a.big_nstride = d->y_nstride;
+        a.thin = x; a.CS = d->C; a.Hin = d->H; a.Win = d->W; a.thin_nstride = d->x_nstride;
+        a.ss = d->stride; a.Q = d->C * T; a.o_bs = 1;
+        for (int c = 0; c < d->C; ++c)
+            for (int ta = 0; ta < d->kh; ++ta)
+                for (int tb = 0; tb < d->kw; ++tb) {
+                    const int q = c * T + ta * d->kw + tb;
+                    a.ch[q] = c; a.di[q] = ta - d->pad; a.dj[q] = tb - d->pad;
+                    a.oq[q] = q * d->K;
+                }
+    } else {
+        a.big = x; a.CB = d->C; a.Hb = d->H; a.Wb = d->W; a.big_nstride = d->x_nstride;
+        a.thin = dy; a.CS = d->K; a.Hin = d->Ho; a.Win = d->Wo; a.thin_nstride = d->y_nstride;
+        a.ss = 1; a.Q = d->K * T; a.o_bs = (long)T * d->K;
+        for (int k = 0; k < d->K; ++k)
+            for (int ta = 0; ta < d->kh; ++ta)
+                for (int tb = 0; tb < d->kw; ++tb) {
+                    const int q = k * T + ta * d->kw + tb;
+                    a.ch[q] = k; a.di[q] = d->pad - ta; a.dj[q] = d->pad - tb;
+                    a.oq[q] = (ta * d->kw + tb) * d->K + k;
+                }
+    }
+    int dimax = -(1 << 20), djmax = -(1 << 20);
+    a.dimin = a.djmin = 1 << 20;
+    for (int q = 0; q < a.Q; ++q) {
+        if (a.di[q] < a.dimin) a.dimin = a.di[q];
+        if (a.di[q] > dimax) dimax = a.di[q];
+        if (a.dj[q] < a.djmin) a.djmin = a.dj[q];
+        if (a.dj[q] > djmax) djmax = a.dj[q];
+    }
+    a.KR = dimax - a.dimin + 1;
+    a.LW = (((a.Wb - 1) * a.ss + (djmax - a.djmin) + 1) + 63) & ~63;
+    for (int q = 0; q < a.Q; ++q) a.loff[q] = (a.ch[q] * a.KR + (a.di[q] - a.dimin)) * a.LW + (a.dj[q] - a.djmin);
+    const int NR = a.N * a.Hb;
+    int blocks = ctx->num_cu;
+    if (blocks > NR) blocks = NR;
+    void* ws = nullptr;
+    if (int e = ghm_scratch(ctx, (size_t)blocks * a.n_out * sizeof(float), &ws)) return e;
+    a.part = (float*)ws;
+    const int pxc = a.CB == 64 ? 128 : 64;
+    const size_t lds = (size_t)(3 * a.CB * pxc + 2 * a.CS * a.KR * a.LW) * sizeof(float);
+    const int cbq = (a.Q + 31) / 32;
+#define GHM_TW_CASE(RB_, CBQ_)                                                                              \
+    if (a.CB == RB_ * 32 && cbq == CBQ_) {                                                                  \
+        static bool opted = false;                                                                          \
+        if (!opted) {                                                                                       \
+            GHM_HIP(hipFuncSetAttribute((const void*)thin_wgrad_kernel<RB_, CBQ_>,                          \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));            \
+            opted = true;                                                                                   \
+        }                                                                                                   \
+        hipLaunchKernelGGL((thin_wgrad_kernel<RB_, CBQ_>), dim3(blocks), dim3(640), lds, ctx->stream, a);   \
+        GHM_LAUNCH_CHECK();                                                                                 \
+    } else
+    GHM_TW_CASE(2, 1)
+    GHM_TW_CASE(2, 2)
+    GHM_TW_CASE(4, 1) {
+        ghm_set_error("thin_wgrad: no variant for %d channels x %d columns", a.CB, a.Q);
+        return -3;
+    }
+#undef GHM_TW_CASE
+    return ghm_reduce_splits(ctx, a.part, blocks, a.n_out, a.n_out, dwp, accumulate);
+}

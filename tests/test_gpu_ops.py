@@ -91,6 +91,8 @@ def test_thin_layer_kernels(gpu, case, variants):
     for kind, want in zip((0, 1, 3), variants):
         if want is not None:
             assert ops.conv_variant(d, kind) == want
+    if (K in (64, 128) or C in (64, 128)) and d.Wo >= 256:
+        assert ops.conv_variant(d, 2).startswith("thin_wgrad_kernel")
     _check_conv(gpu, case)
     # and they agree with the general kernels they replace
     rng = np.random.RandomState(3)
