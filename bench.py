@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step as a captured HIP graph (no per-kernel events)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--one-stream", action="store_true", help="run both GAN stages on a single HIP stream")
+    ap.add_argument("--no-grad-streams", action="store_true",
+                    help="keep the weight/bias gradients on the stage's own stream (default: a second stream per stage)")
     ap.add_argument("--profile", action="store_true", help="print a per-program-entry timing table to stderr")
     args = ap.parse_args()
 
@@ -82,7 +84,8 @@ def main():
     dev = device.Device(local_rank)
     comm = dist.Comm(dev, rank, world) if world > 1 else None
     B = args.batch_per_gpu
-    backend = dict(device=dev, comm=comm, use_graph=args.graph, seed=0, verbose=False, two_streams=not args.one_stream)
+    backend = dict(device=dev, comm=comm, use_graph=args.graph, seed=0, verbose=False, two_streams=not args.one_stream,
+                   side_streams=(not args.no_grad_streams) and not args.graph)
     model = make_model('test1_nobn_bilin_both', **backend)
     if args.mode != 'both':
         # configs 2 / 3 of BASELINE.json: same nets, one stage trained
@@ -165,7 +168,8 @@ def main():
         "config": {"workload": "test1_nobn_bilin_both joint DCGAN+pix2pix train step (train_mode=%s), 512x512, "
                                "batch %d per GPU, RMSprop lr 1e-4, LSGAN + 100*L1" % (args.mode, B),
                    "global_batch": B * world, "in_shp": 512, "parallelism": "dp%d" % world,
-                   "hip_graph": bool(args.graph), "streams": 1 if eng.devs[0] is eng.devs[1] else 2},
+                   "hip_graph": bool(args.graph),
+                   "streams": (1 if eng.devs[0] is eng.devs[1] else 2) * (2 if eng.side[0] is not None else 1)},
         "step_algorithmic_tflops": round(JOINT_GFLOP_PER_IMG * value / 1e3, 2) if args.mode == 'both' else None,
         "step_frac_of_fp32_mfma_peak": round(JOINT_GFLOP_PER_IMG * value / world / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)
         if args.mode == 'both' else None,

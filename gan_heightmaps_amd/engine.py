@@ -239,8 +239,12 @@ def _rewrite(out_node):
 class NetPlan:
     """One network lowered for a fixed batch size: buffers + emitters of forward/backward programs."""
 
-    def __init__(self, dev, ops, out_layer, batch, store, inputs=None, out_tensor=None, name="net"):
+    def __init__(self, dev, ops, out_layer, batch, store, inputs=None, out_tensor=None, name="net", side=None):
+        """``side=(Device, Ops)``: a second stream of the same GPU for the weight / bias gradients, which only
+        feed the optimiser: they fork off the main stream where their output gradient is ready and run beside
+        the data-gradient chain (the caller joins the two streams before the update)."""
         self.dev, self.ops, self.batch, self.store, self.name = dev, ops, batch, store, name
+        self.side = side
         nodes, of = _build_ir(out_layer)
         self.out_node = _rewrite(of[id(out_layer)])
         self.order = _toposort(self.out_node)
@@ -493,17 +497,21 @@ class NetPlan:
                     self._need_wgrad_ws(d)
                     gw, gb = st.grad(l.W), st.grad(l.b)
                     aw = accumulate_wgrad
+                    wo, wdev = ops, None
+                    if self.side is not None:
+                        wdev, wo = self.side
+                        prog.append(("fork", lambda wdev=wdev: wdev.wait_for(dev), None, wdev))
                     if n.op == 'deconv':
-                        prog.append(("deconv_wgrad", lambda d=d, G=G, x=x, gw=gw, aw=aw:
-                                     ops.conv2d_wgrad(d, G, x, gw, self.wgrad_ws, aw), conv_meta(ops, d, 2)))
+                        prog.append(("deconv_wgrad", lambda d=d, G=G, x=x, gw=gw, aw=aw, wo=wo:
+                                     wo.conv2d_wgrad(d, G, x, gw, self.wgrad_ws, aw), conv_meta(ops, d, 2), wdev))
                     else:
-                        prog.append(("%s_wgrad" % n.op, lambda d=d, G=G, x=x, gw=gw, aw=aw:
-                                     ops.conv2d_wgrad(d, x, G, gw, self.wgrad_ws, aw), conv_meta(ops, d, 2)))
+                        prog.append(("%s_wgrad" % n.op, lambda d=d, G=G, x=x, gw=gw, aw=aw, wo=wo:
+                                     wo.conv2d_wgrad(d, x, G, gw, self.wgrad_ws, aw), conv_meta(ops, d, 2), wdev))
                     # a bias that feeds a BatchNorm has an identically zero gradient (the BN backward output sums to
                     # zero per channel): its slice of the zero-initialised gradient buffer is simply never written
                     bn_fed = len(n.consumers) == 1 and n.consumers[0].op == 'bn' and n.act == linear
                     if not bn_fed:
-                        prog.append(("bias_grad", lambda G=G, gb=gb, aw=aw: ops.channel_sum(G, gb, aw)))
+                        prog.append(("bias_grad", lambda G=G, gb=gb, aw=aw, wo=wo: wo.channel_sum(G, gb, aw), None, wdev))
                 if need_dx:
                     gi, acc = target(xin)
                     if n.op == 'deconv':
@@ -607,9 +615,10 @@ def time_program(dev, prog, repeat=1):
     out = []
     for e in prog:
         label, fn = e[0], e[1]
-        dev.timer_start(1)
+        d = e[3] if len(e) > 3 and e[3] is not None else dev      # entries on a side stream are timed there
+        d.timer_start(1)
         for _ in range(repeat):
             fn()
-        dev.timer_stop(1)
-        out.append((label, dev.timer_ms(1) / repeat, e[2] if len(e) > 2 else None))
+        d.timer_stop(1)
+        out.append((label, d.timer_ms(1) / repeat, e[2] if len(e) > 2 else None))
     return out

@@ -48,10 +48,22 @@ def _interleave(a, b):
 
 class GanStep:
     def __init__(self, dev, dcgan_gen, dcgan_disc, p2p_gen, p2p_disc, alpha, lsgan, reconstruction, opt_spec,
-                 train_mode='both', comm=None, use_graph=True, two_streams=True, force_exchange=False):
+                 train_mode='both', comm=None, use_graph=True, two_streams=True, force_exchange=False,
+                 side_streams=None):
         self.dev = dev
+        if side_streams is None:            # forked branches replay slowly inside a HIP graph: eager mode only
+            side_streams = not use_graph
+        if side_streams and use_graph:
+            raise ValueError("side_streams needs use_graph=False")
         self.devs = [dev, Device(dev.index) if two_streams else dev]
         self.ops = [Ops(self.devs[0]), Ops(self.devs[1])]
+        # optional second stream per stage for the weight / bias gradients (engine.NetPlan side=)
+        self.side = [None, None]
+        if side_streams:
+            sd = [Device(dev.index), Device(dev.index) if two_streams else None]
+            if sd[1] is None:
+                sd[1] = sd[0]
+            self.side = [(sd[0], Ops(sd[0])), (sd[1], Ops(sd[1]))]
         self.nets = {'dcgan_gen': dcgan_gen, 'dcgan_disc': dcgan_disc, 'p2p_gen': p2p_gen,
                      'p2p_disc': p2p_disc["out"]}
         self.p2p_disc_inputs = p2p_disc["inputs"]
@@ -111,11 +123,14 @@ class GanStep:
         i_a, i_b = self.p2p_disc_inputs
         ca, H, W = d_in_layer.shape[1:]
         b.d_in = dA.empty((2 * B, ca, H, W))
-        b.G = NetPlan(dA, oA, G, B, self.stores['dcgan_gen'], out_tensor=b.d_in.samples(B, 2 * B), name="G")
-        b.D = NetPlan(dA, oA, D, 2 * B, self.stores['dcgan_disc'], inputs={d_in_layer: b.d_in}, name="D")
-        b.P = NetPlan(dB, oB, P, 2 * B, self.stores['p2p_disc'], name="P")
+        b.G = NetPlan(dA, oA, G, B, self.stores['dcgan_gen'], out_tensor=b.d_in.samples(B, 2 * B), name="G",
+                      side=self.side[0])
+        b.D = NetPlan(dA, oA, D, 2 * B, self.stores['dcgan_disc'], inputs={d_in_layer: b.d_in}, name="D",
+                      side=self.side[0])
+        b.P = NetPlan(dB, oB, P, 2 * B, self.stores['p2p_disc'], name="P", side=self.side[1])
         pa, pb = b.P.input_tensor(i_a), b.P.input_tensor(i_b)
-        b.U = NetPlan(dB, oB, U, B, self.stores['p2p_gen'], out_tensor=pb.samples(B, 2 * B), name="U")
+        b.U = NetPlan(dB, oB, U, B, self.stores['p2p_gen'], out_tensor=pb.samples(B, 2 * B), name="U",
+                      side=self.side[1])
         b.z = b.G.input_nodes[0].out
         b.x = b.U.input_tensor(u_in_layer)
         b.y = dB.empty((B,) + tuple(pb.shape[1:]))
@@ -184,17 +199,22 @@ class GanStep:
             b.U.emit_backward(tb, gu, wgrad=True, transposed=tdone)
         else:
             tb.append(("recon", lambda: oB.recon_loss(b.U.out, b.y, slot(3), None, 1.0, l2)))
+        if self.side[0] is not None:        # the gradient streams rejoin before anything consumes the gradients
+            ta.append(("join", lambda: dA.wait_for(self.side[0][0])))
+            tb.append(("join", lambda: dB.wait_for(self.side[1][0])))
         b.train_compute = [ta, tb]
         # ---- exchange + update (:131-141) ----
         keys = (['dcgan_gen', 'dcgan_disc'] if do_dcgan else []) + (['p2p_gen', 'p2p_disc'] if do_p2p else [])
         b.exchange = []
         if self.exchange:
-            # one communicator, on stream A: wait for the pix2pix stream, sum every bucket, update everything on
-            # stream A, then let stream B continue behind it
+            # one communicator, every collective on stream A in one fixed order on all ranks: the DCGAN buckets
+            # (stream A's own work, ready in stream order) go first and overlap the tail of the pix2pix stream;
+            # then stream A waits for stream B, sums the pix2pix buckets and the losses, updates everything,
+            # and stream B continues behind it
             for k in keys:
                 st = self.stores[k]
-                b.exchange.append(("allreduce_" + k, lambda st=st: oA.allreduce_sum(st.g, st.n_train)))
-            b.exchange.append(("allreduce_losses", lambda: oA.allreduce_sum(lo, 8)))
+                b.exchange.append(("allreduce_" + k, lambda st=st: oA.allreduce_sum(st.g, st.n_train), LANE_OF[k]))
+            b.exchange.append(("allreduce_losses", lambda: oA.allreduce_sum(lo, 8), 1))
         gs = 1.0 / self.world
         hp = self.opt_spec.hp
         b.update = [[], []]
@@ -297,10 +317,14 @@ class GanStep:
         dA, dB = self.devs
         if self.exchange:
             self._run_lanes(b, 'train_compute', b.train_compute, wrap)
+            for e in b.exchange:                            # RCCL calls stay outside the captured graphs
+                if e[2] == 0:
+                    e[1]()
             if dB is not dA:
                 dA.wait_for(dB)
-            for e in b.exchange:                            # RCCL calls stay outside the captured graphs
-                e[1]()
+            for e in b.exchange:
+                if e[2] != 0:
+                    e[1]()
             self._run_lanes(b, 'train_update', b.update, wrap)
             if dB is not dA:
                 dB.wait_for(dA)
@@ -326,10 +350,11 @@ class GanStep:
         for lane in (0, 1):
             dev = self.devs[lane]
             for e in b.train_compute[lane] + b.update[lane]:
-                dev.timer_start(1)
+                d = e[3] if len(e) > 3 and e[3] is not None else dev
+                d.timer_start(1)
                 e[1]()
-                dev.timer_stop(1)
-                out.append((e[0], dev.timer_ms(1), e[2] if len(e) > 2 else None))
+                d.timer_stop(1)
+                out.append((e[0], d.timer_ms(1), e[2] if len(e) > 2 else None))
         if self.exchange:
             self.sync()
             for e in b.exchange:

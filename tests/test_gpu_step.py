@@ -263,3 +263,24 @@ def test_sampling_utilities_on_device(dev, tmp_path):
     assert util.imread(str(tmp_path / "clip" / "concat_0024.png")).shape == (32, 64, 3)
     model.generate_gz(6, 3, str(tmp_path / "gz"))
     assert len(list((tmp_path / "gz").iterdir())) == 6
+
+
+def test_gradient_side_streams_bitwise(dev):
+    """weight / bias gradients forked onto a second stream per stage (eager mode): same bits as the plain path,
+    step after step"""
+    cfg = ostep.default_cfg(**SMALL)
+    B = 4
+    Z, X, Y = ostep.synthetic_batch(B, cfg, seed=3)
+    plain = build_model(cfg, 11, dev, use_graph=False, side_streams=False)
+    forked = build_model(cfg, 11, dev, use_graph=False, side_streams=True)
+    assert forked.engine.side[0] is not None and plain.engine.side[0] is None
+    for _ in range(3):
+        a, b = plain.train_fn(Z, X, Y), forked.train_fn(Z, X, Y)
+        assert a == b
+    pa, pb = model_params(plain), model_params(forked)
+    for k in pa:
+        for u, v in zip(pa[k], pb[k]):
+            assert np.array_equal(u, v)
+    # the default picks the side streams exactly when the step is not captured into a graph
+    assert build_model(cfg, 11, dev, use_graph=False).engine.side[0] is not None
+    assert build_model(cfg, 11, dev).engine.side[0] is None
