@@ -52,7 +52,7 @@ class GanStep:
                  side_streams=None):
         self.dev = dev
         if side_streams is None:            # forked branches replay slowly inside a HIP graph: eager mode only
-            side_streams = not use_graph
+            side_streams = (not use_graph) and two_streams
         if side_streams and use_graph:
             raise ValueError("side_streams needs use_graph=False")
         self.devs = [dev, Device(dev.index) if two_streams else dev]
