@@ -88,4 +88,10 @@ bool thin_wgrad_ok(const ghm_conv_desc* d, const float* x, const float* dy);
 int thin_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* dy, float* dwp, int accumulate);
 // out[i] (+)= sum over S slices of part[s*split_stride + i], fixed order (conv_igemm.hip)
 int ghm_reduce_splits(ghm_ctx* ctx, const float* part, int S, long n, long split_stride, float* out, int accumulate);
+bool thin_fanin_s1_fwd_ok(const ghm_conv_desc* d);
+int thin_fanin_s1_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,
+                      float* y, int act, float alpha, int accumulate);
+bool thin_fanin_s1_dgrad_ok(const ghm_conv_desc* d);
+int thin_fanin_s1_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const float* wp, const float* bias,
+                        float* dx, int act, float alpha, int accumulate);
 

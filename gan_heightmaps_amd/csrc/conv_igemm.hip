@@ -1568,6 +1568,7 @@ int ghm_conv2d_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const f
     if (int e = check_desc(d)) return e;
     GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
     if (d->C <= 4 && thin_fanout_fwd_ok(d, act)) return thin_fanout_fwd(ctx, d, x, wp, bias, y, act, alpha, accumulate);
+    if (d->K <= 4 && thin_fanin_s1_fwd_ok(d)) return thin_fanin_s1_fwd(ctx, d, x, wp, bias, y, act, alpha, accumulate);
     if (taps_as_rows(d, d->K)) {
         const int T = d->kh * d->kw;
         void* ws = nullptr;
@@ -1624,6 +1625,7 @@ int ghm_conv2d_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, cons
     if (d->K <= 4 && thin_fanout_dgrad_ok(d, act))
         return thin_fanout_dgrad(ctx, d, dy, wp, bias, dx, act, alpha, accumulate);
     if (thin_fanin_s2_ok(d, dx)) return thin_fanin_s2(ctx, d, dy, wp, bias, dx, act, alpha, accumulate);
+    if (d->C <= 4 && thin_fanin_s1_dgrad_ok(d)) return thin_fanin_s1_dgrad(ctx, d, dy, wp, bias, dx, act, alpha, accumulate);
     if (taps_as_rows(d, d->C)) {
         const int T = d->kh * d->kw;
         void* ws = nullptr;
@@ -1913,6 +1915,14 @@ int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t 
     }
     if (kind == 1 && d->K <= 4 && thin_fanout_dgrad_ok(d, GHM_ACT_LINEAR)) {
         snprintf(out, out_len, "fanout_kernel<dgrad>");
+        return 0;
+    }
+    if (kind == 0 && d->K <= 4 && thin_fanin_s1_fwd_ok(d)) {
+        snprintf(out, out_len, "fanin_s1_kernel<fwd>");
+        return 0;
+    }
+    if (kind == 1 && d->C <= 4 && !thin_fanin_s2_ok(d, nullptr) && thin_fanin_s1_dgrad_ok(d)) {
+        snprintf(out, out_len, "fanin_s1_kernel<dgrad>");
         return 0;
     }
     if (kind == 1 && thin_fanin_s2_ok(d, nullptr)) {

@@ -803,3 +803,183 @@ int thin_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float
 #undef GHM_TW_CASE
     return ghm_reduce_splits(ctx, a.part, blocks, a.n_out, a.n_out, dwp, accumulate);
 }
+
+// ------------------------------------------------------------------------------------------------
+// many -> few, stride 1, 'same' geometry (g_out forward; data gradient of d_conv1):
+//   out[n, j, p] = act(bias[j] + sum_t sum_c W[(j,t)][c] * in[n, c, p + off_t]),   JS*T <= 32 rows (j, t)
+// Taps as MFMA rows: S[(j,t)][q] = sum_c W[(j,t)][c] * in[c][q] is a 32 x pixels x CB GEMM whose B operand
+// (two channels x 32 consecutive pixels per k-step) comes straight from global memory with lanes along
+// pixels; the block computes S over its 16x64 output tile plus the filter halo into LDS and a second phase
+// sums the T shifted planes per output pixel.  Replaces the unfused form (S through HBM: 25 planes written
+// and re-read).  Algorithmic HBM bytes: the wide input once (x1.33 with the halo, mostly L2 hits).
+// ------------------------------------------------------------------------------------------------
+struct FaninS1Args {
+    const float* in;
+    const float* wp;
+    const float* bias;
+    float* out;
+    int N, CB, H, W;
+    long in_nstride, out_nstride;
+    int JS, KS, T, pad_lo;        // halo origin = tile origin - pad_lo
+    long w_cs;                    // weight stride between big channels
+    int wbase[32];                // weight offset of row (j, t); -1 for dead rows
+    int soff[32];                 // LDS offset of tap t relative to the output pixel (halo coordinates), per row
+    int act;
+    float alpha;
+    int accumulate;
+};
+
+template <int TH, int TW, int KS, int KSTEPS>
+__global__ __launch_bounds__(512) void fanin_s1_kernel(const FaninS1Args a) {
+    constexpr int HH = TH + KS - 1, HW_ = TW + KS - 1, NQ = HH * HW_;
+    constexpr int T = KS * KS;
+    extern __shared__ float S[];          // [T*JS rows used][NQ]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int h = lane >> 5, l = lane & 31;
+    const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+    const int bid = blockIdx.x;
+    const int n = bid / (tiles_x * tiles_y), trem = bid - n * tiles_x * tiles_y;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int y0 = ty * TH - a.pad_lo, x0 = tx * TW - a.pad_lo;      // halo origin (may be negative)
+    const int HWp = a.H * a.W;
+    const int R = a.JS * T;
+
+    // A fragments: lane (l, h) holds W[row l][c = 2s + h] for every k-step s (CB/2 <= 64 registers)
+    float A[KSTEPS];
+    const int wb = l < R ? a.wbase[l] : -1;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        const float w = a.wp[wb >= 0 ? wb + (long)(2 * s + h) * a.w_cs : 0];
+        A[s] = wb >= 0 ? w : 0.f;
+    }
+    const float* img = a.in + (long)n * a.in_nstride + (long)h * HWp;     // this half-wave's channel parity
+    constexpr int NSTRIP = (NQ + 31) / 32;
+    float Bn[KSTEPS];
+    bool okn = false;
+    auto fetch = [&](int strip) {
+        const int q = strip * 32 + l;
+        const int qy = q / HW_, qx = q - qy * HW_;
+        const int y = y0 + qy, x = x0 + qx;
+        okn = q < NQ && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        const float* src = img + (okn ? y * a.W + x : 0);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) Bn[s] = src[(long)(2 * s) * HWp];
+    };
+    if (wv < NSTRIP) fetch(wv);
+    for (int strip = wv; strip < NSTRIP; strip += 8) {
+        float Bc[KSTEPS];
+        const bool ok = okn;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) Bc[s] = ok ? Bn[s] : 0.f;
+        if (strip + 8 < NSTRIP) fetch(strip + 8);      // next strip's 2 x KSTEPS lines are in flight under the MFMAs
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], Bc[s], acc, 0, 0, 0);
+        const int q = strip * 32 + l;
+        if (q < NQ) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < R) S[row * NQ + q] = acc[e];
+            }
+        }
+    }
+    __syncthreads();
+    // shift-add: TH*TW output pixels x JS channels, consecutive threads on consecutive pixels
+    for (int i = threadIdx.x; i < TH * TW * a.JS; i += 512) {
+        const int j = i / (TH * TW), p = i - j * (TH * TW);
+        const int py = p / TW, px = p - py * TW;
+        const float* s0 = S + (j * T) * NQ + py * HW_ + px;
+        float v = a.bias ? a.bias[j] : 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) v += s0[t * NQ + a.soff[t]];
+        float* o = a.out + (long)n * a.out_nstride + (long)j * HWp + (ty * TH + py) * a.W + tx * TW + px;
+        if (a.accumulate) v += *o;
+        *o = ghm_act(v, a.act, a.alpha);
+    }
+}
+
+static bool fanin_s1_geometry_ok(int thin, int big, int kh, int kw, int H, int W, int N) {
+    return thin_enabled() && kh == kw && (kh == 5 || kh == 3) && thin * kh * kw <= 32 && (big == 64 || big == 128) &&
+           H % 16 == 0 && W % 64 == 0 && (long)N * H * W >= 32768;
+}
+
+// forward of a conv with <= 4 filters (stride 1, same size)
+bool thin_fanin_s1_fwd_ok(const ghm_conv_desc* d) {
+    return d->stride == 1 && d->Ho == d->H && d->Wo == d->W && fanin_s1_geometry_ok(d->K, d->C, d->kh, d->kw, d->H, d->W, d->N);
+}
+// data gradient of a conv with <= 4 input channels (stride 1, same size)
+bool thin_fanin_s1_dgrad_ok(const ghm_conv_desc* d) {
+    return d->stride == 1 && d->Ho == d->H && d->Wo == d->W && fanin_s1_geometry_ok(d->C, d->K, d->kh, d->kw, d->H, d->W, d->N);
+}
+
+static int launch_fanin_s1(ghm_ctx* ctx, FaninS1Args& a) {
+    constexpr int TH = 16, TW = 64;
+    const int hw = TW + a.KS - 1, nq = (TH + a.KS - 1) * hw;
+    const size_t lds = (size_t)a.JS * a.T * nq * sizeof(float);
+    const dim3 grid(a.N * (a.H / TH) * (a.W / TW));
+#define GHM_FS1_CASE(KS_, KST_)                                                                             \
+    if (a.KS == KS_ && a.CB == 2 * KST_) {                                                                  \
+        static bool opted = false;                                                                          \
+        if (!opted) {                                                                                       \
+            GHM_HIP(hipFuncSetAttribute((const void*)fanin_s1_kernel<TH, TW, KS_, KST_>,                    \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));            \
+            opted = true;                                                                                   \
+        }                                                                                                   \
+        hipLaunchKernelGGL((fanin_s1_kernel<TH, TW, KS_, KST_>), grid, dim3(512), lds, ctx->stream, a);     \
+        GHM_LAUNCH_CHECK();                                                                                 \
+        return 0;                                                                                           \
+    }
+    GHM_FS1_CASE(5, 32)
+    GHM_FS1_CASE(5, 64)
+    GHM_FS1_CASE(3, 32)
+    GHM_FS1_CASE(3, 64)
+#undef GHM_FS1_CASE
+    ghm_set_error("fanin_s1: no variant for k=%d", a.KS);
+    return -3;
+}
+
+int thin_fanin_s1_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,
+                      float* y, int act, float alpha, int accumulate) {
+    FaninS1Args a;
+    memset(&a, 0, sizeof(a));
+    const int T = d->kh * d->kw, hw = 64 + d->kw - 1;
+    a.in = x; a.wp = wp; a.bias = bias; a.out = y;
+    a.N = d->N; a.CB = d->C; a.H = d->H; a.W = d->W; a.in_nstride = d->x_nstride; a.out_nstride = d->y_nstride;
+    a.JS = d->K; a.KS = d->kh; a.T = T; a.pad_lo = d->pad;
+    a.w_cs = (long)T * d->K;
+    for (int r = 0; r < 32; ++r) a.wbase[r] = -1;
+    for (int j = 0; j < d->K; ++j)
+        for (int ta = 0; ta < d->kh; ++ta)
+            for (int tb = 0; tb < d->kw; ++tb) {
+                const int t = ta * d->kw + tb;
+                a.wbase[j * T + t] = t * d->K + j;
+                a.soff[t] = ta * hw + tb;                 // out(py,px) reads in(py + ta - pad, px + tb - pad)
+            }
+    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
+    return launch_fanin_s1(ctx, a);
+}
+
+int thin_fanin_s1_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const float* wp, const float* bias,
+                        float* dx, int act, float alpha, int accumulate) {
+    FaninS1Args a;
+    memset(&a, 0, sizeof(a));
+    const int T = d->kh * d->kw, hw = 64 + d->kw - 1;
+    a.in = dy; a.wp = wp; a.bias = bias; a.out = dx;
+    a.N = d->N; a.CB = d->K; a.H = d->H; a.W = d->W; a.in_nstride = d->y_nstride; a.out_nstride = d->x_nstride;
+    a.JS = d->C; a.KS = d->kh; a.T = T; a.pad_lo = d->kh - 1 - d->pad;
+    a.w_cs = 1;
+    for (int r = 0; r < 32; ++r) a.wbase[r] = -1;
+    for (int c = 0; c < d->C; ++c)
+        for (int ta = 0; ta < d->kh; ++ta)
+            for (int tb = 0; tb < d->kw; ++tb) {
+                const int t = ta * d->kw + tb;
+                a.wbase[c * T + t] = (c * T + t) * d->K;
+                // dx(u) += W[tap] * dy(u + pad - ta): halo coordinate = (pad - ta) + pad_lo = kh - 1 - ta
+                a.soff[t] = (d->kh - 1 - ta) * hw + (d->kw - 1 - tb);
+            }
+    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
+    return launch_fanin_s1(ctx, a);
+}

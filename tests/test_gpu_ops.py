@@ -72,11 +72,13 @@ def test_conv_fwd_dgrad_wgrad(gpu, case, tile):
 # first / last layers at full resolution: <= 4 channels on one side, large maps (conv_thin.hip)
 THIN_CASES = [
     # N, C, H, W, K, k, s, pad        fwd / dgrad / dgrad_t variants expected
-    ((2, 1, 128, 128, 64, 5, 1, 2), ("fanout_kernel<fwd>", None, None)),             # d_conv1
+    ((2, 1, 128, 128, 64, 5, 1, 2), ("fanout_kernel<fwd>", "fanin_s1_kernel<dgrad>", None)),   # d_conv1
     ((2, 4, 256, 256, 64, 3, 2, 1), ("fanout_kernel<fwd>", "fanin_s2_kernel<3>", None)),   # pd_conv1
     ((2, 1, 256, 256, 64, 3, 2, 1), ("fanout_kernel<fwd>", "fanin_s2_kernel<3>", None)),   # unet conv1
     ((2, 3, 256, 256, 128, 2, 2, 0), ("fanout_kernel<fwd>", "fanin_s2_kernel<2>", None)),  # final Deconv2DLayer
-    ((2, 64, 128, 128, 1, 5, 1, 2), (None, "fanout_kernel<dgrad>", "fanout_kernel<dgrad_t>")),   # g_out
+    ((2, 64, 128, 128, 1, 5, 1, 2), ("fanin_s1_kernel<fwd>", "fanout_kernel<dgrad>", "fanout_kernel<dgrad_t>")),   # g_out
+    ((2, 1, 64, 256, 64, 5, 1, 2), ("fanout_kernel<fwd>", "fanin_s1_kernel<dgrad>", None)),   # d_conv1, rectangular
+    ((2, 128, 128, 128, 3, 3, 1, 1), ("fanin_s1_kernel<fwd>", None, None)),          # 3 filters x 9 taps, 128 channels
     ((1, 64, 128, 256, 3, 3, 1, 1), (None, "fanout_kernel<dgrad>", "fanout_kernel<dgrad_t>")),   # 3 filters, 27 rows
     ((2, 3, 128, 256, 64, 3, 1, 1), ("fanout_kernel<fwd>", None, None)),             # 3 channels x 9 taps, rectangular
     ((2, 3, 128, 256, 48, 3, 1, 1), ("igemm_kernel<64,256,fwd>", None, None)),       # ragged filters: general kernel

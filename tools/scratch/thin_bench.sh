@@ -1,5 +1,3 @@
-python tools/conv_bench.py 8 1 512 512 64 5 1 2 --kinds wgrad 2>&1 | grep -v "^$"
-python tools/conv_bench.py 32 1 256 256 64 5 1 2 --kinds wgrad 2>&1 | grep -v "^$"
-python tools/conv_bench.py 2 1 1024 1024 64 5 1 2 --kinds wgrad 2>&1 | grep -v "^$"
-python tools/conv_bench.py 2 1 512 512 64 5 1 2 --kinds wgrad 2>&1 | grep -v "^$"
-python tools/conv_bench.py 1 1 512 512 64 5 1 2 --kinds wgrad 2>&1 | grep -v "^$"
+python -m pytest tests/test_gpu_ops.py -x -q -k "thin or taps" > gpurun_out/t.txt 2>&1; tail -5 gpurun_out/t.txt
+python tools/conv_bench.py 4 64 512 512 1 5 1 2 --kinds fwd 2>&1 | grep -v "^$"
+python tools/conv_bench.py 4 1 512 512 64 5 1 2 --kinds dgrad 2>&1 | grep -v "^$"
