@@ -962,7 +962,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 2) void wgrad_ker
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
-            if (ks == BKP / 4 - 1 && more && a.debug < 2) store_slab(buf ^ 1);
+            if (ks == BKP / 2 - 3 && more && a.debug < 2) store_slab(buf ^ 1);
         }
         __syncthreads();
     }
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(c
     constexpr int PATCH = ((CB * PS + 3) / 4) * 4;
     constexpr int NEL = CB * KS * PWN;          // patch elements to fetch per slab
     constexpr int AL = (NEL + 255) / 256;
-    constexpr int LDB = BN + 4;
+    constexpr int LDB = BN + 2;               // 4*LDB = 8 (mod 32): the transposed dy-tile stores spread over all banks
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int PV = BKP / 4;                 // float4 per filter row of the dy tile
     constexpr int CPP = 256 / PV;               // filters covered per pass
@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(c
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
-            if (ks == BKP / 4 - 1 && more && a.debug < 2) store_slab(buf ^ 1);
+            if (ks == BKP / 2 - 3 && more && a.debug < 2) store_slab(buf ^ 1);
         }
         __syncthreads();
     }

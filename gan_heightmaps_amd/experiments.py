@@ -2,9 +2,9 @@
 ``python experiments.py <experiment> <mode>``, experiments test1_nobn, test1_nobn_finetunep2p_bilin and
 test1_nobn_bilin_both, modes train / interp / gen.
 
-The HDF5 + Keras-augmentation iterator of the reference (util.py:10-62) is outside this round's scope
-(SURVEY.md 8 f1); ``get_iterators`` reads an ``.npz`` with xt/yt/xv/yv uint8 NHWC arrays when given one and
-otherwise serves seeded synthetic batches with the reference's value ranges.
+``get_iterators`` returns the device-side counterpart of util.Hdf5Iterator (gan_heightmaps_amd.data); h5py is not
+in this image, so it reads an ``.npz`` with xt/yt/xv/yv uint8 NHWC arrays when given one and otherwise serves
+seeded synthetic batches with the reference's value ranges.
 """
 import os
 import sys
@@ -87,8 +87,9 @@ _COMMON = dict(
     in_shp=512, latent_dim=1000, is_a_grayscale=True, is_b_grayscale=False, lsgan=True, opt=rmsprop)
 
 
-def make_model(name, **backend):
-    """Construct the Pix2Pix of experiment ``name``; ``backend`` = device / comm / use_graph / seed / verbose."""
+def experiment_kwargs(name):
+    """The keyword arguments experiments.py passes to Pix2Pix for experiment ``name`` (checked against the
+    reference's own file, executed, in tests/test_reference_graph.py)."""
     kw = dict(_COMMON)
     kw['opt_args'] = {'learning_rate': shared(floatX(1e-4))}
     if name == 'test1_nobn':
@@ -101,6 +102,12 @@ def make_model(name, **backend):
         kw['train_mode'] = 'both'
     else:
         raise KeyError(name)
+    return kw
+
+
+def make_model(name, **backend):
+    """Construct the Pix2Pix of experiment ``name``; ``backend`` = device / comm / use_graph / seed / verbose."""
+    kw = experiment_kwargs(name)
     kw.update(backend)
     return Pix2Pix(**kw)
 

@@ -1,0 +1,92 @@
+"""The drop-in boundary, pinned on the reference itself: tests/golden/reference_graph.json is what the REFERENCE's
+experiments.py + architectures/{dcgan,p2p,layers}.py build when they are executed unmodified against this
+package's layer vocabulary (tests/golden/make_reference_graph.py, run where /root/reference exists).  Here the
+same networks are built from this package's own re-typed architectures / experiments and must agree layer for
+layer: class, output shape, parameter names / shapes / tags, nonlinearity, and the Pix2Pix keyword arguments."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gan_heightmaps_amd import experiments as E
+from gan_heightmaps_amd import init as INIT
+from gan_heightmaps_amd import layers as L
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = json.load(open(os.path.join(HERE, "golden", "reference_graph.json")))
+
+_spec = importlib.util.spec_from_file_location("make_reference_graph", os.path.join(HERE, "golden", "make_reference_graph.py"))
+MRG = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(MRG)
+
+
+def build():
+    kw = E.experiment_kwargs(FIX["experiment"])
+    INIT.set_rng(np.random.RandomState(0))
+    nets = {
+        "dcgan_gen": kw["gen_fn_dcgan"](kw["latent_dim"], kw["is_a_grayscale"], **kw["gen_params_dcgan"]),
+        "dcgan_disc": kw["disc_fn_dcgan"](kw["in_shp"], kw["is_a_grayscale"], **kw["disc_params_dcgan"]),
+        "p2p_gen": kw["gen_fn_p2p"](kw["in_shp"], kw["is_a_grayscale"], kw["is_b_grayscale"], **kw["gen_params_p2p"]),
+    }
+    pd = kw["disc_fn_p2p"](kw["in_shp"], kw["is_a_grayscale"], kw["is_b_grayscale"], **kw["disc_params_p2p"])
+    nets["p2p_disc"] = pd["out"]
+    return kw, nets, pd
+
+
+def test_networks_match_what_the_reference_files_build():
+    kw, nets, pd = build()
+    for name, out in nets.items():
+        mine = json.loads(json.dumps(MRG.describe(out)))
+        ref = FIX["networks"][name]
+        assert len(mine) == len(ref), name
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            assert a == b, "%s layer %d: %r != %r" % (name, i, a, b)
+        assert int(L.count_params(out)) == FIX["param_counts"][name]
+    assert [list(l.shape) for l in pd["inputs"]] == FIX["p2p_disc_inputs"]
+    assert sum(FIX["param_counts"].values()) == 56566662
+
+
+def test_pix2pix_kwargs_match_what_the_reference_experiment_passes():
+    kw = E.experiment_kwargs(FIX["experiment"])
+    ref = FIX["pix2pix_kwargs"]
+    assert set(kw) == set(ref)
+    for k, v in ref.items():
+        mine = MRG.jsonable(kw[k])
+        if isinstance(v, str) and v.startswith("<"):
+            # a function: same name (the module differs: reference file vs this package)
+            assert mine.rsplit(".", 1)[-1] == v.rsplit(".", 1)[-1], k
+        elif isinstance(v, dict) and any(isinstance(x, str) and x.startswith("<") for x in v.values()):
+            assert set(mine) == set(v), k
+            for kk, vv in v.items():
+                if isinstance(vv, str) and vv.startswith("<"):
+                    assert mine[kk].rsplit(".", 1)[-1] == vv.rsplit(".", 1)[-1], (k, kk)
+                else:
+                    assert mine[kk] == vv, (k, kk)
+        elif k == "opt_args":
+            assert abs(mine["learning_rate"]["shared"] - v["learning_rate"]["shared"]) < 1e-12
+        else:
+            assert mine == v, k
+
+
+def test_training_call_and_iterators_of_the_reference_experiment():
+    # experiments.py:120-125: batch size 4, 1000 epochs, augmentation on, A grayscale / B colour
+    assert FIX["train_kwargs"]["batch_size"] == 4 and FIX["train_kwargs"]["num_epochs"] == 1000
+    for it in FIX["iterators"]:
+        assert it["bs"] == 4 and it["is_a_grayscale"] is True and it["is_b_grayscale"] is False
+        assert it["imgen"] == dict(horizontal_flip=True, vertical_flip=True, rotation_range=360, fill_mode="reflect")
+    it_train, it_val = E.get_iterators(None, 4, True, False, True, in_shp=32, n_synthetic=8)
+    g = it_train.imgen
+    assert (g.horizontal_flip, g.vertical_flip, g.rotation_range, g.fill_mode) == (True, True, 360, "reflect")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree only exists in the build container")
+def test_fixture_is_reproducible_from_the_reference(tmp_path, monkeypatch):
+    """re-run the generator against /root/reference and compare with the committed fixture"""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_reference_graph.py")],
+                         capture_output=True, text=True, env=dict(os.environ, GHM_FIXTURE_OUT=str(tmp_path / "g.json")))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.load(open(tmp_path / "g.json")) == FIX
