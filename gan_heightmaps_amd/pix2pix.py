@@ -17,7 +17,7 @@ from . import layers as L
 from .device import Device
 from .step import GanStep, TRAIN_KEYS
 from .updates import adam, shared, OptimizerSpec
-from .util import convert_to_rgb, imsave
+from .util import convert_to_rgb, imsave, plot_grid
 
 floatX = _init.floatX
 
@@ -111,10 +111,14 @@ class Pix2Pix:
 
     # ---- training loop (pix2pix.py:187-275) ----------------------------------------------------------------
     def train(self, it_train, it_val, batch_size, num_epochs, out_dir, model_dir=None, save_every=10, resume=False,
-              quick_run=False, validate_on_train_iterator=True, dump_images=False):
+              quick_run=False, validate_on_train_iterator=True, dump_images=True):
         """Same loop as the reference: per epoch N//batch_size train_fn steps then N//batch_size loss_fn steps,
-        a CSV row of epoch means, periodic checkpoints.  The reference's validation loop draws its batches from
-        ``it_train`` (pix2pix.py:204); ``validate_on_train_iterator=True`` keeps that behaviour."""
+        a CSV row of epoch means, then the per-epoch image dumps (a 4x4 grid of [A | U(A)] from ``it_val``, one batch of
+        A->B pairs from each iterator, 20 DCGAN samples -- pix2pix.py:262-270; they advance the iterators, so they
+        are part of the training trajectory; ``dump_images=False`` skips them), periodic checkpoints.  The
+        reference's validation loop draws its batches from ``it_train`` (pix2pix.py:204);
+        ``validate_on_train_iterator=True`` keeps that behaviour.  Checked event for event against the reference's
+        own loop in tests/test_reference_trainloop.py."""
         def _next(it):
             return next(it) if hasattr(it, '__next__') else it.next()
 
@@ -164,6 +168,8 @@ class Pix2Pix:
             f.flush()
             if dump_images:
                 if self.train_mode in ['both', 'p2p']:
+                    plot_grid("%s/out_%i.png" % (out_dir, e + 1), it_val, self.gen_fn,
+                              is_a_grayscale=self.is_a_grayscale, is_b_grayscale=self.is_b_grayscale)
                     self.generate_atob(it_train, 1, "%s/dump_train" % out_dir, deterministic=False)
                     self.generate_atob(it_val, 1, "%s/dump_valid" % out_dir, deterministic=False)
                 if self.train_mode in ['both', 'dcgan']:
