@@ -23,7 +23,8 @@ REF = "/root/reference"
 
 
 class RecordingGenerator:
-    def __init__(self):
+    def __init__(self, **kw):
+        self.kw = kw
         self.seeds = []
 
     def flow(self, x, y=None, batch_size=None, seed=None):

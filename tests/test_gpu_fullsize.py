@@ -173,3 +173,55 @@ def test_full_size_batch4_step_properties(gpu):
         del m
     # bit-for-bit repeatable from the same seed (split-K partials are reduced in a fixed order, no atomics on data)
     assert np.array_equal(runs[0], runs[1])
+
+
+def test_full_size_step_against_the_reference_executed_fixture(gpu):
+    """tests/golden/reference_step_fullsize.npz: the reference's experiments.py -> Pix2Pix.__init__ -> its own 512x512
+    architecture files, executed on the oracle's ops in float64 (tests/golden/make_reference_step_fullsize.py), one
+    train_fn call at batch 2.  The HIP step must start from the same parameters (same RNG draws in the same order),
+    return the same five losses and move every parameter tensor the same way."""
+    import os
+    dev, ops, D = gpu
+    from gan_heightmaps_amd.experiments import make_model
+    from gan_heightmaps_amd import layers as L
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_step_fullsize.npz"))
+    seed, batch, dseed = (int(v) for v in fix["meta"])
+    cfg = ostep.default_cfg()
+    model = make_model('test1_nobn_bilin_both', device=dev, seed=seed, verbose=False)
+    Z, X, Y = ostep.synthetic_batch(batch, cfg, seed=dseed)
+
+    def summaries():
+        out = {}
+        for a in ("dcgan", "p2p"):
+            for b in ("gen", "disc"):
+                for i, v in enumerate(L.get_all_param_values(getattr(model, a)[b])):
+                    v64 = np.asarray(v, np.float64).ravel()
+                    idx = np.linspace(0, v64.size - 1, 8).astype(np.int64)
+                    out["%s/%s/%03d" % (a, b, i)] = np.concatenate([[v64.sum(), np.sqrt((v64 * v64).sum())], v64[idx]])
+        return out
+    before = summaries()
+    keys = sorted(k[len("before/"):] for k in fix.files if k.startswith("before/"))
+    assert sorted(before) == keys and len(keys) == 180
+    for k in keys:
+        assert np.allclose(before[k], fix["before/" + k], rtol=1e-6, atol=1e-9), k      # identical initial parameters
+    got = model.train_fn(Z, X, Y)
+    assert rel(got, fix["train0"]) < 1e-5, (got, fix["train0"])
+    after = summaries()
+    # RMSprop's first step moves every element by lr * g / sqrt(0.1 g^2 + 1e-6): compare the movement itself
+    d_hip = np.concatenate([(after[k] - before[k])[2:] for k in keys])
+    d_ref = np.concatenate([(fix["after/" + k] - fix["before/" + k])[2:] for k in keys])
+    assert np.linalg.norm(d_ref) > 0
+    assert rel(d_hip, d_ref) < 2e-2, rel(d_hip, d_ref)
+    assert np.mean(np.abs(d_hip - d_ref) < 2e-5) > 0.98
+    # total movement per tensor (sum over all elements), relative to lr * sqrt(10) * size
+    worst = 0.0
+    for k in keys:
+        ds_hip, ds_ref = (after[k] - before[k])[0], (fix["after/" + k] - fix["before/" + k])[0]
+        scale = max(abs(ds_ref), 1e-4 * 3.2 * 8)
+        worst = max(worst, abs(ds_hip - ds_ref) / scale)
+    assert worst < 0.25, worst
+    # norms after the step
+    for k in keys:
+        # (biases that feed a BatchNorm start at 0 and have an exactly-zero true gradient: they only carry noise)
+        assert abs(after[k][1] - fix["after/" + k][1]) <= 1e-4 * fix["after/" + k][1] + 1e-6, k
+    del model
