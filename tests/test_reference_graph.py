@@ -90,3 +90,47 @@ def test_fixture_is_reproducible_from_the_reference(tmp_path, monkeypatch):
                          capture_output=True, text=True, env=dict(os.environ, GHM_FIXTURE_OUT=str(tmp_path / "g.json")))
     assert out.returncode == 0, out.stderr[-2000:]
     assert json.load(open(tmp_path / "g.json")) == FIX
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree only exists in the build container")
+def test_reference_experiment_script_runs_on_the_aliased_backend(monkeypatch, tmp_path):
+    """gan_heightmaps_amd.as_lasagne.install() + the reference's experiments.py, unmodified, up to and including
+    the construction of Pix2Pix on this package's engine (a recording device stands in for the GPU)."""
+    import runpy
+    import sys
+    import types
+    from tests.fake_device import FakeDevice, RecordingOps
+    import gan_heightmaps_amd.as_lasagne as shim
+    import gan_heightmaps_amd.pix2pix as PP
+    import gan_heightmaps_amd.step as ST
+    saved = dict(sys.modules)
+    try:
+        shim.install()
+        monkeypatch.setattr(PP, "Device", lambda index=0: FakeDevice())
+        monkeypatch.setattr(ST, "Ops", RecordingOps)
+        monkeypatch.setattr(ST, "Device", lambda index=0: FakeDevice())
+        FakeDevice.index = 0
+        built = {}
+
+        def train(self, it_train, it_val, **kw):
+            built["model"], built["kw"], built["it"] = self, kw, it_train
+        monkeypatch.setattr(PP.Pix2Pix, "train", train)
+        X = np.zeros((8, 16, 16, 1), np.uint8)
+        Y = np.zeros((8, 16, 16, 3), np.uint8)
+        sys.modules["h5py"] = types.SimpleNamespace(File=lambda path, mode: dict(xt=X, yt=Y, xv=X, yv=Y))
+        monkeypatch.setattr(sys, "argv", ["experiments.py", "test1_nobn_bilin_both", "train"])
+        monkeypatch.syspath_prepend("/root/reference")
+        monkeypatch.chdir(tmp_path)
+        runpy.run_path("/root/reference/experiments.py", run_name="__main__")
+    finally:
+        for k in list(sys.modules):
+            if k not in saved:
+                del sys.modules[k]
+        sys.modules.update(saved)
+    m = built["model"]
+    assert built["kw"]["batch_size"] == 4 and built["it"].N == 8
+    assert m.train_mode == "both" and m.engine.opt_spec.kind == "rmsprop" and abs(m.lr.get_value() - 1e-4) < 1e-12
+    assert {k: int(L.count_params(v)) for k, v in (("dcgan_gen", m.dcgan["gen"]), ("dcgan_disc", m.dcgan["disc"]),
+                                                   ("p2p_gen", m.p2p["gen"]), ("p2p_disc", m.p2p["disc"]))} == FIX["param_counts"]
+    b = m.engine.built(4)            # the four 512x512 plans lower to device programs
+    assert sum(len(lane) for lane in b.train_compute) > 250
