@@ -543,6 +543,99 @@ inline bool vec_ok(int HW, Args... strides_or_ptr_ok) {
 
 }  // namespace
 
+
+// ---- Upscale2DLayer(2, 'repeat') followed by a 5x5 'same' convolution (every stage of dcgan.default_generator,
+// architectures/dcgan.py:22-31) == four 3x3 convolutions of the LOW-resolution input, one per output parity
+// (p, q), whose weights are sums of the 5x5 taps that land on the same low-resolution pixel:
+//   correlation tap a (offset a-2) of output row 2i+p reads low-res row i + floor((p+a-2)/2)
+//     p=0: a in {0,1} -> -1, {2,3} -> 0, {4} -> +1        p=1: {0} -> -1, {1,2} -> 0, {3,4} -> +1
+// 9 instead of 25 MACs per output value, and the 4x up-sampled tensor is never materialised.  The collapsed
+// weights are a packed 3x3 conv with 4K filters ordered (pq, k): its output [N, 4K, H, W] is, as memory, the
+// "parity-planar" tensor [4N, K, H, W] (sample 4n+pq = parity plane pq of image n) on which BatchNorm and the
+// activation run unchanged; pp_to_hi interleaves the planes into [N, K, 2H, 2W].
+__device__ __forceinline__ int upconv_group(int p, int a) {       // low-res offset + 1 of tap a for parity p
+    return p == 0 ? (a < 2 ? 0 : (a < 4 ? 1 : 2)) : (a < 1 ? 0 : (a < 3 ? 1 : 2));
+}
+
+__global__ __launch_bounds__(256) void upconv_collapse_kernel(const float* __restrict__ wp5, float* __restrict__ wpc, int C,
+                                                              int K) {
+    const long total = (long)C * 9 * 4 * K;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % K);
+    long t = i / K;
+    const int pq = (int)(t % 4); t /= 4;
+    const int rs = (int)(t % 9);
+    const int c = (int)(t / 9);
+    const int p = pq >> 1, q = pq & 1, r = rs / 3, s_ = rs % 3;
+    float v = 0.f;
+    for (int a = 0; a < 5; ++a) {
+        if (upconv_group(p, a) != r) continue;
+        for (int b = 0; b < 5; ++b)
+            if (upconv_group(q, b) == s_) v += wp5[((long)c * 25 + a * 5 + b) * K + k];
+    }
+    wpc[i] = v;
+}
+
+__global__ __launch_bounds__(256) void upconv_expand_kernel(const float* __restrict__ dwpc, float* __restrict__ dwp5, int C,
+                                                            int K, int accumulate) {
+    const long total = (long)C * 25 * K;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % K);
+    long t = i / K;
+    const int ab = (int)(t % 25);
+    const int c = (int)(t / 25);
+    const int a = ab / 5, b = ab % 5;
+    float v = 0.f;
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) {
+        const int rs = upconv_group(pq >> 1, a) * 3 + upconv_group(pq & 1, b);
+        v += dwpc[(((long)c * 9 + rs) * 4 + pq) * K + k];
+    }
+    dwp5[i] = accumulate ? dwp5[i] + v : v;
+}
+
+__global__ __launch_bounds__(256) void bias_tile4_kernel(const float* __restrict__ b, float* __restrict__ bc, int K) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 4 * K) bc[i] = b[i % K];
+}
+
+// pp [4N, K, H, W] <-> hi [N, K, 2H, 2W]; one thread per low-res pixel moves its 2x2 block (16-byte rows)
+__global__ __launch_bounds__(256) void pp_to_hi_kernel(const float* __restrict__ pp, float* __restrict__ hi, long hi_nstride,
+                                                       int N, int K, int H, int W) {
+    const long total = (long)N * K * H * W;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % W);
+    long t = i / W;
+    const int y = (int)(t % H); t /= H;
+    const int k = (int)(t % K);
+    const int n = (int)(t / K);
+    const long plane = (long)K * H * W;
+    const float* src = pp + ((long)n * 4) * plane + ((long)k * H + y) * W + x;
+    float* dst = hi + (long)n * hi_nstride + ((long)k * 2 * H + 2 * y) * (2 * W) + 2 * x;
+    *reinterpret_cast<float2*>(dst) = make_float2(src[0], src[plane]);
+    *reinterpret_cast<float2*>(dst + 2 * W) = make_float2(src[2 * plane], src[3 * plane]);
+}
+
+__global__ __launch_bounds__(256) void hi_to_pp_kernel(const float* __restrict__ hi, long hi_nstride, float* __restrict__ pp,
+                                                       int N, int K, int H, int W) {
+    const long total = (long)N * K * H * W;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int x = (int)(i % W);
+    long t = i / W;
+    const int y = (int)(t % H); t /= H;
+    const int k = (int)(t % K);
+    const int n = (int)(t / K);
+    const long plane = (long)K * H * W;
+    float* dst = pp + ((long)n * 4) * plane + ((long)k * H + y) * W + x;
+    const float* src = hi + (long)n * hi_nstride + ((long)k * 2 * H + 2 * y) * (2 * W) + 2 * x;
+    const float2 a = *reinterpret_cast<const float2*>(src), b = *reinterpret_cast<const float2*>(src + 2 * W);
+    dst[0] = a.x; dst[plane] = a.y; dst[2 * plane] = b.x; dst[3 * plane] = b.y;
+}
+
 #define EW_GRID(total) dim3(ceil_div((long)(total), 256)), dim3(256), 0, ctx->stream
 
 extern "C" {
@@ -680,6 +773,37 @@ int ghm_avgpool_fwd(ghm_ctx* ctx, const float* x, float* y, int32_t N, int32_t C
 
 int ghm_avgpool_bwd(ghm_ctx* ctx, const float* dy, float* dx, int32_t N, int32_t C, int32_t H, int32_t W, int32_t p) {
     hipLaunchKernelGGL(avgpool_bwd_kernel, EW_GRID((long)N * C * H * W), dy, dx, (long)N * C, H, W, p);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_upconv_collapse_weights(ghm_ctx* ctx, const float* wp5, const float* bias, float* wpc, float* bias4, int32_t C,
+                                int32_t K) {
+    hipLaunchKernelGGL(upconv_collapse_kernel, EW_GRID((long)C * 36 * K), wp5, wpc, C, K);
+    GHM_LAUNCH_CHECK();
+    if (bias && bias4) {
+        hipLaunchKernelGGL(bias_tile4_kernel, EW_GRID(4L * K), bias, bias4, K);
+        GHM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int ghm_upconv_expand_wgrad(ghm_ctx* ctx, const float* dwpc, float* dwp5, int32_t C, int32_t K, int32_t accumulate) {
+    hipLaunchKernelGGL(upconv_expand_kernel, EW_GRID((long)C * 25 * K), dwpc, dwp5, C, K, accumulate);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_pp_to_hi(ghm_ctx* ctx, const float* pp, float* hi, int64_t hi_nstride, int32_t N, int32_t K, int32_t H, int32_t W) {
+    GHM_CHECK(((uintptr_t)hi % 8 == 0) && hi_nstride % 2 == 0, "pp_to_hi: 8-byte aligned destination required");
+    hipLaunchKernelGGL(pp_to_hi_kernel, EW_GRID((long)N * K * H * W), pp, hi, (long)hi_nstride, N, K, H, W);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_hi_to_pp(ghm_ctx* ctx, const float* hi, int64_t hi_nstride, float* pp, int32_t N, int32_t K, int32_t H, int32_t W) {
+    GHM_CHECK(((uintptr_t)hi % 8 == 0) && hi_nstride % 2 == 0, "hi_to_pp: 8-byte aligned source required");
+    hipLaunchKernelGGL(hi_to_pp_kernel, EW_GRID((long)N * K * H * W), hi, (long)hi_nstride, pp, N, K, H, W);
     GHM_LAUNCH_CHECK();
     return 0;
 }

@@ -286,6 +286,21 @@ class Ops:
         assert dy.contiguous and dx.contiguous
         call("ghm_avgpool_bwd", self.h, _vp(dy), _vp(dx), dx.N, dx.Cc, dx.H, dx.W, p)
 
+    def upconv_collapse_weights(self, wp5, bias, wpc, bias4, C, K):
+        call("ghm_upconv_collapse_weights", self.h, _vp(wp5), _vp(bias), _vp(wpc), _vp(bias4), C, K)
+
+    def upconv_expand_wgrad(self, dwpc, dwp5, C, K, accumulate=False):
+        call("ghm_upconv_expand_wgrad", self.h, _vp(dwpc), _vp(dwp5), C, K, int(accumulate))
+
+    def pp_to_hi(self, pp, hi):
+        """pp [4N,K,H,W] (contiguous) -> hi [N,K,2H,2W]"""
+        assert pp.contiguous and pp.N == 4 * hi.N
+        call("ghm_pp_to_hi", self.h, _vp(pp), _vp(hi), hi.nstride, hi.N, pp.Cc, pp.H, pp.W)
+
+    def hi_to_pp(self, hi, pp):
+        assert pp.contiguous and pp.N == 4 * hi.N
+        call("ghm_hi_to_pp", self.h, _vp(hi), hi.nstride, _vp(pp), hi.N, pp.Cc, pp.H, pp.W)
+
     def upsample_nearest2_fwd(self, x, y):
         assert y.contiguous
         call("ghm_upsample_nearest2_fwd", self.h, _vp(x), x.nstride, _vp(y), x.N, x.Cc, x.H, x.W)

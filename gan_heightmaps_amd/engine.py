@@ -14,6 +14,8 @@ Graph rewrites before placement (both exact):
 Placement: inputs of a ConcatLayer(axis=1) are written in place into channel slices of the concat
 buffer (sample stride = total channels * H * W), so concatenation costs no copy.
 """
+import os
+
 import numpy as np
 
 from . import layers as L
@@ -233,6 +235,34 @@ def _rewrite(out_node):
                     _replace(order, n, m)
                     changed = True
                     break
+    # R3: Upscale2DLayer(2) -> 5x5 'same' conv  ==>  3x3 conv with 4K filters on the low-res input whose output is
+    # the parity-planar [4B, K, H, W] tensor (BatchNorm / activation run on it unchanged), then one interleave
+    # pass to [B, K, 2H, 2W].  9 instead of 25 MACs per output, no 4x up-sampled tensor (csrc/elementwise.hip).
+    if os.environ.get("GHM_NO_UPCONV") is None:
+        changed = True
+        while changed:
+            changed = False
+            order = _toposort(out_node)
+            for n in order:
+                if n.op != 'conv' or n.inputs[0].op != 'up_nearest' or len(n.inputs[0].consumers) != 1:
+                    continue
+                l = n.layer
+                if l.filter_size != (5, 5) or l.stride != (1, 1) or l.pad != (2, 2):
+                    continue
+                uc = Node('upconv', [n.inputs[0].inputs[0]], l)
+                uc.act = n.act
+                tail_old, tail_new = n, uc
+                if len(n.consumers) == 1 and n.consumers[0].op == 'bn':
+                    tail_old = tail_new = n.consumers[0]
+                    tail_new.inputs = [uc]
+                sh = Node('pp_to_hi', [tail_new], None)
+                if tail_old is out_node:
+                    out_node = sh
+                for m in order:
+                    if m is not tail_new:
+                        m.inputs = [sh if i is tail_old else i for i in m.inputs]
+                changed = True
+                break
     return out_node
 
 
@@ -278,6 +308,14 @@ class NetPlan:
             elif n.op == 'concat':
                 s0 = n.inputs[0].shape
                 n.shape = (B, sum(i.shape[1] for i in n.inputs), s0[2], s0[3])
+            elif n.op == 'upconv':
+                s0 = n.inputs[0].shape
+                n.shape = (4 * s0[0], n.layer.num_filters, s0[2], s0[3])
+            elif n.op == 'pp_to_hi':
+                s0 = n.inputs[0].shape
+                n.shape = (s0[0] // 4, s0[1], 2 * s0[2], 2 * s0[3])
+            elif n.op == 'bn':
+                n.shape = tuple(n.inputs[0].shape)
             else:
                 ls = n.layer.get_output_shape_for((B,) + tuple(n.inputs[0].shape[1:])) \
                     if n.op not in ('dense',) else (B, n.layer.num_units)
@@ -320,6 +358,11 @@ class NetPlan:
                 C = n.shape[1]
                 n.aux['mean'] = self.dev.empty((1, C, 1, 1))
                 n.aux['inv'] = self.dev.empty((1, C, 1, 1))
+            if n.op == 'upconv':
+                C, K = n.inputs[0].shape[1], n.shape[1]
+                for name in ('wpc', 'wpcT', 'dwpc'):
+                    n.aux[name] = self.dev.empty((1, C * 9 * 4 * K, 1, 1))
+                n.aux['b4'] = self.dev.empty((1, 4 * K, 1, 1))
 
     def input_tensor(self, layer):
         return self.node_of_layer[id(layer)].out
@@ -340,6 +383,11 @@ class NetPlan:
                              x_t.nstride, y_t.nstride)
         # deconv: descriptor of the conv it is the adjoint of (conv input = deconv OUTPUT = x_t here)
         return conv_desc(x_t.N, x_t.Cc, x_t.H, x_t.W, y_t.Cc, k[0], k[1], l.stride[0], 0, x_t.nstride, y_t.nstride)
+
+    def _upconv_desc(self, n, x_t):
+        """3x3 'same' conv with 4K filters on the low-res input x_t -> parity-planar output seen as [N, 4K, H, W]"""
+        K = n.shape[1]
+        return conv_desc(x_t.N, x_t.Cc, x_t.H, x_t.W, 4 * K, 3, 3, 1, 1, x_t.nstride, 4 * K * x_t.H * x_t.W)
 
     def _need_wgrad_ws(self, d):
         b = self.ops.wgrad_workspace(d)
@@ -390,6 +438,18 @@ class NetPlan:
                                               l.epsilon, l.alpha)))
                     prog.append(("bn_apply", lambda x=x, y=y, m=m, iv=iv, g=g, be=be, a=a:
                                  ops.bn_apply(x, y, m, iv, g, be, a.kind, a.alpha)))
+            elif n.op == 'upconv':
+                d = self._upconv_desc(n, x)
+                w5, b = st.value(n.layer.W), st.value(n.layer.b)
+                wpc, b4 = n.aux['wpc'], n.aux['b4']
+                C, K = x.Cc, n.shape[1]
+                y4 = y.reshape((x.N, 4 * K, x.H, x.W))
+                prog.append(("collapse_w", lambda w5=w5, b=b, wpc=wpc, b4=b4, C=C, K=K:
+                             ops.upconv_collapse_weights(w5, b, wpc, b4, C, K)))
+                prog.append(("upconv_fwd", lambda d=d, x=x, wpc=wpc, b4=b4, y4=y4, a=a:
+                             ops.conv2d_fwd(d, x, wpc, b4, y4, a.kind, a.alpha), conv_meta(ops, d, 0)))
+            elif n.op == 'pp_to_hi':
+                prog.append(("pp_to_hi", lambda x=x, y=y: ops.pp_to_hi(x, y)))
             elif n.op == 'act':
                 prog.append(("act_fwd", lambda x=x, y=y, a=a: ops.act_fwd(x, y, a.kind, a.alpha)))
             elif n.op == 'up_nearest':
@@ -422,7 +482,7 @@ class NetPlan:
         # which nodes need a gradient at all
         req = {}
         for n in self.order:
-            has_p = wgrad and n.op in ('conv', 'deconv', 'dense', 'bn')
+            has_p = wgrad and n.op in ('conv', 'deconv', 'dense', 'bn', 'upconv')
             req[id(n)] = has_p or any(req[id(i)] for i in n.inputs) or id(n) in want_in
         grads, written = {}, set()
         key = (tag, n0, n1)
@@ -438,7 +498,7 @@ class NetPlan:
                 cat, c0 = n.alias
                 g = grad_of(cat).channels(c0, c0 + n.shape[1])
             else:
-                g = dev.empty((nb,) + tuple(n.shape[1:]))
+                g = dev.empty((nb * (n.shape[0] // self.batch),) + tuple(n.shape[1:]))
             cache[id(n)] = g
             grads[id(n)] = g
             return g
@@ -531,6 +591,50 @@ class NetPlan:
                         d2 = self._desc(n, gi, G)
                         prog.append(("%s_dgrad" % n.op, lambda d=d2, G=G, w=w, gi=gi, acc=acc:
                                      ops.conv2d_dgrad(d, G, w, gi, None, 'linear', 0.0, acc), conv_meta(ops, d2, 1)))
+                    mark_written(xin)
+            elif n.op == 'upconv':
+                if nslice is not None:
+                    raise NotImplementedError("sample slices through a collapsed up-sample convolution")
+                if a != linear:
+                    prog.append(("act_bwd", lambda G=G, y=y, a=a: ops.act_bwd(G, y, G, a.kind, a.alpha)))
+                l = n.layer
+                d = self._upconv_desc(n, x)
+                C, K = x.Cc, n.shape[1]
+                G4 = G.reshape((x.N, 4 * K, x.H, x.W))
+                wpc, wpcT, dwpc = n.aux['wpc'], n.aux['wpcT'], n.aux['dwpc']
+                if wgrad:
+                    self._need_wgrad_ws(d)
+                    gw, gb = st.grad(l.W), st.grad(l.b)
+                    aw = accumulate_wgrad
+                    wo, wdev = ops, None
+                    if self.side is not None:
+                        wdev, wo = self.side
+                        prog.append(("fork", lambda wdev=wdev: wdev.wait_for(dev), None, wdev))
+                    prog.append(("upconv_wgrad", lambda d=d, x=x, G4=G4, dwpc=dwpc, wo=wo:
+                                 wo.conv2d_wgrad(d, x, G4, dwpc, self.wgrad_ws, False), conv_meta(ops, d, 2), wdev))
+                    prog.append(("expand_wgrad", lambda dwpc=dwpc, gw=gw, C=C, K=K, aw=aw, wo=wo:
+                                 wo.upconv_expand_wgrad(dwpc, gw, C, K, aw), None, wdev))
+                    bn_fed = len(n.consumers) == 1 and n.consumers[0].op == 'bn' and n.act == linear
+                    if not bn_fed:
+                        prog.append(("bias_grad", lambda G=G, gb=gb, aw=aw, wo=wo: wo.channel_sum(G, gb, aw), None, wdev))
+                if need_dx:
+                    gi, acc = target(xin)
+                    if C > 4 and ops.dgrad_t_supported(d):
+                        if ('c', id(l.W)) not in transposed:
+                            transposed.add(('c', id(l.W)))
+                            prog.append(("transpose_w", lambda d=d, wpc=wpc, wpcT=wpcT: ops.transpose_weights(d, wpc, wpcT)))
+                        prog.append(("upconv_dgrad", lambda d=d, G4=G4, wpcT=wpcT, gi=gi, acc=acc:
+                                     ops.conv2d_dgrad_t(d, G4, wpcT, gi, None, 'linear', 0.0, acc), conv_meta(ops, d, 3)))
+                    else:
+                        prog.append(("upconv_dgrad", lambda d=d, G4=G4, wpc=wpc, gi=gi, acc=acc:
+                                     ops.conv2d_dgrad(d, G4, wpc, gi, None, 'linear', 0.0, acc), conv_meta(ops, d, 1)))
+                    mark_written(xin)
+            elif n.op == 'pp_to_hi':
+                if need_dx:
+                    gi, acc = target(xin)
+                    if acc or nslice is not None:
+                        raise NotImplementedError("parity-planar tensor with several consumers / sample slices")
+                    prog.append(("hi_to_pp", lambda G=G, gi=gi: ops.hi_to_pp(G, gi)))
                     mark_written(xin)
             elif n.op == 'bn':
                 l = n.layer

@@ -472,3 +472,55 @@ def test_taps_as_rows_path(gpu, case):
     assert rel(dx2.numpy(), dx2_ref) < TOL
     ops.conv2d_dgrad(d2, dev.tensor(g2), dev.tensor(D.pack_conv_w(W2).ravel()), dx2, accumulate=True)
     assert rel(dx2.numpy(), 2 * dx2_ref) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 16, 8, 8, 32), (1, 8, 16, 32, 4), (2, 64, 32, 32, 64), (3, 5, 4, 6, 1)])
+def test_upscale_conv5_collapsed_to_four_3x3(gpu, case):
+    """Upscale2DLayer(2) -> Conv2DLayer(5x5, 'same') (dcgan.py:22-31) evaluated as a 3x3 conv with 4K filters on the
+    low-res input + parity interleave; forward, data gradient and weight gradient against the oracle's literal
+    upscale + 5x5 convolution"""
+    dev, ops, D = gpu
+    N, C, H, W, K = case
+    rng = np.random.RandomState(sum(case))
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    Wt = (rng.randn(K, C, 5, 5) / np.sqrt(C * 25)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    xu = O.upscale_nearest_fwd(x.astype(np.float64), 2)
+    y_ref = O.conv2d_fwd(xu, Wt.astype(np.float64), b.astype(np.float64), 1, 2)
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    dxu, dW_ref, db_ref = O.conv2d_vjp(xu, Wt.astype(np.float64), dy.astype(np.float64), 1, 2)
+    dx_ref = O.upscale_nearest_vjp(dxu, 2)
+
+    wp5 = dev.tensor(D.pack_conv_w(Wt).ravel())
+    bd = dev.tensor(b)
+    wpc, b4 = dev.empty((1, C * 9 * 4 * K, 1, 1)), dev.empty((1, 4 * K, 1, 1))
+    ops.upconv_collapse_weights(wp5, bd, wpc, b4, C, K)
+    assert np.array_equal(b4.numpy().ravel(), np.tile(b, 4))
+    d = D.conv_desc(N, C, H, W, 4 * K, 3, 3, 1, 1)
+    xd = dev.tensor(x)
+    pp = dev.empty((4 * N, K, H, W))
+    ops.conv2d_fwd(d, xd, wpc, b4, pp.reshape((N, 4 * K, H, W)))
+    hi = dev.empty((N, K, 2 * H, 2 * W))
+    ops.pp_to_hi(pp, hi)
+    assert rel(hi.numpy(), y_ref) < TOL
+    # backward: dy (hi) -> pp -> 3x3 data gradient (sums the four parities) and collapsed weight gradient -> 5x5
+    dyd = dev.tensor(dy)
+    dpp = dev.empty((4 * N, K, H, W))
+    ops.hi_to_pp(dyd, dpp)
+    back = dev.empty((N, K, 2 * H, 2 * W))
+    ops.pp_to_hi(dpp, back)
+    assert np.array_equal(back.numpy(), dy)                      # the two permutations are inverses
+    dxd = dev.empty((N, C, H, W))
+    ops.conv2d_dgrad(d, dpp.reshape((N, 4 * K, H, W)), wpc, dxd)
+    assert rel(dxd.numpy(), dx_ref) < TOL
+    dwc = dev.zeros((1, C * 9 * 4 * K, 1, 1))
+    ops.conv2d_wgrad(d, xd, dpp.reshape((N, 4 * K, H, W)), dwc, dev.alloc(ops.wgrad_workspace(d)))
+    dw5 = dev.zeros((1, C * 25 * K, 1, 1))
+    ops.upconv_expand_wgrad(dwc, dw5, C, K)
+    assert rel(D.unpack_conv_w(dw5.numpy().ravel(), K, C, 5, 5), dW_ref) < TOL
+    ops.upconv_expand_wgrad(dwc, dw5, C, K, accumulate=True)
+    assert rel(D.unpack_conv_w(dw5.numpy().ravel(), K, C, 5, 5), 2 * dW_ref) < TOL
+    # bias gradient = per-channel sum over the parity-planar tensor
+    dbd = dev.empty((1, K, 1, 1))
+    ops.channel_sum(dpp, dbd)
+    assert rel(dbd.numpy().ravel(), db_ref) < TOL

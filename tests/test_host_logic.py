@@ -129,7 +129,9 @@ def test_gan_step_program_structure_on_fake_device():
                                                            ['rmsprop_p2p_gen', 'rmsprop_p2p_disc']]
     assert b.exchange == []
     # D is differentiated twice: once with weight gradients (2B batch), once data-gradient only (fake half)
-    d_wgrads = sum(1 for lane in b.train_compute for e in lane if e[0] == 'conv_wgrad')
+    # (the generator's Upscale2D -> 5x5 convs run as collapsed 3x3 convs: 'upconv_wgrad')
+    d_wgrads = sum(1 for lane in b.train_compute for e in lane if e[0] in ('conv_wgrad', 'upconv_wgrad'))
+    assert sum(1 for lane in b.train_compute for e in lane if e[0] == 'upconv_wgrad') == 3
     n_convs = sum(1 for net in (G, Dn, U, P["out"]) for l in L.get_all_layers(net)
                   if isinstance(l, L.Conv2DLayer))
     assert d_wgrads == n_convs
