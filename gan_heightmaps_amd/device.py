@@ -231,6 +231,23 @@ class Ops:
     def transpose_weights(self, d, wp, wpT):
         call("ghm_conv2d_transpose_weights", self.h, C.byref(d), _vp(wp), _vp(wpT))
 
+    def transpose_table(self, items):
+        """items: [(wp DevTensor, wpT DevTensor, C, T, K)] -> (device table ptr, n, total blocks) for
+        transpose_weights_batched (uploaded once: the pointers are fixed for the life of a plan)"""
+        rec = np.zeros(len(items), dtype=[('wp', '<u8'), ('wpT', '<u8'), ('C', '<i4'), ('T', '<i4'), ('K', '<i4'),
+                                          ('b0', '<i4')])
+        b0 = 0
+        for i, (wp, wpT, Cc, T, K) in enumerate(items):
+            rec[i] = (wp.ptr, wpT.ptr, Cc, T, K, b0)
+            b0 += T * ((Cc + 31) // 32) * ((K + 31) // 32)
+        ptr = self.dev.alloc(max(rec.nbytes, 32))
+        self.dev.h2d(ptr, rec.view(np.uint8))
+        return ptr, len(items), b0
+
+    def transpose_weights_batched(self, table):
+        ptr, n, blocks = table
+        call("ghm_transpose_weights_batched", self.h, C.c_void_p(ptr), n, blocks)
+
     def conv2d_dgrad_t(self, d, dy, wpT, dx, bias=None, act='linear', alpha=0.0, accumulate=False):
         call("ghm_conv2d_dgrad_t", self.h, C.byref(d), _vp(dy), _vp(wpT), _vp(bias), _vp(dx), ACT_CODES[act], alpha,
              int(accumulate))

@@ -463,6 +463,28 @@ class NetPlan:
             else:
                 raise NotImplementedError(n.op)
 
+    def emit_transposes(self, prog, transposed):
+        """One launch that refreshes every transposed weight copy the data-gradient kernels of this net read
+        (instead of one small launch per layer inside emit_backward); call after the forward pass of the step."""
+        ops, st = self.ops, self.store
+        items = []
+        for n in self.order:
+            if n.op == 'conv':
+                l = n.layer
+                d = self._desc(n, n.inputs[0].out, n.out)
+                if l.W.shape[1] > 4 and ops.dgrad_t_supported(d) and id(l.W) not in transposed:
+                    transposed.add(id(l.W))
+                    items.append((st.value(l.W), st.transposed(l.W), d.C, d.kh * d.kw, d.K))
+            elif n.op == 'upconv':
+                l = n.layer
+                d = self._upconv_desc(n, n.inputs[0].out)
+                if d.C > 4 and ops.dgrad_t_supported(d) and ('c', id(l.W)) not in transposed:
+                    transposed.add(('c', id(l.W)))
+                    items.append((n.aux['wpc'], n.aux['wpcT'], d.C, 9, d.K))
+        if items:
+            table = ops.transpose_table(items)
+            prog.append(("transpose_w", lambda table=table: ops.transpose_weights_batched(table)))
+
     # ---- backward --------------------------------------------------------------------------------
     def emit_backward(self, prog, seed, nslice=None, wgrad=True, input_grads=(), accumulate_wgrad=False, tag="bwd",
                       transposed=None):

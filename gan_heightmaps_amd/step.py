@@ -185,11 +185,15 @@ class GanStep:
         do_p2p = self.train_mode in ('both', 'p2p')
         tdone = set()      # conv weights whose transposed copy is already fresh in this program
         if do_dcgan:
+            b.D.emit_transposes(ta, tdone)
+            b.G.emit_transposes(ta, tdone)
             b.D.emit_backward(ta, b.seed_D, wgrad=True, tag="dloss", transposed=tdone)
             gin = b.D.emit_backward(ta, b.seed_G, nslice=(B, 2 * B), wgrad=False, input_grads=[d_in_layer],
                                     tag="gloss", transposed=tdone)
             b.G.emit_backward(ta, gin[d_in_layer], wgrad=True, transposed=tdone)
         if do_p2p:
+            b.P.emit_transposes(tb, tdone)
+            b.U.emit_transposes(tb, tdone)
             b.P.emit_backward(tb, b.seed_PD, wgrad=True, tag="dloss", transposed=tdone)
             gin = b.P.emit_backward(tb, b.seed_PG, nslice=(B, 2 * B), wgrad=False, input_grads=[i_b], tag="gloss",
                                     transposed=tdone)
