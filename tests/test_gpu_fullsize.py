@@ -225,3 +225,26 @@ def test_full_size_step_against_the_reference_executed_fixture(gpu):
         # (biases that feed a BatchNorm start at 0 and have an exactly-zero true gradient: they only carry noise)
         assert abs(after[k][1] - fix["after/" + k][1]) <= 1e-4 * fix["after/" + k][1] + 1e-6, k
     del model
+
+
+@pytest.mark.parametrize("name", ["test1_nobn", "test1_nobn_finetunep2p_bilin", "test1_nobn_bilin_both"])
+def test_every_reference_experiment_steps_at_full_size(gpu, name):
+    """experiments.py:22-131: the three registered experiments (k2-s2 deconv U-Net, p2p-only fine-tuning, the joint
+    BASELINE config) build, take one 512x512 train step at batch 4 and generate, with finite results"""
+    dev, ops, D = gpu
+    from gan_heightmaps_amd.experiments import make_model
+    cfg = ostep.default_cfg()
+    Z, X, Y = ostep.synthetic_batch(4, cfg, seed=1)
+    model = make_model(name, device=dev, seed=0, verbose=False)
+    before = model.loss_fn(Z, X, Y)
+    losses = model.train_fn(Z, X, Y)
+    assert len(losses) == 5 and np.isfinite(losses).all() and np.isfinite(before).all()
+    after = model.loss_fn(Z, X, Y)
+    # the trained stage(s) moved, the untouched stage's losses did not (train_mode, pix2pix.py:131-141)
+    if model.train_mode == 'p2p':
+        assert after[0] == pytest.approx(before[0], rel=1e-3) and after[1] == pytest.approx(before[1], rel=1e-3)
+    assert after[3] != before[3] or model.train_mode == 'dcgan'
+    g, z = model.gen_fn_det(X), model.z_fn_det(Z)
+    assert g.shape == (4, 3, 512, 512) and z.shape == (4, 1, 512, 512)
+    assert np.isfinite(g).all() and np.isfinite(z).all() and np.abs(g).max() <= 1.0 and 0.0 <= z.min() <= z.max() <= 1.0
+    del model
