@@ -99,6 +99,33 @@ def install_shims(recorder):
     _module("pix2pix", Pix2Pix=Pix2Pix)
 
 
+# name -> (module, function, positional args, keyword args); nonlinearities by name
+VARIANTS = {
+    "dcgan_gen_bilinear": ("dcgan", "default_generator", (100, False), dict(bilinear_upsample=True)),
+    "dcgan_gen_repeats": ("dcgan", "default_generator", (64, True), dict(num_repeats=1, nch=64, final_size=64,
+                                                                          div=[2, 2, 4, 4])),
+    "dcgan_gen_dropout": ("dcgan", "default_generator", (64, True), dict(dropout_p=0.25, nch=64, final_size=32,
+                                                                          div=[2, 2, 4])),
+    "dcgan_disc_bn_avg": ("dcgan", "default_discriminator", (512, False), dict(bn=True, pool_mode="average",
+                                                                               nonlinearity="sigmoid")),
+    "dcgan_disc_repeats": ("dcgan", "default_discriminator", (512, True), dict(num_repeats=2, nonlinearity="linear")),
+    "unet_deconv": ("p2p", "g_unet", (512, True, False), dict(nf=32, act="tanh", bilinear_upsample=False)),
+    "unet_repeats_dropout": ("p2p", "g_unet", (512, False, True), dict(nf=16, act="sigmoid", dropout=True,
+                                                                       num_repeats=1, bilinear_upsample=True)),
+    "unet_256": ("p2p", "g_unet_256", (256, True, False), dict(nf=32, act="tanh", dropout=0.5)),
+    "patchgan_bn": ("p2p", "discriminator", (512, True, False), dict(nf=32, act="sigmoid", bn=True, num_repeats=1)),
+    "patchgan2": ("p2p", "discriminator2", (512, False, False), dict(nf=16, act="linear", mul_factor=[1, 2, 4],
+                                                                     num_repeats=1)),
+    "fake_generator": ("p2p", "fake_generator", (True, False), dict(act="tanh")),
+    "fake_discriminator": ("p2p", "fake_discriminator", (True, False), dict()),
+}
+
+
+def resolve(kws, NL):
+    names = {"linear": NL.linear, "tanh": NL.tanh, "sigmoid": NL.sigmoid}
+    return {k: (names[v] if k in ("act", "nonlinearity") and v in names else v) for k, v in kws.items()}
+
+
 def describe(out_layer):
     rows = []
     for l in L.get_all_layers(out_layer):
@@ -138,6 +165,7 @@ def main():
         runpy.run_path(os.path.join(REF, "experiments.py"), run_name="__main__")
     finally:
         sys.argv = argv
+    from gan_heightmaps_amd import nonlinearities as NL
     kw = rec["pix2pix_kwargs"]
     INIT.set_rng(np.random.RandomState(0))
     nets = {
@@ -147,7 +175,16 @@ def main():
     }
     pd = kw["disc_fn_p2p"](kw["in_shp"], kw["is_a_grayscale"], kw["is_b_grayscale"], **kw["disc_params_p2p"])
     nets["p2p_disc"] = pd["out"]
+    # every architecture function of the reference, over the keyword variants it exposes
+    import importlib
+    ref_dcgan, ref_p2p = importlib.import_module("architectures.dcgan"), importlib.import_module("architectures.p2p")
+    variants = {}
+    for name, (mod, fn, args, kws) in VARIANTS.items():
+        INIT.set_rng(np.random.RandomState(0))
+        res = getattr(ref_dcgan if mod == "dcgan" else ref_p2p, fn)(*args, **resolve(kws, NL))
+        variants[name] = describe(res["out"] if isinstance(res, dict) else res)
     out = {
+        "variants": variants,
         "provenance": "python tests/golden/make_reference_graph.py  (reference files executed, not copied)",
         "experiment": "test1_nobn_bilin_both",
         "pix2pix_kwargs": jsonable(kw),

@@ -134,3 +134,20 @@ def test_reference_experiment_script_runs_on_the_aliased_backend(monkeypatch, tm
                                                    ("p2p_gen", m.p2p["gen"]), ("p2p_disc", m.p2p["disc"]))} == FIX["param_counts"]
     b = m.engine.built(4)            # the four 512x512 plans lower to device programs
     assert sum(len(lane) for lane in b.train_compute) > 250
+
+
+@pytest.mark.parametrize("name", sorted(MRG.VARIANTS))
+def test_architecture_variants_match_the_reference_functions(name):
+    """every architecture function of the reference over the keyword variants it exposes (deconv U-Net,
+    num_repeats, dropout, BatchNorm discriminators, average pooling, bilinear DCGAN, g_unet_256, discriminator2,
+    the fake_* test nets): the reference's function, executed, and this package's function build the same layers"""
+    from gan_heightmaps_amd import nonlinearities as NL
+    from gan_heightmaps_amd.architectures import dcgan, p2p
+    mod, fn, args, kws = MRG.VARIANTS[name]
+    INIT.set_rng(np.random.RandomState(0))
+    res = getattr(dcgan if mod == "dcgan" else p2p, fn)(*args, **MRG.resolve(kws, NL))
+    mine = json.loads(json.dumps(MRG.describe(res["out"] if isinstance(res, dict) else res)))
+    ref = FIX["variants"][name]
+    assert len(mine) == len(ref), (len(mine), len(ref))
+    for i, (a, b) in enumerate(zip(mine, ref)):
+        assert a == b, "%s layer %d: %r != %r" % (name, i, a, b)
