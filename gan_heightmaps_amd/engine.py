@@ -269,12 +269,16 @@ def _rewrite(out_node):
 class NetPlan:
     """One network lowered for a fixed batch size: buffers + emitters of forward/backward programs."""
 
-    def __init__(self, dev, ops, out_layer, batch, store, inputs=None, out_tensor=None, name="net", side=None):
+    def __init__(self, dev, ops, out_layer, batch, store, inputs=None, out_tensor=None, name="net", side=None,
+                 bn_groups=1):
         """``side=(Device, Ops)``: a second stream of the same GPU for the weight / bias gradients, which only
         feed the optimiser: they fork off the main stream where their output gradient is ready and run beside
         the data-gradient chain (the caller joins the two streams before the update)."""
         self.dev, self.ops, self.batch, self.store, self.name = dev, ops, batch, store, name
         self.side = side
+        # bn_groups=2: the batch is [real | fake] (two get_output calls of the reference, pix2pix.py:94-95,98-101):
+        # every BatchNormLayer normalises each half with its own statistics
+        self.bn_groups = bn_groups
         nodes, of = _build_ir(out_layer)
         self.out_node = _rewrite(of[id(out_layer)])
         self.order = _toposort(self.out_node)
@@ -358,6 +362,9 @@ class NetPlan:
                 C = n.shape[1]
                 n.aux['mean'] = self.dev.empty((1, C, 1, 1))
                 n.aux['inv'] = self.dev.empty((1, C, 1, 1))
+                if self.bn_groups == 2:
+                    n.aux['mean_g'] = [n.aux['mean'], self.dev.empty((1, C, 1, 1))]
+                    n.aux['inv_g'] = [n.aux['inv'], self.dev.empty((1, C, 1, 1))]
             if n.op == 'upconv':
                 C, K = n.inputs[0].shape[1], n.shape[1]
                 for name in ('wpc', 'wpcT', 'dwpc'):
@@ -430,6 +437,20 @@ class NetPlan:
                 if deterministic:
                     prog.append(("bn_apply_det", lambda x=x, y=y, rm=rm, ri=ri, g=g, be=be, a=a:
                                  ops.bn_apply(x, y, rm, ri, g, be, a.kind, a.alpha)))
+                elif self.bn_groups == 2:
+                    # per-half statistics; the running statistics take the update of the SECOND half only: Lasagne
+                    # attaches one default_update per get_output call to the same storage, both computed from the
+                    # old value, so one of them survives (unspecified which; the later call is assumed here)
+                    hb = x.N // 2
+                    for h in (0, 1):
+                        xs, ys = x.samples(h * hb, (h + 1) * hb), y.samples(h * hb, (h + 1) * hb)
+                        m, iv = n.aux['mean_g'][h], n.aux['inv_g'][h]
+                        upd = update_running and h == 1
+                        prog.append(("bn_stats", lambda xs=xs, m=m, iv=iv, rm=rm, ri=ri, l=l, upd=upd:
+                                     ops.bn_stats(xs, m, iv, self.bn_ws, rm if upd else None, ri if upd else None,
+                                                  l.epsilon, l.alpha)))
+                        prog.append(("bn_apply", lambda xs=xs, ys=ys, m=m, iv=iv, g=g, be=be, a=a:
+                                     ops.bn_apply(xs, ys, m, iv, g, be, a.kind, a.alpha)))
                 else:
                     m, iv = n.aux['mean'], n.aux['inv']
                     upd = update_running
@@ -671,9 +692,22 @@ class NetPlan:
                 if acc:
                     dst = dev.empty(gi.shape) if ('bn_tmp', id(n)) not in cache else cache[('bn_tmp', id(n))]
                     cache[('bn_tmp', id(n))] = dst
-                m, iv = n.aux['mean'], n.aux['inv']
-                prog.append(("bn_bwd", lambda G=G, y=y, x=x, dst=dst, m=m, iv=iv, gam=gam, dg=dg, db=db, a=a, aw=aw:
-                             ops.bn_backward(G, y, x, dst, m, iv, gam, dg, db, self.bn_ws, a.kind, a.alpha, aw)))
+                if self.bn_groups == 2:
+                    hb = self.batch // 2
+                    halves = (0, 1) if nslice is None else ((n0 // hb,) if (n1 - n0) == hb and n0 % hb == 0 else None)
+                    if halves is None:
+                        raise NotImplementedError("sample slice that is not one half of a [real | fake] batch")
+                    for idx, h in enumerate(halves):
+                        sub = (lambda t, h=h: t.samples(h * hb, (h + 1) * hb)) if nslice is None else (lambda t: t)
+                        m, iv = n.aux['mean_g'][h], n.aux['inv_g'][h]
+                        awh = aw or idx > 0          # the second half adds to dgamma / dbeta
+                        prog.append(("bn_bwd", lambda G=sub(G), y=sub(y), x=sub(x), dst=sub(dst), m=m, iv=iv, gam=gam,
+                                     dg=dg, db=db, a=a, awh=awh:
+                                     ops.bn_backward(G, y, x, dst, m, iv, gam, dg, db, self.bn_ws, a.kind, a.alpha, awh)))
+                else:
+                    m, iv = n.aux['mean'], n.aux['inv']
+                    prog.append(("bn_bwd", lambda G=G, y=y, x=x, dst=dst, m=m, iv=iv, gam=gam, dg=dg, db=db, a=a, aw=aw:
+                                 ops.bn_backward(G, y, x, dst, m, iv, gam, dg, db, self.bn_ws, a.kind, a.alpha, aw)))
                 if acc:
                     prog.append(("bn_bwd_acc", lambda dst=dst, gi=gi: ops.copy_view(dst, gi, True)))
                 mark_written(xin)

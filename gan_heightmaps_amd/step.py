@@ -75,10 +75,6 @@ class GanStep:
         # lets a single-GPU box exercise exactly what N ranks run
         self.exchange = self.world > 1 or (force_exchange and comm is not None)
         self.use_graph = use_graph
-        for k in ('dcgan_disc', 'p2p_disc'):
-            if _has_bn(self.nets[k]):
-                raise NotImplementedError("discriminators with BatchNorm: the batched real|fake pass would mix "
-                                          "their batch statistics (no reference experiment enables it)")
         self.stores = {k: ParamStore(self.devs[LANE_OF[k]], L.get_all_params(v)) for k, v in self.nets.items()}
         # per-net optimiser state + hyper-parameter scalars [lr, t] in HBM
         self.hyper = {}
@@ -126,8 +122,9 @@ class GanStep:
         b.G = NetPlan(dA, oA, G, B, self.stores['dcgan_gen'], out_tensor=b.d_in.samples(B, 2 * B), name="G",
                       side=self.side[0])
         b.D = NetPlan(dA, oA, D, 2 * B, self.stores['dcgan_disc'], inputs={d_in_layer: b.d_in}, name="D",
-                      side=self.side[0])
-        b.P = NetPlan(dB, oB, P, 2 * B, self.stores['p2p_disc'], name="P", side=self.side[1])
+                      side=self.side[0], bn_groups=2 if _has_bn(D) else 1)
+        b.P = NetPlan(dB, oB, P, 2 * B, self.stores['p2p_disc'], name="P", side=self.side[1],
+                      bn_groups=2 if _has_bn(P) else 1)
         pa, pb = b.P.input_tensor(i_a), b.P.input_tensor(i_b)
         b.U = NetPlan(dB, oB, U, B, self.stores['p2p_gen'], out_tensor=pb.samples(B, 2 * B), name="U",
                       side=self.side[1])

@@ -96,13 +96,13 @@ def forward(state, Z, X, Y, dtype=np.float64, deterministic=False):
     dk = dict(in_shp=cfg['in_shp'], h=d['h'], div=d['div'], bn=d['bn'], nonlinearity=d['nonlinearity'],
               pool_mode=d['pool_mode'])
     fw['d_real'], _ = nets.dcgan_disc_fwd(P[('dcgan', 'disc')], x, **dk)
-    fw['d_fake'], _ = nets.dcgan_disc_fwd(P[('dcgan', 'disc')], fw['gz'], **dk)
+    fw['d_fake'], cur_d = nets.dcgan_disc_fwd(P[('dcgan', 'disc')], fw['gz'], **dk)
     # p2p (:98-101): U(X) shared by Dp(X, U(X)) and the reconstruction loss
     pk = dict(act=p['act'], mul_factor=p['mul_factor'], bn=p['bn'])
     fw['p_real'], _ = nets.patchgan_fwd(P[('p2p', 'disc')], x, y, **pk)
     fw['ux'], cur_u = nets.unet_fwd(P[('p2p', 'gen')], x, cfg['in_shp'], u['act'], u['bilinear_upsample'],
                                     deterministic)
-    fw['p_fake'], _ = nets.patchgan_fwd(P[('p2p', 'disc')], x, fw['ux'], **pk)
+    fw['p_fake'], cur_p = nets.patchgan_fwd(P[('p2p', 'disc')], x, fw['ux'], **pk)
     ls = cfg['lsgan']
     fw['gen_loss_dcgan'] = _adv(fw['d_fake'], 1.0, ls)                                      # :107
     fw['disc_loss_dcgan'] = T.add(_adv(fw['d_real'], 1.0, ls), _adv(fw['d_fake'], 0.0, ls))  # :108
@@ -111,7 +111,11 @@ def forward(state, Z, X, Y, dtype=np.float64, deterministic=False):
     fw['recon_loss'] = T.scalar_loss(fw['ux'], lambda v: rec(v, y.v))
     fw['gen_total_p2p'] = T.add(fw['gen_loss_p2p'], T.scale(fw['recon_loss'], cfg['alpha']))  # :117
     fw['disc_loss_p2p'] = T.add(_adv(fw['p_real'], 1.0, ls), _adv(fw['p_fake'], 0.0, ls))   # :121
-    fw['bn_stats'] = {('dcgan', 'gen'): cur_g.bn_stats, ('p2p', 'gen'): cur_u.bn_stats}
+    # discriminators with BatchNorm are evaluated twice (real, fake): each call attaches its own default_update to the
+    # same running-statistics storage, both computed from the old value, so one survives -- unspecified which in
+    # Theano; the later get_output call (the fake pass) is assumed, here and in the HIP path
+    fw['bn_stats'] = {('dcgan', 'gen'): cur_g.bn_stats, ('p2p', 'gen'): cur_u.bn_stats,
+                      ('dcgan', 'disc'): cur_d.bn_stats, ('p2p', 'disc'): cur_p.bn_stats}
     fw['inputs'] = (z, x, y)
     return fw
 

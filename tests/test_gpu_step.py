@@ -73,7 +73,7 @@ def dev():
     d.close()
 
 
-@pytest.mark.parametrize("variant", ["rmsprop_bilinear", "adam_deconv", "p2p_only_l2", "dcgan_only_bce"])
+@pytest.mark.parametrize("variant", ["rmsprop_bilinear", "adam_deconv", "p2p_only_l2", "dcgan_only_bce", "bn_discriminators"])
 def test_train_step_parity(dev, variant):
     over = dict(SMALL)
     if variant == "adam_deconv":
@@ -85,6 +85,10 @@ def test_train_step_parity(dev, variant):
         over.update(train_mode='dcgan', lsgan=False,
                     disc_dcgan=dict(nch=16, div=[4, 2, 2], nonlinearity='sigmoid'),
                     disc_p2p=dict(nf=4, mul_factor=[1, 2], act='sigmoid'))
+    elif variant == "bn_discriminators":
+        # dcgan.default_discriminator(bn=True) / p2p.discriminator(bn=True): the batched [real | fake] pass keeps
+        # per-half BatchNorm statistics (two get_output calls in the reference)
+        over.update(disc_dcgan=dict(nch=16, div=[4, 2, 2], bn=True), disc_p2p=dict(nf=4, mul_factor=[1, 2], bn=True))
     cfg = ostep.default_cfg(**over)
     B, seed = 4, 7      # seed chosen so that D's final ReLU (dcgan.py:50) is alive: seed 11 gives d == 0
     model = build_model(cfg, seed, dev)
