@@ -40,6 +40,9 @@ SIGNATURES = {
     "ghm_capture_end": [_p, C.POINTER(_p)],
     "ghm_graph_launch": [_p, _p],
     "ghm_graph_destroy": [_p],
+    "ghm_step_build": [_i32, _p, _p, _p],
+    "ghm_step_run": [_p],
+    "ghm_step_destroy": [_p],
     "ghm_timer_start": [_p, _i32],
     "ghm_timer_stop": [_p, _i32],
     "ghm_timer_elapsed_ms": [_p, _i32, C.POINTER(_f)],

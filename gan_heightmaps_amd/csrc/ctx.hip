@@ -179,6 +179,36 @@ int ghm_graph_destroy(ghm_graph* g) {
     return 0;
 }
 
+// ---- a whole train step as one call: the captured graphs of its stages, one per stream ----
+struct ghm_step {
+    int n = 0;
+    ghm_ctx* ctx[4] = {};
+    ghm_graph* graph[4] = {};
+};
+
+int ghm_step_build(int32_t n, ghm_ctx* const* ctxs, ghm_graph* const* graphs, ghm_step** out) {
+    GHM_CHECK(n >= 1 && n <= 4, "ghm_step_build: 1..4 stages");
+    ghm_step* s = new ghm_step();
+    s->n = n;
+    for (int i = 0; i < n; ++i) {
+        GHM_CHECK(ctxs[i] && graphs[i], "ghm_step_build: null stage %d", i);
+        s->ctx[i] = ctxs[i];
+        s->graph[i] = graphs[i];
+    }
+    *out = s;
+    return 0;
+}
+
+int ghm_step_run(ghm_step* s) {
+    for (int i = 0; i < s->n; ++i) GHM_HIP(hipGraphLaunch(s->graph[i]->exec, s->ctx[i]->stream));
+    return 0;
+}
+
+int ghm_step_destroy(ghm_step* s) {
+    delete s;          // the graphs stay owned by their creator (ghm_graph_destroy)
+    return 0;
+}
+
 int ghm_timer_start(ghm_ctx* ctx, int32_t slot) {
     GHM_CHECK(slot >= 0 && slot < GHM_MAX_TIMERS, "timer slot out of range");
     if (!ctx->ev_start[slot]) {

@@ -163,6 +163,24 @@ class Device:
     def graph_destroy(self, g):
         call("ghm_graph_destroy", g)
 
+    @staticmethod
+    def step_build(stages):
+        """stages: [(Device, graph handle)] -> step handle: ghm_step_run launches every stage graph in one call"""
+        n = len(stages)
+        ctxs = (C.c_void_p * n)(*[d.h for d, _ in stages])
+        graphs = (C.c_void_p * n)(*[g for _, g in stages])
+        st = C.c_void_p()
+        call("ghm_step_build", n, ctxs, graphs, C.byref(st))
+        return st
+
+    @staticmethod
+    def step_run(st):
+        call("ghm_step_run", st)
+
+    @staticmethod
+    def step_destroy(st):
+        call("ghm_step_destroy", st)
+
     def timer_start(self, slot=0):
         call("ghm_timer_start", self.h, slot)
 

@@ -278,9 +278,11 @@ class GanStep:
                 finally:
                     gs.append(self.devs[lane].capture_end())
             b.graphs[name] = gs
-        for lane, g in enumerate(b.graphs[name]):
-            if g is not None:
-                self.devs[lane].graph_launch(g)
+            stages = [(self.devs[lane], g) for lane, g in enumerate(gs) if g is not None]
+            b.steps = getattr(b, 'steps', {})
+            b.steps[name] = type(self.devs[0]).step_build(stages) if stages else None
+        if b.steps.get(name) is not None:
+            type(self.devs[0]).step_run(b.steps[name])          # the whole stage-parallel step: one C call
 
     def _read_losses(self):
         self.sync()
