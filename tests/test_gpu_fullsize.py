@@ -248,3 +248,25 @@ def test_every_reference_experiment_steps_at_full_size(gpu, name):
     assert g.shape == (4, 3, 512, 512) and z.shape == (4, 1, 512, 512)
     assert np.isfinite(g).all() and np.isfinite(z).all() and np.abs(g).max() <= 1.0 and 0.0 <= z.min() <= z.max() <= 1.0
     del model
+
+
+def test_config5_geometry_1024(gpu):
+    """BASELINE config 5 geometry (beyond the reference: p2p.py:137 asserts 512): 1024x1024 crops need one more U-Net
+    level and one more DCGAN stage; the same architecture functions build it and the engine steps it (fp32 here;
+    throughput-only, there is no parity target for this size)"""
+    dev, ops, D = gpu
+    from gan_heightmaps_amd import experiments as E
+    from gan_heightmaps_amd.pix2pix import Pix2Pix
+    kw = E.experiment_kwargs('test1_nobn_bilin_both')
+    kw.update(in_shp=1024, device=dev, seed=0, verbose=False)
+    kw['gen_params_dcgan'] = {'num_repeats': 0, 'div': [2, 2, 4, 4, 8, 8, 8, 8], 'final_size': 1024}
+    kw['disc_params_dcgan'] = dict(kw['disc_params_dcgan'], div=[8, 8, 4, 4, 4, 2, 2, 2], nch=1024)
+    model = Pix2Pix(**kw)
+    rng = np.random.RandomState(0)
+    Z = rng.rand(2, 1000).astype(np.float32)
+    X = rng.rand(2, 1, 1024, 1024).astype(np.float32)
+    Y = (rng.rand(2, 3, 1024, 1024) * 2 - 1).astype(np.float32)
+    losses = model.train_fn(Z, X, Y)
+    assert len(losses) == 5 and np.isfinite(losses).all()
+    assert model.gen_fn_det(X).shape == (2, 3, 1024, 1024) and model.z_fn_det(Z).shape == (2, 1, 1024, 1024)
+    del model
