@@ -73,7 +73,8 @@ def dev():
     d.close()
 
 
-@pytest.mark.parametrize("variant", ["rmsprop_bilinear", "adam_deconv", "p2p_only_l2", "dcgan_only_bce", "bn_discriminators"])
+@pytest.mark.parametrize("variant", ["rmsprop_bilinear", "adam_deconv", "p2p_only_l2", "dcgan_only_bce", "bn_discriminators",
+                                     "config1_dcgan64_b16"])
 def test_train_step_parity(dev, variant):
     over = dict(SMALL)
     if variant == "adam_deconv":
@@ -89,8 +90,13 @@ def test_train_step_parity(dev, variant):
         # dcgan.default_discriminator(bn=True) / p2p.discriminator(bn=True): the batched [real | fake] pass keeps
         # per-half BatchNorm statistics (two get_output calls in the reference)
         over.update(disc_dcgan=dict(nch=16, div=[4, 2, 2], bn=True), disc_p2p=dict(nf=4, mul_factor=[1, 2], bn=True))
+    elif variant == "config1_dcgan64_b16":
+        # BASELINE config 1: DCGAN 64x64 generator + discriminator, batch 16
+        over = dict(in_shp=64, latent_dim=100, train_mode='dcgan',
+                    gen_dcgan=dict(nch=64, div=[2, 2, 4, 4]), disc_dcgan=dict(nch=64, div=[8, 4, 2, 1]),
+                    gen_p2p=dict(nf=4), disc_p2p=dict(nf=4, mul_factor=[1, 2]))
     cfg = ostep.default_cfg(**over)
-    B, seed = 4, 7      # seed chosen so that D's final ReLU (dcgan.py:50) is alive: seed 11 gives d == 0
+    B, seed = (16, 7) if variant == "config1_dcgan64_b16" else (4, 7)      # seed chosen so that D's final ReLU (dcgan.py:50) is alive: seed 11 gives d == 0
     model = build_model(cfg, seed, dev)
     state = ostep.init_state(cfg, seed, np.float32)
     # identical initial parameters on both sides (independent construction paths)
