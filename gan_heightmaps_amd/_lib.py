@@ -63,6 +63,8 @@ SIGNATURES = {
     "ghm_maxpool2_bwd": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f],
     "ghm_avgpool_fwd": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32],
     "ghm_avgpool_bwd": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32],
+    "ghm_dropout": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _f, C.c_uint32, _p],
+    "ghm_counter_tick": [_p, _p],
     "ghm_transpose_weights_batched": [_p, _p, _i32, _i32],
     "ghm_upconv_collapse_weights": [_p, _p, _p, _p, _p, _i32, _i32],
     "ghm_upconv_expand_wgrad": [_p, _p, _p, _i32, _i32, _i32],

@@ -636,6 +636,32 @@ __global__ __launch_bounds__(256) void hi_to_pp_kernel(const float* __restrict__
     dst[0] = a.x; dst[plane] = a.y; dst[2 * plane] = b.x; dst[3 * plane] = b.y;
 }
 
+
+// ---- DropoutLayer(p, rescale=True) (architectures/p2p.py:200-223, dcgan.py:25-26): y = x * mask / (1 - p).
+// The mask is a counter-based hash of (element index, layer key, step counter): nothing is stored, the backward
+// recomputes it, and the oracle evaluates the same hash (Theano's MRG stream itself cannot be reproduced).
+__device__ __forceinline__ unsigned lowbias32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool dropout_keep(unsigned idx, unsigned key, unsigned step, float p) {
+    const unsigned hsh = lowbias32(lowbias32(idx ^ key) + step * 0x9e3779b9U);
+    return (float)(hsh >> 8) * (1.0f / 16777216.0f) >= p;
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, long xs, float* __restrict__ y, long ys,
+                                                      int N, int C, int HW, float p, unsigned key,
+                                                      const unsigned* __restrict__ counter) {
+    const long total = (long)N * C * HW;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long chw = (long)C * HW;
+    const int n = (int)(i / chw);
+    const long r = i - (long)n * chw;
+    const float scale = 1.0f / (1.0f - p);
+    y[(long)n * ys + r] = dropout_keep((unsigned)i, key, *counter, p) ? x[(long)n * xs + r] * scale : 0.f;
+}
+__global__ void counter_tick_kernel(unsigned* counter) { *counter += 1u; }
+
 #define EW_GRID(total) dim3(ceil_div((long)(total), 256)), dim3(256), 0, ctx->stream
 
 extern "C" {
@@ -804,6 +830,21 @@ int ghm_pp_to_hi(ghm_ctx* ctx, const float* pp, float* hi, int64_t hi_nstride, i
 int ghm_hi_to_pp(ghm_ctx* ctx, const float* hi, int64_t hi_nstride, float* pp, int32_t N, int32_t K, int32_t H, int32_t W) {
     GHM_CHECK(((uintptr_t)hi % 8 == 0) && hi_nstride % 2 == 0, "hi_to_pp: 8-byte aligned source required");
     hipLaunchKernelGGL(hi_to_pp_kernel, EW_GRID((long)N * K * H * W), hi, (long)hi_nstride, pp, N, K, H, W);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_dropout(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t ys, int32_t N, int32_t C, int32_t HW, float p,
+                uint32_t key, const void* counter) {
+    GHM_CHECK(p >= 0.f && p < 1.f && (long)N * C * HW < (1L << 32), "ghm_dropout: p in [0,1), < 2^32 elements");
+    hipLaunchKernelGGL(dropout_kernel, EW_GRID((long)N * C * HW), x, (long)xs, y, (long)ys, N, C, HW, p, key,
+                       (const unsigned*)counter);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_counter_tick(ghm_ctx* ctx, void* counter) {
+    hipLaunchKernelGGL(counter_tick_kernel, dim3(1), dim3(1), 0, ctx->stream, (unsigned*)counter);
     GHM_LAUNCH_CHECK();
     return 0;
 }

@@ -321,6 +321,14 @@ class Ops:
         assert dy.contiguous and dx.contiguous
         call("ghm_avgpool_bwd", self.h, _vp(dy), _vp(dx), dx.N, dx.Cc, dx.H, dx.W, p)
 
+    def dropout(self, x, y, p, key, counter):
+        """y = dropout(x); with x = dy it is the backward (same mask: same key, same counter value)"""
+        call("ghm_dropout", self.h, _vp(x), x.nstride, _vp(y), y.nstride, x.N, x.Cc, x.HW, float(p), int(key) & 0xffffffff,
+             _vp(counter))
+
+    def counter_tick(self, counter):
+        call("ghm_counter_tick", self.h, _vp(counter))
+
     def upconv_collapse_weights(self, wp5, bias, wpc, bias4, C, K):
         call("ghm_upconv_collapse_weights", self.h, _vp(wp5), _vp(bias), _vp(wpc), _vp(bias4), C, K)
 

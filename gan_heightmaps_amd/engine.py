@@ -157,10 +157,10 @@ def _build_ir(out_layer):
         elif isinstance(l, L.ConcatLayer):
             n = Node('concat', [of[id(i)] for i in l.input_layers], l)
         elif isinstance(l, L.DropoutLayer):
-            if l.p > 0:
-                raise NotImplementedError("DropoutLayer(p>0) has no kernel yet (unused by test1_nobn_bilin_both)")
-            of[id(l)] = of[id(l.input_layer)]
-            continue
+            if l.p <= 0:
+                of[id(l)] = of[id(l.input_layer)]
+                continue
+            n = Node('dropout', [of[id(l.input_layer)]], l, p=float(l.p))
         else:
             raise NotImplementedError("no lowering for %r" % (l,))
         of[id(l)] = n
@@ -270,7 +270,7 @@ class NetPlan:
     """One network lowered for a fixed batch size: buffers + emitters of forward/backward programs."""
 
     def __init__(self, dev, ops, out_layer, batch, store, inputs=None, out_tensor=None, name="net", side=None,
-                 bn_groups=1):
+                 bn_groups=1, rng_seed=0, rng_counter=None):
         """``side=(Device, Ops)``: a second stream of the same GPU for the weight / bias gradients, which only
         feed the optimiser: they fork off the main stream where their output gradient is ready and run beside
         the data-gradient chain (the caller joins the two streams before the update)."""
@@ -294,6 +294,14 @@ class NetPlan:
             self._bn_scratch = dev.empty((1, 2 * cmax, 1, 1))
         self.wgrad_ws = None
         self._wgrad_ws_bytes = 0
+        # DropoutLayer: masks are hashes of (element, per-layer key, step counter); the counter lives in HBM and is
+        # advanced once per non-deterministic forward pass (so a captured graph draws fresh masks on replay)
+        self.dropout_nodes = [n for n in self.order if n.op == 'dropout']
+        self.rng_counter = rng_counter
+        if self.dropout_nodes and self.rng_counter is None:
+            self.rng_counter = dev.zeros((1, 1, 1, 1))
+        for i, n in enumerate(self.dropout_nodes):
+            n.aux['key'] = (rng_seed * 0x9E3779B1 + (i + 1) * 0x85EBCA77) & 0xffffffff
 
     # ---- shapes and placement ----------------------------------------------------------------
     def _shapes(self):
@@ -407,6 +415,8 @@ class NetPlan:
     # ---- forward ---------------------------------------------------------------------------------
     def emit_forward(self, prog, deterministic=False, update_running=True):
         ops, st = self.ops, self.store
+        if self.dropout_nodes and not deterministic:
+            prog.append(("rng_tick", lambda c=self.rng_counter: ops.counter_tick(c)))
         for n in self.order:
             y = n.out
             if n.op in ('input', 'reshape', 'concat'):
@@ -471,6 +481,12 @@ class NetPlan:
                              ops.conv2d_fwd(d, x, wpc, b4, y4, a.kind, a.alpha), conv_meta(ops, d, 0)))
             elif n.op == 'pp_to_hi':
                 prog.append(("pp_to_hi", lambda x=x, y=y: ops.pp_to_hi(x, y)))
+            elif n.op == 'dropout':
+                if deterministic:
+                    prog.append(("dropout_det", lambda x=x, y=y: ops.copy_view(x, y)))
+                else:
+                    prog.append(("dropout_fwd", lambda x=x, y=y, p=n.attrs['p'], k=n.aux['key'], c=self.rng_counter:
+                                 ops.dropout(x, y, p, k, c)))
             elif n.op == 'act':
                 prog.append(("act_fwd", lambda x=x, y=y, a=a: ops.act_fwd(x, y, a.kind, a.alpha)))
             elif n.op == 'up_nearest':
@@ -671,6 +687,15 @@ class NetPlan:
                     else:
                         prog.append(("upconv_dgrad", lambda d=d, G4=G4, wpc=wpc, gi=gi, acc=acc:
                                      ops.conv2d_dgrad(d, G4, wpc, gi, None, 'linear', 0.0, acc), conv_meta(ops, d, 1)))
+                    mark_written(xin)
+            elif n.op == 'dropout':
+                if need_dx:
+                    gi, acc = target(xin)
+                    if acc or nslice is not None:
+                        raise NotImplementedError("DropoutLayer input with several consumers / sample slices")
+                    # same key, same counter value as the forward pass of this step -> the same mask
+                    prog.append(("dropout_bwd", lambda G=G, gi=gi, p=n.attrs['p'], k=n.aux['key'], c=self.rng_counter:
+                                 ops.dropout(G, gi, p, k, c)))
                     mark_written(xin)
             elif n.op == 'pp_to_hi':
                 if need_dx:

@@ -422,3 +422,28 @@ def glorot_uniform(rng, shape, dtype=np.float32):
     std = np.sqrt(2.0 / ((n1 + n2) * rf))
     a = np.sqrt(3.0) * std
     return rng.uniform(-a, a, size=shape).astype(dtype)
+
+
+# --------------------------------------------------------------------------------------
+# DropoutLayer(p, rescale=True): the mask is this build's own counter-based hash (ghm_dropout in
+# csrc/elementwise.hip) -- Theano's MRG_RandomStreams cannot be reproduced; lasagne semantics otherwise
+# (architectures/p2p.py:200-223, dcgan.py:25-26): y = x * mask / (1 - p), identity when deterministic
+# --------------------------------------------------------------------------------------
+
+
+def _lowbias32(x):
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16); x = (x * np.uint32(0x7feb352d)).astype(np.uint32)
+    x ^= x >> np.uint32(15); x = (x * np.uint32(0x846ca68b)).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def dropout_mask(shape, p, key, step):
+    with np.errstate(over='ignore'):
+        idx = np.arange(int(np.prod(shape)), dtype=np.uint32)
+        h = _lowbias32((_lowbias32(idx ^ np.uint32(key & 0xffffffff)) +
+                        np.uint32((step * 0x9e3779b9) & 0xffffffff)).astype(np.uint32))
+    u = (h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (u >= np.float32(p)).reshape(shape)
+

@@ -168,3 +168,9 @@ def add(a, b):
 
 def scale(a, s):
     return Node(a.v * s, (a,), lambda g: (g * s,))
+
+
+def dropout(x, p, key, step):
+    m = ops.dropout_mask(x.v.shape, p, key, step).astype(x.v.dtype) / x.v.dtype.type(1.0 - np.float32(p))
+    return Node(x.v * m, (x,), lambda g: (g * m,))
+

@@ -151,8 +151,11 @@ def get_output(layer, inputs=None, deterministic=False):
             elif cls == 'Pool2DLayer':
                 y = TP.avgpool(x, l.pool_size[0])
             elif cls == 'DropoutLayer':
-                assert deterministic or l.p == 0
-                y = x
+                if deterministic or l.p == 0:
+                    y = x
+                else:       # this build's hash-based mask (oracle/ops.py dropout_mask); env['__rng__'](layer) -> (key, step)
+                    key, step = c.env['__rng__'](l)
+                    y = TP.dropout(x, l.p, key, step)
             else:
                 raise NotImplementedError(cls)
             vals[id(l)] = y

@@ -524,3 +524,85 @@ def test_upscale_conv5_collapsed_to_four_3x3(gpu, case):
     dbd = dev.empty((1, K, 1, 1))
     ops.channel_sum(dpp, dbd)
     assert rel(dbd.numpy().ravel(), db_ref) < TOL
+
+
+def test_dropout_hash_mask_and_backward(gpu):
+    """DropoutLayer(p): the device mask is bit-identical to oracle.ops.dropout_mask for the same (key, step); the
+    backward is the same call on dy; a tick of the device counter changes the mask"""
+    dev, ops, D = gpu
+    rng = np.random.RandomState(0)
+    x = rng.randn(3, 5, 7, 9).astype(np.float32)
+    counter = dev.zeros((1, 1, 1, 1))
+    xd, yd = dev.tensor(x), dev.empty(x.shape)
+    for step, p, key in [(0, 0.5, 0x1234ABCD), (1, 0.5, 0x1234ABCD), (2, 0.25, 7)]:
+        ops.dropout(xd, yd, p, key, counter)
+        m = O.dropout_mask(x.shape, p, key, step)
+        got = yd.numpy()
+        assert np.array_equal(got != 0, m & (x != 0))
+        assert np.allclose(got, x * m / (1 - p), rtol=1e-6, atol=0)
+        assert abs(m.mean() - (1 - p)) < 0.05
+        ops.counter_tick(counter)
+    # strided destination (a channel slice of a wider buffer) and the backward on a gradient
+    wide = dev.zeros((3, 8, 7, 9))
+    ops.dropout(xd, wide.channels(2, 7), 0.5, 99, counter)
+    m = O.dropout_mask(x.shape, 0.5, 99, 3)
+    assert np.allclose(wide.numpy()[:, 2:7], x * m * 2) and not wide.numpy()[:, :2].any()
+
+
+def test_dropout_networks_against_the_interpreter(gpu):
+    """g_unet(dropout=True) (p2p.py:200-223) and default_generator(dropout_p) (dcgan.py:25-26) through the engine:
+    forward with fresh masks per pass, backward through the same masks -- against the layer-graph interpreter on the
+    oracle's ops (tests/golden/symtheano.py) with the same keys and step counter"""
+    import sys
+    dev, ops, D = gpu
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import symtheano as ST
+    from oracle import tape as TP
+    from gan_heightmaps_amd import init as INIT, layers as L
+    from gan_heightmaps_amd.architectures import dcgan, p2p
+    from gan_heightmaps_amd.engine import NetPlan, ParamStore
+    from gan_heightmaps_amd.nonlinearities import tanh
+    for which in ("unet", "dcgan"):
+        INIT.set_rng(np.random.RandomState(3))
+        if which == "unet":
+            net = p2p.g_unet(32, True, False, nf=4, act=tanh, dropout=True, bilinear_upsample=True)
+            xin = np.random.RandomState(1).rand(3, 1, 32, 32).astype(np.float32)
+        else:
+            net = dcgan.default_generator(16, True, nch=16, div=[2, 2, 4], final_size=32, dropout_p=0.3)
+            xin = np.random.RandomState(1).rand(3, 16).astype(np.float32)
+        drops = [l for l in L.get_all_layers(net) if isinstance(l, L.DropoutLayer)]
+        assert len(drops) == 3
+        in_layer = [l for l in L.get_all_layers(net) if isinstance(l, L.InputLayer)][0]
+        store = ParamStore(dev, L.get_all_params(net))
+        plan = NetPlan(dev, ops, net, 3, store, name=which, rng_seed=5)
+        keys = {id(n.layer): n.aux['key'] for n in plan.dropout_nodes}
+        fwd, bwd = [], []
+        plan.emit_forward(fwd)
+        seed = np.random.RandomState(2).randn(*plan.out.shape).astype(np.float32)
+        seed_d = dev.tensor(seed)
+        plan.emit_backward(bwd, seed_d)
+        outs = []
+        for step in (1, 2):                      # the counter is ticked at the start of every forward pass
+            plan.input_nodes[0].out.set(xin.reshape(plan.input_nodes[0].shape))
+            seed_d.set(seed)
+            for e in fwd + bwd:
+                e[1]()
+            got = plan.out.numpy()
+            c = ST.Ctx({'X': xin, '__rng__': lambda l, step=step: (keys[id(l)], step)}, np.float64)
+            ref = ST.get_output(net, ST.placeholder('X')).ev(c)
+            assert rel(got, ref.v) < 1e-5, (which, step)
+            TP.backward(ref, seed.astype(np.float64).reshape(ref.v.shape))
+            for p in L.get_all_params(net, trainable=True):
+                g_ref = c.param(p).g
+                if g_ref is None or np.linalg.norm(g_ref) < 1e-9:
+                    continue
+                assert rel(store.download_grad(p), g_ref) < 5e-4, (which, step, p.name, p.shape)
+            outs.append(got)
+        assert not np.array_equal(outs[0], outs[1])          # fresh masks per pass
+        det = []
+        plan_det_prog = []
+        plan.emit_forward(plan_det_prog, deterministic=True)
+        for e in plan_det_prog:
+            e[1]()
+        c = ST.Ctx({'X': xin}, np.float64)
+        assert rel(plan.out.numpy(), ST.get_output(net, ST.placeholder('X'), deterministic=True).ev(c).v) < 1e-5

@@ -294,3 +294,36 @@ def test_gradient_side_streams_bitwise(dev):
     # the default picks the side streams exactly when the step is not captured into a graph
     assert build_model(cfg, 11, dev, use_graph=False).engine.side[0] is not None
     assert build_model(cfg, 11, dev).engine.side[0] is None
+
+
+def test_dropout_generators_in_the_full_step(dev):
+    """g_unet(dropout=True) + default_generator(dropout_p) inside Pix2Pix: train_fn / loss_fn run, the
+    non-deterministic generator functions draw a fresh mask per call, the deterministic ones are repeatable
+    (DropoutLayer is the identity there)"""
+    from gan_heightmaps_amd.architectures import dcgan, p2p
+    from gan_heightmaps_amd.pix2pix import Pix2Pix
+    from gan_heightmaps_amd import nonlinearities as NL, updates as UP
+    model = Pix2Pix(
+        gen_fn_dcgan=dcgan.default_generator, disc_fn_dcgan=dcgan.default_discriminator,
+        gen_params_dcgan=dict(nch=16, div=[2, 2, 4], final_size=32, dropout_p=0.25),
+        disc_params_dcgan=dict(nch=16, div=[4, 2, 2], nonlinearity=NL.linear),
+        gen_fn_p2p=p2p.g_unet, disc_fn_p2p=p2p.discriminator,
+        gen_params_p2p=dict(nf=4, act=NL.tanh, dropout=True, bilinear_upsample=True),
+        disc_params_p2p=dict(nf=4, act=NL.linear, mul_factor=[1, 2]),
+        in_shp=32, latent_dim=24, is_a_grayscale=True, is_b_grayscale=False, lsgan=True,
+        opt=UP.rmsprop, opt_args={'learning_rate': UP.shared(np.float32(1e-4))}, train_mode='both', verbose=False,
+        seed=3, device=dev)
+    cfg = ostep.default_cfg(**SMALL)
+    Z, X, Y = ostep.synthetic_batch(4, cfg, seed=1)
+    for _ in range(3):                           # eager, captured, replayed: the counter lives in HBM
+        losses = model.train_fn(Z, X, Y)
+        assert np.isfinite(losses).all()
+    assert np.isfinite(model.loss_fn(Z, X, Y)).all()
+    a, b = model.gen_fn(X), model.gen_fn(X)
+    assert not np.array_equal(a, b)
+    assert np.array_equal(model.gen_fn_det(X), model.gen_fn_det(X))
+    za, zb = model.z_fn(Z), model.z_fn(Z)
+    assert not np.array_equal(za, zb) and np.array_equal(model.z_fn_det(Z), model.z_fn_det(Z))
+    # graph replay keeps drawing fresh masks: two replayed steps on identical inputs give different recon losses
+    l1, l2 = model.loss_fn(Z, X, Y), model.loss_fn(Z, X, Y)
+    assert l1[3] != l2[3]
