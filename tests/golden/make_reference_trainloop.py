@@ -116,6 +116,15 @@ class Harness:
         return {"header": header, "rows": body, "files": files, "saved": list(self.saved), "log": self.log}
 
 
+PLATEAU_CASES = [dict(), dict(mode='min', patience=2, factor=0.5), dict(mode='max', patience=1, cooldown=2),
+                 dict(mode='min', patience=0, factor=0.1, min_lr=1e-3, epsilon=0.01)]
+
+
+def plateau_sequence(seed):
+    rng = np.random.RandomState(seed)
+    return np.round(1.5 + 0.2 * np.sin(np.arange(60) / 3.0) + 0.05 * rng.randn(60), 3).tolist()
+
+
 def main():
     import make_reference_graph as G
     import make_reference_iterator as I
@@ -135,6 +144,20 @@ def main():
     h.attach(m, ['dcgan_gen', 'dcgan_disc', 'p2p_gen', 'p2p_recon', 'p2p_disc'])      # pix2pix.py:157
     with tempfile.TemporaryDirectory() as td:
         out = h.run(m, os.path.join(td, "out"), os.path.join(td, "models"))
+    # keras_ports.ReduceLROnPlateau (keras_ports.py:7-111), executed: learning-rate trajectories on fixed sequences
+    np.Inf = np.inf                                    # the reference predates NumPy 2.0
+    KP = load_py2(os.path.join(REF, "keras_ports.py"), "reference_keras_ports")
+    from gan_heightmaps_amd.updates import shared
+    out["plateau"] = []
+    for kw in PLATEAU_CASES:
+        lr = shared(np.float32(0.01))
+        cb = KP.ReduceLROnPlateau(lr, **kw)
+        cb.on_train_begin()
+        traj = []
+        for e, v in enumerate(plateau_sequence(len(kw))):
+            cb.on_epoch_end(v, e + 1)
+            traj.append([float(lr.get_value()), int(cb.wait), int(cb.cooldown_counter)])
+        out["plateau"].append({"kw": kw, "trajectory": traj})
     out["provenance"] = "python tests/golden/make_reference_trainloop.py (reference pix2pix.py executed via lib2to3, not copied)"
     path = os.environ.get("GHM_FIXTURE_OUT") or os.path.join(HERE, "reference_trainloop.json")
     json.dump(out, open(path, "w"), indent=1)
