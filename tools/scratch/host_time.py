@@ -3,12 +3,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 from gan_heightmaps_amd import device as D
 from gan_heightmaps_amd.experiments import make_model
-from oracle import step as S
 dev = D.Device(0)
 for graph in (False, True):
     m = make_model('test1_nobn_bilin_both', device=dev, seed=0, verbose=False, use_graph=graph)
     eng = m.engine
-    cfg = S.default_cfg(); Z, X, Y = S.synthetic_batch(4, cfg, seed=1)
+    rng = np.random.RandomState(1)
+Z = rng.rand(4, 1000).astype(np.float32); X = rng.rand(4, 1, 512, 512).astype(np.float32)
+Y = (rng.rand(4, 3, 512, 512) * 2 - 1).astype(np.float32)
     b = eng.built(4); eng._upload(b, Z, X, Y)
     for _ in range(3): eng.enqueue_train(b)
     eng.sync()

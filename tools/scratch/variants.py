@@ -3,9 +3,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 from gan_heightmaps_amd import device as D
 from gan_heightmaps_amd.experiments import make_model
-from oracle import step as S
 dev = D.Device(0)
-cfg = S.default_cfg(); Z, X, Y = S.synthetic_batch(4, cfg, seed=1)
+rng = np.random.RandomState(1)
+Z = rng.rand(4, 1000).astype(np.float32); X = rng.rand(4, 1, 512, 512).astype(np.float32)
+Y = (rng.rand(4, 3, 512, 512) * 2 - 1).astype(np.float32)
 for name in ('test1_nobn', 'test1_nobn_finetunep2p_bilin', 'test1_nobn_bilin_both'):
     m = make_model(name, device=dev, seed=0, verbose=False, use_graph=False)
     l = m.train_fn(Z, X, Y)
