@@ -8,8 +8,8 @@ for graph in (False, True):
     m = make_model('test1_nobn_bilin_both', device=dev, seed=0, verbose=False, use_graph=graph)
     eng = m.engine
     rng = np.random.RandomState(1)
-Z = rng.rand(4, 1000).astype(np.float32); X = rng.rand(4, 1, 512, 512).astype(np.float32)
-Y = (rng.rand(4, 3, 512, 512) * 2 - 1).astype(np.float32)
+    Z = rng.rand(4, 1000).astype(np.float32); X = rng.rand(4, 1, 512, 512).astype(np.float32)
+    Y = (rng.rand(4, 3, 512, 512) * 2 - 1).astype(np.float32)
     b = eng.built(4); eng._upload(b, Z, X, Y)
     for _ in range(3): eng.enqueue_train(b)
     eng.sync()
