@@ -69,6 +69,55 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     }
 }
 
+// Row-structured partials, grid (S = N * segs, C): block (n, seg) of channel c sums one contiguous run of the
+// (n, c) row with 16-byte loads and no per-element index arithmetic; sums and products in fp64.  BWD: sums of dz and dz * xhat (dz = dout * act'(y)); otherwise sums of x and x^2.
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_rows_partial(const float* __restrict__ x, long xs, const float* __restrict__ dout,
+                                                       long ds, const float* __restrict__ y, long ys, int HW, int segs,
+                                                       int seg_len, const float* __restrict__ mean,
+                                                       const float* __restrict__ inv, int act, float alpha,
+                                                       double* __restrict__ ws) {
+    const int c = blockIdx.y, s = blockIdx.x;
+    const int n = s / segs, seg = s - n * segs;
+    const int lo = seg * seg_len, hi = min(lo + seg_len, HW);
+    const long row = (long)c * HW;
+    const float* xp = x + n * xs + row;
+    double a = 0.0, b = 0.0;
+    if constexpr (BWD) {
+        const float* dp = dout + n * ds + row;
+        const float* yp = y + n * ys + row;
+        const float m = mean[c], iv = inv[c];
+#pragma unroll 2
+        for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+            const float4 d = *reinterpret_cast<const float4*>(dp + i);
+            const float4 yy = *reinterpret_cast<const float4*>(yp + i);
+            const float4 xx = *reinterpret_cast<const float4*>(xp + i);
+            const float z0 = d.x * ghm_dact_from_out(yy.x, act, alpha), z1 = d.y * ghm_dact_from_out(yy.y, act, alpha);
+            const float z2 = d.z * ghm_dact_from_out(yy.z, act, alpha), z3 = d.w * ghm_dact_from_out(yy.w, act, alpha);
+            a += ((double)z0 + (double)z1) + ((double)z2 + (double)z3);
+            b += ((double)z0 * ((xx.x - m) * iv) + (double)z1 * ((xx.y - m) * iv)) +
+                 ((double)z2 * ((xx.z - m) * iv) + (double)z3 * ((xx.w - m) * iv));
+        }
+    } else {
+#pragma unroll 4
+        for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(xp + i);
+            // every product and sum in fp64: channels whose mean is large against their spread (DCGAN generator
+            // at initialisation) lose E[x^2] - mean^2 to fp32 rounding otherwise
+            const double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+            a += (x0 + x1) + (x2 + x3);
+            b += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
+        }
+    }
+    __shared__ double red[4];
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        ws[((long)c * BN_MAX_SPLIT + s) * 2 + 0] = a;
+        ws[((long)c * BN_MAX_SPLIT + s) * 2 + 1] = b;
+    }
+}
+
 __global__ void bn_stats_final(const double* __restrict__ ws, int C, int S, double count, float eps,
                                float* __restrict__ mean, float* __restrict__ inv, float* run_mean, float* run_inv,
                                float ra) {
@@ -173,11 +222,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ do
     const float m = mean[c], iv = inv[c], g = gamma[c] * iv;
     const float mb = sums[2 * c] * inv_count, mg = sums[2 * c + 1] * inv_count;
     const long o = c * v.HW + i;
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        const float dz = dout[n * ds + o + k] * ghm_dact_from_out(y[n * ys + o + k], act, alpha);
-        const float xh = (x[n * xs + o + k] - m) * iv;
-        dx[n * dxs + o + k] = g * (dz - mb - xh * mg);
+    if constexpr (VEC == 4) {
+        const float4 d = *reinterpret_cast<const float4*>(dout + n * ds + o);
+        const float4 yy = *reinterpret_cast<const float4*>(y + n * ys + o);
+        const float4 xx = *reinterpret_cast<const float4*>(x + n * xs + o);
+        float4 r;
+        r.x = g * (d.x * ghm_dact_from_out(yy.x, act, alpha) - mb - (xx.x - m) * iv * mg);
+        r.y = g * (d.y * ghm_dact_from_out(yy.y, act, alpha) - mb - (xx.y - m) * iv * mg);
+        r.z = g * (d.z * ghm_dact_from_out(yy.z, act, alpha) - mb - (xx.z - m) * iv * mg);
+        r.w = g * (d.w * ghm_dact_from_out(yy.w, act, alpha) - mb - (xx.w - m) * iv * mg);
+        *reinterpret_cast<float4*>(dx + n * dxs + o) = r;
+    } else {
+        const float dz = dout[n * ds + o] * ghm_dact_from_out(y[n * ys + o], act, alpha);
+        const float xh = (x[n * xs + o] - m) * iv;
+        dx[n * dxs + o] = g * (dz - mb - xh * mg);
     }
 }
 
@@ -678,11 +736,33 @@ static int bn_split(int C, long count) {
     return (int)S;
 }
 
+// split of the row-structured partial kernels: S = N * segs <= BN_MAX_SPLIT blocks per channel, ~8 blocks per CU in
+// total, at least 2048 elements per block; 0 when the geometry does not allow 16-byte row loads
+static int bn_row_segs(int N, int C, int HW, int* seg_len) {
+    if (HW % 4 != 0 || N > BN_MAX_SPLIT) return 0;
+    long segs = (2048 + (long)C * N - 1) / ((long)C * N);
+    const long by_split = BN_MAX_SPLIT / N, by_len = HW / 2048 > 0 ? HW / 2048 : 1;
+    if (segs > by_split) segs = by_split;
+    if (segs > by_len) segs = by_len;
+    if (segs < 1) segs = 1;
+    int len = (int)((HW + segs - 1) / segs);
+    len = (len + 3) / 4 * 4;
+    *seg_len = len;
+    return (int)((HW + len - 1) / len);
+}
+
 int ghm_bn_stats(ghm_ctx* ctx, const float* x, int32_t N, int32_t C, int32_t HW, int64_t nstride, float eps, float* mean,
                  float* inv, float* run_mean, float* run_inv, float run_alpha, void* ws) {
     const long count = (long)N * HW;
-    const int S = bn_split(C, count);
-    hipLaunchKernelGGL(bn_stats_partial, dim3(S, C), dim3(256), 0, ctx->stream, x, N, HW, (long)nstride, S, (double*)ws);
+    int S = bn_split(C, count), seg_len = 0;
+    const int segs = (nstride % 4 == 0 && aligned16(x)) ? bn_row_segs(N, C, HW, &seg_len) : 0;
+    if (segs > 0) {
+        S = N * segs;
+        hipLaunchKernelGGL((bn_rows_partial<false>), dim3(S, C), dim3(256), 0, ctx->stream, x, (long)nstride, nullptr, 0L,
+                           nullptr, 0L, HW, segs, seg_len, nullptr, nullptr, 0, 0.f, (double*)ws);
+    } else {
+        hipLaunchKernelGGL(bn_stats_partial, dim3(S, C), dim3(256), 0, ctx->stream, x, N, HW, (long)nstride, S, (double*)ws);
+    }
     GHM_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_final, dim3(ceil_div(C, 256)), dim3(256), 0, ctx->stream, (const double*)ws, C, S,
                        (double)count, eps, mean, inv, run_mean, run_inv, run_alpha);
@@ -709,17 +789,26 @@ int ghm_bn_backward(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y,
                     const float* gamma, float* dgamma, float* dbeta, int32_t act, float alpha, int32_t accumulate,
                     void* ws) {
     const long count = (long)N * HW;
-    const int S = bn_split(C, count);
+    int S = bn_split(C, count), seg_len = 0;
     double* wsd = (double*)ws;
     float* sums = (float*)((char*)ws + (size_t)C * BN_MAX_SPLIT * 2 * sizeof(double));
-    hipLaunchKernelGGL(bn_bwd_partial, dim3(S, C), dim3(256), 0, ctx->stream, dout, (long)ds, y, (long)ys, x, (long)xs, N,
-                       HW, S, mean, inv, act, alpha, wsd);
+    const bool vec = HW % 4 == 0 && ds % 4 == 0 && ys % 4 == 0 && xs % 4 == 0 && dxs % 4 == 0 && aligned16(dout) &&
+                     aligned16(y) && aligned16(x) && aligned16(dx);
+    const int segs = vec ? bn_row_segs(N, C, HW, &seg_len) : 0;
+    if (segs > 0) {
+        S = N * segs;
+        hipLaunchKernelGGL((bn_rows_partial<true>), dim3(S, C), dim3(256), 0, ctx->stream, x, (long)xs, dout, (long)ds, y,
+                           (long)ys, HW, segs, seg_len, mean, inv, act, alpha, wsd);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_partial, dim3(S, C), dim3(256), 0, ctx->stream, dout, (long)ds, y, (long)ys, x, (long)xs, N,
+                           HW, S, mean, inv, act, alpha, wsd);
+    }
     GHM_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_final, dim3(ceil_div(C, 256)), dim3(256), 0, ctx->stream, (const double*)wsd, C, S, sums,
                        dgamma, dbeta, accumulate);
     GHM_LAUNCH_CHECK();
     const View v{N, C, HW};
-    if (HW % 4 == 0) {
+    if (vec) {
         hipLaunchKernelGGL((bn_bwd_apply<4>), EW_GRID((long)N * C * (HW / 4)), dout, (long)ds, y, (long)ys, x, (long)xs, dx,
                            (long)dxs, v, mean, inv, gamma, sums, 1.f / (float)count, act, alpha);
     } else {

@@ -222,8 +222,9 @@ def test_full_size_step_against_the_reference_executed_fixture(gpu):
     assert worst < 0.25, worst
     # norms after the step
     for k in keys:
-        # (biases that feed a BatchNorm start at 0 and have an exactly-zero true gradient: they only carry noise)
-        assert abs(after[k][1] - fix["after/" + k][1]) <= 1e-4 * fix["after/" + k][1] + 1e-6, k
+        # (biases that feed a BatchNorm start at 0 and have an exactly-zero true gradient: they only carry the
+        # summation-order noise of the BN backward reductions, RMSprop-amplified; hence the absolute term)
+        assert abs(after[k][1] - fix["after/" + k][1]) <= 1e-4 * fix["after/" + k][1] + 3e-6, k
     del model
 
 

@@ -115,7 +115,11 @@ def test_train_step_parity(dev, variant):
             flat_g = np.concatenate([g.ravel() for g in mg[key]])
             flat_r = np.concatenate([g.ravel() for g in ref['grads'][key]])
             assert np.linalg.norm(flat_r) > 1e-3, "vacuous test: reference gradient is zero"
-            assert rel(flat_g, flat_r) < 2e-4, (it, key, rel(flat_g, flat_r))
+            # config 1 at initialisation has generator channels whose batch mean is ~50x their spread: BatchNorm's
+            # E[x^2] - mean^2 amplifies the fp32 rounding of the convolutions there (per-tensor 2-3e-4 with any
+            # summation order); north_star's bound is 1e-3
+            tol = 6e-4 if variant == "config1_dcgan64_b16" else 2e-4
+            assert rel(flat_g, flat_r) < tol, (it, key, rel(flat_g, flat_r))
         mp = model_params(model)
         for key in ostep.NET_ORDER:
             ref_p = state['params'][key[0]][key[1]]
