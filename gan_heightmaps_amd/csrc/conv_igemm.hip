@@ -392,6 +392,7 @@ struct PatchArgs {
     float alpha;
     int accumulate;
     int slabs_per_split;
+    int debug;             // tuning only (GHM_ABLATE): 1 = skip global loads, 2 = also skip LDS stores
 };
 
 template <int KS, int BM, int RT, int WM, int WN, int CP, int ST>
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
         const bool more = (s + 1) < s_end;
-        if (more) load_slab();
+        if (more && a.debug < 1) load_slab();
         const float* Ab = As + buf * ASZ + abase;
         const float* Pb = Ps + buf * PSZ + pbase;
         float af[2][TM], bf[2][TN];
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
-            if (ks == (CP * T) / 2 - 1 && more) store_slab(buf ^ 1);
+            if (ks == (CP * T) / 2 - 1 && more && a.debug < 2) store_slab(buf ^ 1);
         }
         __syncthreads();
     }
@@ -1640,6 +1641,7 @@ int ghm_conv2d_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const f
             pa.in_nstride = d->x_nstride;
             pa.R = d->K; pa.out_nstride = d->y_nstride; pa.pad = d->pad;
             pa.act = act; pa.alpha = alpha; pa.accumulate = accumulate;
+            if (const char* f = getenv("GHM_ABLATE")) pa.debug = atoi(f);
             return launch_patch(ctx, pl, pa, d->kh, d->stride);
         }
     }
