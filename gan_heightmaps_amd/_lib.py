@@ -104,6 +104,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise GhmError("%s not found: build it with `python gan_heightmaps_amd/csrc/build.py` "
                        "(there is no CPU fallback)" % LIB_PATH)
+    # the host driver only supports dmabuf IPC: RCCL's cross-process buffer registration needs this before the HIP
+    # runtime initialises (no effect on a single process)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
