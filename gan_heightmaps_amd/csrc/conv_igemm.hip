@@ -373,8 +373,9 @@ __global__ __launch_bounds__(256) void direct_smallr_kernel(const IgemmArgs a) {
 //   - the input patch those pixels touch, (RT+KS-1) x (32+KS-1) per channel, ONCE (not once per tap),
 // and every MFMA B fragment (32 consecutive pixels of one row) is read from the patch at a compile-time
 // offset: k-step (cp, tap) pairs channel 2cp (lanes 0-31) with channel 2cp+1 (lanes 32-63) on the same tap.
-// The pixel tile is fixed for the block, so bounds masks and LDS offsets are loop invariants and a slab
-// costs pointer bumps only.
+// The pixel tile is fixed for the block, so bounds masks and source offsets are loop invariants and a slab
+// costs pointer bumps only.  Both LDS images are filled by global->LDS DMA issued one slab ahead (no staging
+// registers, no LDS store phase); the wave waits for its own DMA (vmcnt) just before the slab barrier.
 // ------------------------------------------------------------------------------------------------
 struct PatchArgs {
     const float* in;
@@ -392,27 +393,29 @@ struct PatchArgs {
     float alpha;
     int accumulate;
     int slabs_per_split;
-    int debug;             // tuning only (GHM_ABLATE): 1 = skip global loads, 2 = also skip LDS stores
+    int debug;             // tuning only (GHM_ABLATE): 1 = skip the staging of all slabs but the first
+    const float* zeros;    // ctx->zeros: source of padding elements for the LDS-DMA staging
 };
 
 template <int KS, int BM, int RT, int WM, int WN, int CP, int ST>
-__global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
+__global__ __launch_bounds__(256, ST == 2 ? 3 : 2) void conv_patch_kernel(const PatchArgs a) {
     constexpr int T = KS * KS, CB = 2 * CP;
     constexpr int BN = RT * 32;
-    constexpr int LDA = BM + 4;
+    constexpr int LDA = BM;                         // unpadded: a weight row is one contiguous run of the DMA image
     constexpr int PH = (RT - 1) * ST + KS, PWN = 31 * ST + KS, PW = PWN, PS = PH * PW;
     constexpr int KR = CB * T;                      // weight rows per slab
     constexpr int ASZ = KR * LDA, PSZ = ((CB * PS + 3) / 4) * 4;
     constexpr int TM = BM / (WM * 32), TN = RT / WN;
     constexpr int AV = BM / 4;                      // float4 per weight row
-    constexpr int AL = (KR * AV + 255) / 256;
+    constexpr int NA4 = KR * AV;                    // float4 of the weight slab
+    constexpr int AL = (NA4 + 255) / 256;
     constexpr int NEL = CB * PH * PWN;
     constexpr int BL = (NEL + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                               // 2 x ASZ
     float* Ps = smem + 2 * ASZ;                     // 2 x PSZ
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int frag_k = lane >> 5, frag_i = lane & 31;
     // ---- block -> (r tile, image, tile row, tile column); r fastest so neighbours share the patch in L2
@@ -431,17 +434,21 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
     const int s_begin = blockIdx.y * a.slabs_per_split;
     const int s_end = min(nslabs, s_begin + a.slabs_per_split);
 
-    // ---- loop-invariant fetch descriptors (element offsets relative to per-slab base pointers) ----
-    int a_off[AL], a_lds[AL];
+    // ---- staging: both LDS images are LINEAR in the fetch index (weight slab: float4 f = row * AV + c4 at float
+    // 4f; patch: element e = (c, py, px) at float e), so every wave-instruction of a global->LDS DMA fills 64
+    // consecutive slots (uniform base + lane * size) and nothing passes through VGPRs.  Padding elements and filter
+    // columns past R read a.zeros.  Per-lane state: element offsets relative to the per-slab base pointers.
+    int a_off[AL];
+    unsigned amask = 0;
 #pragma unroll
     for (int q = 0; q < AL; ++q) {
-        const int e = tid + q * 256;
-        const int row = e / AV, c4 = e - row * AV;
-        const bool v = row < KR && (r0 + c4 * 4) < a.R;
-        a_lds[q] = v ? row * LDA + c4 * 4 : -1;
+        const int f = tid + q * 256;
+        const int row = f / AV, c4 = f - row * AV;
+        const bool v = f < NA4 && (r0 + c4 * 4) < a.R;
         a_off[q] = v ? row * a.R + r0 + c4 * 4 : 0;
+        amask |= (v ? 1u : 0u) << q;
     }
-    int p_off[BL], p_lds[BL];
+    int p_off[BL];
     unsigned pmask = 0;
 #pragma unroll
     for (int q = 0; q < BL; ++q) {
@@ -449,9 +456,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
         const int c = e / (PH * PWN), r = e - c * (PH * PWN);
         const int py = r / PWN, px = r - py * PWN;
         const int y = y0 * ST + py - a.pad, x = x0 * ST + px - a.pad;
-        const bool inr = e < NEL;
-        const bool ok = inr && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
-        p_lds[q] = inr ? c * PS + py * PW + px : -1;
+        const bool ok = e < NEL && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
         p_off[q] = ok ? c * HWin + y * a.Win + x : 0;
         pmask |= (ok ? 1u : 0u) << q;
     }
@@ -459,30 +464,29 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
     const float* ibase = a.in + (long)n * a.in_nstride + (long)s_begin * CB * HWin; // uniform
     const long a_step = (long)KR * a.R, p_step = (long)CB * HWin;
 
-    float areg[AL * 4];          // scalars, not float4[]: keeps the staging registers out of scratch
-    float breg[BL];
-    auto load_slab = [&]() {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto stage_slab = [&](int buf) {
+        float* Ab = As + buf * ASZ + wave * 256;        // this wave's 64 float4 slots of pass q start at q*1024 floats
+        float* Pb = Ps + buf * PSZ + wave * 64;
 #pragma unroll
         for (int q = 0; q < AL; ++q) {
-            const float4 t = *reinterpret_cast<const float4*>(wbase + a_off[q]);
-            areg[4 * q + 0] = t.x; areg[4 * q + 1] = t.y; areg[4 * q + 2] = t.z; areg[4 * q + 3] = t.w;
+            if (q * 256 + wave * 64 < NA4) {            // uniform; NA4 % 16 == 0 and the tail lanes fall on whole rows
+                const float* g = ((amask >> q) & 1u) ? wbase + a_off[q] : a.zeros;
+                if (tid + q * 256 < NA4)
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ab + q * 1024), 16, 0, 0);
+            }
         }
 #pragma unroll
-        for (int q = 0; q < BL; ++q) breg[q] = ibase[p_off[q]];
+        for (int q = 0; q < BL; ++q) {
+            if (q * 256 + wave * 64 < NEL) {
+                const float* g = ((pmask >> q) & 1u) ? ibase + p_off[q] : a.zeros;
+                if (tid + q * 256 < NEL)
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Pb + q * 256), 4, 0, 0);
+            }
+        }
         wbase += a_step;
         ibase += p_step;
-    };
-    auto store_slab = [&](int buf) {
-        float* Ab = As + buf * ASZ;
-        float* Pb = Ps + buf * PSZ;
-#pragma unroll
-        for (int q = 0; q < AL; ++q)
-            if (a_lds[q] >= 0)
-                *reinterpret_cast<float4*>(Ab + a_lds[q]) =
-                    make_float4(areg[4 * q + 0], areg[4 * q + 1], areg[4 * q + 2], areg[4 * q + 3]);
-#pragma unroll
-        for (int q = 0; q < BL; ++q)
-            if (p_lds[q] >= 0) Pb[p_lds[q]] = ((pmask >> q) & 1u) ? breg[q] : 0.f;
     };
 
     f32x16 acc[TM][TN];
@@ -493,10 +497,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if (s_begin < s_end) {
-        load_slab();
-        store_slab(0);
-    }
+    if (s_begin < s_end) stage_slab(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // lane bases: A rows (frag_k selects the odd channel of the pair), patch (pixel column, row segment)
     const int abase = frag_k * T * LDA + wm * (BM / WM) + frag_i;
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
         const bool more = (s + 1) < s_end;
-        if (more && a.debug < 1) load_slab();
+        if (more && a.debug < 1) stage_slab(buf ^ 1);   // lands during this slab's MFMAs; waited for before the barrier
         const float* Ab = As + buf * ASZ + abase;
         const float* Pb = Ps + buf * PSZ + pbase;
         float af[2][TM], bf[2][TN];
@@ -528,8 +530,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const PatchArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
-            if (ks == (CP * T) / 2 - 1 && more && a.debug < 2) store_slab(buf ^ 1);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -1487,7 +1489,7 @@ PatchPlan plan_patch(int N, int CH, int H, int W, int R, int ks, int num_cu, int
     const int cb = ks == 5 ? 2 : 4;
     if (R < 32 || (R & 3) || (W % 32) || (H % p.rt) || (CH % cb) || CH < 2 * cb) return p;
     const int T = ks * ks;
-    const int lda = p.bm + 4, ph = (p.rt - 1) * st + ks, pw = 31 * st + ks;
+    const int lda = p.bm, ph = (p.rt - 1) * st + ks, pw = 31 * st + ks;
     const int asz = cb * T * lda, psz = ((cb * ph * pw + 3) / 4) * 4;
     p.lds = (size_t)2 * (asz + psz) * sizeof(float);
     const int ntr = (R + p.bm - 1) / p.bm;
@@ -1508,6 +1510,7 @@ PatchPlan plan_patch(int N, int CH, int H, int W, int R, int ks, int num_cu, int
 int launch_patch(ghm_ctx* ctx, const PatchPlan& pl, PatchArgs a, int ks, int st = 1) {
     a.slabs_per_split = pl.slabs_per_split;
     a.partial = nullptr;
+    a.zeros = ctx->zeros;
     if (pl.splits > 1) {
         void* ws = nullptr;
         if (int e = ghm_scratch(ctx, (size_t)pl.splits * a.R * a.N * a.H * a.W * sizeof(float), &ws)) return e;
