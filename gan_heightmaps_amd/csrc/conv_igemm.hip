@@ -398,7 +398,7 @@ struct PatchArgs {
 };
 
 template <int KS, int BM, int RT, int WM, int WN, int CP, int ST>
-__global__ __launch_bounds__(256, ST == 2 ? 3 : 2) void conv_patch_kernel(const PatchArgs a) {
+__global__ __launch_bounds__(256, ST == 2 ? 3 : 4) void conv_patch_kernel(const PatchArgs a) {
     constexpr int T = KS * KS, CB = 2 * CP;
     constexpr int BN = RT * 32;
     constexpr int LDA = BM;                         // unpadded: a weight row is one contiguous run of the DMA image
@@ -536,30 +536,92 @@ __global__ __launch_bounds__(256, ST == 2 ? 3 : 2) void conv_patch_kernel(const 
     }
 
     // ---- epilogue ----
+    // Loads and stores share vmcnt: a bias (or accumulate) load issued after a store makes the wave wait for that
+    // store's acknowledgement, once per element if they interleave.  So the bias goes to registers first (one batch,
+    // one wait), the activation class is chosen once, and old values are read 16 at a time.
+    // Addresses: wave-uniform row pointer (SGPR pair) + one unsigned 32-bit lane offset, so no per-element 64-bit
+    // address registers are held.  Element e of row tile i sits k = i*32 + (e&3) + 8*(e>>2) rows below the wave's
+    // first row; the lane adds 4*frag_k rows and its pixel column.
     const long P = (long)a.N * HW;
+    const int ru = r0 + wm * (BM / WM);                          // uniform first row of this wave
+    const int rl = ru + 4 * frag_k;                              // this lane's first row
+    if (a.partial) {
+        float* const pb = a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HW + (long)(y0 + wn * TN) * a.W + x0;
+        const unsigned lo = 4u * frag_k * (unsigned)P + frag_i;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int y = y0 + wn * TN + j, x = x0 + frag_i;
-        const long pix = (long)n * HW + (long)y * a.W + x;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int r = r0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * frag_k;
-                if (r < a.R) {
-                    if (a.partial) {
-                        a.partial[((long)blockIdx.y * a.R + r) * P + pix] = acc[i][j][e];
-                    } else {
-                        float v = acc[i][j][e];
-                        if (a.bias) v += a.bias[r];
-                        float* o = a.out + (long)n * a.out_nstride + (long)r * HW + (long)y * a.W + x;
-                        if (a.accumulate) v += *o;
-                        *o = ghm_act(v, a.act, a.alpha);
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    float* rowp = pb + (long)k * P + j * a.W;
+                    if (rl + k < a.R) rowp[lo] = acc[i][j][e];
+                }
+        return;
+    }
+    // bias through LDS (free after the last slab barrier): LDS reads count on lgkmcnt, not on the stores' vmcnt
+    float* const sb = smem;
+    if (tid < BM) sb[tid] = (a.bias && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
+    __syncthreads();
+    const float* const lb = sb + wm * (BM / WM) + 4 * frag_k;
+    float* const ub = a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN) * a.W + x0;
+    const unsigned lo = 4u * frag_k * (unsigned)HW + frag_i;
+    const bool pwl = a.act == GHM_ACT_LINEAR || a.act == GHM_ACT_RELU || a.act == GHM_ACT_LRELU;
+    if (r0 + BM <= a.R && pwl) {
+        // every tile of this workload: full row tile, piecewise-linear activation (linear = slope 1)
+        const float slope = a.act == GHM_ACT_LINEAR ? 1.f : (a.act == GHM_ACT_RELU ? 0.f : a.alpha);
+        if (!a.accumulate) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                        float* rowp = ub + (long)k * HW + j * a.W;
+                        const float v = acc[i][j][e] + lb[k];
+                        rowp[lo] = v > 0.f ? v : slope * v;
+                    }
+        } else {
+            // read-modify-write (a data gradient summed into an existing one): 16 old values per batch of stores
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float old[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                        const float* rowp = ub + (long)k * HW + j * a.W;
+                        old[e] = rowp[lo];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                        float* rowp = ub + (long)k * HW + j * a.W;
+                        const float v = acc[i][j][e] + lb[k] + old[e];
+                        rowp[lo] = v > 0.f ? v : slope * v;
                     }
                 }
-            }
         }
+        return;
     }
+    // ragged row tiles, tanh / sigmoid: element by element
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                if (rl + k < a.R) {
+                    float* rowp = ub + (long)k * HW + j * a.W;
+                    float v = acc[i][j][e] + lb[k];
+                    if (a.accumulate) v += rowp[lo];
+                    rowp[lo] = ghm_act(v, a.act, a.alpha);
+                }
+            }
 }
 
 // ------------------------------------------------------------------------------------------------
