@@ -34,6 +34,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GHM_FENCE_MASK 0x0616
 #endif
 #define GHM_FRAG_FENCE() __builtin_amdgcn_sched_barrier(GHM_FENCE_MASK)
+// Alternative used by the forward patch kernel: ask the scheduler for one LDS read after every MFMA of the k-step
+// (sched_group_barrier masks: 0x008 MFMA, 0x100 LDS read), so the next step's fragment reads are spread over this
+// step's MFMAs instead of bunched before their use.  Measured: 5x5 forward 132 -> 136 TFLOP/s, 3x3 118.7 -> 120.7.
+#define GHM_INTERLEAVE(n)                                          \
+    _Pragma("unroll") for (int m_ = 0; m_ < (n); ++m_) {           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         \
+    }
 
 #define MAX_TAPS 25
 
@@ -530,6 +538,7 @@ __global__ __launch_bounds__(256, ST == 2 ? 3 : 4) void conv_patch_kernel(const 
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+            if (ks + 1 < CP * T) GHM_INTERLEAVE(TM * TN);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
