@@ -134,6 +134,11 @@ def _check_conv(gpu, case):
     # fused epilogue
     ops.conv2d_fwd(d, xd, wd, bd, yd, act='lrelu', alpha=0.2)
     assert rel(yd.numpy(), O.lrelu_fwd(y_ref, 0.2)) < TOL
+    # the other activations of the epilogue (relu shares the piecewise-linear fast path, tanh / sigmoid take the
+    # element-by-element one)
+    for act, f in (('relu', lambda v: np.maximum(v, 0.0)), ('tanh', np.tanh), ('sigmoid', lambda v: 1.0 / (1.0 + np.exp(-v)))):
+        ops.conv2d_fwd(d, xd, wd, bd, yd, act=act)
+        assert rel(yd.numpy(), f(y_ref)) < TOL, act
     # dgrad (+ accumulate)
     dyd, dxd = dev.tensor(dy), dev.empty(x.shape)
     ops.conv2d_dgrad(d, dyd, wd, dxd)
