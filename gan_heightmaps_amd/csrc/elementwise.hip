@@ -437,6 +437,41 @@ __global__ __launch_bounds__(256) void up_bilinear_bwd_kernel(const float* __res
 }
 
 
+// Same adjoint, two coarse columns per thread and one plane per blockIdx.y: the five fine columns a pair touches are
+// one scalar + one 16-byte load per fine row, and no 64-bit index arithmetic.  Needs W even and 16-byte aligned rows.
+__global__ __launch_bounds__(256) void up_bilinear_bwd2_kernel(const float* __restrict__ dy, float* __restrict__ dx, long dxs,
+                                                               int C, int H, int W, int accumulate) {
+    const int pl = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int Wh = W >> 1;
+    if (t >= H * Wh) return;
+    const int i = t / Wh, j0 = (t - i * Wh) * 2;
+    const int n = pl / C, c = pl - n * C;
+    const int W2 = 2 * W;
+    const float* g = dy + (long)pl * 4 * H * W + 2 * j0;
+    const float wl = j0 >= 1 ? 0.5f : 0.f;                 // fine column 2*j0 - 1 exists
+    const float wr = (j0 + 1 == W - 1) ? 1.f : 0.5f;       // the clamped last column takes its right neighbour twice
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int r = -1; r <= 1; ++r) {
+        const int fr = 2 * i + r;
+        if (fr < 0) continue;
+        const float wrow = r == 0 ? 1.f : ((r == 1 && i == H - 1) ? 1.f : 0.5f);
+        const float* row = g + (long)fr * W2;
+        const float4 f = *reinterpret_cast<const float4*>(row);
+        const float fm = j0 >= 1 ? row[-1] : 0.f;
+        s0 += wrow * (f.x + 0.5f * f.y + wl * fm);
+        s1 += wrow * (f.z + wr * f.w + 0.5f * f.y);
+    }
+    float* p = dx + n * dxs + (long)c * H * W + (long)i * W + j0;
+    if (accumulate) {
+        const float2 o = *reinterpret_cast<const float2*>(p);
+        s0 += o.x;
+        s1 += o.y;
+    }
+    *reinterpret_cast<float2*>(p) = make_float2(s0, s1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // input pipeline (/root/reference/util.py:28-40 + Keras ImageDataGenerator): one pass that turns a
 // uint8 NHWC batch into the normalised fp32 NCHW tensor the nets consume, resampled through a per-sample affine
@@ -961,7 +996,12 @@ int ghm_upsample_bilinear2_fwd(ghm_ctx* ctx, const float* x, int64_t xs, float* 
 
 int ghm_upsample_bilinear2_bwd(ghm_ctx* ctx, const float* dy, float* dx, int64_t dxs, int32_t N, int32_t C, int32_t H,
                                int32_t W, int32_t accumulate) {
-    hipLaunchKernelGGL(up_bilinear_bwd_kernel, EW_GRID((long)N * C * H * W), dy, dx, (long)dxs, N, C, H, W, accumulate);
+    if (W % 2 == 0 && dxs % 2 == 0 && aligned16(dy) && ((uintptr_t)dx & 7) == 0 && (long)N * C <= 65535) {
+        hipLaunchKernelGGL(up_bilinear_bwd2_kernel, dim3(ceil_div((long)H * (W / 2), 256), N * C), dim3(256), 0, ctx->stream, dy,
+                           dx, (long)dxs, C, H, W, accumulate);
+    } else {
+        hipLaunchKernelGGL(up_bilinear_bwd_kernel, EW_GRID((long)N * C * H * W), dy, dx, (long)dxs, N, C, H, W, accumulate);
+    }
     GHM_LAUNCH_CHECK();
     return 0;
 }

@@ -324,11 +324,15 @@ def test_pool_upsample_act(gpu):
     ops.upsample_bilinear2_bwd(gd, dxd, accumulate=True)
     assert rel(dxd.numpy(), 2 * O.bilinear_up2_vjp(g.astype(np.float64))) < TOL
     # 1x1 and 2x2 bilinear edge cases (U-Net 2x2 -> 4x4)
-    for hw in [(1, 1), (2, 2), (1, 3)]:
+    for hw in [(1, 1), (2, 2), (1, 3), (3, 4), (8, 2)]:
         xs = rng.randn(2, 3, *hw).astype(np.float32)
         us = dev.empty((2, 3, 2 * hw[0], 2 * hw[1]))
         ops.upsample_bilinear2_fwd(dev.tensor(xs), us)
         assert rel(us.numpy(), O.bilinear_theano_literal(xs.astype(np.float64))) < TOL
+        gs = rng.randn(2, 3, 2 * hw[0], 2 * hw[1]).astype(np.float32)      # adjoint: even widths take the two-column kernel
+        dxs = dev.empty(xs.shape)
+        ops.upsample_bilinear2_bwd(dev.tensor(gs), dxs)
+        assert rel(dxs.numpy(), O.bilinear_up2_vjp(gs.astype(np.float64))) < TOL
     # activations fwd/bwd
     for act, alpha, f, df in [('sigmoid', 0, O.sigmoid_fwd, O.sigmoid_vjp_from_out),
                               ('tanh', 0, O.tanh_fwd, O.tanh_vjp_from_out)]:
