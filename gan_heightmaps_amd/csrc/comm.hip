@@ -3,6 +3,7 @@
 // collective code at all; one process per GPU, gradients summed per net bucket.
 #include <dlfcn.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "common.h"
 
@@ -24,6 +25,26 @@ struct RcclApi {
 };
 
 RcclApi g_api;
+
+// RCCL prints a start-up banner (ROCm version / hostname / library path) on STDOUT while it initialises.  The
+// launcher contract reserves rank 0's stdout for one JSON line, so fd 1 points at stderr for the duration of the
+// calls that can trigger it.
+struct StdoutToStderr {
+    int saved;
+    StdoutToStderr() {
+        fflush(stdout);
+        saved = dup(1);
+        if (saved >= 0) dup2(2, 1);
+    }
+    ~StdoutToStderr() {
+        fflush(stdout);
+        if (saved >= 0) {
+            dup2(saved, 1);
+            close(saved);
+        }
+    }
+};
+bool g_first_collective = true;
 
 int load_rccl() {
     if (g_api.handle) return 0;
@@ -61,6 +82,7 @@ int load_rccl() {
 extern "C" {
 
 int ghm_comm_unique_id(uint8_t id_out[128]) {
+    StdoutToStderr quiet;
     if (int e = load_rccl()) return e;
     rccl_uid id;
     GHM_RCCL(g_api.GetUniqueId(&id));
@@ -69,6 +91,7 @@ int ghm_comm_unique_id(uint8_t id_out[128]) {
 }
 
 int ghm_comm_init(ghm_ctx* ctx, int32_t rank, int32_t world, const uint8_t id[128]) {
+    StdoutToStderr quiet;
     if (int e = load_rccl()) return e;
     GHM_CHECK(ctx->comm == nullptr, "communicator already initialised");
     GHM_HIP(hipSetDevice(ctx->device));
@@ -95,6 +118,13 @@ int ghm_comm_destroy(ghm_ctx* ctx) {
 int ghm_allreduce_sum(ghm_ctx* ctx, float* buf, int64_t n) {
     if (ctx->world == 1 && ctx->comm == nullptr) return 0;   // single process: the sum is the identity
     GHM_CHECK(ctx->comm != nullptr, "ghm_allreduce_sum without ghm_comm_init");
+    if (g_first_collective) {       // channel set-up happens on the first collective
+        g_first_collective = false;
+        StdoutToStderr quiet;
+        GHM_RCCL(g_api.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT32, RCCL_SUM, (rccl_comm)ctx->comm, ctx->stream));
+        GHM_HIP(hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
     GHM_RCCL(g_api.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT32, RCCL_SUM, (rccl_comm)ctx->comm, ctx->stream));
     return 0;
 }
