@@ -82,7 +82,10 @@ def main():
     if device.device_count() == 0:
         sys.exit("bench.py: no HIP device visible (there is no CPU fallback)")
     dev = device.Device(local_rank)
-    comm = dist.Comm(dev, rank, world) if world > 1 else None
+    # the communicator gets its own context of the same GPU: its stream is the communication stream, so the bucket
+    # all-reduces run beside the rest of the backward pass (step.py)
+    cdev = device.Device(local_rank) if world > 1 else None
+    comm = dist.Comm(cdev, rank, world) if world > 1 else None
     B = args.batch_per_gpu
     backend = dict(device=dev, comm=comm, use_graph=args.graph, seed=0, verbose=False, two_streams=not args.one_stream,
                    side_streams=(not args.no_grad_streams) and not args.graph)
@@ -209,6 +212,7 @@ def main():
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
+        cdev.close()
     for d in set(eng.devs):
         if d is not dev:
             d.close()

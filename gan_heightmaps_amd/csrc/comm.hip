@@ -44,7 +44,6 @@ struct StdoutToStderr {
         }
     }
 };
-bool g_first_collective = true;
 
 int load_rccl() {
     if (g_api.handle) return 0;
@@ -102,6 +101,14 @@ int ghm_comm_init(ghm_ctx* ctx, int32_t rank, int32_t world, const uint8_t id[12
     ctx->comm = comm;
     ctx->rank = rank;
     ctx->world = world;
+    // RCCL sets its channels up (and prints) on the first collective: do that one here, inside the collective
+    // initialisation call and with stdout parked, so that no later all-reduce blocks the host or carries state
+    float* warm = nullptr;
+    GHM_HIP(hipMalloc((void**)&warm, 256));
+    GHM_HIP(hipMemsetAsync(warm, 0, 256, ctx->stream));
+    GHM_RCCL(g_api.AllReduce(warm, warm, 1, RCCL_FLOAT32, RCCL_SUM, comm, ctx->stream));
+    GHM_HIP(hipStreamSynchronize(ctx->stream));
+    GHM_HIP(hipFree(warm));
     return 0;
 }
 
@@ -116,22 +123,15 @@ int ghm_comm_destroy(ghm_ctx* ctx) {
 }
 
 int ghm_allreduce_sum(ghm_ctx* ctx, float* buf, int64_t n) {
-    if (ctx->world == 1 && ctx->comm == nullptr) return 0;   // single process: the sum is the identity
-    GHM_CHECK(ctx->comm != nullptr, "ghm_allreduce_sum without ghm_comm_init");
-    if (g_first_collective) {       // channel set-up happens on the first collective
-        g_first_collective = false;
-        StdoutToStderr quiet;
-        GHM_RCCL(g_api.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT32, RCCL_SUM, (rccl_comm)ctx->comm, ctx->stream));
-        GHM_HIP(hipStreamSynchronize(ctx->stream));
-        return 0;
-    }
+    // no identity shortcut: a caller that reduces on a context without a communicator is reducing on the wrong
+    // context (its gradients would silently stay local while being scaled by 1/world)
+    GHM_CHECK(ctx->comm != nullptr, "ghm_allreduce_sum on a context without a communicator (ghm_comm_init)");
     GHM_RCCL(g_api.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT32, RCCL_SUM, (rccl_comm)ctx->comm, ctx->stream));
     return 0;
 }
 
 int ghm_allreduce_max(ghm_ctx* ctx, float* buf, int64_t n) {
-    if (ctx->world == 1 && ctx->comm == nullptr) return 0;
-    GHM_CHECK(ctx->comm != nullptr, "ghm_allreduce_max without ghm_comm_init");
+    GHM_CHECK(ctx->comm != nullptr, "ghm_allreduce_max on a context without a communicator (ghm_comm_init)");
     GHM_RCCL(g_api.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT32, RCCL_MAX, (rccl_comm)ctx->comm, ctx->stream));
     return 0;
 }

@@ -19,15 +19,29 @@ def env_rank_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+_T_IMPORT = time.time()
+STALE_SLACK_S = 60.0     # ranks of one launch start within this many seconds of each other
+
+
 def rendezvous_path():
+    """GHM_RDZV_FILE if set; else a file keyed on what every worker of ONE job shares under any launcher:
+    MASTER_ADDR, MASTER_PORT (unique per job on a node), WORLD_SIZE and the launcher's run id.  Under
+    torch.distributed.run the launcher's pid is added (all its workers share it as parent)."""
+    if os.environ.get("GHM_RDZV_FILE"):
+        return os.environ["GHM_RDZV_FILE"]
     base = os.environ.get("GHM_RDZV_DIR", "/tmp")
-    tag = "%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
-                        os.getppid())       # all workers of one launch share the launcher as parent
+    run_id = os.environ.get("TORCHELASTIC_RUN_ID")
+    tag = "%s_%s_%s_%s" % (os.environ.get("MASTER_ADDR", "local").replace("/", "_"), os.environ.get("MASTER_PORT", "0"),
+                           os.environ.get("WORLD_SIZE", "1"), run_id or "norunid")
+    if run_id is not None:
+        tag += "_%d" % os.getppid()
     return os.path.join(base, "ghm_rdzv_%s.uid" % tag)
 
 
 def exchange_unique_id(rank, world, make_id, path=None, timeout=300.0):
-    """rank 0: make_id() -> 128 bytes, published through ``path``; other ranks: wait for it."""
+    """rank 0: make_id() -> 128 bytes, published through ``path``; other ranks: wait for it.  A file left behind
+    by a crashed earlier job with the same key is recognised by its age (older than this process by more than
+    STALE_SLACK_S) and ignored until rank 0 replaces it."""
     path = path or rendezvous_path()
     if rank == 0:
         uid = bytes(make_id())
@@ -40,9 +54,10 @@ def exchange_unique_id(rank, world, make_id, path=None, timeout=300.0):
     t0 = time.time()
     while True:
         try:
+            fresh = os.path.getmtime(path) >= _T_IMPORT - STALE_SLACK_S
             with open(path, "rb") as f:
                 uid = f.read()
-            if len(uid) == 128:
+            if fresh and len(uid) == 128:
                 return uid
         except FileNotFoundError:
             pass

@@ -2,9 +2,10 @@
 ``python experiments.py <experiment> <mode>``, experiments test1_nobn, test1_nobn_finetunep2p_bilin and
 test1_nobn_bilin_both, modes train / interp / gen.
 
-``get_iterators`` returns the device-side counterpart of util.Hdf5Iterator (gan_heightmaps_amd.data); h5py is not
-in this image, so it reads an ``.npz`` with xt/yt/xv/yv uint8 NHWC arrays when given one and otherwise serves
-seeded synthetic batches with the reference's value ranges.
+``get_iterators`` returns the device-side counterpart of util.Hdf5Iterator (gan_heightmaps_amd.data) over the
+xt/yt/xv/yv uint8 NHWC arrays of an HDF5 file (when h5py is importable -- it is not in this image) or of an
+``.npz`` with the same four keys.  A missing or unreadable dataset is an error; synthetic batches with the
+reference's value ranges are served only when asked for (``dataset=None`` or ``GHM_DATASET=synthetic``).
 """
 import os
 import sys
@@ -58,14 +59,23 @@ def get_iterators(dataset, batch_size, is_a_grayscale, is_b_grayscale, da=True, 
     dataset, augmented with flips + 360-degree rotation + reflect fill when ``da``.  The reference opens an HDF5
     file (h5py is not available here): an ``.npz`` with the same four keys is read instead, else synthetic data."""
     from .data import Hdf5Iterator, ImageDataGenerator
-    if dataset is not None and os.path.exists(dataset) and dataset.endswith(".npz"):
+    if dataset is None or dataset == "synthetic":
+        xt, yt = synthetic_arrays(n_synthetic, in_shp, is_a_grayscale, is_b_grayscale, 0)
+        xv, yv = xt, yt
+    elif not os.path.exists(dataset):
+        raise FileNotFoundError("dataset %r does not exist (set GHM_DATASET to an .h5 / .npz file with xt, yt, xv, yv, "
+                                "or to 'synthetic' for random batches)" % (dataset,))
+    elif dataset.endswith(".npz"):
         d = np.load(dataset)
         xt, yt, xv, yv = d['xt'], d['yt'], d['xv'], d['yv']
     else:
-        if dataset is not None:
-            print("dataset %r not available: using synthetic 512x512 batches" % (dataset,), file=sys.stderr)
-        xt, yt = synthetic_arrays(n_synthetic, in_shp, is_a_grayscale, is_b_grayscale, 0)
-        xv, yv = xt, yt
+        try:
+            import h5py
+        except ImportError:
+            raise ImportError("reading %r needs h5py, which is not installed; convert the file to an .npz with the "
+                              "keys xt, yt, xv, yv (uint8, NHWC)" % (dataset,))
+        d = h5py.File(dataset, "r")             # experiments.py:11: datasets stay on disk and are sliced per batch
+        xt, yt, xv, yv = d['xt'], d['yt'], d['xv'], d['yv']
     if da:
         imgen = ImageDataGenerator(horizontal_flip=True, vertical_flip=True, rotation_range=360, fill_mode="reflect")
     else:
@@ -115,31 +125,59 @@ def make_model(name, **backend):
 DATASET = os.environ.get("GHM_DATASET", "/data/lisa/data/cbeckham/textures_v2_brown500.h5")
 
 
-def _run(name, out_name, mode, num_epochs=1000, **train_kw):
-    assert mode in ["train", "interp", "gen"]
-    model = make_model(name)
+BASE_RUN = "test1_repeatnod_fixp2p_nobn"             # the run whose checkpoints the other entry points load
+FINETUNE_RUN = "test1_repeatnod_fixp2p_nobn_finetunep2p_bilin"
+
+
+def _train(model, out_name, num_epochs, dataset=None, **train_kw):
     bs = 4
-    it_train, it_val = get_iterators(DATASET, bs, True, False, True)
+    it_train, it_val = get_iterators(DATASET if dataset is None else dataset, bs, True, False, True,
+                                     device=model.device)
+    model.train(it_train, it_val, batch_size=bs, num_epochs=num_epochs, out_dir="output/%s" % out_name,
+                model_dir="models/%s" % out_name, **train_kw)
+
+
+def test1_nobn(mode, num_epochs=1000, models_dir="models", **kw):
+    """experiments.py:22-55"""
+    assert mode in ["train", "interp", "gen"]
+    model = make_model('test1_nobn', **kw.pop('backend', {}))
     if mode == "train":
-        model.train(it_train, it_val, batch_size=bs, num_epochs=num_epochs, out_dir="output/%s" % out_name,
-                    model_dir="models/%s" % out_name, **train_kw)
-    elif mode == "gen":
-        model.generate_gz(100, 10, "deleteme")
+        _train(model, BASE_RUN, num_epochs, **kw)
+    elif mode == "interp":
+        model.load_model("%s/%s/600.model.bak" % (models_dir, BASE_RUN))
+        zs = model.sampler(2, model.latent_dim)
+        # the reference passes (z1, z2, "/tmp/test.png") against the signature (out_name, zsample1, zsample2)
+        # (experiments.py:51 vs pix2pix.py:328): the evident intent is kept
+        model.generate_interpolation("/tmp/test.png", floatX(zs[0]), floatX(zs[1]), mode='matrix')
     else:
-        raise NotImplementedError("interpolation utilities are outside this round's scope (SURVEY 8 f3)")
+        model.load_model("%s/%s/600.model.bak" % (models_dir, BASE_RUN))
+        model.generate_gz(100, 10, "deleteme")
     return model
 
 
-def test1_nobn(mode, **kw):
-    return _run('test1_nobn', "test1_repeatnod_fixp2p_nobn", mode, **kw)
+def test1_nobn_finetunep2p_bilin(mode, num_epochs=1000, models_dir="models", load_base=True, **kw):
+    """experiments.py:58-93: the DCGAN half comes from the base run's checkpoint, only the pix2pix half trains"""
+    assert mode in ["train", "interp", "gen"]
+    model = make_model('test1_nobn_finetunep2p_bilin', **kw.pop('backend', {}))
+    if load_base:
+        model.load_model("%s/%s/1000.model.bak" % (models_dir, BASE_RUN), mode='dcgan')
+    if mode == "train":
+        _train(model, FINETUNE_RUN, num_epochs, **kw)
+    elif mode == "interp":
+        model.load_model("%s/%s/1000.model.bak" % (models_dir, BASE_RUN), mode='dcgan')
+        model.load_model("%s/%s/1000.model.bak" % (models_dir, FINETUNE_RUN), mode='p2p')
+        model.generate_interpolation_clip(100, 4, "output/%s/interp_clip_600_concat_bothdet/" % FINETUNE_RUN,
+                                          concat=True, deterministic=True)
+    return model
 
 
-def test1_nobn_finetunep2p_bilin(mode, **kw):
-    return _run('test1_nobn_finetunep2p_bilin', "test1_repeatnod_fixp2p_nobn_finetunep2p_bilin", mode, **kw)
-
-
-def test1_nobn_bilin_both(mode, **kw):
-    return _run('test1_nobn_bilin_both', "test1_nobn_bilin_both_deleteme", mode, **kw)
+def test1_nobn_bilin_both(mode, num_epochs=1000, **kw):
+    """experiments.py:99-127 (only 'train' does anything in the reference)"""
+    assert mode in ["train", "interp", "gen"]
+    model = make_model('test1_nobn_bilin_both', **kw.pop('backend', {}))
+    if mode == "train":
+        _train(model, "test1_nobn_bilin_both_deleteme", num_epochs, **kw)
+    return model
 
 
 def main(argv):

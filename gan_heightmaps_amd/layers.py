@@ -109,16 +109,31 @@ def _pair(v):
     return (int(v), int(v)) if np.isscalar(v) else (int(v[0]), int(v[1]))
 
 
+_DEFAULT = object()     # "argument not given" (lasagne's defaults are initialiser objects; an explicit None means no bias)
+
+
+def _w_spec(W):
+    """lasagne accepts an initialiser, a numpy array or a shared variable for W"""
+    return _init.GlorotUniform() if W is None or W is _DEFAULT else W
+
+
+def _b_spec(b):
+    if b is None:
+        raise NotImplementedError("b=None (a layer without bias): no reference architecture uses it and the packed "
+                                  "parameter layout has no bias-free form")
+    return _init.Constant(0.) if b is _DEFAULT else b
+
+
 class DenseLayer(Layer):
     """y = x W + b, W[in, units]; default nonlinearity rectify (architectures/dcgan.py:16 passes linear)."""
 
-    def __init__(self, incoming, num_units, W=None, b=None, nonlinearity=rectify, name=None):
+    def __init__(self, incoming, num_units, W=_DEFAULT, b=_DEFAULT, nonlinearity=rectify, name=None):
         Layer.__init__(self, incoming, name)
         self.num_units = int(num_units)
         self.nonlinearity = as_nonlinearity(nonlinearity)
         n_in = int(np.prod(self.input_shape[1:]))
-        self.W = self.add_param(W or _init.GlorotUniform(), (n_in, self.num_units), "W", 'dense_w')
-        self.b = self.add_param(b or _init.Constant(0.), (self.num_units,), "b", 'vec', regularizable=False)
+        self.W = self.add_param(_w_spec(W), (n_in, self.num_units), "W", 'dense_w')
+        self.b = self.add_param(_b_spec(b), (self.num_units,), "b", 'vec', regularizable=False)
 
     def get_output_shape_for(self, s):
         return (s[0], self.num_units)
@@ -128,7 +143,7 @@ class Conv2DLayer(Layer):
     """lasagne Conv2DLayer: W[num_filters, C, kh, kw], b; stride 1, pad 0, rectify, flip_filters=True
     (true convolution) by default.  pad='same' -> k//2 (odd k), 'valid' -> 0 (SURVEY Appendix A.1)."""
 
-    def __init__(self, incoming, num_filters, filter_size, stride=(1, 1), pad=0, W=None, b=None,
+    def __init__(self, incoming, num_filters, filter_size, stride=(1, 1), pad=0, W=_DEFAULT, b=_DEFAULT,
                  nonlinearity=rectify, flip_filters=True, name=None):
         Layer.__init__(self, incoming, name)
         self.num_filters = int(num_filters)          # py3: nch/elem is a float (architectures/dcgan.py:19)
@@ -150,8 +165,8 @@ class Conv2DLayer(Layer):
             raise NotImplementedError("anisotropic stride/pad")
         self.nonlinearity = as_nonlinearity(nonlinearity)
         cin = self.input_shape[1]
-        self.W = self.add_param(W or _init.GlorotUniform(), (self.num_filters, cin) + self.filter_size, "W", 'conv_w')
-        self.b = self.add_param(b or _init.Constant(0.), (self.num_filters,), "b", 'vec', regularizable=False)
+        self.W = self.add_param(_w_spec(W), (self.num_filters, cin) + self.filter_size, "W", 'conv_w')
+        self.b = self.add_param(_b_spec(b), (self.num_filters,), "b", 'vec', regularizable=False)
 
     def get_output_shape_for(self, s):
         h = (s[2] + 2 * self.pad[0] - self.filter_size[0]) // self.stride[0] + 1
@@ -163,7 +178,7 @@ class TransposedConv2DLayer(Layer):
     """lasagne Deconv2DLayer: W[C_in, num_filters, kh, kw], crop=0, flip_filters=False; output size
     (in-1)*stride + k - 2*crop; exact adjoint of Conv2DLayer's true convolution."""
 
-    def __init__(self, incoming, num_filters, filter_size, stride=(1, 1), crop=0, W=None, b=None,
+    def __init__(self, incoming, num_filters, filter_size, stride=(1, 1), crop=0, W=_DEFAULT, b=_DEFAULT,
                  nonlinearity=rectify, name=None):
         Layer.__init__(self, incoming, name)
         self.num_filters = int(num_filters)
@@ -174,8 +189,8 @@ class TransposedConv2DLayer(Layer):
             raise NotImplementedError("crop != 0 / anisotropic stride")
         self.nonlinearity = as_nonlinearity(nonlinearity)
         cin = self.input_shape[1]
-        self.W = self.add_param(W or _init.GlorotUniform(), (cin, self.num_filters) + self.filter_size, "W", 'conv_w')
-        self.b = self.add_param(b or _init.Constant(0.), (self.num_filters,), "b", 'vec', regularizable=False)
+        self.W = self.add_param(_w_spec(W), (cin, self.num_filters) + self.filter_size, "W", 'conv_w')
+        self.b = self.add_param(_b_spec(b), (self.num_filters,), "b", 'vec', regularizable=False)
 
     def get_output_shape_for(self, s):
         h = (s[2] - 1) * self.stride[0] + self.filter_size[0]

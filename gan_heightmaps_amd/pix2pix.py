@@ -17,9 +17,25 @@ from . import layers as L
 from .device import Device
 from .step import GanStep, TRAIN_KEYS
 from .updates import adam, shared, OptimizerSpec
-from .util import convert_to_rgb, imsave, plot_grid
+from .util import convert_to_rgb, imsave, makedirs, plot_grid, writes as util_writes
 
 floatX = _init.floatX
+
+
+class _Py2CompatPickler(pickle._Pickler):
+    """numpy >= 2 pickles an ndarray through the global ``numpy._core.multiarray._reconstruct``; the reference's
+    environment (Python 2, numpy <= 1.16) only has ``numpy.core.multiarray``, which every numpy up to 2.x still
+    resolves.  Write that spelling so a checkpoint saved here loads in the reference (pix2pix.py:174-186)."""
+
+    def save_global(self, obj, name=None):
+        mod = getattr(obj, '__module__', None) or ''
+        if mod.startswith('numpy._core'):
+            nm = name or getattr(obj, '__qualname__', obj.__name__)
+            self.write(pickle.GLOBAL + ('numpy.core' + mod[len('numpy._core'):]).encode() + b'\n' +
+                       nm.encode() + b'\n')
+            self.memoize(obj)
+            return
+        pickle._Pickler.save_global(self, obj, name)
 
 
 class Pix2Pix:
@@ -75,12 +91,17 @@ class Pix2Pix:
         if not isinstance(spec, OptimizerSpec):
             raise TypeError("opt must be gan_heightmaps_amd.updates.rmsprop or .adam")
         self.lr = opt_args['learning_rate'] if 'learning_rate' in opt_args else spec.learning_rate
-        self.device = device if device is not None else Device(0)
+        if device is None:
+            # one process per GPU: the launcher's LOCAL_RANK names this process' device (a communicator brings its own)
+            device = Device(comm.dev.index) if comm is not None else Device(int(os.environ.get("LOCAL_RANK", "0")))
+        self.device = device
+        self.comm = comm
         self.engine = GanStep(self.device, dcgan_gen, dcgan_disc, p2p_gen, p2p_disc, alpha, lsgan, reconstruction,
                               spec, train_mode, comm=comm, use_graph=use_graph, two_streams=two_streams,
                               force_exchange=force_exchange, side_streams=side_streams)
         self.train_keys = list(TRAIN_KEYS)
         eng = self.engine
+        eng.broadcast_parameters()          # replicas start from rank 0's (possibly unseeded) initial weights
         self.train_fn = lambda Z, X, Y: eng.train(floatX(Z), floatX(X), floatX(Y))
         self.loss_fn = lambda Z, X, Y: eng.loss(floatX(Z), floatX(X), floatX(Y))
         self.gen_fn = lambda X: eng.generate('p2p_gen', X, False)
@@ -88,15 +109,23 @@ class Pix2Pix:
         self.z_fn = lambda Z: eng.generate('dcgan_gen', Z, False)
         self.z_fn_det = lambda Z: eng.generate('dcgan_gen', Z, True)
 
+    def _is_writer(self):
+        """files (results.txt, PNG dumps, checkpoints) are written by rank 0 only; every rank still runs the
+        forward passes and iterator draws of the per-epoch dumps, which are part of the training trajectory"""
+        comm = getattr(self, 'comm', None)
+        return comm is None or comm.rank == 0
+
     # ---- checkpoint (pix2pix.py:158-186): gzip + pickle of get_all_param_values per net -------------------
     def save_model(self, filename):
+        if not self._is_writer():
+            return
         with gzip.open(filename, "wb") as g:
-            pickle.dump({
+            _Py2CompatPickler(g, 2).dump({      # protocol 2 == py2 HIGHEST_PROTOCOL, readable by the reference
                 'dcgan': {'gen': L.get_all_param_values(self.dcgan['gen']),
                           'disc': L.get_all_param_values(self.dcgan['disc'])},
                 'p2p': {'gen': L.get_all_param_values(self.p2p['gen']),
                         'disc': L.get_all_param_values(self.p2p['disc'])}
-            }, g, 2)        # protocol 2 == py2 HIGHEST_PROTOCOL, readable by the reference
+            })
 
     def load_model(self, filename, mode='both'):
         assert mode in ['both', 'dcgan', 'p2p']
@@ -141,10 +170,12 @@ class Pix2Pix:
 
         header = ["epoch"] + ["train_%s" % k for k in self.train_keys] + ["valid_%s" % k for k in self.train_keys] \
             + ["lr", "time", "mode"]
-        os.makedirs(out_dir, exist_ok=True)
-        if model_dir is not None:
-            os.makedirs(model_dir, exist_ok=True)
-        f = open("%s/results.txt" % out_dir, "w" if not resume else "a")
+        writer = self._is_writer()
+        if writer:
+            os.makedirs(out_dir, exist_ok=True)
+            if model_dir is not None:
+                os.makedirs(model_dir, exist_ok=True)
+        f = open("%s/results.txt" % out_dir if writer else os.devnull, "w" if not resume else "a")
         if not resume:
             f.write(",".join(header) + "\n")
             f.flush()
@@ -167,14 +198,15 @@ class Pix2Pix:
             f.write(line + "\n")
             f.flush()
             if dump_images:
-                if self.train_mode in ['both', 'p2p']:
-                    plot_grid("%s/out_%i.png" % (out_dir, e + 1), it_val, self.gen_fn,
-                              is_a_grayscale=self.is_a_grayscale, is_b_grayscale=self.is_b_grayscale)
-                    self.generate_atob(it_train, 1, "%s/dump_train" % out_dir, deterministic=False)
-                    self.generate_atob(it_val, 1, "%s/dump_valid" % out_dir, deterministic=False)
-                if self.train_mode in ['both', 'dcgan']:
-                    self.generate_gz(num_examples=20, batch_size=batch_size, out_dir="%s/dump_a" % out_dir,
-                                     deterministic=False)
+                with util_writes(writer):
+                    if self.train_mode in ['both', 'p2p']:
+                        plot_grid("%s/out_%i.png" % (out_dir, e + 1), it_val, self.gen_fn,
+                                  is_a_grayscale=self.is_a_grayscale, is_b_grayscale=self.is_b_grayscale)
+                        self.generate_atob(it_train, 1, "%s/dump_train" % out_dir, deterministic=False)
+                        self.generate_atob(it_val, 1, "%s/dump_valid" % out_dir, deterministic=False)
+                    if self.train_mode in ['both', 'dcgan']:
+                        self.generate_gz(num_examples=20, batch_size=batch_size, out_dir="%s/dump_a" % out_dir,
+                                         deterministic=False)
             if model_dir is not None and (e + 1) % save_every == 0:
                 self.save_model("%s/%i.model" % (model_dir, e + 1))
         f.close()
@@ -189,7 +221,7 @@ class Pix2Pix:
         ``<ctr>.a.png`` (the input A) and ``<ctr>.b.png`` (U(A), or the iterator's own B when
         ``dont_predict``)."""
         fn = self.gen_fn_det if deterministic else self.gen_fn
-        os.makedirs(out_dir, exist_ok=True)
+        makedirs(out_dir)
         ctr = 0
         for _ in range(num_batches):
             this_x, this_y = self._next(itr)
@@ -202,7 +234,7 @@ class Pix2Pix:
     def generate_gz(self, num_examples, batch_size, out_dir, deterministic=True):
         """DCGAN samples g(z) (pix2pix.py:306-326): one draw of ``sampler(num_examples, latent_dim)``,
         ``num_examples // batch_size`` forward passes, ``<ctr>.png`` each."""
-        os.makedirs(out_dir, exist_ok=True)
+        makedirs(out_dir)
         fn = self.z_fn_det if deterministic else self.z_fn
         z = floatX(self.sampler(num_examples, self.latent_dim))
         ctr = 0

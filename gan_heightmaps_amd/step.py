@@ -18,7 +18,7 @@ big convolutions.
 import numpy as np
 
 from . import layers as L
-from .device import Device, Ops
+from .device import Ops
 from .engine import NetPlan, ParamStore
 
 TRAIN_KEYS = ['dcgan_gen', 'dcgan_disc', 'p2p_gen', 'p2p_recon', 'p2p_disc']
@@ -55,15 +55,17 @@ class GanStep:
             side_streams = (not use_graph) and two_streams
         if side_streams and use_graph:
             raise ValueError("side_streams needs use_graph=False")
-        self.devs = [dev, Device(dev.index) if two_streams else dev]
-        self.ops = [Ops(self.devs[0]), Ops(self.devs[1])]
+        mk = type(dev)                      # second / side streams are further contexts of the same kind on this GPU
+        mkops = getattr(dev, 'ops_class', Ops)
+        self.devs = [dev, mk(dev.index) if two_streams else dev]
+        self.ops = [mkops(self.devs[0]), mkops(self.devs[1])]
         # optional second stream per stage for the weight / bias gradients (engine.NetPlan side=)
         self.side = [None, None]
         if side_streams:
-            sd = [Device(dev.index), Device(dev.index) if two_streams else None]
+            sd = [mk(dev.index), mk(dev.index) if two_streams else None]
             if sd[1] is None:
                 sd[1] = sd[0]
-            self.side = [(sd[0], Ops(sd[0])), (sd[1], Ops(sd[1]))]
+            self.side = [(sd[0], mkops(sd[0])), (sd[1], mkops(sd[1]))]
         self.nets = {'dcgan_gen': dcgan_gen, 'dcgan_disc': dcgan_disc, 'p2p_gen': p2p_gen,
                      'p2p_disc': p2p_disc["out"]}
         self.p2p_disc_inputs = p2p_disc["inputs"]
@@ -71,6 +73,15 @@ class GanStep:
         self.opt_spec, self.train_mode = opt_spec, train_mode
         self.comm = comm
         self.world = comm.world if comm is not None else 1
+        self.rank = comm.rank if comm is not None else 0
+        # the communicator's context is the COMMUNICATION stream: a Comm made on its own Device of the same GPU lets
+        # the bucket all-reduces run beside the rest of the backward pass; a Comm made on ``dev`` itself serialises
+        # them on stream A.  Either way it must be this GPU, or every rank would reduce somebody else's buffers.
+        self.cdev = comm.dev if comm is not None else None
+        self.cops = getattr(self.cdev, 'ops_class', Ops)(self.cdev) if comm is not None else None
+        if comm is not None and getattr(comm.dev, 'index', None) != getattr(dev, 'index', None):
+            raise ValueError("comm was initialised on device %r, the step runs on device %r"
+                             % (getattr(comm.dev, 'index', None), getattr(dev, 'index', None)))
         # data-parallel code path (stream hand-over, RCCL all-reduce, updates on stream A) even with one rank:
         # lets a single-GPU box exercise exactly what N ranks run
         self.exchange = self.world > 1 or (force_exchange and comm is not None)
@@ -100,6 +111,44 @@ class GanStep:
         self.devs[0].sync()
         if self.devs[1] is not self.devs[0]:
             self.devs[1].sync()
+        if self.cdev is not None and self.cdev is not self.devs[0]:
+            self.cdev.sync()
+
+    def broadcast_parameters(self, root=0):
+        """Make every replica start from rank ``root``'s parameters, BatchNorm state and optimiser state (the
+        reference never seeds lasagne's RNG -- SURVEY Appendix A.9 -- so unseeded ranks would otherwise train
+        different weights with averaged gradients).  A broadcast is an all-reduce whose other contributions are
+        zero: exact, and it needs no further collective in the C ABI."""
+        if self.comm is None or self.world == 1:
+            return
+        self.sync()
+        for k in ('dcgan_gen', 'dcgan_disc', 'p2p_gen', 'p2p_disc'):
+            st = self.stores[k]
+            bufs = [(st.w, st.n_train), (st.s, st.n_state)] + [(t, st.n_train) for _, t in sorted(st.opt_state.items())]
+            bufs.append((self.hyper[k], 2))
+            for t, n in bufs:
+                if n <= 0:
+                    continue
+                if self.rank != root:
+                    self.cdev.memset_zero(t.ptr, 4 * n)
+                self.cops.allreduce_sum(t, n)
+        self.sync()
+
+    def replica_checksums(self):
+        """(min, max) over the ranks of a CRC of every parameter / state buffer: equal on healthy replicas."""
+        import zlib
+        self.sync()
+        crc = 0
+        for k in ('dcgan_gen', 'dcgan_disc', 'p2p_gen', 'p2p_disc'):
+            st = self.stores[k]
+            for t in (st.w, st.s):
+                crc = zlib.crc32(t.numpy().tobytes(), crc)
+        if self.comm is None or self.world == 1:
+            return crc, crc
+        lo16, hi16 = float(crc & 0xffff), float(crc >> 16)          # exactly representable in fp32
+        mx = (self.comm.max_scalar(hi16), self.comm.max_scalar(lo16))
+        mn = (-self.comm.max_scalar(-hi16), -self.comm.max_scalar(-lo16))
+        return (int(mn[0]) << 16 | int(mn[1])), (int(mx[0]) << 16 | int(mx[1]))
 
     def set_lr(self, lr):
         self.sync()
@@ -120,14 +169,14 @@ class GanStep:
         ca, H, W = d_in_layer.shape[1:]
         b.d_in = dA.empty((2 * B, ca, H, W))
         b.G = NetPlan(dA, oA, G, B, self.stores['dcgan_gen'], out_tensor=b.d_in.samples(B, 2 * B), name="G",
-                      side=self.side[0])
+                      side=self.side[0], rng_seed=self.rank)      # replicas draw different dropout masks
         b.D = NetPlan(dA, oA, D, 2 * B, self.stores['dcgan_disc'], inputs={d_in_layer: b.d_in}, name="D",
                       side=self.side[0], bn_groups=2 if _has_bn(D) else 1)
         b.P = NetPlan(dB, oB, P, 2 * B, self.stores['p2p_disc'], name="P", side=self.side[1],
                       bn_groups=2 if _has_bn(P) else 1)
         pa, pb = b.P.input_tensor(i_a), b.P.input_tensor(i_b)
         b.U = NetPlan(dB, oB, U, B, self.stores['p2p_gen'], out_tensor=pb.samples(B, 2 * B), name="U",
-                      side=self.side[1])
+                      side=self.side[1], rng_seed=self.rank)
         b.z = b.G.input_nodes[0].out
         b.x = b.U.input_tensor(u_in_layer)
         b.y = dB.empty((B,) + tuple(pb.shape[1:]))
@@ -181,47 +230,94 @@ class GanStep:
         do_dcgan = self.train_mode in ('both', 'dcgan')
         do_p2p = self.train_mode in ('both', 'p2p')
         tdone = set()      # conv weights whose transposed copy is already fresh in this program
+        # ---- data-parallel exchange (no reference counterpart) ----
+        # One all-reduce per net bucket on the COMMUNICATION stream (the communicator's context), enqueued where the
+        # bucket's last gradient kernel has been issued: the discriminator buckets reduce under the generator's
+        # backward pass, the DCGAN buckets under the pix2pix stage.  The communication stream waits for the streams
+        # that wrote the bucket (events recorded at this point of the program), the collectives run in host-enqueue
+        # order, and that order is a pure function of the program -- identical on every rank.
+        cdev, cops = self.cdev, self.cops
+        embed = self.exchange and not self.use_graph          # RCCL calls stay outside captured graphs
+        b.xchg = {}
+
+        def xchg(k, lane):
+            st = self.stores[k]
+            srcs = [self.devs[lane]] + ([self.side[lane][0]] if self.side[lane] is not None else [])
+
+            def fn():
+                for d in srcs:
+                    cdev.wait_for(d)
+                cops.allreduce_sum(st.g, st.n_train)
+            b.xchg[k] = ("allreduce_" + k, fn, None, cdev)
+            return b.xchg[k]
+
         if do_dcgan:
             b.D.emit_transposes(ta, tdone)
             b.G.emit_transposes(ta, tdone)
             b.D.emit_backward(ta, b.seed_D, wgrad=True, tag="dloss", transposed=tdone)
+            if self.exchange:
+                e = xchg('dcgan_disc', 0)
+                if embed:
+                    ta.append(e)
             gin = b.D.emit_backward(ta, b.seed_G, nslice=(B, 2 * B), wgrad=False, input_grads=[d_in_layer],
                                     tag="gloss", transposed=tdone)
             b.G.emit_backward(ta, gin[d_in_layer], wgrad=True, transposed=tdone)
+            if self.exchange:
+                e = xchg('dcgan_gen', 0)
+                if embed:
+                    ta.append(e)
         if do_p2p:
             b.P.emit_transposes(tb, tdone)
             b.U.emit_transposes(tb, tdone)
             b.P.emit_backward(tb, b.seed_PD, wgrad=True, tag="dloss", transposed=tdone)
+            if self.exchange:
+                e = xchg('p2p_disc', 1)
+                if embed:
+                    tb.append(e)
             gin = b.P.emit_backward(tb, b.seed_PG, nslice=(B, 2 * B), wgrad=False, input_grads=[i_b], tag="gloss",
                                     transposed=tdone)
             gu = gin[i_b]
             # (:115-117) recon loss and alpha * d recon / d U(X) added to the adversarial gradient
             tb.append(("recon", lambda: oB.recon_loss(b.U.out, b.y, slot(3), gu, self.alpha, l2, True)))
             b.U.emit_backward(tb, gu, wgrad=True, transposed=tdone)
+            if self.exchange:
+                e = xchg('p2p_gen', 1)
+                if embed:
+                    tb.append(e)
         else:
             tb.append(("recon", lambda: oB.recon_loss(b.U.out, b.y, slot(3), None, 1.0, l2)))
         if self.side[0] is not None:        # the gradient streams rejoin before anything consumes the gradients
             ta.append(("join", lambda: dA.wait_for(self.side[0][0])))
             tb.append(("join", lambda: dB.wait_for(self.side[1][0])))
         b.train_compute = [ta, tb]
-        # ---- exchange + update (:131-141) ----
+        # ---- after both stage programs: (graph mode: the bucket all-reduces, in a fixed order), the losses, then
+        # the stage streams wait for the communication stream and apply their own nets' updates (:131-141) ----
         keys = (['dcgan_gen', 'dcgan_disc'] if do_dcgan else []) + (['p2p_gen', 'p2p_disc'] if do_p2p else [])
         b.exchange = []
         if self.exchange:
-            # one communicator, every collective on stream A in one fixed order on all ranks: the DCGAN buckets
-            # (stream A's own work, ready in stream order) go first and overlap the tail of the pix2pix stream;
-            # then stream A waits for stream B, sums the pix2pix buckets and the losses, updates everything,
-            # and stream B continues behind it
-            for k in keys:
-                st = self.stores[k]
-                b.exchange.append(("allreduce_" + k, lambda st=st: oA.allreduce_sum(st.g, st.n_train), LANE_OF[k]))
-            b.exchange.append(("allreduce_losses", lambda: oA.allreduce_sum(lo, 8), 1))
+            if not embed:
+                for k in ('dcgan_disc', 'dcgan_gen', 'p2p_disc', 'p2p_gen'):
+                    if k in b.xchg:
+                        b.exchange.append(b.xchg[k])
+
+            def reduce_losses():
+                cdev.wait_for(dA)
+                if dB is not dA:
+                    cdev.wait_for(dB)
+                cops.allreduce_sum(lo, 8)
+            b.exchange.append(("allreduce_losses", reduce_losses, None, cdev))
+
+            def rejoin():
+                dA.wait_for(cdev)
+                if dB is not dA:
+                    dB.wait_for(cdev)
+            b.exchange.append(("wait_comm", rejoin, None, cdev))
         gs = 1.0 / self.world
         hp = self.opt_spec.hp
         b.update = [[], []]
         for k in keys:
             st, hy = self.stores[k], self.hyper[k]
-            lane = 0 if self.exchange else LANE_OF[k]
+            lane = LANE_OF[k]
             o = self.ops[lane]
             if self.opt_spec.kind == 'rmsprop':
                 b.update[lane].append(("rmsprop_" + k, lambda st=st, hy=hy, o=o: o.rmsprop(
@@ -311,58 +407,55 @@ class GanStep:
         else:
             self._run_lanes(b, 'loss', b.loss_prog)
             if self.exchange:
-                self.sync()
-                self.ops[0].allreduce_sum(self.losses_dev, 8)
+                self._reduce_losses_now()
         return self._read_losses()
 
     def enqueue_train(self, b, wrap=None):
         """one train step on the data already resident in b.z / b.x / b.y (asynchronous)"""
-        dA, dB = self.devs
         if self.exchange:
-            self._run_lanes(b, 'train_compute', b.train_compute, wrap)
-            for e in b.exchange:                            # RCCL calls stay outside the captured graphs
-                if e[2] == 0:
-                    e[1]()
-            if dB is not dA:
-                dA.wait_for(dB)
+            self._run_lanes(b, 'train_compute', b.train_compute, wrap)     # eager: bucket all-reduces are inside
             for e in b.exchange:
-                if e[2] != 0:
-                    e[1]()
+                e[1]()
             self._run_lanes(b, 'train_update', b.update, wrap)
-            if dB is not dA:
-                dB.wait_for(dA)
         else:
             if not hasattr(b, 'train_all'):
                 b.train_all = [b.train_compute[0] + b.update[0], b.train_compute[1] + b.update[1]]
             self._run_lanes(b, 'train_all', b.train_all, wrap)
+
+    def _reduce_losses_now(self):
+        self.sync()
+        self.cops.allreduce_sum(self.losses_dev, 8)
 
     def loss(self, Z, X, Y):
         b = self.built(int(np.shape(X)[0]))
         self._upload(b, Z, X, Y)
         self._run_lanes(b, 'loss', b.loss_prog)
         if self.exchange:
-            self.sync()
-            self.ops[0].allreduce_sum(self.losses_dev, 8)
+            self._reduce_losses_now()
         return self._read_losses()
 
     def profile_train(self, B):
         """[(label, ms, meta)] per program entry, stream by stream (synchronising; mutates parameters like a
-        real step)."""
+        real step: compute, then the exchange, then the updates)."""
         b = self.built(B)
         out = []
-        for lane in (0, 1):
-            dev = self.devs[lane]
-            for e in b.train_compute[lane] + b.update[lane]:
+
+        def timed(entries, dev):
+            for e in entries:
                 d = e[3] if len(e) > 3 and e[3] is not None else dev
                 d.timer_start(1)
                 e[1]()
                 d.timer_stop(1)
                 out.append((e[0], d.timer_ms(1), e[2] if len(e) > 2 else None))
+
+        for lane in (0, 1):
+            timed(b.train_compute[lane], self.devs[lane])
         if self.exchange:
             self.sync()
-            for e in b.exchange:
-                e[1]()
+            timed(b.exchange, self.cdev)
             self.sync()
+        for lane in (0, 1):
+            timed(b.update[lane], self.devs[lane])
         return out
 
     # ---- forward-only entry points (pix2pix.py:144-147) -------------------------------------------------

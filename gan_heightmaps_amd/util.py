@@ -38,6 +38,28 @@ def compose_imgs(a, b, is_a_grayscale=True, is_b_grayscale=False):
     return np.concatenate([left, right], axis=1).astype(np.float64)
 
 
+_WRITES = [True]
+
+
+class writes:
+    """``with writes(False):`` -- imsave / plot_grid / makedirs below do everything but touch the file system
+    (data-parallel ranks other than 0 still draw the batches and run the forward passes of the per-epoch dumps)."""
+
+    def __init__(self, enabled):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        _WRITES.append(self.enabled and _WRITES[-1])
+
+    def __exit__(self, *exc):
+        _WRITES.pop()
+
+
+def makedirs(d):
+    if _WRITES[-1]:
+        os.makedirs(d, exist_ok=True)
+
+
 def to_uint8(img01):
     """float [0,1] -> uint8 the way skimage's img_as_ubyte does (round half to even of 255*x)"""
     return np.rint(np.clip(np.asarray(img01, np.float64), 0, 1) * 255.0).astype(np.uint8)
@@ -45,6 +67,8 @@ def to_uint8(img01):
 
 def imsave(fname, arr):
     """PNG writer standing in for skimage.io.imsave(fname=..., arr=...) at pix2pix.py:303-304,325,418-422."""
+    if not _WRITES[-1]:
+        return
     from PIL import Image
     arr = np.asarray(arr)
     if arr.dtype != np.uint8:
@@ -74,5 +98,6 @@ def plot_grid(out_filename, itr, out_fn, is_a_grayscale, is_b_grayscale, N=4):
         ax = fig.add_subplot(N, N, cell + 1)
         ax.imshow(compose_imgs(a[0], shown[0], is_a_grayscale=is_a_grayscale, is_b_grayscale=is_b_grayscale))
         ax.axis('off')
-    fig.savefig(out_filename)
+    if _WRITES[-1]:
+        fig.savefig(out_filename)
     plt.close('all')

@@ -6,8 +6,9 @@ from gan_heightmaps_amd.device import DevTensor
 
 
 class FakeDevice:
-    def __init__(self):
+    def __init__(self, index=0):
         self.h = None
+        self.index = index
         self._next = 1 << 20
         self.bytes_allocated = 0
         self.uploads = 0
@@ -45,6 +46,9 @@ class FakeDevice:
     def sync(self):
         pass
 
+    def wait_for(self, other):
+        pass
+
 
 class RecordingOps:
     def __init__(self, dev):
@@ -67,3 +71,119 @@ class RecordingOps:
         def rec(*args, **kw):
             self.calls.append((name, args, kw))
         return rec
+
+
+FakeDevice.ops_class = RecordingOps
+
+
+# ---- a host-memory device: allocations are numpy arrays, and the handful of ops a data-parallel exchange needs do
+# ---- arithmetic (all-reduce through torch.distributed/gloo, the optimiser update, memset); every other op is
+# ---- recorded only.  Contexts made by ``type(dev)(index)`` share one arena and one host-order event log, like HIP
+# ---- streams of one GPU share its memory.  Use ``host_device_class()`` for a fresh arena per test.
+def host_device_class():
+    import bisect
+
+    class Shared:
+        bases, arrays, log, nctx = [], {}, [], 0
+
+    class HostOps:
+        def __init__(self, dev):
+            self.dev = dev
+
+        def bn_workspace(self, C):
+            return 1024
+
+        def wgrad_workspace(self, d):
+            return 1024
+
+        def dgrad_t_supported(self, d):
+            return d.stride == 1
+
+        def conv_variant(self, d, kind):
+            return "host<%d>" % kind
+
+        def transpose_table(self, items):
+            return (0, len(items), 0)
+
+        def allreduce_sum(self, buf, n):
+            import torch
+            import torch.distributed as tdist
+            v = self.dev.view(buf.ptr, n)
+            t = torch.from_numpy(v)
+            tdist.all_reduce(t)
+            Shared.log.append((self.dev.name, "allreduce_sum", int(buf.ptr), int(n)))
+
+        def rmsprop(self, p, g, acc, n, hyper, rho=0.9, eps=1e-6, grad_scale=1.0):
+            pv, gv, av = (self.dev.view(t.ptr, n) for t in (p, g, acc))
+            lr = self.dev.view(hyper.ptr, 1)[0]
+            gs = gv * np.float32(grad_scale)
+            av[:] = np.float32(rho) * av + np.float32(1 - rho) * gs * gs        # lasagne.updates.rmsprop
+            pv[:] = pv - lr * gs / np.sqrt(av + np.float32(eps))
+            Shared.log.append((self.dev.name, "rmsprop", int(p.ptr), int(n)))
+
+        def __getattr__(self, name):
+            def rec(*args, **kw):
+                ptrs = tuple(int(a.ptr) for a in args if isinstance(a, DevTensor))
+                Shared.log.append((self.dev.name, name) + ptrs)
+            return rec
+
+    class HostDevice:
+        ops_class = HostOps
+        shared = Shared
+
+        def __init__(self, index=0):
+            self.h, self.index = None, index
+            self.name = "ctx%d" % Shared.nctx
+            Shared.nctx += 1
+            self.bytes_allocated = 0
+
+        def alloc(self, nbytes):
+            n = (int(max(nbytes, 16)) + 3) // 4
+            base = (Shared.bases[-1] + 4 * Shared.arrays[Shared.bases[-1]].size + 1024) if Shared.bases else 1 << 20
+            base = (base + 255) // 256 * 256
+            Shared.bases.append(base)
+            Shared.arrays[base] = np.zeros(n, np.float32)
+            self.bytes_allocated += nbytes
+            return base
+
+        def free(self, ptr):
+            pass
+
+        def view(self, ptr, n):
+            i = bisect.bisect_right(Shared.bases, ptr) - 1
+            base = Shared.bases[i]
+            off = (ptr - base) // 4
+            arr = Shared.arrays[base]
+            assert 0 <= off and off + n <= arr.size, "out-of-range host view"
+            return arr[off:off + n]
+
+        def empty(self, shape):
+            shape = tuple(int(s) for s in shape)
+            n = int(np.prod(shape))
+            return DevTensor(self, self.alloc(4 * n), shape if len(shape) in (2, 4) else (1, n, 1, 1))
+
+        zeros = empty
+
+        def tensor(self, arr):
+            arr = np.ascontiguousarray(arr, np.float32)
+            t = self.empty(arr.shape if arr.ndim in (2, 4) else (1, arr.size, 1, 1))
+            self.h2d(t.ptr, arr)
+            return t
+
+        def h2d(self, ptr, arr):
+            a = np.ascontiguousarray(arr).view(np.uint8).ravel()
+            self.view(ptr, (a.size + 3) // 4).view(np.uint8)[:a.size] = a
+
+        def d2h(self, arr, ptr, nbytes):
+            arr.reshape(-1).view(np.uint8)[:nbytes] = self.view(ptr, (nbytes + 3) // 4).view(np.uint8)[:nbytes]
+
+        def memset_zero(self, ptr, nbytes):
+            self.view(ptr, nbytes // 4)[:] = 0
+
+        def sync(self):
+            pass
+
+        def wait_for(self, other):
+            Shared.log.append((self.name, "wait_for", other.name))
+
+    return HostDevice

@@ -190,28 +190,53 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     assert rel(m2.loss_fn(Z, X, Y), m1.loss_fn(Z, X, Y)) < 1e-6
 
 
-def test_data_parallel_code_path_with_one_rank(dev):
-    """world=1 RCCL communicator + force_exchange: the exact N-rank sequence (stage streams -> stream A waits for
-    stream B -> one ncclAllReduce per net bucket on stream A -> all four optimiser kernels on stream A -> stream B
-    waits) must reproduce the single-process step bit for bit (sum over one rank, grad_scale 1)."""
-    from gan_heightmaps_amd import dist
+@pytest.mark.parametrize("mode", ["graph_comm_on_stream_a", "eager_comm_stream_overlap"])
+def test_data_parallel_code_path_with_one_rank(dev, mode):
+    """world=1 RCCL communicator + force_exchange: the exact N-rank program must reproduce the single-process step bit
+    for bit (a sum over one rank, grad_scale 1).
+    graph: the communicator lives on stream A; compute graphs, then one ncclAllReduce per net bucket + the losses,
+    then the update graphs.  eager: the communicator has its own context = a communication stream; each bucket's
+    all-reduce is enqueued inside the stage programs right after the bucket's last gradient kernel (event waits on
+    the stage and gradient streams), the stage streams wait for the communication stream before their updates."""
+    from gan_heightmaps_amd import device, dist
     cfg = ostep.default_cfg(**SMALL)
     Zs = [ostep.synthetic_batch(4, cfg, seed=40 + i) for i in range(3)]
     ref_model = build_model(cfg, 7, dev)
     ref = [ref_model.train_fn(*b) for b in Zs]
     ref_params = model_params(ref_model)
-    comm = dist.Comm(dev, 0, 1)
+    eager = mode.startswith("eager")
+    cdev = device.Device(dev.index) if eager else dev
+    comm = dist.Comm(cdev, 0, 1)
     try:
-        m = build_model(cfg, 7, dev, comm=comm, force_exchange=True)
-        assert m.engine.exchange and len(m.engine.built(4).exchange) == 5
-        got = [m.train_fn(*b) for b in Zs]          # eager, captured (compute / update graphs), replayed
+        m = build_model(cfg, 7, dev, comm=comm, force_exchange=True, use_graph=not eager)
+        b = m.engine.built(4)
+        assert m.engine.exchange and m.engine.cdev is cdev
+        labels = [e[0] for e in b.exchange]
+        inside = [e[0] for lane in b.train_compute for e in lane if e[0].startswith("allreduce_")]
+        if eager:
+            assert m.engine.side[0] is not None and len(inside) == 4 and labels == ["allreduce_losses", "wait_comm"]
+        else:
+            assert inside == [] and len(labels) == 6
+        got = [m.train_fn(*b_) for b_ in Zs]        # graph mode: eager, captured, replayed
         assert np.array_equal(np.asarray(got), np.asarray(ref))
         p = model_params(m)
         for key in ref_params:
-            for a, b in zip(p[key], ref_params[key]):
-                assert np.array_equal(a, b)
+            for a, b_ in zip(p[key], ref_params[key]):
+                assert np.array_equal(a, b_)
+        assert m.engine.replica_checksums()[0] == m.engine.replica_checksums()[1]
     finally:
         comm.close()
+        if eager:
+            cdev.close()
+
+
+def test_allreduce_without_a_communicator_is_an_error(dev):
+    """the C ABI has no identity shortcut: reducing on a context that has no communicator fails loudly
+    (a step whose gradients silently stayed local would still scale them by 1/world)"""
+    from gan_heightmaps_amd.device import Ops
+    t = dev.zeros((1, 8, 1, 1))
+    with pytest.raises(RuntimeError, match="communicator"):
+        Ops(dev).allreduce_sum(t, 8)
 
 
 def test_train_loop_with_device_iterator(dev, tmp_path):

@@ -67,6 +67,31 @@ def test_save_model_layout_equals_the_reference_layout(tmp_path):
                 assert np.array_equal(u, v) and u.dtype == v.dtype       # seed 123 on both sides
 
 
+def test_checkpoint_globals_resolve_in_the_reference_environment(tmp_path):
+    """The reference runs Python 2 with numpy <= 1.16: every pickle GLOBAL of a checkpoint written here must name a
+    module that exists there.  numpy >= 2 reduces an ndarray through numpy._core.multiarray._reconstruct, which does
+    not; save_model writes numpy.core.multiarray instead (valid in every numpy up to 2.x)."""
+    import gzip
+    import pickle
+    import pickletools
+    m = _model(seed=11)
+    m.save_model(str(tmp_path / "mine.model"))
+    raw = gzip.open(tmp_path / "mine.model").read()
+    globals_ = {arg for op, arg, _ in pickletools.genops(raw) if op.name == "GLOBAL"}
+    assert globals_ == {"numpy.core.multiarray _reconstruct", "numpy ndarray", "numpy dtype", "_codecs encode"}, globals_
+    assert raw[:2] == b"\x80\x02"                                     # protocol 2 == py2 HIGHEST_PROTOCOL
+    # what a stock numpy-2 pickle would have contained (the defect this guards against)
+    stock = {arg for op, arg, _ in pickletools.genops(pickle.dumps(np.zeros(2, np.float32), 2)) if op.name == "GLOBAL"}
+    if int(np.__version__.split(".")[0]) >= 2:
+        assert "numpy._core.multiarray _reconstruct" in stock
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        back = pickle.loads(raw, encoding="latin1")
+    for u, v in zip(back["p2p"]["gen"], L.get_all_param_values(m.p2p["gen"])):
+        assert np.array_equal(u, v) and u.dtype == v.dtype
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree only exists in the build container")
 def test_reference_load_model_reads_our_checkpoint(tmp_path):
     G = _gen()

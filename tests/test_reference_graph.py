@@ -107,8 +107,7 @@ def test_reference_experiment_script_runs_on_the_aliased_backend(monkeypatch, tm
     try:
         shim.install()
         monkeypatch.setattr(PP, "Device", lambda index=0: FakeDevice())
-        monkeypatch.setattr(ST, "Ops", RecordingOps)
-        monkeypatch.setattr(ST, "Device", lambda index=0: FakeDevice())
+        monkeypatch.setattr(ST, "Ops", RecordingOps)       # further contexts are made with type(dev): FakeDevice
         FakeDevice.index = 0
         built = {}
 
