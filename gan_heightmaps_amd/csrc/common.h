@@ -86,6 +86,9 @@ int thin_fanin_s2(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const f
                   float* dx, int act, float alpha, int accumulate);
 bool thin_wgrad_ok(const ghm_conv_desc* d, const float* x, const float* dy);
 int thin_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* dy, float* dwp, int accumulate);
+// split-K epilogue of a forward-form convolution: out = act(sum of S partial slices [S][R][N*H*W] + bias (+ out))
+int ghm_splitk_finish(ghm_ctx* ctx, const float* partial, int S, float* out, const float* bias, int N, int R, int H,
+                      int W, long out_nstride, int act, float alpha, int accumulate);
 // out[i] (+)= sum over S slices of part[s*split_stride + i], fixed order (conv_igemm.hip)
 int ghm_reduce_splits(ghm_ctx* ctx, const float* part, int S, long n, long split_stride, float* out, int accumulate);
 bool thin_fanin_s1_fwd_ok(const ghm_conv_desc* d);

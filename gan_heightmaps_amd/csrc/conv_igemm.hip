@@ -1670,6 +1670,18 @@ WVariant pick_wgrad(const ghm_conv_desc* d, int num_cu) {
 
 }  // namespace
 
+int ghm_splitk_finish(ghm_ctx* ctx, const float* partial, int S, float* out, const float* bias, int N, int R, int H,
+                      int W, long out_nstride, int act, float alpha, int accumulate) {
+    IgemmArgs e;
+    memset(&e, 0, sizeof(e));
+    e.partial = const_cast<float*>(partial); e.out = out; e.bias = bias; e.N = N; e.R = R;
+    e.Hout = H; e.Wout = W; e.out_nstride = out_nstride; e.Hs = H; e.Ws = W; e.os = 1;
+    e.act = act; e.alpha = alpha; e.accumulate = accumulate;
+    hipLaunchKernelGGL(igemm_splitk_epilogue, dim3(ceil_div((long)N * H * W * R, 256)), dim3(256), 0, ctx->stream, e, S);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
 int ghm_reduce_splits(ghm_ctx* ctx, const float* part, int S, long n, long split_stride, float* out, int accumulate) {
     hipLaunchKernelGGL(reduce_splits_kernel, dim3(ceil_div((n + 3) / 4, 256)), dim3(256), 0, ctx->stream, part, S, n,
                        split_stride, out, accumulate);

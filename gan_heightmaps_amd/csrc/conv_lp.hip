@@ -1,0 +1,1018 @@
+// Reduced-precision matrix-core convolutions for gfx950 (MI355X): bf16 or fp16 operands on
+// v_mfma_f32_32x32x16_{bf16,f16} (2.5 PFLOP/s dense peak, 16x the fp32 MFMA rate), fp32 accumulate, fp32 storage.
+//
+// BASELINE configs 4 / 5 (bf16 / fp16 joint step).  The reference computes in floatX=float32 (experiment.5.sh:5), so
+// this is an ADDITIONAL arithmetic mode of the same layers (Conv2DLayer: architectures/dcgan.py:22,42, p2p.py:20-21
+// and their gradients), never the default.  Rule (restated in oracle/lp.py): both operands of every convolution
+// product are rounded to bf16 / fp16 with round-to-nearest-even, products are exact, sums are fp32; activations,
+// gradients, BatchNorm, losses, master weights and the optimiser stay fp32 in HBM.
+//
+// Why the activations stay fp32 in HBM: every convolution of the step is followed by fp32 element-wise work
+// (BatchNorm statistics, pooling, losses) that wants the unrounded value, and with 9..25 taps of reuse per staged
+// element the conversion costs a few VALU instructions per 100 MFMA cycles.  So the kernels read the same NCHW fp32
+// tensors as the fp32 path and convert while staging to LDS:
+//   * activations / output gradients (MFMA "B" operand, lanes along pixels): a thread gathers the 8 channels of one
+//     pixel (8 dword loads, each coalesced over the pixels of the wave), packs them with v_cvt_pk_*_f32 into one
+//     16-byte LDS unit -> the LDS patch is [8-channel block][row][col][8 ch], and a B fragment (8 consecutive k for
+//     one pixel) is ONE conflict-free ds_read_b128 at a compile-time offset per tap, as in the fp32 patch kernel;
+//   * weights (MFMA "A" operand): packed once per step into wq[c/8][tap][r][8 ch] (ghm_lp_pack_weights), so that a
+//     slab's rows are contiguous 16-byte units and go global -> LDS by DMA (global_load_lds, 16 B per lane);
+//   * weight gradient: the contraction runs over pixels, so 8 consecutive pixels of one channel are the 16-byte unit;
+//     they ARE contiguous in NCHW, so a thread loads an aligned window of 16 (stride 2: 24) floats once and emits the
+//     k shifted copies (one per filter column) the (channel, tap) rows need -- the im2col tile exists only in LDS.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <int DT>
+struct Lp;
+template <>
+struct Lp<GHM_DTYPE_BF16> {
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        f32x2 v = {a, b};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));     // v_cvt_pk_bf16_f32 (RNE)
+    }
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <>
+struct Lp<GHM_DTYPE_F16> {
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        f32x2 v = {a, b};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));      // v_cvt_pk_f16_f32 (RNE)
+    }
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+template <int DT>
+__device__ __forceinline__ u32x4 lp_pack8(const float* v) {
+    u32x4 w;
+    w.x = Lp<DT>::pack2(v[0], v[1]);
+    w.y = Lp<DT>::pack2(v[2], v[3]);
+    w.z = Lp<DT>::pack2(v[4], v[5]);
+    w.w = Lp<DT>::pack2(v[6], v[7]);
+    return w;
+}
+
+__device__ __forceinline__ int lp_xcd_remap(int bid, int nb) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: fp32 packed wp[c][tap][r]  ->  wq[c/8][tap][r (padded to 128)][8 ch]  (16-byte units)
+//   transposed = 0: the forward operand (reduction over the conv's input channels c, rows = filters)
+//   transposed = 1: the data-gradient operand wqT[k/8][T-1-tap][c (padded)][8 k] = wp[c][tap][k]
+//                   (reduction over the filters k, rows = input channels, taps flipped: the adjoint convolution)
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void lp_pack_kernel(const float* __restrict__ wp, u32x4* __restrict__ wq, int C, int T,
+                                                      int R, int nblk, int Rpad) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)nblk * T * Rpad) return;
+    const int r = (int)(idx % Rpad);
+    const long bt = idx / Rpad;
+    const int tap = (int)(bt % T), cb = (int)(bt / T);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cb * 8 + j;
+        v[j] = (c < C && r < R) ? wp[((long)c * T + tap) * R + r] : 0.f;
+    }
+    wq[idx] = lp_pack8<DT>(v);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void lp_pack_t_kernel(const float* __restrict__ wp, u32x4* __restrict__ wq, int C, int T,
+                                                        int K, int nblk, int Cpad) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)nblk * T * Cpad) return;
+    const int c = (int)(idx % Cpad);
+    const long bt = idx / Cpad;
+    const int tapT = (int)(bt % T), kb = (int)(bt / T);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = kb * 8 + j;
+        v[j] = (c < C && k < K) ? wp[((long)c * T + (T - 1 - tapT)) * K + k] : 0.f;
+    }
+    wq[idx] = lp_pack8<DT>(v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward-form convolution (forward pass; stride-1 data gradient on the transposed pack; 3x3 stride-2 forward).
+// A block owns BM output channels x (RT rows x 32 columns) of one image.  K loop: slabs of 16 input channels; inside
+// a slab one iteration per filter ROW a (KS k-steps, one per filter column b, each a 16-deep MFMA):
+//   weights of (slab, a): [2 ch-blocks][KS][BM] 16-byte units by DMA, double-buffered, issued one iteration ahead;
+//   input patch of the slab: [2 ch-blocks][PH][PW] units, gathered + converted through registers during the slab's
+//   first iteration into the other patch buffer.
+// Accumulators: TM x TN tiles of 32 x 32 (rows = channels, columns = 32 pixels of one row).
+// ------------------------------------------------------------------------------------------------
+struct LpConvArgs {
+    const float* in;
+    const u32x4* wq;
+    const float* bias;
+    float* out;
+    float* partial;
+    int N, CH, H, W;       // OUTPUT grid
+    int Hin, Win;
+    long in_nstride;
+    int R, Rpad;
+    long out_nstride;
+    int pad, act;
+    float alpha;
+    int accumulate;
+    int slabs_per_split;
+};
+
+template <int DT, int KS, int ST, int BM, int RT, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
+    constexpr int T = KS * KS;
+    constexpr int TM = BM / (WM * 32), TN = RT / WN;
+    constexpr int PH = (RT - 1) * ST + KS, PW = 31 * ST + KS;
+    constexpr int PUNITS = 2 * PH * PW;
+    constexpr int WUNITS = 2 * KS * BM;
+    constexpr int NQ = (PUNITS + 255) / 256;
+    constexpr int NI = WUNITS / 64;                 // DMA wave-instructions per weight tile
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
+    __shared__ __attribute__((aligned(16))) u32x4 smem[2 * WUNITS + 2 * PUNITS];
+    u32x4* const Wl = smem;
+    u32x4* const Pl = smem + 2 * WUNITS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int kg = lane >> 5, li = lane & 31;
+    const int ntr = (a.R + BM - 1) / BM;
+    const int tiles_x = a.W / 32, tiles_y = a.H / RT;
+    int L = lp_xcd_remap(blockIdx.x, gridDim.x);
+    const int r0 = (L % ntr) * BM;
+    L /= ntr;
+    const int tx = L % tiles_x;
+    L /= tiles_x;
+    const int ty = L % tiles_y;
+    const int n = L / tiles_y;
+    const int y0 = ty * RT, x0 = tx * 32;
+    const int HW = a.H * a.W, HWin = a.Hin * a.Win;
+    const int nslabs = a.CH / 16;
+    const int s_begin = blockIdx.y * a.slabs_per_split;
+    const int s_end = min(nslabs, s_begin + a.slabs_per_split);
+
+    // ---- patch gather: item e = (channel block, patch row, patch column); 8 channel planes per item ----
+    int p_off[NQ];
+    unsigned pmask = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = tid + q * 256;
+        const int cb = e / (PH * PW), rem = e - cb * (PH * PW);
+        const int py = rem / PW, px = rem - py * PW;
+        const int y = y0 * ST + py - a.pad, x = x0 * ST + px - a.pad;
+        const bool ok = e < PUNITS && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
+        p_off[q] = ok ? cb * 8 * HWin + y * a.Win + x : 0;
+        pmask |= (ok ? 1u : 0u) << q;
+    }
+    const float* ibase = a.in + (long)n * a.in_nstride + (long)s_begin * 16 * HWin;
+    float pv[NQ][8];
+    auto load_patch = [&]() {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float* g = ibase + p_off[q];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[q][j] = g[(long)j * HWin];
+        }
+        ibase += (long)16 * HWin;
+    };
+    auto store_patch = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tid + q * 256;
+            if (!((pmask >> q) & 1u)) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[q][j] = 0.f;
+            }
+            if (e < PUNITS) Pl[buf * PUNITS + e] = lp_pack8<DT>(pv[q]);
+        }
+    };
+    // ---- weight DMA: tile (slab s, filter row fa) = chunks (cb, b) of BM consecutive 16-byte rows ----
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto stage_weights = [&](int s, int fa, int buf) {
+        const u32x4* src = a.wq + ((long)(2 * s) * T + fa * KS) * a.Rpad + r0 + lane;
+#pragma unroll
+        for (int w0 = 0; w0 < NI; w0 += 4) {
+            const int w = w0 + wave;
+            if (w < NI) {
+                const int ci = w / (BM / 64), h = w - ci * (BM / 64);
+                const int cb = ci / KS, b = ci - cb * KS;
+                const u32x4* g = src + ((long)cb * T + b) * a.Rpad + h * 64;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Wl + buf * WUNITS + ci * BM + h * 64), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (s_begin < s_end) {
+        stage_weights(s_begin, 0, 0);
+        load_patch();
+        store_patch(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int wlane = kg * KS * BM + wm * (BM / WM) + li;
+    const int plane = kg * PH * PW + (wn * TN * ST) * PW + li * ST;
+    int it = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int pbuf = (s - s_begin) & 1;
+        const bool next_slab = (s + 1) < s_end;
+        for (int fa = 0; fa < KS; ++fa, ++it) {
+            const int wbuf = it & 1;
+            if (fa + 1 < KS)
+                stage_weights(s, fa + 1, wbuf ^ 1);
+            else if (next_slab)
+                stage_weights(s + 1, 0, wbuf ^ 1);
+            if (fa == 0 && next_slab) load_patch();
+            const u32x4* Wb = Wl + wbuf * WUNITS + wlane;
+            const u32x4* Pb = Pl + pbuf * PUNITS + plane + fa * PW;
+#pragma unroll
+            for (int b = 0; b < KS; ++b) {
+                u32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = Wb[b * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = Pb[j * ST * PW + b];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = Lp<DT>::mfma(af[i], bf[j], acc[i][j]);
+            }
+            if (fa == 0 && next_slab) store_patch(pbuf ^ 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lanes along pixels; row of element e of tile i: i*32 + (e&3) + 8*(e>>2) + 4*kg ----
+    const long P = (long)a.N * HW;
+    const int ru = r0 + wm * (BM / WM);
+    const int rl = ru + 4 * kg;
+    if (a.partial) {
+        float* const pb = a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HW + (long)(y0 + wn * TN) * a.W + x0;
+        const unsigned lo = 4u * kg * (unsigned)P + li;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    float* rowp = pb + (long)k * P + j * a.W;
+                    if (rl + k < a.R) rowp[lo] = acc[i][j][e];
+                }
+        return;
+    }
+    float* const sb = reinterpret_cast<float*>(smem);          // bias through LDS (free after the last barrier)
+    if (tid < BM) sb[tid] = (a.bias && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
+    __syncthreads();
+    const float* const lb = sb + wm * (BM / WM) + 4 * kg;
+    float* const ub = a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN) * a.W + x0;
+    const unsigned lo = 4u * kg * (unsigned)HW + li;
+    const bool pwl = a.act == GHM_ACT_LINEAR || a.act == GHM_ACT_RELU || a.act == GHM_ACT_LRELU;
+    if (r0 + BM <= a.R && pwl) {
+        const float slope = a.act == GHM_ACT_LINEAR ? 1.f : (a.act == GHM_ACT_RELU ? 0.f : a.alpha);
+        if (!a.accumulate) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                        float* rowp = ub + (long)k * HW + j * a.W;
+                        const float v = acc[i][j][e] + lb[k];
+                        rowp[lo] = v > 0.f ? v : slope * v;
+                    }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float old[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                        old[e] = (ub + (long)k * HW + j * a.W)[lo];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                        float* rowp = ub + (long)k * HW + j * a.W;
+                        const float v = acc[i][j][e] + lb[k] + old[e];
+                        rowp[lo] = v > 0.f ? v : slope * v;
+                    }
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                if (rl + k < a.R) {
+                    float* rowp = ub + (long)k * HW + j * a.W;
+                    float v = acc[i][j][e] + lb[k];
+                    if (a.accumulate) v += rowp[lo];
+                    rowp[lo] = ghm_act(v, a.act, a.alpha);
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Data gradient of a 3x3 / stride-2 / pad-1 convolution (U-Net encoder, PatchGAN; architectures/p2p.py:20-21).
+// dx[c, 2i+pu, 2j+pv] only receives the taps whose parity matches (1, 2, 2 or 4 of the 9): the four output parity
+// classes are four small stride-1 gathers over the SAME dy patch.  A block computes all four classes of BM channels x
+// (RT x 32) class pixels; every k-step (16 dy channels, one tap) feeds exactly one class -> 9 k-steps per slab, no
+// zero-insertion waste.  Operands: dy patch [2 ch-blocks][RT+1][33] units gathered + converted through registers,
+// weights = the transposed pack wqT[k/8][8-tap][c][8 k] (all 9 taps of a slab by DMA).  The two column parities of a
+// pixel pair live in the same lane, so the epilogue stores 8 contiguous bytes per lane.
+// a.in = dy [N, CH=K, Hc, Wc], a.out = dx [N, R=C, 2Hc, 2Wc] (a.H, a.W = dx grid; a.Hin, a.Win = class grid).
+// ------------------------------------------------------------------------------------------------
+template <int DT, int BM, int RT>
+__global__ __launch_bounds__(256, 2) void lp_dgrad_s2_kernel(const LpConvArgs a) {
+    constexpr int T = 9, WM = 2, WN = 2;
+    constexpr int TM = BM / (WM * 32), TN = RT / WN;
+    constexpr int PH = RT + 1, PW = 33;
+    constexpr int PUNITS = 2 * PH * PW;
+    constexpr int WUNITS = 2 * T * BM;
+    constexpr int NQ = (PUNITS + 255) / 256;
+    constexpr int NI = WUNITS / 64;
+    __shared__ __attribute__((aligned(16))) u32x4 smem[2 * WUNITS + 2 * PUNITS];
+    u32x4* const Wl = smem;
+    u32x4* const Pl = smem + 2 * WUNITS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int kg = lane >> 5, li = lane & 31;
+    const int Hc = a.Hin, Wc = a.Win;
+    const int ntr = (a.R + BM - 1) / BM;
+    const int tiles_x = Wc / 32, tiles_y = Hc / RT;
+    int L = lp_xcd_remap(blockIdx.x, gridDim.x);
+    const int r0 = (L % ntr) * BM;
+    L /= ntr;
+    const int tx = L % tiles_x;
+    L /= tiles_x;
+    const int ty = L % tiles_y;
+    const int n = L / tiles_y;
+    const int i0 = ty * RT, j0 = tx * 32;
+    const int HWc = Hc * Wc, HWx = a.H * a.W;
+    const int nslabs = a.CH / 16;
+    const int s_begin = blockIdx.y * a.slabs_per_split;
+    const int s_end = min(nslabs, s_begin + a.slabs_per_split);
+
+    int p_off[NQ];
+    unsigned pmask = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = tid + q * 256;
+        const int cb = e / (PH * PW), rem = e - cb * (PH * PW);
+        const int py = rem / PW, px = rem - py * PW;
+        const int y = i0 + py, x = j0 + px;
+        const bool ok = e < PUNITS && y < Hc && x < Wc;
+        p_off[q] = ok ? cb * 8 * HWc + y * Wc + x : 0;
+        pmask |= (ok ? 1u : 0u) << q;
+    }
+    const float* ibase = a.in + (long)n * a.in_nstride + (long)s_begin * 16 * HWc;
+    float pv[NQ][8];
+    auto load_patch = [&]() {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float* g = ibase + p_off[q];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[q][j] = g[(long)j * HWc];
+        }
+        ibase += (long)16 * HWc;
+    };
+    auto store_patch = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tid + q * 256;
+            if (!((pmask >> q) & 1u)) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[q][j] = 0.f;
+            }
+            if (e < PUNITS) Pl[buf * PUNITS + e] = lp_pack8<DT>(pv[q]);
+        }
+    };
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto stage_weights = [&](int s, int buf) {
+        const u32x4* src = a.wq + (long)(2 * s) * T * a.Rpad + r0 + lane;
+#pragma unroll
+        for (int w0 = 0; w0 < NI; w0 += 4) {
+            const int w = w0 + wave;
+            if (w < NI) {
+                const int ci = w / (BM / 64), h = w - ci * (BM / 64);        // ci = cb * T + tap
+                const u32x4* g = src + (long)ci * a.Rpad + h * 64;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Wl + buf * WUNITS + ci * BM + h * 64), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[4][TM][TN];                          // [parity class pu*2+pv]
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[cl][i][j][e] = 0.f;
+
+    if (s_begin < s_end) {
+        stage_weights(s_begin, 0);
+        load_patch();
+        store_patch(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int wlane = kg * T * BM + wm * (BM / WM) + li;
+    const int plane = kg * PH * PW + (wn * TN) * PW + li;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        const bool more = (s + 1) < s_end;
+        if (more) {
+            stage_weights(s + 1, buf ^ 1);
+            load_patch();
+        }
+        const u32x4* Wb = Wl + buf * WUNITS + wlane;
+        const u32x4* Pb = Pl + buf * PUNITS + plane;
+#pragma unroll
+        for (int tw = 0; tw < T; ++tw) {                    // tw: tap index in the transposed pack = 8 - original tap
+            const int ta = (8 - tw) / 3, tb = (8 - tw) % 3;  // original (a, b)
+            const int pu = ta == 1 ? 0 : 1, pvv = tb == 1 ? 0 : 1;
+            const int di = ta == 0 ? 1 : 0, dj = tb == 0 ? 1 : 0;
+            u32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Wb[tw * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Pb[(j + di) * PW + dj];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[pu * 2 + pvv][i][j] = Lp<DT>::mfma(af[i], bf[j], acc[pu * 2 + pvv][i][j]);
+        }
+        if (more) store_patch(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = class pixel (row i0 + wn*TN + j, column j0 + li); its two column parities are adjacent ----
+    const long P = (long)a.N * HWx;
+    const int ru = r0 + wm * (BM / WM) + 4 * kg;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ic = i0 + wn * TN + j, jc = j0 + li;
+#pragma unroll
+        for (int pu = 0; pu < 2; ++pu) {
+            const long pix = (long)(2 * ic + pu) * a.W + 2 * jc;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = ru + i * 32 + (e & 3) + 8 * (e >> 2);
+                    if (r >= a.R) continue;
+                    float v0 = acc[pu * 2 + 0][i][j][e], v1 = acc[pu * 2 + 1][i][j][e];
+                    if (a.partial) {
+                        float* o = a.partial + ((long)blockIdx.y * a.R + r) * P + (long)n * HWx + pix;
+                        *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
+                    } else {
+                        float* o = a.out + (long)n * a.out_nstride + (long)r * HWx + pix;
+                        if (a.bias) { v0 += a.bias[r]; v1 += a.bias[r]; }
+                        if (a.accumulate) {
+                            const float2 old = *reinterpret_cast<const float2*>(o);
+                            v0 += old.x; v1 += old.y;
+                        }
+                        *reinterpret_cast<float2*>(o) = make_float2(ghm_act(v0, a.act, a.alpha), ghm_act(v1, a.act, a.alpha));
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient: dwp[(c, tap)][k] = sum over pixels of x[c, pixel + tap] * dy[k, pixel].
+// GEMM rows = (channel, tap) of CBW = 128 / T channels, columns = BN filters, contraction = the SPX = 32 * NSEG
+// pixels of one output-row segment per slab.  LDS tiles hold 8-pixel units: A [128 rows][SPX/8 (+1 pad)], B
+// [BN][SPX/8 (+1 pad)]; the odd row stride makes the 32 rows of a fragment read hit distinct bank groups.
+// ------------------------------------------------------------------------------------------------
+struct LpWgradArgs {
+    const float* x;
+    const float* dy;
+    float* out;
+    int N, C, H, W;
+    long x_nstride;
+    int K, Ho, Wo;
+    long y_nstride;
+    int pad;
+    int CT;
+    int slabs_per_split;
+    long split_stride;
+    int accumulate;
+};
+
+template <int DT, int KS, int ST, int BN, int WM, int WN, int NSEG>
+__global__ __launch_bounds__(256, 2) void lp_wgrad_kernel(const LpWgradArgs a) {
+    constexpr int T = KS * KS;
+    constexpr int CBW = 128 / T, ROWS = CBW * T, BM = 128;
+    constexpr int SPX = 32 * NSEG, NCH = SPX / 8, LD = NCH + 1;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int NA = CBW * KS * NCH;              // A staging items: (channel, filter row, pixel chunk)
+    constexpr int AQ = (NA + 255) / 256;
+    constexpr int WIN = ST == 1 ? 4 : 6;            // float4 per aligned input window (16 / 24 floats)
+    constexpr int NB = BN * NCH;                    // B staging items: (filter, pixel chunk)
+    constexpr int BQ = (NB + 255) / 256;
+    constexpr int ASZ = BM * LD, BSZ = BN * LD;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) u32x4 smem[2 * (ASZ + BSZ)];
+    u32x4* const Al = smem;
+    u32x4* const Bl = smem + 2 * ASZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int kg = lane >> 5, li = lane & 31;
+    const int c0 = blockIdx.x * CBW, k0 = blockIdx.y * BN;
+    const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
+    const int segs_per_row = a.Wo / SPX;
+    const int total_slabs = a.N * a.Ho * segs_per_row;
+    const int s_begin = blockIdx.z * a.slabs_per_split;
+    const int s_end = min(s_begin + a.slabs_per_split, total_slabs);
+
+    // rows ROWS..127 of the A tiles are never written: zero them once (both buffers)
+    for (int e = tid; e < 2 * ASZ; e += 256) Al[e] = u32x4{0u, 0u, 0u, 0u};
+
+    // ---- A staging constants: item (c, fa, q) -> window of input row (i*ST + fa - pad), columns from (j0+8q)*ST - 4
+    int a_c[AQ], a_fa[AQ], a_q[AQ];
+    bool a_valid[AQ];
+#pragma unroll
+    for (int p = 0; p < AQ; ++p) {
+        const int e = tid + p * 256;
+        const int c = e / (KS * NCH), rem = e - c * (KS * NCH);
+        a_c[p] = c;
+        a_fa[p] = rem / NCH;
+        a_q[p] = rem - a_fa[p] * NCH;
+        a_valid[p] = e < NA && (c0 + c) < a.C;
+    }
+    int sn, si, sj;
+    {
+        const int row = s_begin / segs_per_row;
+        sj = (s_begin - row * segs_per_row) * SPX;
+        sn = row / a.Ho;
+        si = row - sn * a.Ho;
+    }
+    float aw[AQ][WIN * 4];
+    float bw[BQ][8];
+    auto load_slab = [&]() {
+        const float* xb = a.x + (long)sn * a.x_nstride;
+#pragma unroll
+        for (int p = 0; p < AQ; ++p) {
+            const int y = si * ST + a_fa[p] - a.pad;
+            const int xs = (sj + 8 * a_q[p]) * ST - 4;
+            const bool rok = a_valid[p] && (unsigned)y < (unsigned)a.H;
+            const float* rowp = xb + (long)(c0 + (rok ? a_c[p] : 0)) * HW + (long)(rok ? y : 0) * a.W;
+#pragma unroll
+            for (int g = 0; g < WIN; ++g) {
+                const int xg = xs + 4 * g;
+                const bool ok = rok && xg >= 0 && xg < a.W;
+                const float4 v = *reinterpret_cast<const float4*>(rowp + (ok ? xg : 0));
+                aw[p][4 * g + 0] = ok ? v.x : 0.f;
+                aw[p][4 * g + 1] = ok ? v.y : 0.f;
+                aw[p][4 * g + 2] = ok ? v.z : 0.f;
+                aw[p][4 * g + 3] = ok ? v.w : 0.f;
+            }
+        }
+        const float* yb = a.dy + (long)sn * a.y_nstride + (long)si * a.Wo + sj;
+#pragma unroll
+        for (int p = 0; p < BQ; ++p) {
+            const int e = tid + p * 256;
+            const int f = e / NCH, q = e - f * NCH;
+            const bool ok = e < NB && (k0 + f) < a.K;
+            const float* g = yb + (long)(ok ? k0 + f : 0) * HoWo + 8 * q;
+            const float4 v0 = *reinterpret_cast<const float4*>(g), v1 = *reinterpret_cast<const float4*>(g + 4);
+            bw[p][0] = ok ? v0.x : 0.f; bw[p][1] = ok ? v0.y : 0.f; bw[p][2] = ok ? v0.z : 0.f; bw[p][3] = ok ? v0.w : 0.f;
+            bw[p][4] = ok ? v1.x : 0.f; bw[p][5] = ok ? v1.y : 0.f; bw[p][6] = ok ? v1.z : 0.f; bw[p][7] = ok ? v1.w : 0.f;
+        }
+        sj += SPX;
+        if (sj >= a.Wo) {
+            sj = 0;
+            if (++si >= a.Ho) {
+                si = 0;
+                ++sn;
+            }
+        }
+        if (sn >= a.N) { sn = 0; si = 0; sj = 0; }          // past the end: keep addresses valid
+    };
+    auto store_slab = [&](int buf) {
+        u32x4* Ab = Al + buf * ASZ;
+        u32x4* Bb = Bl + buf * BSZ;
+#pragma unroll
+        for (int p = 0; p < AQ; ++p) {
+            if (tid + p * 256 < NA) {
+#pragma unroll
+                for (int b = 0; b < KS; ++b) {
+                    float v[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) v[t] = aw[p][4 + t * ST + b - KS / 2];     // pad == KS / 2 (checked by the host)
+                    Ab[((a_c[p] * KS + a_fa[p]) * KS + b) * LD + a_q[p]] = lp_pack8<DT>(v);
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < BQ; ++p) {
+            const int e = tid + p * 256;
+            if (e < NB) {
+                const int f = e / NCH, q = e - f * NCH;
+                Bb[f * LD + q] = lp_pack8<DT>(bw[p]);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    __syncthreads();                                    // the zero fill precedes the first tile stores
+    if (s_begin < s_end) {
+        load_slab();
+        store_slab(0);
+    }
+    __syncthreads();
+    const int alane = (wm * (BM / WM) + li) * LD + kg;
+    const int blane = (wn * (BN / WN) + li) * LD + kg;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        const bool more = (s + 1) < s_end;
+        if (more) load_slab();
+        const u32x4* Ab = Al + buf * ASZ + alane;
+        const u32x4* Bb = Bl + buf * BSZ + blane;
+#pragma unroll
+        for (int ks = 0; ks < NCH / 2; ++ks) {
+            u32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ab[i * 32 * LD + ks * 2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bb[j * 32 * LD + ks * 2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Lp<DT>::mfma(af[i], bf[j], acc[i][j]);
+        }
+        if (more) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* ob = a.out + (long)blockIdx.z * a.split_stride;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = k0 + wn * (BN / WN) + j * 32 + li;
+        if (col >= a.K) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rt = wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+                const int row = c0 * T + rt;
+                if (rt < ROWS && row < a.CT) {
+                    float* o = ob + (long)row * a.K + col;
+                    float v = acc[i][j][e];
+                    if (a.accumulate) v += *o;
+                    *o = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct LpPlan {
+    bool ok;
+    int bm, rt, splits, slabs_per_split, grid;
+};
+
+LpPlan lp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
+    LpPlan p;
+    p.ok = false;
+    if (getenv("GHM_NO_LP")) return p;
+    if (!((ks == 3 && (st == 1 || st == 2)) || (ks == 5 && st == 1))) return p;
+    p.bm = R >= 96 ? 128 : 64;
+    p.rt = st == 2 ? 4 : 8;
+    if (R < 32 || (W % 32) || (H % p.rt) || (CH % 16) || CH < 16) return p;
+    const int ntr = (R + p.bm - 1) / p.bm;
+    p.grid = ntr * (W / 32) * (H / p.rt) * N;
+    const int nslabs = CH / 16;
+    p.splits = 1;
+    if (p.grid < num_cu + num_cu / 2) {
+        p.splits = (2 * num_cu + p.grid - 1) / p.grid;
+        const int maxs = nslabs / 2 > 0 ? nslabs / 2 : 1;
+        if (p.splits > maxs) p.splits = maxs;
+    }
+    if (const char* f = getenv("GHM_LP_SPLITS")) p.splits = atoi(f) < nslabs ? (atoi(f) > 0 ? atoi(f) : 1) : nslabs;
+    p.slabs_per_split = (nslabs + p.splits - 1) / p.splits;
+    p.splits = (nslabs + p.slabs_per_split - 1) / p.slabs_per_split;
+    p.ok = true;
+    return p;
+}
+
+template <int DT>
+int lp_launch_conv(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a, int ks, int st) {
+    a.slabs_per_split = pl.slabs_per_split;
+    a.partial = nullptr;
+    if (pl.splits > 1) {
+        void* ws = nullptr;
+        if (int e = ghm_scratch(ctx, (size_t)pl.splits * a.R * a.N * a.H * a.W * sizeof(float), &ws)) return e;
+        a.partial = (float*)ws;
+    }
+    const dim3 g(pl.grid, pl.splits);
+#define GHM_LP_CASE(KS_, ST_, BM_, RT_, WM_, WN_)                                                              \
+    if (ks == KS_ && st == ST_ && pl.bm == BM_) {                                                              \
+        hipLaunchKernelGGL((lp_conv_kernel<DT, KS_, ST_, BM_, RT_, WM_, WN_>), g, dim3(256), 0, ctx->stream, a); \
+        GHM_LAUNCH_CHECK();                                                                                    \
+    } else
+    GHM_LP_CASE(5, 1, 128, 8, 2, 2)
+    GHM_LP_CASE(5, 1, 64, 8, 1, 4)
+    GHM_LP_CASE(3, 1, 128, 8, 2, 2)
+    GHM_LP_CASE(3, 1, 64, 8, 1, 4)
+    GHM_LP_CASE(3, 2, 128, 4, 2, 2)
+    GHM_LP_CASE(3, 2, 64, 4, 1, 4) {
+        ghm_set_error("no lp_conv variant for k=%d s=%d bm=%d", ks, st, pl.bm);
+        return -3;
+    }
+#undef GHM_LP_CASE
+    if (pl.splits > 1)
+        return ghm_splitk_finish(ctx, a.partial, pl.splits, a.out, a.bias, a.N, a.R, a.H, a.W, a.out_nstride, a.act,
+                                 a.alpha, a.accumulate);
+    return 0;
+}
+
+// 3x3 stride-2 pad-1 data gradient on the transposed pack
+LpPlan lp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu) {
+    LpPlan p;
+    p.ok = false;
+    if (getenv("GHM_NO_LP") || getenv("GHM_NO_LP_DGRAD_S2")) return p;
+    if (!(d->stride == 2 && d->kh == 3 && d->kw == 3 && d->pad == 1 && d->H == 2 * d->Ho && d->W == 2 * d->Wo)) return p;
+    p.bm = d->C >= 96 ? 128 : 64;
+    p.rt = p.bm == 128 ? 2 : 4;
+    if (d->Wo % 32 || d->Ho % p.rt || d->K % 16 || d->K < 16 || d->C < 32 || (d->x_nstride & 1) || ((d->H * d->W) & 1)) return p;
+    const int ntr = (d->C + p.bm - 1) / p.bm;
+    p.grid = ntr * (d->Wo / 32) * (d->Ho / p.rt) * d->N;
+    const int nslabs = d->K / 16;
+    p.splits = 1;
+    if (p.grid < num_cu + num_cu / 2) {
+        p.splits = (2 * num_cu + p.grid - 1) / p.grid;
+        const int maxs = nslabs / 2 > 0 ? nslabs / 2 : 1;
+        if (p.splits > maxs) p.splits = maxs;
+    }
+    p.slabs_per_split = (nslabs + p.splits - 1) / p.splits;
+    p.splits = (nslabs + p.slabs_per_split - 1) / p.slabs_per_split;
+    p.ok = true;
+    return p;
+}
+
+template <int DT>
+int lp_launch_dgrad_s2(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a) {
+    a.slabs_per_split = pl.slabs_per_split;
+    a.partial = nullptr;
+    if (pl.splits > 1) {
+        void* ws = nullptr;
+        if (int e = ghm_scratch(ctx, (size_t)pl.splits * a.R * a.N * a.H * a.W * sizeof(float), &ws)) return e;
+        a.partial = (float*)ws;
+    }
+    const dim3 g(pl.grid, pl.splits);
+    if (pl.bm == 128)
+        hipLaunchKernelGGL((lp_dgrad_s2_kernel<DT, 128, 2>), g, dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((lp_dgrad_s2_kernel<DT, 64, 4>), g, dim3(256), 0, ctx->stream, a);
+    GHM_LAUNCH_CHECK();
+    if (pl.splits > 1)
+        return ghm_splitk_finish(ctx, a.partial, pl.splits, a.out, a.bias, a.N, a.R, a.H, a.W, a.out_nstride, a.act,
+                                 a.alpha, a.accumulate);
+    return 0;
+}
+
+struct LpWPlan {
+    bool ok;
+    int bn, nseg, splits, slabs_per_split, row_tiles;
+};
+
+LpWPlan lp_wplan(const ghm_conv_desc* d, int num_cu) {
+    LpWPlan v;
+    v.ok = false;
+    if (getenv("GHM_NO_LP") || getenv("GHM_NO_LP_WGRAD")) return v;
+    const bool k_ok = (d->kh == 3 && d->kw == 3 && (d->stride == 1 || d->stride == 2)) ||
+                      (d->kh == 5 && d->kw == 5 && d->stride == 1);
+    if (!k_ok || d->pad != d->kh / 2 || d->Wo % 32 || d->W % 4 || d->K < 32 || d->C * d->kh * d->kw < 96) return v;
+    if (d->x_nstride % 4 || d->y_nstride % 4 || (d->Ho * d->Wo) % 4 || (d->H * d->W) % 4) return v;
+    if (d->Ho != (d->H + d->stride - 1) / d->stride) return v;
+    const int T = d->kh * d->kw;
+    v.bn = d->K >= 96 ? 128 : 64;
+    v.nseg = (d->Wo % 64 == 0 && getenv("GHM_LP_WGRAD_SEG1") == nullptr) ? 2 : 1;
+    v.row_tiles = ceil_div(d->C, 128 / T);
+    const long tiles = (long)v.row_tiles * ceil_div(d->K, v.bn);
+    const long slabs = (long)d->N * d->Ho * (d->Wo / (32 * v.nseg));
+    long want = (2L * num_cu) / tiles;
+    if (const char* f = getenv("GHM_LP_WGRAD_SPLITS")) want = atol(f);
+    const long max_by_work = slabs / 4 > 0 ? slabs / 4 : 1;         // at least 4 slabs per split
+    long S = want < max_by_work ? want : max_by_work;
+    if (S < 1) S = 1;
+    if (S > 1024) S = 1024;
+    v.slabs_per_split = (int)((slabs + S - 1) / S);
+    v.splits = (int)((slabs + v.slabs_per_split - 1) / v.slabs_per_split);
+    v.ok = true;
+    return v;
+}
+
+template <int DT>
+int lp_launch_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const LpWPlan& v, const float* x, const float* dy, float* dwp,
+                    void* workspace, int accumulate) {
+    LpWgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.dy = dy;
+    a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.x_nstride = d->x_nstride;
+    a.K = d->K; a.Ho = d->Ho; a.Wo = d->Wo; a.y_nstride = d->y_nstride;
+    a.pad = d->pad;
+    a.CT = d->C * d->kh * d->kw;
+    a.slabs_per_split = v.slabs_per_split;
+    const long n = (long)a.CT * a.K;
+    if (v.splits > 1) {
+        GHM_CHECK(workspace != nullptr, "lp wgrad needs a workspace for %d splits", v.splits);
+        a.out = (float*)workspace; a.split_stride = n; a.accumulate = 0;
+    } else {
+        a.out = dwp; a.split_stride = 0; a.accumulate = accumulate;
+    }
+    const dim3 grid(v.row_tiles, ceil_div(a.K, v.bn), v.splits);
+#define GHM_LPW_CASE(KS_, ST_, BN_, WM_, WN_)                                                                        \
+    if (d->kh == KS_ && d->stride == ST_ && v.bn == BN_) {                                                           \
+        if (v.nseg == 2)                                                                                             \
+            hipLaunchKernelGGL((lp_wgrad_kernel<DT, KS_, ST_, BN_, WM_, WN_, 2>), grid, dim3(256), 0, ctx->stream, a); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((lp_wgrad_kernel<DT, KS_, ST_, BN_, WM_, WN_, 1>), grid, dim3(256), 0, ctx->stream, a); \
+        GHM_LAUNCH_CHECK();                                                                                          \
+    } else
+    GHM_LPW_CASE(5, 1, 128, 2, 2)
+    GHM_LPW_CASE(5, 1, 64, 4, 1)
+    GHM_LPW_CASE(3, 1, 128, 2, 2)
+    GHM_LPW_CASE(3, 1, 64, 4, 1)
+    GHM_LPW_CASE(3, 2, 128, 2, 2)
+    GHM_LPW_CASE(3, 2, 64, 4, 1) {
+        ghm_set_error("no lp_wgrad variant for k=%d s=%d bn=%d", d->kh, d->stride, v.bn);
+        return -3;
+    }
+#undef GHM_LPW_CASE
+    if (v.splits > 1) return ghm_reduce_splits(ctx, (const float*)workspace, v.splits, n, n, dwp, accumulate);
+    return 0;
+}
+
+// forward-form geometry of the three uses: kind 0 forward, kind 1 data gradient (stride 1 only), kind 2 weight gradient
+bool lp_fwd_geom(const ghm_conv_desc* d) {
+    return d->kh == d->kw && ((d->stride == 1 && d->Ho == d->H && d->Wo == d->W) ||
+                              (d->stride == 2 && d->Ho * 2 == d->H && d->Wo * 2 == d->W && d->pad == 1));
+}
+
+int rpad128(int r) { return (r + 127) / 128 * 128; }
+
+}  // namespace
+
+extern "C" {
+
+int ghm_lp_supported(const ghm_conv_desc* d, int32_t kind, int32_t dtype) {
+    if (dtype != GHM_DTYPE_BF16 && dtype != GHM_DTYPE_F16) return 0;
+    if (kind == 0) return lp_fwd_geom(d) && lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, 256).ok;
+    if (kind == 1) {
+        if (d->stride == 2) return lp_plan_dgrad_s2(d, 256).ok;
+        return d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W &&
+               lp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, 256).ok;
+    }
+    if (kind == 2) return lp_wplan(d, 256).ok;
+    return 0;
+}
+
+int ghm_lp_weight_bytes(const ghm_conv_desc* d, int32_t transposed, size_t* bytes) {
+    const int T = d->kh * d->kw;
+    const int red = transposed ? d->K : d->C, rows = transposed ? d->C : d->K;
+    *bytes = (size_t)((red + 15) / 16 * 2) * T * rpad128(rows) * 16;
+    return 0;
+}
+
+int ghm_lp_pack_weights(ghm_ctx* ctx, const ghm_conv_desc* d, const float* wp, void* wq, int32_t dtype,
+                        int32_t transposed) {
+    GHM_CHECK(dtype == GHM_DTYPE_BF16 || dtype == GHM_DTYPE_F16, "ghm_lp_pack_weights: dtype %d", dtype);
+    const int T = d->kh * d->kw;
+    const int red = transposed ? d->K : d->C, rows = transposed ? d->C : d->K;
+    const int nblk = (red + 15) / 16 * 2, rp = rpad128(rows);
+    const long total = (long)nblk * T * rp;
+    const dim3 g(ceil_div(total, 256)), b(256);
+    if (!transposed) {
+        if (dtype == GHM_DTYPE_BF16)
+            hipLaunchKernelGGL((lp_pack_kernel<GHM_DTYPE_BF16>), g, b, 0, ctx->stream, wp, (u32x4*)wq, d->C, T, d->K, nblk, rp);
+        else
+            hipLaunchKernelGGL((lp_pack_kernel<GHM_DTYPE_F16>), g, b, 0, ctx->stream, wp, (u32x4*)wq, d->C, T, d->K, nblk, rp);
+    } else {
+        if (dtype == GHM_DTYPE_BF16)
+            hipLaunchKernelGGL((lp_pack_t_kernel<GHM_DTYPE_BF16>), g, b, 0, ctx->stream, wp, (u32x4*)wq, d->C, T, d->K, nblk, rp);
+        else
+            hipLaunchKernelGGL((lp_pack_t_kernel<GHM_DTYPE_F16>), g, b, 0, ctx->stream, wp, (u32x4*)wq, d->C, T, d->K, nblk, rp);
+    }
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_conv2d_fwd_lp(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* wq, const float* bias, float* y,
+                      int32_t act, float alpha, int32_t accumulate, int32_t dtype) {
+    GHM_CHECK(ghm_lp_supported(d, 0, dtype), "ghm_conv2d_fwd_lp: geometry / dtype not served by the matrix-core "
+              "low-precision kernels (ask ghm_lp_supported first)");
+    GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    const LpPlan pl = lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ctx->num_cu);
+    LpConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = x; a.wq = (const u32x4*)wq; a.bias = bias; a.out = y;
+    a.N = d->N; a.CH = d->C; a.H = d->Ho; a.W = d->Wo; a.Hin = d->H; a.Win = d->W; a.in_nstride = d->x_nstride;
+    a.R = d->K; a.Rpad = rpad128(d->K); a.out_nstride = d->y_nstride; a.pad = d->pad;
+    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
+    return dtype == GHM_DTYPE_BF16 ? lp_launch_conv<GHM_DTYPE_BF16>(ctx, pl, a, d->kh, d->stride)
+                                   : lp_launch_conv<GHM_DTYPE_F16>(ctx, pl, a, d->kh, d->stride);
+}
+
+int ghm_conv2d_dgrad_lp(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* wqT, const float* bias,
+                        float* dx, int32_t act, float alpha, int32_t accumulate, int32_t dtype) {
+    GHM_CHECK(ghm_lp_supported(d, 1, dtype), "ghm_conv2d_dgrad_lp: geometry / dtype not served (ask ghm_lp_supported)");
+    GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    if (d->stride == 2) {
+        const LpPlan pl = lp_plan_dgrad_s2(d, ctx->num_cu);
+        LpConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = dy; a.wq = (const u32x4*)wqT; a.bias = bias; a.out = dx;
+        a.N = d->N; a.CH = d->K; a.H = d->H; a.W = d->W; a.Hin = d->Ho; a.Win = d->Wo; a.in_nstride = d->y_nstride;
+        a.R = d->C; a.Rpad = rpad128(d->C); a.out_nstride = d->x_nstride; a.pad = d->pad;
+        a.act = act; a.alpha = alpha; a.accumulate = accumulate;
+        return dtype == GHM_DTYPE_BF16 ? lp_launch_dgrad_s2<GHM_DTYPE_BF16>(ctx, pl, a)
+                                       : lp_launch_dgrad_s2<GHM_DTYPE_F16>(ctx, pl, a);
+    }
+    // the data gradient of a stride-1 conv is the forward conv K -> C with flipped taps (folded into the
+    // transposed pack) and padding k-1-pad
+    const LpPlan pl = lp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ctx->num_cu);
+    LpConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = dy; a.wq = (const u32x4*)wqT; a.bias = bias; a.out = dx;
+    a.N = d->N; a.CH = d->K; a.H = d->H; a.W = d->W; a.Hin = d->H; a.Win = d->W; a.in_nstride = d->y_nstride;
+    a.R = d->C; a.Rpad = rpad128(d->C); a.out_nstride = d->x_nstride; a.pad = d->kh - 1 - d->pad;
+    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
+    return dtype == GHM_DTYPE_BF16 ? lp_launch_conv<GHM_DTYPE_BF16>(ctx, pl, a, d->kh, 1)
+                                   : lp_launch_conv<GHM_DTYPE_F16>(ctx, pl, a, d->kh, 1);
+}
+
+int ghm_conv2d_wgrad_lp_workspace(const ghm_conv_desc* d, size_t* bytes) {
+    const LpWPlan v = lp_wplan(d, 256);
+    const size_t n = (size_t)d->C * d->kh * d->kw * d->K;
+    *bytes = (v.ok && v.splits > 1) ? (size_t)v.splits * n * sizeof(float) : 16;
+    return 0;
+}
+
+int ghm_conv2d_wgrad_lp(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* dy, float* dwp,
+                        void* workspace, int32_t accumulate, int32_t dtype) {
+    GHM_CHECK(ghm_lp_supported(d, 2, dtype), "ghm_conv2d_wgrad_lp: geometry / dtype not served (ask ghm_lp_supported)");
+    const LpWPlan v = lp_wplan(d, 256);
+    return dtype == GHM_DTYPE_BF16 ? lp_launch_wgrad<GHM_DTYPE_BF16>(ctx, d, v, x, dy, dwp, workspace, accumulate)
+                                   : lp_launch_wgrad<GHM_DTYPE_F16>(ctx, d, v, x, dy, dwp, workspace, accumulate);
+}
+
+}  // extern "C"

@@ -7,6 +7,7 @@ from . import _lib
 from ._lib import ConvDesc, call
 
 ACT_CODES = {'linear': 0, 'relu': 1, 'lrelu': 2, 'sigmoid': 3, 'tanh': 4}
+DTYPE_CODES = {'f32': 0, 'bf16': 1, 'f16': 2}       # GHM_DTYPE_* (include/ghm.h)
 
 
 def device_count():
@@ -277,6 +278,35 @@ class Ops:
 
     def conv2d_wgrad(self, d, x, dy, dwp, ws, accumulate=False):
         call("ghm_conv2d_wgrad", self.h, C.byref(d), _vp(x), _vp(dy), _vp(dwp), _vp(ws), int(accumulate))
+
+    # ---- bf16 / fp16 matrix-core convolutions (fp32 tensors in HBM; include/ghm.h GHM_DTYPE_*) ----
+    def lp_supported(self, d, kind, dtype):
+        return bool(_lib.load().ghm_lp_supported(C.byref(d), int(kind), DTYPE_CODES[dtype]))
+
+    def lp_weight_bytes(self, d, transposed=False):
+        n = C.c_size_t()
+        call("ghm_lp_weight_bytes", C.byref(d), int(transposed), C.byref(n))
+        return n.value
+
+    def lp_pack_weights(self, d, wp, wq, dtype, transposed=False):
+        call("ghm_lp_pack_weights", self.h, C.byref(d), _vp(wp), _vp(wq), DTYPE_CODES[dtype], int(transposed))
+
+    def conv2d_fwd_lp(self, d, x, wq, bias, y, dtype, act='linear', alpha=0.0, accumulate=False):
+        call("ghm_conv2d_fwd_lp", self.h, C.byref(d), _vp(x), _vp(wq), _vp(bias), _vp(y), ACT_CODES[act], alpha,
+             int(accumulate), DTYPE_CODES[dtype])
+
+    def conv2d_dgrad_lp(self, d, dy, wqT, dx, dtype, bias=None, act='linear', alpha=0.0, accumulate=False):
+        call("ghm_conv2d_dgrad_lp", self.h, C.byref(d), _vp(dy), _vp(wqT), _vp(bias), _vp(dx), ACT_CODES[act], alpha,
+             int(accumulate), DTYPE_CODES[dtype])
+
+    def wgrad_lp_workspace(self, d):
+        n = C.c_size_t()
+        call("ghm_conv2d_wgrad_lp_workspace", C.byref(d), C.byref(n))
+        return n.value
+
+    def conv2d_wgrad_lp(self, d, x, dy, dwp, ws, dtype, accumulate=False):
+        call("ghm_conv2d_wgrad_lp", self.h, C.byref(d), _vp(x), _vp(dy), _vp(dwp), _vp(ws), int(accumulate),
+             DTYPE_CODES[dtype])
 
     def channel_sum(self, x, out, accumulate=False):
         call("ghm_channel_sum", self.h, _vp(x), x.N, x.Cc, x.HW, x.nstride, _vp(out), int(accumulate))

@@ -89,6 +89,15 @@ class ParamStore:
     def download_grad(self, p):
         return self._from_device_layout(p, self.grad(p).numpy().ravel())
 
+    def lp_pack(self, key, nbytes):
+        """device buffer of a 16-byte-unit bf16 / fp16 weight pack (ghm_lp_pack_weights), refreshed from the fp32
+        master weights once per step before its first use"""
+        if not hasattr(self, '_lp'):
+            self._lp = {}
+        if key not in self._lp:
+            self._lp[key] = self.dev.alloc(nbytes)
+        return self._lp[key]
+
     def transposed(self, p):
         """scratch for the transposed packed weights of a stride-1 conv (refreshed each step before its first
         data-gradient use: ghm_conv2d_transpose_weights)"""
@@ -270,12 +279,16 @@ class NetPlan:
     """One network lowered for a fixed batch size: buffers + emitters of forward/backward programs."""
 
     def __init__(self, dev, ops, out_layer, batch, store, inputs=None, out_tensor=None, name="net", side=None,
-                 bn_groups=1, rng_seed=0, rng_counter=None):
+                 bn_groups=1, rng_seed=0, rng_counter=None, dtype='f32'):
         """``side=(Device, Ops)``: a second stream of the same GPU for the weight / bias gradients, which only
         feed the optimiser: they fork off the main stream where their output gradient is ready and run beside
         the data-gradient chain (the caller joins the two streams before the update)."""
         self.dev, self.ops, self.batch, self.store, self.name = dev, ops, batch, store, name
         self.side = side
+        # arithmetic of the convolution products: 'f32' (the reference's floatX) or 'bf16' / 'f16' on the matrix cores
+        # for every geometry the low-precision kernels serve; tensors in HBM are fp32 either way (include/ghm.h)
+        assert dtype in ('f32', 'bf16', 'f16')
+        self.dtype = dtype
         # bn_groups=2: the batch is [real | fake] (two get_output calls of the reference, pix2pix.py:94-95,98-101):
         # every BatchNormLayer normalises each half with its own statistics
         self.bn_groups = bn_groups
@@ -404,8 +417,23 @@ class NetPlan:
         K = n.shape[1]
         return conv_desc(x_t.N, x_t.Cc, x_t.H, x_t.W, 4 * K, 3, 3, 1, 1, x_t.nstride, 4 * K * x_t.H * x_t.W)
 
+    def _lp(self, d, kind):
+        return self.dtype != 'f32' and self.ops.lp_supported(d, kind, self.dtype)
+
+    def _lp_pack_entry(self, prog, d, w_src, key, transposed, done):
+        """-> device pointer of the bf16 / fp16 pack of ``w_src``; emits the refresh once per program set ``done``"""
+        wq = self.store.lp_pack((key, transposed, self.dtype), self.ops.lp_weight_bytes(d, transposed))
+        if done is None or (key, transposed) not in done:
+            if done is not None:
+                done.add((key, transposed))
+            prog.append(("lp_pack_t" if transposed else "lp_pack", lambda d=d, w=w_src, wq=wq, t=transposed:
+                         self.ops.lp_pack_weights(d, w, wq, self.dtype, t)))
+        return wq
+
     def _need_wgrad_ws(self, d):
         b = self.ops.wgrad_workspace(d)
+        if self._lp(d, 2):
+            b = max(b, self.ops.wgrad_lp_workspace(d))
         if b > self._wgrad_ws_bytes:
             if self.wgrad_ws is not None:
                 self.dev.free(self.wgrad_ws)
@@ -413,7 +441,9 @@ class NetPlan:
             self._wgrad_ws_bytes = b
 
     # ---- forward ---------------------------------------------------------------------------------
-    def emit_forward(self, prog, deterministic=False, update_running=True):
+    def emit_forward(self, prog, deterministic=False, update_running=True, lp_done=None):
+        """``lp_done``: set of low-precision weight packs already refreshed in the program being built (a net that is
+        evaluated twice per step packs once)"""
         ops, st = self.ops, self.store
         if self.dropout_nodes and not deterministic:
             prog.append(("rng_tick", lambda c=self.rng_counter: ops.counter_tick(c)))
@@ -433,8 +463,14 @@ class NetPlan:
             if n.op in ('conv', 'dense'):
                 d = self._desc(n, x, y)
                 w, b = st.value(n.layer.W), st.value(n.layer.b)
-                prog.append(("%s_fwd" % n.op, lambda d=d, x=x, w=w, b=b, y=y, a=a:
-                             ops.conv2d_fwd(d, x, w, b, y, a.kind, a.alpha), conv_meta(ops, d, 0)))
+                if n.op == 'conv' and self._lp(d, 0):
+                    wq = self._lp_pack_entry(prog, d, w, ('w', id(n.layer.W)), False, lp_done)
+                    prog.append(("conv_fwd", lambda d=d, x=x, wq=wq, b=b, y=y, a=a:
+                                 ops.conv2d_fwd_lp(d, x, wq, b, y, self.dtype, a.kind, a.alpha),
+                                 conv_meta(ops, d, 0, self.dtype)))
+                else:
+                    prog.append(("%s_fwd" % n.op, lambda d=d, x=x, w=w, b=b, y=y, a=a:
+                                 ops.conv2d_fwd(d, x, w, b, y, a.kind, a.alpha), conv_meta(ops, d, 0)))
             elif n.op == 'deconv':
                 d = self._desc(n, y, x)
                 w, b = st.value(n.layer.W), st.value(n.layer.b)
@@ -477,8 +513,14 @@ class NetPlan:
                 y4 = y.reshape((x.N, 4 * K, x.H, x.W))
                 prog.append(("collapse_w", lambda w5=w5, b=b, wpc=wpc, b4=b4, C=C, K=K:
                              ops.upconv_collapse_weights(w5, b, wpc, b4, C, K)))
-                prog.append(("upconv_fwd", lambda d=d, x=x, wpc=wpc, b4=b4, y4=y4, a=a:
-                             ops.conv2d_fwd(d, x, wpc, b4, y4, a.kind, a.alpha), conv_meta(ops, d, 0)))
+                if self._lp(d, 0):
+                    wq = self._lp_pack_entry(prog, d, wpc, ('c', id(n.layer.W)), False, None)    # after collapse_w
+                    prog.append(("upconv_fwd", lambda d=d, x=x, wq=wq, b4=b4, y4=y4, a=a:
+                                 ops.conv2d_fwd_lp(d, x, wq, b4, y4, self.dtype, a.kind, a.alpha),
+                                 conv_meta(ops, d, 0, self.dtype)))
+                else:
+                    prog.append(("upconv_fwd", lambda d=d, x=x, wpc=wpc, b4=b4, y4=y4, a=a:
+                                 ops.conv2d_fwd(d, x, wpc, b4, y4, a.kind, a.alpha), conv_meta(ops, d, 0)))
             elif n.op == 'pp_to_hi':
                 prog.append(("pp_to_hi", lambda x=x, y=y: ops.pp_to_hi(x, y)))
             elif n.op == 'dropout':
@@ -509,12 +551,16 @@ class NetPlan:
             if n.op == 'conv':
                 l = n.layer
                 d = self._desc(n, n.inputs[0].out, n.out)
+                if self._lp(d, 1):
+                    continue                      # its data gradient reads the low-precision transposed pack instead
                 if l.W.shape[1] > 4 and ops.dgrad_t_supported(d) and id(l.W) not in transposed:
                     transposed.add(id(l.W))
                     items.append((st.value(l.W), st.transposed(l.W), d.C, d.kh * d.kw, d.K))
             elif n.op == 'upconv':
                 l = n.layer
                 d = self._upconv_desc(n, n.inputs[0].out)
+                if self._lp(d, 1):
+                    continue
                 if d.C > 4 and ops.dgrad_t_supported(d) and ('c', id(l.W)) not in transposed:
                     transposed.add(('c', id(l.W)))
                     items.append((n.aux['wpc'], n.aux['wpcT'], d.C, 9, d.K))
@@ -623,6 +669,10 @@ class NetPlan:
                     if n.op == 'deconv':
                         prog.append(("deconv_wgrad", lambda d=d, G=G, x=x, gw=gw, aw=aw, wo=wo:
                                      wo.conv2d_wgrad(d, G, x, gw, self.wgrad_ws, aw), conv_meta(ops, d, 2), wdev))
+                    elif n.op == 'conv' and self._lp(d, 2):
+                        prog.append(("conv_wgrad", lambda d=d, G=G, x=x, gw=gw, aw=aw, wo=wo:
+                                     wo.conv2d_wgrad_lp(d, x, G, gw, self.wgrad_ws, self.dtype, aw),
+                                     conv_meta(ops, d, 2, self.dtype), wdev))
                     else:
                         prog.append(("%s_wgrad" % n.op, lambda d=d, G=G, x=x, gw=gw, aw=aw, wo=wo:
                                      wo.conv2d_wgrad(d, x, G, gw, self.wgrad_ws, aw), conv_meta(ops, d, 2), wdev))
@@ -637,6 +687,12 @@ class NetPlan:
                         d2 = self._desc(n, G, gi)
                         prog.append(("deconv_dgrad", lambda d=d2, G=G, w=w, gi=gi, acc=acc:
                                      ops.conv2d_fwd(d, G, w, None, gi, 'linear', 0.0, acc), conv_meta(ops, d2, 0)))
+                    elif n.op == 'conv' and self._lp(self._desc(n, gi, G), 1):
+                        d2 = self._desc(n, gi, G)
+                        wqT = self._lp_pack_entry(prog, d2, w, ('w', id(l.W)), True, transposed)
+                        prog.append(("conv_dgrad", lambda d=d2, G=G, wqT=wqT, gi=gi, acc=acc:
+                                     ops.conv2d_dgrad_lp(d, G, wqT, gi, self.dtype, None, 'linear', 0.0, acc),
+                                     conv_meta(ops, d2, 3, self.dtype)))
                     elif n.op == 'conv' and l.W.shape[1] > 4 and ops.dgrad_t_supported(self._desc(n, gi, G)):
                         # data gradient as a forward-form conv on the transposed weights (LDS-patch kernels)
                         d2 = self._desc(n, gi, G)
@@ -669,8 +725,13 @@ class NetPlan:
                     if self.side is not None:
                         wdev, wo = self.side
                         prog.append(("fork", lambda wdev=wdev: wdev.wait_for(dev), None, wdev))
-                    prog.append(("upconv_wgrad", lambda d=d, x=x, G4=G4, dwpc=dwpc, wo=wo:
-                                 wo.conv2d_wgrad(d, x, G4, dwpc, self.wgrad_ws, False), conv_meta(ops, d, 2), wdev))
+                    if self._lp(d, 2):
+                        prog.append(("upconv_wgrad", lambda d=d, x=x, G4=G4, dwpc=dwpc, wo=wo:
+                                     wo.conv2d_wgrad_lp(d, x, G4, dwpc, self.wgrad_ws, self.dtype, False),
+                                     conv_meta(ops, d, 2, self.dtype), wdev))
+                    else:
+                        prog.append(("upconv_wgrad", lambda d=d, x=x, G4=G4, dwpc=dwpc, wo=wo:
+                                     wo.conv2d_wgrad(d, x, G4, dwpc, self.wgrad_ws, False), conv_meta(ops, d, 2), wdev))
                     prog.append(("expand_wgrad", lambda dwpc=dwpc, gw=gw, C=C, K=K, aw=aw, wo=wo:
                                  wo.upconv_expand_wgrad(dwpc, gw, C, K, aw), None, wdev))
                     bn_fed = len(n.consumers) == 1 and n.consumers[0].op == 'bn' and n.act == linear
@@ -678,7 +739,12 @@ class NetPlan:
                         prog.append(("bias_grad", lambda G=G, gb=gb, aw=aw, wo=wo: wo.channel_sum(G, gb, aw), None, wdev))
                 if need_dx:
                     gi, acc = target(xin)
-                    if C > 4 and ops.dgrad_t_supported(d):
+                    if self._lp(d, 1):
+                        wqT = self._lp_pack_entry(prog, d, wpc, ('c', id(l.W)), True, transposed)
+                        prog.append(("upconv_dgrad", lambda d=d, G4=G4, wqT=wqT, gi=gi, acc=acc:
+                                     ops.conv2d_dgrad_lp(d, G4, wqT, gi, self.dtype, None, 'linear', 0.0, acc),
+                                     conv_meta(ops, d, 3, self.dtype)))
+                    elif C > 4 and ops.dgrad_t_supported(d):
                         if ('c', id(l.W)) not in transposed:
                             transposed.add(('c', id(l.W)))
                             prog.append(("transpose_w", lambda d=d, wpc=wpc, wpcT=wpcT: ops.transpose_weights(d, wpc, wpcT)))
@@ -783,9 +849,13 @@ class NetPlan:
                 for l in input_grads}
 
 
-def conv_meta(ops, d, kind):
+def conv_meta(ops, d, kind, dtype='f32'):
     """roofline metadata of one conv launch: kernel variant name and ALGORITHMIC flops (2 x MACs)."""
-    return {"kernel": ops.conv_variant(d, kind),
+    if dtype != 'f32':
+        name = "lp_%s_kernel<%s, %d, %d>" % ("wgrad" if kind == 2 else "conv", dtype, d.kh, d.stride)
+    else:
+        name = ops.conv_variant(d, kind)
+    return {"kernel": name, "dtype": dtype,
             "flops": 2.0 * d.N * d.K * d.Ho * d.Wo * d.C * d.kh * d.kw,
             "geom": "N%d C%d %dx%d K%d k%d s%d" % (d.N, d.C, d.H, d.W, d.K, d.kh, d.stride)}
 

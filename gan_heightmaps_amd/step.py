@@ -49,8 +49,11 @@ def _interleave(a, b):
 class GanStep:
     def __init__(self, dev, dcgan_gen, dcgan_disc, p2p_gen, p2p_disc, alpha, lsgan, reconstruction, opt_spec,
                  train_mode='both', comm=None, use_graph=True, two_streams=True, force_exchange=False,
-                 side_streams=None):
+                 side_streams=None, dtype='f32'):
         self.dev = dev
+        # arithmetic of the convolution products (include/ghm.h GHM_DTYPE_*): 'f32' = the reference's floatX; 'bf16' /
+        # 'f16' = BASELINE configs 4 / 5 (matrix-core operands rounded, fp32 accumulation, fp32 tensors and optimiser)
+        self.dtype = dtype
         if side_streams is None:            # forked branches replay slowly inside a HIP graph: eager mode only
             side_streams = (not use_graph) and two_streams
         if side_streams and use_graph:
@@ -169,14 +172,14 @@ class GanStep:
         ca, H, W = d_in_layer.shape[1:]
         b.d_in = dA.empty((2 * B, ca, H, W))
         b.G = NetPlan(dA, oA, G, B, self.stores['dcgan_gen'], out_tensor=b.d_in.samples(B, 2 * B), name="G",
-                      side=self.side[0], rng_seed=self.rank)      # replicas draw different dropout masks
+                      side=self.side[0], rng_seed=self.rank, dtype=self.dtype)      # replicas draw different dropout masks
         b.D = NetPlan(dA, oA, D, 2 * B, self.stores['dcgan_disc'], inputs={d_in_layer: b.d_in}, name="D",
-                      side=self.side[0], bn_groups=2 if _has_bn(D) else 1)
+                      side=self.side[0], bn_groups=2 if _has_bn(D) else 1, dtype=self.dtype)
         b.P = NetPlan(dB, oB, P, 2 * B, self.stores['p2p_disc'], name="P", side=self.side[1],
-                      bn_groups=2 if _has_bn(P) else 1)
+                      bn_groups=2 if _has_bn(P) else 1, dtype=self.dtype)
         pa, pb = b.P.input_tensor(i_a), b.P.input_tensor(i_b)
         b.U = NetPlan(dB, oB, U, B, self.stores['p2p_gen'], out_tensor=pb.samples(B, 2 * B), name="U",
-                      side=self.side[1], rng_seed=self.rank)
+                      side=self.side[1], rng_seed=self.rank, dtype=self.dtype)
         b.z = b.G.input_nodes[0].out
         b.x = b.U.input_tensor(u_in_layer)
         b.y = dB.empty((B,) + tuple(pb.shape[1:]))
@@ -463,7 +466,8 @@ class GanStep:
         k = (key, B, deterministic)
         if k not in self._infer:
             lane = LANE_OF[key]
-            plan = NetPlan(self.devs[lane], self.ops[lane], self.nets[key], B, self.stores[key], name=key + "_infer")
+            plan = NetPlan(self.devs[lane], self.ops[lane], self.nets[key], B, self.stores[key], name=key + "_infer",
+                           dtype=self.dtype)
             prog = []
             plan.emit_forward(prog, deterministic=deterministic)
             self._infer[k] = (plan, prog)

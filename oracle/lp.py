@@ -1,0 +1,43 @@
+"""Reduced-precision convolution semantics of the MI355X path (TEST INFRASTRUCTURE ONLY; beyond the reference, which
+computes in floatX=float32 -- experiment.5.sh:5 -- so there is nothing in /root/reference to pin this on).
+
+BASELINE configs 4 / 5 ask for bf16 / fp16 matrix-core arithmetic: the HIP kernels (csrc/conv_lp.hip) round the two
+operands of every convolution product to bf16 (or fp16) with round-to-nearest-even, multiply exactly and accumulate
+in float32; activations, gradients, BatchNorm, losses, master weights and the optimiser stay float32.  This module
+states that rule in numpy so the kernels can be checked bit-tightly: conv(round(x), round(W)) in float64.
+"""
+import numpy as np
+
+from . import ops
+
+
+def round_bf16(a):
+    """float32 -> nearest bfloat16 (ties to even), returned as float32"""
+    a = np.ascontiguousarray(a, np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+    out = u.astype(np.uint32).view(np.float32).reshape(a.shape)
+    return np.where(np.isfinite(a), out, a)
+
+
+def round_f16(a):
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+ROUND = {'bf16': round_bf16, 'f16': round_f16, 'f32': lambda a: np.asarray(a, np.float32)}
+
+
+def conv2d_fwd(x, W, b, stride, pad, dtype):
+    r = ROUND[dtype]
+    return ops.conv2d_fwd(r(x).astype(np.float64), r(W).astype(np.float64),
+                          None if b is None else np.asarray(b, np.float64), stride, pad)
+
+
+def conv2d_vjp(x, W, dy, stride, pad, dtype):
+    """(dx, dW, db) with every matrix-core operand rounded: dx = conv^T(round(dy), round(W)),
+    dW = corr(round(x), round(dy)); db is a plain float32 sum (not a matrix-core product)."""
+    r = ROUND[dtype]
+    x64, W64, dy64 = (r(v).astype(np.float64) for v in (x, W, dy))
+    dx, dW, _ = ops.conv2d_vjp(x64, W64, dy64, stride, pad)
+    db = np.asarray(dy, np.float64).sum(axis=(0, 2, 3))
+    return dx, dW, db

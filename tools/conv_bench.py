@@ -17,6 +17,8 @@ def main():
     ap.add_argument("geom", type=int, nargs=8, help="N C H W K k stride pad")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
+                    help="bf16 / f16: the *_lp entry points (kinds fwd, dgrad_t, wgrad)")
     args = ap.parse_args()
     N, C, H, W, K, k, s, pad = args.geom
     dev = D.Device(0)
@@ -38,7 +40,26 @@ def main():
            "dgrad_t": lambda: ops.conv2d_dgrad_t(d, y, wT, dx),
            "dgrad": lambda: ops.conv2d_dgrad(d, y, w, dx),
            "wgrad": lambda: ops.conv2d_wgrad(d, x, y, dw, ws)}
+    if args.dtype != "f32":
+        dt = args.dtype
+        wq = dev.alloc(ops.lp_weight_bytes(d, False))
+        wqT = dev.alloc(ops.lp_weight_bytes(d, True))
+        ops.lp_pack_weights(d, w, wq, dt, False)
+        ops.lp_pack_weights(d, w, wqT, dt, True)
+        ws_lp = dev.alloc(max(ops.wgrad_lp_workspace(d), 16))
+        fns = {}
+        if ops.lp_supported(d, 0, dt):
+            fns["fwd"] = lambda: ops.conv2d_fwd_lp(d, x, wq, b, y, dt, 'lrelu', 0.2)
+        if ops.lp_supported(d, 1, dt):
+            fns["dgrad_t"] = lambda: ops.conv2d_dgrad_lp(d, y, wqT, dx, dt)
+        if ops.lp_supported(d, 2, dt):
+            fns["wgrad"] = lambda: ops.conv2d_wgrad_lp(d, x, y, dw, ws_lp, dt)
+        fns["pack"] = lambda: ops.lp_pack_weights(d, w, wq, dt, False)
+        fns["pack_t"] = lambda: ops.lp_pack_weights(d, w, wqT, dt, True)
     for i, kind in enumerate(args.kinds.split(",")):
+        if kind not in fns:
+            print("%-6s not served in %s" % (kind, args.dtype))
+            continue
         fn = fns[kind]
         for _ in range(3):
             fn()
@@ -48,8 +69,10 @@ def main():
             fn()
         dev.timer_stop(0)
         ms = dev.timer_ms(0) / args.reps
-        print("%-6s %-34s %8.3f ms  %7.1f TFLOP/s  (%.1f GFLOP)" %
-              (kind, ops.conv_variant(d, ["fwd", "dgrad", "wgrad", "dgrad_t"].index(kind)), ms, flops / ms / 1e9, flops / 1e9))
+        name = ("lp<%s>" % args.dtype) if args.dtype != "f32" else \
+            ops.conv_variant(d, ["fwd", "dgrad", "wgrad", "dgrad_t"].index(kind))
+        print("%-7s %-34s %8.3f ms  %7.1f TFLOP/s  (%.1f GFLOP)  N%d C%d %dx%d K%d k%d s%d" %
+              (kind, name, ms, flops / ms / 1e9, flops / 1e9, N, C, H, W, K, k, s))
     dev.close()
 
 
