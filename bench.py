@@ -24,6 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+LP_MFMA_PEAK_TFLOPS = 2500.0           # MI355X_MICROARCH.md: dense bf16 / fp16 v_mfma_f32_32x32x16 (not the 2:1-sparse 5 PF)
+PEAK = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16": LP_MFMA_PEAK_TFLOPS, "f16": LP_MFMA_PEAK_TFLOPS}
 JOINT_GFLOP_PER_IMG = 683.29           # algorithmic 2 x MACs of the joint train step
 
 
@@ -69,6 +71,12 @@ def main():
     ap.add_argument("--no-grad-streams", action="store_true",
                     help="keep the weight/bias gradients on the stage's own stream (default: a second stream per stage)")
     ap.add_argument("--profile", action="store_true", help="print a per-program-entry timing table to stderr")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
+                    help="arithmetic of the convolution products.  f32 (default) = the reference's floatX=float32 and the "
+                         "headline metric; bf16 / f16 = BASELINE configs 4 / 5 (matrix-core operands rounded, fp32 "
+                         "accumulation, fp32 tensors / master weights / optimiser): an additional line, never the headline")
+    ap.add_argument("--in-shp", type=int, default=512, choices=[512, 1024],
+                    help="1024 = BASELINE config 5 geometry (one more U-Net level and DCGAN stage; beyond the reference)")
     args = ap.parse_args()
 
     from gan_heightmaps_amd import device, dist
@@ -88,13 +96,24 @@ def main():
     comm = dist.Comm(cdev, rank, world) if world > 1 else None
     B = args.batch_per_gpu
     backend = dict(device=dev, comm=comm, use_graph=args.graph, seed=0, verbose=False, two_streams=not args.one_stream,
-                   side_streams=(not args.no_grad_streams) and not args.graph)
-    model = make_model('test1_nobn_bilin_both', **backend)
+                   side_streams=(not args.no_grad_streams) and not args.graph, dtype=args.dtype)
+    S = args.in_shp
+    if S == 512:
+        model = make_model('test1_nobn_bilin_both', **backend)
+    else:
+        # config 5: the same architecture functions one level deeper (p2p.py:137 asserts 512 in the reference)
+        from gan_heightmaps_amd.experiments import experiment_kwargs
+        from gan_heightmaps_amd.pix2pix import Pix2Pix
+        kw = experiment_kwargs('test1_nobn_bilin_both')
+        kw.update(in_shp=S, **backend)
+        kw['gen_params_dcgan'] = {'num_repeats': 0, 'div': [2, 2, 4, 4, 8, 8, 8, 8], 'final_size': S}
+        kw['disc_params_dcgan'] = dict(kw['disc_params_dcgan'], div=[8, 8, 4, 4, 4, 2, 2, 2], nch=1024)
+        model = Pix2Pix(**kw)
     if args.mode != 'both':
         # configs 2 / 3 of BASELINE.json: same nets, one stage trained
         model.engine.train_mode = args.mode
     eng = model.engine
-    Z, X, Y = synthetic_batch(B, 1000, 512, seed=1000 + rank)
+    Z, X, Y = synthetic_batch(B, 1000, S, seed=1000 + rank)
     b = eng.built(B)
     eng._upload(b, Z, X, Y)                      # inputs resident in HBM before the timed region
 
@@ -171,15 +190,18 @@ def main():
     out = {
         "metric": "512px heightmap+texture train images/sec", "value": round(value, 3), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "test1_nobn_bilin_both joint DCGAN+pix2pix train step (train_mode=%s), 512x512, "
-                               "batch %d per GPU, RMSprop lr 1e-4, LSGAN + 100*L1" % (args.mode, B),
-                   "global_batch": B * world, "in_shp": 512, "parallelism": "dp%d" % world,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "test1_nobn_bilin_both joint DCGAN+pix2pix train step (train_mode=%s), %dx%d, "
+                               "batch %d per GPU, RMSprop lr 1e-4, LSGAN + 100*L1%s"
+                               % (args.mode, S, S, B, "" if args.dtype == "f32" else
+                                  "; convolution products in %s on the matrix cores, fp32 accumulation / tensors / "
+                                  "master weights / optimiser" % args.dtype),
+                   "global_batch": B * world, "in_shp": S, "parallelism": "dp%d" % world,
                    "hip_graph": bool(args.graph),
                    "streams": (1 if eng.devs[0] is eng.devs[1] else 2) * (2 if eng.side[0] is not None else 1)},
-        "step_algorithmic_tflops": round(JOINT_GFLOP_PER_IMG * value / 1e3, 2) if args.mode == 'both' else None,
+        "step_algorithmic_tflops": round(JOINT_GFLOP_PER_IMG * value / 1e3, 2) if args.mode == 'both' and S == 512 else None,
         "step_frac_of_fp32_mfma_peak": round(JOINT_GFLOP_PER_IMG * value / world / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)
-        if args.mode == 'both' else None,
+        if args.mode == 'both' and S == 512 else None,
         # the nominal count above prices Upscale2D -> 5x5 convs at 25 MACs per output; they execute 9 (collapsed
         # 3x3 form): this is what the matrix cores actually do per second
         "step_executed_tflops": round(executed_flops_per_step / (ms_per_step * 1e-3) / 1e12 * world, 2)
@@ -192,21 +214,26 @@ def main():
         flops_per_launch = flops_per_step / launches_per_step
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")      # written by tools/pmc_traffic.py
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get(dominant, {}).get("hbm_bytes_per_launch")
+        for pmc in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):      # written by tools/pmc_traffic.py
+            pmc = os.path.join(ROOT, "profiles", pmc)
+            if traffic is None and os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get(dominant, {}).get("hbm_bytes_per_launch")
         iso = flops_per_launch / (isolated_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        # the dominant kernel is priced against the peak of the arithmetic IT runs in (a thin / small-map kernel that
+        # stays fp32 in a bf16 step is an fp32 kernel)
+        kdt = args.dtype if dominant.startswith("lp_") else "f32"
+        peak = PEAK[kdt]
+        out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "kernel_dtype": kdt,
+                           "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                            "concurrent_streams": (1 if eng.devs[0] is eng.devs[1] else 2) * (2 if eng.side[0] is not None else 1),
-                           "achieved_isolated": round(iso, 2), "frac_isolated": round(iso / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "achieved_isolated": round(iso, 2), "frac_isolated": round(iso / peak, 4),
                            "kernel": dominant, "launches_per_step": launches_per_step,
                            "avg_launch_ms": round(avg_ms, 4),
                            "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3),
                            "share_of_step_time": round(avg_ms * launches_per_step / ms_per_step, 3)}
     else:
         out["roofline"] = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and S == 512:
         out["cpu_baseline"] = cpu_baseline(1)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -138,11 +138,14 @@ struct LpConvArgs {
     int slabs_per_split;
 };
 
-template <int DT, int KS, int ST, int BM, int RT, int WM, int WN>
+template <int DT, int KS, int ST, int BM, int RT, int WM, int WN, int TW>
 __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
+    // TW = columns of the pixel tile (32, or 16 / 8 for narrow maps): the 32 pixel lanes of a fragment cover RPF = 32 / TW
+    // consecutive rows of TW columns; the block's tile is (RT * RPF) rows x TW columns
     constexpr int T = KS * KS;
+    constexpr int RPF = 32 / TW, ROWS = RT * RPF;
     constexpr int TM = BM / (WM * 32), TN = RT / WN;
-    constexpr int PH = (RT - 1) * ST + KS, PW = 31 * ST + KS;
+    constexpr int PH = (ROWS - 1) * ST + KS, PW = (TW - 1) * ST + KS;
     constexpr int PUNITS = 2 * PH * PW;
     constexpr int WUNITS = 2 * KS * BM;
     constexpr int NQ = (PUNITS + 255) / 256;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int kg = lane >> 5, li = lane & 31;
     const int ntr = (a.R + BM - 1) / BM;
-    const int tiles_x = a.W / 32, tiles_y = a.H / RT;
+    const int tiles_x = a.W / TW, tiles_y = a.H / ROWS;
     int L = lp_xcd_remap(blockIdx.x, gridDim.x);
     const int r0 = (L % ntr) * BM;
     L /= ntr;
@@ -164,7 +167,8 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
     L /= tiles_x;
     const int ty = L % tiles_y;
     const int n = L / tiles_y;
-    const int y0 = ty * RT, x0 = tx * 32;
+    const int y0 = ty * ROWS, x0 = tx * TW;
+    const int lx = li % TW, ly = li / TW;                 // this lane's pixel inside a fragment
     const int HW = a.H * a.W, HWin = a.Hin * a.Win;
     const int nslabs = a.CH / 16;
     const int s_begin = blockIdx.y * a.slabs_per_split;
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
     __syncthreads();
 
     const int wlane = kg * KS * BM + wm * (BM / WM) + li;
-    const int plane = kg * PH * PW + (wn * TN * ST) * PW + li * ST;
+    const int plane = kg * PH * PW + ((wn * TN * RPF + ly) * ST) * PW + lx * ST;
     int it = 0;
     for (int s = s_begin; s < s_end; ++s) {
         const int pbuf = (s - s_begin) & 1;
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[i] = Wb[b * BM + i * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = Pb[j * ST * PW + b];
+                for (int j = 0; j < TN; ++j) bf[j] = Pb[j * RPF * ST * PW + b];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -276,8 +280,8 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
     const int ru = r0 + wm * (BM / WM);
     const int rl = ru + 4 * kg;
     if (a.partial) {
-        float* const pb = a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HW + (long)(y0 + wn * TN) * a.W + x0;
-        const unsigned lo = 4u * kg * (unsigned)P + li;
+        float* const pb = a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HW + (long)(y0 + wn * TN * RPF) * a.W + x0;
+        const unsigned lo = 4u * kg * (unsigned)P + ly * a.W + lx;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                    float* rowp = pb + (long)k * P + j * a.W;
+                    float* rowp = pb + (long)k * P + j * RPF * a.W;
                     if (rl + k < a.R) rowp[lo] = acc[i][j][e];
                 }
         return;
@@ -294,8 +298,8 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
     if (tid < BM) sb[tid] = (a.bias && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
     __syncthreads();
     const float* const lb = sb + wm * (BM / WM) + 4 * kg;
-    float* const ub = a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN) * a.W + x0;
-    const unsigned lo = 4u * kg * (unsigned)HW + li;
+    float* const ub = a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN * RPF) * a.W + x0;
+    const unsigned lo = 4u * kg * (unsigned)HW + ly * a.W + lx;
     const bool pwl = a.act == GHM_ACT_LINEAR || a.act == GHM_ACT_RELU || a.act == GHM_ACT_LRELU;
     if (r0 + BM <= a.R && pwl) {
         const float slope = a.act == GHM_ACT_LINEAR ? 1.f : (a.act == GHM_ACT_RELU ? 0.f : a.alpha);
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                        float* rowp = ub + (long)k * HW + j * a.W;
+                        float* rowp = ub + (long)k * HW + j * RPF * a.W;
                         const float v = acc[i][j][e] + lb[k];
                         rowp[lo] = v > 0.f ? v : slope * v;
                     }
@@ -320,12 +324,12 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                        old[e] = (ub + (long)k * HW + j * a.W)[lo];
+                        old[e] = (ub + (long)k * HW + j * RPF * a.W)[lo];
                     }
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                        float* rowp = ub + (long)k * HW + j * a.W;
+                        float* rowp = ub + (long)k * HW + j * RPF * a.W;
                         const float v = acc[i][j][e] + lb[k] + old[e];
                         rowp[lo] = v > 0.f ? v : slope * v;
                     }
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
             for (int e = 0; e < 16; ++e) {
                 const int k = i * 32 + (e & 3) + 8 * (e >> 2);
                 if (rl + k < a.R) {
-                    float* rowp = ub + (long)k * HW + j * a.W;
+                    float* rowp = ub + (long)k * HW + j * RPF * a.W;
                     float v = acc[i][j][e] + lb[k];
                     if (a.accumulate) v += rowp[lo];
                     rowp[lo] = ghm_act(v, a.act, a.alpha);
@@ -726,7 +730,7 @@ namespace {
 
 struct LpPlan {
     bool ok;
-    int bm, rt, splits, slabs_per_split, grid;
+    int bm, rt, tw, splits, slabs_per_split, grid;
 };
 
 LpPlan lp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
@@ -735,10 +739,14 @@ LpPlan lp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
     if (getenv("GHM_NO_LP")) return p;
     if (!((ks == 3 && (st == 1 || st == 2)) || (ks == 5 && st == 1))) return p;
     p.bm = R >= 96 ? 128 : 64;
-    p.rt = st == 2 ? 4 : 8;
-    if (R < 32 || (W % 32) || (H % p.rt) || (CH % 16) || CH < 16) return p;
+    // pixel tile: 8 x 32 (stride 2: 4 x 32); narrow maps: 8 x 16 or 8 x 8 (fragments of 2 x 16 / 4 x 8 pixels)
+    p.tw = W % 32 == 0 ? 32 : (W % 16 == 0 ? 16 : 8);
+    p.rt = p.tw == 32 ? (st == 2 ? 4 : 8) : (p.tw == 16 ? 4 : 2);
+    const int rows = p.rt * (32 / p.tw);
+    if (R < 32 || (W % p.tw) || (H % rows) || (CH % 16) || CH < 16) return p;
+    if (getenv("GHM_LP_NO_NARROW") && p.tw != 32) return p;
     const int ntr = (R + p.bm - 1) / p.bm;
-    p.grid = ntr * (W / 32) * (H / p.rt) * N;
+    p.grid = ntr * (W / p.tw) * (H / rows) * N;
     const int nslabs = CH / 16;
     p.splits = 1;
     if (p.grid < num_cu + num_cu / 2) {
@@ -763,18 +771,30 @@ int lp_launch_conv(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a, int ks, int st)
         a.partial = (float*)ws;
     }
     const dim3 g(pl.grid, pl.splits);
-#define GHM_LP_CASE(KS_, ST_, BM_, RT_, WM_, WN_)                                                              \
-    if (ks == KS_ && st == ST_ && pl.bm == BM_) {                                                              \
-        hipLaunchKernelGGL((lp_conv_kernel<DT, KS_, ST_, BM_, RT_, WM_, WN_>), g, dim3(256), 0, ctx->stream, a); \
-        GHM_LAUNCH_CHECK();                                                                                    \
+#define GHM_LP_CASE(KS_, ST_, BM_, RT_, WM_, WN_, TW_)                                                              \
+    if (ks == KS_ && st == ST_ && pl.bm == BM_ && pl.tw == TW_ && pl.rt == RT_) {                                   \
+        hipLaunchKernelGGL((lp_conv_kernel<DT, KS_, ST_, BM_, RT_, WM_, WN_, TW_>), g, dim3(256), 0, ctx->stream, a); \
+        GHM_LAUNCH_CHECK();                                                                                         \
     } else
-    GHM_LP_CASE(5, 1, 128, 8, 2, 2)
-    GHM_LP_CASE(5, 1, 64, 8, 1, 4)
-    GHM_LP_CASE(3, 1, 128, 8, 2, 2)
-    GHM_LP_CASE(3, 1, 64, 8, 1, 4)
-    GHM_LP_CASE(3, 2, 128, 4, 2, 2)
-    GHM_LP_CASE(3, 2, 64, 4, 1, 4) {
-        ghm_set_error("no lp_conv variant for k=%d s=%d bm=%d", ks, st, pl.bm);
+    GHM_LP_CASE(5, 1, 128, 8, 2, 2, 32)
+    GHM_LP_CASE(5, 1, 64, 8, 1, 4, 32)
+    GHM_LP_CASE(3, 1, 128, 8, 2, 2, 32)
+    GHM_LP_CASE(3, 1, 64, 8, 1, 4, 32)
+    GHM_LP_CASE(3, 2, 128, 4, 2, 2, 32)
+    GHM_LP_CASE(3, 2, 64, 4, 1, 4, 32)
+    GHM_LP_CASE(5, 1, 128, 4, 2, 2, 16)
+    GHM_LP_CASE(5, 1, 64, 4, 1, 4, 16)
+    GHM_LP_CASE(3, 1, 128, 4, 2, 2, 16)
+    GHM_LP_CASE(3, 1, 64, 4, 1, 4, 16)
+    GHM_LP_CASE(3, 2, 128, 4, 2, 2, 16)
+    GHM_LP_CASE(3, 2, 64, 4, 1, 4, 16)
+    GHM_LP_CASE(5, 1, 128, 2, 2, 2, 8)
+    GHM_LP_CASE(5, 1, 64, 2, 2, 2, 8)
+    GHM_LP_CASE(3, 1, 128, 2, 2, 2, 8)
+    GHM_LP_CASE(3, 1, 64, 2, 2, 2, 8)
+    GHM_LP_CASE(3, 2, 128, 2, 2, 2, 8)
+    GHM_LP_CASE(3, 2, 64, 2, 2, 2, 8) {
+        ghm_set_error("no lp_conv variant for k=%d s=%d bm=%d tw=%d rt=%d", ks, st, pl.bm, pl.tw, pl.rt);
         return -3;
     }
 #undef GHM_LP_CASE

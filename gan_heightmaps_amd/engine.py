@@ -852,7 +852,8 @@ class NetPlan:
 def conv_meta(ops, d, kind, dtype='f32'):
     """roofline metadata of one conv launch: kernel variant name and ALGORITHMIC flops (2 x MACs)."""
     if dtype != 'f32':
-        name = "lp_%s_kernel<%s, %d, %d>" % ("wgrad" if kind == 2 else "conv", dtype, d.kh, d.stride)
+        fam = "wgrad" if kind == 2 else ("dgrad_s2" if kind in (1, 3) and d.stride == 2 else "conv")
+        name = "lp_%s_kernel<%s, %d, %d>" % (fam, dtype, d.kh, d.stride)
     else:
         name = ops.conv_variant(d, kind)
     return {"kernel": name, "dtype": dtype,

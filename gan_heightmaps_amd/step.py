@@ -54,6 +54,10 @@ class GanStep:
         # arithmetic of the convolution products (include/ghm.h GHM_DTYPE_*): 'f32' = the reference's floatX; 'bf16' /
         # 'f16' = BASELINE configs 4 / 5 (matrix-core operands rounded, fp32 accumulation, fp32 tensors and optimiser)
         self.dtype = dtype
+        # fp16 operands underflow below 6e-8 and the per-pixel gradients of the 512x512 layers sit around 1e-6..1e-9:
+        # the loss-gradient seeds are scaled by 2^15 (the largest seed, 2(d-t)/B, stays below 2) and the optimiser divides it out again (every gradient kernel is
+        # linear in its seed; gradients in HBM are fp32, so the scale costs nothing).  bf16 has fp32's range: scale 1.
+        self.loss_scale = 32768.0 if dtype == 'f16' else 1.0
         if side_streams is None:            # forked branches replay slowly inside a HIP graph: eager mode only
             side_streams = (not use_graph) and two_streams
         if side_streams and use_graph:
@@ -205,19 +209,21 @@ class GanStep:
         b.seed_D, b.seed_G = dA.empty(d_out.shape), dA.empty(d_fake.shape)
         b.seed_PD, b.seed_PG = dB.empty(p_out.shape), dB.empty(p_fake.shape)
 
+        LS = self.loss_scale
+
         def losses_a(prog, g):
             # (:107) gen_loss_dcgan, (:108) disc_loss_dcgan
-            prog.append(("loss", lambda: advA(d_fake, 1.0, slot(0), b.seed_G if g else None)))
-            prog.append(("loss", lambda: advA(d_real, 1.0, slot(1), b.seed_D.samples(0, B) if g else None)))
+            prog.append(("loss", lambda: advA(d_fake, 1.0, slot(0), b.seed_G if g else None, LS)))
+            prog.append(("loss", lambda: advA(d_real, 1.0, slot(1), b.seed_D.samples(0, B) if g else None, LS)))
             prog.append(("loss", lambda: advA(d_fake, 0.0, slot(1), b.seed_D.samples(B, 2 * B) if g else None,
-                                              1.0, True)))
+                                              LS, True)))
 
         def losses_b(prog, g):
             # (:110) gen_loss_p2p, (:121) disc_loss_p2p
-            prog.append(("loss", lambda: advB(p_fake, 1.0, slot(2), b.seed_PG if g else None)))
-            prog.append(("loss", lambda: advB(p_real, 1.0, slot(4), b.seed_PD.samples(0, B) if g else None)))
+            prog.append(("loss", lambda: advB(p_fake, 1.0, slot(2), b.seed_PG if g else None, LS)))
+            prog.append(("loss", lambda: advB(p_real, 1.0, slot(4), b.seed_PD.samples(0, B) if g else None, LS)))
             prog.append(("loss", lambda: advB(p_fake, 0.0, slot(4), b.seed_PD.samples(B, 2 * B) if g else None,
-                                              1.0, True)))
+                                              LS, True)))
 
         # ---- loss_fn (:143): forward + losses, BN running stats still update ----
         la, lb = list(fa), list(fb)
@@ -281,7 +287,7 @@ class GanStep:
                                     transposed=tdone)
             gu = gin[i_b]
             # (:115-117) recon loss and alpha * d recon / d U(X) added to the adversarial gradient
-            tb.append(("recon", lambda: oB.recon_loss(b.U.out, b.y, slot(3), gu, self.alpha, l2, True)))
+            tb.append(("recon", lambda: oB.recon_loss(b.U.out, b.y, slot(3), gu, self.alpha * LS, l2, True)))
             b.U.emit_backward(tb, gu, wgrad=True, transposed=tdone)
             if self.exchange:
                 e = xchg('p2p_gen', 1)
@@ -315,7 +321,7 @@ class GanStep:
                 if dB is not dA:
                     dB.wait_for(cdev)
             b.exchange.append(("wait_comm", rejoin, None, cdev))
-        gs = 1.0 / self.world
+        gs = 1.0 / (self.world * self.loss_scale)
         hp = self.opt_spec.hp
         b.update = [[], []]
         for k in keys:
