@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=4)
     ap.add_argument("--mode", default="both", choices=["both", "dcgan", "p2p"])
     ap.add_argument("--graph", action="store_true", help="replay the step as a captured HIP graph (no per-kernel events)")
+    ap.add_argument("--issue", default="recorded", choices=["recorded", "eager"],
+                    help="recorded (default): the step's multi-stream launch sequence is recorded once in libghm.so and "
+                         "every step is ONE ghm_step_run call; eager: one C call per kernel from Python")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--one-stream", action="store_true", help="run both GAN stages on a single HIP stream")
     ap.add_argument("--no-grad-streams", action="store_true",
@@ -95,7 +98,8 @@ def main():
     cdev = device.Device(local_rank) if world > 1 else None
     comm = dist.Comm(cdev, rank, world) if world > 1 else None
     B = args.batch_per_gpu
-    backend = dict(device=dev, comm=comm, use_graph=args.graph, seed=0, verbose=False, two_streams=not args.one_stream,
+    issue = True if args.graph else ('recorded' if args.issue == 'recorded' else False)
+    backend = dict(device=dev, comm=comm, use_graph=issue, seed=0, verbose=False, two_streams=not args.one_stream,
                    side_streams=(not args.no_grad_streams) and not args.graph, dtype=args.dtype)
     S = args.in_shp
     if S == 512:
@@ -117,7 +121,7 @@ def main():
     b = eng.built(B)
     eng._upload(b, Z, X, Y)                      # inputs resident in HBM before the timed region
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2 if issue == 'recorded' else 0)):     # recorded: call 0 eager, call 1 records
         eng.enqueue_train(b)
     eng.sync()
 
@@ -158,7 +162,7 @@ def main():
 
     def wrap(lane, e):
         if is_dom(e):
-            d = eng.devs[lane]
+            d = e[3] if len(e) > 3 and e[3] is not None else eng.devs[lane]
             d.timer_start(len(slots))
             e[1]()
             d.timer_stop(len(slots))
@@ -166,14 +170,23 @@ def main():
         else:
             e[1]()
 
+    if issue == 'recorded' and dominant:
+        # re-record the step with HIP-event brackets around every launch of the dominant kernel; the recorded timer
+        # slots advance by ``launches_per_step`` per replay, so every launch of the timed region has its own events
+        b.steps.pop('train', None)
+        eng.enqueue_train(b, wrap)              # records (with the brackets) and replays once: untimed
+        type(dev).step_timer_stride(b.steps['train'], launches_per_step)
+        rec_devs, inst_steps = list(slots), min(args.steps, 4000 // max(launches_per_step, 1) - 1)
+        eng.sync()
+
     # ---- timed region ----
     if comm is not None:
         comm.barrier()
     eng.sync()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        if args.graph:
-            eng.enqueue_train(b)
+        if issue is not False:
+            eng.enqueue_train(b)                # ONE ghm_step_run (recorded) / two graph launches (--graph)
         else:
             eng.enqueue_train(b, wrap if s < inst_steps else (lambda lane, e: e[1]()))
     eng.sync()
@@ -183,7 +196,14 @@ def main():
     if comm is not None:
         elapsed = comm.max_scalar(elapsed)
     losses = eng._read_losses()
-    slot = len(slots)
+    if issue == 'recorded' and dominant:
+        # replay r (1-based; replay 0 was the recording call) used slots [r * L, (r + 1) * L)
+        L_ = launches_per_step
+        first = args.steps - inst_steps + 1
+        timed = [(d, i + r * L_) for r in range(first, args.steps + 1) for i, d in enumerate(rec_devs)]
+    else:
+        timed = [(d, i) for i, d in enumerate(slots)]
+    slot = len(timed)
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = B * world * args.steps / elapsed
@@ -197,7 +217,8 @@ def main():
                                   "; convolution products in %s on the matrix cores, fp32 accumulation / tensors / "
                                   "master weights / optimiser" % args.dtype),
                    "global_batch": B * world, "in_shp": S, "parallelism": "dp%d" % world,
-                   "hip_graph": bool(args.graph),
+                   "hip_graph": bool(args.graph), "issue": "graph" if args.graph else args.issue,
+                   "host_calls_per_step": 1 if issue == 'recorded' else None,
                    "streams": (1 if eng.devs[0] is eng.devs[1] else 2) * (2 if eng.side[0] is not None else 1)},
         "step_algorithmic_tflops": round(JOINT_GFLOP_PER_IMG * value / 1e3, 2) if args.mode == 'both' and S == 512 else None,
         "step_frac_of_fp32_mfma_peak": round(JOINT_GFLOP_PER_IMG * value / world / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)
@@ -209,7 +230,7 @@ def main():
         "losses": [float(x) for x in losses],
     }
     if dominant and slot:
-        tot_ms = sum(d.timer_ms(i) for i, d in enumerate(slots))
+        tot_ms = sum(d.timer_ms(i) for d, i in timed)
         avg_ms = tot_ms / slot                           # in the timed region (the other stream keeps running)
         flops_per_launch = flops_per_step / launches_per_step
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12

@@ -41,6 +41,9 @@ SIGNATURES = {
     "ghm_graph_launch": [_p, _p],
     "ghm_graph_destroy": [_p],
     "ghm_step_build": [_i32, _p, _p, _p],
+    "ghm_step_record_begin": [_i32, _p, C.POINTER(_p)],
+    "ghm_step_record_end": [_p],
+    "ghm_step_timer_stride": [_p, _i32],
     "ghm_step_run": [_p],
     "ghm_step_destroy": [_p],
     "ghm_timer_start": [_p, _i32],

@@ -126,6 +126,16 @@ int ghm_allreduce_sum(ghm_ctx* ctx, float* buf, int64_t n) {
     // no identity shortcut: a caller that reduces on a context without a communicator is reducing on the wrong
     // context (its gradients would silently stay local while being scaled by 1/world)
     GHM_CHECK(ctx->comm != nullptr, "ghm_allreduce_sum on a context without a communicator (ghm_comm_init)");
+    if (ctx->rec) {         // part of a recorded step: the collective is issued at every replay
+        ghm_step* st = ctx->rec;
+        rccl_comm comm = (rccl_comm)ctx->comm;
+        hipStream_t s = ctx->stream;
+        st->cmds.emplace_back([=]() {
+            if (g_api.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT32, RCCL_SUM, comm, s) != 0 && st->err == hipSuccess)
+                st->err = hipErrorUnknown;
+        });
+        return 0;
+    }
     GHM_RCCL(g_api.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT32, RCCL_SUM, (rccl_comm)ctx->comm, ctx->stream));
     return 0;
 }

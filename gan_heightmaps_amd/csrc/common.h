@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <functional>
 #include <string>
+#include <vector>
 
 #include "../../include/ghm.h"
 
@@ -14,7 +16,27 @@ struct ghm_graph {
     hipGraphExec_t exec = nullptr;
 };
 
+struct ghm_ctx;
+
+// A train step as ONE call (ghm_step_run).  Two forms:
+//   graphs:   the captured HIP graph of each stage stream (ghm_step_build);
+//   recorded: the host's own launch sequence -- every kernel launch, stream wait, memset, timer and collective issued
+//             on the attached contexts between ghm_step_record_begin / _end is appended to ``cmds`` instead of being
+//             executed, and replayed in that order on the same streams.  This is the eager multi-stream schedule
+//             without the per-launch host work of the caller (HIP graphs replay forked streams slowly on this stack).
+struct ghm_step {
+    int n = 0;
+    ghm_ctx* ctx[8] = {};
+    ghm_graph* graph[8] = {};
+    bool recorded = false, recording = false;
+    std::vector<std::function<void()>> cmds;
+    long runs = 0;              // completed replays
+    int timer_stride = 0;       // recorded timer slots advance by this much per replay (0: reuse the slots)
+    hipError_t err = hipSuccess;
+};
+
 struct ghm_ctx {
+    ghm_step* rec = nullptr;       // non-null while a recorded step is being built on this context
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start[GHM_MAX_TIMERS] = {};
@@ -51,6 +73,31 @@ void ghm_set_error(const char* fmt, ...);
     } while (0)
 
 #define GHM_LAUNCH_CHECK() GHM_HIP(hipGetLastError())
+
+// Every kernel launch of the library goes through this: executed now, or appended to the step being recorded on the
+// context (the arguments are captured by value).  ``ctx`` is the ghm_ctx* in scope at every launch site.
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, ...) GHM_LAUNCH_IMPL((kernel), __VA_ARGS__)
+#define GHM_LAUNCH_IMPL(kernel, grid, block, lds, stream, ...)                                       \
+    do {                                                                                               \
+        if (ctx->rec) {                                                                                \
+            const dim3 g_ = (grid), b_ = (block);                                                      \
+            const size_t l_ = (size_t)(lds);                                                           \
+            hipStream_t s_ = (stream);                                                                 \
+            ctx->rec->cmds.emplace_back([=]() { kernel<<<g_, b_, l_, s_>>>(__VA_ARGS__); });          \
+        } else {                                                                                       \
+            kernel<<<(grid), (block), (lds), (stream)>>>(__VA_ARGS__);                                 \
+        }                                                                                              \
+    } while (0)
+
+// the same for the other stream operations (copies, memsets, waits, timers, collectives)
+template <typename F>
+static inline void ghm_submit(ghm_ctx* ctx, F f) {
+    if (ctx->rec)
+        ctx->rec->cmds.emplace_back(f);
+    else
+        f();
+}
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 

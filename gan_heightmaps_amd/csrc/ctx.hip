@@ -112,11 +112,29 @@ int ghm_d2h(ghm_ctx* ctx, void* dst_host, const void* src, size_t bytes) {
 }
 
 int ghm_d2d(ghm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (ctx->rec) {
+        ghm_step* st = ctx->rec;
+        hipStream_t s = ctx->stream;
+        st->cmds.emplace_back([=]() {
+            hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess && st->err == hipSuccess) st->err = e;
+        });
+        return 0;
+    }
     GHM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
 
 int ghm_memset_zero(ghm_ctx* ctx, void* dst, size_t bytes) {
+    if (ctx->rec) {
+        ghm_step* st = ctx->rec;
+        hipStream_t s = ctx->stream;
+        st->cmds.emplace_back([=]() {
+            hipError_t e = hipMemsetAsync(dst, 0, bytes, s);
+            if (e != hipSuccess && st->err == hipSuccess) st->err = e;
+        });
+        return 0;
+    }
     GHM_HIP(hipMemsetAsync(dst, 0, bytes, ctx->stream));
     return 0;
 }
@@ -130,6 +148,19 @@ int ghm_sync(ghm_ctx* ctx) {
 int ghm_stream_wait(ghm_ctx* ctx, ghm_ctx* other) {
     // everything enqueued on ``ctx`` after this call runs after everything enqueued on ``other`` so far
     GHM_CHECK(ctx->device == other->device, "ghm_stream_wait across devices");
+    if (ctx->rec) {
+        ghm_step* st = ctx->rec;
+        hipStream_t mine = ctx->stream, theirs = other->stream;
+        st->cmds.emplace_back([=]() {
+            hipEvent_t ev;
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(ev, theirs);
+            if (e == hipSuccess) e = hipStreamWaitEvent(mine, ev, 0);
+            if (e == hipSuccess) e = hipEventDestroy(ev);
+            if (e != hipSuccess && st->err == hipSuccess) st->err = e;
+        });
+        return 0;
+    }
     hipEvent_t ev;
     GHM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     GHM_HIP(hipEventRecord(ev, other->stream));
@@ -139,7 +170,7 @@ int ghm_stream_wait(ghm_ctx* ctx, ghm_ctx* other) {
 }
 
 int ghm_capture_begin(ghm_ctx* ctx) {
-    GHM_CHECK(!ctx->capturing, "nested capture");
+    GHM_CHECK(!ctx->capturing && !ctx->rec, "nested capture");
     GHM_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     ctx->capturing = true;
     return 0;
@@ -179,15 +210,9 @@ int ghm_graph_destroy(ghm_graph* g) {
     return 0;
 }
 
-// ---- a whole train step as one call: the captured graphs of its stages, one per stream ----
-struct ghm_step {
-    int n = 0;
-    ghm_ctx* ctx[4] = {};
-    ghm_graph* graph[4] = {};
-};
-
+// ---- a whole train step as one call (struct ghm_step: common.h) ----
 int ghm_step_build(int32_t n, ghm_ctx* const* ctxs, ghm_graph* const* graphs, ghm_step** out) {
-    GHM_CHECK(n >= 1 && n <= 4, "ghm_step_build: 1..4 stages");
+    GHM_CHECK(n >= 1 && n <= 8, "ghm_step_build: 1..8 stages");
     ghm_step* s = new ghm_step();
     s->n = n;
     for (int i = 0; i < n; ++i) {
@@ -199,18 +224,77 @@ int ghm_step_build(int32_t n, ghm_ctx* const* ctxs, ghm_graph* const* graphs, gh
     return 0;
 }
 
+int ghm_step_record_begin(int32_t n, ghm_ctx* const* ctxs, ghm_step** out) {
+    GHM_CHECK(n >= 1 && n <= 8, "ghm_step_record_begin: 1..8 contexts");
+    for (int i = 0; i < n; ++i)
+        GHM_CHECK(ctxs[i] && !ctxs[i]->rec && !ctxs[i]->capturing, "ghm_step_record_begin: context %d is busy", i);
+    ghm_step* s = new ghm_step();
+    s->n = n;
+    s->recording = true;
+    for (int i = 0; i < n; ++i) {
+        s->ctx[i] = ctxs[i];
+        ctxs[i]->rec = s;
+        ctxs[i]->capturing = true;      // the same restrictions as graph capture: no allocation, no synchronisation
+    }
+    *out = s;
+    return 0;
+}
+
+int ghm_step_record_end(ghm_step* s) {
+    GHM_CHECK(s && s->recording, "ghm_step_record_end without ghm_step_record_begin");
+    for (int i = 0; i < s->n; ++i) {
+        s->ctx[i]->rec = nullptr;
+        s->ctx[i]->capturing = false;
+    }
+    s->recording = false;
+    s->recorded = true;
+    return 0;
+}
+
+int ghm_step_timer_stride(ghm_step* s, int32_t stride) {
+    s->timer_stride = stride;
+    return 0;
+}
+
 int ghm_step_run(ghm_step* s) {
+    if (s->recorded) {
+        GHM_CHECK(!s->recording, "ghm_step_run while the step is still being recorded");
+        GHM_HIP(hipSetDevice(s->ctx[0]->device));
+        for (auto& c : s->cmds) c();
+        ++s->runs;
+        if (s->err != hipSuccess) {
+            ghm_set_error("recorded step: %s", hipGetErrorString(s->err));
+            s->err = hipSuccess;
+            return -1;
+        }
+        GHM_HIP(hipGetLastError());
+        return 0;
+    }
     for (int i = 0; i < s->n; ++i) GHM_HIP(hipGraphLaunch(s->graph[i]->exec, s->ctx[i]->stream));
     return 0;
 }
 
 int ghm_step_destroy(ghm_step* s) {
-    delete s;          // the graphs stay owned by their creator (ghm_graph_destroy)
+    if (s && s->recording) ghm_step_record_end(s);
+    delete s;          // graphs stay owned by their creator (ghm_graph_destroy)
     return 0;
+}
+
+static void timer_record(ghm_ctx* ctx, int slot, bool start) {
+    if (!ctx->ev_start[slot]) {
+        (void)hipEventCreate(&ctx->ev_start[slot]);
+        (void)hipEventCreate(&ctx->ev_stop[slot]);
+    }
+    (void)hipEventRecord(start ? ctx->ev_start[slot] : ctx->ev_stop[slot], ctx->stream);
 }
 
 int ghm_timer_start(ghm_ctx* ctx, int32_t slot) {
     GHM_CHECK(slot >= 0 && slot < GHM_MAX_TIMERS, "timer slot out of range");
+    if (ctx->rec) {         // recorded: the slot advances by the step's timer stride on every replay
+        ghm_step* st = ctx->rec;
+        st->cmds.emplace_back([=]() { timer_record(ctx, (int)((slot + st->runs * st->timer_stride) % GHM_MAX_TIMERS), true); });
+        return 0;
+    }
     if (!ctx->ev_start[slot]) {
         GHM_HIP(hipEventCreate(&ctx->ev_start[slot]));
         GHM_HIP(hipEventCreate(&ctx->ev_stop[slot]));
@@ -220,6 +304,12 @@ int ghm_timer_start(ghm_ctx* ctx, int32_t slot) {
 }
 
 int ghm_timer_stop(ghm_ctx* ctx, int32_t slot) {
+    if (ctx->rec) {
+        GHM_CHECK(slot >= 0 && slot < GHM_MAX_TIMERS, "timer slot out of range");
+        ghm_step* st = ctx->rec;
+        st->cmds.emplace_back([=]() { timer_record(ctx, (int)((slot + st->runs * st->timer_stride) % GHM_MAX_TIMERS), false); });
+        return 0;
+    }
     GHM_CHECK(slot >= 0 && slot < GHM_MAX_TIMERS && ctx->ev_stop[slot], "timer slot not started");
     GHM_HIP(hipEventRecord(ctx->ev_stop[slot], ctx->stream));
     return 0;

@@ -175,6 +175,24 @@ class Device:
         return st
 
     @staticmethod
+    def step_record_begin(devs):
+        """every operation issued on ``devs`` from now on is appended to the returned step instead of being executed
+        (ghm_step_record_begin); end with step_record_end, replay with step_run"""
+        n = len(devs)
+        ctxs = (C.c_void_p * n)(*[d.h for d in devs])
+        st = C.c_void_p()
+        call("ghm_step_record_begin", n, ctxs, C.byref(st))
+        return st
+
+    @staticmethod
+    def step_record_end(st):
+        call("ghm_step_record_end", st)
+
+    @staticmethod
+    def step_timer_stride(st, stride):
+        call("ghm_step_timer_stride", st, int(stride))
+
+    @staticmethod
     def step_run(st):
         call("ghm_step_run", st)
 

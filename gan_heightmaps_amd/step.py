@@ -58,10 +58,14 @@ class GanStep:
         # the loss-gradient seeds are scaled by 2^15 (the largest seed, 2(d-t)/B, stays below 2) and the optimiser divides it out again (every gradient kernel is
         # linear in its seed; gradients in HBM are fp32, so the scale costs nothing).  bf16 has fp32's range: scale 1.
         self.loss_scale = 32768.0 if dtype == 'f16' else 1.0
-        if side_streams is None:            # forked branches replay slowly inside a HIP graph: eager mode only
-            side_streams = (not use_graph) and two_streams
-        if side_streams and use_graph:
-            raise ValueError("side_streams needs use_graph=False")
+        # how a step is issued: False = eager (one C call per kernel), True = one captured HIP graph per stage stream,
+        # 'recorded' = the eager multi-stream launch sequence recorded once in the library and replayed by ONE
+        # ghm_step_run call per step (side streams, communication stream and collectives included)
+        assert use_graph in (True, False, 'recorded')
+        if side_streams is None:            # forked branches replay slowly inside a HIP graph: not in graph mode
+            side_streams = (use_graph is not True) and two_streams
+        if side_streams and use_graph is True:
+            raise ValueError("side_streams needs use_graph=False or 'recorded'")
         mk = type(dev)                      # second / side streams are further contexts of the same kind on this GPU
         mkops = getattr(dev, 'ops_class', Ops)
         self.devs = [dev, mk(dev.index) if two_streams else dev]
@@ -246,7 +250,7 @@ class GanStep:
         # that wrote the bucket (events recorded at this point of the program), the collectives run in host-enqueue
         # order, and that order is a pure function of the program -- identical on every rank.
         cdev, cops = self.cdev, self.cops
-        embed = self.exchange and not self.use_graph          # RCCL calls stay outside captured graphs
+        embed = self.exchange and self.use_graph is not True  # RCCL calls stay outside captured HIP graphs
         b.xchg = {}
 
         def xchg(k, lane):
@@ -357,7 +361,7 @@ class GanStep:
         """Run one launch list per stream: eager (interleaved so both streams fill) on the first call,
         captured into one HIP graph per stream on the second, replayed afterwards.  ``wrap(lane, entry)``
         replaces the plain call (used by bench.py to bracket kernels with HIP events; implies eager)."""
-        if wrap is not None or not self.use_graph:
+        if wrap is not None or self.use_graph is not True:
             for lane, e in _interleave(lanes[0], lanes[1]):
                 if wrap is not None:
                     wrap(lane, e)
@@ -414,13 +418,67 @@ class GanStep:
         if train:
             self.enqueue_train(b)
         else:
-            self._run_lanes(b, 'loss', b.loss_prog)
-            if self.exchange:
-                self._reduce_losses_now()
+            self._run_loss(b)
         return self._read_losses()
+
+    def _run_loss(self, b):
+        if self.use_graph == 'recorded':
+            self._run_recorded(b, 'loss')
+        else:
+            self._run_lanes(b, 'loss', b.loss_prog)
+        if self.exchange:
+            self._reduce_losses_now()
+
+    def _all_devs(self):
+        out = []
+        for d in list(self.devs) + [sd[0] for sd in self.side if sd is not None] + [self.cdev]:
+            if d is not None and all(d is not o for o in out):
+                out.append(d)
+        return out
+
+    def _sequence(self, b, name):
+        """the host-order launch sequence [(lane, entry)] of a whole call (both stage programs interleaved, then the
+        exchange, then the updates)"""
+        key = '_seq_' + name
+        if not hasattr(b, key):
+            if name == 'train':
+                seq = list(_interleave(b.train_compute[0], b.train_compute[1]))
+                seq += [(0, e) for e in b.exchange]
+                seq += list(_interleave(b.update[0], b.update[1]))
+            else:
+                seq = list(_interleave(b.loss_prog[0], b.loss_prog[1]))
+            setattr(b, key, seq)
+        return getattr(b, key)
+
+    def _run_recorded(self, b, name, wrap=None):
+        """call 0 eager (library workspaces take their size), call 1 records the sequence and replays it, later calls
+        are ONE ghm_step_run each.  ``wrap(lane, entry)`` at record time brackets entries with recorded timers."""
+        seq = self._sequence(b, name)
+        n = b.calls.get(name, 0)
+        b.calls[name] = n + 1
+        if n == 0:
+            for lane, e in seq:
+                e[1]()
+            return
+        b.steps = getattr(b, 'steps', {})
+        if name not in b.steps:
+            D = type(self.devs[0])
+            st = D.step_record_begin(self._all_devs())
+            try:
+                for lane, e in seq:
+                    if wrap is not None:
+                        wrap(lane, e)
+                    else:
+                        e[1]()
+            finally:
+                D.step_record_end(st)
+            b.steps[name] = st
+        type(self.devs[0]).step_run(b.steps[name])
 
     def enqueue_train(self, b, wrap=None):
         """one train step on the data already resident in b.z / b.x / b.y (asynchronous)"""
+        if self.use_graph == 'recorded':
+            return self._run_recorded(b, 'train', wrap)
         if self.exchange:
             self._run_lanes(b, 'train_compute', b.train_compute, wrap)     # eager: bucket all-reduces are inside
             for e in b.exchange:
@@ -438,9 +496,7 @@ class GanStep:
     def loss(self, Z, X, Y):
         b = self.built(int(np.shape(X)[0]))
         self._upload(b, Z, X, Y)
-        self._run_lanes(b, 'loss', b.loss_prog)
-        if self.exchange:
-            self._reduce_losses_now()
+        self._run_loss(b)
         return self._read_losses()
 
     def profile_train(self, B):

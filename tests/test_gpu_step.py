@@ -325,6 +325,49 @@ def test_gradient_side_streams_bitwise(dev):
     assert build_model(cfg, 11, dev).engine.side[0] is None
 
 
+@pytest.mark.parametrize("variant", ["plain", "adam_bn_disc", "one_rank_exchange"])
+def test_recorded_step_is_the_eager_schedule_in_one_call(dev, variant):
+    """use_graph='recorded' (ghm_step_record_begin / ghm_step_run): the eager four-stream launch sequence -- gradient
+    side streams, stream waits, (world-1) RCCL all-reduces on the communication stream, updates -- recorded once in the
+    library and replayed by ONE C call per step: bit-identical to eager, step after step, and loss_fn too; the learning
+    rate stays a device scalar (set_value between replays is seen); dropout counters advance on replay."""
+    from gan_heightmaps_amd import device, dist
+    over = dict(SMALL)
+    kw = {}
+    if variant == "adam_bn_disc":
+        over.update(opt='adam', lr=1e-3, disc_dcgan=dict(nch=16, div=[4, 2, 2], bn=True),
+                    disc_p2p=dict(nf=4, mul_factor=[1, 2], bn=True))
+    cfg = ostep.default_cfg(**over)
+    cdev = comm = None
+    if variant == "one_rank_exchange":
+        cdev = device.Device(dev.index)
+        comm = dist.Comm(cdev, 0, 1)
+        kw = dict(comm=comm, force_exchange=True)
+    try:
+        eager = build_model(cfg, 11, dev, use_graph=False, **kw)
+        rec = build_model(cfg, 11, dev, use_graph='recorded', **kw)
+        assert rec.engine.side[0] is not None                    # the recorded form keeps the side streams
+        for it in range(5):
+            Z, X, Y = ostep.synthetic_batch(4, cfg, seed=30 + it)
+            assert eager.train_fn(Z, X, Y) == rec.train_fn(Z, X, Y), it
+            if it == 2:
+                assert eager.loss_fn(Z, X, Y) == rec.loss_fn(Z, X, Y)
+                eager.lr.set_value(np.float32(3e-4))
+                rec.lr.set_value(np.float32(3e-4))
+            if it == 3:
+                assert eager.loss_fn(Z, X, Y) == rec.loss_fn(Z, X, Y)      # the recorded loss program, replayed
+        b = rec.engine.built(4)
+        assert 'train' in b.steps and 'loss' in b.steps and b.calls['train'] == 5
+        pa, pb = model_params(eager), model_params(rec)
+        for k in pa:
+            for u, v in zip(pa[k], pb[k]):
+                assert np.array_equal(u, v)
+    finally:
+        if comm is not None:
+            comm.close()
+            cdev.close()
+
+
 def test_dropout_generators_in_the_full_step(dev):
     """g_unet(dropout=True) + default_generator(dropout_p) inside Pix2Pix: train_fn / loss_fn run, the
     non-deterministic generator functions draw a fresh mask per call, the deterministic ones are repeatable
