@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--no-grad-streams", action="store_true",
                     help="keep the weight/bias gradients on the stage's own stream (default: a second stream per stage)")
     ap.add_argument("--profile", action="store_true", help="print a per-program-entry timing table to stderr")
+    ap.add_argument("--ablate", default="", help="TUNING ONLY (results are wrong): comma-separated program-entry labels or "
+                    "kernel-name prefixes whose launches are skipped, to see what a class of kernels costs inside the "
+                    "overlapped schedule; the JSON line is marked invalid")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
                     help="arithmetic of the convolution products.  f32 (default) = the reference's floatX=float32 and the "
                          "headline metric; bf16 / f16 = BASELINE configs 4 / 5 (matrix-core operands rounded, fp32 "
@@ -119,6 +122,15 @@ def main():
     eng = model.engine
     Z, X, Y = synthetic_batch(B, 1000, S, seed=1000 + rank)
     b = eng.built(B)
+    if args.ablate:
+        pats = [p for p in args.ablate.split(",") if p]
+
+        def dead(e):
+            k = e[2]["kernel"] if len(e) > 2 and e[2] else ""
+            return any(e[0] == p or (k and k.startswith(p)) for p in pats)
+        for lanes in (b.train_compute, b.update):
+            for i in (0, 1):
+                lanes[i][:] = [((e[0], (lambda: None)) + tuple(e[2:])) if dead(e) else e for e in lanes[i]]
     eng._upload(b, Z, X, Y)                      # inputs resident in HBM before the timed region
 
     for _ in range(max(args.warmup, 2 if issue == 'recorded' else 0)):     # recorded: call 0 eager, call 1 records
@@ -140,6 +152,12 @@ def main():
             e[1] += 1
             e[2] += meta["flops"] if meta else 0.0
         if args.profile and rank == 0:
+            streams = {}
+            for r0_, ms_ in zip(runs[0], [t[1] for t in table]):
+                if r0_[0] not in ("fork", "join"):
+                    streams[r0_[3]] = streams.get(r0_[3], 0.0) + ms_
+            print("isolated time per stream (A / B = DCGAN / pix2pix stage, ' = its gradient stream, C = communication): "
+                  + ", ".join("%s %.2f ms" % kv for kv in sorted(streams.items())), file=sys.stderr)
             tot = sum(v[0] for v in by_kernel.values())
             for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][0]):
                 print("%-44s %9.3f ms %5.1f%% n=%3d %8.1f GFLOP %6.1f TF/s" %
@@ -208,6 +226,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = B * world * args.steps / elapsed
     out = {
+        **({"INVALID": "ablation run (--ablate %s): kernels skipped, results wrong" % args.ablate} if args.ablate else {}),
         "metric": "512px heightmap+texture train images/sec", "value": round(value, 3), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -235,7 +254,8 @@ def main():
         flops_per_launch = flops_per_step / launches_per_step
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         traffic = None
-        for pmc in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):      # written by tools/pmc_traffic.py
+        kdt_name = args.dtype if dominant.startswith("lp_") else "f32"
+        for pmc in ("r02_pmc_traffic_%s.json" % ("f32" if kdt_name == "f32" else "bf16"), "r01_pmc_traffic.json"):    # tools/pmc_traffic.py
             pmc = os.path.join(ROOT, "profiles", pmc)
             if traffic is None and os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get(dominant, {}).get("hbm_bytes_per_launch")

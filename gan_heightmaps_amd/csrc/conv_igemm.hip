@@ -1135,11 +1135,16 @@ __global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(c
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int c0 = blockIdx.x * CB, n0 = blockIdx.y * BN;
+    // The row tiles (x) of one (filter tile, pixel split) read the SAME dy tile.  Workgroups go to the 8 XCDs round
+    // robin, so in dispatch order those tiles would fetch it into 8 different L2s; remapped, the blocks that share a
+    // dy tile are neighbours on one XCD (profiles/r01_pmc_traffic.json: 4-7x the operand bytes fetched before).
+    const int Lg = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+    const int bx = Lg % gridDim.x, by = (Lg / gridDim.x) % gridDim.y, bz = Lg / (gridDim.x * gridDim.y);
+    const int c0 = bx * CB, n0 = by * BN;
     const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
     const int slabs_per_row = a.Wo / BKP;
     const int total_slabs = a.N * a.Ho * slabs_per_row;
-    const int s_begin = blockIdx.z * a.slabs_per_split;
+    const int s_begin = bz * a.slabs_per_split;
     const int s_end = min(s_begin + a.slabs_per_split, total_slabs);
 
     // ---- per-thread constants of the patch fetch ----
@@ -1270,7 +1275,7 @@ __global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(c
         __syncthreads();
     }
 
-    float* ob = a.out + (long)blockIdx.z * a.split_stride;
+    float* ob = a.out + (long)bz * a.split_stride;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * (BN / WN) + j * 32 + frag_i;

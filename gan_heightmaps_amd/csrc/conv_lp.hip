@@ -567,11 +567,14 @@ __global__ __launch_bounds__(256, 2) void lp_wgrad_kernel(const LpWgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int kg = lane >> 5, li = lane & 31;
-    const int c0 = blockIdx.x * CBW, k0 = blockIdx.y * BN;
+    // blocks that share a dy tile (same filter tile and pixel split, different row tiles) become neighbours on one XCD
+    const int Lg = lp_xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+    const int bx = Lg % gridDim.x, by = (Lg / gridDim.x) % gridDim.y, bz = Lg / (gridDim.x * gridDim.y);
+    const int c0 = bx * CBW, k0 = by * BN;
     const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
     const int segs_per_row = a.Wo / SPX;
     const int total_slabs = a.N * a.Ho * segs_per_row;
-    const int s_begin = blockIdx.z * a.slabs_per_split;
+    const int s_begin = bz * a.slabs_per_split;
     const int s_end = min(s_begin + a.slabs_per_split, total_slabs);
 
     // rows ROWS..127 of the A tiles are never written: zero them once (both buffers)
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void lp_wgrad_kernel(const LpWgradArgs a) {
         __syncthreads();
     }
 
-    float* ob = a.out + (long)blockIdx.z * a.split_stride;
+    float* ob = a.out + (long)bz * a.split_stride;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = k0 + wn * (BN / WN) + j * 32 + li;

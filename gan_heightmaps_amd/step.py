@@ -505,22 +505,24 @@ class GanStep:
         b = self.built(B)
         out = []
 
-        def timed(entries, dev):
+        def timed(entries, dev, lane):
             for e in entries:
-                d = e[3] if len(e) > 3 and e[3] is not None else dev
+                side = len(e) > 3 and e[3] is not None
+                d = e[3] if side else dev
                 d.timer_start(1)
                 e[1]()
                 d.timer_stop(1)
-                out.append((e[0], d.timer_ms(1), e[2] if len(e) > 2 else None))
+                meta = e[2] if len(e) > 2 else None
+                out.append((e[0], d.timer_ms(1), meta, "%s%s" % ("AB"[lane] if lane in (0, 1) else "C", "'" if side else "")))
 
         for lane in (0, 1):
-            timed(b.train_compute[lane], self.devs[lane])
+            timed(b.train_compute[lane], self.devs[lane], lane)
         if self.exchange:
             self.sync()
-            timed(b.exchange, self.cdev)
+            timed(b.exchange, self.cdev, 2)
             self.sync()
         for lane in (0, 1):
-            timed(b.update[lane], self.devs[lane])
+            timed(b.update[lane], self.devs[lane], lane)
         return out
 
     # ---- forward-only entry points (pix2pix.py:144-147) -------------------------------------------------
