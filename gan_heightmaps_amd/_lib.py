@@ -57,6 +57,7 @@ SIGNATURES = {
     "ghm_conv2d_wgrad": [_p, _D, _p, _p, _p, _p, _i32],
     "ghm_lp_weight_bytes": [_D, _i32, C.POINTER(C.c_size_t)],
     "ghm_lp_pack_weights": [_p, _D, _p, _p, _i32, _i32],
+    "ghm_lp_pack_batched": [_p, _p, _i32, _i32, _i32],
     "ghm_conv2d_fwd_lp": [_p, _D, _p, _p, _p, _p, _i32, _f, _i32, _i32],
     "ghm_conv2d_dgrad_lp": [_p, _D, _p, _p, _p, _p, _i32, _f, _i32, _i32],
     "ghm_conv2d_wgrad_lp_workspace": [_D, C.POINTER(C.c_size_t)],

@@ -340,6 +340,10 @@ __global__ __launch_bounds__(256) void direct_smallr_kernel(const IgemmArgs a) {
     const int uu = rem / a.Ws, vv = rem - uu * a.Ws;
     const float* inb = a.in + (long)n * a.in_nstride;
     const int HinWin = a.Hin * a.Win;
+    // a long channel reduction with few output pixels is split over blockIdx.y (slabs_per_split = channels per slice):
+    // 2048 threads each walking 512 channels x 9 taps is latency-bound, 32 slices of 16 channels fill the chip
+    const int ch_begin = blockIdx.y * a.slabs_per_split;
+    const int ch_end = min(a.CH, ch_begin + a.slabs_per_split);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < a.ntaps; ++t) {
         const int y = uu * a.ss + a.di[t], x = vv * a.ss + a.dj[t];
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(256) void direct_smallr_kernel(const IgemmArgs a) {
         const float* src = inb + (y * a.Win + x);
         const int tapw = a.wi[t];
 #pragma unroll 4
-        for (int ch = 0; ch < a.CH; ++ch) {
+        for (int ch = ch_begin; ch < ch_end; ++ch) {
             const float v = ok ? src[(long)ch * HinWin] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -358,6 +362,12 @@ __global__ __launch_bounds__(256) void direct_smallr_kernel(const IgemmArgs a) {
                 }
             }
         }
+    }
+    if (a.partial) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < a.R) a.partial[((long)blockIdx.y * a.R + r) * P + p] = acc[r];
+        return;
     }
     float* ob = a.out + (long)n * a.out_nstride + (long)(uu * a.os + a.ou) * a.Wout + (vv * a.os + a.ov);
     const int HWout = a.Hout * a.Wout;
@@ -371,6 +381,51 @@ __global__ __launch_bounds__(256) void direct_smallr_kernel(const IgemmArgs a) {
             *o = ghm_act(v, a.act, a.alpha);
         }
     }
+}
+
+// Data gradient of a convolution with <= 4 filters (d_out, pd_out: architectures/dcgan.py:50, p2p.py:289): the
+// reduction runs over those few filters and the taps, so it is element-wise work -- one thread per dx element, any
+// stride.  (Through the implicit-GEMM tiles this took 4 parity launches with a 16-deep K slab holding one real row.)
+struct SmallKDgradArgs {
+    const float* dy;
+    const float* wp;       // [C][T][K]
+    const float* bias;
+    float* dx;
+    int N, C, H, W, K, Ho, Wo, kh, kw, stride, pad;
+    long x_nstride, y_nstride;
+    int act;
+    float alpha;
+    int accumulate;
+};
+
+__global__ __launch_bounds__(256) void smallk_dgrad_kernel(const SmallKDgradArgs a) {
+    const long HW = (long)a.H * a.W;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)a.N * a.C * HW) return;
+    const long nc = idx / HW;
+    const int rem = (int)(idx - nc * HW), u = rem / a.W, v = rem - u * a.W;
+    const int n = (int)(nc / a.C), c = (int)(nc - (long)n * a.C);
+    const float* dyb = a.dy + (long)n * a.y_nstride;
+    const float* wc = a.wp + (long)c * a.kh * a.kw * a.K;
+    const int HoWo = a.Ho * a.Wo;
+    float s = a.bias ? a.bias[c] : 0.f;
+    for (int ta = 0; ta < a.kh; ++ta) {
+        const int yy = u + a.pad - ta;
+        if (yy < 0 || yy % a.stride) continue;
+        const int i = yy / a.stride;
+        if (i >= a.Ho) continue;
+        for (int tb = 0; tb < a.kw; ++tb) {
+            const int xx = v + a.pad - tb;
+            if (xx < 0 || xx % a.stride) continue;
+            const int j = xx / a.stride;
+            if (j >= a.Wo) continue;
+            const float* w = wc + (ta * a.kw + tb) * a.K;
+            for (int k = 0; k < a.K; ++k) s = fmaf(dyb[(long)k * HoWo + i * a.Wo + j], w[k], s);
+        }
+    }
+    float* o = a.dx + (long)n * a.x_nstride + (long)c * HW + rem;
+    if (a.accumulate) s += *o;
+    *o = ghm_act(s, a.act, a.alpha);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1464,6 +1519,24 @@ int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
     a.slabs_per_split = 1 << 30;
     if (const char* f = getenv("GHM_ABLATE")) a.debug = atoi(f);
     if (a.R <= 4) {
+        a.slabs_per_split = a.CH;
+        if (P <= 65536 && a.CH >= 64 && getenv("GHM_NO_SMALLR_SPLIT") == nullptr) {
+            // few output pixels, long channel reduction: slices of >= 8 channels until ~4 blocks per CU are in flight
+            int S = (4 * ctx->num_cu + ceil_div(P, 256) - 1) / ceil_div(P, 256);
+            if (S > a.CH / 8) S = a.CH / 8;
+            if (S > 1) {
+                a.slabs_per_split = ceil_div(a.CH, S);
+                S = ceil_div(a.CH, a.slabs_per_split);
+                void* ws = nullptr;
+                if (int e = ghm_scratch(ctx, (size_t)S * a.R * P * sizeof(float), &ws)) return e;
+                a.partial = (float*)ws;
+                hipLaunchKernelGGL((direct_smallr_kernel<WT>), dim3(ceil_div(P, 256), S), dim3(256), 0, ctx->stream, a);
+                GHM_LAUNCH_CHECK();
+                hipLaunchKernelGGL(igemm_splitk_epilogue, dim3(ceil_div(P * a.R, 256)), dim3(256), 0, ctx->stream, a, S);
+                GHM_LAUNCH_CHECK();
+                return 0;
+            }
+        }
         if (P <= 16384 && (long)a.ntaps * a.CH >= 256) {
             hipLaunchKernelGGL((direct_smallr_wave_kernel<WT>), dim3(ceil_div(P, 4)), dim3(256), 0, ctx->stream, a);
         } else {
@@ -1760,6 +1833,19 @@ int ghm_conv2d_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, cons
         return thin_fanout_dgrad(ctx, d, dy, wp, bias, dx, act, alpha, accumulate);
     if (thin_fanin_s2_ok(d, dx)) return thin_fanin_s2(ctx, d, dy, wp, bias, dx, act, alpha, accumulate);
     if (d->C <= 4 && thin_fanin_s1_dgrad_ok(d)) return thin_fanin_s1_dgrad(ctx, d, dy, wp, bias, dx, act, alpha, accumulate);
+    if (d->K <= 4 && d->C > 4 && getenv("GHM_NO_SMALLK_DGRAD") == nullptr) {
+        SmallKDgradArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.dy = dy; sa.wp = wp; sa.bias = bias; sa.dx = dx;
+        sa.N = d->N; sa.C = d->C; sa.H = d->H; sa.W = d->W; sa.K = d->K; sa.Ho = d->Ho; sa.Wo = d->Wo;
+        sa.kh = d->kh; sa.kw = d->kw; sa.stride = d->stride; sa.pad = d->pad;
+        sa.x_nstride = d->x_nstride; sa.y_nstride = d->y_nstride;
+        sa.act = act; sa.alpha = alpha; sa.accumulate = accumulate;
+        hipLaunchKernelGGL(smallk_dgrad_kernel, dim3(ceil_div((long)d->N * d->C * d->H * d->W, 256)), dim3(256), 0,
+                           ctx->stream, sa);
+        GHM_LAUNCH_CHECK();
+        return 0;
+    }
     if (taps_as_rows(d, d->C)) {
         const int T = d->kh * d->kw;
         void* ws = nullptr;
@@ -2070,6 +2156,10 @@ int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t 
     }
     if (kind == 1 && thin_fanin_s2_ok(d, nullptr)) {
         snprintf(out, out_len, "fanin_s2_kernel<%d>", d->kh);
+        return 0;
+    }
+    if (kind == 1 && d->K <= 4 && d->C > 4 && getenv("GHM_NO_SMALLK_DGRAD") == nullptr) {
+        snprintf(out, out_len, "smallk_dgrad_kernel");
         return 0;
     }
     if (kind == 2 && thin_wgrad_ok(d, nullptr, nullptr)) {

@@ -112,6 +112,38 @@ __global__ __launch_bounds__(256) void lp_pack_t_kernel(const float* __restrict_
     wq[idx] = lp_pack8<DT>(v);
 }
 
+// every pack of a net in ONE launch: a device table of {wp, wq, red, T, rows, nblk, rpad, transposed, first block};
+// a block (256 units) finds its item by a linear scan of the (<= 128-entry) table
+struct LpPackItem {
+    const float* wp;
+    u32x4* wq;
+    int red, T, rows, nblk, rpad, transposed, block_begin, pad_;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void lp_pack_batched_kernel(const LpPackItem* __restrict__ items, int n) {
+    int li = 0;
+    while (li + 1 < n && (int)blockIdx.x >= items[li + 1].block_begin) ++li;
+    const LpPackItem it = items[li];
+    const long idx = (long)(blockIdx.x - it.block_begin) * 256 + threadIdx.x;
+    if (idx >= (long)it.nblk * it.T * it.rpad) return;
+    const int r = (int)(idx % it.rpad);
+    const long bt = idx / it.rpad;
+    const int tap = (int)(bt % it.T), cb = (int)(bt / it.T);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cb * 8 + j;
+        const bool ok = c < it.red && r < it.rows;
+        // plain: wp[c][tap][r] (reduction over the conv's input channels c, rows = filters)
+        // transposed: element (k = c, tapT = tap, row = input channel r) = wp[r][T-1-tap][k]
+        const long src = it.transposed ? ((long)r * it.T + (it.T - 1 - tap)) * it.red + c
+                                       : ((long)c * it.T + tap) * it.rows + r;
+        v[j] = ok ? it.wp[src] : 0.f;
+    }
+    it.wq[idx] = lp_pack8<DT>(v);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Forward-form convolution (forward pass; stride-1 data gradient on the transposed pack; 3x3 stride-2 forward).
 // A block owns BM output channels x (RT rows x 32 columns) of one image.  K loop: slabs of 16 input channels; inside
@@ -975,6 +1007,20 @@ int ghm_lp_pack_weights(ghm_ctx* ctx, const ghm_conv_desc* d, const float* wp, v
         else
             hipLaunchKernelGGL((lp_pack_t_kernel<GHM_DTYPE_F16>), g, b, 0, ctx->stream, wp, (u32x4*)wq, d->C, T, d->K, nblk, rp);
     }
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_lp_pack_batched(ghm_ctx* ctx, const void* table, int32_t n_items, int32_t total_blocks, int32_t dtype) {
+    static_assert(sizeof(LpPackItem) == 48, "table layout is part of the ABI (see ghm.h)");
+    GHM_CHECK(dtype == GHM_DTYPE_BF16 || dtype == GHM_DTYPE_F16, "ghm_lp_pack_batched: dtype %d", dtype);
+    if (n_items <= 0 || total_blocks <= 0) return 0;
+    if (dtype == GHM_DTYPE_BF16)
+        hipLaunchKernelGGL((lp_pack_batched_kernel<GHM_DTYPE_BF16>), dim3(total_blocks), dim3(256), 0, ctx->stream,
+                           (const LpPackItem*)table, n_items);
+    else
+        hipLaunchKernelGGL((lp_pack_batched_kernel<GHM_DTYPE_F16>), dim3(total_blocks), dim3(256), 0, ctx->stream,
+                           (const LpPackItem*)table, n_items);
     GHM_LAUNCH_CHECK();
     return 0;
 }

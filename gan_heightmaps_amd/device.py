@@ -309,6 +309,24 @@ class Ops:
     def lp_pack_weights(self, d, wp, wq, dtype, transposed=False):
         call("ghm_lp_pack_weights", self.h, C.byref(d), _vp(wp), _vp(wq), DTYPE_CODES[dtype], int(transposed))
 
+    def lp_pack_table(self, items):
+        """items: [(wp DevTensor | ptr, wq ptr, red, T, rows, transposed)] -> (device table ptr, n, total blocks) for
+        lp_pack_batched (uploaded once: the pointers are fixed for the life of a plan)"""
+        rec = np.zeros(len(items), dtype=[('wp', '<u8'), ('wq', '<u8'), ('red', '<i4'), ('T', '<i4'), ('rows', '<i4'),
+                                          ('nblk', '<i4'), ('rpad', '<i4'), ('tr', '<i4'), ('b0', '<i4'), ('pad', '<i4')])
+        b0 = 0
+        for i, (wp, wq, red, T, rows, tr) in enumerate(items):
+            nblk, rpad = (red + 15) // 16 * 2, (rows + 127) // 128 * 128
+            rec[i] = (wp.ptr if isinstance(wp, DevTensor) else int(wp), int(wq), red, T, rows, nblk, rpad, int(tr), b0, 0)
+            b0 += (nblk * T * rpad + 255) // 256
+        ptr = self.dev.alloc(max(rec.nbytes, 48))
+        self.dev.h2d(ptr, rec.view(np.uint8))
+        return ptr, len(items), b0
+
+    def lp_pack_batched(self, table, dtype):
+        ptr, n, blocks = table
+        call("ghm_lp_pack_batched", self.h, C.c_void_p(ptr), n, blocks, DTYPE_CODES[dtype])
+
     def conv2d_fwd_lp(self, d, x, wq, bias, y, dtype, act='linear', alpha=0.0, accumulate=False):
         call("ghm_conv2d_fwd_lp", self.h, C.byref(d), _vp(x), _vp(wq), _vp(bias), _vp(y), ACT_CODES[act], alpha,
              int(accumulate), DTYPE_CODES[dtype])

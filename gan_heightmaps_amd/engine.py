@@ -315,6 +315,32 @@ class NetPlan:
             self.rng_counter = dev.zeros((1, 1, 1, 1))
         for i, n in enumerate(self.dropout_nodes):
             n.aux['key'] = (rng_seed * 0x9E3779B1 + (i + 1) * 0x85EBCA77) & 0xffffffff
+        self._lp_wq, self._lp_table = {}, None
+        if self.dtype != 'f32':
+            self._plan_lp_packs()
+
+    def _plan_lp_packs(self):
+        """bf16 / fp16 weight packs of the whole net (forward and transposed, plain and collapsed up-sample convs):
+        buffers + ONE device table, refreshed by one ghm_lp_pack_batched launch at the start of every forward program
+        (after the collapse of the generator's 5x5 weights)"""
+        items = []
+        for n in self.order:
+            if n.op == 'conv':
+                d = self._desc(n, n.inputs[0].out, n.out)
+                src, key = self.store.value(n.layer.W), ('w', id(n.layer.W))
+            elif n.op == 'upconv':
+                d = self._upconv_desc(n, n.inputs[0].out)
+                src, key = n.aux['wpc'], ('c', id(n.layer.W))
+            else:
+                continue
+            T = d.kh * d.kw
+            for transposed, kind in ((False, 0), (True, 1)):
+                if self._lp(d, kind) and (key, transposed) not in self._lp_wq:
+                    wq = self.store.lp_pack((key, transposed, self.dtype), self.ops.lp_weight_bytes(d, transposed))
+                    self._lp_wq[(key, transposed)] = wq
+                    items.append((src, wq, d.K if transposed else d.C, T, d.C if transposed else d.K, transposed))
+        if items:
+            self._lp_table = self.ops.lp_pack_table(items)
 
     # ---- shapes and placement ----------------------------------------------------------------
     def _shapes(self):
@@ -417,11 +443,20 @@ class NetPlan:
         K = n.shape[1]
         return conv_desc(x_t.N, x_t.Cc, x_t.H, x_t.W, 4 * K, 3, 3, 1, 1, x_t.nstride, 4 * K * x_t.H * x_t.W)
 
+    def _use_dgrad_t(self, d, W):
+        """data gradient through the transposed weight copy (forward-form kernels)?  Not for <= 4 filters unless the
+        thin fan-out kernel serves them: their reduction is element-wise work (smallk_dgrad_kernel)"""
+        if W.shape[1] <= 4 or not self.ops.dgrad_t_supported(d):
+            return False
+        return d.K > 4 or self.ops.conv_variant(d, 3).startswith("fanout_kernel")
+
     def _lp(self, d, kind):
         return self.dtype != 'f32' and self.ops.lp_supported(d, kind, self.dtype)
 
     def _lp_pack_entry(self, prog, d, w_src, key, transposed, done):
         """-> device pointer of the bf16 / fp16 pack of ``w_src``; emits the refresh once per program set ``done``"""
+        if (key, transposed) in self._lp_wq:
+            return self._lp_wq[(key, transposed)]         # refreshed by the batched pack at the start of the forward
         wq = self.store.lp_pack((key, transposed, self.dtype), self.ops.lp_weight_bytes(d, transposed))
         if done is None or (key, transposed) not in done:
             if done is not None:
@@ -447,6 +482,12 @@ class NetPlan:
         ops, st = self.ops, self.store
         if self.dropout_nodes and not deterministic:
             prog.append(("rng_tick", lambda c=self.rng_counter: ops.counter_tick(c)))
+        hoist = self._lp_table is not None
+        if hoist:
+            for n in self.order:
+                if n.op == 'upconv':
+                    self._emit_collapse(prog, n)
+            prog.append(("lp_pack", lambda t=self._lp_table: ops.lp_pack_batched(t, self.dtype)))
         for n in self.order:
             y = n.out
             if n.op in ('input', 'reshape', 'concat'):
@@ -511,8 +552,8 @@ class NetPlan:
                 wpc, b4 = n.aux['wpc'], n.aux['b4']
                 C, K = x.Cc, n.shape[1]
                 y4 = y.reshape((x.N, 4 * K, x.H, x.W))
-                prog.append(("collapse_w", lambda w5=w5, b=b, wpc=wpc, b4=b4, C=C, K=K:
-                             ops.upconv_collapse_weights(w5, b, wpc, b4, C, K)))
+                if not hoist:
+                    self._emit_collapse(prog, n)
                 if self._lp(d, 0):
                     wq = self._lp_pack_entry(prog, d, wpc, ('c', id(n.layer.W)), False, None)    # after collapse_w
                     prog.append(("upconv_fwd", lambda d=d, x=x, wq=wq, b4=b4, y4=y4, a=a:
@@ -542,6 +583,13 @@ class NetPlan:
             else:
                 raise NotImplementedError(n.op)
 
+    def _emit_collapse(self, prog, n):
+        st, ops = self.store, self.ops
+        w5, b = st.value(n.layer.W), st.value(n.layer.b)
+        C, K = n.inputs[0].shape[1], n.shape[1]
+        prog.append(("collapse_w", lambda w5=w5, b=b, wpc=n.aux['wpc'], b4=n.aux['b4'], C=C, K=K:
+                     ops.upconv_collapse_weights(w5, b, wpc, b4, C, K)))
+
     def emit_transposes(self, prog, transposed):
         """One launch that refreshes every transposed weight copy the data-gradient kernels of this net read
         (instead of one small launch per layer inside emit_backward); call after the forward pass of the step."""
@@ -553,7 +601,7 @@ class NetPlan:
                 d = self._desc(n, n.inputs[0].out, n.out)
                 if self._lp(d, 1):
                     continue                      # its data gradient reads the low-precision transposed pack instead
-                if l.W.shape[1] > 4 and ops.dgrad_t_supported(d) and id(l.W) not in transposed:
+                if self._use_dgrad_t(d, l.W) and id(l.W) not in transposed:
                     transposed.add(id(l.W))
                     items.append((st.value(l.W), st.transposed(l.W), d.C, d.kh * d.kw, d.K))
             elif n.op == 'upconv':
@@ -693,7 +741,7 @@ class NetPlan:
                         prog.append(("conv_dgrad", lambda d=d2, G=G, wqT=wqT, gi=gi, acc=acc:
                                      ops.conv2d_dgrad_lp(d, G, wqT, gi, self.dtype, None, 'linear', 0.0, acc),
                                      conv_meta(ops, d2, 3, self.dtype)))
-                    elif n.op == 'conv' and l.W.shape[1] > 4 and ops.dgrad_t_supported(self._desc(n, gi, G)):
+                    elif n.op == 'conv' and self._use_dgrad_t(self._desc(n, gi, G), l.W):
                         # data gradient as a forward-form conv on the transposed weights (LDS-patch kernels)
                         d2 = self._desc(n, gi, G)
                         wT = st.transposed(l.W)
