@@ -62,6 +62,9 @@ SIGNATURES = {
     "ghm_conv2d_dgrad_lp": [_p, _D, _p, _p, _p, _p, _i32, _f, _i32, _i32],
     "ghm_conv2d_wgrad_lp_workspace": [_D, C.POINTER(C.c_size_t)],
     "ghm_conv2d_wgrad_lp": [_p, _D, _p, _p, _p, _p, _i32, _i32],
+    "ghm_conv2d_fwd_pool": [_p, _D, _p, _p, _p, _p, _p, _i32, _f, _i32],
+    "ghm_maxpool2_mask_bwd": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f],
+    "ghm_maxpool2_mask_bwd_bias": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f, _p, _i32],
     "ghm_channel_sum": [_p, _p, _i32, _i32, _i32, _i64, _p, _i32],
     "ghm_bn_stats": [_p, _p, _i32, _i32, _i32, _i64, _f, _p, _p, _p, _p, _f, _p],
     "ghm_bn_apply": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _f],
@@ -101,7 +104,8 @@ SIGNATURES = {
     "ghm_conv2d_variant": [_D, _i32, C.c_char_p, _i32],
 }
 _SPECIAL = {"ghm_last_error": ([], C.c_char_p), "ghm_bn_workspace": ([_i32], C.c_size_t),
-            "ghm_dgrad_t_supported": ([_D], C.c_int), "ghm_lp_supported": ([_D, _i32, _i32], C.c_int)}
+            "ghm_dgrad_t_supported": ([_D], C.c_int), "ghm_lp_supported": ([_D, _i32, _i32], C.c_int),
+            "ghm_conv2d_pool_supported": ([_D, _i32, _i32], C.c_int)}
 
 _lib = None
 

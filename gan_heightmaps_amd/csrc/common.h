@@ -125,6 +125,9 @@ __device__ __forceinline__ float ghm_dact_from_out(float y, int act, float alpha
 bool thin_fanout_fwd_ok(const ghm_conv_desc* d, int act);   // the kernel's epilogue does linear / relu / lrelu
 int thin_fanout_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,
                     float* y, int act, float alpha, int accumulate);
+bool thin_fanout_fwd_pool_ok(const ghm_conv_desc* d, int act);    // + activation + 2x2 max-pool in the epilogue
+int thin_fanout_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,
+                         float* pooled, unsigned char* mask, int act, float alpha);
 bool thin_fanout_dgrad_ok(const ghm_conv_desc* d, int act);
 int thin_fanout_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const float* wp, const float* bias,
                       float* dx, int act, float alpha, int accumulate);
@@ -133,6 +136,10 @@ int thin_fanin_s2(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const f
                   float* dx, int act, float alpha, int accumulate);
 bool thin_wgrad_ok(const ghm_conv_desc* d, const float* x, const float* dy);
 int thin_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* dy, float* dwp, int accumulate);
+// conv_lp.hip: conv + activation + 2x2 max-pool on the low-precision matrix cores
+bool lp_conv_pool_supported(const ghm_conv_desc* d, int act, int dtype);
+int lp_conv_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* wq, const float* bias, float* pooled,
+                     unsigned char* mask, int act, float alpha, int dtype);
 // split-K epilogue of a forward-form convolution: out = act(sum of S partial slices [S][R][N*H*W] + bias (+ out))
 int ghm_splitk_finish(ghm_ctx* ctx, const float* partial, int S, float* out, const float* bias, int N, int R, int H,
                       int W, long out_nstride, int act, float alpha, int accumulate);

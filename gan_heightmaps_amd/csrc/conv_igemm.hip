@@ -458,9 +458,23 @@ struct PatchArgs {
     int slabs_per_split;
     int debug;             // tuning only (GHM_ABLATE): 1 = skip the staging of all slabs but the first
     const float* zeros;    // ctx->zeros: source of padding elements for the LDS-DMA staging
+    float* pool_out;       // POOL: dense [N, R, H/2, W/2] maximum of act(conv + bias) over 2x2 windows ...
+    unsigned char* pool_mask;   // ... and the 4-bit arg-max mask of every window (bit 2*dr + dc; all ties set)
 };
 
-template <int KS, int BM, int RT, int WM, int WN, int CP, int ST>
+// The 2x2 max-pool of a patch-kernel accumulator tile, in the epilogue (POOL): a wave owns TN consecutive pixel rows
+// of 32 columns, lanes along columns -- the row pair (2j, 2j+1) of a window is in one lane, the column pair in lanes
+// (2t, 2t+1): one cross-lane exchange, even lanes store.  v0 / v1: the two rows' values of this lane's column.
+__device__ __forceinline__ void pool2_store(float v0, float v1, bool col_even, bool live, float* po, unsigned char* pm) {
+    const float w0 = __shfl_xor(v0, 1, 64), w1 = __shfl_xor(v1, 1, 64);      // the neighbour column's two rows
+    const float m = fmaxf(fmaxf(v0, v1), fmaxf(w0, w1));
+    if (col_even && live) {
+        *po = m;
+        *pm = (unsigned char)((v0 == m ? 1u : 0u) | (w0 == m ? 2u : 0u) | (v1 == m ? 4u : 0u) | (w1 == m ? 8u : 0u));
+    }
+}
+
+template <int KS, int BM, int RT, int WM, int WN, int CP, int ST, bool POOL = false>
 __global__ __launch_bounds__(256, ST == 2 ? 3 : 4) void conv_patch_kernel(const PatchArgs a) {
     constexpr int T = KS * KS, CB = 2 * CP;
     constexpr int BN = RT * 32;
@@ -629,6 +643,27 @@ __global__ __launch_bounds__(256, ST == 2 ? 3 : 4) void conv_patch_kernel(const 
     if (tid < BM) sb[tid] = (a.bias && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
     __syncthreads();
     const float* const lb = sb + wm * (BM / WM) + 4 * frag_k;
+    if constexpr (POOL) {
+        static_assert(TN % 2 == 0 && ST == 1, "pooled epilogue: row pairs inside a wave");
+        const int Wp = a.W / 2;
+        const long HWp = (long)(a.H / 2) * Wp;
+        const long base = ((long)n * a.R + rl) * HWp + (long)((y0 + wn * TN) / 2) * Wp + (x0 + frag_i) / 2;
+        const float slope = a.act == GHM_ACT_LINEAR ? 1.f : (a.act == GHM_ACT_RELU ? 0.f : a.alpha);
+#pragma unroll
+        for (int j2 = 0; j2 < TN / 2; ++j2)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    float v0 = acc[i][2 * j2][e] + lb[k], v1 = acc[i][2 * j2 + 1][e] + lb[k];
+                    v0 = v0 > 0.f ? v0 : slope * v0;
+                    v1 = v1 > 0.f ? v1 : slope * v1;
+                    const long o = base + (long)k * HWp + j2 * Wp;
+                    pool2_store(v0, v1, (frag_i & 1) == 0, rl + k < a.R, a.pool_out + o, a.pool_mask + o);
+                }
+        return;
+    }
     float* const ub = a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN) * a.W + x0;
     const unsigned lo = 4u * frag_k * (unsigned)HW + frag_i;
     const bool pwl = a.act == GHM_ACT_LINEAR || a.act == GHM_ACT_RELU || a.act == GHM_ACT_LRELU;
@@ -1823,6 +1858,49 @@ int ghm_conv2d_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const f
             a.di[t] = ta - d->pad; a.dj[t] = tb - d->pad; a.wi[t] = t;
         }
     return launch_igemm<false>(ctx, a);
+}
+
+static bool pool_geom_ok(const ghm_conv_desc* d, int act) {
+    return (act == GHM_ACT_LINEAR || act == GHM_ACT_RELU || act == GHM_ACT_LRELU) && d->stride == 1 && d->kh == d->kw &&
+           d->Ho == d->H && d->Wo == d->W && d->H % 2 == 0 && d->W % 4 == 0 && getenv("GHM_NO_POOL_FUSE") == nullptr;
+}
+
+static bool patch_pool_ok(const ghm_conv_desc* d, int num_cu) {
+    const PatchPlan pl = plan_patch(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, num_cu, 1);
+    return pl.ok && pl.splits == 1 && pl.bm == 64;
+}
+
+int ghm_conv2d_pool_supported(const ghm_conv_desc* d, int32_t act, int32_t dtype) {
+    if (!pool_geom_ok(d, act)) return 0;
+    if (d->C <= 4) return thin_fanout_fwd_pool_ok(d, act) ? 1 : 0;
+    if (dtype != GHM_DTYPE_F32 && lp_conv_pool_supported(d, act, dtype)) return 2;
+    return patch_pool_ok(d, 256) ? 1 : 0;
+}
+
+int ghm_conv2d_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* w, const float* bias,
+                        float* pooled, uint8_t* mask, int32_t act, float alpha, int32_t dtype) {
+    if (int e = check_desc(d)) return e;
+    const int form = ghm_conv2d_pool_supported(d, act, dtype);
+    GHM_CHECK(form != 0, "ghm_conv2d_fwd_pool: geometry / activation not served (ask ghm_conv2d_pool_supported)");
+    if (d->C <= 4) return thin_fanout_fwd_pool(ctx, d, x, (const float*)w, bias, pooled, mask, act, alpha);
+    if (form == 2) return lp_conv_fwd_pool(ctx, d, x, w, bias, pooled, mask, act, alpha, dtype);
+    const PatchPlan pl = plan_patch(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, ctx->num_cu, 1);
+    GHM_CHECK(pl.ok && pl.splits == 1 && pl.bm == 64, "ghm_conv2d_fwd_pool: no single-pass patch plan on this device");
+    PatchArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.in = x; pa.wp = (const float*)w; pa.bias = bias; pa.out = nullptr;
+    pa.N = d->N; pa.CH = d->C; pa.H = d->Ho; pa.W = d->Wo; pa.Hin = d->H; pa.Win = d->W; pa.in_nstride = d->x_nstride;
+    pa.R = d->K; pa.out_nstride = 0; pa.pad = d->pad;
+    pa.act = act; pa.alpha = alpha; pa.accumulate = 0;
+    pa.slabs_per_split = pl.slabs_per_split; pa.partial = nullptr; pa.zeros = ctx->zeros;
+    pa.pool_out = pooled; pa.pool_mask = mask;
+    const dim3 g(pl.grid, 1);
+    if (d->kh == 5)
+        hipLaunchKernelGGL((conv_patch_kernel<5, 64, 8, 1, 4, 1, 1, true>), g, dim3(256), pl.lds, ctx->stream, pa);
+    else
+        hipLaunchKernelGGL((conv_patch_kernel<3, 64, 8, 1, 4, 2, 1, true>), g, dim3(256), pl.lds, ctx->stream, pa);
+    GHM_LAUNCH_CHECK();
+    return 0;
 }
 
 int ghm_conv2d_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const float* wp, const float* bias,

@@ -168,9 +168,20 @@ struct LpConvArgs {
     float alpha;
     int accumulate;
     int slabs_per_split;
+    float* pool_out;            // POOL: dense [N, R, H/2, W/2] maximum of act(conv + bias) over 2x2 windows ...
+    unsigned char* pool_mask;   // ... and the 4-bit arg-max mask of every window (bit 2*dr + dc; all ties set)
 };
 
-template <int DT, int KS, int ST, int BM, int RT, int WM, int WN, int TW>
+__device__ __forceinline__ void lp_pool2_store(float v0, float v1, bool col_even, bool live, float* po, unsigned char* pm) {
+    const float w0 = __shfl_xor(v0, 1, 64), w1 = __shfl_xor(v1, 1, 64);      // the neighbour column's two rows
+    const float m = fmaxf(fmaxf(v0, v1), fmaxf(w0, w1));
+    if (col_even && live) {
+        *po = m;
+        *pm = (unsigned char)((v0 == m ? 1u : 0u) | (w0 == m ? 2u : 0u) | (v1 == m ? 4u : 0u) | (w1 == m ? 8u : 0u));
+    }
+}
+
+template <int DT, int KS, int ST, int BM, int RT, int WM, int WN, int TW, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
     // TW = columns of the pixel tile (32, or 16 / 8 for narrow maps): the 32 pixel lanes of a fragment cover RPF = 32 / TW
     // consecutive rows of TW columns; the block's tile is (RT * RPF) rows x TW columns
@@ -330,6 +341,29 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
     if (tid < BM) sb[tid] = (a.bias && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
     __syncthreads();
     const float* const lb = sb + wm * (BM / WM) + 4 * kg;
+    if constexpr (POOL) {
+        // 2x2 max-pool of act(conv + bias) in the epilogue: the row pair of a window is in one lane (TN consecutive
+        // rows per wave), the column pair in lanes (2t, 2t+1); even lanes store the maximum and the arg-max mask
+        static_assert(TN % 2 == 0 && ST == 1 && TW == 32, "pooled epilogue: row pairs inside a wave, 32-column tiles");
+        const int Wp = a.W / 2;
+        const long HWp = (long)(a.H / 2) * Wp;
+        const long base = ((long)n * a.R + rl) * HWp + (long)((y0 + wn * TN) / 2) * Wp + (x0 + li) / 2;
+        const float slope = a.act == GHM_ACT_LINEAR ? 1.f : (a.act == GHM_ACT_RELU ? 0.f : a.alpha);
+#pragma unroll
+        for (int j2 = 0; j2 < TN / 2; ++j2)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    float v0 = acc[i][2 * j2][e] + lb[k], v1 = acc[i][2 * j2 + 1][e] + lb[k];
+                    v0 = v0 > 0.f ? v0 : slope * v0;
+                    v1 = v1 > 0.f ? v1 : slope * v1;
+                    const long o = base + (long)k * HWp + j2 * Wp;
+                    lp_pool2_store(v0, v1, (li & 1) == 0, rl + k < a.R, a.pool_out + o, a.pool_mask + o);
+                }
+        return;
+    }
     float* const ub = a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN * RPF) * a.W + x0;
     const unsigned lo = 4u * kg * (unsigned)HW + ly * a.W + lx;
     const bool pwl = a.act == GHM_ACT_LINEAR || a.act == GHM_ACT_RELU || a.act == GHM_ACT_LRELU;
@@ -966,6 +1000,47 @@ bool lp_fwd_geom(const ghm_conv_desc* d) {
 int rpad128(int r) { return (r + 127) / 128 * 128; }
 
 }  // namespace
+
+static bool lp_pool_act_ok(int act) { return act == GHM_ACT_LINEAR || act == GHM_ACT_RELU || act == GHM_ACT_LRELU; }
+
+bool lp_conv_pool_supported(const ghm_conv_desc* d, int act, int dtype) {
+    if (dtype != GHM_DTYPE_BF16 && dtype != GHM_DTYPE_F16) return false;
+    if (!(lp_pool_act_ok(act) && d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W && d->H % 2 == 0)) return false;
+    const LpPlan pl = lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, 256);
+    return pl.ok && pl.tw == 32 && pl.splits == 1 && getenv("GHM_NO_POOL_FUSE") == nullptr;
+}
+
+int lp_conv_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* wq, const float* bias, float* pooled,
+                     unsigned char* mask, int act, float alpha, int dtype) {
+    const LpPlan pl = lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, ctx->num_cu);
+    GHM_CHECK(pl.ok && pl.tw == 32 && pl.splits == 1, "lp_conv_fwd_pool: geometry not served");
+    LpConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = x; a.wq = (const u32x4*)wq; a.bias = bias; a.out = nullptr;
+    a.N = d->N; a.CH = d->C; a.H = d->Ho; a.W = d->Wo; a.Hin = d->H; a.Win = d->W; a.in_nstride = d->x_nstride;
+    a.R = d->K; a.Rpad = rpad128(d->K); a.out_nstride = 0; a.pad = d->pad;
+    a.act = act; a.alpha = alpha; a.accumulate = 0;
+    a.slabs_per_split = pl.slabs_per_split;
+    a.pool_out = pooled; a.pool_mask = mask;
+    const dim3 g(pl.grid, 1);
+#define GHM_LPP_CASE(DT_, KS_, BM_, WM_, WN_)                                                                          \
+    if (dtype == DT_ && d->kh == KS_ && pl.bm == BM_) {                                                               \
+        hipLaunchKernelGGL((lp_conv_kernel<DT_, KS_, 1, BM_, 8, WM_, WN_, 32, true>), g, dim3(256), 0, ctx->stream, a); \
+        GHM_LAUNCH_CHECK();                                                                                           \
+        return 0;                                                                                                     \
+    }
+    GHM_LPP_CASE(GHM_DTYPE_BF16, 5, 128, 2, 2)
+    GHM_LPP_CASE(GHM_DTYPE_BF16, 5, 64, 1, 4)
+    GHM_LPP_CASE(GHM_DTYPE_BF16, 3, 128, 2, 2)
+    GHM_LPP_CASE(GHM_DTYPE_BF16, 3, 64, 1, 4)
+    GHM_LPP_CASE(GHM_DTYPE_F16, 5, 128, 2, 2)
+    GHM_LPP_CASE(GHM_DTYPE_F16, 5, 64, 1, 4)
+    GHM_LPP_CASE(GHM_DTYPE_F16, 3, 128, 2, 2)
+    GHM_LPP_CASE(GHM_DTYPE_F16, 3, 64, 1, 4)
+#undef GHM_LPP_CASE
+    ghm_set_error("no pooled lp_conv variant for k=%d bm=%d", d->kh, pl.bm);
+    return -3;
+}
 
 extern "C" {
 

@@ -47,6 +47,8 @@ struct FanoutArgs {
     // derived by launch_fanout: tap extent, staged-row geometry, per-q LDS and weight offsets
     int dimin, djmin, RPI, KRT, LW;
     int loff[THIN_MAX_Q], widx[THIN_MAX_Q];
+    float* pool_out;            // POOL: dense [N, R, Hout/2, Wout/2] maximum of act(conv + bias) over 2x2 windows ...
+    unsigned char* pool_mask;   // ... and the 4-bit arg-max mask of every window (bit 2*dr + dc; all ties set)
 };
 
 // LDS hand-over between the loader wave and the MFMA waves: wait for this wave's LDS traffic only.  A
@@ -69,7 +71,11 @@ template <> struct StoreVec<2> { typedef float2 type; };
 //   row: 32 lanes write NS*128 contiguous bytes of a channel plane.  They never issue a global load, so
 //   nothing ever waits on their stores (loads and stores share vmcnt on gfx9); with at most 64 memory
 //   instructions outstanding per wave, the wide stores are what keeps enough bytes in flight to reach HBM rate.
-template <int KSTEPS, int RB, int NS, bool ACC>
+//   POOL (d_conv1 -> LeakyRectify -> MaxPool2D, architectures/dcgan.py:42-47): a group is TWO output rows x 64 pixels
+//   (NS = 2): the lane that owns pixels (2l, 2l+1) of both rows owns one whole pooling window, so the epilogue takes
+//   the maximum in registers and stores the pooled value (4 B, 128 contiguous bytes per 32 lanes) and the 4-bit arg-max
+//   mask -- the 537 MB full-resolution activation is never written.
+template <int KSTEPS, int RB, int NS, bool ACC, bool POOL = false>
 __global__ __launch_bounds__(320, 2) void fanout_kernel(const FanoutArgs a) {
     typedef typename StoreVec<NS>::type vec_t;
     extern __shared__ float lds[];
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(320, 2) void fanout_kernel(const FanoutArgs a) {
         }
     }
     const int GPR = a.Wout / (NS * 32);       // pixel groups per output row
-    const int G = a.RPI * GPR;
+    const int G = POOL ? (a.RPI / 2) * GPR : a.RPI * GPR;
     const int HWout = a.Hout * a.Wout;
     // store addressing: wave-uniform 64-bit base (scalar) + 32-bit per-lane byte offset
     const unsigned plane = (unsigned)HWout * 4u;
@@ -145,6 +151,66 @@ __global__ __launch_bounds__(320, 2) void fanout_kernel(const FanoutArgs a) {
         } else {
             const int n = r / IPI, u0 = (r - n * IPI) * a.RPI;
             for (int g = wv; g < G; g += 4) {
+                if constexpr (POOL) {
+                    static_assert(!POOL || (NS == 2 && !ACC), "pooled fan-out: 2 pixels x 2 rows per lane");
+                    const int rp = g / GPR, x0 = (g - rp * GPR) * (NS * 32);
+                    const int ri = 2 * rp;
+                    const float* bsrc = cur + (ri * a.LW + x0) * a.ss;
+                    f32x16 acc[2][NS][RB];              // [row of the pair][pixel of the pair][row block]
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int k = 0; k < NS; ++k)
+#pragma unroll
+                            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                                for (int e = 0; e < 16; ++e) acc[q][k][rb][e] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < KSTEPS; ++j) {
+                        float B[2][NS];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int k = 0; k < NS; ++k) B[q][k] = bsrc[q * a.LW * a.ss + off[j] + k * a.ss];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                                for (int rb = 0; rb < RB; ++rb)
+                                    acc[q][k][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rb][j], B[q][k], acc[q][k][rb], 0, 0, 0);
+                    }
+                    const int Wp = a.Wout / 2;
+                    const long HWp = (long)(a.Hout / 2) * Wp;
+                    const long pbase = (long)n * a.R * HWp + (long)((u0 + ri) / 2) * Wp + x0 / 2 + l;
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) {
+                        float bv[16];
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            const float4 t = *reinterpret_cast<const float4*>(sbias + rb * 32 + 8 * e4 + 4 * h);
+                            bv[4 * e4] = t.x; bv[4 * e4 + 1] = t.y; bv[4 * e4 + 2] = t.z; bv[4 * e4 + 3] = t.w;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int row = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            float v[4];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) {
+                                    const float t = acc[q][k][rb][e] + bv[e];
+                                    v[2 * q + k] = t > 0.f ? t : slope * t;
+                                }
+                            const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                            const long o = pbase + (long)row * HWp;
+                            a.pool_out[o] = m;
+                            a.pool_mask[o] = (unsigned char)((v[0] == m ? 1u : 0u) | (v[1] == m ? 2u : 0u) |
+                                                             (v[2] == m ? 4u : 0u) | (v[3] == m ? 8u : 0u));
+                        }
+                    }
+                    continue;
+                }
                 const int ri = g / GPR, x0 = (g - ri * GPR) * (NS * 32);
                 const float* bsrc = cur + (ri * a.LW + x0) * a.ss;
                 f32x16 acc[NS][RB];
@@ -281,6 +347,23 @@ static int launch_fanout(ghm_ctx* ctx, FanoutArgs& a, int kh, int kw) {
     return -3;
 }
 
+template <int KSTEPS>
+static int launch_fanout_pool_t(ghm_ctx* ctx, const FanoutArgs& a) {
+    const int NI = a.N * (a.Hout / a.RPI);
+    int blocks = ctx->num_cu;
+    if (blocks > NI) blocks = NI;
+    const size_t lds = (size_t)(2 * 32 + 4 * KSTEPS + 2 * a.CS * a.KRT * a.LW) * sizeof(float);
+    static bool opted_in = false;
+    if (!opted_in) {
+        GHM_HIP(hipFuncSetAttribute((const void*)fanout_kernel<KSTEPS, 2, 2, false, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        opted_in = true;
+    }
+    hipLaunchKernelGGL((fanout_kernel<KSTEPS, 2, 2, false, true>), dim3(blocks), dim3(320), lds, ctx->stream, a);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
 static bool thin_enabled() { return getenv("GHM_NO_THIN") == nullptr; }
 static bool fanout_act_ok(int act) { return act == GHM_ACT_LINEAR || act == GHM_ACT_RELU || act == GHM_ACT_LRELU; }
 
@@ -308,6 +391,50 @@ int thin_fanout_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const 
                 a.ch[q] = c; a.di[q] = ta - d->pad; a.dj[q] = tb - d->pad;
             }
     return launch_fanout(ctx, a, d->kh, d->kw);
+}
+
+// forward conv with <= 4 input channels + activation + 2x2 max-pool, fused (64 filters, stride 1, 'same')
+bool thin_fanout_fwd_pool_ok(const ghm_conv_desc* d, int act) {
+    if (!(thin_enabled() && fanout_act_ok(act) && d->K == 64 && d->stride == 1 && d->Ho == d->H && d->Wo == d->W)) return false;
+    const int q = d->C * d->kh * d->kw;
+    const size_t lds = (size_t)(2 * 32 + 4 * 18 + 2 * d->C * (d->kh + 1) * ((((d->Wo - 1) + d->kw) + 63) & ~63)) * sizeof(float);
+    return d->C <= 4 && q <= THIN_MAX_Q && d->Wo % 64 == 0 && d->Ho % 2 == 0 && (long)d->N * d->Ho * d->Wo >= 32768 &&
+           (long)d->C * d->H * d->W < (1L << 30) && lds <= 150 * 1024 && getenv("GHM_NO_POOL_FUSE") == nullptr;
+}
+
+int thin_fanout_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,
+                         float* pooled, unsigned char* mask, int act, float alpha) {
+    FanoutArgs a;
+    memset(&a, 0, sizeof(a));
+    const int T = d->kh * d->kw;
+    a.in = x; a.wp = wp; a.bias = bias; a.out = nullptr; a.zeros = ctx->zeros;
+    a.pool_out = pooled; a.pool_mask = mask;
+    a.N = d->N; a.CS = d->C; a.Hin = d->H; a.Win = d->W; a.in_nstride = d->x_nstride;
+    a.R = d->K; a.Hout = d->Ho; a.Wout = d->Wo; a.out_nstride = 0;
+    a.ss = 1; a.T = T; a.Q = d->C * T;
+    a.w_rs = 1; a.w_cs = (long)T * d->K; a.w_ts = d->K;
+    a.act = act; a.alpha = alpha; a.accumulate = 0;
+    a.dimin = a.djmin = -d->pad;
+    for (int c = 0; c < d->C; ++c)
+        for (int ta = 0; ta < d->kh; ++ta)
+            for (int tb = 0; tb < d->kw; ++tb) {
+                const int q = c * T + ta * d->kw + tb;
+                a.ch[q] = c; a.di[q] = ta - d->pad; a.dj[q] = tb - d->pad;
+            }
+    a.RPI = 2;                                   // one row PAIR per iteration: 8 groups of 2 x 64 pixels at 512 columns
+    a.KRT = d->kh + 1;
+    a.LW = (((d->Wo - 1) + d->kw) + 63) & ~63;
+    for (int q = 0; q < a.Q; ++q) {
+        const int cs = q / a.T, t = q - cs * a.T;
+        a.loff[q] = (a.ch[q] * a.KRT + (a.di[q] - a.dimin)) * a.LW + (a.dj[q] - a.djmin);
+        a.widx[q] = (int)(cs * a.w_cs + t * a.w_ts);
+    }
+    const int ks = (a.Q + 1) / 2;
+    if (ks <= 5) return launch_fanout_pool_t<5>(ctx, a);
+    if (ks <= 13) return launch_fanout_pool_t<13>(ctx, a);
+    if (ks <= 18) return launch_fanout_pool_t<18>(ctx, a);
+    ghm_set_error("fanout pool: %d reduction rows unsupported", a.Q);
+    return -3;
 }
 
 // data gradient (stride 1) of a conv with <= 4 filters: dx[C big] <- dy[K small]

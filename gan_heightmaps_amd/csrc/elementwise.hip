@@ -334,6 +334,56 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
     *reinterpret_cast<float2*>(dx + o + W) = rb;
 }
 
+// Backward of the FUSED conv + activation + 2x2 max-pool (ghm_conv2d_fwd_pool): the forward kept the pooled value y
+// and a 4-bit arg-max mask per pooled pixel (bit 2*dr + dc: position (dr, dc) of the window equals the maximum; all
+// ties set), so the full-resolution activation never existed.  dx[2i+dr, 2j+dc] = bit ? dy[i,j] * act'(y[i,j]) : 0
+// (the activation is monotonic: the derivative at the arg-max is the derivative at the pooled value).
+// One thread per TWO pooled pixels: two 16-byte stores.
+// BIAS: the block also reduces what it wrote (a block lies inside one (n, c) plane: Ho * W/4 is a multiple of 256) into
+// part[c][n * blocks_per_plane + block in plane] -- the conv's bias gradient without re-reading the gradient tensor
+// out[c] (+)= sum_k part[c][k], fixed order; one wave per channel
+__global__ __launch_bounds__(64) void partial_rows_sum_kernel(const float* __restrict__ part, int C, int S,
+                                                              float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < S; k += 64) s += part[(long)c * S + k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (threadIdx.x == 0) out[c] = (accumulate ? out[c] : 0.f) + s;
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(256) void maxpool2_mask_bwd_kernel(const unsigned char* __restrict__ mask,
+                                                                const float* __restrict__ y, const float* __restrict__ dy,
+                                                                float* __restrict__ dx, long planes, int H, int W, int act,
+                                                                float alpha, float* __restrict__ part, int C, int bpp) {
+    const int Ho = H / 2, Wo2 = W / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= planes * Ho * Wo2) return;
+    const long pl = idx / (Ho * Wo2);
+    const int rem = (int)(idx - pl * Ho * Wo2), i = rem / Wo2, j2 = rem - i * Wo2;
+    const long po = pl * Ho * (W / 2) + (long)i * (W / 2) + 2 * j2;
+    const unsigned m2 = *reinterpret_cast<const unsigned short*>(mask + po);
+    const float2 yv = *reinterpret_cast<const float2*>(y + po);
+    const float2 gv = *reinterpret_cast<const float2*>(dy + po);
+    const float g0 = gv.x * ghm_dact_from_out(yv.x, act, alpha), g1 = gv.y * ghm_dact_from_out(yv.y, act, alpha);
+    const unsigned m0 = m2 & 0xffu, m1 = m2 >> 8;
+    const long o = pl * H * W + (long)(2 * i) * W + 4 * j2;
+    *reinterpret_cast<float4*>(dx + o) = make_float4((m0 & 1u) ? g0 : 0.f, (m0 & 2u) ? g0 : 0.f, (m1 & 1u) ? g1 : 0.f, (m1 & 2u) ? g1 : 0.f);
+    *reinterpret_cast<float4*>(dx + o + W) = make_float4((m0 & 4u) ? g0 : 0.f, (m0 & 8u) ? g0 : 0.f, (m1 & 4u) ? g1 : 0.f, (m1 & 8u) ? g1 : 0.f);
+    if constexpr (BIAS) {
+        float sum = g0 * (float)__popc(m0 & 15u) + g1 * (float)__popc(m1 & 15u);
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+        __shared__ float red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int n = (int)(pl / C), c = (int)(pl - (long)n * C);
+            const int blk = (int)(blockIdx.x - pl * bpp);
+            part[(long)c * ((planes / C) * bpp) + (long)n * bpp + blk] = (red[0] + red[1]) + (red[2] + red[3]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long planes,
                                                           int H, int W, int p) {
     const int Ho = H / p, Wo = W / p;
@@ -911,6 +961,34 @@ int ghm_maxpool2_bwd(ghm_ctx* ctx, const float* x, const float* y, const float* 
     GHM_CHECK(H % 2 == 0 && W % 2 == 0, "maxpool2 needs even H, W (got %dx%d)", H, W);
     hipLaunchKernelGGL(maxpool2_bwd_kernel, EW_GRID((long)N * C * (H / 2) * (W / 2)), x, y, dy, dx, (long)N * C, H, W, act,
                        alpha);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_maxpool2_mask_bwd(ghm_ctx* ctx, const uint8_t* mask, const float* y, const float* dy, float* dx, int32_t N,
+                          int32_t C, int32_t H, int32_t W, int32_t act, float alpha) {
+    GHM_CHECK(H % 2 == 0 && W % 4 == 0, "maxpool2_mask_bwd needs even H and W %% 4 == 0 (got %dx%d)", H, W);
+    hipLaunchKernelGGL((maxpool2_mask_bwd_kernel<false>), EW_GRID((long)N * C * (H / 2) * (W / 4)), mask, y, dy, dx,
+                       (long)N * C, H, W, act, alpha, (float*)nullptr, C, 0);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_maxpool2_mask_bwd_bias(ghm_ctx* ctx, const uint8_t* mask, const float* y, const float* dy, float* dx, int32_t N,
+                               int32_t C, int32_t H, int32_t W, int32_t act, float alpha, float* dbias, int32_t accumulate) {
+    GHM_CHECK(H % 2 == 0 && W % 4 == 0, "maxpool2_mask_bwd needs even H and W %% 4 == 0 (got %dx%d)", H, W);
+    const long per_plane = (long)(H / 2) * (W / 4);
+    if (per_plane % 256 != 0) {          // blocks would straddle planes: two passes
+        if (int e = ghm_maxpool2_mask_bwd(ctx, mask, y, dy, dx, N, C, H, W, act, alpha)) return e;
+        return ghm_channel_sum(ctx, dx, N, C, H * W, (int64_t)C * H * W, dbias, accumulate);
+    }
+    const int bpp = (int)(per_plane / 256), S = N * bpp;
+    void* ws = nullptr;
+    if (int e = ghm_scratch(ctx, (size_t)C * S * sizeof(float), &ws)) return e;
+    hipLaunchKernelGGL((maxpool2_mask_bwd_kernel<true>), EW_GRID((long)N * C * per_plane), mask, y, dy, dx, (long)N * C, H,
+                       W, act, alpha, (float*)ws, C, bpp);
+    GHM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(partial_rows_sum_kernel, dim3(C), dim3(64), 0, ctx->stream, (const float*)ws, C, S, dbias, accumulate);
     GHM_LAUNCH_CHECK();
     return 0;
 }

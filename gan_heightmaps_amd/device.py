@@ -344,6 +344,26 @@ class Ops:
         call("ghm_conv2d_wgrad_lp", self.h, C.byref(d), _vp(x), _vp(dy), _vp(dwp), _vp(ws), int(accumulate),
              DTYPE_CODES[dtype])
 
+    # ---- conv + activation + 2x2 max-pool fused (architectures/dcgan.py:42-47) ----
+    def conv_pool_supported(self, d, act, dtype='f32'):
+        """0: not served; 1: served with the fp32 packed weights; 2: served with the low-precision pack"""
+        return int(_lib.load().ghm_conv2d_pool_supported(C.byref(d), ACT_CODES[act], DTYPE_CODES[dtype]))
+
+    def conv2d_fwd_pool(self, d, x, w, bias, pooled, mask_ptr, act, alpha, dtype='f32'):
+        assert pooled.contiguous
+        call("ghm_conv2d_fwd_pool", self.h, C.byref(d), _vp(x), _vp(w), _vp(bias), _vp(pooled), C.c_void_p(int(mask_ptr)),
+             ACT_CODES[act], alpha, DTYPE_CODES[dtype])
+
+    def maxpool2_mask_bwd(self, mask_ptr, y, dy, dx, act, alpha, dbias=None, accumulate=False):
+        """y, dy: pooled [N,C,H/2,W/2]; dx: full-resolution [N,C,H,W]; dbias: also (+)= the per-channel sum of dx"""
+        assert y.contiguous and dy.contiguous and dx.contiguous
+        if dbias is None:
+            call("ghm_maxpool2_mask_bwd", self.h, C.c_void_p(int(mask_ptr)), _vp(y), _vp(dy), _vp(dx), dx.N, dx.Cc, dx.H,
+                 dx.W, ACT_CODES[act], alpha)
+        else:
+            call("ghm_maxpool2_mask_bwd_bias", self.h, C.c_void_p(int(mask_ptr)), _vp(y), _vp(dy), _vp(dx), dx.N, dx.Cc,
+                 dx.H, dx.W, ACT_CODES[act], alpha, _vp(dbias), int(accumulate))
+
     def channel_sum(self, x, out, accumulate=False):
         call("ghm_channel_sum", self.h, _vp(x), x.N, x.Cc, x.HW, x.nstride, _vp(out), int(accumulate))
 

@@ -298,6 +298,7 @@ class NetPlan:
         self.node_of_layer = of
         self.input_nodes = [n for n in self.order if n.op == 'input']
         self._shapes()
+        self._fuse_convpool()
         self._place(inputs or {}, out_tensor)
         self._scratch = {}
         self.bn_ws = None
@@ -325,8 +326,8 @@ class NetPlan:
         (after the collapse of the generator's 5x5 weights)"""
         items = []
         for n in self.order:
-            if n.op == 'conv':
-                d = self._desc(n, n.inputs[0].out, n.out)
+            if n.op in ('conv', 'convpool'):
+                d = self._desc(n, n.inputs[0].out, self._full(n))
                 src, key = self.store.value(n.layer.W), ('w', id(n.layer.W))
             elif n.op == 'upconv':
                 d = self._upconv_desc(n, n.inputs[0].out)
@@ -372,6 +373,34 @@ class NetPlan:
                     if n.op not in ('dense',) else (B, n.layer.num_units)
                 n.shape = tuple(ls) if len(ls) == 4 else (B, ls[1], 1, 1)
 
+    def _fuse_convpool(self):
+        """Conv2DLayer -> LeakyRectify -> MaxPool2DLayer(2) (architectures/dcgan.py:42-47) -> ONE node whose kernel
+        pools in its epilogue and keeps a 4-bit arg-max mask (ghm_conv2d_fwd_pool): the full-resolution activation is
+        never written, the backward rebuilds the conv's output gradient from mask + pooled value + pooled gradient."""
+        if os.environ.get("GHM_NO_POOL_FUSE") is not None:
+            return
+        for n in list(self.order):
+            if n.op != 'maxpool' or n is self.out_node:
+                continue
+            c = n.inputs[0]
+            if c.op != 'conv' or len(c.consumers) != 1 or c.act.kind not in ('linear', 'relu', 'lrelu'):
+                continue
+            l, xs = c.layer, c.inputs[0].shape
+            d = conv_desc(xs[0], xs[1], xs[2], xs[3], l.num_filters, l.filter_size[0], l.filter_size[1], l.stride[0], l.pad[0])
+            if not self.ops.conv_pool_supported(d, c.act.kind, self.dtype):
+                continue
+            c.op = 'convpool'
+            c.aux['full_shape'] = tuple(c.shape)
+            c.shape = tuple(n.shape)
+            for m in self.order:
+                m.inputs = [c if i is n else i for i in m.inputs]
+            self.order.remove(n)
+        for m in self.order:
+            m.consumers = []
+        for m in self.order:
+            for i in m.inputs:
+                i.consumers.append(m)
+
     def _place(self, inputs, out_tensor):
         for n in self.order:
             if n.op == 'concat':
@@ -412,6 +441,8 @@ class NetPlan:
                 if self.bn_groups == 2:
                     n.aux['mean_g'] = [n.aux['mean'], self.dev.empty((1, C, 1, 1))]
                     n.aux['inv_g'] = [n.aux['inv'], self.dev.empty((1, C, 1, 1))]
+            if n.op == 'convpool':
+                n.aux['mask'] = self.dev.alloc(int(np.prod(n.shape)))          # one byte per pooled pixel
             if n.op == 'upconv':
                 C, K = n.inputs[0].shape[1], n.shape[1]
                 for name in ('wpc', 'wpcT', 'dwpc'):
@@ -432,11 +463,19 @@ class NetPlan:
         if n.op == 'dense':
             return conv_desc(x_t.N, x_t.Cc * x_t.HW, 1, 1, l.num_units, 1, 1, 1, 0, x_t.nstride, y_t.nstride)
         k = l.filter_size
-        if n.op == 'conv':
+        if n.op in ('conv', 'convpool'):
             return conv_desc(x_t.N, x_t.Cc, x_t.H, x_t.W, l.num_filters, k[0], k[1], l.stride[0], l.pad[0],
                              x_t.nstride, y_t.nstride)
         # deconv: descriptor of the conv it is the adjoint of (conv input = deconv OUTPUT = x_t here)
         return conv_desc(x_t.N, x_t.Cc, x_t.H, x_t.W, y_t.Cc, k[0], k[1], l.stride[0], 0, x_t.nstride, y_t.nstride)
+
+    def _full(self, n, nb=None):
+        """geometry stand-in for the conv output of node n (the fused conv + pool node has no such tensor in the
+        forward pass: only its shape and dense sample stride matter)"""
+        if n.op != 'convpool':
+            return n.out
+        fs = n.aux['full_shape']
+        return DevTensor(self.dev, 0, ((nb if nb is not None else fs[0]),) + tuple(fs[1:]))
 
     def _upconv_desc(self, n, x_t):
         """3x3 'same' conv with 4K filters on the low-res input x_t -> parity-planar output seen as [N, 4K, H, W]"""
@@ -512,6 +551,17 @@ class NetPlan:
                 else:
                     prog.append(("%s_fwd" % n.op, lambda d=d, x=x, w=w, b=b, y=y, a=a:
                                  ops.conv2d_fwd(d, x, w, b, y, a.kind, a.alpha), conv_meta(ops, d, 0)))
+            elif n.op == 'convpool':
+                d = self._desc(n, x, self._full(n))
+                w, b = st.value(n.layer.W), st.value(n.layer.b)
+                form = ops.conv_pool_supported(d, a.kind, self.dtype)
+                assert form in (1, 2), "fused conv + pool no longer served for %r" % (n,)
+                wsrc, dt = w, 'f32'
+                if form == 2:
+                    wsrc, dt = self._lp_pack_entry(prog, d, w, ('w', id(n.layer.W)), False, lp_done), self.dtype
+                prog.append(("convpool_fwd", lambda d=d, x=x, wsrc=wsrc, b=b, y=y, m=n.aux['mask'], a=a, dt=dt:
+                             ops.conv2d_fwd_pool(d, x, wsrc, b, y, m, a.kind, a.alpha, dt),
+                             conv_meta(ops, d, 0, dt, pooled=True)))
             elif n.op == 'deconv':
                 d = self._desc(n, y, x)
                 w, b = st.value(n.layer.W), st.value(n.layer.b)
@@ -596,9 +646,9 @@ class NetPlan:
         ops, st = self.ops, self.store
         items = []
         for n in self.order:
-            if n.op == 'conv':
+            if n.op in ('conv', 'convpool'):
                 l = n.layer
-                d = self._desc(n, n.inputs[0].out, n.out)
+                d = self._desc(n, n.inputs[0].out, self._full(n))
                 if self._lp(d, 1):
                     continue                      # its data gradient reads the low-precision transposed pack instead
                 if self._use_dgrad_t(d, l.W) and id(l.W) not in transposed:
@@ -635,7 +685,7 @@ class NetPlan:
         # which nodes need a gradient at all
         req = {}
         for n in self.order:
-            has_p = wgrad and n.op in ('conv', 'deconv', 'dense', 'bn', 'upconv')
+            has_p = wgrad and n.op in ('conv', 'convpool', 'deconv', 'dense', 'bn', 'upconv')
             req[id(n)] = has_p or any(req[id(i)] for i in n.inputs) or id(n) in want_in
         grads, written = {}, set()
         key = (tag, n0, n1)
@@ -697,7 +747,21 @@ class NetPlan:
             x, y = sl(xin.out), sl(n.out)
             a = n.act
             need_dx = req[id(xin)]
-            if n.op in ('conv', 'deconv', 'dense'):
+            if n.op == 'convpool':
+                # gradient of the conv's (never materialised) full-resolution output from the arg-max mask, the pooled
+                # value (sign -> activation derivative) and the pooled gradient; then an ordinary conv backward
+                fs = n.aux['full_shape']
+                per = int(np.prod(n.shape[1:]))                  # mask bytes per sample
+                Gf = cache.get(('full', id(n)))
+                if Gf is None:
+                    Gf = cache[('full', id(n))] = dev.empty((nb,) + tuple(fs[1:]))
+                mptr = n.aux['mask'] + n0 * per
+                # with the weight gradients wanted, the same pass also sums what it writes per channel: the bias gradient
+                gb_fused = st.grad(n.layer.b) if wgrad else None
+                prog.append(("maxpool_mask_bwd", lambda m=mptr, y=y, G=G, Gf=Gf, a=a, gb=gb_fused, aw=accumulate_wgrad:
+                             ops.maxpool2_mask_bwd(m, y, G, Gf, a.kind, a.alpha, gb, aw)))
+                G, a = Gf, linear
+            if n.op in ('conv', 'convpool', 'deconv', 'dense'):
                 if a != linear and not n.aux.get(('grad_is_pre', key)):
                     prog.append(("act_bwd", lambda G=G, y=y, a=a: ops.act_bwd(G, y, G, a.kind, a.alpha)))
                 l = n.layer
@@ -717,17 +781,17 @@ class NetPlan:
                     if n.op == 'deconv':
                         prog.append(("deconv_wgrad", lambda d=d, G=G, x=x, gw=gw, aw=aw, wo=wo:
                                      wo.conv2d_wgrad(d, G, x, gw, self.wgrad_ws, aw), conv_meta(ops, d, 2), wdev))
-                    elif n.op == 'conv' and self._lp(d, 2):
+                    elif n.op in ('conv', 'convpool') and self._lp(d, 2):
                         prog.append(("conv_wgrad", lambda d=d, G=G, x=x, gw=gw, aw=aw, wo=wo:
                                      wo.conv2d_wgrad_lp(d, x, G, gw, self.wgrad_ws, self.dtype, aw),
                                      conv_meta(ops, d, 2, self.dtype), wdev))
                     else:
-                        prog.append(("%s_wgrad" % n.op, lambda d=d, G=G, x=x, gw=gw, aw=aw, wo=wo:
+                        prog.append(("%s_wgrad" % ('conv' if n.op == 'convpool' else n.op), lambda d=d, G=G, x=x, gw=gw, aw=aw, wo=wo:
                                      wo.conv2d_wgrad(d, x, G, gw, self.wgrad_ws, aw), conv_meta(ops, d, 2), wdev))
                     # a bias that feeds a BatchNorm has an identically zero gradient (the BN backward output sums to
                     # zero per channel): its slice of the zero-initialised gradient buffer is simply never written
                     bn_fed = len(n.consumers) == 1 and n.consumers[0].op == 'bn' and n.act == linear
-                    if not bn_fed:
+                    if not bn_fed and n.op != 'convpool':       # convpool: summed by the mask backward pass above
                         prog.append(("bias_grad", lambda G=G, gb=gb, aw=aw, wo=wo: wo.channel_sum(G, gb, aw), None, wdev))
                 if need_dx:
                     gi, acc = target(xin)
@@ -735,13 +799,13 @@ class NetPlan:
                         d2 = self._desc(n, G, gi)
                         prog.append(("deconv_dgrad", lambda d=d2, G=G, w=w, gi=gi, acc=acc:
                                      ops.conv2d_fwd(d, G, w, None, gi, 'linear', 0.0, acc), conv_meta(ops, d2, 0)))
-                    elif n.op == 'conv' and self._lp(self._desc(n, gi, G), 1):
+                    elif n.op in ('conv', 'convpool') and self._lp(self._desc(n, gi, G), 1):
                         d2 = self._desc(n, gi, G)
                         wqT = self._lp_pack_entry(prog, d2, w, ('w', id(l.W)), True, transposed)
                         prog.append(("conv_dgrad", lambda d=d2, G=G, wqT=wqT, gi=gi, acc=acc:
                                      ops.conv2d_dgrad_lp(d, G, wqT, gi, self.dtype, None, 'linear', 0.0, acc),
                                      conv_meta(ops, d2, 3, self.dtype)))
-                    elif n.op == 'conv' and self._use_dgrad_t(self._desc(n, gi, G), l.W):
+                    elif n.op in ('conv', 'convpool') and self._use_dgrad_t(self._desc(n, gi, G), l.W):
                         # data gradient as a forward-form conv on the transposed weights (LDS-patch kernels)
                         d2 = self._desc(n, gi, G)
                         wT = st.transposed(l.W)
@@ -752,7 +816,7 @@ class NetPlan:
                                      ops.conv2d_dgrad_t(d, G, wT, gi, None, 'linear', 0.0, acc), conv_meta(ops, d2, 3)))
                     else:
                         d2 = self._desc(n, gi, G)
-                        prog.append(("%s_dgrad" % n.op, lambda d=d2, G=G, w=w, gi=gi, acc=acc:
+                        prog.append(("%s_dgrad" % ('conv' if n.op == 'convpool' else n.op), lambda d=d2, G=G, w=w, gi=gi, acc=acc:
                                      ops.conv2d_dgrad(d, G, w, gi, None, 'linear', 0.0, acc), conv_meta(ops, d2, 1)))
                     mark_written(xin)
             elif n.op == 'upconv':
@@ -897,9 +961,12 @@ class NetPlan:
                 for l in input_grads}
 
 
-def conv_meta(ops, d, kind, dtype='f32'):
+def conv_meta(ops, d, kind, dtype='f32', pooled=False):
     """roofline metadata of one conv launch: kernel variant name and ALGORITHMIC flops (2 x MACs)."""
-    if dtype != 'f32':
+    if pooled:
+        name = ("lp_conv_kernel<%s, %d, %d>" % (dtype, d.kh, d.stride)) if dtype != 'f32' else \
+            ("fanout_kernel<fwd+pool>" if d.C <= 4 else ops.conv_variant(d, 0).split(" splits")[0].replace(">", ", pool>"))
+    elif dtype != 'f32':
         fam = "wgrad" if kind == 2 else ("dgrad_s2" if kind in (1, 3) and d.stride == 2 else "conv")
         name = "lp_%s_kernel<%s, %d, %d>" % (fam, dtype, d.kh, d.stride)
     else:

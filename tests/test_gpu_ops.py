@@ -615,3 +615,91 @@ def test_dropout_networks_against_the_interpreter(gpu):
             e[1]()
         c = ST.Ctx({'X': xin}, np.float64)
         assert rel(plan.out.numpy(), ST.get_output(net, ST.placeholder('X'), deterministic=True).ev(c).v) < 1e-5
+
+
+POOL_CASES = [
+    # N, C, H, W, K, k        (stride 1, 'same'); which kernel takes it
+    (8, 1, 64, 64, 64, 5),     # thin fan-out (d_conv1): one window per lane
+    (2, 4, 128, 128, 64, 3),   # thin fan-out, 4 input channels
+    (8, 16, 128, 128, 64, 5),  # patch kernel 5x5
+    (4, 16, 128, 128, 128, 5),  # patch kernel 5x5, two filter tiles
+    (8, 32, 128, 128, 64, 3),  # patch kernel 3x3
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", POOL_CASES)
+def test_conv_lrelu_maxpool_fused(gpu, case, dtype):
+    """Conv2DLayer -> LeakyRectify(0.2) -> MaxPool2DLayer(2) (architectures/dcgan.py:42-47) as ONE kernel
+    (ghm_conv2d_fwd_pool) + the mask backward (ghm_maxpool2_mask_bwd): the pooled values against the oracle, and --
+    because the fused epilogue pools the very accumulators the unfused kernel stores -- BITWISE against conv + max-pool
+    as two launches, mask included (checked through the backward, which must equal ghm_maxpool2_bwd on the
+    materialised activation bit for bit, ties and LeakyReLU slope included)."""
+    from oracle import lp as LP
+    dev, ops, D = gpu
+    N, C, H, W, K, k = case
+    pad = k // 2
+    rng = np.random.RandomState(sum(case))
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, k, k, 1, pad)
+    form = ops.conv_pool_supported(d, 'lrelu', dtype)
+    assert form == (1 if (C <= 4 or dtype == 'f32') else 2), (case, dtype, form)
+    wp = dev.tensor(D.pack_conv_w(Wt).ravel())
+    xd, bd = dev.tensor(x), dev.tensor(b)
+    w = wp
+    if form == 2:
+        w = dev.alloc(ops.lp_weight_bytes(d, False))
+        ops.lp_pack_weights(d, wp, w, dtype, False)
+    pooled = dev.empty((N, K, H // 2, W // 2))
+    mask = dev.alloc(N * K * (H // 2) * (W // 2))
+    ops.conv2d_fwd_pool(d, xd, w, bd, pooled, mask, 'lrelu', 0.2, dtype)
+    got = pooled.numpy()
+    # oracle
+    if form == 2:
+        y64 = LP.conv2d_fwd(x, Wt, b, 1, pad, dtype)
+    else:
+        y64 = O.conv2d_fwd(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), 1, pad)
+    ref = O.maxpool_fwd(O.lrelu_fwd(y64, 0.2), 2)
+    assert rel(got, ref) < (TOL if form == 1 else 2e-5), rel(got, ref)
+    # the same two ops unfused, on the device
+    yd = dev.empty((N, K, H, W))
+    if form == 2:
+        ops.conv2d_fwd_lp(d, xd, w, bd, yd, dtype, 'lrelu', 0.2)
+    else:
+        ops.conv2d_fwd(d, xd, wp, bd, yd, 'lrelu', 0.2)
+    pd = dev.empty((N, K, H // 2, W // 2))
+    ops.maxpool2_fwd(yd, pd)
+    assert np.array_equal(got, pd.numpy())
+    dp = rng.randn(N, K, H // 2, W // 2).astype(np.float32)
+    dpd = dev.tensor(dp)
+    dx_mask, dx_ref = dev.empty((N, K, H, W)), dev.empty((N, K, H, W))
+    ops.maxpool2_mask_bwd(mask, pooled, dpd, dx_mask, 'lrelu', 0.2)
+    ops.maxpool2_bwd(yd, pd, dpd, dx_ref, 'lrelu', 0.2)
+    assert np.array_equal(dx_mask.numpy(), dx_ref.numpy())
+    # the variant that also sums what it writes per channel (the conv's bias gradient), plain and accumulating
+    db = dev.zeros((1, K, 1, 1))
+    dx2 = dev.empty((N, K, H, W))
+    ops.maxpool2_mask_bwd(mask, pooled, dpd, dx2, 'lrelu', 0.2, db)
+    assert np.array_equal(dx2.numpy(), dx_ref.numpy())
+    want_db = dx_ref.numpy().astype(np.float64).sum(axis=(0, 2, 3))
+    assert rel(db.numpy().ravel(), want_db) < 1e-5
+    ops.maxpool2_mask_bwd(mask, pooled, dpd, dx2, 'lrelu', 0.2, db, True)
+    assert rel(db.numpy().ravel(), 2 * want_db) < 1e-5
+    vjp = O.lrelu_vjp(y64, 0.2, O.maxpool_vjp(O.lrelu_fwd(y64, 0.2), ref, dp.astype(np.float64), 2))
+    assert rel(dx_mask.numpy(), vjp) < 1e-4
+    for t in (xd, bd, pooled, yd, pd, dpd, dx_mask, dx_ref, wp):
+        dev.free(t.ptr)
+    dev.free(mask)
+
+
+def test_conv_pool_not_served_is_refused(gpu):
+    dev, ops, D = gpu
+    from gan_heightmaps_amd._lib import GhmError
+    d = D.conv_desc(2, 16, 16, 16, 64, 5, 5, 1, 2)          # small map: too few tiles for a single-pass plan
+    assert ops.conv_pool_supported(d, 'lrelu') == 0
+    assert ops.conv_pool_supported(D.conv_desc(8, 16, 128, 128, 64, 5, 5, 1, 2), 'tanh') == 0
+    with pytest.raises(GhmError):
+        ops.conv2d_fwd_pool(d, dev.zeros((2, 16, 16, 16)), dev.zeros((1, 64, 1, 1)), None, dev.zeros((2, 64, 8, 8)),
+                            dev.alloc(2 * 64 * 64), 'lrelu', 0.2)
