@@ -143,9 +143,9 @@ def main():
     if not args.graph:
         # three instrumented (untimed) steps, per-entry median: every entry runs alone between two HIP events
         runs = [eng.profile_train(B) for _ in range(3)]
-        table = [(r[0][0], sorted(x[1] for x in r)[1], r[0][2]) for r in zip(*runs)]
+        table = [(r[0][0], sorted(x[1] for x in r)[1], r[0][2], r[0][3]) for r in zip(*runs)]
         by_kernel = {}
-        for label, ms, meta in table:
+        for label, ms, meta, _lane in table:
             k = meta["kernel"].split(" splits")[0] if meta else label
             e = by_kernel.setdefault(k, [0.0, 0, 0.0])
             e[0] += ms
@@ -162,9 +162,9 @@ def main():
             for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][0]):
                 print("%-44s %9.3f ms %5.1f%% n=%3d %8.1f GFLOP %6.1f TF/s" %
                       (k, v[0], 100 * v[0] / tot, v[1], v[2] / 1e9, v[2] / 1e9 / max(v[0], 1e-9)), file=sys.stderr)
-            for label, ms, meta in sorted(table, key=lambda t: -t[1])[:(400 if os.environ.get('GHM_PROFILE_ALL') else 40)]:
-                print("  %-18s %8.3f ms %s %s" % (label, ms, meta["kernel"] if meta else "",
-                                                 meta["geom"] if meta else ""), file=sys.stderr)
+            for label, ms, meta, lane_ in sorted(table, key=lambda t: -t[1])[:(400 if os.environ.get('GHM_PROFILE_ALL') else 40)]:
+                print("  %-2s %-18s %8.3f ms %s %s" % (lane_, label, ms, meta["kernel"] if meta else "",
+                                                      meta["geom"] if meta else ""), file=sys.stderr)
         dominant = max((k for k in by_kernel if by_kernel[k][2] > 0), key=lambda k: by_kernel[k][0])
         launches_per_step = by_kernel[dominant][1]
         flops_per_step = by_kernel[dominant][2]

@@ -76,6 +76,42 @@ class RecordingOps:
 FakeDevice.ops_class = RecordingOps
 
 
+class PolicyOps(RecordingOps):
+    """RecordingOps whose capability queries answer like libghm.so does for the big layers, so that the lowering's
+    reduced-precision and fused conv + pool decisions can be exercised without a GPU: the low-precision kernels serve
+    3x3 / 5x5 convs with channels % 16 == 0 and maps >= 32 wide, the fused conv + pool every stride-1 'same' conv with
+    a linear / relu / lrelu epilogue (thin layers on the fp32 weights, the rest on the low-precision pack)."""
+
+    def lp_supported(self, d, kind, dtype):
+        if dtype == 'f32' or d.kh not in (3, 5) or d.kh != d.kw:
+            return False
+        red, rows = (d.C, d.K) if kind in (0, 2) else (d.K, d.C)
+        if kind == 2:
+            return d.Wo % 32 == 0 and d.K >= 32 and d.C * d.kh * d.kw >= 96
+        return red % 16 == 0 and rows >= 32 and (d.Wo if kind == 0 else d.W) % 32 == 0
+
+    def lp_weight_bytes(self, d, transposed=False):
+        return 256
+
+    def wgrad_lp_workspace(self, d):
+        return 1024
+
+    def lp_pack_table(self, items):
+        self.calls.append(("lp_pack_table", tuple((int(t[2]), int(t[3]), int(t[4]), bool(t[5])) for t in items), {}))
+        return (0, len(items), 1)
+
+    def conv_pool_supported(self, d, act, dtype='f32'):
+        if act not in ('linear', 'relu', 'lrelu') or d.stride != 1 or d.Ho != d.H or d.W % 4:
+            return 0
+        if d.C <= 4:
+            return 1
+        return 2 if self.lp_supported(d, 0, dtype) else 1
+
+
+class PolicyDevice(FakeDevice):
+    ops_class = PolicyOps
+
+
 # ---- a host-memory device: allocations are numpy arrays, and the handful of ops a data-parallel exchange needs do
 # ---- arithmetic (all-reduce through torch.distributed/gloo, the optimiser update, memset); every other op is
 # ---- recorded only.  Contexts made by ``type(dev)(index)`` share one arena and one host-order event log, like HIP

@@ -137,6 +137,141 @@ def test_gan_step_program_structure_on_fake_device():
     assert d_wgrads == n_convs
 
 
+def test_discriminator_conv_lrelu_maxpool_is_fused_when_the_library_serves_it():
+    """Conv2DLayer -> LeakyRectify -> MaxPool2DLayer (dcgan.py:42-47) becomes one 'convpool' node: pooled output, a
+    byte mask, and in the backward the mask pass (which also sums the bias gradient) in front of an ordinary conv
+    backward -- for the D-loss pass (weight gradients) and the G-loss pass on the fake half (data gradients only)"""
+    from tests.fake_device import PolicyDevice, PolicyOps
+    net = dcgan.default_discriminator(64, True, nch=32, div=[2, 1, 1], nonlinearity=linear)
+    dev = PolicyDevice()
+    ops = PolicyOps(dev)
+    store = ParamStore(dev, L.get_all_params(net))
+    plan = NetPlan(dev, ops, net, 4, store)
+    kinds = [n.op for n in plan.order]
+    assert kinds.count('convpool') == 3 and 'maxpool' not in kinds and kinds.count('conv') == 1     # d_out stays a conv
+    cp = [n for n in plan.order if n.op == 'convpool']
+    assert [n.shape for n in cp] == [(4, 16, 32, 32), (4, 32, 16, 16), (4, 32, 8, 8)]
+    assert [n.aux['full_shape'] for n in cp] == [(4, 16, 64, 64), (4, 32, 32, 32), (4, 32, 16, 16)]
+    fwd = []
+    plan.emit_forward(fwd)
+    assert [e[0] for e in fwd].count('convpool_fwd') == 3 and 'maxpool_fwd' not in [e[0] for e in fwd]
+    seed = dev.empty(plan.out.shape)
+    bwd = []
+    plan.emit_backward(bwd, seed, wgrad=True, tag="dloss")
+    labels = [e[0] for e in bwd]
+    assert labels.count('maxpool_mask_bwd') == 3 and 'maxpool_bwd' not in labels
+    assert labels.count('conv_wgrad') == 4 and labels.count('bias_grad') == 1       # only d_out's bias is a separate sum
+    for e in bwd:
+        e[1]()
+    unpool = [c for c in ops.calls if c[0] == 'maxpool2_mask_bwd']
+    assert all(c[1][6] is not None for c in unpool)                # the bias-gradient slice rides along
+    ops.calls.clear()
+    g2 = []
+    gin = plan.emit_backward(g2, dev.empty((2, 1, 1, 1)), nslice=(2, 4), wgrad=False,
+                             input_grads=[plan.input_nodes[0].layer], tag="gloss")
+    for e in g2:
+        e[1]()
+    unpool = [c for c in ops.calls if c[0] == 'maxpool2_mask_bwd']
+    assert len(unpool) == 3 and all(c[1][6] is None for c in unpool)
+    # the fake half's masks: byte offset = 2 samples into each mask buffer
+    for c, n in zip(unpool, reversed(cp)):
+        assert c[1][0] == n.aux['mask'] + 2 * int(np.prod(n.shape[1:]))
+    assert gin[plan.input_nodes[0].layer].shape == (2, 1, 64, 64)
+    # with GHM_NO_POOL_FUSE the graph keeps its max-pool nodes
+    os.environ["GHM_NO_POOL_FUSE"] = "1"
+    try:
+        plain = NetPlan(dev, ops, net, 4, ParamStore(dev, L.get_all_params(net)))
+    finally:
+        os.environ.pop("GHM_NO_POOL_FUSE")
+    assert [n.op for n in plain.order].count('maxpool') == 3
+
+
+def test_reduced_precision_lowering_on_fake_device():
+    """dtype='bf16': served convolutions call the *_lp entry points, every pack of a net is refreshed by ONE batched
+    launch at the start of its forward (after the collapse of the generator's 5x5 weights), layers the low-precision
+    kernels do not serve keep the fp32 entry points, and fp16 scales the loss seeds / unscales in the optimiser"""
+    from tests.fake_device import PolicyDevice, PolicyOps
+    dev = PolicyDevice()
+    G = dcgan.default_generator(24, True, nch=64, div=[1, 2, 2, 2], initial_size=8)     # 8 -> 128
+    Dn = dcgan.default_discriminator(128, True, nch=64, div=[2, 1, 1], nonlinearity=linear)
+    U = p2p.g_unet(128, True, False, nf=32, act=tanh, bilinear_upsample=True)
+    P = p2p.discriminator(128, True, False, nf=32, act=linear, mul_factor=[1, 2])
+    spec = updates.rmsprop(learning_rate=updates.shared(1e-4))
+    eng = GanStep(dev, G, Dn, U, P, 100, True, 'l1', spec, 'both', use_graph=False, two_streams=False, dtype='f16')
+    assert eng.loss_scale == 32768.0
+    b = eng.built(4)
+    prog = b.train_compute[0] + b.train_compute[1]
+    labels = [e[0] for e in prog]
+    assert labels.count('lp_pack') == 4                                 # one per net
+    lp_entries = [e for e in prog if len(e) > 2 and e[2] and e[2].get('dtype') == 'f16']
+    fp32_convs = [e for e in prog if len(e) > 2 and e[2] and e[2].get('dtype') == 'f32']
+    assert len(lp_entries) >= 20 and len(fp32_convs) >= 10              # both kinds of layers exist in these nets
+    assert {'conv_fwd', 'conv_dgrad', 'conv_wgrad', 'upconv_fwd', 'upconv_wgrad', 'convpool_fwd'} <= {e[0] for e in lp_entries}
+    # in the generator's forward every collapse precedes the batched pack, which precedes the first convolution
+    ga = [e[0] for e in b.train_compute[0]]
+    first_pack = ga.index('lp_pack')
+    assert all(i < first_pack for i, l in enumerate(ga[:ga.index('upconv_fwd')]) if l == 'collapse_w')
+    assert first_pack < ga.index('upconv_fwd')
+    for e in prog + b.update[0] + b.update[1]:
+        e[1]()
+    calls = [o.calls for o in eng.ops]
+    flat = [c for cs in calls for c in cs]
+    seeds = [c for c in flat if c[0] in ('lsgan_loss',) and c[1][3] is not None]
+    assert seeds and all(c[1][4] == 32768.0 for c in seeds)
+    rms = [c for c in flat if c[0] == 'rmsprop']
+    assert len(rms) == 4 and all(abs(c[1][-1] - 1.0 / 32768.0) < 1e-12 for c in rms)
+    # the same nets in fp32: no low-precision call at all
+    eng32 = GanStep(PolicyDevice(), G, Dn, U, P, 100, True, 'l1', spec, 'both', use_graph=False, two_streams=False)
+    p32 = eng32.built(4)
+    assert 'lp_pack' not in [e[0] for lane in p32.train_compute for e in lane]
+
+
+def test_recorded_issue_replays_the_whole_sequence_in_one_call():
+    """use_graph='recorded': call 0 runs eagerly, call 1 records every entry of both stage programs, the exchange and
+    the updates between step_record_begin / _end on ALL contexts (stage, gradient, communication streams) and replays,
+    later calls are one step_run"""
+    events = []
+
+    class RecDevice(FakeDevice):
+        ops_class = RecordingOps
+
+        @staticmethod
+        def step_record_begin(devs):
+            events.append(('begin', len(devs)))
+            return 'step'
+
+        @staticmethod
+        def step_record_end(st):
+            events.append(('end', st))
+
+        @staticmethod
+        def step_run(st):
+            events.append(('run', st))
+
+    dev = RecDevice()
+    G = dcgan.default_generator(24, True, nch=16, div=[2, 2, 4])
+    Dn = dcgan.default_discriminator(32, True, nch=16, div=[4, 2, 2], nonlinearity=linear)
+    U = p2p.g_unet(32, True, False, nf=4, act=tanh, bilinear_upsample=True)
+    P = p2p.discriminator(32, True, False, nf=4, act=linear, mul_factor=[1, 2])
+    spec = updates.rmsprop(learning_rate=updates.shared(1e-4))
+    eng = GanStep(dev, G, Dn, U, P, 100, True, 'l1', spec, 'both', use_graph='recorded')
+    assert eng.side[0] is not None and len(eng._all_devs()) == 4
+    b = eng.built(4)
+    n_entries = len(eng._sequence(b, 'train'))
+    assert n_entries == sum(len(l) for l in b.train_compute) + sum(len(l) for l in b.update)
+    count = lambda: sum(len(o.calls) for o in eng.ops) + sum(len(sd[1].calls) for sd in eng.side)
+    base = count()                               # capability queries made while the plans were built
+    eng.enqueue_train(b)
+    per_step = count() - base
+    assert events == [] and per_step >= n_entries - 50       # fork / join entries are stream waits, not Ops calls
+    eng.enqueue_train(b)
+    assert events == [('begin', 4), ('end', 'step'), ('run', 'step')]
+    assert count() == base + 2 * per_step        # the recording pass issued the same calls once more
+    eng.enqueue_train(b)
+    eng.enqueue_train(b)
+    assert events[3:] == [('run', 'step'), ('run', 'step')] and count() == base + 2 * per_step
+
+
 def test_array_iterator_normalisation_and_layout():
     X, Y = experiments.synthetic_arrays(6, 8, True, False, seed=1)
     it = experiments.ArrayIterator(X, Y, 4, True, False)
