@@ -53,6 +53,7 @@ SIGNATURES = {
     "ghm_conv2d_dgrad": [_p, _D, _p, _p, _p, _p, _i32, _f, _i32],
     "ghm_conv2d_transpose_weights": [_p, _D, _p, _p],
     "ghm_conv2d_dgrad_t": [_p, _D, _p, _p, _p, _p, _i32, _f, _i32],
+    "ghm_conv2d_dgrad_dact": [_p, _D, _p, _p, _p, _p, _i64, _i32, _f, _i32],
     "ghm_conv2d_wgrad_workspace": [_D, C.POINTER(C.c_size_t)],
     "ghm_conv2d_wgrad": [_p, _D, _p, _p, _p, _p, _i32],
     "ghm_lp_weight_bytes": [_D, _i32, C.POINTER(C.c_size_t)],
@@ -105,7 +106,8 @@ SIGNATURES = {
 }
 _SPECIAL = {"ghm_last_error": ([], C.c_char_p), "ghm_bn_workspace": ([_i32], C.c_size_t),
             "ghm_dgrad_t_supported": ([_D], C.c_int), "ghm_lp_supported": ([_D, _i32, _i32], C.c_int),
-            "ghm_conv2d_pool_supported": ([_D, _i32, _i32], C.c_int)}
+            "ghm_conv2d_pool_supported": ([_D, _i32, _i32], C.c_int),
+            "ghm_dgrad_dact_supported": ([_D, _i32], C.c_int)}
 
 _lib = None
 

@@ -140,6 +140,9 @@ int thin_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float
 bool lp_conv_pool_supported(const ghm_conv_desc* d, int act, int dtype);
 int lp_conv_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* wq, const float* bias, float* pooled,
                      unsigned char* mask, int act, float alpha, int dtype);
+bool lp_dgrad_s2_single_pass(const ghm_conv_desc* d, int dtype);
+int lp_dgrad_s2_dact(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* wqT, float* dx, const float* dact_y,
+                     long dact_nstride, int dact, float dact_alpha, int dtype);
 // split-K epilogue of a forward-form convolution: out = act(sum of S partial slices [S][R][N*H*W] + bias (+ out))
 int ghm_splitk_finish(ghm_ctx* ctx, const float* partial, int S, float* out, const float* bias, int N, int R, int H,
                       int W, long out_nstride, int act, float alpha, int accumulate);

@@ -396,6 +396,10 @@ struct SmallKDgradArgs {
     int act;
     float alpha;
     int accumulate;
+    const float* dact_y;       // see PatchArgs
+    long dact_nstride;
+    int dact;
+    float dact_alpha;
 };
 
 __global__ __launch_bounds__(256) void smallk_dgrad_kernel(const SmallKDgradArgs a) {
@@ -425,7 +429,9 @@ __global__ __launch_bounds__(256) void smallk_dgrad_kernel(const SmallKDgradArgs
     }
     float* o = a.dx + (long)n * a.x_nstride + (long)c * HW + rem;
     if (a.accumulate) s += *o;
-    *o = ghm_act(s, a.act, a.alpha);
+    s = ghm_act(s, a.act, a.alpha);
+    if (a.dact_y) s *= a.dact_y[(long)n * a.dact_nstride + (long)c * HW + rem] > 0.f ? 1.f : a.dact_alpha;
+    *o = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -460,6 +466,12 @@ struct PatchArgs {
     const float* zeros;    // ctx->zeros: source of padding elements for the LDS-DMA staging
     float* pool_out;       // POOL: dense [N, R, H/2, W/2] maximum of act(conv + bias) over 2x2 windows ...
     unsigned char* pool_mask;   // ... and the 4-bit arg-max mask of every window (bit 2*dr + dc; all ties set)
+    // data gradients only: out *= act'(dact_y) with dact_y = the (post-activation) tensor whose gradient this is --
+    // the backward of the PRODUCER's nonlinearity folded into this epilogue instead of a separate act_bwd pass
+    const float* dact_y;
+    long dact_nstride;
+    int dact;
+    float dact_alpha;
 };
 
 // The 2x2 max-pool of a patch-kernel accumulator tile, in the epilogue (POOL): a wave owns TN consecutive pixel rows
@@ -687,22 +699,24 @@ __global__ __launch_bounds__(256, ST == 2 ? 3 : 4) void conv_patch_kernel(const 
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    float old[16];
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                        const float* rowp = ub + (long)k * HW + j * a.W;
-                        old[e] = rowp[lo];
-                    }
+                    for (int e0 = 0; e0 < 16; e0 += 4) {          // 4 old values per batch of stores (more spill)
+                        float old[4];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                        float* rowp = ub + (long)k * HW + j * a.W;
-                        const float v = acc[i][j][e] + lb[k] + old[e];
-                        rowp[lo] = v > 0.f ? v : slope * v;
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = i * 32 + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2);
+                            const float* rowp = ub + (long)k * HW + j * a.W;
+                            old[e] = rowp[lo];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = i * 32 + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2);
+                            float* rowp = ub + (long)k * HW + j * a.W;
+                            const float v = acc[i][j][e0 + e] + lb[k] + old[e];
+                            rowp[lo] = v > 0.f ? v : slope * v;
+                        }
                     }
-                }
         }
         return;
     }
@@ -733,7 +747,7 @@ __global__ __launch_bounds__(256, ST == 2 ? 3 : 4) void conv_patch_kernel(const 
 // a.in = dy [N, CH=K, Hc, Wc] (class grid = conv output grid), a.out = dx [N, R=C, 2Hc, 2Wc],
 // a.wp = wpT[k][8 - tap][c].
 // ------------------------------------------------------------------------------------------------
-template <int BM, int WM, int CP>
+template <int BM, int WM, int CP, bool DACT = false>
 __global__ __launch_bounds__(256, 2) void dgrad_s2_patch_kernel(const PatchArgs a) {
     constexpr int T = 9, CB = 2 * CP, RT = 2, WN = 2;
     constexpr int LDA = BM + 4;
@@ -877,9 +891,13 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_patch_kernel(const PatchArgs 
                     } else {
                         float v = acc[cl][i][e];
                         if (a.bias) v += a.bias[r];
-                        float* o = a.out + (long)n * a.out_nstride + (long)r * HWx + (long)y * a.W + x;
+                        const long off = (long)r * HWx + (long)y * a.W + x;
+                        float* o = a.out + (long)n * a.out_nstride + off;
                         if (a.accumulate) v += *o;
-                        *o = ghm_act(v, a.act, a.alpha);
+                        v = ghm_act(v, a.act, a.alpha);
+                        if constexpr (DACT)      // its own instantiation: the plain kernel sits at the VGPR limit.  relu /
+                            v *= a.dact_y[(long)n * a.dact_nstride + off] > 0.f ? 1.f : a.dact_alpha;   // lrelu: slope
+                        *o = v;
                     }
                 }
             }
@@ -1860,6 +1878,35 @@ int ghm_conv2d_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const f
     return launch_igemm<false>(ctx, a);
 }
 
+struct DactArg {
+    const float* y;
+    long nstride;
+    int kind;
+    float alpha;
+};
+
+static bool smallk_dgrad_ok(const ghm_conv_desc* d) {
+    return d->K <= 4 && d->C > 4 && getenv("GHM_NO_SMALLK_DGRAD") == nullptr &&
+           !(d->K <= 4 && thin_fanout_dgrad_ok(d, GHM_ACT_LINEAR)) && !thin_fanin_s2_ok(d, nullptr);
+}
+
+static int launch_smallk_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const float* wp, const float* bias,
+                               float* dx, int act, float alpha, int accumulate, const float* dact_y, long dact_nstride,
+                               int dact, float dact_alpha) {
+    SmallKDgradArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.dy = dy; sa.wp = wp; sa.bias = bias; sa.dx = dx;
+    sa.N = d->N; sa.C = d->C; sa.H = d->H; sa.W = d->W; sa.K = d->K; sa.Ho = d->Ho; sa.Wo = d->Wo;
+    sa.kh = d->kh; sa.kw = d->kw; sa.stride = d->stride; sa.pad = d->pad;
+    sa.x_nstride = d->x_nstride; sa.y_nstride = d->y_nstride;
+    sa.act = act; sa.alpha = alpha; sa.accumulate = accumulate;
+    sa.dact_y = dact_y; sa.dact_nstride = dact_nstride; sa.dact = dact; sa.dact_alpha = dact_alpha;
+    hipLaunchKernelGGL(smallk_dgrad_kernel, dim3(ceil_div((long)d->N * d->C * d->H * d->W, 256)), dim3(256), 0, ctx->stream,
+                       sa);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
 static bool pool_geom_ok(const ghm_conv_desc* d, int act) {
     return (act == GHM_ACT_LINEAR || act == GHM_ACT_RELU || act == GHM_ACT_LRELU) && d->stride == 1 && d->kh == d->kw &&
            d->Ho == d->H && d->Wo == d->W && d->H % 2 == 0 && d->W % 4 == 0 && getenv("GHM_NO_POOL_FUSE") == nullptr;
@@ -1911,19 +1958,7 @@ int ghm_conv2d_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, cons
         return thin_fanout_dgrad(ctx, d, dy, wp, bias, dx, act, alpha, accumulate);
     if (thin_fanin_s2_ok(d, dx)) return thin_fanin_s2(ctx, d, dy, wp, bias, dx, act, alpha, accumulate);
     if (d->C <= 4 && thin_fanin_s1_dgrad_ok(d)) return thin_fanin_s1_dgrad(ctx, d, dy, wp, bias, dx, act, alpha, accumulate);
-    if (d->K <= 4 && d->C > 4 && getenv("GHM_NO_SMALLK_DGRAD") == nullptr) {
-        SmallKDgradArgs sa;
-        memset(&sa, 0, sizeof(sa));
-        sa.dy = dy; sa.wp = wp; sa.bias = bias; sa.dx = dx;
-        sa.N = d->N; sa.C = d->C; sa.H = d->H; sa.W = d->W; sa.K = d->K; sa.Ho = d->Ho; sa.Wo = d->Wo;
-        sa.kh = d->kh; sa.kw = d->kw; sa.stride = d->stride; sa.pad = d->pad;
-        sa.x_nstride = d->x_nstride; sa.y_nstride = d->y_nstride;
-        sa.act = act; sa.alpha = alpha; sa.accumulate = accumulate;
-        hipLaunchKernelGGL(smallk_dgrad_kernel, dim3(ceil_div((long)d->N * d->C * d->H * d->W, 256)), dim3(256), 0,
-                           ctx->stream, sa);
-        GHM_LAUNCH_CHECK();
-        return 0;
-    }
+    if (smallk_dgrad_ok(d)) return launch_smallk_dgrad(ctx, d, dy, wp, bias, dx, act, alpha, accumulate, nullptr, 0, 0, 0.f);
     if (taps_as_rows(d, d->C)) {
         const int T = d->kh * d->kw;
         void* ws = nullptr;
@@ -2008,54 +2043,82 @@ int ghm_transpose_weights_batched(ghm_ctx* ctx, const void* table, int32_t n_ite
     return 0;
 }
 
+// 3x3 stride-2 pad-1 data gradient on the transposed weights (dgrad_s2_patch_kernel); ``da``: fold the producer's
+// activation derivative into the epilogue (single-pass plans only)
+static int dgrad_s2_splits(const ghm_conv_desc* d, int num_cu) {
+    const int bm = d->C >= 96 ? 128 : 64;
+    const int grid = ((d->C + bm - 1) / bm) * (d->Wo / 32) * (d->Ho / 2) * d->N;
+    const int nslabs = d->K / 4;
+    int splits = 1;
+    if (grid < num_cu + num_cu / 2) {
+        splits = (2 * num_cu + grid - 1) / grid;
+        const int maxs = nslabs / 4 > 0 ? nslabs / 4 : 1;
+        if (splits > maxs) splits = maxs;
+    }
+    const int sps = (nslabs + splits - 1) / splits;
+    return (nslabs + sps - 1) / sps;
+}
+
+static int dgrad_s2_patch_launch(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const float* wpT, const float* bias,
+                                 float* dx, int act, float alpha, int accumulate, const DactArg* da) {
+    PatchArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.in = dy; pa.wp = wpT; pa.bias = bias; pa.out = dx;
+    pa.N = d->N; pa.CH = d->K; pa.H = d->H; pa.W = d->W; pa.Hin = d->Ho; pa.Win = d->Wo;
+    pa.in_nstride = d->y_nstride; pa.R = d->C; pa.out_nstride = d->x_nstride; pa.pad = d->pad;
+    pa.act = act; pa.alpha = alpha; pa.accumulate = accumulate;
+    if (da) { pa.dact_y = da->y; pa.dact_nstride = da->nstride; pa.dact = da->kind; pa.dact_alpha = da->alpha; }
+    const int bm = d->C >= 96 ? 128 : 64;
+    constexpr int cb = 4;
+    const int ntr = (d->C + bm - 1) / bm;
+    const int grid = ntr * (d->Wo / 32) * (d->Ho / 2) * d->N;
+    const int nslabs = d->K / cb;
+    int splits = 1;
+    if (grid < ctx->num_cu + ctx->num_cu / 2) {
+        splits = (2 * ctx->num_cu + grid - 1) / grid;
+        const int maxs = nslabs / 4 > 0 ? nslabs / 4 : 1;
+        if (splits > maxs) splits = maxs;
+    }
+    pa.slabs_per_split = (nslabs + splits - 1) / splits;
+    splits = (nslabs + pa.slabs_per_split - 1) / pa.slabs_per_split;
+    GHM_CHECK(!(da && splits > 1), "dgrad + activation derivative needs a single-pass plan (ask ghm_dgrad_dact_supported)");
+    if (splits > 1) {
+        void* ws = nullptr;
+        if (int e = ghm_scratch(ctx, (size_t)splits * pa.R * pa.N * pa.H * pa.W * sizeof(float), &ws)) return e;
+        pa.partial = (float*)ws;
+    }
+    const size_t lds = (size_t)2 * (cb * 9 * (bm + 4) + ((cb * 99 + 3) / 4) * 4) * sizeof(float);
+    const dim3 g(grid, splits);
+    if (da) {
+        if (bm == 128)
+            hipLaunchKernelGGL((dgrad_s2_patch_kernel<128, 2, 2, true>), g, dim3(256), lds, ctx->stream, pa);
+        else
+            hipLaunchKernelGGL((dgrad_s2_patch_kernel<64, 2, 2, true>), g, dim3(256), lds, ctx->stream, pa);
+    } else if (bm == 128)
+        hipLaunchKernelGGL((dgrad_s2_patch_kernel<128, 2, 2>), g, dim3(256), lds, ctx->stream, pa);
+    else
+        hipLaunchKernelGGL((dgrad_s2_patch_kernel<64, 2, 2>), g, dim3(256), lds, ctx->stream, pa);
+    GHM_LAUNCH_CHECK();
+    if (splits > 1) {
+        IgemmArgs e;
+        memset(&e, 0, sizeof(e));
+        e.partial = pa.partial; e.out = dx; e.bias = bias; e.N = d->N; e.R = d->C;
+        e.Hout = d->H; e.Wout = d->W; e.out_nstride = d->x_nstride; e.Hs = d->H; e.Ws = d->W; e.os = 1;
+        e.act = act; e.alpha = alpha; e.accumulate = accumulate;
+        hipLaunchKernelGGL(igemm_splitk_epilogue, dim3(ceil_div((long)d->N * d->H * d->W * d->C, 256)), dim3(256), 0,
+                           ctx->stream, e, splits);
+        GHM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 int ghm_conv2d_dgrad_t(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const float* wpT, const float* bias,
                        float* dx, int32_t act, float alpha, int32_t accumulate) {
     if (int e = check_desc(d)) return e;
     GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
     if (d->stride == 2) {
         GHM_CHECK(ghm_dgrad_t_supported(d), "ghm_conv2d_dgrad_t: this stride-2 geometry has no transposed-weight kernel");
-        PatchArgs pa;
-        memset(&pa, 0, sizeof(pa));
-        pa.in = dy; pa.wp = wpT; pa.bias = bias; pa.out = dx;
-        pa.N = d->N; pa.CH = d->K; pa.H = d->H; pa.W = d->W; pa.Hin = d->Ho; pa.Win = d->Wo;
-        pa.in_nstride = d->y_nstride; pa.R = d->C; pa.out_nstride = d->x_nstride; pa.pad = d->pad;
-        pa.act = act; pa.alpha = alpha; pa.accumulate = accumulate;
-        const int bm = d->C >= 96 ? 128 : 64;
-        constexpr int cb = 4;
-        const int ntr = (d->C + bm - 1) / bm;
-        const int grid = ntr * (d->Wo / 32) * (d->Ho / 2) * d->N;
-        const int nslabs = d->K / cb;
-        int splits = 1;
-        if (grid < ctx->num_cu + ctx->num_cu / 2) {
-            splits = (2 * ctx->num_cu + grid - 1) / grid;
-            const int maxs = nslabs / 4 > 0 ? nslabs / 4 : 1;
-            if (splits > maxs) splits = maxs;
-        }
-        pa.slabs_per_split = (nslabs + splits - 1) / splits;
-        splits = (nslabs + pa.slabs_per_split - 1) / pa.slabs_per_split;
-        if (splits > 1) {
-            void* ws = nullptr;
-            if (int e = ghm_scratch(ctx, (size_t)splits * pa.R * pa.N * pa.H * pa.W * sizeof(float), &ws)) return e;
-            pa.partial = (float*)ws;
-        }
-        const size_t lds = (size_t)2 * (cb * 9 * (bm + 4) + ((cb * 99 + 3) / 4) * 4) * sizeof(float);
-        const dim3 g(grid, splits);
-        if (bm == 128)
-            hipLaunchKernelGGL((dgrad_s2_patch_kernel<128, 2, 2>), g, dim3(256), lds, ctx->stream, pa);
-        else
-            hipLaunchKernelGGL((dgrad_s2_patch_kernel<64, 2, 2>), g, dim3(256), lds, ctx->stream, pa);
-        GHM_LAUNCH_CHECK();
-        if (splits > 1) {
-            IgemmArgs e;
-            memset(&e, 0, sizeof(e));
-            e.partial = pa.partial; e.out = dx; e.bias = bias; e.N = d->N; e.R = d->C;
-            e.Hout = d->H; e.Wout = d->W; e.out_nstride = d->x_nstride; e.Hs = d->H; e.Ws = d->W; e.os = 1;
-            e.act = act; e.alpha = alpha; e.accumulate = accumulate;
-            hipLaunchKernelGGL(igemm_splitk_epilogue, dim3(ceil_div((long)d->N * d->H * d->W * d->C, 256)), dim3(256), 0,
-                               ctx->stream, e, splits);
-            GHM_LAUNCH_CHECK();
-        }
-        return 0;
+        return dgrad_s2_patch_launch(ctx, d, dy, wpT, bias, dx, act, alpha, accumulate, nullptr);
     }
     // the data gradient of a stride-1 conv is the forward conv K -> C with flipped taps (already folded into
     // wpT by ghm_conv2d_transpose_weights) and padding k-1-pad
@@ -2091,6 +2154,29 @@ int ghm_conv2d_dgrad_t(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, co
             a.di[t] = ta - padT; a.dj[t] = tb - padT; a.wi[t] = t;
         }
     return launch_igemm<false>(ctx, a);
+}
+
+int ghm_dgrad_dact_supported(const ghm_conv_desc* d, int32_t dtype) {
+    if (getenv("GHM_NO_DACT_FUSE")) return 0;
+    if (smallk_dgrad_ok(d)) return 1;                                           // fp32 packed wp
+    if (dtype != GHM_DTYPE_F32 && lp_dgrad_s2_single_pass(d, dtype)) return 3;   // low-precision transposed pack
+    if (d->stride == 2 && ghm_dgrad_t_supported(d) && dgrad_s2_splits(d, 256) == 1) return 2;     // fp32 wpT
+    return 0;
+}
+
+int ghm_conv2d_dgrad_dact(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* w, float* dx,
+                          const float* dact_y, int64_t dact_nstride, int32_t dact, float dact_alpha, int32_t dtype) {
+    if (int e = check_desc(d)) return e;
+    const int form = ghm_dgrad_dact_supported(d, dtype);
+    GHM_CHECK(form != 0 && dact_y != nullptr, "ghm_conv2d_dgrad_dact: not served (ask ghm_dgrad_dact_supported)");
+    GHM_CHECK(dact == GHM_ACT_RELU || dact == GHM_ACT_LRELU, "ghm_conv2d_dgrad_dact: relu / leaky relu only");
+    if (dact == GHM_ACT_RELU) dact_alpha = 0.f;          // the kernels multiply by (y > 0 ? 1 : slope)
+    if (form == 1)
+        return launch_smallk_dgrad(ctx, d, dy, (const float*)w, nullptr, dx, GHM_ACT_LINEAR, 0.f, 0, dact_y, (long)dact_nstride,
+                                   dact, dact_alpha);
+    if (form == 3) return lp_dgrad_s2_dact(ctx, d, dy, w, dx, dact_y, (long)dact_nstride, dact, dact_alpha, dtype);
+    const DactArg da = {dact_y, (long)dact_nstride, dact, dact_alpha};
+    return dgrad_s2_patch_launch(ctx, d, dy, (const float*)w, nullptr, dx, GHM_ACT_LINEAR, 0.f, 0, &da);
 }
 
 int ghm_conv2d_wgrad_workspace(const ghm_conv_desc* d, size_t* bytes) {

@@ -170,6 +170,11 @@ struct LpConvArgs {
     int slabs_per_split;
     float* pool_out;            // POOL: dense [N, R, H/2, W/2] maximum of act(conv + bias) over 2x2 windows ...
     unsigned char* pool_mask;   // ... and the 4-bit arg-max mask of every window (bit 2*dr + dc; all ties set)
+    // stride-2 data gradient only: out *= act'(dact_y): the backward of the producer's nonlinearity in this epilogue
+    const float* dact_y;
+    long dact_nstride;
+    int dact;
+    float dact_alpha;
 };
 
 __device__ __forceinline__ void lp_pool2_store(float v0, float v1, bool col_even, bool live, float* po, unsigned char* pm) {
@@ -585,7 +590,14 @@ __global__ __launch_bounds__(256, 2) void lp_dgrad_s2_kernel(const LpConvArgs a)
                             const float2 old = *reinterpret_cast<const float2*>(o);
                             v0 += old.x; v1 += old.y;
                         }
-                        *reinterpret_cast<float2*>(o) = make_float2(ghm_act(v0, a.act, a.alpha), ghm_act(v1, a.act, a.alpha));
+                        v0 = ghm_act(v0, a.act, a.alpha);
+                        v1 = ghm_act(v1, a.act, a.alpha);
+                        if (a.dact_y) {
+                            const float2 yy = *reinterpret_cast<const float2*>(a.dact_y + (long)n * a.dact_nstride + (long)r * HWx + pix);
+                            v0 *= yy.x > 0.f ? 1.f : a.dact_alpha;        // relu / leaky relu: the slope of the producer
+                            v1 *= yy.y > 0.f ? 1.f : a.dact_alpha;
+                        }
+                        *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
                     }
                 }
         }
@@ -1000,6 +1012,26 @@ bool lp_fwd_geom(const ghm_conv_desc* d) {
 int rpad128(int r) { return (r + 127) / 128 * 128; }
 
 }  // namespace
+
+bool lp_dgrad_s2_single_pass(const ghm_conv_desc* d, int dtype) {
+    if (dtype != GHM_DTYPE_BF16 && dtype != GHM_DTYPE_F16) return false;
+    const LpPlan pl = lp_plan_dgrad_s2(d, 256);
+    return pl.ok && pl.splits == 1 && (d->x_nstride & 1) == 0;
+}
+
+int lp_dgrad_s2_dact(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* wqT, float* dx, const float* dact_y,
+                     long dact_nstride, int dact, float dact_alpha, int dtype) {
+    const LpPlan pl = lp_plan_dgrad_s2(d, ctx->num_cu);
+    GHM_CHECK(pl.ok && pl.splits == 1, "lp_dgrad_s2_dact: not a single-pass plan");
+    LpConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = dy; a.wq = (const u32x4*)wqT; a.out = dx;
+    a.N = d->N; a.CH = d->K; a.H = d->H; a.W = d->W; a.Hin = d->Ho; a.Win = d->Wo; a.in_nstride = d->y_nstride;
+    a.R = d->C; a.Rpad = rpad128(d->C); a.out_nstride = d->x_nstride; a.pad = d->pad;
+    a.act = GHM_ACT_LINEAR;
+    a.dact_y = dact_y; a.dact_nstride = dact_nstride; a.dact = dact; a.dact_alpha = dact_alpha;
+    return dtype == GHM_DTYPE_BF16 ? lp_launch_dgrad_s2<GHM_DTYPE_BF16>(ctx, pl, a) : lp_launch_dgrad_s2<GHM_DTYPE_F16>(ctx, pl, a);
+}
 
 static bool lp_pool_act_ok(int act) { return act == GHM_ACT_LINEAR || act == GHM_ACT_RELU || act == GHM_ACT_LRELU; }
 

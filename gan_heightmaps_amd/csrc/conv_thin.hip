@@ -191,22 +191,40 @@ __global__ __launch_bounds__(320, 2) void fanout_kernel(const FanoutArgs a) {
                             const float4 t = *reinterpret_cast<const float4*>(sbias + rb * 32 + 8 * e4 + 4 * h);
                             bv[4 * e4] = t.x; bv[4 * e4 + 1] = t.y; bv[4 * e4 + 2] = t.z; bv[4 * e4 + 3] = t.w;
                         }
+                        // a lane owns one window per channel row; lanes (2t, 2t+1) trade every other row so that each
+                        // stores TWO adjacent pooled pixels of one row: 8-byte value + 2-byte mask stores, half as many
+                        const bool odd = l & 1;
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
+                        for (int e2 = 0; e2 < 8; ++e2) {
+                            // rows ea (kept by even lanes) and eb (kept by odd lanes): two registers live at a time
+                            const int ea = 2 * e2, eb = 2 * e2 + 1;
+                            float pm[2];
+                            unsigned pk[2];
+#pragma unroll
+                            for (int z = 0; z < 2; ++z) {
+                                const int e = 2 * e2 + z;
+                                float v[4];
+#pragma unroll
+                                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                                    for (int k = 0; k < 2; ++k) {
+                                        const float t = acc[q][k][rb][e] + bv[e];
+                                        v[2 * q + k] = t > 0.f ? t : slope * t;
+                                    }
+                                pm[z] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                                pk[z] = (v[0] == pm[z] ? 1u : 0u) | (v[1] == pm[z] ? 2u : 0u) | (v[2] == pm[z] ? 4u : 0u) |
+                                        (v[3] == pm[z] ? 8u : 0u);
+                            }
+                            const float keep = odd ? pm[1] : pm[0], send = odd ? pm[0] : pm[1];
+                            const unsigned keepk = odd ? pk[1] : pk[0], sendk = odd ? pk[0] : pk[1];
+                            const float recv = __shfl_xor(send, 1, 64);
+                            const unsigned recvk = (unsigned)__shfl_xor((int)sendk, 1, 64);
+                            const int e = odd ? eb : ea;
                             const int row = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                            float v[4];
-#pragma unroll
-                            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                                for (int k = 0; k < 2; ++k) {
-                                    const float t = acc[q][k][rb][e] + bv[e];
-                                    v[2 * q + k] = t > 0.f ? t : slope * t;
-                                }
-                            const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                            const long o = pbase + (long)row * HWp;
-                            a.pool_out[o] = m;
-                            a.pool_mask[o] = (unsigned char)((v[0] == m ? 1u : 0u) | (v[1] == m ? 2u : 0u) |
-                                                             (v[2] == m ? 4u : 0u) | (v[3] == m ? 8u : 0u));
+                            const long o = pbase - (odd ? 1 : 0) + (long)row * HWp;      // first pixel of the lane pair
+                            *reinterpret_cast<float2*>(a.pool_out + o) = odd ? make_float2(recv, keep) : make_float2(keep, recv);
+                            *reinterpret_cast<unsigned short*>(a.pool_mask + o) =
+                                (unsigned short)(odd ? (recvk | (keepk << 8)) : (keepk | (recvk << 8)));
                         }
                     }
                     continue;

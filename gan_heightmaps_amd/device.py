@@ -289,6 +289,16 @@ class Ops:
         call("ghm_conv2d_dgrad_t", self.h, C.byref(d), _vp(dy), _vp(wpT), _vp(bias), _vp(dx), ACT_CODES[act], alpha,
              int(accumulate))
 
+    def dgrad_dact_supported(self, d, dtype='f32'):
+        """0: not served; 1 / 2 / 3: served, reading the fp32 packed wp / the fp32 wpT / the low-precision wqT"""
+        return int(_lib.load().ghm_dgrad_dact_supported(C.byref(d), DTYPE_CODES[dtype]))
+
+    def conv2d_dgrad_dact(self, d, dy, w, dx, y, act, alpha, dtype='f32'):
+        """dx = conv^T(dy) * act'(y): the data gradient with the producer's activation backward in its epilogue"""
+        assert y.shape == dx.shape
+        call("ghm_conv2d_dgrad_dact", self.h, C.byref(d), _vp(dy), _vp(w), _vp(dx), _vp(y), y.nstride, ACT_CODES[act], alpha,
+             DTYPE_CODES[dtype])
+
     def wgrad_workspace(self, d):
         n = C.c_size_t()
         call("ghm_conv2d_wgrad_workspace", C.byref(d), C.byref(n))

@@ -795,7 +795,31 @@ class NetPlan:
                         prog.append(("bias_grad", lambda G=G, gb=gb, aw=aw, wo=wo: wo.channel_sum(G, gb, aw), None, wdev))
                 if need_dx:
                     gi, acc = target(xin)
-                    if n.op == 'deconv':
+                    # the producer's own nonlinearity (a conv -> LeakyRectify -> conv chain without BatchNorm: the
+                    # PatchGAN, p2p.py:285-286) differentiated in THIS data gradient's epilogue instead of a separate
+                    # read-modify-write pass over the gradient tensor
+                    form = 0
+                    if (not acc and n.op in ('conv', 'convpool') and xin.op in ('conv', 'deconv', 'dense')
+                            and xin.act.kind in ('relu', 'lrelu') and len(xin.consumers) == 1 and not xin.aux.get(('grad_is_pre', key))):
+                        form = ops.dgrad_dact_supported(self._desc(n, gi, G), self.dtype) or 0
+                    if form:
+                        d2 = self._desc(n, gi, G)
+                        dt = 'f32'
+                        if form == 1:
+                            wsel = w
+                        elif form == 2:
+                            wsel = st.transposed(l.W)
+                            if id(l.W) not in transposed:
+                                transposed.add(id(l.W))
+                                prog.append(("transpose_w", lambda d=d2, w=w, wT=wsel: ops.transpose_weights(d, w, wT)))
+                        else:
+                            wsel, dt = self._lp_pack_entry(prog, d2, w, ('w', id(l.W)), True, transposed), self.dtype
+                        xa = xin.act
+                        prog.append(("conv_dgrad", lambda d=d2, G=G, wsel=wsel, gi=gi, x=x, xa=xa, dt=dt:
+                                     ops.conv2d_dgrad_dact(d, G, wsel, gi, x, xa.kind, xa.alpha, dt),
+                                     conv_meta(ops, d2, 3 if form != 1 else 1, dt)))
+                        xin.aux[('grad_is_pre', key)] = True
+                    elif n.op == 'deconv':
                         d2 = self._desc(n, G, gi)
                         prog.append(("deconv_dgrad", lambda d=d2, G=G, w=w, gi=gi, acc=acc:
                                      ops.conv2d_fwd(d, G, w, None, gi, 'linear', 0.0, acc), conv_meta(ops, d2, 0)))

@@ -703,3 +703,40 @@ def test_conv_pool_not_served_is_refused(gpu):
     with pytest.raises(GhmError):
         ops.conv2d_fwd_pool(d, dev.zeros((2, 16, 16, 16)), dev.zeros((1, 64, 1, 1)), None, dev.zeros((2, 64, 8, 8)),
                             dev.alloc(2 * 64 * 64), 'lrelu', 0.2)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [(8, 64, 256, 256, 128, 3, 2, 1), (8, 128, 128, 128, 256, 3, 2, 1), (4, 64, 32, 32, 1, 3, 2, 1),
+                                  (2, 32, 16, 16, 2, 5, 1, 2)])
+def test_dgrad_with_producer_activation_backward_fused(gpu, case, dtype):
+    """ghm_conv2d_dgrad_dact: dx = conv^T(dy) * act'(y) in one kernel (PatchGAN conv -> LeakyRectify -> conv chains,
+    p2p.py:285-286) == the plain data gradient followed by ghm_act_bwd, bit for bit, in every served form (<= 4
+    filters; 3x3 stride 2 on the fp32 and on the bf16 matrix cores)."""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(sum(case))
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    form = ops.dgrad_dact_supported(d, dtype)
+    assert form == (1 if K <= 4 else (3 if dtype == 'bf16' else 2)), (case, dtype, form)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    wp = dev.tensor(D.pack_conv_w(Wt).ravel())
+    dy = dev.tensor(rng.randn(N, K, d.Ho, d.Wo).astype(np.float32))
+    y = dev.tensor(rng.randn(N, C, H, W).astype(np.float32))           # the producer's (post-LeakyReLU) output
+    fused, plain = dev.empty((N, C, H, W)), dev.empty((N, C, H, W))
+    if form == 1:
+        w = wp
+        ops.conv2d_dgrad(d, dy, wp, plain)
+    elif form == 2:
+        w = dev.empty((1, C * k * k * K, 1, 1))
+        ops.transpose_weights(d, wp, w)
+        ops.conv2d_dgrad_t(d, dy, w, plain)
+    else:
+        w = dev.alloc(ops.lp_weight_bytes(d, True))
+        ops.lp_pack_weights(d, wp, w, dtype, True)
+        ops.conv2d_dgrad_lp(d, dy, w, plain, dtype)
+    ops.act_bwd(plain, y, plain, 'lrelu', 0.01)
+    ops.conv2d_dgrad_dact(d, dy, w, fused, y, 'lrelu', 0.01, dtype)
+    a, b = fused.numpy(), plain.numpy()
+    assert np.array_equal(a, b) and np.abs(a).max() > 0
+    for t in (wp, dy, y, fused, plain):
+        dev.free(t.ptr)
