@@ -748,28 +748,29 @@ __global__ __launch_bounds__(256, ST == 2 ? 3 : 4) void conv_patch_kernel(const 
 // a.wp = wpT[k][8 - tap][c].
 // ------------------------------------------------------------------------------------------------
 template <int BM, int WM, int CP, bool DACT = false>
-__global__ __launch_bounds__(256, 2) void dgrad_s2_patch_kernel(const PatchArgs a) {
-    constexpr int T = 9, CB = 2 * CP, RT = 2, WN = 2;
-    constexpr int LDA = BM + 4;
+__global__ __launch_bounds__(256, 3) void dgrad_s2_patch_kernel(const PatchArgs a) {
+    constexpr int T = 9, CB = 2 * CP, WN = 4 / WM, RT = WN;      // a wave: BM/WM channels x one class row x 4 classes
+    constexpr int LDA = BM;                         // unpadded: both LDS images are linear in the DMA fetch index
     constexpr int PH = RT + 1, PWN = 33, PW = 33, PS = PH * PW;
     constexpr int KR = CB * T;
     constexpr int ASZ = KR * LDA, PSZ = ((CB * PS + 3) / 4) * 4;
     constexpr int TM = BM / (WM * 32);
     static_assert(WM * WN == 4, "4 waves");
     constexpr int AV = BM / 4;
-    constexpr int AL = (KR * AV + 255) / 256;
+    constexpr int NA4 = KR * AV;
+    constexpr int AL = (NA4 + 255) / 256;
     constexpr int NEL = CB * PH * PWN;
     constexpr int BL = (NEL + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Ps = smem + 2 * ASZ;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int frag_k = lane >> 5, frag_i = lane & 31;
     const int Hc = a.Hin, Wc = a.Win;                 // class grid == dy grid
     const int ntr = (a.R + BM - 1) / BM;
-    const int tiles_x = Wc / 32, tiles_y = Hc / RT;
+    const int tiles_x = Wc / 32, tiles_y = (Hc + RT - 1) / RT;
     int L = xcd_remap(blockIdx.x, gridDim.x);
     const int r0 = (L % ntr) * BM;
     L /= ntr;
@@ -783,16 +784,19 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_patch_kernel(const PatchArgs 
     const int s_begin = blockIdx.y * a.slabs_per_split;
     const int s_end = min(nslabs, s_begin + a.slabs_per_split);
 
-    int a_off[AL], a_lds[AL];
+    // staging exactly as in conv_patch_kernel: weight slab (float4 f = row * AV + c4) and dy patch (element e =
+    // (c, py, px)) by global->LDS DMA one slab ahead; the patch only needs padding on its far edges (rows i, i+1)
+    int a_off[AL];
+    unsigned amask = 0;
 #pragma unroll
     for (int q = 0; q < AL; ++q) {
-        const int e = tid + q * 256;
-        const int row = e / AV, c4 = e - row * AV;
-        const bool v = row < KR && (r0 + c4 * 4) < a.R;
-        a_lds[q] = v ? row * LDA + c4 * 4 : -1;
+        const int f = tid + q * 256;
+        const int row = f / AV, c4 = f - row * AV;
+        const bool v = f < NA4 && (r0 + c4 * 4) < a.R;
         a_off[q] = v ? row * a.R + r0 + c4 * 4 : 0;
+        amask |= (v ? 1u : 0u) << q;
     }
-    int p_off[BL], p_lds[BL];
+    int p_off[BL];
     unsigned pmask = 0;
 #pragma unroll
     for (int q = 0; q < BL; ++q) {
@@ -800,9 +804,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_patch_kernel(const PatchArgs 
         const int c = e / (PH * PWN), r = e - c * (PH * PWN);
         const int py = r / PWN, px = r - py * PWN;
         const int y = i0 + py, x = j0 + px;
-        const bool inr = e < NEL;
-        const bool ok = inr && y < Hc && x < Wc;
-        p_lds[q] = inr ? c * PS + py * PW + px : -1;
+        const bool ok = e < NEL && y < Hc && x < Wc;
         p_off[q] = ok ? c * HWc + y * Wc + x : 0;
         pmask |= (ok ? 1u : 0u) << q;
     }
@@ -810,30 +812,29 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_patch_kernel(const PatchArgs 
     const float* ibase = a.in + (long)n * a.in_nstride + (long)s_begin * CB * HWc;
     const long a_step = (long)KR * a.R, p_step = (long)CB * HWc;
 
-    float areg[AL * 4];
-    float breg[BL];
-    auto load_slab = [&]() {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto stage_slab = [&](int buf) {
+        float* Ab = As + buf * ASZ + wave * 256;
+        float* Pb = Ps + buf * PSZ + wave * 64;
 #pragma unroll
         for (int q = 0; q < AL; ++q) {
-            const float4 t = *reinterpret_cast<const float4*>(wbase + a_off[q]);
-            areg[4 * q + 0] = t.x; areg[4 * q + 1] = t.y; areg[4 * q + 2] = t.z; areg[4 * q + 3] = t.w;
+            if (q * 256 + wave * 64 < NA4) {
+                const float* g = ((amask >> q) & 1u) ? wbase + a_off[q] : a.zeros;
+                if (tid + q * 256 < NA4)
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Ab + q * 1024), 16, 0, 0);
+            }
         }
 #pragma unroll
-        for (int q = 0; q < BL; ++q) breg[q] = ibase[p_off[q]];
+        for (int q = 0; q < BL; ++q) {
+            if (q * 256 + wave * 64 < NEL) {
+                const float* g = ((pmask >> q) & 1u) ? ibase + p_off[q] : a.zeros;
+                if (tid + q * 256 < NEL)
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Pb + q * 256), 4, 0, 0);
+            }
+        }
         wbase += a_step;
         ibase += p_step;
-    };
-    auto store_slab = [&](int buf) {
-        float* Ab = As + buf * ASZ;
-        float* Pb = Ps + buf * PSZ;
-#pragma unroll
-        for (int q = 0; q < AL; ++q)
-            if (a_lds[q] >= 0)
-                *reinterpret_cast<float4*>(Ab + a_lds[q]) =
-                    make_float4(areg[4 * q + 0], areg[4 * q + 1], areg[4 * q + 2], areg[4 * q + 3]);
-#pragma unroll
-        for (int q = 0; q < BL; ++q)
-            if (p_lds[q] >= 0) Pb[p_lds[q]] = ((pmask >> q) & 1u) ? breg[q] : 0.f;
     };
 
     f32x16 acc[4][TM];                              // [parity class pu*2+pv][row tile]
@@ -844,65 +845,87 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_patch_kernel(const PatchArgs 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[cl][i][e] = 0.f;
 
-    if (s_begin < s_end) {
-        load_slab();
-        store_slab(0);
-    }
+    if (s_begin < s_end) stage_slab(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int abase = frag_k * T * LDA + wm * (BM / WM) + frag_i;
     const int pbase = frag_k * PS + wn * PW + frag_i;
+    // k-step ks = (cp, tw): tw = tap index in wpT order = 8 - original tap (ta, tb); the tap feeds class
+    // (pu, pv) = (ta != 1, tb != 1) from dy[i + (ta == 0)][j + (tb == 0)]
+    auto a_off_of = [](int ks) { return (2 * (ks / T) * T + ks % T) * LDA; };
+    auto p_off_of = [](int ks) {
+        const int tw = ks % T, ta = (8 - tw) / 3, tb = (8 - tw) % 3;
+        return 2 * (ks / T) * PS + (ta == 0 ? 1 : 0) * PW + (tb == 0 ? 1 : 0);
+    };
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
         const bool more = (s + 1) < s_end;
-        if (more) load_slab();
+        if (more) stage_slab(buf ^ 1);
         const float* Ab = As + buf * ASZ + abase;
         const float* Pb = Ps + buf * PSZ + pbase;
+        float af[2][TM], bf[2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = Ab[a_off_of(0) + i * 32];
+        bf[0] = Pb[p_off_of(0)];
 #pragma unroll
         for (int ks = 0; ks < CP * T; ++ks) {
-            const int cp = ks / T, tw = ks % T;             // tw: tap index in wpT order = 8 - original tap
-            const int ta = (8 - tw) / 3, tb = (8 - tw) % 3;  // original (a, b)
-            const int pu = ta == 1 ? 0 : 1, pv = tb == 1 ? 0 : 1;
-            const int di = ta == 0 ? 1 : 0, dj = tb == 0 ? 1 : 0;
-            const float bf = Pb[2 * cp * PS + di * PW + dj];
+            if (ks + 1 < CP * T) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float af = Ab[(2 * cp * T + tw) * LDA + i * 32];
-                acc[pu * 2 + pv][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[pu * 2 + pv][i], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) af[(ks + 1) & 1][i] = Ab[a_off_of(ks + 1) + i * 32];
+                bf[(ks + 1) & 1] = Pb[p_off_of(ks + 1)];
             }
-            if (ks == (CP * T) / 2 - 1 && more) store_slab(buf ^ 1);
+            const int tw = ks % T, ta = (8 - tw) / 3, tb = (8 - tw) % 3;
+            const int cl = (ta == 1 ? 0 : 2) + (tb == 1 ? 0 : 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[cl][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1], acc[cl][i], 0, 0, 0);
+            if (ks + 1 < CP * T) GHM_INTERLEAVE(TM);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
+    // epilogue: the two column parities of class pixel (ic, jc) are dx columns 2jc, 2jc+1 -- both in this lane: one
+    // 8-byte store per (row parity, channel).  Wave-uniform row pointers + one 32-bit lane offset (as conv_patch_kernel).
     const long P = (long)a.N * HWx;
-    const int ic = i0 + wn, jc = j0 + frag_i;
+    const int ic = i0 + wn;                                       // uniform
+    const int ru = r0 + wm * (BM / WM), rl = ru + 4 * frag_k;
+    float* const sb = smem;                                       // bias through LDS (free after the last slab barrier)
+    if (tid < BM) sb[tid] = (a.bias && !a.partial && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
+    __syncthreads();
+    if (ic >= Hc) return;
+    const float* const lb = sb + wm * (BM / WM) + 4 * frag_k;
+    const long rowpix = (long)(2 * ic) * a.W + 2 * j0;
+    float* const ub = a.partial ? a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HWx + rowpix
+                                : a.out + (long)n * a.out_nstride + (long)ru * HWx + rowpix;
+    const long rstride = a.partial ? P : (long)HWx;
+    const unsigned lo = 4u * frag_k * (unsigned)rstride + 2u * frag_i;
+    const float* const yb = DACT ? a.dact_y + (long)n * a.dact_nstride + (long)ru * HWx + rowpix : nullptr;
+    const bool plain = a.partial != nullptr;
 #pragma unroll
-    for (int cl = 0; cl < 4; ++cl) {
-        const int y = 2 * ic + (cl >> 1), x = 2 * jc + (cl & 1);
-        const long pix = (long)n * HWx + (long)y * a.W + x;
+    for (int pu = 0; pu < 2; ++pu)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int r = r0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * frag_k;
-                if (r < a.R) {
-                    if (a.partial) {
-                        a.partial[((long)blockIdx.y * a.R + r) * P + pix] = acc[cl][i][e];
-                    } else {
-                        float v = acc[cl][i][e];
-                        if (a.bias) v += a.bias[r];
-                        const long off = (long)r * HWx + (long)y * a.W + x;
-                        float* o = a.out + (long)n * a.out_nstride + off;
-                        if (a.accumulate) v += *o;
-                        v = ghm_act(v, a.act, a.alpha);
-                        if constexpr (DACT)      // its own instantiation: the plain kernel sits at the VGPR limit.  relu /
-                            v *= a.dact_y[(long)n * a.dact_nstride + off] > 0.f ? 1.f : a.dact_alpha;   // lrelu: slope
-                        *o = v;
+                const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                if (rl + k < a.R) {
+                    float2* o = reinterpret_cast<float2*>(ub + (long)k * rstride + pu * a.W + lo);
+                    float2 v = make_float2(acc[2 * pu][i][e], acc[2 * pu + 1][i][e]);
+                    if (!plain) {
+                        v.x += lb[k]; v.y += lb[k];
+                        if (a.accumulate) { const float2 old = *o; v.x += old.x; v.y += old.y; }
+                        v.x = ghm_act(v.x, a.act, a.alpha);
+                        v.y = ghm_act(v.y, a.act, a.alpha);
+                        if constexpr (DACT) {    // its own instantiation (register budget).  relu / lrelu: slope
+                            const float2 yy = *reinterpret_cast<const float2*>(yb + (long)k * HWx + pu * a.W + lo);
+                            v.x *= yy.x > 0.f ? 1.f : a.dact_alpha;
+                            v.y *= yy.y > 0.f ? 1.f : a.dact_alpha;
+                        }
                     }
+                    *o = v;
                 }
             }
-        }
-    }
 }
 
 // wpT[k][T-1-tap][c] = wp[c][tap][k]: packed weights of the adjoint convolution (data gradient as a forward conv)
@@ -2047,7 +2070,8 @@ int ghm_transpose_weights_batched(ghm_ctx* ctx, const void* table, int32_t n_ite
 // activation derivative into the epilogue (single-pass plans only)
 static int dgrad_s2_splits(const ghm_conv_desc* d, int num_cu) {
     const int bm = d->C >= 96 ? 128 : 64;
-    const int grid = ((d->C + bm - 1) / bm) * (d->Wo / 32) * (d->Ho / 2) * d->N;
+    const int rt = bm == 128 ? 2 : 4;
+    const int grid = ((d->C + bm - 1) / bm) * (d->Wo / 32) * ((d->Ho + rt - 1) / rt) * d->N;
     const int nslabs = d->K / 4;
     int splits = 1;
     if (grid < num_cu + num_cu / 2) {
@@ -2071,7 +2095,8 @@ static int dgrad_s2_patch_launch(ghm_ctx* ctx, const ghm_conv_desc* d, const flo
     const int bm = d->C >= 96 ? 128 : 64;
     constexpr int cb = 4;
     const int ntr = (d->C + bm - 1) / bm;
-    const int grid = ntr * (d->Wo / 32) * (d->Ho / 2) * d->N;
+    const int rt = bm == 128 ? 2 : 4;               // class rows per block (= waves along rows)
+    const int grid = ntr * (d->Wo / 32) * ((d->Ho + rt - 1) / rt) * d->N;
     const int nslabs = d->K / cb;
     int splits = 1;
     if (grid < ctx->num_cu + ctx->num_cu / 2) {
@@ -2087,17 +2112,18 @@ static int dgrad_s2_patch_launch(ghm_ctx* ctx, const ghm_conv_desc* d, const flo
         if (int e = ghm_scratch(ctx, (size_t)splits * pa.R * pa.N * pa.H * pa.W * sizeof(float), &ws)) return e;
         pa.partial = (float*)ws;
     }
-    const size_t lds = (size_t)2 * (cb * 9 * (bm + 4) + ((cb * 99 + 3) / 4) * 4) * sizeof(float);
+    pa.zeros = (const float*)ctx->zeros;
+    const size_t lds = (size_t)2 * (cb * 9 * bm + ((cb * (rt + 1) * 33 + 3) / 4) * 4) * sizeof(float);
     const dim3 g(grid, splits);
     if (da) {
         if (bm == 128)
             hipLaunchKernelGGL((dgrad_s2_patch_kernel<128, 2, 2, true>), g, dim3(256), lds, ctx->stream, pa);
         else
-            hipLaunchKernelGGL((dgrad_s2_patch_kernel<64, 2, 2, true>), g, dim3(256), lds, ctx->stream, pa);
+            hipLaunchKernelGGL((dgrad_s2_patch_kernel<64, 1, 2, true>), g, dim3(256), lds, ctx->stream, pa);
     } else if (bm == 128)
         hipLaunchKernelGGL((dgrad_s2_patch_kernel<128, 2, 2>), g, dim3(256), lds, ctx->stream, pa);
     else
-        hipLaunchKernelGGL((dgrad_s2_patch_kernel<64, 2, 2>), g, dim3(256), lds, ctx->stream, pa);
+        hipLaunchKernelGGL((dgrad_s2_patch_kernel<64, 1, 2>), g, dim3(256), lds, ctx->stream, pa);
     GHM_LAUNCH_CHECK();
     if (splits > 1) {
         IgemmArgs e;
@@ -2356,7 +2382,7 @@ int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t 
             snprintf(out, out_len, "conv_patch_kernel<%d, %d, %d, %d, %d, %d, 1> splits=%d", d->kh, pl.bm, pl.rt,
                      pl.bm == 128 ? 2 : 1, pl.bm == 128 ? 2 : 4, d->kh == 5 ? 1 : 2, pl.splits);
         else if (d->stride == 2)
-            snprintf(out, out_len, "dgrad_s2_patch_kernel<%d, 2, 2>", d->C >= 96 ? 128 : 64);
+            snprintf(out, out_len, "dgrad_s2_patch_kernel<%d, %d, 2>", d->C >= 96 ? 128 : 64, d->C >= 96 ? 2 : 1);
         else
             snprintf(out, out_len, "igemm_kernel<fwd on wT>");
         return 0;
