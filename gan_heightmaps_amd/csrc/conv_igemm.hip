@@ -2068,20 +2068,40 @@ int ghm_transpose_weights_batched(ghm_ctx* ctx, const void* table, int32_t n_ite
 
 // 3x3 stride-2 pad-1 data gradient on the transposed weights (dgrad_s2_patch_kernel); ``da``: fold the producer's
 // activation derivative into the epilogue (single-pass plans only)
-static int dgrad_s2_splits(const ghm_conv_desc* d, int num_cu) {
-    const int bm = d->C >= 96 ? 128 : 64;
-    const int rt = bm == 128 ? 2 : 4;
-    const int grid = ((d->C + bm - 1) / bm) * (d->Wo / 32) * ((d->Ho + rt - 1) / rt) * d->N;
-    const int nslabs = d->K / 4;
-    int splits = 1;
-    if (grid < num_cu + num_cu / 2) {
-        splits = (2 * num_cu + grid - 1) / grid;
-        const int maxs = nslabs / 4 > 0 ? nslabs / 4 : 1;
-        if (splits > maxs) splits = maxs;
+struct DgradS2Plan {
+    int bm, wm, rt;             // channels per block, waves along channels (4 / wm class rows per block)
+    int grid, splits, slabs_per_split;
+};
+
+// Tile choice: the split-K form writes `splits` partial dx tensors and re-reads them -- for these layers that is more
+// HBM traffic than the kernel's own operands, so a grid that is too small first shrinks the tile (128 ch x 2 rows ->
+// 64 x 4 -> 64 x 2 class rows) and only splits the contraction when even the smallest tile leaves CUs idle.
+static DgradS2Plan dgrad_s2_plan(const ghm_conv_desc* d, int num_cu) {
+    static const int tiles[3][2] = {{128, 2}, {64, 1}, {64, 2}};
+    DgradS2Plan p;
+    int first = d->C >= 96 ? 0 : 1, forced = -1;
+    if (const char* f = getenv("GHM_DGRAD_S2_TILE")) forced = atoi(f);
+    for (int t = first; t < 3; ++t) {
+        if (forced >= 0) t = forced > 2 ? 2 : forced;
+        p.bm = tiles[t][0]; p.wm = tiles[t][1]; p.rt = 4 / p.wm;
+        p.grid = ((d->C + p.bm - 1) / p.bm) * (d->Wo / 32) * ((d->Ho + p.rt - 1) / p.rt) * d->N;
+        // measured (tools/s2_sweep.sh): the 128-channel tile only pays on grids of several waves of blocks
+        if (forced >= 0 || p.grid >= (t == 0 ? 4 : 2) * num_cu) break;
     }
-    const int sps = (nslabs + splits - 1) / splits;
-    return (nslabs + sps - 1) / sps;
+    const int nslabs = d->K / 4;
+    p.splits = 1;
+    if (p.grid < num_cu) {
+        p.splits = (2 * num_cu + p.grid - 1) / p.grid;
+        const int maxs = nslabs / 4 > 0 ? nslabs / 4 : 1;
+        if (p.splits > maxs) p.splits = maxs;
+    }
+    if (const char* f = getenv("GHM_DGRAD_S2_SPLITS")) p.splits = atoi(f) < 1 ? 1 : atoi(f);
+    p.slabs_per_split = (nslabs + p.splits - 1) / p.splits;
+    p.splits = (nslabs + p.slabs_per_split - 1) / p.slabs_per_split;
+    return p;
 }
+
+static int dgrad_s2_splits(const ghm_conv_desc* d, int num_cu) { return dgrad_s2_plan(d, num_cu).splits; }
 
 static int dgrad_s2_patch_launch(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const float* wpT, const float* bias,
                                  float* dx, int act, float alpha, int accumulate, const DactArg* da) {
@@ -2092,20 +2112,10 @@ static int dgrad_s2_patch_launch(ghm_ctx* ctx, const ghm_conv_desc* d, const flo
     pa.in_nstride = d->y_nstride; pa.R = d->C; pa.out_nstride = d->x_nstride; pa.pad = d->pad;
     pa.act = act; pa.alpha = alpha; pa.accumulate = accumulate;
     if (da) { pa.dact_y = da->y; pa.dact_nstride = da->nstride; pa.dact = da->kind; pa.dact_alpha = da->alpha; }
-    const int bm = d->C >= 96 ? 128 : 64;
+    const DgradS2Plan pl = dgrad_s2_plan(d, ctx->num_cu);
     constexpr int cb = 4;
-    const int ntr = (d->C + bm - 1) / bm;
-    const int rt = bm == 128 ? 2 : 4;               // class rows per block (= waves along rows)
-    const int grid = ntr * (d->Wo / 32) * ((d->Ho + rt - 1) / rt) * d->N;
-    const int nslabs = d->K / cb;
-    int splits = 1;
-    if (grid < ctx->num_cu + ctx->num_cu / 2) {
-        splits = (2 * ctx->num_cu + grid - 1) / grid;
-        const int maxs = nslabs / 4 > 0 ? nslabs / 4 : 1;
-        if (splits > maxs) splits = maxs;
-    }
-    pa.slabs_per_split = (nslabs + splits - 1) / splits;
-    splits = (nslabs + pa.slabs_per_split - 1) / pa.slabs_per_split;
+    const int splits = pl.splits;
+    pa.slabs_per_split = pl.slabs_per_split;
     GHM_CHECK(!(da && splits > 1), "dgrad + activation derivative needs a single-pass plan (ask ghm_dgrad_dact_supported)");
     if (splits > 1) {
         void* ws = nullptr;
@@ -2113,17 +2123,19 @@ static int dgrad_s2_patch_launch(ghm_ctx* ctx, const ghm_conv_desc* d, const flo
         pa.partial = (float*)ws;
     }
     pa.zeros = (const float*)ctx->zeros;
-    const size_t lds = (size_t)2 * (cb * 9 * bm + ((cb * (rt + 1) * 33 + 3) / 4) * 4) * sizeof(float);
-    const dim3 g(grid, splits);
-    if (da) {
-        if (bm == 128)
-            hipLaunchKernelGGL((dgrad_s2_patch_kernel<128, 2, 2, true>), g, dim3(256), lds, ctx->stream, pa);
-        else
-            hipLaunchKernelGGL((dgrad_s2_patch_kernel<64, 1, 2, true>), g, dim3(256), lds, ctx->stream, pa);
-    } else if (bm == 128)
-        hipLaunchKernelGGL((dgrad_s2_patch_kernel<128, 2, 2>), g, dim3(256), lds, ctx->stream, pa);
-    else
-        hipLaunchKernelGGL((dgrad_s2_patch_kernel<64, 1, 2>), g, dim3(256), lds, ctx->stream, pa);
+    const size_t lds = (size_t)2 * (cb * 9 * pl.bm + ((cb * (pl.rt + 1) * 33 + 3) / 4) * 4) * sizeof(float);
+    const dim3 g(pl.grid, splits);
+#define GHM_DS2_CASE(BM_, WM_)                                                                                   \
+    if (pl.bm == BM_ && pl.wm == WM_) {                                                                          \
+        if (da)                                                                                                  \
+            hipLaunchKernelGGL((dgrad_s2_patch_kernel<BM_, WM_, 2, true>), g, dim3(256), lds, ctx->stream, pa);  \
+        else                                                                                                     \
+            hipLaunchKernelGGL((dgrad_s2_patch_kernel<BM_, WM_, 2>), g, dim3(256), lds, ctx->stream, pa);        \
+    }
+    GHM_DS2_CASE(128, 2)
+    GHM_DS2_CASE(64, 1)
+    GHM_DS2_CASE(64, 2)
+#undef GHM_DS2_CASE
     GHM_LAUNCH_CHECK();
     if (splits > 1) {
         IgemmArgs e;
@@ -2381,9 +2393,10 @@ int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t 
         if (d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W && pl.ok)
             snprintf(out, out_len, "conv_patch_kernel<%d, %d, %d, %d, %d, %d, 1> splits=%d", d->kh, pl.bm, pl.rt,
                      pl.bm == 128 ? 2 : 1, pl.bm == 128 ? 2 : 4, d->kh == 5 ? 1 : 2, pl.splits);
-        else if (d->stride == 2)
-            snprintf(out, out_len, "dgrad_s2_patch_kernel<%d, %d, 2>", d->C >= 96 ? 128 : 64, d->C >= 96 ? 2 : 1);
-        else
+        else if (d->stride == 2) {
+            const DgradS2Plan pl = dgrad_s2_plan(d, 256);
+            snprintf(out, out_len, "dgrad_s2_patch_kernel<%d, %d, 2> splits=%d", pl.bm, pl.wm, pl.splits);
+        } else
             snprintf(out, out_len, "igemm_kernel<fwd on wT>");
         return 0;
     }

@@ -175,6 +175,7 @@ struct LpConvArgs {
     long dact_nstride;
     int dact;
     float dact_alpha;
+    int debug;                  // tuning only (GHM_ABLATE bits: 1 no patch loads after the first slab, 2 no MFMAs, 4 no stores)
 };
 
 __device__ __forceinline__ void lp_pool2_store(float v0, float v1, bool col_even, bool live, float* po, unsigned char* pm) {
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
 // a.in = dy [N, CH=K, Hc, Wc], a.out = dx [N, R=C, 2Hc, 2Wc] (a.H, a.W = dx grid; a.Hin, a.Win = class grid).
 // ------------------------------------------------------------------------------------------------
 template <int DT, int BM, int RT>
-__global__ __launch_bounds__(256, 2) void lp_dgrad_s2_kernel(const LpConvArgs a) {
+__global__ __launch_bounds__(256, BM * RT >= 256 ? 2 : 3) void lp_dgrad_s2_kernel(const LpConvArgs a) {
     constexpr int T = 9, WM = 2, WN = 2;
     constexpr int TM = BM / (WM * 32), TN = RT / WN;
     constexpr int PH = RT + 1, PW = 33;
@@ -539,68 +540,85 @@ __global__ __launch_bounds__(256, 2) void lp_dgrad_s2_kernel(const LpConvArgs a)
         const bool more = (s + 1) < s_end;
         if (more) {
             stage_weights(s + 1, buf ^ 1);
-            load_patch();
+            if (!(a.debug & 1)) load_patch();
         }
         const u32x4* Wb = Wl + buf * WUNITS + wlane;
         const u32x4* Pb = Pl + buf * PUNITS + plane;
+        // tw: tap index in the transposed pack = 8 - original tap (ta, tb); the tap feeds class (ta != 1, tb != 1) from
+        // dy[i + (ta == 0)][j + (tb == 0)].  Fragments are read one tap ahead of their MFMAs.
+        auto p_off_of = [](int tw) {
+            const int ta = (8 - tw) / 3, tb = (8 - tw) % 3;
+            return (ta == 0 ? 1 : 0) * PW + (tb == 0 ? 1 : 0);
+        };
+        u32x4 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int tw = 0; tw < T; ++tw) {                    // tw: tap index in the transposed pack = 8 - original tap
-            const int ta = (8 - tw) / 3, tb = (8 - tw) % 3;  // original (a, b)
-            const int pu = ta == 1 ? 0 : 1, pvv = tb == 1 ? 0 : 1;
-            const int di = ta == 0 ? 1 : 0, dj = tb == 0 ? 1 : 0;
-            u32x4 af[TM], bf[TN];
+        for (int i = 0; i < TM; ++i) af[0][i] = Wb[i * 32];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = Wb[tw * BM + i * 32];
+        for (int j = 0; j < TN; ++j) bf[0][j] = Pb[j * PW + p_off_of(0)];
+        if (!(a.debug & 2))
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Pb[(j + di) * PW + dj];
+        for (int tw = 0; tw < T; ++tw) {
+            if (tw + 1 < T) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[(tw + 1) & 1][i] = Wb[(tw + 1) * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[(tw + 1) & 1][j] = Pb[j * PW + p_off_of(tw + 1)];
+            }
+            const int ta = (8 - tw) / 3, tb = (8 - tw) % 3;
+            const int cl = (ta == 1 ? 0 : 2) + (tb == 1 ? 0 : 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[pu * 2 + pvv][i][j] = Lp<DT>::mfma(af[i], bf[j], acc[pu * 2 + pvv][i][j]);
+                    acc[cl][i][j] = Lp<DT>::mfma(af[tw & 1][i], bf[tw & 1][j], acc[cl][i][j]);
+            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch distance at one tap (register budget)
         }
         if (more) store_patch(buf ^ 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    // ---- epilogue: lane = class pixel (row i0 + wn*TN + j, column j0 + li); its two column parities are adjacent ----
+    // ---- epilogue: lane = class pixel (row i0 + wn*TN + j, column j0 + li); its two column parities are adjacent:
+    // one 8-byte store per (row parity, channel).  Wave-uniform row pointers + a 32-bit lane offset; bias through LDS.
     const long P = (long)a.N * HWx;
-    const int ru = r0 + wm * (BM / WM) + 4 * kg;
+    const int ru = r0 + wm * (BM / WM), rl = ru + 4 * kg;
+    float* const sb = reinterpret_cast<float*>(smem);
+    if (tid < BM) sb[tid] = (a.bias && !a.partial && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
+    __syncthreads();
+    const float* const lb = sb + wm * (BM / WM) + 4 * kg;
+    const long rstride = a.partial ? P : (long)HWx;
+    const unsigned lo = 4u * kg * (unsigned)rstride + 2u * li;
+    const bool plain = a.partial != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int ic = i0 + wn * TN + j, jc = j0 + li;
+        const long rowpix = (long)(2 * (i0 + wn * TN + j)) * a.W + 2 * j0;
+        float* const ub = a.partial ? a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HWx + rowpix
+                                    : a.out + (long)n * a.out_nstride + (long)ru * HWx + rowpix;
+        const float* const yb = a.dact_y ? a.dact_y + (long)n * a.dact_nstride + (long)ru * HWx + rowpix : nullptr;
 #pragma unroll
-        for (int pu = 0; pu < 2; ++pu) {
-            const long pix = (long)(2 * ic + pu) * a.W + 2 * jc;
+        for (int pu = 0; pu < 2; ++pu)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int r = ru + i * 32 + (e & 3) + 8 * (e >> 2);
-                    if (r >= a.R) continue;
-                    float v0 = acc[pu * 2 + 0][i][j][e], v1 = acc[pu * 2 + 1][i][j][e];
-                    if (a.partial) {
-                        float* o = a.partial + ((long)blockIdx.y * a.R + r) * P + (long)n * HWx + pix;
-                        *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
-                    } else {
-                        float* o = a.out + (long)n * a.out_nstride + (long)r * HWx + pix;
-                        if (a.bias) { v0 += a.bias[r]; v1 += a.bias[r]; }
-                        if (a.accumulate) {
-                            const float2 old = *reinterpret_cast<const float2*>(o);
-                            v0 += old.x; v1 += old.y;
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    if (rl + k >= a.R) continue;
+                    float2 v = make_float2(acc[pu * 2 + 0][i][j][e], acc[pu * 2 + 1][i][j][e]);
+                    if ((a.debug & 4) && v.x != 12345.f) continue;
+                    float2* o = reinterpret_cast<float2*>(ub + (long)k * rstride + pu * a.W + lo);
+                    if (!plain) {
+                        v.x += lb[k]; v.y += lb[k];
+                        if (a.accumulate) { const float2 old = *o; v.x += old.x; v.y += old.y; }
+                        v.x = ghm_act(v.x, a.act, a.alpha);
+                        v.y = ghm_act(v.y, a.act, a.alpha);
+                        if (yb) {                       // relu / leaky relu: the slope of the producer
+                            const float2 yy = *reinterpret_cast<const float2*>(yb + (long)k * HWx + pu * a.W + lo);
+                            v.x *= yy.x > 0.f ? 1.f : a.dact_alpha;
+                            v.y *= yy.y > 0.f ? 1.f : a.dact_alpha;
                         }
-                        v0 = ghm_act(v0, a.act, a.alpha);
-                        v1 = ghm_act(v1, a.act, a.alpha);
-                        if (a.dact_y) {
-                            const float2 yy = *reinterpret_cast<const float2*>(a.dact_y + (long)n * a.dact_nstride + (long)r * HWx + pix);
-                            v0 *= yy.x > 0.f ? 1.f : a.dact_alpha;        // relu / leaky relu: the slope of the producer
-                            v1 *= yy.y > 0.f ? 1.f : a.dact_alpha;
-                        }
-                        *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
                     }
+                    *o = v;
                 }
-        }
     }
 }
 
@@ -830,7 +848,7 @@ LpPlan lp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
     p.grid = ntr * (W / p.tw) * (H / rows) * N;
     const int nslabs = CH / 16;
     p.splits = 1;
-    if (p.grid < num_cu + num_cu / 2) {
+    if (p.grid < num_cu) {      // a block per CU or more: the partial tensors cost more than the idle slots (tools/s2_sweep.sh)
         p.splits = (2 * num_cu + p.grid - 1) / p.grid;
         const int maxs = nslabs / 2 > 0 ? nslabs / 2 : 1;
         if (p.splits > maxs) p.splits = maxs;
@@ -891,18 +909,34 @@ LpPlan lp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu) {
     p.ok = false;
     if (getenv("GHM_NO_LP") || getenv("GHM_NO_LP_DGRAD_S2")) return p;
     if (!(d->stride == 2 && d->kh == 3 && d->kw == 3 && d->pad == 1 && d->H == 2 * d->Ho && d->W == 2 * d->Wo)) return p;
-    p.bm = d->C >= 96 ? 128 : 64;
-    p.rt = p.bm == 128 ? 2 : 4;
-    if (d->Wo % 32 || d->Ho % p.rt || d->K % 16 || d->K < 16 || d->C < 32 || (d->x_nstride & 1) || ((d->H * d->W) & 1)) return p;
-    const int ntr = (d->C + p.bm - 1) / p.bm;
-    p.grid = ntr * (d->Wo / 32) * (d->Ho / p.rt) * d->N;
+    if (d->Wo % 32 || d->K % 16 || d->K < 16 || d->C < 32 || (d->x_nstride & 1) || ((d->H * d->W) & 1)) return p;
+    // the split-K form writes and re-reads `splits` partial dx tensors -- more HBM traffic than the operands of these
+    // layers: a small grid first shrinks the tile (128 ch x 2 class rows -> 64 x 4 -> 64 x 2), then splits
+    static const int tiles[3][2] = {{128, 2}, {64, 4}, {64, 2}};
+    int forced = -1;
+    if (const char* f = getenv("GHM_LP_DGRAD_S2_TILE")) forced = atoi(f);
+    bool found = false;
+    for (int t = d->C >= 96 ? 0 : 1; t < 3; ++t) {
+        if (forced >= 0) t = forced > 2 ? 2 : forced;
+        if (d->Ho % tiles[t][1] == 0) {
+            p.bm = tiles[t][0]; p.rt = tiles[t][1];
+            p.grid = ((d->C + p.bm - 1) / p.bm) * (d->Wo / 32) * (d->Ho / p.rt) * d->N;
+            found = true;
+            // measured (tools/s2_sweep.sh): these layers are HBM-bound at this precision -- more, smaller blocks win
+            // over operand reuse; the 128-channel tile only pays on grids of several waves of blocks
+            if (p.grid >= (t == 0 ? 4 : 2) * num_cu) break;
+        }
+        if (forced >= 0) break;
+    }
+    if (!found) return p;
     const int nslabs = d->K / 16;
     p.splits = 1;
-    if (p.grid < num_cu + num_cu / 2) {
+    if (p.grid < num_cu) {
         p.splits = (2 * num_cu + p.grid - 1) / p.grid;
         const int maxs = nslabs / 2 > 0 ? nslabs / 2 : 1;
         if (p.splits > maxs) p.splits = maxs;
     }
+    if (const char* f = getenv("GHM_LP_DGRAD_S2_SPLITS")) p.splits = atoi(f) < 1 ? 1 : atoi(f);
     p.slabs_per_split = (nslabs + p.splits - 1) / p.splits;
     p.splits = (nslabs + p.slabs_per_split - 1) / p.slabs_per_split;
     p.ok = true;
@@ -912,6 +946,7 @@ LpPlan lp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu) {
 template <int DT>
 int lp_launch_dgrad_s2(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a) {
     a.slabs_per_split = pl.slabs_per_split;
+    if (const char* f = getenv("GHM_ABLATE")) a.debug = atoi(f);
     a.partial = nullptr;
     if (pl.splits > 1) {
         void* ws = nullptr;
@@ -921,8 +956,10 @@ int lp_launch_dgrad_s2(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a) {
     const dim3 g(pl.grid, pl.splits);
     if (pl.bm == 128)
         hipLaunchKernelGGL((lp_dgrad_s2_kernel<DT, 128, 2>), g, dim3(256), 0, ctx->stream, a);
-    else
+    else if (pl.rt == 4)
         hipLaunchKernelGGL((lp_dgrad_s2_kernel<DT, 64, 4>), g, dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((lp_dgrad_s2_kernel<DT, 64, 2>), g, dim3(256), 0, ctx->stream, a);
     GHM_LAUNCH_CHECK();
     if (pl.splits > 1)
         return ghm_splitk_finish(ctx, a.partial, pl.splits, a.out, a.bias, a.N, a.R, a.H, a.W, a.out_nstride, a.act,
