@@ -3,8 +3,8 @@
 test1_nobn_bilin_both, modes train / interp / gen.
 
 ``get_iterators`` returns the device-side counterpart of util.Hdf5Iterator (gan_heightmaps_amd.data) over the
-xt/yt/xv/yv uint8 NHWC arrays of an HDF5 file (when h5py is importable -- it is not in this image) or of an
-``.npz`` with the same four keys.  A missing or unreadable dataset is an error; synthetic batches with the
+xt/yt/xv/yv uint8 NHWC arrays of an HDF5 file (h5py when importable, else this package's own reader h5lite.py) or of
+an ``.npz`` with the same four keys.  A missing or unreadable dataset is an error; synthetic batches with the
 reference's value ranges are served only when asked for (``dataset=None`` or ``GHM_DATASET=synthetic``).
 """
 import os
@@ -54,27 +54,39 @@ def synthetic_arrays(n, in_shp, is_a_grayscale, is_b_grayscale, seed=0):
     return X, Y
 
 
+def open_dataset(dataset):
+    """``h5py.File(dataset, "r")`` of experiments.py:11: a mapping with the uint8 NHWC arrays xt / yt / xv / yv that
+    stay on disk and are sliced per batch.  ``.npz`` files are accepted too.  HDF5 files are opened with h5py when it is
+    importable and with this package's own reader (h5lite.py: contiguous / chunked / gzip datasets) otherwise."""
+    if not os.path.exists(dataset):
+        raise FileNotFoundError("dataset %r does not exist (set GHM_DATASET to an .h5 / .npz file with xt, yt, xv, yv, "
+                                "or to 'synthetic' for random batches)" % (dataset,))
+    if dataset.endswith(".npz"):
+        d = np.load(dataset)
+    else:
+        try:
+            import h5py
+            d = h5py.File(dataset, "r")
+        except ImportError:
+            from . import h5lite
+            d = h5lite.File(dataset, "r")
+    missing = [k for k in ("xt", "yt", "xv", "yv") if k not in d]
+    if missing:
+        raise KeyError("dataset %r has no array(s) %s (expected xt, yt, xv, yv as written by the reference's "
+                       "notebooks/prototype_cropping_code.ipynb)" % (dataset, ", ".join(missing)))
+    return d
+
+
 def get_iterators(dataset, batch_size, is_a_grayscale, is_b_grayscale, da=True, in_shp=512, n_synthetic=8, device=None):
     """experiments.get_iterators (experiments.py:10-18): (it_train, it_val) over the xt/yt/xv/yv arrays of the
-    dataset, augmented with flips + 360-degree rotation + reflect fill when ``da``.  The reference opens an HDF5
-    file (h5py is not available here): an ``.npz`` with the same four keys is read instead, else synthetic data."""
+    dataset, augmented with flips + 360-degree rotation + reflect fill when ``da``.  ``dataset``: an HDF5 file as the
+    reference opens it (``open_dataset``), an ``.npz`` with the same four keys, or 'synthetic' / None."""
     from .data import Hdf5Iterator, ImageDataGenerator
     if dataset is None or dataset == "synthetic":
         xt, yt = synthetic_arrays(n_synthetic, in_shp, is_a_grayscale, is_b_grayscale, 0)
         xv, yv = xt, yt
-    elif not os.path.exists(dataset):
-        raise FileNotFoundError("dataset %r does not exist (set GHM_DATASET to an .h5 / .npz file with xt, yt, xv, yv, "
-                                "or to 'synthetic' for random batches)" % (dataset,))
-    elif dataset.endswith(".npz"):
-        d = np.load(dataset)
-        xt, yt, xv, yv = d['xt'], d['yt'], d['xv'], d['yv']
     else:
-        try:
-            import h5py
-        except ImportError:
-            raise ImportError("reading %r needs h5py, which is not installed; convert the file to an .npz with the "
-                              "keys xt, yt, xv, yv (uint8, NHWC)" % (dataset,))
-        d = h5py.File(dataset, "r")             # experiments.py:11: datasets stay on disk and are sliced per batch
+        d = open_dataset(dataset)
         xt, yt, xv, yv = d['xt'], d['yt'], d['xv'], d['yv']
     if da:
         imgen = ImageDataGenerator(horizontal_flip=True, vertical_flip=True, rotation_range=360, fill_mode="reflect")
