@@ -10,6 +10,8 @@ python bench.py --steps 20 --warmup 3 --dtype bf16 --no-cpu-baseline > $O/${R}_b
 python bench.py --steps 20 --warmup 3 --dtype f16 --no-cpu-baseline > $O/${R}_bench_f16.json 2>> $O/${R}_bench.err
 python bench.py --steps 10 --warmup 2 --in-shp 1024 --no-cpu-baseline > $O/${R}_bench_1024_f32.json 2>> $O/${R}_bench.err
 python bench.py --steps 10 --warmup 2 --in-shp 1024 --dtype f16 --no-cpu-baseline > $O/${R}_bench_1024_f16.json 2>> $O/${R}_bench.err
+python bench.py --steps 10 --warmup 2 --in-shp 1024 --dtype f16 --batch-per-gpu 2 --no-cpu-baseline > $O/${R}_bench_1024_f16_b2.json 2>> $O/${R}_bench.err
+python bench.py --steps 20 --warmup 3 --batch-per-gpu 8 --no-cpu-baseline > $O/${R}_bench_b8.json 2>> $O/${R}_bench.err
 python bench.py --steps 20 --warmup 3 --mode dcgan --no-cpu-baseline > $O/${R}_bench_mode_dcgan.json 2>> $O/${R}_bench.err
 python bench.py --steps 20 --warmup 3 --mode p2p --no-cpu-baseline > $O/${R}_bench_mode_p2p.json 2>> $O/${R}_bench.err
 python bench.py --steps 20 --warmup 3 --graph --no-cpu-baseline > $O/${R}_bench_graph.json 2>> $O/${R}_bench.err
