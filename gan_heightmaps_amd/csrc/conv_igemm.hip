@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 2) void wgrad_ker
 // tap decode.  Requires Wo % 16 == 0 (every layer with Wo >= 16 in this workload).
 // ------------------------------------------------------------------------------------------------
 template <int KS, int ST, int BN, int WM, int WN, int BKP>
-__global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, (BN >= 128 || ST == 2) ? 3 : 4) void wgrad_patch_kernel(const WgradArgs a) {
     constexpr int T = KS * KS;
     constexpr int CB = 128 / T;                 // channels per row tile (5 for 5x5, 14 for 3x3)
     constexpr int ROWS = CB * T;                // valid rows of the 128-row tile
@@ -1278,22 +1278,42 @@ __global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(c
     const int s_begin = bz * a.slabs_per_split;
     const int s_end = min(s_begin + a.slabs_per_split, total_slabs);
 
-    // ---- per-thread constants of the patch fetch ----
-    int el_lds[AL], el_choff[AL], el_dy[AL], el_dx[AL];
+    // ---- slab order: COLUMN STRIPS.  Slab s = (image sn, strip sjb, output row si) with si fastest, so consecutive
+    // slabs of a block move straight down the image: every per-lane source offset is an invariant of the whole kernel,
+    // the column bounds of an element are invariants of the strip, and a slab costs one uniform pointer bump (+ one
+    // uniform "are all kh rows inside the image" test) instead of per-element address and bounds arithmetic
+    // (that arithmetic was most of the 12 % the global loads cost this kernel, GHM_ABLATE).
+    // Patch element e = (c, ta, col): LDS offset c*PS + ta*PW + col, source offset (c0+c)*HW + ta*W + col relative to
+    // rowbase = x[sn] + (si*ST - pad)*W + (sjb*BKP*ST - pad).
+    unsigned el_off[AL];                             // source offset; SAFE (the slab's first pixel) when the column is outside
+    unsigned el_desc[AL];                            // LDS offset | ta << 16
+    unsigned xmask = 0;                              // bit q: the column of element q is inside the image (per strip)
+    const unsigned SAFE = (unsigned)(a.pad * a.W + a.pad);
+    auto strip_setup = [&](int sjb) {
+        xmask = 0;
+        const int x0 = sjb * BKP * ST;
 #pragma unroll
-    for (int q = 0; q < AL; ++q) {
-        const int e = tid + q * 256;
-        const int c = e / (KS * PWN), r = e - c * (KS * PWN);
-        const int ta = r / PWN, col = r - ta * PWN;
-        const bool v = e < NEL && (c0 + c) < a.C;
-        el_lds[q] = c * PS + ta * PW + col;
-        el_choff[q] = v ? (c0 + c) * HW : -1;
-        el_dy[q] = ta - a.pad;
-        el_dx[q] = col - a.pad;
-        if (e >= NEL) el_lds[q] = -1;
-    }
+        for (int q = 0; q < AL; ++q) {
+            const int e = min(tid + q * 256, NEL - 1);       // idle lanes repeat the last element (same value, same slot)
+            const int c = e / (KS * PWN), r = e - c * (KS * PWN);
+            const int ta = r / PWN, col = r - ta * PWN;
+            const bool xok = (c0 + c) < a.C && (unsigned)(x0 + col - a.pad) < (unsigned)a.W;
+            el_off[q] = xok ? (unsigned)((c0 + c) * HW + ta * a.W + col) : SAFE;
+            el_desc[q] = (unsigned)(c * PS + ta * PW + col) | ((unsigned)ta << 16);
+            xmask |= (xok ? 1u : 0u) << q;
+        }
+    };
     // ---- per-thread constants of the dy tile fetch (float4 along pixels) ----
     const int b_p4 = tid % PV, b_co = tid / PV;          // PV x float4 cover the slab's pixels
+    unsigned dy_off[BV];
+    unsigned dymask = 0;
+#pragma unroll
+    for (int q = 0; q < BV; ++q) {
+        const int col = b_co + q * CPP, co = n0 + col;
+        const bool ok = col < BN && co < a.K;
+        dy_off[q] = (ok ? (unsigned)co * (unsigned)HoWo : 0u) + b_p4 * 4;
+        dymask |= (ok ? 1u : 0u) << q;
+    }
     // ---- fragment bases ----
     const int frag_k = lane >> 5, frag_i = lane & 31;
     int abase[TM];
@@ -1305,56 +1325,60 @@ __global__ __launch_bounds__(256, (BN >= 128) ? 3 : 4) void wgrad_patch_kernel(c
         abase[i] = c * PS + (tap / KS) * PW + (tap % KS) + frag_k * ST;
     }
 
-    // slab cursor (uniform): image n, output row i, first column j0
-    int sn, si, sj;
+    // slab cursor (uniform): image sn, strip sjb, output row si
+    int sn, sjb, si;
     {
-        const int row = s_begin / slabs_per_row;
-        sj = (s_begin - row * slabs_per_row) * BKP;
-        sn = row / a.Ho;
-        si = row - sn * a.Ho;
+        const int per_img = slabs_per_row * a.Ho;
+        sn = s_begin / per_img;
+        const int rem = s_begin - sn * per_img;
+        sjb = rem / a.Ho;
+        si = rem - sjb * a.Ho;
     }
+    strip_setup(sjb);
 
     float areg[AL];
     float4 breg[BV];
     unsigned amask = 0;
     auto load_slab = [&]() {
-        amask = 0;
-        const float* xb = a.x + (long)sn * a.x_nstride;
-        const int y0 = si * ST, x0 = sj * ST;
+        const int y0 = si * ST;
+        const float* rowbase = a.x + (long)sn * a.x_nstride + ((long)(y0 - a.pad) * a.W + (sjb * BKP * ST - a.pad));
+        if (y0 >= a.pad && y0 + KS - 1 - a.pad < a.H) {          // every filter row inside the image (uniform)
+            amask = xmask;
 #pragma unroll
-        for (int q = 0; q < AL; ++q) {
-            const int y = y0 + el_dy[q], x = x0 + el_dx[q];
-            const bool ok = el_choff[q] >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            areg[q] = xb[ok ? el_choff[q] + y * a.W + x : 0];
-            amask |= (ok ? 1u : 0u) << q;
-        }
-        const float* yb = a.dy + (long)sn * a.y_nstride + (si * a.Wo + sj) + b_p4 * 4;
+            for (int q = 0; q < AL; ++q) areg[q] = rowbase[el_off[q]];
+        } else {
+            amask = 0;
 #pragma unroll
-        for (int q = 0; q < BV; ++q) {
-            const int co = n0 + b_co + q * CPP;
-            breg[q] = *reinterpret_cast<const float4*>(yb + (long)((co < a.K && b_co + q * CPP < BN) ? co : 0) * HoWo);
-        }
-        sj += BKP;
-        if (sj >= a.Wo) {
-            sj = 0;
-            if (++si >= a.Ho) {
-                si = 0;
-                ++sn;
+            for (int q = 0; q < AL; ++q) {
+                const int ta = (int)(el_desc[q] >> 16);
+                const bool ok = ((xmask >> q) & 1u) && (unsigned)(y0 + ta - a.pad) < (unsigned)a.H;
+                areg[q] = rowbase[ok ? el_off[q] : SAFE];
+                amask |= (ok ? 1u : 0u) << q;
             }
         }
-        if (sn >= a.N) { sn = 0; si = 0; sj = 0; }      // past the end: keep addresses valid
+        const float* yb = a.dy + (long)sn * a.y_nstride + (si * a.Wo + sjb * BKP);
+#pragma unroll
+        for (int q = 0; q < BV; ++q) breg[q] = *reinterpret_cast<const float4*>(yb + dy_off[q]);
+        if (++si >= a.Ho) {
+            si = 0;
+            if (++sjb >= slabs_per_row) {
+                sjb = 0;
+                ++sn;
+            }
+            if (sn >= a.N) sn = 0;                               // past the end: keep addresses valid
+            strip_setup(sjb);
+        }
     };
     auto store_slab = [&](int buf) {
         float* Pb = Ps + buf * PATCH;
         float* Bb = Bs + buf * BKP * LDB;
 #pragma unroll
-        for (int q = 0; q < AL; ++q)
-            if (el_lds[q] >= 0) Pb[el_lds[q]] = ((amask >> q) & 1u) ? areg[q] : 0.f;
+        for (int q = 0; q < AL; ++q) Pb[el_desc[q] & 0xffffu] = ((amask >> q) & 1u) ? areg[q] : 0.f;
 #pragma unroll
         for (int q = 0; q < BV; ++q) {
             const int col = b_co + q * CPP;
             if (col >= BN) continue;
-            const bool ok = (n0 + col) < a.K;
+            const bool ok = (dymask >> q) & 1u;
             float* d = Bb + (b_p4 * 4) * LDB + col;
             d[0 * LDB] = ok ? breg[q].x : 0.f;
             d[1 * LDB] = ok ? breg[q].y : 0.f;
