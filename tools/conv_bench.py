@@ -15,7 +15,10 @@ from gan_heightmaps_amd import device as D  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("geom", type=int, nargs=8, help="N C H W K k stride pad")
-    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--warm-ms", type=float, default=60.0,
+                    help="untimed warm-up: the GPU idles at ~160 MHz and takes milliseconds to reach its 2.4 GHz "
+                         "shader clock, a 20-launch measurement from idle under-reports by 5-10 %%")
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
                     help="bf16 / f16: the *_lp entry points (kinds fwd, dgrad_t, wgrad)")
@@ -61,9 +64,14 @@ def main():
             print("%-6s not served in %s" % (kind, args.dtype))
             continue
         fn = fns[kind]
-        for _ in range(3):
-            fn()
-        dev.sync()
+        import time
+        t0 = time.time()
+        while True:
+            for _ in range(10):
+                fn()
+            dev.sync()
+            if (time.time() - t0) * 1e3 >= args.warm_ms:
+                break
         dev.timer_start(0)
         for _ in range(args.reps):
             fn()
