@@ -30,6 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // stops LDS reads and MFMAs from crossing (VALU / SALU / VMEM / LDS writes still may: mask bits per the
 // amdgcn sched_barrier builtin).  Measured: wgrad_patch 3x3 100 -> 113 TFLOP/s, 5x5 117 -> 122; the forward
 // patch kernel (5 reads per 4 MFMAs, 4 waves/SIMD) is 2-4 % slower with it and keeps the compiler's order.
+// Round 2: wgrad_patch_kernel moved to GHM_INTERLEAVE below (+1-3 %); wgrad_kernel keeps the fence.
 #ifndef GHM_FENCE_MASK
 #define GHM_FENCE_MASK 0x0616
 #endif
@@ -1419,12 +1420,12 @@ __global__ __launch_bounds__(256, (BN >= 128 || ST == 2) ? 3 : 4) void wgrad_pat
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[(ks + 1) & 1][j] = Bb[(ks + 1) * 2 * LDB + j * 32];
             }
-            GHM_FRAG_FENCE();
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+            if (ks + 1 < BKP / 2) GHM_INTERLEAVE(TM * TN);
             if (ks == BKP / 2 - 3 && more && a.debug < 2) store_slab(buf ^ 1);
         }
         __syncthreads();
