@@ -95,6 +95,12 @@ def main():
                      % (args.gpus, args.gpus))
     if device.device_count() == 0:
         sys.exit("bench.py: no HIP device visible (there is no CPU fallback)")
+    ndev = device.device_count()
+    if local_rank >= ndev:
+        # a launcher that narrows visibility per rank (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES) leaves one device 0
+        sys.stderr.write("bench.py: LOCAL_RANK %d but %d visible device(s): using device %d\n"
+                         % (local_rank, ndev, local_rank % ndev))
+        local_rank %= ndev
     dev = device.Device(local_rank)
     # the communicator gets its own context of the same GPU: its stream is the communication stream, so the bucket
     # all-reduces run beside the rest of the backward pass (step.py)
