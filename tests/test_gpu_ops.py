@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 
+from oracle import lp as LP
 from oracle import ops as O
 
 pytestmark = pytest.mark.gpu
@@ -740,3 +741,81 @@ def test_dgrad_with_producer_activation_backward_fused(gpu, case, dtype):
     assert np.array_equal(a, b) and np.abs(a).max() > 0
     for t in (wp, dy, y, fused, plain):
         dev.free(t.ptr)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tile", ["0", "1", "2"])
+@pytest.mark.parametrize("splits", ["1", "3"])
+@pytest.mark.parametrize("case", [(2, 128, 64, 64, 48, 3, 2, 1), (1, 96, 128, 64, 32, 3, 2, 1), (3, 64, 24, 64, 16, 3, 2, 1)])
+def test_stride2_data_gradient_every_tile_and_split(gpu, case, tile, splits, dtype):
+    """dgrad_s2_patch_kernel / lp_dgrad_s2_kernel: the plan picks one of three tiles (128 channels x 2 class rows,
+    64 x 4, 64 x 2) and splits the contraction only on small grids; here every tile and a forced 3-way split run on
+    the same layers (ragged channel tiles, class-row counts that are not a multiple of the tile, rectangular maps)."""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(7)
+    x_shape = (N, C, H, W)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    dy = rng.randn(N, K, d.Ho, d.Wo).astype(np.float32)
+    lp = dtype != "f32"
+    Wr, dyr = (LP.round_bf16(Wt), LP.round_bf16(dy)) if lp else (Wt, dy)
+    dx_ref, _, _ = O.conv2d_vjp(np.zeros(x_shape), Wr.astype(np.float64), dyr.astype(np.float64), s, pad)
+    wd = dev.tensor(D.pack_conv_w(Wt).reshape(1, -1, 1, 1))
+    dyd, dxd = dev.tensor(dy), dev.empty(x_shape)
+    env = {"GHM_LP_DGRAD_S2_TILE" if lp else "GHM_DGRAD_S2_TILE": tile,
+           "GHM_LP_DGRAD_S2_SPLITS" if lp else "GHM_DGRAD_S2_SPLITS": splits}
+    if lp and (d.Ho % (2 if tile == "0" else (4 if tile == "1" else 2))):
+        pytest.skip("class rows not a multiple of this tile: the plan never picks it")
+    os.environ.update(env)
+    try:
+        if lp:
+            if not ops.lp_supported(d, 1, dtype):
+                pytest.skip("geometry not served at reduced precision")
+            wqT = dev.alloc(ops.lp_weight_bytes(d, True))
+            ops.lp_pack_weights(d, wd, wqT, dtype, True)
+            ops.conv2d_dgrad_lp(d, dyd, wqT, dxd, dtype)
+            assert rel(dxd.numpy(), dx_ref) < 2e-5
+            ops.conv2d_dgrad_lp(d, dyd, wqT, dxd, dtype, accumulate=True)
+            assert rel(dxd.numpy(), 2 * dx_ref) < 2e-5
+        else:
+            assert ops.dgrad_t_supported(d)
+            wtd = dev.zeros((1, C * k * k * K, 1, 1))
+            ops.transpose_weights(d, wd, wtd)
+            name = ops.conv_variant(d, 3)
+            assert name.startswith("dgrad_s2_patch_kernel<%s" % {"0": "128, 2", "1": "64, 1", "2": "64, 2"}[tile]), name
+            ops.conv2d_dgrad_t(d, dyd, wtd, dxd)
+            assert rel(dxd.numpy(), dx_ref) < TOL
+            ops.conv2d_dgrad_t(d, dyd, wtd, dxd, accumulate=True)
+            assert rel(dxd.numpy(), 2 * dx_ref) < TOL
+    finally:
+        for key in env:
+            os.environ.pop(key)
+
+
+@pytest.mark.parametrize("splits", ["1", "3", "7", "50"])
+@pytest.mark.parametrize("case", [(3, 16, 24, 64, 32, 3, 1, 1), (2, 8, 20, 96, 48, 5, 1, 2), (3, 16, 48, 128, 24, 3, 2, 1),
+                                  (2, 12, 10, 48, 16, 3, 1, 1)])
+def test_weight_gradient_split_ranges_cross_strips_and_images(gpu, case, splits):
+    """wgrad_patch_kernel walks the slabs in column strips (image, strip, row); a split's range may start and end
+    anywhere -- inside a strip, across strips, across images -- and the first / last rows of every strip take the
+    bounds-checked path.  Forced split counts that do not divide the slab count, 2-3 strips per row, 16- and 32-pixel slabs."""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(11)
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    dy = rng.randn(N, K, d.Ho, d.Wo).astype(np.float32)
+    _, dW_ref, _ = O.conv2d_vjp(x.astype(np.float64), np.zeros((K, C, k, k)), dy.astype(np.float64), s, pad)
+    os.environ["GHM_WGRAD_SPLITS"] = splits
+    try:
+        assert ops.conv_variant(d, 2).startswith("wgrad_patch_kernel"), ops.conv_variant(d, 2)
+        xd, dyd = dev.tensor(x), dev.tensor(dy)
+        dwd = dev.zeros((1, C * k * k * K, 1, 1))
+        ws = dev.alloc(max(ops.wgrad_workspace(d), 16))
+        ops.conv2d_wgrad(d, xd, dyd, dwd, ws)
+        assert rel(D.unpack_conv_w(dwd.numpy().ravel(), K, C, k, k), dW_ref) < TOL
+        ops.conv2d_wgrad(d, xd, dyd, dwd, ws, accumulate=True)
+        assert rel(D.unpack_conv_w(dwd.numpy().ravel(), K, C, k, k), 2 * dW_ref) < TOL
+    finally:
+        os.environ.pop("GHM_WGRAD_SPLITS")
