@@ -102,6 +102,14 @@ static inline void ghm_submit(ghm_ctx* ctx, F f) {
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // activation and its derivative expressed through the OUTPUT (valid for all five kinds)
+// XCD-aware block remap: consecutive logical tiles (which share halo pixels / operand tiles) land on the same XCD's
+// L2 -- workgroups are dispatched round-robin over the 8 XCDs.  Bijective for any grid size.
+__device__ __forceinline__ int ghm_xcd_remap(int bid, int nb) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 __device__ __forceinline__ float ghm_act(float v, int act, float alpha) {
     switch (act) {
         case GHM_ACT_RELU: return v > 0.f ? v : 0.f;

@@ -982,7 +982,9 @@ __global__ __launch_bounds__(512) void fanin_s1_kernel(const FaninS1Args a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int h = lane >> 5, l = lane & 31;
     const int tiles_x = a.W / TW, tiles_y = a.H / TH;
-    const int bid = blockIdx.x;
+    // neighbouring tiles share halo pixels and the partly used 128-byte lines at their edges: keep them on one XCD's L2
+    // (PMC: 710 MB fetched for 268 MB of input before)
+    const int bid = ghm_xcd_remap(blockIdx.x, gridDim.x);
     const int n = bid / (tiles_x * tiles_y), trem = bid - n * tiles_x * tiles_y;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const int y0 = ty * TH - a.pad_lo, x0 = tx * TW - a.pad_lo;      // halo origin (may be negative)
