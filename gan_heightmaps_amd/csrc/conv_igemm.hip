@@ -487,7 +487,7 @@ __device__ __forceinline__ void pool2_store(float v0, float v1, bool col_even, b
     }
 }
 
-template <int KS, int BM, int RT, int WM, int WN, int CP, int ST, bool POOL = false>
+template <int KS, int BM, int RT, int WM, int WN, int CP, int ST>
 __global__ __launch_bounds__(256, ST == 2 ? 3 : 4) void conv_patch_kernel(const PatchArgs a) {
     constexpr int T = KS * KS, CB = 2 * CP;
     constexpr int BN = RT * 32;
@@ -656,8 +656,9 @@ __global__ __launch_bounds__(256, ST == 2 ? 3 : 4) void conv_patch_kernel(const 
     if (tid < BM) sb[tid] = (a.bias && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
     __syncthreads();
     const float* const lb = sb + wm * (BM / WM) + 4 * frag_k;
-    if constexpr (POOL) {
-        static_assert(TN % 2 == 0 && ST == 1, "pooled epilogue: row pairs inside a wave");
+    // pooled epilogue (a.pool_out set; row pairs inside a wave): a run-time option of the same kernel -- the main loop is
+    // identical and this path needs fewer registers than the plain one
+    if constexpr (TN % 2 == 0 && ST == 1) if (a.pool_out) {
         const int Wp = a.W / 2;
         const long HWp = (long)(a.H / 2) * Wp;
         const long base = ((long)n * a.R + rl) * HWp + (long)((y0 + wn * TN) / 2) * Wp + (x0 + frag_i) / 2;
@@ -1991,9 +1992,9 @@ int ghm_conv2d_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, co
     pa.pool_out = pooled; pa.pool_mask = mask;
     const dim3 g(pl.grid, 1);
     if (d->kh == 5)
-        hipLaunchKernelGGL((conv_patch_kernel<5, 64, 8, 1, 4, 1, 1, true>), g, dim3(256), pl.lds, ctx->stream, pa);
+        hipLaunchKernelGGL((conv_patch_kernel<5, 64, 8, 1, 4, 1, 1>), g, dim3(256), pl.lds, ctx->stream, pa);
     else
-        hipLaunchKernelGGL((conv_patch_kernel<3, 64, 8, 1, 4, 2, 1, true>), g, dim3(256), pl.lds, ctx->stream, pa);
+        hipLaunchKernelGGL((conv_patch_kernel<3, 64, 8, 1, 4, 2, 1>), g, dim3(256), pl.lds, ctx->stream, pa);
     GHM_LAUNCH_CHECK();
     return 0;
 }
