@@ -1743,6 +1743,16 @@ PatchPlan plan_patch(int N, int CH, int H, int W, int R, int ks, int num_cu, int
     const int lda = p.bm, ph = (p.rt - 1) * st + ks, pw = 31 * st + ks;
     const int asz = cb * T * lda, psz = ((cb * ph * pw + 3) / 4) * 4;
     p.lds = (size_t)2 * (asz + psz) * sizeof(float);
+    // TWO blocks per CU, not the four that 30-34 KB of LDS and 121 VGPRs would allow: the block reserves a third of the
+    // CU's LDS + 1 byte.  Alone the kernel loses 0.5-1.2 % (5x5 142.4 -> 140.7 TFLOP/s, it is MFMA-bound at two waves per
+    // SIMD), but half of every CU's registers and 50 KB of its LDS stay free for the kernels of the other three streams
+    // of the step, which then run BESIDE it instead of queueing for its slots: joint step 163.4 -> 167.0 img/s, HIP-graph
+    // form 160.4 -> 164.1, 1024^2 28.8 -> 29.4, batch 8 174.1 -> 176.5 (sweep: 36-52 KB +-0, 54-60 KB +2 %, 66 KB +0.7 %,
+    // one block per CU -0.4 %).  The same reservation on wgrad_patch_kernel, dgrad_s2_patch_kernel and the low-precision
+    // kernels measured -0.5 to -8 %: only this kernel has the slack.  GHM_PATCH_LDS_MIN overrides (tuning).
+    size_t lds_min = 54 * 1024;
+    if (const char* f = getenv("GHM_PATCH_LDS_MIN")) lds_min = (size_t)atol(f);
+    if (p.lds < lds_min) p.lds = lds_min;
     const int ntr = (R + p.bm - 1) / p.bm;
     p.grid = ntr * (W / 32) * (H / p.rt) * N;
     const int nslabs = CH / cb;
