@@ -1842,7 +1842,10 @@ WVariant pick_wgrad(const ghm_conv_desc* d, int num_cu) {
     v.row_tiles = v.patch ? ceil_div(d->C, 128 / T) : ceil_div(CT, v.bm);
     const long tiles = (long)v.row_tiles * ceil_div(d->K, v.bn);
     const long P = (long)d->N * d->Ho * d->Wo;
-    v.bkp = (v.patch && d->Wo % 32 == 0 && getenv("GHM_WGRAD_BKP16") == nullptr) ? 32 : 16;
+    // 32-pixel slabs only for 5x5 (alone: 121 vs 117 TFLOP/s).  3x3 is as fast with 16-pixel slabs (116 vs 115) and then
+    // needs 28 KB of LDS and 111-121 VGPRs instead of 45-56 KB and 136-156: more room for the co-running streams (+0.4 % step)
+    v.bkp = (v.patch && d->Wo % 32 == 0 && d->kh == 5 && getenv("GHM_WGRAD_BKP16") == nullptr) ? 32 : 16;
+    if (v.patch && d->Wo % 32 == 0 && getenv("GHM_WGRAD_BKP32")) v.bkp = 32;
     const long slabs = (P + v.bkp - 1) / v.bkp;
     // one FULL round of resident blocks (a second, partly filled round costs up to 2x): blocks/CU is 3 for the
     // 128-filter tile, 4 otherwise
