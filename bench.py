@@ -162,7 +162,7 @@ def main():
             for r0_, ms_ in zip(runs[0], [t[1] for t in table]):
                 if r0_[0] not in ("fork", "join"):
                     streams[r0_[3]] = streams.get(r0_[3], 0.0) + ms_
-            print("isolated time per stream (A / B = DCGAN / pix2pix stage, ' = its gradient stream, C = communication): "
+            print("isolated time per lane (A / B = DCGAN / pix2pix stage stream, ' = that stage's work on the shared gradient stream, C = communication): "
                   + ", ".join("%s %.2f ms" % kv for kv in sorted(streams.items())), file=sys.stderr)
             tot = sum(v[0] for v in by_kernel.values())
             for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][0]):
@@ -244,7 +244,7 @@ def main():
                    "global_batch": B * world, "in_shp": S, "parallelism": "dp%d" % world,
                    "hip_graph": bool(args.graph), "issue": "graph" if args.graph else args.issue,
                    "host_calls_per_step": 1 if issue == 'recorded' else None,
-                   "streams": (1 if eng.devs[0] is eng.devs[1] else 2) * (2 if eng.side[0] is not None else 1)},
+                   "streams": len({id(d) for d in list(eng.devs) + [sd[0] for sd in eng.side if sd is not None]})},
         "step_algorithmic_tflops": round(JOINT_GFLOP_PER_IMG * value / 1e3, 2) if args.mode == 'both' and S == 512 else None,
         "step_frac_of_fp32_mfma_peak": round(JOINT_GFLOP_PER_IMG * value / world / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)
         if args.mode == 'both' and S == 512 else None,
@@ -272,7 +272,7 @@ def main():
         peak = PEAK[kdt]
         out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "kernel_dtype": kdt,
                            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                           "concurrent_streams": (1 if eng.devs[0] is eng.devs[1] else 2) * (2 if eng.side[0] is not None else 1),
+                           "concurrent_streams": len({id(d) for d in list(eng.devs) + [sd[0] for sd in eng.side if sd is not None]}),
                            "achieved_isolated": round(iso, 2), "frac_isolated": round(iso / peak, 4),
                            "kernel": dominant, "launches_per_step": launches_per_step,
                            "avg_launch_ms": round(avg_ms, 4),

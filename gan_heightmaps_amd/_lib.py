@@ -123,6 +123,9 @@ def load():
     # the host driver only supports dmabuf IPC: RCCL's cross-process buffer registration needs this before the HIP
     # runtime initialises (no effect on a single process)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # one hardware queue per HIP stream (stage A, stage B, gradients, communication, the null stream): with ROCm's
+    # default of four, which streams end up sharing a queue -- and serialising -- depends on their creation order
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -15,6 +15,8 @@ U-Net consumes real X, not G(z)), so they are enqueued on TWO HIP streams (two g
 device): the low-parallelism layers of one stage (4x4 .. 16x16 maps, reductions) overlap the other stage's
 big convolutions.
 """
+import os
+
 import numpy as np
 
 from . import layers as L
@@ -70,10 +72,16 @@ class GanStep:
         mkops = getattr(dev, 'ops_class', Ops)
         self.devs = [dev, mk(dev.index) if two_streams else dev]
         self.ops = [mkops(self.devs[0]), mkops(self.devs[1])]
-        # optional second stream per stage for the weight / bias gradients (engine.NetPlan side=)
+        # optional GRADIENT stream for the weight / bias gradients of both stages (engine.NetPlan side=).  ONE stream for
+        # the two stages, not one each: three MFMA-heavy kernels at a time (stage A, stage B, one weight gradient) is what
+        # the chip runs best -- with a gradient stream per stage the two weight-gradient kernels share CUs with each other
+        # and the step is 3 % slower (162.5 vs 167.6 img/s fp32, 435 vs 465 bf16).  (A per-stage pair used to measure
+        # the same as the shared stream only because ROCm's default of four hardware queues happened to put the two
+        # gradient streams on one queue; GHM_GRAD_STREAM_PER_STAGE=1 restores the pair for measurements.)
         self.side = [None, None]
         if side_streams:
-            sd = [mk(dev.index), mk(dev.index) if two_streams else None]
+            per_stage = two_streams and bool(os.environ.get('GHM_GRAD_STREAM_PER_STAGE'))
+            sd = [mk(dev.index), mk(dev.index) if per_stage else None]
             if sd[1] is None:
                 sd[1] = sd[0]
             self.side = [(sd[0], mkops(sd[0])), (sd[1], mkops(sd[1]))]

@@ -228,7 +228,7 @@ def test_reduced_precision_lowering_on_fake_device():
 
 def test_recorded_issue_replays_the_whole_sequence_in_one_call():
     """use_graph='recorded': call 0 runs eagerly, call 1 records every entry of both stage programs, the exchange and
-    the updates between step_record_begin / _end on ALL contexts (stage, gradient, communication streams) and replays,
+    the updates between step_record_begin / _end on ALL contexts (two stage streams, the gradient stream, communication) and replays,
     later calls are one step_run"""
     events = []
 
@@ -255,7 +255,8 @@ def test_recorded_issue_replays_the_whole_sequence_in_one_call():
     P = p2p.discriminator(32, True, False, nf=4, act=linear, mul_factor=[1, 2])
     spec = updates.rmsprop(learning_rate=updates.shared(1e-4))
     eng = GanStep(dev, G, Dn, U, P, 100, True, 'l1', spec, 'both', use_graph='recorded')
-    assert eng.side[0] is not None and len(eng._all_devs()) == 4
+    assert eng.side[0] is not None and eng.side[0][0] is eng.side[1][0]      # ONE gradient stream for both stages
+    assert len(eng._all_devs()) == 3
     b = eng.built(4)
     n_entries = len(eng._sequence(b, 'train'))
     assert n_entries == sum(len(l) for l in b.train_compute) + sum(len(l) for l in b.update)
@@ -265,7 +266,7 @@ def test_recorded_issue_replays_the_whole_sequence_in_one_call():
     per_step = count() - base
     assert events == [] and per_step >= n_entries - 50       # fork / join entries are stream waits, not Ops calls
     eng.enqueue_train(b)
-    assert events == [('begin', 4), ('end', 'step'), ('run', 'step')]
+    assert events == [('begin', 3), ('end', 'step'), ('run', 'step')]
     assert count() == base + 2 * per_step        # the recording pass issued the same calls once more
     eng.enqueue_train(b)
     eng.enqueue_train(b)
