@@ -187,15 +187,21 @@ class GanStep:
         i_a, i_b = self.p2p_disc_inputs
         ca, H, W = d_in_layer.shape[1:]
         b.d_in = dA.empty((2 * B, ca, H, W))
+        # which nets fork their weight / bias gradients onto the gradient stream: all but the DCGAN generator, whose
+        # small weight gradients stay inline on stage A (measured img/s, fp32 / bf16 / fp32 batch 2 / 1024^2 fp16:
+        # DPU 169.4 / 492.3 / 153.0 / 98.9, PU 169.3 / 498.8 / 150.5 / 97.2, GDPU 167.7 / 471.9 / 150.4 / 97.2,
+        # none 164.5 / 467.1, GD 164.0).  GHM_SIDE_NETS overrides (tuning).
+        _sn = os.environ.get('GHM_SIDE_NETS', 'DPU')
+        _side = lambda k, lane: self.side[lane] if k in _sn else None
         b.G = NetPlan(dA, oA, G, B, self.stores['dcgan_gen'], out_tensor=b.d_in.samples(B, 2 * B), name="G",
-                      side=self.side[0], rng_seed=self.rank, dtype=self.dtype)      # replicas draw different dropout masks
+                      side=_side('G', 0), rng_seed=self.rank, dtype=self.dtype)      # replicas draw different dropout masks
         b.D = NetPlan(dA, oA, D, 2 * B, self.stores['dcgan_disc'], inputs={d_in_layer: b.d_in}, name="D",
-                      side=self.side[0], bn_groups=2 if _has_bn(D) else 1, dtype=self.dtype)
-        b.P = NetPlan(dB, oB, P, 2 * B, self.stores['p2p_disc'], name="P", side=self.side[1],
+                      side=_side('D', 0), bn_groups=2 if _has_bn(D) else 1, dtype=self.dtype)
+        b.P = NetPlan(dB, oB, P, 2 * B, self.stores['p2p_disc'], name="P", side=_side('P', 1),
                       bn_groups=2 if _has_bn(P) else 1, dtype=self.dtype)
         pa, pb = b.P.input_tensor(i_a), b.P.input_tensor(i_b)
         b.U = NetPlan(dB, oB, U, B, self.stores['p2p_gen'], out_tensor=pb.samples(B, 2 * B), name="U",
-                      side=self.side[1], rng_seed=self.rank, dtype=self.dtype)
+                      side=_side('U', 1), rng_seed=self.rank, dtype=self.dtype)
         b.z = b.G.input_nodes[0].out
         b.x = b.U.input_tensor(u_in_layer)
         b.y = dB.empty((B,) + tuple(pb.shape[1:]))
