@@ -78,7 +78,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
 }
 
 template <int BM, int BN, int WM, int WN, bool WT, bool FASTK>
-__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? (WT ? 3 : 4) : 2) void igemm_kernel(const IgemmArgs a) {
+__device__ __forceinline__ void igemm_body(const IgemmArgs& a) {
     constexpr int BK = 16;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -327,6 +327,26 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? (WT ? 3 : 4) : 2) voi
             }
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, bool WT, bool FASTK>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? (WT ? 3 : 4) : 2) void igemm_kernel(const IgemmArgs a) {
+    igemm_body<BM, BN, WM, WN, WT, FASTK>(a);
+}
+
+// The four output parity classes of a stride-2 data gradient in ONE launch (blockIdx.z = class; each class has its own
+// taps, output offset, split count and partial buffer).  On the 2x2 .. 32x32 maps of the U-Net bottleneck the four
+// launches + four split-K epilogues of the per-class form were eight dependent launches of a few microseconds of work
+// each on the critical path of the stage stream.
+struct IgemmArgs4 {
+    IgemmArgs c[4];
+    int nsplit[4];
+};
+
+template <int BM, int BN, int WM, int WN, bool FASTK>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 2) void igemm_kernel_x4(const IgemmArgs4 a4) {
+    if ((int)blockIdx.y >= a4.nsplit[blockIdx.z]) return;         // uniform: this class has fewer splits
+    igemm_body<BM, BN, WM, WN, true, FASTK>(a4.c[blockIdx.z]);
 }
 
 // Direct (VALU) form of the same gather convolution for R <= 4 output channels (g_out, d_out, pd_out,
@@ -978,7 +998,12 @@ __global__ __launch_bounds__(256) void transpose_weights_batched_kernel(const Tr
 }
 
 // split-K epilogue: sum the partial slices, then bias / accumulate / activation and the NCHW scatter
-__global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs a, int S) {
+__device__ __forceinline__ void splitk_epilogue_body(const IgemmArgs& a, int S);
+__global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs a, int S) { splitk_epilogue_body(a, S); }
+__global__ __launch_bounds__(256) void igemm_splitk_epilogue_x4(const IgemmArgs4 a4) {
+    splitk_epilogue_body(a4.c[blockIdx.y], a4.nsplit[blockIdx.y]);
+}
+__device__ __forceinline__ void splitk_epilogue_body(const IgemmArgs& a, int S) {
     const int hw_s = a.Hs * a.Ws;
     const long P = (long)a.N * hw_s;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -1693,6 +1718,64 @@ int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
 }
 
 
+// the four parity classes of a stride-2 data gradient (same R, same sub-grid) through igemm_kernel_x4
+int launch_igemm_x4(ghm_ctx* ctx, IgemmArgs4& a4) {
+    const IgemmArgs& a0 = a4.c[0];
+    const long P = (long)a0.N * a0.Hs * a0.Ws;
+    if (P == 0 || a0.R == 0) return 0;
+    const Variant v = pick_variant(a0.R, P, ctx->num_cu);
+    const bool fast = (a0.CH % 16) == 0;
+    const int grid = ceil_div(a0.R, v.bm) * ceil_div(P, v.bn);
+    int smax = 1;
+    size_t total = 0;
+    for (int c = 0; c < 4; ++c) {
+        IgemmArgs& a = a4.c[c];
+        const int nslabs = ceil_div((long)a.ntaps * a.CH, 16);
+        int splits = 1;
+        if (4 * grid < ctx->num_cu + ctx->num_cu / 2) {                   // the four classes fill the chip together
+            splits = (4 * ctx->num_cu + 4 * grid - 1) / (4 * grid);
+            const int max_by_work = nslabs / 8 > 0 ? nslabs / 8 : 1;
+            if (splits > max_by_work) splits = max_by_work;
+        }
+        if (const char* f = getenv("GHM_FORCE_SPLITK")) splits = atoi(f) < nslabs ? atoi(f) : nslabs;
+        if (splits < 1) splits = 1;
+        a.slabs_per_split = ceil_div(nslabs, splits);
+        splits = ceil_div(nslabs, a.slabs_per_split);
+        a4.nsplit[c] = splits;
+        if (splits > smax) smax = splits;
+        total += (size_t)splits * a.R * P;
+        if (const char* f = getenv("GHM_ABLATE")) a.debug = atoi(f);
+    }
+    void* ws = nullptr;
+    if (int e = ghm_scratch(ctx, total * sizeof(float), &ws)) return e;
+    float* part = (float*)ws;
+    for (int c = 0; c < 4; ++c) {                   // every class goes through its partial slices (one epilogue for all)
+        a4.c[c].partial = part;
+        part += (size_t)a4.nsplit[c] * a4.c[c].R * P;
+    }
+    const dim3 g(grid, smax, 4);
+#define GHM_IGEMM4_CASE(BM_, BN_, WM_, WN_)                                                                      \
+    if (v.bm == BM_ && v.bn == BN_) {                                                                            \
+        if (fast)                                                                                                \
+            hipLaunchKernelGGL((igemm_kernel_x4<BM_, BN_, WM_, WN_, true>), g, dim3(256), 0, ctx->stream, a4);    \
+        else                                                                                                     \
+            hipLaunchKernelGGL((igemm_kernel_x4<BM_, BN_, WM_, WN_, false>), g, dim3(256), 0, ctx->stream, a4);   \
+        GHM_LAUNCH_CHECK();                                                                                      \
+        hipLaunchKernelGGL(igemm_splitk_epilogue_x4, dim3(ceil_div(P * a0.R, 256), 4), dim3(256), 0, ctx->stream, a4); \
+        GHM_LAUNCH_CHECK();                                                                                      \
+        return 0;                                                                                                \
+    }
+    GHM_IGEMM4_CASE(128, 128, 2, 2)
+    GHM_IGEMM4_CASE(128, 64, 2, 2)
+    GHM_IGEMM4_CASE(64, 256, 1, 4)
+    GHM_IGEMM4_CASE(64, 64, 2, 2)
+    GHM_IGEMM4_CASE(32, 256, 1, 4)
+    GHM_IGEMM4_CASE(32, 128, 1, 4)
+#undef GHM_IGEMM4_CASE
+    ghm_set_error("no igemm variant for bm=%d bn=%d", v.bm, v.bn);
+    return -3;
+}
+
 // does this geometry take the taps-as-rows path?  (stride 1, 'same'-style geometry, many pixels)
 bool taps_as_rows(const ghm_conv_desc* d, int small_side) {
     return small_side <= 4 && d->stride == 1 && d->Ho == d->H && d->Wo == d->W && d->kh * d->kw > 1 &&
@@ -2042,6 +2125,8 @@ int ghm_conv2d_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, cons
         return 0;
     }
     const int s = d->stride;
+    IgemmArgs4 a4;
+    int ncls = 0;
     for (int pu = 0; pu < s; ++pu) {
         for (int pv = 0; pv < s; ++pv) {
             IgemmArgs a;
@@ -2066,9 +2151,15 @@ int ghm_conv2d_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, cons
             }
             a.ntaps = nt;
             if (a.Hs <= 0 || a.Ws <= 0) continue;
-            if (int e = launch_igemm<true>(ctx, a)) return e;
+            GHM_CHECK(ncls < 4, "data gradient: stride %d has more than four parity classes", s);
+            a4.c[ncls++] = a;
         }
     }
+    // stride 2 on an even grid: the four classes share R and the sub-grid -> ONE launch + ONE epilogue for all of them
+    if (ncls == 4 && d->H % 2 == 0 && d->W % 2 == 0 && d->C > 4 && getenv("GHM_NO_DGRAD_X4") == nullptr)
+        return launch_igemm_x4(ctx, a4);
+    for (int c = 0; c < ncls; ++c)
+        if (int e = launch_igemm<true>(ctx, a4.c[c])) return e;
     return 0;
 }
 
