@@ -807,6 +807,131 @@ __global__ void counter_tick_kernel(unsigned* counter) { *counter += 1u; }
 
 #define EW_GRID(total) dim3(ceil_div((long)(total), 256)), dim3(256), 0, ctx->stream
 
+// ---- small tensors: one block per channel does the whole layer (N * HW <= BN_SMALL_MAX values per channel) ----
+// The partial / final / apply form above is three dependent launches; for the 1x1 .. 64x64 maps of the U-Net bottleneck
+// and the first DCGAN stages those launches ARE the cost (chains of ~150 of them per step on the stage streams).
+#define BN_SMALL_MAX 16384
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_fwd_small_kernel(const float* __restrict__ x, long xs, float* __restrict__ y, long ys,
+                                                           int N, int HW, float eps, float* __restrict__ mean,
+                                                           float* __restrict__ inv, float* run_mean, float* run_inv, float ra,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           int act, float alpha, int apply) {
+    const int c = blockIdx.x;
+    const int units = HW / VEC, total = N * units;
+    const float* xc = x + (long)c * HW;
+    double a = 0.0, b = 0.0;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int n = e / units, i = (e - n * units) * VEC;
+        if constexpr (VEC == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xc + n * xs + i);
+            const double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+            a += (x0 + x1) + (x2 + x3);
+            b += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
+        } else {
+            const double v = xc[n * xs + i];
+            a += v;
+            b += v * v;
+        }
+    }
+    __shared__ double red[4];
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    const double count = (double)N * HW;
+    const double mu = a / count;
+    double var = b / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float m = (float)mu;
+    const float iv = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) {
+        mean[c] = m;
+        inv[c] = iv;
+        if (run_mean) {
+            run_mean[c] = (1.f - ra) * run_mean[c] + ra * m;
+            run_inv[c] = (1.f - ra) * run_inv[c] + ra * iv;
+        }
+    }
+    if (!apply) return;
+    const float sc = gamma[c] * iv, be = beta[c];
+    float* yc = y + (long)c * HW;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int n = e / units, i = (e - n * units) * VEC;
+        if constexpr (VEC == 4) {
+            float4 t = *reinterpret_cast<const float4*>(xc + n * xs + i);
+            t.x = ghm_act(fmaf(t.x - m, sc, be), act, alpha);
+            t.y = ghm_act(fmaf(t.y - m, sc, be), act, alpha);
+            t.z = ghm_act(fmaf(t.z - m, sc, be), act, alpha);
+            t.w = ghm_act(fmaf(t.w - m, sc, be), act, alpha);
+            *reinterpret_cast<float4*>(yc + n * ys + i) = t;
+        } else {
+            yc[n * ys + i] = ghm_act(fmaf(xc[n * xs + i] - m, sc, be), act, alpha);
+        }
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_small_kernel(const float* __restrict__ dout, long ds, const float* __restrict__ y,
+                                                           long ys, const float* __restrict__ x, long xs,
+                                                           float* __restrict__ dx, long dxs, int N, int HW,
+                                                           const float* __restrict__ mean, const float* __restrict__ inv,
+                                                           const float* __restrict__ gamma, float* dgamma, float* dbeta,
+                                                           int act, float alpha, int accumulate) {
+    const int c = blockIdx.x;
+    const int units = HW / VEC, total = N * units;
+    const long row = (long)c * HW;
+    const float m = mean[c], iv = inv[c];
+    double a = 0.0, b = 0.0;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int n = e / units, i = (e - n * units) * VEC;
+        if constexpr (VEC == 4) {
+            const float4 d = *reinterpret_cast<const float4*>(dout + n * ds + row + i);
+            const float4 yy = *reinterpret_cast<const float4*>(y + n * ys + row + i);
+            const float4 xx = *reinterpret_cast<const float4*>(x + n * xs + row + i);
+            const float z0 = d.x * ghm_dact_from_out(yy.x, act, alpha), z1 = d.y * ghm_dact_from_out(yy.y, act, alpha);
+            const float z2 = d.z * ghm_dact_from_out(yy.z, act, alpha), z3 = d.w * ghm_dact_from_out(yy.w, act, alpha);
+            a += ((double)z0 + (double)z1) + ((double)z2 + (double)z3);
+            b += ((double)z0 * ((xx.x - m) * iv) + (double)z1 * ((xx.y - m) * iv)) +
+                 ((double)z2 * ((xx.z - m) * iv) + (double)z3 * ((xx.w - m) * iv));
+        } else {
+            const float dz = dout[n * ds + row + i] * ghm_dact_from_out(y[n * ys + row + i], act, alpha);
+            const float xh = (x[n * xs + row + i] - m) * iv;
+            a += dz;
+            b += (double)dz * xh;
+        }
+    }
+    __shared__ double red[4];
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    const float fa = (float)a, fb = (float)b;
+    if (threadIdx.x == 0) {
+        dbeta[c] = (accumulate ? dbeta[c] : 0.f) + fa;
+        dgamma[c] = (accumulate ? dgamma[c] : 0.f) + fb;
+    }
+    const float inv_count = 1.f / (float)((long)N * HW);
+    const float g = gamma[c] * iv, mb = fa * inv_count, mg = fb * inv_count;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int n = e / units, i = (e - n * units) * VEC;
+        if constexpr (VEC == 4) {
+            const float4 d = *reinterpret_cast<const float4*>(dout + n * ds + row + i);
+            const float4 yy = *reinterpret_cast<const float4*>(y + n * ys + row + i);
+            const float4 xx = *reinterpret_cast<const float4*>(x + n * xs + row + i);
+            float4 r;
+            r.x = g * (d.x * ghm_dact_from_out(yy.x, act, alpha) - mb - (xx.x - m) * iv * mg);
+            r.y = g * (d.y * ghm_dact_from_out(yy.y, act, alpha) - mb - (xx.y - m) * iv * mg);
+            r.z = g * (d.z * ghm_dact_from_out(yy.z, act, alpha) - mb - (xx.z - m) * iv * mg);
+            r.w = g * (d.w * ghm_dact_from_out(yy.w, act, alpha) - mb - (xx.w - m) * iv * mg);
+            *reinterpret_cast<float4*>(dx + n * dxs + row + i) = r;
+        } else {
+            const float dz = dout[n * ds + row + i] * ghm_dact_from_out(y[n * ys + row + i], act, alpha);
+            const float xh = (x[n * xs + row + i] - m) * iv;
+            dx[n * dxs + row + i] = g * (dz - mb - xh * mg);
+        }
+    }
+}
+
+static bool bn_small(long count) { return count <= BN_SMALL_MAX && getenv("GHM_NO_BN_SMALL") == nullptr; }
+
 extern "C" {
 
 size_t ghm_bn_workspace(int32_t C) { return (size_t)C * BN_MAX_SPLIT * 2 * sizeof(double) + (size_t)C * 2 * sizeof(float); }
@@ -839,6 +964,16 @@ static int bn_row_segs(int N, int C, int HW, int* seg_len) {
 int ghm_bn_stats(ghm_ctx* ctx, const float* x, int32_t N, int32_t C, int32_t HW, int64_t nstride, float eps, float* mean,
                  float* inv, float* run_mean, float* run_inv, float run_alpha, void* ws) {
     const long count = (long)N * HW;
+    if (bn_small(count)) {
+        if (HW % 4 == 0 && nstride % 4 == 0 && aligned16(x))
+            hipLaunchKernelGGL((bn_fwd_small_kernel<4>), dim3(C), dim3(256), 0, ctx->stream, x, (long)nstride, nullptr, 0L, N, HW,
+                               eps, mean, inv, run_mean, run_inv, run_alpha, nullptr, nullptr, 0, 0.f, 0);
+        else
+            hipLaunchKernelGGL((bn_fwd_small_kernel<1>), dim3(C), dim3(256), 0, ctx->stream, x, (long)nstride, nullptr, 0L, N, HW,
+                               eps, mean, inv, run_mean, run_inv, run_alpha, nullptr, nullptr, 0, 0.f, 0);
+        GHM_LAUNCH_CHECK();
+        return 0;
+    }
     int S = bn_split(C, count), seg_len = 0;
     const int segs = (nstride % 4 == 0 && aligned16(x)) ? bn_row_segs(N, C, HW, &seg_len) : 0;
     if (segs > 0) {
@@ -869,11 +1004,39 @@ int ghm_bn_apply(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t ys,
     return 0;
 }
 
+int ghm_bn_forward(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t ys, int32_t N, int32_t C, int32_t HW, float eps,
+                   float* mean, float* inv, float* run_mean, float* run_inv, float run_alpha, const float* gamma,
+                   const float* beta, int32_t act, float alpha, void* ws) {
+    if (bn_small((long)N * HW)) {
+        if (HW % 4 == 0 && xs % 4 == 0 && ys % 4 == 0 && aligned16(x) && aligned16(y))
+            hipLaunchKernelGGL((bn_fwd_small_kernel<4>), dim3(C), dim3(256), 0, ctx->stream, x, (long)xs, y, (long)ys, N, HW, eps,
+                               mean, inv, run_mean, run_inv, run_alpha, gamma, beta, act, alpha, 1);
+        else
+            hipLaunchKernelGGL((bn_fwd_small_kernel<1>), dim3(C), dim3(256), 0, ctx->stream, x, (long)xs, y, (long)ys, N, HW, eps,
+                               mean, inv, run_mean, run_inv, run_alpha, gamma, beta, act, alpha, 1);
+        GHM_LAUNCH_CHECK();
+        return 0;
+    }
+    if (int e = ghm_bn_stats(ctx, x, N, C, HW, xs, eps, mean, inv, run_mean, run_inv, run_alpha, ws)) return e;
+    return ghm_bn_apply(ctx, x, xs, y, ys, N, C, HW, mean, inv, gamma, beta, act, alpha);
+}
+
 int ghm_bn_backward(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y, int64_t ys, const float* x, int64_t xs,
                     float* dx, int64_t dxs, int32_t N, int32_t C, int32_t HW, const float* mean, const float* inv,
                     const float* gamma, float* dgamma, float* dbeta, int32_t act, float alpha, int32_t accumulate,
                     void* ws) {
     const long count = (long)N * HW;
+    if (bn_small(count)) {
+        if (HW % 4 == 0 && ds % 4 == 0 && ys % 4 == 0 && xs % 4 == 0 && dxs % 4 == 0 && aligned16(dout) && aligned16(y) &&
+            aligned16(x) && aligned16(dx))
+            hipLaunchKernelGGL((bn_bwd_small_kernel<4>), dim3(C), dim3(256), 0, ctx->stream, dout, (long)ds, y, (long)ys, x,
+                               (long)xs, dx, (long)dxs, N, HW, mean, inv, gamma, dgamma, dbeta, act, alpha, accumulate);
+        else
+            hipLaunchKernelGGL((bn_bwd_small_kernel<1>), dim3(C), dim3(256), 0, ctx->stream, dout, (long)ds, y, (long)ys, x,
+                               (long)xs, dx, (long)dxs, N, HW, mean, inv, gamma, dgamma, dbeta, act, alpha, accumulate);
+        GHM_LAUNCH_CHECK();
+        return 0;
+    }
     int S = bn_split(C, count), seg_len = 0;
     double* wsd = (double*)ws;
     float* sums = (float*)((char*)ws + (size_t)C * BN_MAX_SPLIT * 2 * sizeof(double));

@@ -388,6 +388,12 @@ class Ops:
         call("ghm_bn_apply", self.h, _vp(x), x.nstride, _vp(y), y.nstride, x.N, x.Cc, x.HW, _vp(mean), _vp(inv),
              _vp(gamma), _vp(beta), ACT_CODES[act], alpha)
 
+    def bn_forward(self, x, y, mean, inv, gamma, beta, ws, run_mean=None, run_inv=None, eps=1e-4, run_alpha=0.1,
+                   act='linear', alpha=0.0):
+        """batch statistics (+ running update) and normalise + activation: one launch for small tensors"""
+        call("ghm_bn_forward", self.h, _vp(x), x.nstride, _vp(y), y.nstride, x.N, x.Cc, x.HW, eps, _vp(mean), _vp(inv),
+             _vp(run_mean), _vp(run_inv), run_alpha, _vp(gamma), _vp(beta), ACT_CODES[act], alpha, _vp(ws))
+
     def bn_backward(self, dout, y, x, dx, mean, inv, gamma, dgamma, dbeta, ws, act='linear', alpha=0.0,
                     accumulate=False):
         call("ghm_bn_backward", self.h, _vp(dout), dout.nstride, _vp(y), y.nstride, _vp(x), x.nstride, _vp(dx),

@@ -583,19 +583,15 @@ class NetPlan:
                         xs, ys = x.samples(h * hb, (h + 1) * hb), y.samples(h * hb, (h + 1) * hb)
                         m, iv = n.aux['mean_g'][h], n.aux['inv_g'][h]
                         upd = update_running and h == 1
-                        prog.append(("bn_stats", lambda xs=xs, m=m, iv=iv, rm=rm, ri=ri, l=l, upd=upd:
-                                     ops.bn_stats(xs, m, iv, self.bn_ws, rm if upd else None, ri if upd else None,
-                                                  l.epsilon, l.alpha)))
-                        prog.append(("bn_apply", lambda xs=xs, ys=ys, m=m, iv=iv, g=g, be=be, a=a:
-                                     ops.bn_apply(xs, ys, m, iv, g, be, a.kind, a.alpha)))
+                        prog.append(("bn_fwd", lambda xs=xs, ys=ys, m=m, iv=iv, rm=rm, ri=ri, l=l, upd=upd, g=g, be=be, a=a:
+                                     ops.bn_forward(xs, ys, m, iv, g, be, self.bn_ws, rm if upd else None,
+                                                    ri if upd else None, l.epsilon, l.alpha, a.kind, a.alpha)))
                 else:
                     m, iv = n.aux['mean'], n.aux['inv']
                     upd = update_running
-                    prog.append(("bn_stats", lambda x=x, m=m, iv=iv, rm=rm, ri=ri, l=l, upd=upd:
-                                 ops.bn_stats(x, m, iv, self.bn_ws, rm if upd else None, ri if upd else None,
-                                              l.epsilon, l.alpha)))
-                    prog.append(("bn_apply", lambda x=x, y=y, m=m, iv=iv, g=g, be=be, a=a:
-                                 ops.bn_apply(x, y, m, iv, g, be, a.kind, a.alpha)))
+                    prog.append(("bn_fwd", lambda x=x, y=y, m=m, iv=iv, rm=rm, ri=ri, l=l, upd=upd, g=g, be=be, a=a:
+                                 ops.bn_forward(x, y, m, iv, g, be, self.bn_ws, rm if upd else None, ri if upd else None,
+                                                l.epsilon, l.alpha, a.kind, a.alpha)))
             elif n.op == 'upconv':
                 d = self._upconv_desc(n, x)
                 w5, b = st.value(n.layer.W), st.value(n.layer.b)

@@ -237,9 +237,21 @@ def test_conv_on_channel_slice_views(gpu):
     assert rel(got[:, 3:], ref) < TOL and np.all(got[:, :3] == 0)
 
 
-@pytest.mark.parametrize("shape", [(4, 24, 1, 1), (4, 8, 16, 16), (3, 5, 7, 9), (2, 64, 64, 64)])
+# (N*H*W <= 16384 per channel: the one-launch-per-layer kernels; above: partial / final / apply; "big" forces the latter)
+@pytest.mark.parametrize("shape", [(4, 24, 1, 1), (4, 8, 16, 16), (3, 5, 7, 9), (2, 64, 64, 64), (4, 40, 64, 64),
+                                   (2, 6, 96, 128), (2, 3, 129, 67)])
 @pytest.mark.parametrize("act,alpha", [('lrelu', 0.2), ('linear', 0.0)])
-def test_batchnorm_fwd_bwd(gpu, shape, act, alpha):
+@pytest.mark.parametrize("path", ["auto", "big"])
+def test_batchnorm_fwd_bwd(gpu, shape, act, alpha, path):
+    if path == "big":
+        os.environ["GHM_NO_BN_SMALL"] = "1"
+    try:
+        _check_batchnorm(gpu, shape, act, alpha)
+    finally:
+        os.environ.pop("GHM_NO_BN_SMALL", None)
+
+
+def _check_batchnorm(gpu, shape, act, alpha):
     dev, ops, D = gpu
     rng = np.random.RandomState(5)
     N, C, H, W = shape
@@ -271,6 +283,22 @@ def test_batchnorm_fwd_bwd(gpu, shape, act, alpha):
     # deterministic path = apply with running stats
     ops.bn_apply(xd, yd, rmd, rid, gd, bd, 'linear', 0.0)
     assert rel(yd.numpy(), O.bn_infer_fwd(x64, beta, gamma, rm_ref, ri_ref)) < TOL
+    # the training forward as ONE entry point (what the step issues): same results as stats + apply, bit for bit
+    md2, ivd2, rmd2, rid2, yd2 = dev.empty((1, C, 1, 1)), dev.empty((1, C, 1, 1)), dev.tensor(rm), dev.tensor(ri), dev.empty(shape)
+    ops.bn_forward(xd, yd2, md2, ivd2, gd, bd, ws, rmd2, rid2, act=act, alpha=alpha)
+    ops.bn_apply(xd, yd, md, ivd, gd, bd, act, alpha)
+    assert np.array_equal(md2.numpy(), md.numpy()) and np.array_equal(ivd2.numpy(), ivd.numpy())
+    assert np.array_equal(rmd2.numpy(), rmd.numpy()) and np.array_equal(rid2.numpy(), rid.numpy())
+    assert np.array_equal(yd2.numpy(), yd.numpy())
+    # accumulate on top of existing parameter gradients
+    ops.bn_backward(dev.tensor(dout), yd, xd, dxd, md, ivd, gd, dgd, dbd, ws, act, alpha, accumulate=True)
+    assert rel(dbd.numpy().ravel(), 2 * dbeta_ref) < 1e-4 and rel(dgd.numpy().ravel(), 2 * dgamma_ref) < 1e-4
+    # sample-strided views (a channel slice of a wider buffer, as the concat-in-place layers use)
+    wide = dev.tensor(np.concatenate([x, rng.randn(*shape).astype(np.float32)], axis=1))
+    view = wide.channels(0, C) if hasattr(wide, 'channels') else None
+    if view is not None:
+        ops.bn_forward(view, yd2, md2, ivd2, gd, bd, ws, act=act, alpha=alpha)
+        assert np.array_equal(yd2.numpy(), yd.numpy())
 
 
 def test_bn_bottleneck_batch4_single_pixel(gpu):
