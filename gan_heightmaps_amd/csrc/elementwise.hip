@@ -739,6 +739,44 @@ __global__ __launch_bounds__(256) void upconv_expand_kernel(const float* __restr
     dwp5[i] = accumulate ? dwp5[i] + v : v;
 }
 
+// all collapsed up-sample convolutions of a net in one launch: item i owns blocks [block_begin, next.block_begin);
+// its first 36*C*K threads collapse the weights, the next 4*K tile the bias
+struct CollapseItem {
+    const float* wp5;
+    const float* bias;
+    float* wpc;
+    float* bias4;
+    int C, K, block_begin, pad;
+};
+
+__global__ __launch_bounds__(256) void upconv_collapse_batched_kernel(const CollapseItem* __restrict__ items, int n) {
+    int li = 0;
+    for (int i = 1; i < n; ++i)
+        if ((int)blockIdx.x >= items[i].block_begin) li = i;
+    const CollapseItem it = items[li];
+    const long total = (long)it.C * 36 * it.K;
+    const long i = (long)(blockIdx.x - it.block_begin) * 256 + threadIdx.x;
+    if (i < total) {
+        const int K = it.K;
+        const int k = (int)(i % K);
+        long t = i / K;
+        const int pq = (int)(t % 4); t /= 4;
+        const int rs = (int)(t % 9);
+        const int c = (int)(t / 9);
+        const int p = pq >> 1, q = pq & 1, r = rs / 3, s_ = rs % 3;
+        float v = 0.f;
+        for (int a = 0; a < 5; ++a) {
+            if (upconv_group(p, a) != r) continue;
+            for (int b = 0; b < 5; ++b)
+                if (upconv_group(q, b) == s_) v += it.wp5[((long)c * 25 + a * 5 + b) * K + k];
+        }
+        it.wpc[i] = v;
+    } else if (it.bias && it.bias4 && i < total + 4L * it.K) {
+        const int j = (int)(i - total);
+        it.bias4[j] = it.bias[j % it.K];
+    }
+}
+
 __global__ __launch_bounds__(256) void bias_tile4_kernel(const float* __restrict__ b, float* __restrict__ bc, int K) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < 4 * K) bc[i] = b[i % K];
@@ -1176,6 +1214,14 @@ int ghm_upconv_collapse_weights(ghm_ctx* ctx, const float* wp5, const float* bia
         hipLaunchKernelGGL(bias_tile4_kernel, EW_GRID(4L * K), bias, bias4, K);
         GHM_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+int ghm_upconv_collapse_batched(ghm_ctx* ctx, const void* table, int32_t n_items, int32_t total_blocks) {
+    if (n_items <= 0 || total_blocks <= 0) return 0;
+    hipLaunchKernelGGL(upconv_collapse_batched_kernel, dim3(total_blocks), dim3(256), 0, ctx->stream,
+                       (const CollapseItem*)table, n_items);
+    GHM_LAUNCH_CHECK();
     return 0;
 }
 

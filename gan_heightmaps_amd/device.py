@@ -268,6 +268,23 @@ class Ops:
     def transpose_weights(self, d, wp, wpT):
         call("ghm_conv2d_transpose_weights", self.h, C.byref(d), _vp(wp), _vp(wpT))
 
+    def collapse_table(self, items):
+        """items: [(wp5, bias, wpc, bias4 DevTensors, C, K)] -> (device table ptr, n, total blocks) for
+        upconv_collapse_batched (uploaded once: the pointers are fixed for the life of a plan)"""
+        rec = np.zeros(len(items), dtype=[('wp5', '<u8'), ('bias', '<u8'), ('wpc', '<u8'), ('b4', '<u8'), ('C', '<i4'),
+                                          ('K', '<i4'), ('b0', '<i4'), ('pad', '<i4')])
+        b0 = 0
+        for i, (w5, b, wpc, b4, Cc, K) in enumerate(items):
+            rec[i] = (w5.ptr, b.ptr if b is not None else 0, wpc.ptr, b4.ptr if b4 is not None else 0, Cc, K, b0, 0)
+            b0 += (36 * Cc * K + 4 * K + 255) // 256
+        ptr = self.dev.alloc(max(rec.nbytes, 40))
+        self.dev.h2d(ptr, rec.view(np.uint8))
+        return ptr, len(items), b0
+
+    def upconv_collapse_batched(self, table):
+        ptr, n, blocks = table
+        call("ghm_upconv_collapse_batched", self.h, C.c_void_p(ptr), n, blocks)
+
     def transpose_table(self, items):
         """items: [(wp DevTensor, wpT DevTensor, C, T, K)] -> (device table ptr, n, total blocks) for
         transpose_weights_batched (uploaded once: the pointers are fixed for the life of a plan)"""

@@ -521,11 +521,18 @@ class NetPlan:
         ops, st = self.ops, self.store
         if self.dropout_nodes and not deterministic:
             prog.append(("rng_tick", lambda c=self.rng_counter: ops.counter_tick(c)))
-        hoist = self._lp_table is not None
+        # the collapsed 3x3 weights of every up-sample convolution of the net: ONE launch at the head of the forward pass
+        # (per layer it was two small launches in front of each of the generator's first, latency-bound stages)
+        ups = [n for n in self.order if n.op == 'upconv']
+        hoist = bool(ups)
         if hoist:
-            for n in self.order:
-                if n.op == 'upconv':
-                    self._emit_collapse(prog, n)
+            if getattr(self, '_collapse_tab', None) is None:
+                self._collapse_tab = ops.collapse_table(
+                    [(st.value(n.layer.W), st.value(n.layer.b), n.aux['wpc'], n.aux['b4'], n.inputs[0].shape[1], n.shape[1])
+                     for n in ups])
+            prog.append(("collapse_w", lambda t=self._collapse_tab: ops.upconv_collapse_batched(t)))
+        if self._lp_table is not None:
+            hoist = True
             prog.append(("lp_pack", lambda t=self._lp_table: ops.lp_pack_batched(t, self.dtype)))
         for n in self.order:
             y = n.out
