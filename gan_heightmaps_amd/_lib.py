@@ -83,6 +83,7 @@ SIGNATURES = {
     "ghm_transpose_weights_batched": [_p, _p, _i32, _i32],
     "ghm_upconv_collapse_weights": [_p, _p, _p, _p, _p, _i32, _i32],
     "ghm_upconv_collapse_batched": [_p, _p, _i32, _i32],
+    "ghm_upconv_expand_batched": [_p, _p, _i32, _i32, _i32],
     "ghm_upconv_expand_wgrad": [_p, _p, _p, _i32, _i32, _i32],
     "ghm_pp_to_hi": [_p, _p, _p, _i64, _i32, _i32, _i32, _i32],
     "ghm_hi_to_pp": [_p, _p, _i64, _p, _i32, _i32, _i32, _i32],

@@ -777,6 +777,35 @@ __global__ __launch_bounds__(256) void upconv_collapse_batched_kernel(const Coll
     }
 }
 
+struct ExpandItem {
+    const float* dwpc;
+    float* dwp5;
+    int C, K, block_begin, pad;
+};
+
+__global__ __launch_bounds__(256) void upconv_expand_batched_kernel(const ExpandItem* __restrict__ items, int n, int accumulate) {
+    int li = 0;
+    for (int i = 1; i < n; ++i)
+        if ((int)blockIdx.x >= items[i].block_begin) li = i;
+    const ExpandItem it = items[li];
+    const long total = (long)it.C * 25 * it.K;
+    const long i = (long)(blockIdx.x - it.block_begin) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int K = it.K;
+    const int k = (int)(i % K);
+    long t = i / K;
+    const int ab = (int)(t % 25);
+    const int c = (int)(t / 25);
+    const int a = ab / 5, b = ab % 5;
+    float v = 0.f;
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) {
+        const int rs = upconv_group(pq >> 1, a) * 3 + upconv_group(pq & 1, b);
+        v += it.dwpc[(((long)c * 9 + rs) * 4 + pq) * K + k];
+    }
+    it.dwp5[i] = accumulate ? it.dwp5[i] + v : v;
+}
+
 __global__ __launch_bounds__(256) void bias_tile4_kernel(const float* __restrict__ b, float* __restrict__ bc, int K) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < 4 * K) bc[i] = b[i % K];
@@ -1221,6 +1250,14 @@ int ghm_upconv_collapse_batched(ghm_ctx* ctx, const void* table, int32_t n_items
     if (n_items <= 0 || total_blocks <= 0) return 0;
     hipLaunchKernelGGL(upconv_collapse_batched_kernel, dim3(total_blocks), dim3(256), 0, ctx->stream,
                        (const CollapseItem*)table, n_items);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_upconv_expand_batched(ghm_ctx* ctx, const void* table, int32_t n_items, int32_t total_blocks, int32_t accumulate) {
+    if (n_items <= 0 || total_blocks <= 0) return 0;
+    hipLaunchKernelGGL(upconv_expand_batched_kernel, dim3(total_blocks), dim3(256), 0, ctx->stream, (const ExpandItem*)table,
+                       n_items, accumulate);
     GHM_LAUNCH_CHECK();
     return 0;
 }

@@ -285,6 +285,22 @@ class Ops:
         ptr, n, blocks = table
         call("ghm_upconv_collapse_batched", self.h, C.c_void_p(ptr), n, blocks)
 
+    def expand_table(self, items):
+        """items: [(dwpc, dwp5 DevTensors, C, K)] -> (device table ptr, n, total blocks) for upconv_expand_batched"""
+        rec = np.zeros(len(items), dtype=[('dwpc', '<u8'), ('dwp5', '<u8'), ('C', '<i4'), ('K', '<i4'), ('b0', '<i4'),
+                                          ('pad', '<i4')])
+        b0 = 0
+        for i, (dwpc, dwp5, Cc, K) in enumerate(items):
+            rec[i] = (dwpc.ptr, dwp5.ptr, Cc, K, b0, 0)
+            b0 += (25 * Cc * K + 255) // 256
+        ptr = self.dev.alloc(max(rec.nbytes, 32))
+        self.dev.h2d(ptr, rec.view(np.uint8))
+        return ptr, len(items), b0
+
+    def upconv_expand_batched(self, table, accumulate=False):
+        ptr, n, blocks = table
+        call("ghm_upconv_expand_batched", self.h, C.c_void_p(ptr), n, blocks, int(accumulate))
+
     def transpose_table(self, items):
         """items: [(wp DevTensor, wpT DevTensor, C, T, K)] -> (device table ptr, n, total blocks) for
         transpose_weights_batched (uploaded once: the pointers are fixed for the life of a plan)"""

@@ -691,6 +691,7 @@ class NetPlan:
             has_p = wgrad and n.op in ('conv', 'convpool', 'deconv', 'dense', 'bn', 'upconv')
             req[id(n)] = has_p or any(req[id(i)] for i in n.inputs) or id(n) in want_in
         grads, written = {}, set()
+        expands = []
         key = (tag, n0, n1)
         cache = self._scratch.setdefault(key, {})
 
@@ -871,8 +872,7 @@ class NetPlan:
                     else:
                         prog.append(("upconv_wgrad", lambda d=d, x=x, G4=G4, dwpc=dwpc, wo=wo:
                                      wo.conv2d_wgrad(d, x, G4, dwpc, self.wgrad_ws, False), conv_meta(ops, d, 2), wdev))
-                    prog.append(("expand_wgrad", lambda dwpc=dwpc, gw=gw, C=C, K=K, aw=aw, wo=wo:
-                                 wo.upconv_expand_wgrad(dwpc, gw, C, K, aw), None, wdev))
+                    expands.append((dwpc, gw, C, K))      # 3x3 -> 5x5 gradient expansion: one launch for all layers, below
                     bn_fed = len(n.consumers) == 1 and n.consumers[0].op == 'bn' and n.act == linear
                     if not bn_fed:
                         prog.append(("bias_grad", lambda G=G, gb=gb, aw=aw, wo=wo: wo.channel_sum(G, gb, aw), None, wdev))
@@ -984,6 +984,15 @@ class NetPlan:
                     mark_written(xin)
             else:
                 raise NotImplementedError(n.op)
+        if expands:
+            # after the last collapsed layer's weight gradient, on the lane the weight gradients run on
+            wo, wdev = (self.side[1], self.side[0]) if self.side is not None else (ops, None)
+            tkey = ('expand', tuple(int(e[0].ptr) for e in expands))
+            tab = self._scratch.setdefault('tables', {}).get(tkey)
+            if tab is None:
+                tab = self._scratch['tables'][tkey] = wo.expand_table(expands)
+            prog.append(("expand_wgrad", lambda tab=tab, aw=accumulate_wgrad, wo=wo: wo.upconv_expand_batched(tab, aw),
+                         None, wdev))
         return {l: (grad_of(self.node_of_layer[id(l)]) if id(self.node_of_layer[id(l)]) in written else None)
                 for l in input_grads}
 
