@@ -1518,7 +1518,7 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
 
 // per-channel sum over (n, hw): bias gradients. grid (S, C) partials, then one thread per channel.
 __global__ __launch_bounds__(256) void channel_sum_partial(const float* __restrict__ x, int N, int HW, long nstride,
-                                                           int S, float* __restrict__ part) {
+                                                           int S, float* __restrict__ part, float* out, int accumulate) {
     const int c = blockIdx.y, sidx = blockIdx.x;
     const long total = (long)N * HW;
     const long chunk = ((total + S - 1) / S + 3) & ~3L;
@@ -1540,7 +1540,11 @@ __global__ __launch_bounds__(256) void channel_sum_partial(const float* __restri
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) part[(long)c * S + sidx] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        const float t = (red[0] + red[1]) + (red[2] + red[3]);
+        if (out) out[c] = (accumulate ? out[c] : 0.f) + t;      // S == 1: the block's sum IS the channel's (no second launch)
+        else part[(long)c * S + sidx] = t;
+    }
 }
 
 __global__ void channel_sum_final(const float* __restrict__ part, int C, int S, float* __restrict__ out, int accumulate) {
@@ -2461,8 +2465,9 @@ int ghm_channel_sum(ghm_ctx* ctx, const float* x, int32_t N, int32_t C, int32_t 
     void* ws = nullptr;
     if (int e = ghm_scratch(ctx, (size_t)C * S * sizeof(float), &ws)) return e;
     hipLaunchKernelGGL(channel_sum_partial, dim3((int)S, C), dim3(256), 0, ctx->stream, x, N, HW, (long)nstride, (int)S,
-                       (float*)ws);
+                       (float*)ws, S == 1 ? out : nullptr, accumulate);
     GHM_LAUNCH_CHECK();
+    if (S == 1) return 0;
     hipLaunchKernelGGL(channel_sum_final, dim3(ceil_div(C, 256)), dim3(256), 0, ctx->stream, (const float*)ws, C, (int)S,
                        out, accumulate);
     GHM_LAUNCH_CHECK();
