@@ -524,15 +524,13 @@ class NetPlan:
         # the collapsed 3x3 weights of every up-sample convolution of the net: ONE launch at the head of the forward pass
         # (per layer it was two small launches in front of each of the generator's first, latency-bound stages)
         ups = [n for n in self.order if n.op == 'upconv']
-        hoist = bool(ups)
-        if hoist:
+        if ups:
             if getattr(self, '_collapse_tab', None) is None:
                 self._collapse_tab = ops.collapse_table(
                     [(st.value(n.layer.W), st.value(n.layer.b), n.aux['wpc'], n.aux['b4'], n.inputs[0].shape[1], n.shape[1])
                      for n in ups])
             prog.append(("collapse_w", lambda t=self._collapse_tab: ops.upconv_collapse_batched(t)))
         if self._lp_table is not None:
-            hoist = True
             prog.append(("lp_pack", lambda t=self._lp_table: ops.lp_pack_batched(t, self.dtype)))
         for n in self.order:
             y = n.out
@@ -605,8 +603,6 @@ class NetPlan:
                 wpc, b4 = n.aux['wpc'], n.aux['b4']
                 C, K = x.Cc, n.shape[1]
                 y4 = y.reshape((x.N, 4 * K, x.H, x.W))
-                if not hoist:
-                    self._emit_collapse(prog, n)
                 if self._lp(d, 0):
                     wq = self._lp_pack_entry(prog, d, wpc, ('c', id(n.layer.W)), False, None)    # after collapse_w
                     prog.append(("upconv_fwd", lambda d=d, x=x, wq=wq, b4=b4, y4=y4, a=a:
@@ -635,13 +631,6 @@ class NetPlan:
                 prog.append(("avgpool_fwd", lambda x=x, y=y, p=n.attrs['p']: ops.avgpool_fwd(x, y, p)))
             else:
                 raise NotImplementedError(n.op)
-
-    def _emit_collapse(self, prog, n):
-        st, ops = self.store, self.ops
-        w5, b = st.value(n.layer.W), st.value(n.layer.b)
-        C, K = n.inputs[0].shape[1], n.shape[1]
-        prog.append(("collapse_w", lambda w5=w5, b=b, wpc=n.aux['wpc'], b4=n.aux['b4'], C=C, K=K:
-                     ops.upconv_collapse_weights(w5, b, wpc, b4, C, K)))
 
     def emit_transposes(self, prog, transposed):
         """One launch that refreshes every transposed weight copy the data-gradient kernels of this net read
