@@ -24,6 +24,7 @@ _D = C.POINTER(ConvDesc)
 
 # name -> argtypes (return type is int unless listed in _SPECIAL)
 SIGNATURES = {
+    "ghm_options_reload": [],
     "ghm_device_count": [C.POINTER(_i32)],
     "ghm_ctx_create": [_i32, C.POINTER(_p)],
     "ghm_ctx_destroy": [_p],
@@ -35,6 +36,7 @@ SIGNATURES = {
     "ghm_d2d": [_p, _p, _p, C.c_size_t],
     "ghm_memset_zero": [_p, _p, C.c_size_t],
     "ghm_sync": [_p],
+    "ghm_scratch_info": [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)],
     "ghm_stream_wait": [_p, _p],
     "ghm_capture_begin": [_p],
     "ghm_capture_end": [_p, C.POINTER(_p)],
@@ -100,6 +102,9 @@ SIGNATURES = {
     "ghm_rmsprop": [_p, _p, _p, _p, _i64, _p, _f, _f, _f],
     "ghm_adam": [_p, _p, _p, _p, _p, _i64, _p, _f, _f, _f, _f],
     "ghm_adam_tick": [_p, _p],
+    "ghm_set_loss_scale_state": [_p, _p],
+    "ghm_grad_check": [_p, _p, _i64],
+    "ghm_loss_scale_update": [_p, _i32, _f, _f],
     "ghm_comm_unique_id": [C.POINTER(C.c_uint8 * 128)],
     "ghm_comm_init": [_p, _i32, _i32, C.POINTER(C.c_uint8 * 128)],
     "ghm_comm_destroy": [_p],
@@ -150,6 +155,30 @@ def check(rc, what=""):
 
 def call(name, *args):
     check(getattr(load(), name)(*args), name)
+
+
+class tuning_env:
+    """``with tuning_env(GHM_FORCE_TILE="big"): ...`` -- set GHM_* tuning switches for a block inside a running process.
+    The library reads each switch once per call site (nothing calls getenv per launch), so both edges of the block
+    tell it to re-read (ghm_options_reload)."""
+
+    def __init__(self, **env):
+        self.env = {k: str(v) for k, v in env.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+        call("ghm_options_reload")
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        call("ghm_options_reload")
+        return False
 
 
 def all_export_names():

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <functional>
 #include <string>
 #include <vector>
@@ -47,8 +48,35 @@ struct ghm_ctx {
     bool capturing = false;
     void* scratch = nullptr;       // library-owned workspace (split-K partials, reduction partials)
     size_t scratch_bytes = 0;
+    // recorded steps / captured graphs hold the workspace pointer BY VALUE: while any exists on this context
+    // (``pinned`` > 0) an outgrown workspace block is retired (kept allocated until the context dies), never freed
+    int pinned = 0;
+    std::vector<void*> retired;
+    size_t retired_bytes = 0;
+    float* ls_state = nullptr;     // dynamic loss scale {scale, 1/scale, clean steps, overflow flag, skipped steps, ...} or null
     float* zeros = nullptr;        // 256 B of zeros: the source of padding elements for LDS-DMA row staging
 };
+
+// Tuning / ablation switches (GHM_* environment variables) are read ONCE per call site and cached: nothing on the launch
+// path calls getenv() per launch.  ghm_options_reload() (include/ghm.h) makes every site re-read its variable (tests and
+// sweep tools that flip a switch inside one process).
+extern int g_ghm_opt_epoch;
+#define GHM_OPT(name)                                            \
+    ([]() -> const char* {                                       \
+        static int ep_ = -1;                                     \
+        static const char* v_ = nullptr;                         \
+        if (ep_ != g_ghm_opt_epoch) {                            \
+            v_ = getenv(name);                                   \
+            ep_ = g_ghm_opt_epoch;                               \
+        }                                                        \
+        return v_;                                               \
+    }())
+
+// CU count the context-free predicates / workspace queries plan with (ghm_lp_supported, ghm_conv2d_pool_supported,
+// ghm_dgrad_dact_supported, ghm_conv2d_wgrad_workspace, ghm_conv2d_variant): the CU count of the device the process's
+// contexts live on (256 before the first ghm_ctx_create), so that a predicate and the launch it vouches for -- which
+// plans with ctx->num_cu -- always agree
+int ghm_plan_cus();
 
 // grow-only workspace owned by the ctx; growing is illegal while a graph is being captured
 int ghm_scratch(ghm_ctx* ctx, size_t bytes, void** out);

@@ -1634,7 +1634,7 @@ Variant pick_variant(int R, long P, int num_cu) {
     // the wide pixel tile is the efficient one (measured: 128x128 + split-K beats 128x64 whenever the layer has
     // at least one full wide tile); the narrow tile only serves the 1x1 .. 8x8 maps
     int bn = (P >= big) ? big : small;
-    if (const char* f = getenv("GHM_FORCE_TILE")) {     // test knob: exercise both pixel-tile widths
+    if (const char* f = GHM_OPT("GHM_FORCE_TILE")) {     // test knob: exercise both pixel-tile widths
         if (f[0] == 'b') bn = big;
         if (f[0] == 's') bn = small;
     }
@@ -1648,10 +1648,10 @@ int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
     if (P == 0 || a.R == 0) return 0;
     a.partial = nullptr;
     a.slabs_per_split = 1 << 30;
-    if (const char* f = getenv("GHM_ABLATE")) a.debug = atoi(f);
+    if (const char* f = GHM_OPT("GHM_ABLATE")) a.debug = atoi(f);
     if (a.R <= 4) {
         a.slabs_per_split = a.CH;
-        if (P <= 65536 && a.CH >= 64 && getenv("GHM_NO_SMALLR_SPLIT") == nullptr) {
+        if (P <= 65536 && a.CH >= 64 && GHM_OPT("GHM_NO_SMALLR_SPLIT") == nullptr) {
             // few output pixels, long channel reduction: slices of >= 8 channels until ~4 blocks per CU are in flight
             int S = (4 * ctx->num_cu + ceil_div(P, 256) - 1) / ceil_div(P, 256);
             if (S > a.CH / 8) S = a.CH / 8;
@@ -1687,7 +1687,7 @@ int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
         const int max_by_work = nslabs / 8 > 0 ? nslabs / 8 : 1;     // keep >= 8 slabs (128 k) per slice
         if (splits > max_by_work) splits = max_by_work;
     }
-    if (const char* f = getenv("GHM_FORCE_SPLITK")) splits = atoi(f) < nslabs ? atoi(f) : nslabs;
+    if (const char* f = GHM_OPT("GHM_FORCE_SPLITK")) splits = atoi(f) < nslabs ? atoi(f) : nslabs;
     if (splits > 1) {
         a.slabs_per_split = ceil_div(nslabs, splits);
         splits = ceil_div(nslabs, a.slabs_per_split);
@@ -1741,14 +1741,14 @@ int launch_igemm_x4(ghm_ctx* ctx, IgemmArgs4& a4) {
             const int max_by_work = nslabs / 8 > 0 ? nslabs / 8 : 1;
             if (splits > max_by_work) splits = max_by_work;
         }
-        if (const char* f = getenv("GHM_FORCE_SPLITK")) splits = atoi(f) < nslabs ? atoi(f) : nslabs;
+        if (const char* f = GHM_OPT("GHM_FORCE_SPLITK")) splits = atoi(f) < nslabs ? atoi(f) : nslabs;
         if (splits < 1) splits = 1;
         a.slabs_per_split = ceil_div(nslabs, splits);
         splits = ceil_div(nslabs, a.slabs_per_split);
         a4.nsplit[c] = splits;
         if (splits > smax) smax = splits;
         total += (size_t)splits * a.R * P;
-        if (const char* f = getenv("GHM_ABLATE")) a.debug = atoi(f);
+        if (const char* f = GHM_OPT("GHM_ABLATE")) a.debug = atoi(f);
     }
     void* ws = nullptr;
     if (int e = ghm_scratch(ctx, total * sizeof(float), &ws)) return e;
@@ -1783,7 +1783,7 @@ int launch_igemm_x4(ghm_ctx* ctx, IgemmArgs4& a4) {
 // does this geometry take the taps-as-rows path?  (stride 1, 'same'-style geometry, many pixels)
 bool taps_as_rows(const ghm_conv_desc* d, int small_side) {
     return small_side <= 4 && d->stride == 1 && d->Ho == d->H && d->Wo == d->W && d->kh * d->kw > 1 &&
-           (long)d->N * d->H * d->W >= 32768 && getenv("GHM_NO_TAPROWS") == nullptr;
+           (long)d->N * d->H * d->W >= 32768 && GHM_OPT("GHM_NO_TAPROWS") == nullptr;
 }
 
 void fill_taps(const ghm_conv_desc* d, ShiftArgs& sa) {
@@ -1818,11 +1818,11 @@ PatchPlan plan_patch(int N, int CH, int H, int W, int R, int ks, int num_cu, int
     // H, W: OUTPUT grid
     PatchPlan p;
     p.ok = false;
-    if (!(ks == 3 || ks == 5) || getenv("GHM_NO_PATCH")) return p;
-    if (st == 2 && (ks != 3 || getenv("GHM_NO_PATCH_S2"))) return p;
+    if (!(ks == 3 || ks == 5) || GHM_OPT("GHM_NO_PATCH")) return p;
+    if (st == 2 && (ks != 3 || GHM_OPT("GHM_NO_PATCH_S2"))) return p;
     // 64 rows x (8 x 32) pixels: 34 KB of LDS -> 4 blocks/CU; measured 3-5 % faster than 128 x (4 x 32) at 2 blocks/CU
     p.bm = 64;
-    if (const char* f = getenv("GHM_PATCH_BM")) p.bm = atoi(f);
+    if (const char* f = GHM_OPT("GHM_PATCH_BM")) p.bm = atoi(f);
     p.rt = p.bm == 128 ? 4 : 8;
     const int cb = ks == 5 ? 2 : 4;
     if (R < 32 || (R & 3) || (W % 32) || (H % p.rt) || (CH % cb) || CH < 2 * cb) return p;
@@ -1838,7 +1838,7 @@ PatchPlan plan_patch(int N, int CH, int H, int W, int R, int ks, int num_cu, int
     // one block per CU -0.4 %).  The same reservation on wgrad_patch_kernel, dgrad_s2_patch_kernel and the low-precision
     // kernels measured -0.5 to -8 %: only this kernel has the slack.  GHM_PATCH_LDS_MIN overrides (tuning).
     size_t lds_min = 54 * 1024;
-    if (const char* f = getenv("GHM_PATCH_LDS_MIN")) lds_min = (size_t)atol(f);
+    if (const char* f = GHM_OPT("GHM_PATCH_LDS_MIN")) lds_min = (size_t)atol(f);
     if (p.lds < lds_min) p.lds = lds_min;
     const int ntr = (R + p.bm - 1) / p.bm;
     p.grid = ntr * (W / 32) * (H / p.rt) * N;
@@ -1915,7 +1915,7 @@ struct WVariant {
 bool wgrad_patch_ok(const ghm_conv_desc* d) {
     const bool k_ok = (d->kh == 3 && d->kw == 3) || (d->kh == 5 && d->kw == 5 && d->stride == 1);
     return k_ok && d->Wo % 16 == 0 && d->C * d->kh * d->kw >= 96 && d->K > 4 && d->pad <= d->kh &&
-           d->y_nstride % 4 == 0 && (d->Ho * d->Wo) % 4 == 0 && getenv("GHM_NO_PATCH") == nullptr;
+           d->y_nstride % 4 == 0 && (d->Ho * d->Wo) % 4 == 0 && GHM_OPT("GHM_NO_PATCH") == nullptr;
 }
 
 WVariant pick_wgrad(const ghm_conv_desc* d, int num_cu) {
@@ -1931,14 +1931,14 @@ WVariant pick_wgrad(const ghm_conv_desc* d, int num_cu) {
     const long P = (long)d->N * d->Ho * d->Wo;
     // 32-pixel slabs only for 5x5 (alone: 121 vs 117 TFLOP/s).  3x3 is as fast with 16-pixel slabs (116 vs 115) and then
     // needs 28 KB of LDS and 111-121 VGPRs instead of 45-56 KB and 136-156: more room for the co-running streams (+0.4 % step)
-    v.bkp = (v.patch && d->Wo % 32 == 0 && d->kh == 5 && getenv("GHM_WGRAD_BKP16") == nullptr) ? 32 : 16;
-    if (v.patch && d->Wo % 32 == 0 && getenv("GHM_WGRAD_BKP32")) v.bkp = 32;
+    v.bkp = (v.patch && d->Wo % 32 == 0 && d->kh == 5 && GHM_OPT("GHM_WGRAD_BKP16") == nullptr) ? 32 : 16;
+    if (v.patch && d->Wo % 32 == 0 && GHM_OPT("GHM_WGRAD_BKP32")) v.bkp = 32;
     const long slabs = (P + v.bkp - 1) / v.bkp;
     // one FULL round of resident blocks (a second, partly filled round costs up to 2x): blocks/CU is 3 for the
     // 128-filter tile, 4 otherwise
     const long slots = (long)num_cu * (v.bn >= 128 ? 3 : 4);
     long want = slots / tiles;
-    if (const char* f = getenv("GHM_WGRAD_SPLITS")) want = atol(f);
+    if (const char* f = GHM_OPT("GHM_WGRAD_SPLITS")) want = atol(f);
     long max_by_work = slabs / (256 / v.bkp) > 0 ? slabs / (256 / v.bkp) : 1;   // at least 256 pixels per split
     long S = want < max_by_work ? want : max_by_work;
     if (S < 1) S = 1;
@@ -2007,7 +2007,7 @@ int ghm_conv2d_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const f
             pa.in_nstride = d->x_nstride;
             pa.R = d->K; pa.out_nstride = d->y_nstride; pa.pad = d->pad;
             pa.act = act; pa.alpha = alpha; pa.accumulate = accumulate;
-            if (const char* f = getenv("GHM_ABLATE")) pa.debug = atoi(f);
+            if (const char* f = GHM_OPT("GHM_ABLATE")) pa.debug = atoi(f);
             return launch_patch(ctx, pl, pa, d->kh, d->stride);
         }
     }
@@ -2035,7 +2035,7 @@ struct DactArg {
 };
 
 static bool smallk_dgrad_ok(const ghm_conv_desc* d) {
-    return d->K <= 4 && d->C > 4 && getenv("GHM_NO_SMALLK_DGRAD") == nullptr &&
+    return d->K <= 4 && d->C > 4 && GHM_OPT("GHM_NO_SMALLK_DGRAD") == nullptr &&
            !(d->K <= 4 && thin_fanout_dgrad_ok(d, GHM_ACT_LINEAR)) && !thin_fanin_s2_ok(d, nullptr);
 }
 
@@ -2058,7 +2058,7 @@ static int launch_smallk_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float
 
 static bool pool_geom_ok(const ghm_conv_desc* d, int act) {
     return (act == GHM_ACT_LINEAR || act == GHM_ACT_RELU || act == GHM_ACT_LRELU) && d->stride == 1 && d->kh == d->kw &&
-           d->Ho == d->H && d->Wo == d->W && d->H % 2 == 0 && d->W % 4 == 0 && getenv("GHM_NO_POOL_FUSE") == nullptr;
+           d->Ho == d->H && d->Wo == d->W && d->H % 2 == 0 && d->W % 4 == 0 && GHM_OPT("GHM_NO_POOL_FUSE") == nullptr;
 }
 
 static bool patch_pool_ok(const ghm_conv_desc* d, int num_cu) {
@@ -2070,7 +2070,7 @@ int ghm_conv2d_pool_supported(const ghm_conv_desc* d, int32_t act, int32_t dtype
     if (!pool_geom_ok(d, act)) return 0;
     if (d->C <= 4) return thin_fanout_fwd_pool_ok(d, act) ? 1 : 0;
     if (dtype != GHM_DTYPE_F32 && lp_conv_pool_supported(d, act, dtype)) return 2;
-    return patch_pool_ok(d, 256) ? 1 : 0;
+    return patch_pool_ok(d, ghm_plan_cus()) ? 1 : 0;
 }
 
 int ghm_conv2d_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* w, const float* bias,
@@ -2160,7 +2160,7 @@ int ghm_conv2d_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, cons
         }
     }
     // stride 2 on an even grid: the four classes share R and the sub-grid -> ONE launch + ONE epilogue for all of them
-    if (ncls == 4 && d->H % 2 == 0 && d->W % 2 == 0 && d->C > 4 && getenv("GHM_NO_DGRAD_X4") == nullptr)
+    if (ncls == 4 && d->H % 2 == 0 && d->W % 2 == 0 && d->C > 4 && GHM_OPT("GHM_NO_DGRAD_X4") == nullptr)
         return launch_igemm_x4(ctx, a4);
     for (int c = 0; c < ncls; ++c)
         if (int e = launch_igemm<true>(ctx, a4.c[c])) return e;
@@ -2180,7 +2180,7 @@ int ghm_dgrad_t_supported(const ghm_conv_desc* d) {
     if (d->stride == 1) return 1;
     return d->stride == 2 && d->kh == 3 && d->kw == 3 && d->pad == 1 && d->H == 2 * d->Ho && d->W == 2 * d->Wo &&
            d->Wo % 32 == 0 && d->Ho % 2 == 0 && d->K % 4 == 0 && d->K >= 8 && d->C % 4 == 0 && d->C >= 32 &&
-           getenv("GHM_NO_PATCH_S2") == nullptr;
+           GHM_OPT("GHM_NO_PATCH_S2") == nullptr;
 }
 
 int ghm_conv2d_transpose_weights(ghm_ctx* ctx, const ghm_conv_desc* d, const float* wp, float* wpT) {
@@ -2214,7 +2214,7 @@ static DgradS2Plan dgrad_s2_plan(const ghm_conv_desc* d, int num_cu) {
     static const int tiles[3][2] = {{128, 2}, {64, 1}, {64, 2}};
     DgradS2Plan p;
     int first = d->C >= 96 ? 0 : 1, forced = -1;
-    if (const char* f = getenv("GHM_DGRAD_S2_TILE")) forced = atoi(f);
+    if (const char* f = GHM_OPT("GHM_DGRAD_S2_TILE")) forced = atoi(f);
     for (int t = first; t < 3; ++t) {
         if (forced >= 0) t = forced > 2 ? 2 : forced;
         p.bm = tiles[t][0]; p.wm = tiles[t][1]; p.rt = 4 / p.wm;
@@ -2229,7 +2229,7 @@ static DgradS2Plan dgrad_s2_plan(const ghm_conv_desc* d, int num_cu) {
         const int maxs = nslabs / 4 > 0 ? nslabs / 4 : 1;
         if (p.splits > maxs) p.splits = maxs;
     }
-    if (const char* f = getenv("GHM_DGRAD_S2_SPLITS")) p.splits = atoi(f) < 1 ? 1 : atoi(f);
+    if (const char* f = GHM_OPT("GHM_DGRAD_S2_SPLITS")) p.splits = atoi(f) < 1 ? 1 : atoi(f);
     p.slabs_per_split = (nslabs + p.splits - 1) / p.splits;
     p.splits = (nslabs + p.slabs_per_split - 1) / p.slabs_per_split;
     return p;
@@ -2329,10 +2329,10 @@ int ghm_conv2d_dgrad_t(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, co
 }
 
 int ghm_dgrad_dact_supported(const ghm_conv_desc* d, int32_t dtype) {
-    if (getenv("GHM_NO_DACT_FUSE")) return 0;
+    if (GHM_OPT("GHM_NO_DACT_FUSE")) return 0;
     if (smallk_dgrad_ok(d)) return 1;                                           // fp32 packed wp
     if (dtype != GHM_DTYPE_F32 && lp_dgrad_s2_single_pass(d, dtype)) return 3;   // low-precision transposed pack
-    if (d->stride == 2 && ghm_dgrad_t_supported(d) && dgrad_s2_splits(d, 256) == 1) return 2;     // fp32 wpT
+    if (d->stride == 2 && ghm_dgrad_t_supported(d) && dgrad_s2_splits(d, ghm_plan_cus()) == 1) return 2;     // fp32 wpT
     return 0;
 }
 
@@ -2353,7 +2353,7 @@ int ghm_conv2d_dgrad_dact(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy,
 
 int ghm_conv2d_wgrad_workspace(const ghm_conv_desc* d, size_t* bytes) {
     // upper bound independent of the CU count (splits <= 1024)
-    const WVariant v = pick_wgrad(d, 256);
+    const WVariant v = pick_wgrad(d, ghm_plan_cus());
     const size_t n = (size_t)d->C * d->kh * d->kw * d->K;
     *bytes = (v.splits > 1 ? (size_t)v.splits * n * sizeof(float) : 16);
     return 0;
@@ -2361,7 +2361,7 @@ int ghm_conv2d_wgrad_workspace(const ghm_conv_desc* d, size_t* bytes) {
 
 static int wgrad_impl(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* dy, float* dwp,
                       void* workspace, int32_t accumulate) {
-    const WVariant v = pick_wgrad(d, 256);
+    const WVariant v = pick_wgrad(d, ghm_plan_cus());
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.dy = dy;
@@ -2371,7 +2371,7 @@ static int wgrad_impl(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, cons
     a.CT = d->C * d->kh * d->kw;
     a.P = d->N * d->Ho * d->Wo;
     a.slabs_per_split = v.slabs_per_split;
-    if (const char* f = getenv("GHM_ABLATE")) a.debug = atoi(f);
+    if (const char* f = GHM_OPT("GHM_ABLATE")) a.debug = atoi(f);
     const long n = (long)a.CT * a.K;
     if (v.splits > 1) {
         GHM_CHECK(workspace != nullptr, "wgrad needs a workspace for %d splits", v.splits);
@@ -2495,7 +2495,7 @@ int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t 
         snprintf(out, out_len, "fanin_s2_kernel<%d>", d->kh);
         return 0;
     }
-    if (kind == 1 && d->K <= 4 && d->C > 4 && getenv("GHM_NO_SMALLK_DGRAD") == nullptr) {
+    if (kind == 1 && d->K <= 4 && d->C > 4 && GHM_OPT("GHM_NO_SMALLK_DGRAD") == nullptr) {
         snprintf(out, out_len, "smallk_dgrad_kernel");
         return 0;
     }
@@ -2524,19 +2524,19 @@ int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t 
         }
     }
     if (kind == 3) {      // data gradient through transposed weights
-        const PatchPlan pl = plan_patch(d->N, d->K, d->H, d->W, d->C, d->kh, 256);
+        const PatchPlan pl = plan_patch(d->N, d->K, d->H, d->W, d->C, d->kh, ghm_plan_cus());
         if (d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W && pl.ok)
             snprintf(out, out_len, "conv_patch_kernel<%d, %d, %d, %d, %d, %d, 1> splits=%d", d->kh, pl.bm, pl.rt,
                      pl.bm == 128 ? 2 : 1, pl.bm == 128 ? 2 : 4, d->kh == 5 ? 1 : 2, pl.splits);
         else if (d->stride == 2) {
-            const DgradS2Plan pl = dgrad_s2_plan(d, 256);
+            const DgradS2Plan pl = dgrad_s2_plan(d, ghm_plan_cus());
             snprintf(out, out_len, "dgrad_s2_patch_kernel<%d, %d, 2> splits=%d", pl.bm, pl.wm, pl.splits);
         } else
             snprintf(out, out_len, "igemm_kernel<fwd on wT>");
         return 0;
     }
     if (kind == 2) {
-        const WVariant v = pick_wgrad(d, 256);
+        const WVariant v = pick_wgrad(d, ghm_plan_cus());
         if (v.patch)
             snprintf(out, out_len, "wgrad_patch_kernel<%d, %d, %d, %d, %d, %d> splits=%d", d->kh, d->stride, v.bn,
                      v.bn == 128 ? 2 : 4, v.bn == 128 ? 2 : 1, v.bkp, v.splits);
@@ -2549,7 +2549,7 @@ int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t 
         if (R <= 4) {
             snprintf(out, out_len, "direct_smallr_kernel");
         } else {
-            const Variant v = pick_variant(R, P, 256);
+            const Variant v = pick_variant(R, P, ghm_plan_cus());
             snprintf(out, out_len, "igemm_kernel<%d,%d,%s>", v.bm, v.bn, kind == 0 ? "fwd" : "wt");
         }
     }

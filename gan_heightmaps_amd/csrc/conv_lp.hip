@@ -835,7 +835,7 @@ struct LpPlan {
 LpPlan lp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
     LpPlan p;
     p.ok = false;
-    if (getenv("GHM_NO_LP")) return p;
+    if (GHM_OPT("GHM_NO_LP")) return p;
     if (!((ks == 3 && (st == 1 || st == 2)) || (ks == 5 && st == 1))) return p;
     p.bm = R >= 96 ? 128 : 64;
     // pixel tile: 8 x 32 (stride 2: 4 x 32); narrow maps: 8 x 16 or 8 x 8 (fragments of 2 x 16 / 4 x 8 pixels)
@@ -843,7 +843,7 @@ LpPlan lp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
     p.rt = p.tw == 32 ? (st == 2 ? 4 : 8) : (p.tw == 16 ? 4 : 2);
     const int rows = p.rt * (32 / p.tw);
     if (R < 32 || (W % p.tw) || (H % rows) || (CH % 16) || CH < 16) return p;
-    if (getenv("GHM_LP_NO_NARROW") && p.tw != 32) return p;
+    if (GHM_OPT("GHM_LP_NO_NARROW") && p.tw != 32) return p;
     const int ntr = (R + p.bm - 1) / p.bm;
     p.grid = ntr * (W / p.tw) * (H / rows) * N;
     const int nslabs = CH / 16;
@@ -853,7 +853,7 @@ LpPlan lp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
         const int maxs = nslabs / 2 > 0 ? nslabs / 2 : 1;
         if (p.splits > maxs) p.splits = maxs;
     }
-    if (const char* f = getenv("GHM_LP_SPLITS")) p.splits = atoi(f) < nslabs ? (atoi(f) > 0 ? atoi(f) : 1) : nslabs;
+    if (const char* f = GHM_OPT("GHM_LP_SPLITS")) p.splits = atoi(f) < nslabs ? (atoi(f) > 0 ? atoi(f) : 1) : nslabs;
     p.slabs_per_split = (nslabs + p.splits - 1) / p.splits;
     p.splits = (nslabs + p.slabs_per_split - 1) / p.slabs_per_split;
     p.ok = true;
@@ -907,14 +907,14 @@ int lp_launch_conv(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a, int ks, int st)
 LpPlan lp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu) {
     LpPlan p;
     p.ok = false;
-    if (getenv("GHM_NO_LP") || getenv("GHM_NO_LP_DGRAD_S2")) return p;
+    if (GHM_OPT("GHM_NO_LP") || GHM_OPT("GHM_NO_LP_DGRAD_S2")) return p;
     if (!(d->stride == 2 && d->kh == 3 && d->kw == 3 && d->pad == 1 && d->H == 2 * d->Ho && d->W == 2 * d->Wo)) return p;
     if (d->Wo % 32 || d->K % 16 || d->K < 16 || d->C < 32 || (d->x_nstride & 1) || ((d->H * d->W) & 1)) return p;
     // the split-K form writes and re-reads `splits` partial dx tensors -- more HBM traffic than the operands of these
     // layers: a small grid first shrinks the tile (128 ch x 2 class rows -> 64 x 4 -> 64 x 2), then splits
     static const int tiles[3][2] = {{128, 2}, {64, 4}, {64, 2}};
     int forced = -1;
-    if (const char* f = getenv("GHM_LP_DGRAD_S2_TILE")) forced = atoi(f);
+    if (const char* f = GHM_OPT("GHM_LP_DGRAD_S2_TILE")) forced = atoi(f);
     bool found = false;
     for (int t = d->C >= 96 ? 0 : 1; t < 3; ++t) {
         if (forced >= 0) t = forced > 2 ? 2 : forced;
@@ -936,7 +936,7 @@ LpPlan lp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu) {
         const int maxs = nslabs / 2 > 0 ? nslabs / 2 : 1;
         if (p.splits > maxs) p.splits = maxs;
     }
-    if (const char* f = getenv("GHM_LP_DGRAD_S2_SPLITS")) p.splits = atoi(f) < 1 ? 1 : atoi(f);
+    if (const char* f = GHM_OPT("GHM_LP_DGRAD_S2_SPLITS")) p.splits = atoi(f) < 1 ? 1 : atoi(f);
     p.slabs_per_split = (nslabs + p.splits - 1) / p.splits;
     p.splits = (nslabs + p.slabs_per_split - 1) / p.slabs_per_split;
     p.ok = true;
@@ -946,7 +946,7 @@ LpPlan lp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu) {
 template <int DT>
 int lp_launch_dgrad_s2(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a) {
     a.slabs_per_split = pl.slabs_per_split;
-    if (const char* f = getenv("GHM_ABLATE")) a.debug = atoi(f);
+    if (const char* f = GHM_OPT("GHM_ABLATE")) a.debug = atoi(f);
     a.partial = nullptr;
     if (pl.splits > 1) {
         void* ws = nullptr;
@@ -975,7 +975,7 @@ struct LpWPlan {
 LpWPlan lp_wplan(const ghm_conv_desc* d, int num_cu) {
     LpWPlan v;
     v.ok = false;
-    if (getenv("GHM_NO_LP") || getenv("GHM_NO_LP_WGRAD")) return v;
+    if (GHM_OPT("GHM_NO_LP") || GHM_OPT("GHM_NO_LP_WGRAD")) return v;
     const bool k_ok = (d->kh == 3 && d->kw == 3 && (d->stride == 1 || d->stride == 2)) ||
                       (d->kh == 5 && d->kw == 5 && d->stride == 1);
     if (!k_ok || d->pad != d->kh / 2 || d->Wo % 32 || d->W % 4 || d->K < 32 || d->C * d->kh * d->kw < 96) return v;
@@ -983,12 +983,12 @@ LpWPlan lp_wplan(const ghm_conv_desc* d, int num_cu) {
     if (d->Ho != (d->H + d->stride - 1) / d->stride) return v;
     const int T = d->kh * d->kw;
     v.bn = d->K >= 96 ? 128 : 64;
-    v.nseg = (d->Wo % 64 == 0 && getenv("GHM_LP_WGRAD_SEG1") == nullptr) ? 2 : 1;
+    v.nseg = (d->Wo % 64 == 0 && GHM_OPT("GHM_LP_WGRAD_SEG1") == nullptr) ? 2 : 1;
     v.row_tiles = ceil_div(d->C, 128 / T);
     const long tiles = (long)v.row_tiles * ceil_div(d->K, v.bn);
     const long slabs = (long)d->N * d->Ho * (d->Wo / (32 * v.nseg));
     long want = (2L * num_cu) / tiles;
-    if (const char* f = getenv("GHM_LP_WGRAD_SPLITS")) want = atol(f);
+    if (const char* f = GHM_OPT("GHM_LP_WGRAD_SPLITS")) want = atol(f);
     const long max_by_work = slabs / 4 > 0 ? slabs / 4 : 1;         // at least 4 slabs per split
     long S = want < max_by_work ? want : max_by_work;
     if (S < 1) S = 1;
@@ -1052,7 +1052,7 @@ int rpad128(int r) { return (r + 127) / 128 * 128; }
 
 bool lp_dgrad_s2_single_pass(const ghm_conv_desc* d, int dtype) {
     if (dtype != GHM_DTYPE_BF16 && dtype != GHM_DTYPE_F16) return false;
-    const LpPlan pl = lp_plan_dgrad_s2(d, 256);
+    const LpPlan pl = lp_plan_dgrad_s2(d, ghm_plan_cus());
     return pl.ok && pl.splits == 1 && (d->x_nstride & 1) == 0;
 }
 
@@ -1075,8 +1075,8 @@ static bool lp_pool_act_ok(int act) { return act == GHM_ACT_LINEAR || act == GHM
 bool lp_conv_pool_supported(const ghm_conv_desc* d, int act, int dtype) {
     if (dtype != GHM_DTYPE_BF16 && dtype != GHM_DTYPE_F16) return false;
     if (!(lp_pool_act_ok(act) && d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W && d->H % 2 == 0)) return false;
-    const LpPlan pl = lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, 256);
-    return pl.ok && pl.tw == 32 && pl.splits == 1 && getenv("GHM_NO_POOL_FUSE") == nullptr;
+    const LpPlan pl = lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, ghm_plan_cus());
+    return pl.ok && pl.tw == 32 && pl.splits == 1 && GHM_OPT("GHM_NO_POOL_FUSE") == nullptr;
 }
 
 int lp_conv_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* wq, const float* bias, float* pooled,
@@ -1115,13 +1115,13 @@ extern "C" {
 
 int ghm_lp_supported(const ghm_conv_desc* d, int32_t kind, int32_t dtype) {
     if (dtype != GHM_DTYPE_BF16 && dtype != GHM_DTYPE_F16) return 0;
-    if (kind == 0) return lp_fwd_geom(d) && lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, 256).ok;
+    if (kind == 0) return lp_fwd_geom(d) && lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ghm_plan_cus()).ok;
     if (kind == 1) {
-        if (d->stride == 2) return lp_plan_dgrad_s2(d, 256).ok;
+        if (d->stride == 2) return lp_plan_dgrad_s2(d, ghm_plan_cus()).ok;
         return d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W &&
-               lp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, 256).ok;
+               lp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ghm_plan_cus()).ok;
     }
-    if (kind == 2) return lp_wplan(d, 256).ok;
+    if (kind == 2) return lp_wplan(d, ghm_plan_cus()).ok;
     return 0;
 }
 
@@ -1214,7 +1214,7 @@ int ghm_conv2d_dgrad_lp(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, c
 }
 
 int ghm_conv2d_wgrad_lp_workspace(const ghm_conv_desc* d, size_t* bytes) {
-    const LpWPlan v = lp_wplan(d, 256);
+    const LpWPlan v = lp_wplan(d, ghm_plan_cus());
     const size_t n = (size_t)d->C * d->kh * d->kw * d->K;
     *bytes = (v.ok && v.splits > 1) ? (size_t)v.splits * n * sizeof(float) : 16;
     return 0;
@@ -1223,7 +1223,7 @@ int ghm_conv2d_wgrad_lp_workspace(const ghm_conv_desc* d, size_t* bytes) {
 int ghm_conv2d_wgrad_lp(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* dy, float* dwp,
                         void* workspace, int32_t accumulate, int32_t dtype) {
     GHM_CHECK(ghm_lp_supported(d, 2, dtype), "ghm_conv2d_wgrad_lp: geometry / dtype not served (ask ghm_lp_supported)");
-    const LpWPlan v = lp_wplan(d, 256);
+    const LpWPlan v = lp_wplan(d, ghm_plan_cus());
     return dtype == GHM_DTYPE_BF16 ? lp_launch_wgrad<GHM_DTYPE_BF16>(ctx, d, v, x, dy, dwp, workspace, accumulate)
                                    : lp_launch_wgrad<GHM_DTYPE_F16>(ctx, d, v, x, dy, dwp, workspace, accumulate);
 }

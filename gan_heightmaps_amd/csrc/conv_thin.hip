@@ -382,7 +382,7 @@ static int launch_fanout_pool_t(ghm_ctx* ctx, const FanoutArgs& a) {
     return 0;
 }
 
-static bool thin_enabled() { return getenv("GHM_NO_THIN") == nullptr; }
+static bool thin_enabled() { return GHM_OPT("GHM_NO_THIN") == nullptr; }
 static bool fanout_act_ok(int act) { return act == GHM_ACT_LINEAR || act == GHM_ACT_RELU || act == GHM_ACT_LRELU; }
 
 // forward conv with <= 4 input channels
@@ -417,7 +417,7 @@ bool thin_fanout_fwd_pool_ok(const ghm_conv_desc* d, int act) {
     const int q = d->C * d->kh * d->kw;
     const size_t lds = (size_t)(2 * 32 + 4 * 18 + 2 * d->C * (d->kh + 1) * ((((d->Wo - 1) + d->kw) + 63) & ~63)) * sizeof(float);
     return d->C <= 4 && q <= THIN_MAX_Q && d->Wo % 64 == 0 && d->Ho % 2 == 0 && (long)d->N * d->Ho * d->Wo >= 32768 &&
-           (long)d->C * d->H * d->W < (1L << 30) && lds <= 150 * 1024 && getenv("GHM_NO_POOL_FUSE") == nullptr;
+           (long)d->C * d->H * d->W < (1L << 30) && lds <= 150 * 1024 && GHM_OPT("GHM_NO_POOL_FUSE") == nullptr;
 }
 
 int thin_fanout_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,

@@ -13,12 +13,23 @@ void ghm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int g_ghm_opt_epoch = 0;
+static int g_plan_cus = 256;
+int ghm_plan_cus() { return g_plan_cus; }
+
 int ghm_scratch(ghm_ctx* ctx, size_t bytes, void** out) {
     if (bytes > ctx->scratch_bytes) {
         GHM_CHECK(!ctx->capturing, "workspace would grow (%zu -> %zu bytes) inside graph capture: run the program "
                   "eagerly once before capturing", ctx->scratch_bytes, bytes);
         GHM_HIP(hipStreamSynchronize(ctx->stream));
-        if (ctx->scratch) GHM_HIP(hipFree(ctx->scratch));
+        if (ctx->scratch) {
+            if (ctx->pinned > 0) {          // a recorded step or graph replays launches that carry this pointer
+                ctx->retired.push_back(ctx->scratch);
+                ctx->retired_bytes += ctx->scratch_bytes;
+            } else {
+                GHM_HIP(hipFree(ctx->scratch));
+            }
+        }
         const size_t want = bytes + bytes / 4;
         GHM_HIP(hipMalloc(&ctx->scratch, want));
         ctx->scratch_bytes = want;
@@ -30,6 +41,11 @@ int ghm_scratch(ghm_ctx* ctx, size_t bytes, void** out) {
 extern "C" {
 
 const char* ghm_last_error(void) { return g_err; }
+
+int ghm_options_reload(void) {
+    ++g_ghm_opt_epoch;
+    return 0;
+}
 
 int ghm_device_count(int32_t* n) {
     int c = 0;
@@ -50,6 +66,7 @@ int ghm_ctx_create(int32_t device, ghm_ctx** out) {
     hipDeviceProp_t prop;
     GHM_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount;
+    g_plan_cus = c->num_cu;
     GHM_HIP(hipMalloc((void**)&c->zeros, 256));
     GHM_HIP(hipMemset(c->zeros, 0, 256));
     *out = c;
@@ -65,6 +82,7 @@ int ghm_ctx_destroy(ghm_ctx* ctx) {
         if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
     }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (void* p : ctx->retired) (void)hipFree(p);
     if (ctx->zeros) (void)hipFree(ctx->zeros);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -79,6 +97,13 @@ int ghm_device_info(ghm_ctx* ctx, char* name, int32_t name_len, int32_t* num_cu,
     }
     if (num_cu) *num_cu = prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return 0;
+}
+
+int ghm_scratch_info(ghm_ctx* ctx, int64_t* bytes, int64_t* retired_bytes, int32_t* pinned) {
+    if (bytes) *bytes = (int64_t)ctx->scratch_bytes;
+    if (retired_bytes) *retired_bytes = (int64_t)ctx->retired_bytes;
+    if (pinned) *pinned = ctx->pinned;
     return 0;
 }
 
@@ -193,6 +218,7 @@ int ghm_capture_end(ghm_ctx* ctx, ghm_graph** out) {
         ghm_set_error("hipGraphInstantiate -> %s", hipGetErrorString(e));
         return -1;
     }
+    ++ctx->pinned;
     *out = g;
     return 0;
 }
@@ -245,6 +271,7 @@ int ghm_step_record_end(ghm_step* s) {
     for (int i = 0; i < s->n; ++i) {
         s->ctx[i]->rec = nullptr;
         s->ctx[i]->capturing = false;
+        ++s->ctx[i]->pinned;
     }
     s->recording = false;
     s->recorded = true;
@@ -276,6 +303,8 @@ int ghm_step_run(ghm_step* s) {
 
 int ghm_step_destroy(ghm_step* s) {
     if (s && s->recording) ghm_step_record_end(s);
+    if (s && s->recorded)
+        for (int i = 0; i < s->n; ++i) --s->ctx[i]->pinned;
     delete s;          // graphs stay owned by their creator (ghm_graph_destroy)
     return 0;
 }

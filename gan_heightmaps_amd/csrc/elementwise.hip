@@ -576,8 +576,10 @@ __global__ __launch_bounds__(256) void image_batch_kernel(const unsigned char* _
 // losses: single-pass grid-stride with fp64 block partials + one atomic per block
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scalar_loss_kernel(const float* __restrict__ d, long n, float target, int kind,
-                                                          float* __restrict__ grad, float gscale, double* __restrict__ part) {
+                                                          float* __restrict__ grad, float gscale, double* __restrict__ part,
+                                                          const float* __restrict__ ls) {
     double acc = 0.0;
+    if (ls) gscale *= ls[0];            // dynamic loss scale (fp16 products): a device scalar, so replays see it change
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float v = d[i];
         if (kind == 0) {
@@ -603,9 +605,11 @@ __global__ void loss_final_kernel(const double* __restrict__ part, int nblocks, 
 
 __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict__ a, long as, const float* __restrict__ b,
                                                          long bs, View v, int l2, float* __restrict__ grad, long gs,
-                                                         float gscale, int accumulate, double* __restrict__ part) {
+                                                         float gscale, int accumulate, double* __restrict__ part,
+                                                         const float* __restrict__ ls) {
     const long chw = (long)v.C * v.HW, total = (long)v.N * chw;
     double acc = 0.0;
+    if (ls) gscale *= ls[0];
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const long n = e / chw, o = e - n * chw;
         const float dlt = a[n * as + o] - b[n * bs + o];
@@ -633,9 +637,13 @@ __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                       float* __restrict__ acc, long n, const float* __restrict__ hyper,
-                                                      float rho, float eps, float gscale) {
+                                                      float rho, float eps, float gscale, const float* __restrict__ ls) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
+    if (ls) {                           // {scale, 1/scale, good steps, overflow flag}: skip the update of an overflowed step
+        if (ls[3] != 0.f) return;
+        gscale *= ls[1];
+    }
     const float lr = hyper[0];
     if (i + 3 < n) {
         float4 pv = *reinterpret_cast<float4*>(p + i);
@@ -664,9 +672,13 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, con
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, const float* __restrict__ hyper, float b1,
-                                                   float b2, float eps, float gscale) {
+                                                   float b2, float eps, float gscale, const float* __restrict__ ls) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (ls) {
+        if (ls[3] != 0.f) return;
+        gscale *= ls[1];
+    }
     const float lr = hyper[0], t = hyper[1] + 1.f;     // t_prev + 1
     const float a_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
     const float gg = g[i] * gscale;
@@ -677,7 +689,46 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     p[i] -= a_t * mn / (sqrtf(vn) + eps);
 }
 
-__global__ void adam_tick_kernel(float* hyper) { hyper[1] += 1.f; }
+__global__ void adam_tick_kernel(float* hyper, const float* ls) {
+    if (ls && ls[3] != 0.f) return;
+    hyper[1] += 1.f;
+}
+
+// any non-finite value in g[0, n) raises the overflow flag of the loss-scale state (ls[3]); benign race: every writer
+// stores the same value
+__global__ __launch_bounds__(256) void grad_check_kernel(const float* __restrict__ g, long n, float* __restrict__ ls) {
+    bool bad = false;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        // exponent all ones <=> inf or nan
+        bad |= ((__float_as_uint(v.x) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(v.y) & 0x7f800000u) == 0x7f800000u) |
+               ((__float_as_uint(v.z) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(v.w) & 0x7f800000u) == 0x7f800000u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= (__float_as_uint(g[(n4 << 2) + threadIdx.x]) & 0x7f800000u) == 0x7f800000u;
+    if (__any(bad) && (threadIdx.x & 63) == 0) ls[3] = 1.f;
+}
+
+// end of a step: overflow -> halve the scale (not below ``lo``), restart the count; otherwise count the step and double
+// the scale after ``interval`` clean steps (not above ``hi``); the flag is cleared for the next step
+__global__ void loss_scale_update_kernel(float* ls, float interval, float lo, float hi) {
+    float s = ls[0], good = ls[2];
+    if (ls[3] != 0.f) {
+        s = fmaxf(s * 0.5f, lo);
+        good = 0.f;
+        ls[4] += 1.f;                    // skipped steps so far (reporting)
+    } else {
+        good += 1.f;
+        if (good >= interval) {
+            s = fminf(s * 2.f, hi);
+            good = 0.f;
+        }
+    }
+    ls[0] = s;
+    ls[1] = 1.f / s;
+    ls[2] = good;
+    ls[3] = 0.f;
+}
 
 template <typename... Args>
 inline bool vec_ok(int HW, Args... strides_or_ptr_ok) {
@@ -997,7 +1048,7 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const float* __restri
     }
 }
 
-static bool bn_small(long count) { return count <= BN_SMALL_MAX && getenv("GHM_NO_BN_SMALL") == nullptr; }
+static bool bn_small(long count) { return count <= BN_SMALL_MAX && GHM_OPT("GHM_NO_BN_SMALL") == nullptr; }
 
 extern "C" {
 
@@ -1343,7 +1394,7 @@ static int scalar_loss(ghm_ctx* ctx, const float* d, int64_t n, float target, in
     void* ws = nullptr;
     if (int e = ghm_scratch(ctx, (size_t)g * sizeof(double), &ws)) return e;
     hipLaunchKernelGGL(scalar_loss_kernel, dim3(g), dim3(256), 0, ctx->stream, d, (long)n, target, kind, grad, grad_scale,
-                       (double*)ws);
+                       (double*)ws, (const float*)ctx->ls_state);
     GHM_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1), 0, ctx->stream, (const double*)ws, g, loss_out,
                        accumulate_loss);
@@ -1368,7 +1419,7 @@ int ghm_recon_loss(ghm_ctx* ctx, const float* a, int64_t as, const float* b, int
     void* ws = nullptr;
     if (int e = ghm_scratch(ctx, (size_t)g * sizeof(double), &ws)) return e;
     hipLaunchKernelGGL(recon_loss_kernel, dim3(g), dim3(256), 0, ctx->stream, a, (long)as, b, (long)bs, v, l2, grad, (long)gs,
-                       grad_scale, accumulate_grad, (double*)ws);
+                       grad_scale, accumulate_grad, (double*)ws, (const float*)ctx->ls_state);
     GHM_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1), 0, ctx->stream, (const double*)ws, g, loss_out, 0);
     GHM_LAUNCH_CHECK();
@@ -1387,7 +1438,8 @@ int ghm_image_batch(ghm_ctx* ctx, const uint8_t* src_nhwc, int32_t N, int32_t H,
 int ghm_rmsprop(ghm_ctx* ctx, float* p, const float* g, float* acc, int64_t n, const float* hyper, float rho, float eps,
                 float grad_scale) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(rmsprop_kernel, EW_GRID((n + 3) / 4), p, g, acc, (long)n, hyper, rho, eps, grad_scale);
+    hipLaunchKernelGGL(rmsprop_kernel, EW_GRID((n + 3) / 4), p, g, acc, (long)n, hyper, rho, eps, grad_scale,
+                       (const float*)ctx->ls_state);
     GHM_LAUNCH_CHECK();
     return 0;
 }
@@ -1395,13 +1447,38 @@ int ghm_rmsprop(ghm_ctx* ctx, float* p, const float* g, float* acc, int64_t n, c
 int ghm_adam(ghm_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float b1, float b2,
              float eps, float grad_scale) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(adam_kernel, EW_GRID(n), p, g, m, v, (long)n, hyper, b1, b2, eps, grad_scale);
+    hipLaunchKernelGGL(adam_kernel, EW_GRID(n), p, g, m, v, (long)n, hyper, b1, b2, eps, grad_scale,
+                       (const float*)ctx->ls_state);
     GHM_LAUNCH_CHECK();
     return 0;
 }
 
 int ghm_adam_tick(ghm_ctx* ctx, float* hyper) {
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, ctx->stream, hyper);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, ctx->stream, hyper, (const float*)ctx->ls_state);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_set_loss_scale_state(ghm_ctx* ctx, float* state) {
+    ctx->ls_state = state;
+    return 0;
+}
+
+int ghm_grad_check(ghm_ctx* ctx, const float* g, int64_t n) {
+    GHM_CHECK(ctx->ls_state, "ghm_grad_check: no loss-scale state on this context (ghm_set_loss_scale_state)");
+    GHM_CHECK(((uintptr_t)g & 15) == 0, "ghm_grad_check: gradient buffer must be 16-byte aligned");
+    if (n == 0) return 0;
+    const long n4 = (n + 3) / 4;
+    const int grid = (int)(n4 < 256L * 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(grad_check_kernel, dim3(grid), dim3(256), 0, ctx->stream, g, (long)n, ctx->ls_state);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_loss_scale_update(ghm_ctx* ctx, int32_t growth_interval, float min_scale, float max_scale) {
+    GHM_CHECK(ctx->ls_state, "ghm_loss_scale_update: no loss-scale state on this context");
+    hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->ls_state, (float)growth_interval,
+                       min_scale, max_scale);
     GHM_LAUNCH_CHECK();
     return 0;
 }

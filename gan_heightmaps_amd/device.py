@@ -139,6 +139,16 @@ class Device:
     def sync(self):
         call("ghm_sync", self.h)
 
+    def scratch_info(self):
+        """(bytes of the library workspace, bytes of retired blocks, recorded steps / graphs pinning them)"""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int32()
+        call("ghm_scratch_info", self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def set_loss_scale_state(self, state):
+        """attach (DevTensor of 8 floats) / detach (None) the dynamic loss-scale state of this context"""
+        call("ghm_set_loss_scale_state", self.h, _vp(state))
+
     def wait_for(self, other):
         """later work on this context's stream waits for everything already enqueued on ``other``'s stream"""
         call("ghm_stream_wait", self.h, other.h)
@@ -530,6 +540,12 @@ class Ops:
 
     def adam_tick(self, hyper):
         call("ghm_adam_tick", self.h, _vp(hyper))
+
+    def grad_check(self, g, n):
+        call("ghm_grad_check", self.h, _vp(g), int(n))
+
+    def loss_scale_update(self, growth_interval=2000, min_scale=1.0, max_scale=2.0 ** 24):
+        call("ghm_loss_scale_update", self.h, int(growth_interval), float(min_scale), float(max_scale))
 
     def allreduce_sum(self, buf, n):
         call("ghm_allreduce_sum", self.h, _vp(buf), int(n))

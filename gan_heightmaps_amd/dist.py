@@ -19,10 +19,6 @@ def env_rank_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-_T_IMPORT = time.time()
-STALE_SLACK_S = 60.0     # ranks of one launch start within this many seconds of each other
-
-
 def rendezvous_path():
     """GHM_RDZV_FILE if set; else a file keyed on what every worker of ONE job shares under any launcher:
     MASTER_ADDR, MASTER_PORT (unique per job on a node), WORLD_SIZE and the launcher's run id.  Under
@@ -38,32 +34,79 @@ def rendezvous_path():
     return os.path.join(base, "ghm_rdzv_%s.uid" % tag)
 
 
+def _write_atomic(path, data):
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as f:
+        f.write(data)
+    os.replace(tmp, path)
+
+
+def _read(path):
+    try:
+        with open(path, "rb") as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+NONCE = 16
+
+
 def exchange_unique_id(rank, world, make_id, path=None, timeout=300.0):
-    """rank 0: make_id() -> 128 bytes, published through ``path``; other ranks: wait for it.  A file left behind
-    by a crashed earlier job with the same key is recognised by its age (older than this process by more than
-    STALE_SLACK_S) and ignored until rank 0 replaces it."""
+    """rank 0: make_id() -> 128 bytes, published through ``path``; other ranks: wait for it.
+
+    No clocks are compared: a file left behind by a crashed earlier job with the same key cannot be taken for this
+    launch's, whenever the ranks start relative to each other.  Every other rank r announces itself with a random
+    nonce in ``path.h<r>`` (and re-creates that file should rank 0's start-up sweep remove it); rank 0 first sweeps
+    everything under the key, then publishes {unique id, the nonces it has seen} and republishes when an
+    announcement changes; rank r accepts only a publication that carries ITS nonce and acknowledges it in
+    ``path.a<r>``; rank 0 returns once every acknowledgement matches what it published."""
     path = path or rendezvous_path()
+    t0 = time.time()
+
+    def expired(what):
+        if time.time() - t0 > timeout:
+            raise TimeoutError("rank %d: %s at %s after %.0fs" % (rank, what, path, timeout))
+
     if rank == 0:
+        for stale in [path] + ["%s.%s%d" % (path, k, r) for k in "ha" for r in range(1, world)]:
+            try:
+                os.remove(stale)
+            except OSError:
+                pass
         uid = bytes(make_id())
         assert len(uid) == 128
-        tmp = path + ".tmp%d" % os.getpid()
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)
-        return uid
-    t0 = time.time()
+        published = None
+        while True:
+            nonces = [_read("%s.h%d" % (path, r)) for r in range(1, world)]
+            if all(n is not None and len(n) == NONCE for n in nonces):
+                if nonces != published:
+                    _write_atomic(path, uid + b"".join(nonces))
+                    published = nonces
+                if all(_read("%s.a%d" % (path, r)) == published[r - 1] for r in range(1, world)):
+                    return uid
+            expired("ranks missing at the rendezvous")
+            time.sleep(0.005)
+    nonce = os.urandom(NONCE)
+    hello = "%s.h%d" % (path, rank)
     while True:
+        if _read(hello) != nonce:
+            _write_atomic(hello, nonce)
+        pub = _read(path)
+        if pub is not None and len(pub) == 128 + NONCE * (world - 1) and \
+                pub[128 + NONCE * (rank - 1):128 + NONCE * rank] == nonce:
+            _write_atomic("%s.a%d" % (path, rank), nonce)
+            return pub[:128]
+        expired("no ncclUniqueId for this launch")
+        time.sleep(0.005)
+
+
+def cleanup_rendezvous(path, world):
+    for f in [path] + ["%s.%s%d" % (path, k, r) for k in "ha" for r in range(1, world)]:
         try:
-            fresh = os.path.getmtime(path) >= _T_IMPORT - STALE_SLACK_S
-            with open(path, "rb") as f:
-                uid = f.read()
-            if fresh and len(uid) == 128:
-                return uid
-        except FileNotFoundError:
+            os.remove(f)
+        except OSError:
             pass
-        if time.time() - t0 > timeout:
-            raise TimeoutError("rank %d: no ncclUniqueId at %s after %.0fs" % (rank, path, timeout))
-        time.sleep(0.01)
 
 
 def shard_batch(arrays, rank, world):
@@ -96,10 +139,7 @@ class Comm:
         self._scratch = dev.zeros((1, 8, 1, 1))
         self.barrier()
         if rank == 0:
-            try:
-                os.remove(self._path)
-            except OSError:
-                pass
+            cleanup_rendezvous(self._path, world)
 
     def barrier(self):
         call("ghm_allreduce_sum", self.dev.h, C.c_void_p(self._scratch.ptr), 1)

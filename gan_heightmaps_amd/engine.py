@@ -683,6 +683,8 @@ class NetPlan:
         expands = []
         key = (tag, n0, n1)
         cache = self._scratch.setdefault(key, {})
+        for n in self.order:                # flags of an earlier emit of the same (tag, slice): every emit decides afresh
+            n.aux.pop(('grad_is_pre', key), None)
 
         def grad_of(n):
             """gradient buffer w.r.t. n.out (allocated once per (tag, slice))."""

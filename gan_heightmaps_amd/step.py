@@ -57,9 +57,16 @@ class GanStep:
         # 'f16' = BASELINE configs 4 / 5 (matrix-core operands rounded, fp32 accumulation, fp32 tensors and optimiser)
         self.dtype = dtype
         # fp16 operands underflow below 6e-8 and the per-pixel gradients of the 512x512 layers sit around 1e-6..1e-9:
-        # the loss-gradient seeds are scaled by 2^15 (the largest seed, 2(d-t)/B, stays below 2) and the optimiser divides it out again (every gradient kernel is
-        # linear in its seed; gradients in HBM are fp32, so the scale costs nothing).  bf16 has fp32's range: scale 1.
-        self.loss_scale = 32768.0 if dtype == 'f16' else 1.0
+        # the loss-gradient seeds are scaled (initially by 2^15) and the optimiser divides the scale out again (every
+        # gradient kernel is linear in its seed; gradients in HBM are fp32, so the scale costs nothing).  The DCGAN
+        # discriminator's output is linear and unbounded, so a fixed scale can push a gradient operand beyond the fp16
+        # range (65504 -> inf -> nan in the fp32 sums): the scale is DYNAMIC, per stage (the two stages are independent
+        # loss graphs) and entirely device state -- ghm_grad_check flags a non-finite gradient bucket, the optimiser
+        # kernels skip the update of a flagged step, ghm_loss_scale_update halves / regrows the scale (include/ghm.h) --
+        # so a recorded / captured step adapts without a host round trip.  bf16 has fp32's range: no scale.
+        self.init_loss_scale = 32768.0 if dtype == 'f16' else 1.0
+        self.ls_growth_interval, self.ls_min, self.ls_max = 2000, 1.0, 2.0 ** 24
+        self._ls_state = []                 # [(Device, DevTensor of 8 floats)] one per stage stream
         # how a step is issued: False = eager (one C call per kernel), True = one captured HIP graph per stage stream,
         # 'recorded' = the eager multi-stream launch sequence recorded once in the library and replayed by ONE
         # ghm_step_run call per step (side streams, communication stream and collectives included)
@@ -72,6 +79,11 @@ class GanStep:
         mkops = getattr(dev, 'ops_class', Ops)
         self.devs = [dev, mk(dev.index) if two_streams else dev]
         self.ops = [mkops(self.devs[0]), mkops(self.devs[1])]
+        if dtype == 'f16':
+            for d in ([self.devs[0]] if self.devs[1] is self.devs[0] else self.devs):
+                t = d.tensor(np.array([self.init_loss_scale, 1.0 / self.init_loss_scale, 0, 0, 0, 0, 0, 0], np.float32))
+                d.set_loss_scale_state(t)
+                self._ls_state.append((d, t))
         # optional GRADIENT stream for the weight / bias gradients of both stages (engine.NetPlan side=).  ONE stream for
         # the two stages, not one each: three MFMA-heavy kernels at a time (stage A, stage B, one weight gradient) is what
         # the chip runs best -- with a gradient stream per stage the two weight-gradient kernels share CUs with each other
@@ -125,6 +137,30 @@ class GanStep:
         self.losses_dev = dev.zeros((1, 8, 1, 1))
         self._built = {}
         self._infer = {}
+
+    def loss_scale_state(self):
+        """[{scale, clean_steps, skipped_steps}] per stage stream (fp16 mode; [] otherwise).  Synchronises."""
+        self.sync()
+        out = []
+        for _, t in self._ls_state:
+            v = t.numpy().ravel()
+            out.append({'scale': float(v[0]), 'clean_steps': int(v[2]), 'skipped_steps': int(v[4])})
+        return out
+
+    def set_loss_scale(self, scale):
+        self.sync()
+        for d, t in self._ls_state:
+            v = t.numpy().ravel()
+            v[0], v[1], v[2], v[3] = scale, 1.0 / scale, 0, 0
+            t.set(v)
+
+    @property
+    def loss_scale(self):
+        """the scale the gradient buffers currently carry (stage A's; the stages only differ after an overflow)"""
+        if not self._ls_state:
+            return 1.0
+        self.sync()
+        return float(self._ls_state[0][1].numpy().ravel()[0])
 
     def sync(self):
         self.devs[0].sync()
@@ -227,7 +263,7 @@ class GanStep:
         b.seed_D, b.seed_G = dA.empty(d_out.shape), dA.empty(d_fake.shape)
         b.seed_PD, b.seed_PG = dB.empty(p_out.shape), dB.empty(p_fake.shape)
 
-        LS = self.loss_scale
+        LS = 1.0            # the fp16 loss scale is device state read by the loss kernels (ghm_set_loss_scale_state)
 
         def losses_a(prog, g):
             # (:107) gen_loss_dcgan, (:108) disc_loss_dcgan
@@ -339,12 +375,20 @@ class GanStep:
                 if dB is not dA:
                     dB.wait_for(cdev)
             b.exchange.append(("wait_comm", rejoin, None, cdev))
-        gs = 1.0 / (self.world * self.loss_scale)
+        gs = 1.0 / self.world          # (x 1 / loss scale inside the optimiser kernels, from the device state)
         hp = self.opt_spec.hp
         b.update = [[], []]
+        # one stream for both stages: one update list, so the fp16 sequence check* -> update* -> scale update is kept
+        ulane = (lambda k: 0) if (self._ls_state and self.devs[1] is self.devs[0]) else (lambda k: LANE_OF[k])
+        if self._ls_state:
+            # fp16: every gradient bucket of the stage is checked (after its all-reduce: all ranks see the same sum, so
+            # they skip or apply together) before the first update of the stage reads the flag
+            for k in keys:
+                st, lane = self.stores[k], ulane(k)
+                b.update[lane].append(("grad_check_" + k, lambda st=st, o=self.ops[lane]: o.grad_check(st.g, st.n_train)))
         for k in keys:
             st, hy = self.stores[k], self.hyper[k]
-            lane = LANE_OF[k]
+            lane = ulane(k)
             o = self.ops[lane]
             if self.opt_spec.kind == 'rmsprop':
                 b.update[lane].append(("rmsprop_" + k, lambda st=st, hy=hy, o=o: o.rmsprop(
@@ -354,6 +398,11 @@ class GanStep:
                     st.w, st.g, st.opt_state['m'], st.opt_state['v'], st.n_train, hy, hp['beta1'], hp['beta2'],
                     hp['epsilon'], gs)))
                 b.update[lane].append(("adam_tick_" + k, lambda hy=hy, o=o: o.adam_tick(hy)))
+        if self._ls_state:
+            for lane in (0, 1):
+                if b.update[lane]:
+                    b.update[lane].append(("loss_scale_update", lambda o=self.ops[lane]: o.loss_scale_update(
+                        self.ls_growth_interval, self.ls_min, self.ls_max)))
         b.graphs = {}
         b.calls = {}
         return b

@@ -5,6 +5,8 @@
   * one FULL-SIZE joint train step of test1_nobn_bilin_both at batch 2 against the numpy oracle (the oracle
     needs ~30-60 s for it on the GPU box's host cores),
   * determinism and batching properties of the full-size batch-4 step."""
+import zlib
+
 import numpy as np
 import pytest
 
@@ -57,7 +59,7 @@ def test_sampled_parity_at_full_size(gpu, case, dtype):
         if not all(served):
             assert not any(served)
             pytest.skip("%s is a thin layer: fp32 kernels in every arithmetic mode" % case[0])
-    rng = np.random.RandomState(abs(hash(case[0])) % 2**31)
+    rng = np.random.RandomState(zlib.crc32(case[0].encode()) & 0x7fffffff)     # stable across processes (str hashes are salted)
     x = rng.randn(N, C, H, W).astype(np.float32)
     Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
     b = rng.randn(K).astype(np.float32)
@@ -229,6 +231,90 @@ def test_full_size_batch4_step_against_the_float64_fixture(gpu):
     del model
 
 
+# Bounds of the reduced-precision full-size step against the float64 fixture (rel-L2; "cos" = cosine of the sampled
+# gradient elements to the exact ones).  ~2x what the MI355X measures (the test prints the measured values): operand
+# rounding is 2^-9 (bf16) / 2^-12 (fp16) per product, accumulated over 9..25 x C products in fp32; the generators' deep
+# batch-4 BatchNorm chains amplify it exactly as they amplify fp32 rounding (the fixture's own fp32-vs-fp64 spread is
+# 1.2e-3 / 4.3e-4 there against 1e-7 per operation).
+LP_FULL_TOL = {'bf16': dict(loss=2e-2, out=3e-2, disc=8e-2, disc_cos=0.995, gen=0.8, gen_cos=0.75, after=2e-4),
+               'f16': dict(loss=3e-3, out=5e-3, disc=1e-2, disc_cos=0.9999, gen=0.15, gen_cos=0.99, after=2e-4)}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_full_size_batch4_step_reduced_precision(gpu, dtype):
+    """BASELINE config 4 (bf16) / the 512x512 half of config 5 (fp16) IN THEIR OWN ARITHMETIC at the reference's batch
+    size (experiments.py:98-125): one joint train step of the four full-size test1_nobn_bilin_both networks with every
+    served convolution on the bf16 / fp16 matrix cores, against the committed float64 fixture
+    (tests/golden/reference_step_fullsize_b4.npz; no oracle runs on the GPU box).  Checked: the five losses, G(z) and
+    U(X) on the lattice + window samples, the discriminators' gradients (sampled elements and per-tensor norms), the
+    generators' gradients through their cosine to the exact gradient, the post-step parameter norms, and that the
+    low-precision kernels really are in the program."""
+    import os
+    dev, ops, D = gpu
+    from gan_heightmaps_amd.experiments import make_model
+    from gan_heightmaps_amd import layers as L
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_step_fullsize_b4.npz"))
+    seed, batch, dseed, stride, win = (int(v) for v in fix["meta"])
+    cfg = ostep.default_cfg()
+    model = make_model('test1_nobn_bilin_both', device=dev, seed=seed, verbose=False, use_graph=False, dtype=dtype)
+    eng = model.engine
+    b = eng.built(batch)
+    lp_flops = all_flops = 0.0
+    for lane in b.train_compute:
+        for e in lane:
+            if len(e) > 2 and e[2] is not None:
+                all_flops += e[2]["flops"]
+                if e[2].get("dtype") == dtype:
+                    lp_flops += e[2]["flops"]
+    assert lp_flops > 0.9 * all_flops, (lp_flops, all_flops)          # the step really runs on the low-precision kernels
+    Z, X, Y = ostep.synthetic_batch(batch, cfg, seed=dseed)
+    got = model.train_fn(Z, X, Y)
+    tol = LP_FULL_TOL[dtype]
+    m = dict(loss=rel(got, fix["losses64"]), out=0.0)
+    for key, t in (("gz", b.G.out), ("ux", b.U.out)):
+        a = t.numpy().astype(np.float64)
+        lat = a[:, :, ::stride, ::stride]
+        w = np.stack([a[n, :, 37 * (n + 1):37 * (n + 1) + win, 53 * (n + 1):53 * (n + 1) + win] for n in range(batch)])
+        m['out'] = max(m['out'], rel(lat, fix[key + "_sample64"]), rel(w, fix[key + "_window64"]))
+
+    def summary(v):
+        v64 = np.asarray(v, np.float64).ravel()
+        idx = np.linspace(0, v64.size - 1, 8).astype(np.int64)
+        return np.concatenate([[v64.sum(), np.sqrt((v64 * v64).sum())], v64[idx]])
+
+    m.update(disc=0.0, disc_cos=1.0, gen=0.0, gen_cos=1.0, after=0.0)
+    for a_, b_, k in [('dcgan', 'gen', 'dcgan_gen'), ('dcgan', 'disc', 'dcgan_disc'), ('p2p', 'gen', 'p2p_gen'),
+                      ('p2p', 'disc', 'p2p_disc')]:
+        st = eng.stores[k]
+        params = L.get_all_params(getattr(model, a_)[b_], trainable=True)
+        keys = sorted(q for q in fix.files if q.startswith("grad/%s/" % k))
+        assert len(keys) == len(params)
+        mine = [summary(st.download_grad(p)) / eng.loss_scale for p in params]
+        ref = [fix[q] for q in keys]
+        live = [i for i, r in enumerate(ref) if r[1] > 1e-12]
+        el_m = np.concatenate([mine[i][2:] for i in live])
+        el_r = np.concatenate([ref[i][2:] for i in live])
+        nm_m = np.array([mine[i][1] for i in live])
+        nm_r = np.array([ref[i][1] for i in live])
+        assert np.all(np.isfinite(el_m)) and np.all(np.isfinite(nm_m)), k
+        which = 'disc' if b_ == 'disc' else 'gen'
+        m[which] = max(m[which], rel(el_m, el_r), rel(nm_m, nm_r))
+        m[which + '_cos'] = min(m[which + '_cos'], float(el_m @ el_r / (np.linalg.norm(el_m) * np.linalg.norm(el_r))))
+        after = [summary(v) for v in L.get_all_param_values(getattr(model, a_)[b_])]
+        akeys = sorted(q for q in fix.files if q.startswith("after/%s/" % k))
+        n_mine, n_ref = np.array([v[1] for v in after]), np.array([fix[q][1] for q in akeys])
+        m['after'] = max(m['after'], float(np.max(np.abs(n_mine - n_ref) / (n_ref + 3e-2))))
+    print("full-size batch-4 step in %s vs float64 fixture: " % dtype + ", ".join("%s %.3g" % kv for kv in sorted(m.items())))
+    for key, v in m.items():
+        if key.endswith('_cos'):
+            assert v > tol[key], (key, v, m)
+        else:
+            assert v < tol[key], (key, v, m)
+    # master weights, gradients and optimiser state stay fp32; fp16 carries the loss scale
+    assert eng.loss_scale == (32768.0 if dtype == 'f16' else 1.0)
+    del model
+
+
 def test_full_size_batch4_step_properties(gpu):
     dev, ops, D = gpu
     from gan_heightmaps_amd.experiments import make_model
@@ -334,23 +420,58 @@ def test_every_reference_experiment_steps_at_full_size(gpu, name):
     del model
 
 
-def test_config5_geometry_1024(gpu):
-    """BASELINE config 5 geometry (beyond the reference: p2p.py:137 asserts 512): 1024x1024 crops need one more U-Net
-    level and one more DCGAN stage; the same architecture functions build it and the engine steps it (fp32 here;
-    throughput-only, there is no parity target for this size)"""
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_config5_geometry_1024(gpu, dtype):
+    """BASELINE config 5 (beyond the reference: p2p.py:137 asserts 512): 1024x1024 crops need one more U-Net level and
+    one more DCGAN stage; the same architecture functions build it and the engine steps it at the config's per-GPU
+    batch (16 images on 8 GPUs = 2).  ``f16`` = the config's own arithmetic (fp16 matrix-core products, fp32
+    accumulation, loss scale).  There is no parity target for this size, so the checks are the size-independent
+    properties: the low-precision kernels carry the step, finite losses, output ranges of sigmoid / tanh, the update
+    moves the losses, an fp16 step stays close to the fp32 step of the same parameters, and two runs from the same
+    seed are bit-identical."""
     dev, ops, D = gpu
     from gan_heightmaps_amd import experiments as E
     from gan_heightmaps_amd.pix2pix import Pix2Pix
-    kw = E.experiment_kwargs('test1_nobn_bilin_both')
-    kw.update(in_shp=1024, device=dev, seed=0, verbose=False)
-    kw['gen_params_dcgan'] = {'num_repeats': 0, 'div': [2, 2, 4, 4, 8, 8, 8, 8], 'final_size': 1024}
-    kw['disc_params_dcgan'] = dict(kw['disc_params_dcgan'], div=[8, 8, 4, 4, 4, 2, 2, 2], nch=1024)
-    model = Pix2Pix(**kw)
+
+    def make(dt):
+        kw = E.experiment_kwargs('test1_nobn_bilin_both')
+        kw.update(in_shp=1024, device=dev, seed=0, verbose=False, dtype=dt)
+        kw['gen_params_dcgan'] = {'num_repeats': 0, 'div': [2, 2, 4, 4, 8, 8, 8, 8], 'final_size': 1024}
+        kw['disc_params_dcgan'] = dict(kw['disc_params_dcgan'], div=[8, 8, 4, 4, 4, 2, 2, 2], nch=1024)
+        return Pix2Pix(**kw)
+
     rng = np.random.RandomState(0)
     Z = rng.rand(2, 1000).astype(np.float32)
     X = rng.rand(2, 1, 1024, 1024).astype(np.float32)
     Y = (rng.rand(2, 3, 1024, 1024) * 2 - 1).astype(np.float32)
-    losses = model.train_fn(Z, X, Y)
-    assert len(losses) == 5 and np.isfinite(losses).all()
-    assert model.gen_fn_det(X).shape == (2, 3, 1024, 1024) and model.z_fn_det(Z).shape == (2, 1, 1024, 1024)
-    del model
+    runs = []
+    for rep in range(2 if dtype != 'f32' else 1):
+        model = make(dtype)
+        if dtype != 'f32' and rep == 0:
+            b = model.engine.built(2)
+            lp = sum(e[2]["flops"] for lane in b.train_compute for e in lane
+                     if len(e) > 2 and e[2] is not None and e[2].get("dtype") == dtype)
+            tot = sum(e[2]["flops"] for lane in b.train_compute for e in lane if len(e) > 2 and e[2] is not None)
+            assert lp > 0.9 * tot, (lp, tot)
+            assert model.engine.loss_scale == 32768.0
+        l0 = model.loss_fn(Z, X, Y)
+        l1 = model.train_fn(Z, X, Y)
+        l2 = model.train_fn(Z, X, Y)
+        l3 = model.train_fn(Z, X, Y)
+        runs.append(np.array([l0, l1, l2, l3], np.float64))
+        assert np.isfinite(runs[-1]).all(), runs[-1]
+        if rep == 0:
+            assert rel(l0, l1) < 1e-6                       # loss_fn and train_fn see the same pre-update losses
+            assert not np.allclose(l1, l2)                  # the update happened
+            assert l3[3] < l1[3]                            # the L1 reconstruction term goes down on a repeated batch
+            g, z = model.gen_fn_det(X), model.z_fn_det(Z)
+            assert g.shape == (2, 3, 1024, 1024) and z.shape == (2, 1, 1024, 1024)
+            assert np.isfinite(g).all() and np.isfinite(z).all() and np.abs(g).max() <= 1.0 and 0.0 <= z.min() <= z.max() <= 1.0
+        del model
+    if dtype != 'f32':
+        assert np.array_equal(runs[0], runs[1])              # bit-repeatable
+        ref = make('f32')
+        r1 = np.asarray(ref.train_fn(Z, X, Y), np.float64)
+        print("config 5 (1024^2, batch 2) %s vs fp32 losses of the first step: rel-L2 %.3g" % (dtype, rel(runs[0][1], r1)))
+        assert rel(runs[0][1], r1) < 5e-3, (runs[0][1], r1)
+        del ref

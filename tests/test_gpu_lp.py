@@ -13,6 +13,8 @@ import os
 import numpy as np
 import pytest
 
+from gan_heightmaps_amd._lib import tuning_env
+
 from oracle import lp as LP
 from oracle import ops as O
 
@@ -170,26 +172,18 @@ def test_lp_strided_views_and_forced_splits(gpu):
     ops.lp_pack_weights(d, wp, wq, 'bf16', False)
     y_lp = LP.conv2d_fwd(x, Wt, b, s, pad, 'bf16')
     for env in ({}, {"GHM_LP_SPLITS": "4"}):
-        os.environ.update(env)
-        try:
+        with tuning_env(**env):
             dev.memset_zero(wide_y.ptr, 4 * wide_y.size)
             ops.conv2d_fwd_lp(d, xv, wq, dev.tensor(b), yv, 'bf16')
-        finally:
-            for key in env:
-                os.environ.pop(key)
         full = wide_y.numpy()
         assert rel(full[:, 32:], y_lp) < EXACT and not full[:, :32].any()
     yv.set(dy)
     dW_lp = LP.conv2d_vjp(x, Wt, dy, s, pad, 'bf16')[1]
     for env in ({"GHM_LP_WGRAD_SPLITS": "1"}, {"GHM_LP_WGRAD_SPLITS": "7"}, {"GHM_LP_WGRAD_SEG1": "1"}):
-        os.environ.update(env)
-        try:
+        with tuning_env(**env):
             ws = dev.alloc(max(ops.wgrad_lp_workspace(d), 16))
             dwd = dev.zeros((1, C * k * k * K, 1, 1))
             ops.conv2d_wgrad_lp(d, xv, yv, dwd, ws, 'bf16')
-        finally:
-            for key in env:
-                os.environ.pop(key)
         assert rel(D.unpack_conv_w(dwd.numpy().ravel(), K, C, k, k), dW_lp) < EXACT, env
 
 
@@ -278,3 +272,76 @@ def test_reduced_precision_train_step(gpu, dtype):
     assert worst['gen'] < tol['gen'] and worst['cos'] > tol['cos'], worst
     # master weights stay fp32
     assert all(v.dtype == np.float32 for vals in model_params(model).values() for v in vals)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_reduced_precision_training_follows_the_fp32_trajectory(gpu, dtype):
+    """Evidence that a reduced-precision run TRAINS (the single-step gradient bounds above are loose for the deep
+    BatchNorm generators): 40 consecutive joint train steps at 128x128 from identical parameters on identical batches,
+    once with fp32 products and once with bf16 / fp16 products.  The five loss curves must stay inside a band around
+    the fp32 curves at every step, agree in their last-10-step means, and the reconstruction loss -- the term that
+    dominates the U-Net's objective (alpha = 100) -- must fall by the same amount in both runs."""
+    from oracle import step as ostep
+    from tests.test_gpu_step import build_model
+    dev, ops, D = gpu
+    cfg = ostep.default_cfg(**LP_STEP)
+    steps = 40
+    curves = {}
+    for dt in ('f32', dtype):
+        model = build_model(cfg, 7, dev, dtype=dt)
+        out = []
+        for it in range(steps):
+            Z, X, Y = ostep.synthetic_batch(4, cfg, seed=500 + it % 4)       # four batches, revisited: losses can fall
+            out.append(model.train_fn(Z, X, Y))
+        curves[dt] = np.asarray(out, np.float64)
+        assert np.isfinite(curves[dt]).all()
+        del model
+    a, b = curves['f32'], curves[dtype]
+    per_step = max(rel(b[i], a[i]) for i in range(steps))
+    tail = rel(b[-10:].mean(axis=0), a[-10:].mean(axis=0))
+    drop_a, drop_b = a[:4, 3].mean() - a[-4:, 3].mean(), b[:4, 3].mean() - b[-4:, 3].mean()
+    print("trajectory %s vs f32 over %d steps: worst per-step rel-L2 of the loss vector %.3g, last-10 means %.3g, "
+          "recon drop %.4f vs %.4f" % (dtype, steps, per_step, tail, drop_b, drop_a))
+    band = {'bf16': (5e-2, 2e-2), 'f16': (1e-2, 5e-3)}[dtype]
+    assert per_step < band[0] and tail < band[1], (per_step, tail)
+    assert drop_a > 0 and abs(drop_b - drop_a) < 0.1 * drop_a, (drop_a, drop_b)
+
+
+def test_fp16_overflow_skips_the_update_and_lowers_the_scale(gpu):
+    """Dynamic loss scaling (include/ghm.h ghm_set_loss_scale_state): a loss scale that pushes gradient operands beyond
+    the fp16 range (inf after v_cvt_pk_f16_f32 -> inf / nan in the fp32 sums) must not reach the master weights or the
+    RMSprop state: the step is skipped on the device (no host round trip: the recorded step replays unchanged), the
+    scale is halved, and training resumes by itself once the scale fits."""
+    from oracle import step as ostep
+    from tests.test_gpu_step import build_model, model_params, model_grads
+    dev, ops, D = gpu
+    cfg = ostep.default_cfg(**LP_STEP)
+    model = build_model(cfg, 7, dev, dtype='f16', use_graph='recorded')
+    eng = model.engine
+    assert [s['scale'] for s in eng.loss_scale_state()] == [32768.0, 32768.0]
+    Z, X, Y = ostep.synthetic_batch(4, cfg, seed=900)
+    for _ in range(3):                                   # eager, record, replay: a healthy scale
+        assert np.isfinite(model.train_fn(Z, X, Y)).all()
+    st = eng.loss_scale_state()
+    assert all(s['skipped_steps'] == 0 and s['clean_steps'] == 3 and s['scale'] == 32768.0 for s in st), st
+    p0 = model_params(model)
+    acc0 = {k: s.opt_state['acc'].numpy().copy() for k, s in eng.stores.items()}
+    eng.set_loss_scale(2.0 ** 40)                        # seeds ~1e12: every low-precision data gradient overflows
+    losses = model.train_fn(Z, X, Y)
+    assert np.isfinite(losses).all()                     # the losses themselves are not scaled
+    assert not all(np.isfinite(g).all() for gs in model_grads(model).values() for g in gs)      # the overflow is real
+    st = eng.loss_scale_state()
+    assert all(s['skipped_steps'] == 1 and s['scale'] == 2.0 ** 39 and s['clean_steps'] == 0 for s in st), st
+    p1 = model_params(model)
+    for k in p0:
+        for u, v in zip(p0[k], p1[k]):
+            assert np.array_equal(u, v)                  # nothing moved
+    for k, s in eng.stores.items():
+        assert np.array_equal(acc0[k], s.opt_state['acc'].numpy())
+    for _ in range(40):                                  # the scale walks down until the step fits, then training resumes
+        assert np.isfinite(model.train_fn(Z, X, Y)).all()
+    st = eng.loss_scale_state()
+    assert all(s['clean_steps'] > 0 and 2.0 ** 10 <= s['scale'] < 2.0 ** 39 for s in st), st
+    p2 = model_params(model)
+    assert all(np.isfinite(v).all() for vals in p2.values() for v in vals)
+    assert any(not np.array_equal(u, v) for k in p0 for u, v in zip(p0[k], p2[k]))

@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 
+from gan_heightmaps_amd._lib import tuning_env
+
 from oracle import lp as LP
 from oracle import ops as O
 
@@ -63,11 +65,8 @@ CONV_CASES = [
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("tile", ["big", "small"])
 def test_conv_fwd_dgrad_wgrad(gpu, case, tile):
-    os.environ["GHM_FORCE_TILE"] = tile
-    try:
+    with tuning_env(GHM_FORCE_TILE=tile):
         _check_conv(gpu, case)
-    finally:
-        os.environ.pop("GHM_FORCE_TILE")
 
 
 # first / last layers at full resolution: <= 4 channels on one side, large maps (conv_thin.hip)
@@ -107,12 +106,9 @@ def test_thin_layer_kernels(gpu, case, variants):
     dx1, dx2 = dev.empty((N, C, H, W)), dev.empty((N, C, H, W))
     ops.conv2d_fwd(d, x, w, b, y1, act='tanh')
     ops.conv2d_dgrad(d, dy, w, dx1)
-    os.environ["GHM_NO_THIN"] = "1"
-    try:
+    with tuning_env(GHM_NO_THIN="1"):
         ops.conv2d_fwd(d, x, w, b, y2, act='tanh')
         ops.conv2d_dgrad(d, dy, w, dx2)
-    finally:
-        os.environ.pop("GHM_NO_THIN")
     assert rel(y1.numpy(), y2.numpy()) < 1e-5 and rel(dx1.numpy(), dx2.numpy()) < 1e-5
 
 
@@ -243,12 +239,8 @@ def test_conv_on_channel_slice_views(gpu):
 @pytest.mark.parametrize("act,alpha", [('lrelu', 0.2), ('linear', 0.0)])
 @pytest.mark.parametrize("path", ["auto", "big"])
 def test_batchnorm_fwd_bwd(gpu, shape, act, alpha, path):
-    if path == "big":
-        os.environ["GHM_NO_BN_SMALL"] = "1"
-    try:
+    with tuning_env(**({"GHM_NO_BN_SMALL": "1"} if path == "big" else {})):
         _check_batchnorm(gpu, shape, act, alpha)
-    finally:
-        os.environ.pop("GHM_NO_BN_SMALL", None)
 
 
 def _check_batchnorm(gpu, shape, act, alpha):
@@ -464,15 +456,12 @@ def test_conv_split_k(gpu, case, splits):
     d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
     xd, wd, bd = dev.tensor(x), dev.tensor(D.pack_conv_w(Wt).reshape(1, -1, 1, 1)), dev.tensor(b)
     yd, dyd, dxd = dev.empty(y_ref.shape), dev.tensor(dy), dev.zeros(x.shape)
-    os.environ["GHM_FORCE_SPLITK"] = splits
-    try:
+    with tuning_env(GHM_FORCE_SPLITK=splits):
         ops.conv2d_fwd(d, xd, wd, bd, yd, act='lrelu', alpha=0.01)
         assert rel(yd.numpy(), O.lrelu_fwd(y_ref, 0.01)) < TOL
         ops.conv2d_dgrad(d, dyd, wd, dxd)
         ops.conv2d_dgrad(d, dyd, wd, dxd, accumulate=True)
         assert rel(dxd.numpy(), 2 * dx_ref) < TOL
-    finally:
-        os.environ.pop("GHM_FORCE_SPLITK")
 
 
 @pytest.mark.parametrize("case", [(2, 16, 128, 128, 1, 5, 1, 2), (1, 8, 192, 192, 3, 3, 1, 1)])
@@ -795,8 +784,7 @@ def test_stride2_data_gradient_every_tile_and_split(gpu, case, tile, splits, dty
            "GHM_LP_DGRAD_S2_SPLITS" if lp else "GHM_DGRAD_S2_SPLITS": splits}
     if lp and (d.Ho % (2 if tile == "0" else (4 if tile == "1" else 2))):
         pytest.skip("class rows not a multiple of this tile: the plan never picks it")
-    os.environ.update(env)
-    try:
+    with tuning_env(**env):
         if lp:
             if not ops.lp_supported(d, 1, dtype):
                 pytest.skip("geometry not served at reduced precision")
@@ -816,9 +804,6 @@ def test_stride2_data_gradient_every_tile_and_split(gpu, case, tile, splits, dty
             assert rel(dxd.numpy(), dx_ref) < TOL
             ops.conv2d_dgrad_t(d, dyd, wtd, dxd, accumulate=True)
             assert rel(dxd.numpy(), 2 * dx_ref) < TOL
-    finally:
-        for key in env:
-            os.environ.pop(key)
 
 
 @pytest.mark.parametrize("splits", ["1", "3", "7", "50"])
@@ -835,8 +820,7 @@ def test_weight_gradient_split_ranges_cross_strips_and_images(gpu, case, splits)
     d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
     dy = rng.randn(N, K, d.Ho, d.Wo).astype(np.float32)
     _, dW_ref, _ = O.conv2d_vjp(x.astype(np.float64), np.zeros((K, C, k, k)), dy.astype(np.float64), s, pad)
-    os.environ["GHM_WGRAD_SPLITS"] = splits
-    try:
+    with tuning_env(GHM_WGRAD_SPLITS=splits):
         assert ops.conv_variant(d, 2).startswith("wgrad_patch_kernel"), ops.conv_variant(d, 2)
         xd, dyd = dev.tensor(x), dev.tensor(dy)
         dwd = dev.zeros((1, C * k * k * K, 1, 1))
@@ -845,5 +829,3 @@ def test_weight_gradient_split_ranges_cross_strips_and_images(gpu, case, splits)
         assert rel(D.unpack_conv_w(dwd.numpy().ravel(), K, C, k, k), dW_ref) < TOL
         ops.conv2d_wgrad(d, xd, dyd, dwd, ws, accumulate=True)
         assert rel(D.unpack_conv_w(dwd.numpy().ravel(), K, C, k, k), 2 * dW_ref) < TOL
-    finally:
-        os.environ.pop("GHM_WGRAD_SPLITS")

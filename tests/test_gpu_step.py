@@ -368,6 +368,49 @@ def test_recorded_step_is_the_eager_schedule_in_one_call(dev, variant):
             cdev.close()
 
 
+def test_recorded_step_survives_workspace_growth(dev):
+    """A recorded step replays launches that carry the context's library workspace (split-K partials, reduction
+    partials) BY VALUE.  A later eager call on the same context that needs more workspace must not free that block:
+    it is retired (kept until the context dies, ghm_scratch_info) and replays stay bit-identical to eager issue."""
+    from gan_heightmaps_amd import device
+    cfg = ostep.default_cfg(**SMALL)
+    eager = build_model(cfg, 11, dev, use_graph=False)
+    rec = build_model(cfg, 11, dev, use_graph='recorded')
+    for it in range(3):                             # call 0 eager, call 1 records + replays, call 2 replays
+        Z, X, Y = ostep.synthetic_batch(4, cfg, seed=60 + it)
+        assert eager.train_fn(Z, X, Y) == rec.train_fn(Z, X, Y), it
+    devs = rec.engine._all_devs()
+    before = [d.scratch_info() for d in devs]
+    assert all(pinned >= 1 for _, _, pinned in before)               # the recorded step pins every context it spans
+    assert any(size > 0 for size, _, _ in before)                    # ... and some of its kernels do use the workspace
+    # forward-only calls at a larger batch and a deep split-K convolution issued eagerly on the SAME contexts
+    rec.z_fn(np.random.RandomState(0).rand(32, cfg['latent_dim']).astype(np.float32))
+    rec.gen_fn(np.random.RandomState(1).rand(32, 1, cfg['in_shp'], cfg['in_shp']).astype(np.float32))
+    d = device.conv_desc(1, 2048, 16, 16, 512, 3, 3, 1, 1)
+    for dv in devs:
+        ops = device.Ops(dv)
+        x, w = dv.zeros((1, 2048, 16, 16)), dv.zeros((1, 2048 * 9 * 512, 1, 1))
+        y, ws = dv.empty((1, 512, 16, 16)), dv.alloc(ops.wgrad_workspace(d))
+        ops.conv2d_fwd(d, x, w, None, y)
+        ops.conv2d_wgrad(d, x, y, w, ws)
+        dv.sync()
+        for t in (x, w, y):
+            dv.free(t.ptr)
+        dv.free(ws)
+    after = [d.scratch_info() for d in devs]
+    grown = [a[0] > b_[0] for a, b_ in zip(after, before)]
+    assert any(grown), (before, after)                               # otherwise this test checks nothing
+    for (size, retired, pinned), (size0, _, _), g in zip(after, before, grown):
+        assert retired == (size0 if g else 0)                        # the outgrown block is kept, not freed
+    for it in range(3, 6):
+        Z, X, Y = ostep.synthetic_batch(4, cfg, seed=60 + it)
+        assert eager.train_fn(Z, X, Y) == rec.train_fn(Z, X, Y), it
+    pa, pb = model_params(eager), model_params(rec)
+    for k in pa:
+        for u, v in zip(pa[k], pb[k]):
+            assert np.array_equal(u, v)
+
+
 def test_dropout_generators_in_the_full_step(dev):
     """g_unet(dropout=True) + default_generator(dropout_p) inside Pix2Pix: train_fn / loss_fn run, the
     non-deterministic generator functions draw a fresh mask per call, the deterministic ones are repeatable

@@ -216,10 +216,15 @@ def test_reduced_precision_lowering_on_fake_device():
         e[1]()
     calls = [o.calls for o in eng.ops]
     flat = [c for cs in calls for c in cs]
+    # the loss scale is DEVICE state attached to the stage's context (dynamic: ghm_set_loss_scale_state); the host-side
+    # factors stay 1, every gradient bucket is checked before the first update and the scale is updated after the last
+    assert dev.ls_state is not None and eng.loss_scale_state()[0]['scale'] == 32768.0
     seeds = [c for c in flat if c[0] in ('lsgan_loss',) and c[1][3] is not None]
-    assert seeds and all(c[1][4] == 32768.0 for c in seeds)
+    assert seeds and all(c[1][4] == 1.0 for c in seeds)
     rms = [c for c in flat if c[0] == 'rmsprop']
-    assert len(rms) == 4 and all(abs(c[1][-1] - 1.0 / 32768.0) < 1e-12 for c in rms)
+    assert len(rms) == 4 and all(c[1][-1] == 1.0 for c in rms)
+    names = [c[0] for c in flat if c[0] in ('grad_check', 'rmsprop', 'loss_scale_update')]
+    assert names == ['grad_check'] * 4 + ['rmsprop'] * 4 + ['loss_scale_update'], names
     # the same nets in fp32: no low-precision call at all
     eng32 = GanStep(PolicyDevice(), G, Dn, U, P, 100, True, 'l1', spec, 'both', use_graph=False, two_streams=False)
     p32 = eng32.built(4)
@@ -299,8 +304,16 @@ def _rdzv_worker(rank, path, q):
     q.put((rank, uid))
 
 
-def test_unique_id_rendezvous_two_processes(tmp_path):
+@pytest.mark.parametrize("leftovers", [False, True])
+def test_unique_id_rendezvous_two_processes(tmp_path, leftovers):
+    """leftovers: a crashed earlier job with the same key left a FRESH publication, announcement and acknowledgement
+    behind (the case a modification-time test cannot tell from this launch's files): they must not be accepted"""
     path = str(tmp_path / "uid")
+    if leftovers:
+        stale = bytes(16)
+        for name, data in ((path, b"\xee" * 128 + stale), (path + ".h1", stale), (path + ".a1", stale)):
+            with open(name, "wb") as f:
+                f.write(data)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     ps = [ctx.Process(target=_rdzv_worker, args=(r, path, q)) for r in (1, 0)]
