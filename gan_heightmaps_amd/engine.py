@@ -660,10 +660,12 @@ class NetPlan:
 
     # ---- backward --------------------------------------------------------------------------------
     def emit_backward(self, prog, seed, nslice=None, wgrad=True, input_grads=(), accumulate_wgrad=False, tag="bwd",
-                      transposed=None):
+                      transposed=None, on_grads=None):
         """Append the backward program.  ``seed``: DevTensor holding dLoss/d(output) (it may be modified in
         place).  ``nslice=(n0, n1)``: run on that sample range of the saved activations.  ``input_grads``:
-        InputLayers whose gradient is wanted.  Returns {InputLayer: DevTensor grad}."""
+        InputLayers whose gradient is wanted.  Returns {InputLayer: DevTensor grad}.
+        ``on_grads(prog, params)``: called (with wgrad) right after the last launch that writes the gradients of
+        ``params`` has been appended -- the data-parallel exchange hangs its sub-bucket all-reduces there (step.py)."""
         ops, st, dev = self.ops, self.store, self.dev
         n0, n1 = nslice if nslice is not None else (0, self.batch)
         nb = n1 - n0
@@ -680,7 +682,7 @@ class NetPlan:
             has_p = wgrad and n.op in ('conv', 'convpool', 'deconv', 'dense', 'bn', 'upconv')
             req[id(n)] = has_p or any(req[id(i)] for i in n.inputs) or id(n) in want_in
         grads, written = {}, set()
-        expands = []
+        expands, expand_params = [], []
         key = (tag, n0, n1)
         cache = self._scratch.setdefault(key, {})
         for n in self.order:                # flags of an earlier emit of the same (tag, slice): every emit decides afresh
@@ -722,6 +724,10 @@ class NetPlan:
         grads[id(self.out_node)] = seed
         written.add(id(self.out_node))
         mark_written(self.out_node)
+
+        def done(*params):
+            if on_grads is not None and wgrad:
+                on_grads(prog, [p for p in params if p is not None])
 
         for n in reversed(self.order):
             if id(n) not in written or not req[id(n)]:
@@ -788,6 +794,7 @@ class NetPlan:
                     bn_fed = len(n.consumers) == 1 and n.consumers[0].op == 'bn' and n.act == linear
                     if not bn_fed and n.op != 'convpool':       # convpool: summed by the mask backward pass above
                         prog.append(("bias_grad", lambda G=G, gb=gb, aw=aw, wo=wo: wo.channel_sum(G, gb, aw), None, wdev))
+                    done(l.W, l.b)
                 if need_dx:
                     gi, acc = target(xin)
                     # the producer's own nonlinearity (a conv -> LeakyRectify -> conv chain without BatchNorm: the
@@ -867,6 +874,8 @@ class NetPlan:
                     bn_fed = len(n.consumers) == 1 and n.consumers[0].op == 'bn' and n.act == linear
                     if not bn_fed:
                         prog.append(("bias_grad", lambda G=G, gb=gb, aw=aw, wo=wo: wo.channel_sum(G, gb, aw), None, wdev))
+                    done(l.b)                              # l.W: written by the batched 3x3 -> 5x5 expansion below
+                    expand_params.append(l.W)
                 if need_dx:
                     gi, acc = target(xin)
                     if self._lp(d, 1):
@@ -931,6 +940,7 @@ class NetPlan:
                                  ops.bn_backward(G, y, x, dst, m, iv, gam, dg, db, self.bn_ws, a.kind, a.alpha, aw)))
                 if acc:
                     prog.append(("bn_bwd_acc", lambda dst=dst, gi=gi: ops.copy_view(dst, gi, True)))
+                done(l.gamma, l.beta)
                 mark_written(xin)
             elif n.op == 'act':
                 if need_dx:
@@ -984,6 +994,7 @@ class NetPlan:
                 tab = self._scratch['tables'][tkey] = wo.expand_table(expands)
             prog.append(("expand_wgrad", lambda tab=tab, aw=accumulate_wgrad, wo=wo: wo.upconv_expand_batched(tab, aw),
                          None, wdev))
+            done(*expand_params)
         return {l: (grad_of(self.node_of_layer[id(l)]) if id(self.node_of_layer[id(l)]) in written else None)
                 for l in input_grads}
 

@@ -51,8 +51,11 @@ def _interleave(a, b):
 class GanStep:
     def __init__(self, dev, dcgan_gen, dcgan_disc, p2p_gen, p2p_disc, alpha, lsgan, reconstruction, opt_spec,
                  train_mode='both', comm=None, use_graph=True, two_streams=True, force_exchange=False,
-                 side_streams=None, dtype='f32'):
+                 side_streams=None, dtype='f32', bucket_mb=None):
         self.dev = dev
+        # data-parallel exchange: a net's gradient bucket travels as sub-buckets of at least this many bytes, each
+        # all-reduced as soon as the backward pass has completed it (_build: bucketer)
+        self.bucket_bytes = int(float(bucket_mb if bucket_mb is not None else os.environ.get('GHM_BUCKET_MB', 32)) * 2 ** 20)
         # arithmetic of the convolution products (include/ghm.h GHM_DTYPE_*): 'f32' = the reference's floatX; 'bf16' /
         # 'f16' = BASELINE configs 4 / 5 (matrix-core operands rounded, fp32 accumulation, fp32 tensors and optimiser)
         self.dtype = dtype
@@ -301,52 +304,83 @@ class GanStep:
         # order, and that order is a pure function of the program -- identical on every rank.
         cdev, cops = self.cdev, self.cops
         embed = self.exchange and self.use_graph is not True  # RCCL calls stay outside captured HIP graphs
-        b.xchg = {}
 
-        def xchg(k, lane):
+        b.xchg_order = []           # [(label, net key, first element, n elements)] in collective order
+
+        def bucketer(k, lane, prog):
+            """-> (on_grads callback for emit_backward, flush): the gradient bucket of net ``k`` as SUB-BUCKETS, contiguous
+            ranges of the flat gradient buffer of >= self.bucket_bytes each, cut in the order the backward pass completes
+            them (last layers first = highest offsets first).  A sub-bucket's all-reduce is enqueued right after the
+            launch that completes its last gradient, so only the final one (the first layers' few parameters) is
+            exposed behind the stage's last kernel; the rest travels under the remaining backward pass."""
             st = self.stores[k]
             srcs = [self.devs[lane]] + ([self.side[lane][0]] if self.side[lane] is not None else [])
+            tr = sorted((p for p in st.params if p.index[0] == 'w'), key=lambda p: p.index[1])
+            offs = [p.index[1] for p in tr] + [st.n_train]
+            buckets, hi, pend = [], st.n_train, []
+            for i in range(len(tr) - 1, -1, -1):
+                pend.append(tr[i])
+                if 4 * (hi - offs[i]) >= self.bucket_bytes or i == 0:
+                    buckets.append({'lo': offs[i], 'hi': hi, 'pending': {id(p) for p in pend}, 'sent': False})
+                    hi, pend = offs[i], []
+            of = {pid: bk for bk in buckets for pid in bk['pending']}
 
-            def fn():
-                for d in srcs:
-                    cdev.wait_for(d)
-                cops.allreduce_sum(st.g, st.n_train)
-            b.xchg[k] = ("allreduce_" + k, fn, None, cdev)
-            return b.xchg[k]
+            def send(bk):
+                bk['sent'] = True
+                lo, n = bk['lo'], bk['hi'] - bk['lo']
+                view = st.g.channels(lo, bk['hi'])
+                label = "allreduce_%s_%d" % (k, buckets.index(bk)) if len(buckets) > 1 else "allreduce_" + k
 
+                def fn():
+                    for d in srcs:
+                        cdev.wait_for(d)
+                    cops.allreduce_sum(view, n)
+                e = (label, fn, None, cdev)
+                b.xchg_order.append((label, k, lo, n))
+                (prog if embed else b.exchange_late).append(e)
+
+            def on_grads(_prog, params):
+                for p in params:
+                    bk = of.get(id(p))
+                    if bk is None:
+                        continue
+                    bk['pending'].discard(id(p))
+                    if not bk['pending'] and not bk['sent']:
+                        send(bk)
+
+            def flush():                # parameters no launch reported (none today): their bucket still travels
+                for bk in buckets:
+                    if not bk['sent']:
+                        send(bk)
+            return on_grads, flush
+
+        b.exchange_late = []        # graph mode: the collectives stay outside the captured graphs, after both programs
+        nohook = (None, lambda: None)
         if do_dcgan:
             b.D.emit_transposes(ta, tdone)
             b.G.emit_transposes(ta, tdone)
-            b.D.emit_backward(ta, b.seed_D, wgrad=True, tag="dloss", transposed=tdone)
-            if self.exchange:
-                e = xchg('dcgan_disc', 0)
-                if embed:
-                    ta.append(e)
+            hook, flush = bucketer('dcgan_disc', 0, ta) if self.exchange else nohook
+            b.D.emit_backward(ta, b.seed_D, wgrad=True, tag="dloss", transposed=tdone, on_grads=hook)
+            flush()
             gin = b.D.emit_backward(ta, b.seed_G, nslice=(B, 2 * B), wgrad=False, input_grads=[d_in_layer],
                                     tag="gloss", transposed=tdone)
-            b.G.emit_backward(ta, gin[d_in_layer], wgrad=True, transposed=tdone)
-            if self.exchange:
-                e = xchg('dcgan_gen', 0)
-                if embed:
-                    ta.append(e)
+            hook, flush = bucketer('dcgan_gen', 0, ta) if self.exchange else nohook
+            b.G.emit_backward(ta, gin[d_in_layer], wgrad=True, transposed=tdone, on_grads=hook)
+            flush()
         if do_p2p:
             b.P.emit_transposes(tb, tdone)
             b.U.emit_transposes(tb, tdone)
-            b.P.emit_backward(tb, b.seed_PD, wgrad=True, tag="dloss", transposed=tdone)
-            if self.exchange:
-                e = xchg('p2p_disc', 1)
-                if embed:
-                    tb.append(e)
+            hook, flush = bucketer('p2p_disc', 1, tb) if self.exchange else nohook
+            b.P.emit_backward(tb, b.seed_PD, wgrad=True, tag="dloss", transposed=tdone, on_grads=hook)
+            flush()
             gin = b.P.emit_backward(tb, b.seed_PG, nslice=(B, 2 * B), wgrad=False, input_grads=[i_b], tag="gloss",
                                     transposed=tdone)
             gu = gin[i_b]
             # (:115-117) recon loss and alpha * d recon / d U(X) added to the adversarial gradient
             tb.append(("recon", lambda: oB.recon_loss(b.U.out, b.y, slot(3), gu, self.alpha * LS, l2, True)))
-            b.U.emit_backward(tb, gu, wgrad=True, transposed=tdone)
-            if self.exchange:
-                e = xchg('p2p_gen', 1)
-                if embed:
-                    tb.append(e)
+            hook, flush = bucketer('p2p_gen', 1, tb) if self.exchange else nohook
+            b.U.emit_backward(tb, gu, wgrad=True, transposed=tdone, on_grads=hook)
+            flush()
         else:
             tb.append(("recon", lambda: oB.recon_loss(b.U.out, b.y, slot(3), None, 1.0, l2)))
         if self.side[0] is not None:        # the gradient streams rejoin before anything consumes the gradients
@@ -358,10 +392,7 @@ class GanStep:
         keys = (['dcgan_gen', 'dcgan_disc'] if do_dcgan else []) + (['p2p_gen', 'p2p_disc'] if do_p2p else [])
         b.exchange = []
         if self.exchange:
-            if not embed:
-                for k in ('dcgan_disc', 'dcgan_gen', 'p2p_disc', 'p2p_gen'):
-                    if k in b.xchg:
-                        b.exchange.append(b.xchg[k])
+            b.exchange.extend(b.exchange_late)          # graph mode: every sub-bucket, in completion order per stage
 
             def reduce_losses():
                 cdev.wait_for(dA)
@@ -370,11 +401,11 @@ class GanStep:
                 cops.allreduce_sum(lo, 8)
             b.exchange.append(("allreduce_losses", reduce_losses, None, cdev))
 
-            def rejoin():
-                dA.wait_for(cdev)
-                if dB is not dA:
-                    dB.wait_for(cdev)
-            b.exchange.append(("wait_comm", rejoin, None, cdev))
+            # one entry per stage stream, so that bench.py can bracket each with HIP events: the time a stage stream
+            # spends in this wait is the EXPOSED part of the exchange
+            b.exchange.append(("wait_comm", lambda: dA.wait_for(cdev), None, dA))
+            if dB is not dA:
+                b.exchange.append(("wait_comm", lambda: dB.wait_for(cdev), None, dB))
         gs = 1.0 / self.world          # (x 1 / loss scale inside the optimiser kernels, from the device state)
         hp = self.opt_spec.hp
         b.update = [[], []]

@@ -151,6 +151,12 @@ def host_device_class():
         def transpose_table(self, items):
             return (0, len(items), 0)
 
+        def expand_table(self, items):
+            return [int(dwp5.ptr) for _, dwp5, _, _ in items]
+
+        def upconv_expand_batched(self, table, accumulate=False):
+            Shared.log.append((self.dev.name, "upconv_expand_batched") + tuple(table))     # the 5x5 gradients it writes
+
         def allreduce_sum(self, buf, n):
             import torch
             import torch.distributed as tdist

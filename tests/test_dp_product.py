@@ -26,7 +26,7 @@ import torch.multiprocessing as tmp_  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = ['dcgan_gen', 'dcgan_disc', 'p2p_gen', 'p2p_disc']
-GRAD_WRITERS = ('conv2d_wgrad', 'channel_sum', 'bn_backward', 'upconv_expand_wgrad')
+GRAD_WRITERS = ('conv2d_wgrad', 'channel_sum', 'bn_backward', 'upconv_expand_batched')
 
 
 def _nets(seed):
@@ -56,7 +56,7 @@ def _pairs(n):
     return rng.rand(n, 1, 32, 32), rng.randn(n, 3, 32, 32)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, bucket_mb):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -81,7 +81,7 @@ def _worker(rank, world, port, out_dir):
     G, D, U, P = _nets(seed=7 if rank == 0 else 1000 + rank)       # unseeded replicas differ
     spec = updates.rmsprop(learning_rate=updates.shared(1e-2))
     eng = GanStep(dev, G, D, U, P, 100, True, 'l1', spec, 'both', comm=GlooComm(), use_graph=False,
-                  two_streams=True, side_streams=True)
+                  two_streams=True, side_streams=True, bucket_mb=bucket_mb)
     before = eng.replica_checksums()
     eng.broadcast_parameters()
     after = eng.replica_checksums()
@@ -116,19 +116,33 @@ def _worker(rank, world, port, out_dir):
         "names": {"A": eng.devs[0].name, "B": eng.devs[1].name, "sideA": eng.side[0][0].name,
                   "sideB": eng.side[1][0].name, "comm": cdev.name},
         "pgrad_avg": [stp.download_grad(p).astype(np.float64) / world for p in pparams],
-        "pvalues": pvalues,
+        "pvalues": pvalues, "xchg_order": list(b.xchg_order),
     }
     with open(os.path.join(out_dir, "r%d.pkl" % rank), "wb") as f:
         pickle.dump(out, f)
     tdist.destroy_process_group()
 
 
-@pytest.fixture(scope="module")
-def ranks(tmp_path_factory):
-    d = tmp_path_factory.mktemp("dp_product")
-    world, port = 2, 33500 + (os.getpid() % 2000)
-    tmp_.spawn(_worker, args=(world, port, str(d)), nprocs=world, join=True)
-    return [pickle.load(open(os.path.join(str(d), "r%d.pkl" % r), "rb")) for r in range(world)]
+# "whole": every net's bucket is one collective (the nets of this test are far below the 32 MB default);
+# "sub": 2 KB sub-buckets -- the shape the full-size U-Net's 140 MB bucket takes at the default size
+@pytest.fixture(scope="module", params=["whole", "sub"])
+def ranks(request, tmp_path_factory):
+    d = tmp_path_factory.mktemp("dp_product_" + request.param)
+    world, port = 2, 33500 + (os.getpid() % 2000) + (0 if request.param == "whole" else 1)
+    bucket_mb = None if request.param == "whole" else 2048.0 / 2 ** 20
+    tmp_.spawn(_worker, args=(world, port, str(d), bucket_mb), nprocs=world, join=True)
+    out = [pickle.load(open(os.path.join(str(d), "r%d.pkl" % r), "rb")) for r in range(world)]
+    for r in out:
+        r["mode"] = request.param
+    return out
+
+
+def _net_of(r, ptr):
+    for k in KEYS:
+        g0, n = r["g_range"][k]
+        if g0 <= ptr < g0 + 4 * n:
+            return k
+    return "losses"
 
 
 def test_replicas_agree_after_broadcast_and_after_the_step(ranks):
@@ -147,26 +161,52 @@ def test_both_ranks_issue_the_same_collective_sequence(ranks):
     seqs = [[e for e in r["log"] if e[1] == "allreduce_sum"] for r in ranks]
     assert seqs[0] == seqs[1]
     r0 = ranks[0]
-    by_ptr = {r0["g_range"][k][0]: k for k in KEYS}
-    order = [by_ptr.get(e[2], "losses") for e in seqs[0]]
+    order = [_net_of(r0, e[2]) for e in seqs[0]]
     # discriminator buckets go out before their generators' (they are ready first), the losses last
-    assert sorted(order[:4]) == sorted(KEYS) and order[4] == "losses" and len(order) == 5
-    assert order.index('dcgan_disc') < order.index('dcgan_gen') and order.index('p2p_disc') < order.index('p2p_gen')
+    assert order[-1] == "losses" and "losses" not in order[:-1] and set(order[:-1]) == set(KEYS)
+    last = {k: max(i for i, o in enumerate(order) if o == k) for k in KEYS}
+    first = {k: min(i for i, o in enumerate(order) if o == k) for k in KEYS}
+    assert last['dcgan_disc'] < first['dcgan_gen'] and last['p2p_disc'] < first['p2p_gen']
     assert all(e[0] == r0["names"]["comm"] for e in seqs[0])      # all on the communication stream
-    for e in seqs[0][:4]:
-        assert e[3] == r0["g_range"][by_ptr[e[2]]][1]            # whole bucket, one collective
+    # the program's own record of its sub-buckets (per net: the host interleaves the two stage programs)
+    for k in KEYS:
+        assert [(e[2], e[3]) for e in seqs[0] if _net_of(r0, e[2]) == k] == \
+            [(r0["g_range"][k][0] + 4 * lo, n) for _, kk, lo, n in r0["xchg_order"] if kk == k]
+    for k in KEYS:
+        g0, n = r0["g_range"][k]
+        rng_ = sorted((e[2], e[3]) for e in seqs[0] if _net_of(r0, e[2]) == k)
+        if r0["mode"] == "whole":
+            assert rng_ == [(g0, n)]                               # whole bucket, one collective
+        else:
+            # sub-buckets: disjoint, contiguous, covering the bucket exactly; each at least the requested size except
+            # the one holding the net's FIRST parameters (whatever is left); sent highest offsets first -- the order
+            # the backward pass completes them in a chain-structured net
+            assert rng_[0][0] == g0 and all(a[0] + 4 * a[1] == b_[0] for a, b_ in zip(rng_, rng_[1:]))
+            assert rng_[-1][0] + 4 * rng_[-1][1] == g0 + 4 * n
+            assert all(4 * m >= 2048 for p_, m in rng_[1:])
+            if k in ('dcgan_disc', 'p2p_disc'):
+                assert len(rng_) >= 2
+                sent = [e[2] for e in seqs[0] if _net_of(r0, e[2]) == k]
+                assert sent == sorted(sent, reverse=True)
 
 
 def test_buckets_are_reduced_after_their_writers_and_updated_after_the_reduce(ranks):
     for r in ranks:
         log, nm = r["log"], r["names"]
-        for k in KEYS:
-            g0, n = r["g_range"][k]
+        reduces = [(i, e) for i, e in enumerate(log) if e[1] == "allreduce_sum" and _net_of(r, e[2]) != "losses"]
+        assert len(reduces) >= 4
+        some_writers = {k: False for k in KEYS}
+        for i_red, e_red in reduces:
+            k = _net_of(r, e_red[2])
+            g0, n = e_red[2], e_red[3]                  # this (sub-)bucket
             lane, side = (nm["A"], nm["sideA"]) if k.startswith("dcgan") else (nm["B"], nm["sideB"])
-            i_red = next(i for i, e in enumerate(log) if e[1] == "allreduce_sum" and e[2] == g0)
             writers = [i for i, e in enumerate(log) if e[1] in GRAD_WRITERS
                        and any(g0 <= p < g0 + 4 * n for p in e[2:] if isinstance(p, int))]
-            assert writers and max(writers) < i_red, k
+            if not writers:                             # a sub-bucket of BatchNorm-fed biases only: never written (zero)
+                assert r["mode"] == "sub"
+                continue
+            some_writers[k] = True
+            assert max(writers) < i_red, k
             # the communication stream waited for the stage stream and its gradient stream after the last writer
             waits = [i for i, e in enumerate(log[:i_red]) if e[0] == nm["comm"] and e[1] == "wait_for"]
             for src in (lane, side):
@@ -177,6 +217,7 @@ def test_buckets_are_reduced_after_their_writers_and_updated_after_the_reduce(ra
             # the stage stream waits for the communication stream (after the LAST collective) before its updates
             last_coll = max(i for i, e in enumerate(log) if e[1] == "allreduce_sum")
             assert any(last_coll < i < i_upd_k and e == (lane, "wait_for", nm["comm"]) for i, e in enumerate(log))
+        assert all(some_writers.values())
 
 
 def test_reduced_buckets_are_the_sum_and_the_update_uses_the_mean(ranks):

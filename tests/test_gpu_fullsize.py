@@ -236,8 +236,12 @@ def test_full_size_batch4_step_against_the_float64_fixture(gpu):
 # rounding is 2^-9 (bf16) / 2^-12 (fp16) per product, accumulated over 9..25 x C products in fp32; the generators' deep
 # batch-4 BatchNorm chains amplify it exactly as they amplify fp32 rounding (the fixture's own fp32-vs-fp64 spread is
 # 1.2e-3 / 4.3e-4 there against 1e-7 per operation).
-LP_FULL_TOL = {'bf16': dict(loss=2e-2, out=3e-2, disc=8e-2, disc_cos=0.995, gen=0.8, gen_cos=0.75, after=2e-4),
-               'f16': dict(loss=3e-3, out=5e-3, disc=1e-2, disc_cos=0.9999, gen=0.15, gen_cos=0.99, after=2e-4)}
+# Measured (MI355X): bf16 loss 6.0e-5, out 1.1e-2, disc 1.9e-3 (cos 0.9999996), gen 8.3e-2 (cos 0.997), after 3.7e-3.
+# "after": post-step parameter norms; RMSprop's first step moves every element by lr*sqrt(10) in the direction of its
+# gradient's SIGN, so elements whose gradient is below the rounding noise move the other way (zero-initialised biases
+# most of all) -- a loose bound by nature.
+LP_FULL_TOL = {'bf16': dict(loss=3e-4, out=3e-2, disc=5e-3, disc_cos=0.9999, gen=0.2, gen_cos=0.98, after=1e-2),
+               'f16': dict(loss=1e-4, out=5e-3, disc=1e-3, disc_cos=0.99999, gen=0.05, gen_cos=0.999, after=1e-2)}
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])

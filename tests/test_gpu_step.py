@@ -325,7 +325,7 @@ def test_gradient_side_streams_bitwise(dev):
     assert build_model(cfg, 11, dev).engine.side[0] is None
 
 
-@pytest.mark.parametrize("variant", ["plain", "adam_bn_disc", "one_rank_exchange"])
+@pytest.mark.parametrize("variant", ["plain", "adam_bn_disc", "one_rank_exchange", "one_rank_exchange_subbuckets"])
 def test_recorded_step_is_the_eager_schedule_in_one_call(dev, variant):
     """use_graph='recorded' (ghm_step_record_begin / ghm_step_run): the eager four-stream launch sequence -- gradient
     side streams, stream waits, (world-1) RCCL all-reduces on the communication stream, updates -- recorded once in the
@@ -339,13 +339,17 @@ def test_recorded_step_is_the_eager_schedule_in_one_call(dev, variant):
                     disc_p2p=dict(nf=4, mul_factor=[1, 2], bn=True))
     cfg = ostep.default_cfg(**over)
     cdev = comm = None
-    if variant == "one_rank_exchange":
+    if variant.startswith("one_rank_exchange"):
         cdev = device.Device(dev.index)
         comm = dist.Comm(cdev, 0, 1)
         kw = dict(comm=comm, force_exchange=True)
+        if variant.endswith("subbuckets"):          # 2 KB sub-buckets: ~10 RCCL calls per net inside the stage programs
+            kw["bucket_mb"] = 2048.0 / 2 ** 20
     try:
-        eager = build_model(cfg, 11, dev, use_graph=False, **kw)
+        eager = build_model(cfg, 11, dev, use_graph=False, **{k: v for k, v in kw.items() if k != "bucket_mb"})
         rec = build_model(cfg, 11, dev, use_graph='recorded', **kw)
+        if "bucket_mb" in kw:
+            assert len(rec.engine.built(4).xchg_order) > 8
         assert rec.engine.side[0] is not None                    # the recorded form keeps the side streams
         for it in range(5):
             Z, X, Y = ostep.synthetic_batch(4, cfg, seed=30 + it)
