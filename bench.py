@@ -37,9 +37,19 @@ def synthetic_batch(B, latent_dim, in_shp, seed):
     return Z, X.astype(np.float32), Y.astype(np.float32)
 
 
-def cpu_baseline(sample_batch=1):
-    """The numpy oracle (kind "port": the reference's Theano CPU path cannot be installed here) on one joint
-    train step of the same 512x512 nets, fp32 im2col + OpenBLAS sgemm, all host cores."""
+def _cpu_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(sample_batch=2, config1_steps=3):
+    """The numpy oracle (kind "port": the reference's Theano CPU path cannot be installed here), fp32 im2col + OpenBLAS
+    sgemm on all host cores, on a bounded sample: ONE joint train step of the same 512x512 nets at batch
+    ``sample_batch`` (>= 2: BatchNorm over a batch of 1 is degenerate), and -- SURVEY 8(d): "img/s at config 1 always"
+    -- ``config1_steps`` train steps of BASELINE config 1 (DCGAN 64x64 generator + discriminator, batch 16)."""
     from oracle import step as ostep
     cfg = ostep.default_cfg()
     st = ostep.init_state(cfg, 0, np.float32)
@@ -47,15 +57,24 @@ def cpu_baseline(sample_batch=1):
     t0 = time.time()
     ostep.train_step(st, Z, X, Y, dtype=np.float32)
     dt = time.time() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    return {"value": sample_batch / dt, "unit": "images/s", "cores": int(threads), "kind": "port",
-            "sample": "%d joint train step(s) (fwd + 4 gradient roots + RMSprop) of the same 512x512 "
+    # config 1 (the same geometry tests/test_gpu_step.py::test_train_step_parity[config1_dcgan64_b16] checks on the GPU)
+    cfg1 = ostep.default_cfg(in_shp=64, latent_dim=100, train_mode='dcgan',
+                             gen_dcgan=dict(nch=64, div=[2, 2, 4, 4]), disc_dcgan=dict(nch=64, div=[8, 4, 2, 1]),
+                             gen_p2p=dict(nf=4), disc_p2p=dict(nf=4, mul_factor=[1, 2]))
+    st1 = ostep.init_state(cfg1, 0, np.float32)
+    Z1, X1, Y1 = ostep.synthetic_batch(16, cfg1, 0)
+    ostep.train_step(st1, Z1, X1, Y1, dtype=np.float32)          # warm the BLAS threads
+    t1 = time.time()
+    for _ in range(config1_steps):
+        ostep.train_step(st1, Z1, X1, Y1, dtype=np.float32)
+    dt1 = time.time() - t1
+    return {"value": sample_batch / dt, "unit": "images/s", "cores": int(_cpu_threads()), "kind": "port",
+            "sample": "1 joint train step (fwd + 4 gradient roots + RMSprop) of the same 512x512 "
                       "test1_nobn_bilin_both nets at batch %d, numpy fp32 im2col+sgemm oracle, %.1f s"
-                      % (1, sample_batch, dt)}
+                      % (sample_batch, dt),
+            "config1": {"value": round(16 * config1_steps / dt1, 2), "unit": "images/s",
+                        "sample": "%d DCGAN train steps at 64x64, batch 16 (BASELINE config 1; the p2p nets of the "
+                                  "oracle's step are 4-filter stubs, train_mode='dcgan'), %.1f s" % (config1_steps, dt1)}}
 
 
 def main():
@@ -180,17 +199,20 @@ def main():
     def is_dom(e):
         return len(e) > 2 and e[2] is not None and e[2]["kernel"].split(" splits")[0] == dominant
 
-    max_slots = 4000
-    inst_steps = min(args.steps, max_slots // max(launches_per_step, 1)) if dominant else 0
-    slots = []          # (device, slot) of every bracketed launch of the dominant kernel
+    def is_comm(e):          # data-parallel runs: every (sub-)bucket all-reduce and each stage stream's wait for them
+        return world > 1 and (e[0].startswith("allreduce_") or e[0] == "wait_comm")
+
+    slots = []          # device of every bracketed entry, in slot order
+    slot_labels = []    # None = a launch of the dominant kernel, else the exchange entry's label
 
     def wrap(lane, e):
-        if is_dom(e):
+        if is_dom(e) or is_comm(e):
             d = e[3] if len(e) > 3 and e[3] is not None else eng.devs[lane]
             d.timer_start(len(slots))
             e[1]()
             d.timer_stop(len(slots))
             slots.append(d)
+            slot_labels.append(None if is_dom(e) else e[0] + ("@A" if d is eng.devs[0] else "@B") * (e[0] == "wait_comm"))
         else:
             e[1]()
 
@@ -199,9 +221,11 @@ def main():
         # slots advance by ``launches_per_step`` per replay, so every launch of the timed region has its own events
         b.steps.pop('train', None)
         eng.enqueue_train(b, wrap)              # records (with the brackets) and replays once: untimed
-        type(dev).step_timer_stride(b.steps['train'], launches_per_step)
-        rec_devs, inst_steps = list(slots), min(args.steps, 4000 // max(launches_per_step, 1) - 1)
+        type(dev).step_timer_stride(b.steps['train'], len(slots))
+        rec_devs, inst_steps = list(slots), min(args.steps, 4000 // max(len(slots), 1) - 1)
         eng.sync()
+    else:
+        inst_steps = min(args.steps, 4000 // max(launches_per_step + 24 * (world > 1), 1)) if dominant else 0
 
     # ---- timed region ----
     if comm is not None:
@@ -222,12 +246,24 @@ def main():
     losses = eng._read_losses()
     if issue == 'recorded' and dominant:
         # replay r (1-based; replay 0 was the recording call) used slots [r * L, (r + 1) * L)
-        L_ = launches_per_step
+        L_ = len(rec_devs)
         first = args.steps - inst_steps + 1
-        timed = [(d, i + r * L_) for r in range(first, args.steps + 1) for i, d in enumerate(rec_devs)]
+        every = [(d, i + r * L_, slot_labels[i]) for r in range(first, args.steps + 1) for i, d in enumerate(rec_devs)]
     else:
-        timed = [(d, i) for i, d in enumerate(slots)]
+        every = [(d, i, slot_labels[i]) for i, d in enumerate(slots)]
+    timed = [(d, i) for d, i, lab in every if lab is None]
     slot = len(timed)
+    # ---- the same loop with the reference's host-array boundary (pix2pix.py:142: train_fn(Z, X, Y) takes numpy
+    # arrays): every step uploads its 16 KB + 4 MB + 12 MB batch over PCIe before it is enqueued ----
+    with_h2d = None
+    if not args.ablate and world == 1:
+        eng.sync()
+        t1 = time.perf_counter()
+        for s in range(args.steps):
+            eng._upload(b, Z, X, Y)
+            eng.enqueue_train(b) if issue is not False else eng.enqueue_train(b, lambda lane, e: e[1]())
+        eng.sync()
+        with_h2d = B * args.steps / (time.perf_counter() - t1)
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = B * world * args.steps / elapsed
@@ -253,7 +289,25 @@ def main():
         "step_executed_tflops": round(executed_flops_per_step / (ms_per_step * 1e-3) / 1e12 * world, 2)
         if executed_flops_per_step else None,
         "losses": [float(x) for x in losses],
+        # inputs uploaded from host arrays every step (the reference's train_fn(Z, X, Y) boundary); never ``value``
+        "value_with_h2d": round(with_h2d, 3) if with_h2d else None,
     }
+    if world > 1:
+        # data-parallel exchange, measured inside the timed region: the all-reduce of every (sub-)bucket on the
+        # communication stream, and -- the part of it that is EXPOSED -- how long each stage stream sat in its wait
+        # for the communication stream before the optimiser updates
+        per = {}
+        for d, i, lab in every:
+            if lab is not None:
+                per.setdefault(lab, []).append(d.timer_ms(i))
+        out["exchange"] = {
+            "rccl_nranks": comm.nranks(), "bucket_mb": eng.bucket_bytes / 2 ** 20,
+            "collectives_per_step": len([k for k in per if k.startswith("allreduce_")]),
+            "buckets": [{"label": lab, "net": k, "MB": round(4 * n / 2 ** 20, 2),
+                         "avg_ms": round(sum(per[lab]) / len(per[lab]), 4) if lab in per else None}
+                        for lab, k, lo, n in b.xchg_order],
+            "exposed_wait_ms_per_step": {k[-1]: round(sum(v) / len(v), 4) for k, v in per.items() if k.startswith("wait_comm")},
+        }
     if dominant and slot:
         tot_ms = sum(d.timer_ms(i) for d, i in timed)
         avg_ms = tot_ms / slot                           # in the timed region (the other stream keeps running)
@@ -281,7 +335,7 @@ def main():
     else:
         out["roofline"] = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and S == 512:
-        out["cpu_baseline"] = cpu_baseline(1)
+        out["cpu_baseline"] = cpu_baseline(2)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if comm is not None:

@@ -108,6 +108,7 @@ SIGNATURES = {
     "ghm_comm_unique_id": [C.POINTER(C.c_uint8 * 128)],
     "ghm_comm_init": [_p, _i32, _i32, C.POINTER(C.c_uint8 * 128)],
     "ghm_comm_destroy": [_p],
+    "ghm_comm_count": [_p, C.POINTER(_i32)],
     "ghm_allreduce_sum": [_p, _p, _i64],
     "ghm_allreduce_max": [_p, _p, _i64],
     "ghm_conv2d_variant": [_D, _i32, C.c_char_p, _i32],

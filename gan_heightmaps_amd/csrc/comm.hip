@@ -20,6 +20,7 @@ struct RcclApi {
     int (*GetUniqueId)(rccl_uid*) = nullptr;
     int (*CommInitRank)(rccl_comm*, int, rccl_uid, int) = nullptr;
     int (*CommDestroy)(rccl_comm) = nullptr;
+    int (*CommCount)(rccl_comm, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
@@ -61,6 +62,7 @@ int load_rccl() {
     RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
     RCCL_SYM(CommInitRank, "ncclCommInitRank");
     RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    RCCL_SYM(CommCount, "ncclCommCount");
     RCCL_SYM(AllReduce, "ncclAllReduce");
     RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef RCCL_SYM
@@ -109,6 +111,14 @@ int ghm_comm_init(ghm_ctx* ctx, int32_t rank, int32_t world, const uint8_t id[12
     GHM_RCCL(g_api.AllReduce(warm, warm, 1, RCCL_FLOAT32, RCCL_SUM, comm, ctx->stream));
     GHM_HIP(hipStreamSynchronize(ctx->stream));
     GHM_HIP(hipFree(warm));
+    return 0;
+}
+
+int ghm_comm_count(ghm_ctx* ctx, int32_t* nranks) {
+    GHM_CHECK(ctx->comm != nullptr, "ghm_comm_count on a context without a communicator");
+    int n = 0;
+    GHM_RCCL(g_api.CommCount((rccl_comm)ctx->comm, &n));      // what RCCL itself says, not what the caller passed in
+    *nranks = n;
     return 0;
 }
 

@@ -141,6 +141,12 @@ class Comm:
         if rank == 0:
             cleanup_rendezvous(self._path, world)
 
+    def nranks(self):
+        """the rank count RCCL reports for this communicator (ncclCommCount)"""
+        n = C.c_int32()
+        call("ghm_comm_count", self.dev.h, C.byref(n))
+        return n.value
+
     def barrier(self):
         call("ghm_allreduce_sum", self.dev.h, C.c_void_p(self._scratch.ptr), 1)
         self.dev.sync()

@@ -241,7 +241,8 @@ def test_full_size_batch4_step_against_the_float64_fixture(gpu):
 # gradient's SIGN, so elements whose gradient is below the rounding noise move the other way (zero-initialised biases
 # most of all) -- a loose bound by nature.
 LP_FULL_TOL = {'bf16': dict(loss=3e-4, out=3e-2, disc=5e-3, disc_cos=0.9999, gen=0.2, gen_cos=0.98, after=1e-2),
-               'f16': dict(loss=1e-4, out=5e-3, disc=1e-3, disc_cos=0.99999, gen=0.05, gen_cos=0.999, after=1e-2)}
+               'f16': dict(loss=3e-5, out=5e-3, disc=2e-3, disc_cos=0.99999, gen=0.05, gen_cos=0.999, after=3e-3)}
+# fp16 measured: loss 6.7e-6, out 1.5e-3, disc 7.1e-4, gen 1.8e-2 (cos 0.9999), after 9.2e-4.
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])

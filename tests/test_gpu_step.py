@@ -214,9 +214,12 @@ def test_data_parallel_code_path_with_one_rank(dev, mode):
         labels = [e[0] for e in b.exchange]
         inside = [e[0] for lane in b.train_compute for e in lane if e[0].startswith("allreduce_")]
         if eager:
-            assert m.engine.side[0] is not None and len(inside) == 4 and labels == ["allreduce_losses", "wait_comm"]
+            # ... and one wait for the communication stream per stage stream (each is bracketed by bench.py: the
+            # exposed part of the exchange)
+            assert m.engine.side[0] is not None and len(inside) == 4 and labels == ["allreduce_losses", "wait_comm", "wait_comm"]
         else:
-            assert inside == [] and len(labels) == 6
+            assert inside == [] and labels == ["allreduce_dcgan_disc", "allreduce_dcgan_gen", "allreduce_p2p_disc",
+                                               "allreduce_p2p_gen", "allreduce_losses", "wait_comm", "wait_comm"]
         got = [m.train_fn(*b_) for b_ in Zs]        # graph mode: eager, captured, replayed
         assert np.array_equal(np.asarray(got), np.asarray(ref))
         p = model_params(m)
@@ -405,7 +408,7 @@ def test_recorded_step_survives_workspace_growth(dev):
     grown = [a[0] > b_[0] for a, b_ in zip(after, before)]
     assert any(grown), (before, after)                               # otherwise this test checks nothing
     for (size, retired, pinned), (size0, _, _), g in zip(after, before, grown):
-        assert retired == (size0 if g else 0)                        # the outgrown block is kept, not freed
+        assert retired >= size0 if g else retired == 0               # every outgrown block is kept, not freed
     for it in range(3, 6):
         Z, X, Y = ostep.synthetic_batch(4, cfg, seed=60 + it)
         assert eager.train_fn(Z, X, Y) == rec.train_fn(Z, X, Y), it
