@@ -106,8 +106,12 @@ void ghm_set_error(const char* fmt, ...);
 // context (the arguments are captured by value).  ``ctx`` is the ghm_ctx* in scope at every launch site.
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernel, ...) GHM_LAUNCH_IMPL((kernel), __VA_ARGS__)
+// TUNING ONLY: GHM_SKIP_KERNELS=<substring>[,<substring>...] drops every launch whose kernel expression contains one of
+// the substrings (results are wrong; tells what a kernel family costs inside the overlapped schedule)
+bool ghm_skip_kernel(const char* name);
 #define GHM_LAUNCH_IMPL(kernel, grid, block, lds, stream, ...)                                       \
     do {                                                                                               \
+        if (ghm_skip_kernel(#kernel)) break;                                                           \
         if (ctx->rec) {                                                                                \
             const dim3 g_ = (grid), b_ = (block);                                                      \
             const size_t l_ = (size_t)(lds);                                                           \

@@ -14,6 +14,17 @@ void ghm_set_error(const char* fmt, ...) {
 }
 
 int g_ghm_opt_epoch = 0;
+bool ghm_skip_kernel(const char* name) {
+    const char* pats = GHM_OPT("GHM_SKIP_KERNELS");
+    if (!pats) return false;
+    char buf[512];
+    strncpy(buf, pats, sizeof(buf) - 1);
+    buf[sizeof(buf) - 1] = 0;
+    for (char* tok = strtok(buf, ","); tok; tok = strtok(nullptr, ","))
+        if (*tok && strstr(name, tok)) return true;
+    return false;
+}
+
 static int g_plan_cus = 256;
 int ghm_plan_cus() { return g_plan_cus; }
 
