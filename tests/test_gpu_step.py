@@ -391,8 +391,9 @@ def test_recorded_step_survives_workspace_growth(dev):
     assert all(pinned >= 1 for _, _, pinned in before)               # the recorded step pins every context it spans
     assert any(size > 0 for size, _, _ in before)                    # ... and some of its kernels do use the workspace
     # forward-only calls at a larger batch and a deep split-K convolution issued eagerly on the SAME contexts
-    rec.z_fn(np.random.RandomState(0).rand(32, cfg['latent_dim']).astype(np.float32))
-    rec.gen_fn(np.random.RandomState(1).rand(32, 1, cfg['in_shp'], cfg['in_shp']).astype(np.float32))
+    for m in (rec, eager):          # (both: z_fn / gen_fn update the BatchNorm running statistics, pix2pix.py:144-147)
+        m.z_fn(np.random.RandomState(0).rand(32, cfg['latent_dim']).astype(np.float32))
+        m.gen_fn(np.random.RandomState(1).rand(32, 1, cfg['in_shp'], cfg['in_shp']).astype(np.float32))
     d = device.conv_desc(1, 2048, 16, 16, 512, 3, 3, 1, 1)
     for dv in devs:
         ops = device.Ops(dv)
