@@ -154,21 +154,24 @@ __global__ __launch_bounds__(256) void lp_pack_batched_kernel(const LpPackItem* 
 // Accumulators: TM x TN tiles of 32 x 32 (rows = channels, columns = 32 pixels of one row).
 // ------------------------------------------------------------------------------------------------
 struct LpConvArgs {
-    const float* in;
+    const u32x4* in_q;     // the conv input (forward) / output gradient (data gradient) as a q tensor (include/ghm.h)
+    long in_q_nstride;     // units (16 B = 8 channels of one pixel) between samples
+    const u32x4* zeros;    // >= 16 bytes of zeros in HBM: the DMA source of padding pixels
     const u32x4* wq;
     const float* bias;
-    float* out;
+    float* out;            // fp32 NCHW output or null
+    uint2* out_q;          // q-tensor output (half units: 4 channels of one pixel) or null
+    long out_q_nstride;    // units between samples
     float* partial;
     int N, CH, H, W;       // OUTPUT grid
     int Hin, Win;
-    long in_nstride;
     int R, Rpad;
     long out_nstride;
     int pad, act;
     float alpha;
     int accumulate;
     int slabs_per_split;
-    float* pool_out;            // POOL: dense [N, R, H/2, W/2] maximum of act(conv + bias) over 2x2 windows ...
+    float* pool_out;            // POOL: dense [N, R, H/2, W/2] maximum of act(conv + bias) over 2x2 windows (or null) ...
     unsigned char* pool_mask;   // ... and the 4-bit arg-max mask of every window (bit 2*dr + dc; all ties set)
     // stride-2 data gradient only: out *= act'(dact_y): the backward of the producer's nonlinearity in this epilogue
     const float* dact_y;
@@ -178,13 +181,59 @@ struct LpConvArgs {
     int debug;                  // tuning only (GHM_ABLATE bits: 1 no patch loads after the first slab, 2 no MFMAs, 4 no stores)
 };
 
-__device__ __forceinline__ void lp_pool2_store(float v0, float v1, bool col_even, bool live, float* po, unsigned char* pm) {
+template <int DT>
+__device__ __forceinline__ uint2 lp_pack4(float a, float b, float c, float d) {
+    return make_uint2(Lp<DT>::pack2(a, b), Lp<DT>::pack2(c, d));
+}
+
+// fp32 NCHW view -> q tensor (the producer-side rounding as a pass of its own: test / fallback path; the step's
+// producers write their q copy from their own epilogues).  One thread per 16-byte unit.
+template <int DT>
+__global__ __launch_bounds__(256) void q_pack_kernel(const float* __restrict__ x, long x_nstride, int N, int C8, int HW,
+                                                     u32x4* __restrict__ q, long q_nstride) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)N * C8 * HW) return;
+    const int p = (int)(idx % HW);
+    const long nc = idx / HW;
+    const int cb = (int)(nc % C8), n = (int)(nc / C8);
+    const float* g = x + (long)n * x_nstride + (long)cb * 8 * HW + p;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = g[(long)j * HW];
+    q[(long)n * q_nstride + (long)cb * HW + p] = lp_pack8<DT>(v);
+}
+
+// q tensor -> fp32 NCHW view (tests, and consumers that have no q path)
+template <int DT>
+__global__ __launch_bounds__(256) void q_unpack_kernel(const u32x4* __restrict__ q, long q_nstride, int N, int C8, int HW,
+                                                       float* __restrict__ x, long x_nstride) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)N * C8 * HW) return;
+    const int p = (int)(idx % HW);
+    const long nc = idx / HW;
+    const int cb = (int)(nc % C8), n = (int)(nc / C8);
+    const u32x4 u = q[(long)n * q_nstride + (long)cb * HW + p];
+    float* g = x + (long)n * x_nstride + (long)cb * 8 * HW + p;
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (DT == GHM_DTYPE_BF16) {
+            g[(long)(2 * j) * HW] = __uint_as_float(w[j] << 16);
+            g[(long)(2 * j + 1) * HW] = __uint_as_float(w[j] & 0xffff0000u);
+        } else {
+            const f16x2 h = __builtin_bit_cast(f16x2, w[j]);
+            g[(long)(2 * j) * HW] = (float)h[0];
+            g[(long)(2 * j + 1) * HW] = (float)h[1];
+        }
+    }
+}
+
+// the 2x2 maximum of act(v) over rows (v0, v1) of this lane and of the neighbour column's lane, and its arg-max mask
+__device__ __forceinline__ float lp_pool2(float v0, float v1, unsigned& mask) {
     const float w0 = __shfl_xor(v0, 1, 64), w1 = __shfl_xor(v1, 1, 64);      // the neighbour column's two rows
     const float m = fmaxf(fmaxf(v0, v1), fmaxf(w0, w1));
-    if (col_even && live) {
-        *po = m;
-        *pm = (unsigned char)((v0 == m ? 1u : 0u) | (w0 == m ? 2u : 0u) | (v1 == m ? 4u : 0u) | (w1 == m ? 8u : 0u));
-    }
+    mask = (v0 == m ? 1u : 0u) | (w0 == m ? 2u : 0u) | (v1 == m ? 4u : 0u) | (w1 == m ? 8u : 0u);
+    return m;
 }
 
 template <int DT, int KS, int ST, int BM, int RT, int WM, int WN, int TW, bool POOL = false>
@@ -223,9 +272,11 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
     const int s_begin = blockIdx.y * a.slabs_per_split;
     const int s_end = min(nslabs, s_begin + a.slabs_per_split);
 
-    // ---- patch gather: item e = (channel block, patch row, patch column); 8 channel planes per item ----
+    // ---- patch staging: item e = (channel block, patch row, patch column) is ONE 16-byte unit of the q tensor, brought
+    // global -> LDS by DMA (no registers, no conversion); padding pixels come from a zero unit in HBM ----
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
     int p_off[NQ];
-    unsigned pmask = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int e = tid + q * 256;
@@ -233,34 +284,21 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
         const int py = rem / PW, px = rem - py * PW;
         const int y = y0 * ST + py - a.pad, x = x0 * ST + px - a.pad;
         const bool ok = e < PUNITS && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
-        p_off[q] = ok ? cb * 8 * HWin + y * a.Win + x : 0;
-        pmask |= (ok ? 1u : 0u) << q;
+        p_off[q] = ok ? cb * HWin + y * a.Win + x : -1;
     }
-    const float* ibase = a.in + (long)n * a.in_nstride + (long)s_begin * 16 * HWin;
-    float pv[NQ][8];
-    auto load_patch = [&]() {
+    const u32x4* ibase = a.in_q + (long)n * a.in_q_nstride + (long)s_begin * 2 * HWin;
+    auto stage_patch = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const float* g = ibase + p_off[q];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pv[q][j] = g[(long)j * HWin];
-        }
-        ibase += (long)16 * HWin;
-    };
-    auto store_patch = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = tid + q * 256;
-            if (!((pmask >> q) & 1u)) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pv[q][j] = 0.f;
+            if (q * 256 + wave * 64 < PUNITS) {                  // wave-uniform: this wave has items in group q
+                const u32x4* g = p_off[q] >= 0 ? ibase + p_off[q] : a.zeros;
+                if (tid + q * 256 < PUNITS)
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Pl + buf * PUNITS + q * 256 + wave * 64), 16, 0, 0);
             }
-            if (e < PUNITS) Pl[buf * PUNITS + e] = lp_pack8<DT>(pv[q]);
         }
+        ibase += 2 * HWin;
     };
     // ---- weight DMA: tile (slab s, filter row fa) = chunks (cb, b) of BM consecutive 16-byte rows ----
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
     auto stage_weights = [&](int s, int fa, int buf) {
         const u32x4* src = a.wq + ((long)(2 * s) * T + fa * KS) * a.Rpad + r0 + lane;
 #pragma unroll
@@ -285,8 +323,7 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
 
     if (s_begin < s_end) {
         stage_weights(s_begin, 0, 0);
-        load_patch();
-        store_patch(0);
+        stage_patch(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -303,9 +340,10 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
                 stage_weights(s, fa + 1, wbuf ^ 1);
             else if (next_slab)
                 stage_weights(s + 1, 0, wbuf ^ 1);
-            if (fa == 0 && next_slab) load_patch();
+            if (fa == 0 && next_slab && !(a.debug & 1)) stage_patch(pbuf ^ 1);
             const u32x4* Wb = Wl + wbuf * WUNITS + wlane;
             const u32x4* Pb = Pl + pbuf * PUNITS + plane + fa * PW;
+            if (!(a.debug & 2))
 #pragma unroll
             for (int b = 0; b < KS; ++b) {
                 u32x4 af[TM], bf[TN];
@@ -318,13 +356,13 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = Lp<DT>::mfma(af[i], bf[j], acc[i][j]);
             }
-            if (fa == 0 && next_slab) store_patch(pbuf ^ 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     }
 
-    // ---- epilogue: lanes along pixels; row of element e of tile i: i*32 + (e&3) + 8*(e>>2) + 4*kg ----
+    // ---- epilogue: lanes along pixels; row of element e of tile i: i*32 + (e&3) + 8*(e>>2) + 4*kg.  The four values
+    // e = 4g .. 4g+3 of a lane are four consecutive channels of one pixel: half of a q unit (kg picks the half) ----
     const long P = (long)a.N * HW;
     const int ru = r0 + wm * (BM / WM);
     const int rl = ru + 4 * kg;
@@ -347,82 +385,89 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
     if (tid < BM) sb[tid] = (a.bias && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
     __syncthreads();
     const float* const lb = sb + wm * (BM / WM) + 4 * kg;
+    if (a.debug & 4) return;
     if constexpr (POOL) {
         // 2x2 max-pool of act(conv + bias) in the epilogue: the row pair of a window is in one lane (TN consecutive
         // rows per wave), the column pair in lanes (2t, 2t+1); even lanes store the maximum and the arg-max mask
         static_assert(TN % 2 == 0 && ST == 1 && TW == 32, "pooled epilogue: row pairs inside a wave, 32-column tiles");
         const int Wp = a.W / 2;
         const long HWp = (long)(a.H / 2) * Wp;
-        const long base = ((long)n * a.R + rl) * HWp + (long)((y0 + wn * TN) / 2) * Wp + (x0 + li) / 2;
+        const long pix = (long)((y0 + wn * TN) / 2) * Wp + (x0 + li) / 2;
+        const long base = ((long)n * a.R + rl) * HWp + pix;
+        uint2* const qb = a.out_q ? a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(ru / 8) * HWp + pix) + kg : nullptr;
         const float slope = a.act == GHM_ACT_LINEAR ? 1.f : (a.act == GHM_ACT_RELU ? 0.f : a.alpha);
+        const bool even = (li & 1) == 0;
 #pragma unroll
         for (int j2 = 0; j2 < TN / 2; ++j2)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                    float v0 = acc[i][2 * j2][e] + lb[k], v1 = acc[i][2 * j2 + 1][e] + lb[k];
-                    v0 = v0 > 0.f ? v0 : slope * v0;
-                    v1 = v1 > 0.f ? v1 : slope * v1;
-                    const long o = base + (long)k * HWp + j2 * Wp;
-                    lp_pool2_store(v0, v1, (li & 1) == 0, rl + k < a.R, a.pool_out + o, a.pool_mask + o);
+                for (int g = 0; g < 4; ++g) {
+                    float m[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int e = 4 * g + t, k = i * 32 + t + 8 * g;
+                        float v0 = acc[i][2 * j2][e] + lb[k], v1 = acc[i][2 * j2 + 1][e] + lb[k];
+                        v0 = v0 > 0.f ? v0 : slope * v0;
+                        v1 = v1 > 0.f ? v1 : slope * v1;
+                        unsigned mk;
+                        m[t] = lp_pool2(v0, v1, mk);
+                        if (even && rl + k < a.R) {
+                            const long o = base + (long)k * HWp + j2 * Wp;
+                            if (a.pool_out) a.pool_out[o] = m[t];
+                            a.pool_mask[o] = (unsigned char)mk;
+                        }
+                    }
+                    if (qb && even && rl + i * 32 + 8 * g < a.R)
+                        qb[2 * ((long)(i * 4 + g) * HWp + j2 * Wp)] = lp_pack4<DT>(m[0], m[1], m[2], m[3]);
                 }
         return;
     }
-    float* const ub = a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN * RPF) * a.W + x0;
+    float* const ub = a.out ? a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN * RPF) * a.W + x0 : nullptr;
     const unsigned lo = 4u * kg * (unsigned)HW + ly * a.W + lx;
+    uint2* const qb = a.out_q ? a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(ru / 8) * HW +
+                                                 (long)(y0 + wn * TN * RPF + ly) * a.W + x0 + lx) + kg : nullptr;
     const bool pwl = a.act == GHM_ACT_LINEAR || a.act == GHM_ACT_RELU || a.act == GHM_ACT_LRELU;
-    if (r0 + BM <= a.R && pwl) {
-        const float slope = a.act == GHM_ACT_LINEAR ? 1.f : (a.act == GHM_ACT_RELU ? 0.f : a.alpha);
-        if (!a.accumulate) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                        float* rowp = ub + (long)k * HW + j * RPF * a.W;
-                        const float v = acc[i][j][e] + lb[k];
-                        rowp[lo] = v > 0.f ? v : slope * v;
-                    }
-        } else {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    float old[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                        old[e] = (ub + (long)k * HW + j * RPF * a.W)[lo];
-                    }
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                        float* rowp = ub + (long)k * HW + j * RPF * a.W;
-                        const float v = acc[i][j][e] + lb[k] + old[e];
-                        rowp[lo] = v > 0.f ? v : slope * v;
-                    }
-                }
-        }
-        return;
-    }
+    const float slope = a.act == GHM_ACT_LINEAR ? 1.f : (a.act == GHM_ACT_RELU ? 0.f : a.alpha);
+    const bool full = r0 + BM <= a.R;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            float v[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                if (rl + k < a.R) {
-                    float* rowp = ub + (long)k * HW + j * RPF * a.W;
-                    float v = acc[i][j][e] + lb[k];
-                    if (a.accumulate) v += rowp[lo];
-                    rowp[lo] = ghm_act(v, a.act, a.alpha);
+                v[e] = acc[i][j][e] + lb[k];
+            }
+            if (a.accumulate) {           // (fp32 output present: checked by the host)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    if (full || rl + k < a.R) v[e] += (ub + (long)k * HW + j * RPF * a.W)[lo];
                 }
             }
+            if (pwl) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = ghm_act(v[e], a.act, a.alpha);
+            }
+            if (ub) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    if (full || rl + k < a.R) (ub + (long)k * HW + j * RPF * a.W)[lo] = v[e];
+                }
+            }
+            if (qb) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (full || rl + i * 32 + 8 * g < a.R)
+                        qb[2 * ((long)(i * 4 + g) * HW + j * RPF * a.W)] = lp_pack4<DT>(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -468,7 +513,6 @@ __global__ __launch_bounds__(256, BM * RT >= 256 ? 2 : 3) void lp_dgrad_s2_kerne
     const int s_end = min(nslabs, s_begin + a.slabs_per_split);
 
     int p_off[NQ];
-    unsigned pmask = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int e = tid + q * 256;
@@ -476,33 +520,23 @@ __global__ __launch_bounds__(256, BM * RT >= 256 ? 2 : 3) void lp_dgrad_s2_kerne
         const int py = rem / PW, px = rem - py * PW;
         const int y = i0 + py, x = j0 + px;
         const bool ok = e < PUNITS && y < Hc && x < Wc;
-        p_off[q] = ok ? cb * 8 * HWc + y * Wc + x : 0;
-        pmask |= (ok ? 1u : 0u) << q;
+        p_off[q] = ok ? cb * HWc + y * Wc + x : -1;
     }
-    const float* ibase = a.in + (long)n * a.in_nstride + (long)s_begin * 16 * HWc;
-    float pv[NQ][8];
-    auto load_patch = [&]() {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const float* g = ibase + p_off[q];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pv[q][j] = g[(long)j * HWc];
-        }
-        ibase += (long)16 * HWc;
-    };
-    auto store_patch = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = tid + q * 256;
-            if (!((pmask >> q) & 1u)) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pv[q][j] = 0.f;
-            }
-            if (e < PUNITS) Pl[buf * PUNITS + e] = lp_pack8<DT>(pv[q]);
-        }
-    };
+    const u32x4* ibase = a.in_q + (long)n * a.in_q_nstride + (long)s_begin * 2 * HWc;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    // the dy patch of a slab: one 16-byte q unit per (channel block, row, column), global -> LDS by DMA
+    auto stage_patch = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q * 256 + wave * 64 < PUNITS) {
+                const u32x4* g = p_off[q] >= 0 ? ibase + p_off[q] : a.zeros;
+                if (tid + q * 256 < PUNITS)
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Pl + buf * PUNITS + q * 256 + wave * 64), 16, 0, 0);
+            }
+        }
+        ibase += 2 * HWc;
+    };
     auto stage_weights = [&](int s, int buf) {
         const u32x4* src = a.wq + (long)(2 * s) * T * a.Rpad + r0 + lane;
 #pragma unroll
@@ -528,8 +562,7 @@ __global__ __launch_bounds__(256, BM * RT >= 256 ? 2 : 3) void lp_dgrad_s2_kerne
 
     if (s_begin < s_end) {
         stage_weights(s_begin, 0);
-        load_patch();
-        store_patch(0);
+        stage_patch(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -540,7 +573,7 @@ __global__ __launch_bounds__(256, BM * RT >= 256 ? 2 : 3) void lp_dgrad_s2_kerne
         const bool more = (s + 1) < s_end;
         if (more) {
             stage_weights(s + 1, buf ^ 1);
-            if (!(a.debug & 1)) load_patch();
+            if (!(a.debug & 1)) stage_patch(buf ^ 1);
         }
         const u32x4* Wb = Wl + buf * WUNITS + wlane;
         const u32x4* Pb = Pl + buf * PUNITS + plane;
@@ -573,7 +606,6 @@ __global__ __launch_bounds__(256, BM * RT >= 256 ? 2 : 3) void lp_dgrad_s2_kerne
                     acc[cl][i][j] = Lp<DT>::mfma(af[tw & 1][i], bf[tw & 1][j], acc[cl][i][j]);
             __builtin_amdgcn_sched_barrier(0);      // keep the prefetch distance at one tap (register budget)
         }
-        if (more) store_patch(buf ^ 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -593,7 +625,11 @@ __global__ __launch_bounds__(256, BM * RT >= 256 ? 2 : 3) void lp_dgrad_s2_kerne
     for (int j = 0; j < TN; ++j) {
         const long rowpix = (long)(2 * (i0 + wn * TN + j)) * a.W + 2 * j0;
         float* const ub = a.partial ? a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HWx + rowpix
-                                    : a.out + (long)n * a.out_nstride + (long)ru * HWx + rowpix;
+                                    : (a.out ? a.out + (long)n * a.out_nstride + (long)ru * HWx + rowpix : nullptr);
+        // q output: unit (channel block ru/8 + 4i + g, pixel (2*(i0+..)+pu, 2*(j0+li) + {0, 1})), half kg
+        uint2* const qrow = (a.out_q && !a.partial) ? a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(ru / 8) * HWx + rowpix + 2 * li) + kg
+                                                     : nullptr;
+        float2 qv[4];
         const float* const yb = a.dact_y ? a.dact_y + (long)n * a.dact_nstride + (long)ru * HWx + rowpix : nullptr;
 #pragma unroll
         for (int pu = 0; pu < 2; ++pu)
@@ -608,7 +644,7 @@ __global__ __launch_bounds__(256, BM * RT >= 256 ? 2 : 3) void lp_dgrad_s2_kerne
                     float2* o = reinterpret_cast<float2*>(ub + (long)k * rstride + pu * a.W + lo);
                     if (!plain) {
                         v.x += lb[k]; v.y += lb[k];
-                        if (a.accumulate) { const float2 old = *o; v.x += old.x; v.y += old.y; }
+                        if (a.accumulate) { const float2 old = *o; v.x += old.x; v.y += old.y; }      // (fp32 output present)
                         v.x = ghm_act(v.x, a.act, a.alpha);
                         v.y = ghm_act(v.y, a.act, a.alpha);
                         if (yb) {                       // relu / leaky relu: the slope of the producer
@@ -617,7 +653,15 @@ __global__ __launch_bounds__(256, BM * RT >= 256 ? 2 : 3) void lp_dgrad_s2_kerne
                             v.y *= yy.y > 0.f ? 1.f : a.dact_alpha;
                         }
                     }
-                    *o = v;
+                    if (ub) *o = v;
+                    if (qrow) {           // four consecutive channels (e = 4g .. 4g+3) of the lane's two pixels
+                        qv[e & 3] = v;
+                        if ((e & 3) == 3) {
+                            uint2* qo = qrow + 2 * ((long)(i * 4 + (e >> 2)) * HWx + pu * a.W);
+                            qo[0] = lp_pack4<DT>(qv[0].x, qv[1].x, qv[2].x, qv[3].x);
+                            qo[2] = lp_pack4<DT>(qv[0].y, qv[1].y, qv[2].y, qv[3].y);
+                        }
+                    }
                 }
     }
 }
@@ -860,15 +904,55 @@ LpPlan lp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
     return p;
 }
 
+static inline size_t align256(size_t n) { return (n + 255) / 256 * 256; }
+
 template <int DT>
-int lp_launch_conv(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a, int ks, int st) {
-    a.slabs_per_split = pl.slabs_per_split;
+int lp_q_pack(ghm_ctx* ctx, const float* x, long x_nstride, int N, int C, int HW, void* q, long q_nstride) {
+    const long total = (long)N * (C / 8) * HW;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL((q_pack_kernel<DT>), dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, x, x_nstride, N, C / 8, HW,
+                       (u32x4*)q, q_nstride);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+// workspace of one launch: [q copy of an fp32 input (fp32-input entry points only)][split-K partials]
+template <int DT>
+int lp_prepare(ghm_ctx* ctx, LpConvArgs& a, int splits, const float* x32, long x32_nstride) {
+    a.zeros = (const u32x4*)ctx->zeros;
     a.partial = nullptr;
-    if (pl.splits > 1) {
-        void* ws = nullptr;
-        if (int e = ghm_scratch(ctx, (size_t)pl.splits * a.R * a.N * a.H * a.W * sizeof(float), &ws)) return e;
-        a.partial = (float*)ws;
+    const size_t qbytes = x32 ? align256((size_t)a.N * (a.CH / 8) * a.Hin * a.Win * 16) : 0;
+    const size_t pbytes = splits > 1 ? (size_t)splits * a.R * a.N * a.H * a.W * sizeof(float) : 0;
+    if (qbytes + pbytes == 0) return 0;
+    void* ws = nullptr;
+    if (int e = ghm_scratch(ctx, qbytes + pbytes, &ws)) return e;
+    if (x32) {
+        a.in_q = (const u32x4*)ws;
+        a.in_q_nstride = (long)(a.CH / 8) * a.Hin * a.Win;
+        if (int e = lp_q_pack<DT>(ctx, x32, x32_nstride, a.N, a.CH, a.Hin * a.Win, ws, a.in_q_nstride)) return e;
     }
+    if (pbytes) a.partial = (float*)((char*)ws + qbytes);
+    return 0;
+}
+
+// after a split-K launch: the fixed-order reduction writes the fp32 output; a requested q output is packed from it
+template <int DT>
+int lp_finish_splits(ghm_ctx* ctx, const LpConvArgs& a, int splits) {
+    GHM_CHECK(a.out != nullptr, "split-K low-precision convolution needs an fp32 output (ask ghm_lp_q_direct)");
+    if (int e = ghm_splitk_finish(ctx, a.partial, splits, a.out, a.bias, a.N, a.R, a.H, a.W, a.out_nstride, a.act, a.alpha,
+                                  a.accumulate))
+        return e;
+    if (a.out_q) return lp_q_pack<DT>(ctx, a.out, a.out_nstride, a.N, a.R, a.H * a.W, a.out_q, a.out_q_nstride);
+    return 0;
+}
+
+template <int DT>
+int lp_launch_conv(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a, int ks, int st, const float* x32 = nullptr, long x32_nstride = 0) {
+    a.slabs_per_split = pl.slabs_per_split;
+    if (const char* f = GHM_OPT("GHM_ABLATE")) a.debug = atoi(f);
+    GHM_CHECK(!(a.accumulate && !a.out), "accumulate needs the fp32 output");
+    GHM_CHECK(!a.out_q || a.R % 8 == 0, "q output needs a multiple of 8 channels");
+    if (int e = lp_prepare<DT>(ctx, a, pl.splits, x32, x32_nstride)) return e;
     const dim3 g(pl.grid, pl.splits);
 #define GHM_LP_CASE(KS_, ST_, BM_, RT_, WM_, WN_, TW_)                                                              \
     if (ks == KS_ && st == ST_ && pl.bm == BM_ && pl.tw == TW_ && pl.rt == RT_) {                                   \
@@ -897,9 +981,7 @@ int lp_launch_conv(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a, int ks, int st)
         return -3;
     }
 #undef GHM_LP_CASE
-    if (pl.splits > 1)
-        return ghm_splitk_finish(ctx, a.partial, pl.splits, a.out, a.bias, a.N, a.R, a.H, a.W, a.out_nstride, a.act,
-                                 a.alpha, a.accumulate);
+    if (pl.splits > 1) return lp_finish_splits<DT>(ctx, a, pl.splits);
     return 0;
 }
 
@@ -944,15 +1026,12 @@ LpPlan lp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu) {
 }
 
 template <int DT>
-int lp_launch_dgrad_s2(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a) {
+int lp_launch_dgrad_s2(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a, const float* dy32 = nullptr, long dy32_nstride = 0) {
     a.slabs_per_split = pl.slabs_per_split;
     if (const char* f = GHM_OPT("GHM_ABLATE")) a.debug = atoi(f);
-    a.partial = nullptr;
-    if (pl.splits > 1) {
-        void* ws = nullptr;
-        if (int e = ghm_scratch(ctx, (size_t)pl.splits * a.R * a.N * a.H * a.W * sizeof(float), &ws)) return e;
-        a.partial = (float*)ws;
-    }
+    GHM_CHECK(!(a.accumulate && !a.out), "accumulate needs the fp32 output");
+    GHM_CHECK(!a.out_q || a.R % 8 == 0, "q output needs a multiple of 8 channels");
+    if (int e = lp_prepare<DT>(ctx, a, pl.splits, dy32, dy32_nstride)) return e;
     const dim3 g(pl.grid, pl.splits);
     if (pl.bm == 128)
         hipLaunchKernelGGL((lp_dgrad_s2_kernel<DT, 128, 2>), g, dim3(256), 0, ctx->stream, a);
@@ -961,9 +1040,7 @@ int lp_launch_dgrad_s2(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a) {
     else
         hipLaunchKernelGGL((lp_dgrad_s2_kernel<DT, 64, 2>), g, dim3(256), 0, ctx->stream, a);
     GHM_LAUNCH_CHECK();
-    if (pl.splits > 1)
-        return ghm_splitk_finish(ctx, a.partial, pl.splits, a.out, a.bias, a.N, a.R, a.H, a.W, a.out_nstride, a.act,
-                                 a.alpha, a.accumulate);
+    if (pl.splits > 1) return lp_finish_splits<DT>(ctx, a, pl.splits);
     return 0;
 }
 
@@ -1056,18 +1133,44 @@ bool lp_dgrad_s2_single_pass(const ghm_conv_desc* d, int dtype) {
     return pl.ok && pl.splits == 1 && (d->x_nstride & 1) == 0;
 }
 
-int lp_dgrad_s2_dact(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* wqT, float* dx, const float* dact_y,
-                     long dact_nstride, int dact, float dact_alpha, int dtype) {
+// the operands / results of one low-precision product: each tensor as fp32 NCHW and / or as a q tensor (include/ghm.h)
+struct LpIO {
+    const float* in32;          // fp32 input (packed to a q copy in the workspace first) -- or --
+    const void* inq;            // the input as a q tensor
+    long inq_ns;
+    float* out32;               // fp32 output or null
+    void* outq;                 // q output or null
+    long outq_ns;
+};
+
+static int lp_check_io(const LpIO& io, const char* who) {
+    GHM_CHECK((io.in32 != nullptr) != (io.inq != nullptr), "%s: exactly one of the fp32 / q input", who);
+    GHM_CHECK(io.out32 != nullptr || io.outq != nullptr, "%s: no output", who);
+    GHM_CHECK((((uintptr_t)io.inq | (uintptr_t)io.outq) & 15) == 0, "%s: q tensors are 16-byte aligned", who);
+    return 0;
+}
+
+static int lp_dgrad_s2_io(ghm_ctx* ctx, const ghm_conv_desc* d, const LpIO& io, const void* wqT, const float* bias, int act,
+                          float alpha, int accumulate, const float* dact_y, long dact_nstride, int dact, float dact_alpha,
+                          int dtype, bool single_pass) {
     const LpPlan pl = lp_plan_dgrad_s2(d, ctx->num_cu);
-    GHM_CHECK(pl.ok && pl.splits == 1, "lp_dgrad_s2_dact: not a single-pass plan");
+    GHM_CHECK(pl.ok && (!single_pass || pl.splits == 1), "lp stride-2 data gradient: plan not served");
     LpConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = dy; a.wq = (const u32x4*)wqT; a.out = dx;
-    a.N = d->N; a.CH = d->K; a.H = d->H; a.W = d->W; a.Hin = d->Ho; a.Win = d->Wo; a.in_nstride = d->y_nstride;
+    a.in_q = (const u32x4*)io.inq; a.in_q_nstride = io.inq_ns;
+    a.wq = (const u32x4*)wqT; a.bias = bias; a.out = io.out32; a.out_q = (uint2*)io.outq; a.out_q_nstride = io.outq_ns;
+    a.N = d->N; a.CH = d->K; a.H = d->H; a.W = d->W; a.Hin = d->Ho; a.Win = d->Wo;
     a.R = d->C; a.Rpad = rpad128(d->C); a.out_nstride = d->x_nstride; a.pad = d->pad;
-    a.act = GHM_ACT_LINEAR;
+    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
     a.dact_y = dact_y; a.dact_nstride = dact_nstride; a.dact = dact; a.dact_alpha = dact_alpha;
-    return dtype == GHM_DTYPE_BF16 ? lp_launch_dgrad_s2<GHM_DTYPE_BF16>(ctx, pl, a) : lp_launch_dgrad_s2<GHM_DTYPE_F16>(ctx, pl, a);
+    return dtype == GHM_DTYPE_BF16 ? lp_launch_dgrad_s2<GHM_DTYPE_BF16>(ctx, pl, a, io.in32, d->y_nstride)
+                                   : lp_launch_dgrad_s2<GHM_DTYPE_F16>(ctx, pl, a, io.in32, d->y_nstride);
+}
+
+int lp_dgrad_s2_dact(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* wqT, float* dx, const float* dact_y,
+                     long dact_nstride, int dact, float dact_alpha, int dtype) {
+    const LpIO io{dy, nullptr, 0, dx, nullptr, 0};
+    return lp_dgrad_s2_io(ctx, d, io, wqT, nullptr, GHM_ACT_LINEAR, 0.f, 0, dact_y, dact_nstride, dact, dact_alpha, dtype, true);
 }
 
 static bool lp_pool_act_ok(int act) { return act == GHM_ACT_LINEAR || act == GHM_ACT_RELU || act == GHM_ACT_LRELU; }
@@ -1079,18 +1182,25 @@ bool lp_conv_pool_supported(const ghm_conv_desc* d, int act, int dtype) {
     return pl.ok && pl.tw == 32 && pl.splits == 1 && GHM_OPT("GHM_NO_POOL_FUSE") == nullptr;
 }
 
-int lp_conv_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* wq, const float* bias, float* pooled,
-                     unsigned char* mask, int act, float alpha, int dtype) {
+static int lp_fwd_pool_io(ghm_ctx* ctx, const ghm_conv_desc* d, const LpIO& io, const void* wq, const float* bias,
+                          unsigned char* mask, int act, float alpha, int dtype) {
     const LpPlan pl = lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, ctx->num_cu);
     GHM_CHECK(pl.ok && pl.tw == 32 && pl.splits == 1, "lp_conv_fwd_pool: geometry not served");
+    GHM_CHECK(!io.outq || d->K % 8 == 0, "q output needs a multiple of 8 channels");
     LpConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = x; a.wq = (const u32x4*)wq; a.bias = bias; a.out = nullptr;
-    a.N = d->N; a.CH = d->C; a.H = d->Ho; a.W = d->Wo; a.Hin = d->H; a.Win = d->W; a.in_nstride = d->x_nstride;
+    a.in_q = (const u32x4*)io.inq; a.in_q_nstride = io.inq_ns;
+    a.wq = (const u32x4*)wq; a.bias = bias; a.out = nullptr;
+    a.out_q = (uint2*)io.outq; a.out_q_nstride = io.outq_ns;
+    a.N = d->N; a.CH = d->C; a.H = d->Ho; a.W = d->Wo; a.Hin = d->H; a.Win = d->W;
     a.R = d->K; a.Rpad = rpad128(d->K); a.out_nstride = 0; a.pad = d->pad;
     a.act = act; a.alpha = alpha; a.accumulate = 0;
     a.slabs_per_split = pl.slabs_per_split;
-    a.pool_out = pooled; a.pool_mask = mask;
+    a.pool_out = io.out32; a.pool_mask = mask;
+    if (const char* f = GHM_OPT("GHM_ABLATE")) a.debug = atoi(f);
+    if (int e = dtype == GHM_DTYPE_BF16 ? lp_prepare<GHM_DTYPE_BF16>(ctx, a, 1, io.in32, d->x_nstride)
+                                        : lp_prepare<GHM_DTYPE_F16>(ctx, a, 1, io.in32, d->x_nstride))
+        return e;
     const dim3 g(pl.grid, 1);
 #define GHM_LPP_CASE(DT_, KS_, BM_, WM_, WN_)                                                                          \
     if (dtype == DT_ && d->kh == KS_ && pl.bm == BM_) {                                                               \
@@ -1109,6 +1219,49 @@ int lp_conv_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const
 #undef GHM_LPP_CASE
     ghm_set_error("no pooled lp_conv variant for k=%d bm=%d", d->kh, pl.bm);
     return -3;
+}
+
+int lp_conv_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* wq, const float* bias, float* pooled,
+                     unsigned char* mask, int act, float alpha, int dtype) {
+    const LpIO io{x, nullptr, 0, pooled, nullptr, 0};
+    return lp_fwd_pool_io(ctx, d, io, wq, bias, mask, act, alpha, dtype);
+}
+
+static int lp_fwd_io(ghm_ctx* ctx, const ghm_conv_desc* d, const LpIO& io, const void* wq, const float* bias, int act,
+                     float alpha, int accumulate, int dtype) {
+    GHM_CHECK(ghm_lp_supported(d, 0, dtype), "low-precision forward convolution: geometry / dtype not served by the "
+              "matrix-core kernels (ask ghm_lp_supported first)");
+    GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    const LpPlan pl = lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ctx->num_cu);
+    LpConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in_q = (const u32x4*)io.inq; a.in_q_nstride = io.inq_ns;
+    a.wq = (const u32x4*)wq; a.bias = bias; a.out = io.out32; a.out_q = (uint2*)io.outq; a.out_q_nstride = io.outq_ns;
+    a.N = d->N; a.CH = d->C; a.H = d->Ho; a.W = d->Wo; a.Hin = d->H; a.Win = d->W;
+    a.R = d->K; a.Rpad = rpad128(d->K); a.out_nstride = d->y_nstride; a.pad = d->pad;
+    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
+    return dtype == GHM_DTYPE_BF16 ? lp_launch_conv<GHM_DTYPE_BF16>(ctx, pl, a, d->kh, d->stride, io.in32, d->x_nstride)
+                                   : lp_launch_conv<GHM_DTYPE_F16>(ctx, pl, a, d->kh, d->stride, io.in32, d->x_nstride);
+}
+
+static int lp_dgrad_io(ghm_ctx* ctx, const ghm_conv_desc* d, const LpIO& io, const void* wqT, const float* bias, int act,
+                       float alpha, int accumulate, int dtype) {
+    GHM_CHECK(ghm_lp_supported(d, 1, dtype), "low-precision data gradient: geometry / dtype not served (ask ghm_lp_supported)");
+    GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    if (d->stride == 2)
+        return lp_dgrad_s2_io(ctx, d, io, wqT, bias, act, alpha, accumulate, nullptr, 0, 0, 0.f, dtype, false);
+    // the data gradient of a stride-1 conv is the forward conv K -> C with flipped taps (folded into the
+    // transposed pack) and padding k-1-pad
+    const LpPlan pl = lp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ctx->num_cu);
+    LpConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in_q = (const u32x4*)io.inq; a.in_q_nstride = io.inq_ns;
+    a.wq = (const u32x4*)wqT; a.bias = bias; a.out = io.out32; a.out_q = (uint2*)io.outq; a.out_q_nstride = io.outq_ns;
+    a.N = d->N; a.CH = d->K; a.H = d->H; a.W = d->W; a.Hin = d->H; a.Win = d->W;
+    a.R = d->C; a.Rpad = rpad128(d->C); a.out_nstride = d->x_nstride; a.pad = d->kh - 1 - d->pad;
+    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
+    return dtype == GHM_DTYPE_BF16 ? lp_launch_conv<GHM_DTYPE_BF16>(ctx, pl, a, d->kh, 1, io.in32, d->y_nstride)
+                                   : lp_launch_conv<GHM_DTYPE_F16>(ctx, pl, a, d->kh, 1, io.in32, d->y_nstride);
 }
 
 extern "C" {
@@ -1169,48 +1322,90 @@ int ghm_lp_pack_batched(ghm_ctx* ctx, const void* table, int32_t n_items, int32_
     return 0;
 }
 
+int ghm_q_pack(ghm_ctx* ctx, const float* x, int64_t x_nstride, int32_t N, int32_t C, int32_t HW, void* q,
+               int64_t q_nstride, int32_t dtype) {
+    GHM_CHECK((dtype == GHM_DTYPE_BF16 || dtype == GHM_DTYPE_F16) && C % 8 == 0 && ((uintptr_t)q & 15) == 0,
+              "ghm_q_pack: dtype bf16 / f16, channels %% 8 == 0, 16-byte aligned q");
+    return dtype == GHM_DTYPE_BF16 ? lp_q_pack<GHM_DTYPE_BF16>(ctx, x, x_nstride, N, C, HW, q, q_nstride)
+                                   : lp_q_pack<GHM_DTYPE_F16>(ctx, x, x_nstride, N, C, HW, q, q_nstride);
+}
+
+int ghm_q_unpack(ghm_ctx* ctx, const void* q, int64_t q_nstride, int32_t N, int32_t C, int32_t HW, float* x,
+                 int64_t x_nstride, int32_t dtype) {
+    GHM_CHECK((dtype == GHM_DTYPE_BF16 || dtype == GHM_DTYPE_F16) && C % 8 == 0 && ((uintptr_t)q & 15) == 0,
+              "ghm_q_unpack: dtype bf16 / f16, channels %% 8 == 0, 16-byte aligned q");
+    const long total = (long)N * (C / 8) * HW;
+    if (total == 0) return 0;
+    if (dtype == GHM_DTYPE_BF16)
+        hipLaunchKernelGGL((q_unpack_kernel<GHM_DTYPE_BF16>), dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream,
+                           (const u32x4*)q, (long)q_nstride, N, C / 8, HW, x, (long)x_nstride);
+    else
+        hipLaunchKernelGGL((q_unpack_kernel<GHM_DTYPE_F16>), dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream,
+                           (const u32x4*)q, (long)q_nstride, N, C / 8, HW, x, (long)x_nstride);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_lp_q_direct(const ghm_conv_desc* d, int32_t kind, int32_t dtype) {
+    // does the kernel of this product write its q output (and may it skip the fp32 one)?  Not in the split-K form.
+    if (!ghm_lp_supported(d, kind, dtype)) return 0;
+    if (kind == 0) return (d->K % 8 == 0) && lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ghm_plan_cus()).splits == 1;
+    if (kind == 1) {
+        if (d->C % 8) return 0;
+        if (d->stride == 2) return lp_plan_dgrad_s2(d, ghm_plan_cus()).splits == 1;
+        return lp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ghm_plan_cus()).splits == 1;
+    }
+    return 0;
+}
+
 int ghm_conv2d_fwd_lp(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* wq, const float* bias, float* y,
                       int32_t act, float alpha, int32_t accumulate, int32_t dtype) {
-    GHM_CHECK(ghm_lp_supported(d, 0, dtype), "ghm_conv2d_fwd_lp: geometry / dtype not served by the matrix-core "
-              "low-precision kernels (ask ghm_lp_supported first)");
-    GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
-    const LpPlan pl = lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ctx->num_cu);
-    LpConvArgs a;
-    memset(&a, 0, sizeof(a));
-    a.in = x; a.wq = (const u32x4*)wq; a.bias = bias; a.out = y;
-    a.N = d->N; a.CH = d->C; a.H = d->Ho; a.W = d->Wo; a.Hin = d->H; a.Win = d->W; a.in_nstride = d->x_nstride;
-    a.R = d->K; a.Rpad = rpad128(d->K); a.out_nstride = d->y_nstride; a.pad = d->pad;
-    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
-    return dtype == GHM_DTYPE_BF16 ? lp_launch_conv<GHM_DTYPE_BF16>(ctx, pl, a, d->kh, d->stride)
-                                   : lp_launch_conv<GHM_DTYPE_F16>(ctx, pl, a, d->kh, d->stride);
+    const LpIO io{x, nullptr, 0, y, nullptr, 0};
+    if (int e = lp_check_io(io, "ghm_conv2d_fwd_lp")) return e;
+    return lp_fwd_io(ctx, d, io, wq, bias, act, alpha, accumulate, dtype);
+}
+
+int ghm_conv2d_fwd_lp_q(ghm_ctx* ctx, const ghm_conv_desc* d, const void* xq, int64_t xq_nstride, const void* wq,
+                        const float* bias, float* y, void* yq, int64_t yq_nstride, int32_t act, float alpha,
+                        int32_t accumulate, int32_t dtype) {
+    const LpIO io{nullptr, xq, (long)xq_nstride, y, yq, (long)yq_nstride};
+    if (int e = lp_check_io(io, "ghm_conv2d_fwd_lp_q")) return e;
+    return lp_fwd_io(ctx, d, io, wq, bias, act, alpha, accumulate, dtype);
 }
 
 int ghm_conv2d_dgrad_lp(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* wqT, const float* bias,
                         float* dx, int32_t act, float alpha, int32_t accumulate, int32_t dtype) {
-    GHM_CHECK(ghm_lp_supported(d, 1, dtype), "ghm_conv2d_dgrad_lp: geometry / dtype not served (ask ghm_lp_supported)");
-    GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
-    if (d->stride == 2) {
-        const LpPlan pl = lp_plan_dgrad_s2(d, ctx->num_cu);
-        LpConvArgs a;
-        memset(&a, 0, sizeof(a));
-        a.in = dy; a.wq = (const u32x4*)wqT; a.bias = bias; a.out = dx;
-        a.N = d->N; a.CH = d->K; a.H = d->H; a.W = d->W; a.Hin = d->Ho; a.Win = d->Wo; a.in_nstride = d->y_nstride;
-        a.R = d->C; a.Rpad = rpad128(d->C); a.out_nstride = d->x_nstride; a.pad = d->pad;
-        a.act = act; a.alpha = alpha; a.accumulate = accumulate;
-        return dtype == GHM_DTYPE_BF16 ? lp_launch_dgrad_s2<GHM_DTYPE_BF16>(ctx, pl, a)
-                                       : lp_launch_dgrad_s2<GHM_DTYPE_F16>(ctx, pl, a);
-    }
-    // the data gradient of a stride-1 conv is the forward conv K -> C with flipped taps (folded into the
-    // transposed pack) and padding k-1-pad
-    const LpPlan pl = lp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ctx->num_cu);
-    LpConvArgs a;
-    memset(&a, 0, sizeof(a));
-    a.in = dy; a.wq = (const u32x4*)wqT; a.bias = bias; a.out = dx;
-    a.N = d->N; a.CH = d->K; a.H = d->H; a.W = d->W; a.Hin = d->H; a.Win = d->W; a.in_nstride = d->y_nstride;
-    a.R = d->C; a.Rpad = rpad128(d->C); a.out_nstride = d->x_nstride; a.pad = d->kh - 1 - d->pad;
-    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
-    return dtype == GHM_DTYPE_BF16 ? lp_launch_conv<GHM_DTYPE_BF16>(ctx, pl, a, d->kh, 1)
-                                   : lp_launch_conv<GHM_DTYPE_F16>(ctx, pl, a, d->kh, 1);
+    const LpIO io{dy, nullptr, 0, dx, nullptr, 0};
+    if (int e = lp_check_io(io, "ghm_conv2d_dgrad_lp")) return e;
+    return lp_dgrad_io(ctx, d, io, wqT, bias, act, alpha, accumulate, dtype);
+}
+
+int ghm_conv2d_dgrad_lp_q(ghm_ctx* ctx, const ghm_conv_desc* d, const void* dyq, int64_t dyq_nstride, const void* wqT,
+                          const float* bias, float* dx, void* dxq, int64_t dxq_nstride, int32_t act, float alpha,
+                          int32_t accumulate, int32_t dtype) {
+    const LpIO io{nullptr, dyq, (long)dyq_nstride, dx, dxq, (long)dxq_nstride};
+    if (int e = lp_check_io(io, "ghm_conv2d_dgrad_lp_q")) return e;
+    return lp_dgrad_io(ctx, d, io, wqT, bias, act, alpha, accumulate, dtype);
+}
+
+int ghm_conv2d_dgrad_dact_lp_q(ghm_ctx* ctx, const ghm_conv_desc* d, const void* dyq, int64_t dyq_nstride, const void* wqT,
+                               float* dx, void* dxq, int64_t dxq_nstride, const float* dact_y, int64_t dact_nstride,
+                               int32_t dact, float dact_alpha, int32_t dtype) {
+    const LpIO io{nullptr, dyq, (long)dyq_nstride, dx, dxq, (long)dxq_nstride};
+    if (int e = lp_check_io(io, "ghm_conv2d_dgrad_dact_lp_q")) return e;
+    GHM_CHECK(lp_dgrad_s2_single_pass(d, dtype) && (dact == GHM_ACT_RELU || dact == GHM_ACT_LRELU),
+              "ghm_conv2d_dgrad_dact_lp_q: not served (ask ghm_dgrad_dact_supported: form 3)");
+    return lp_dgrad_s2_io(ctx, d, io, wqT, nullptr, GHM_ACT_LINEAR, 0.f, 0, dact_y, (long)dact_nstride, dact, dact_alpha,
+                          dtype, true);
+}
+
+int ghm_conv2d_fwd_pool_lp_q(ghm_ctx* ctx, const ghm_conv_desc* d, const void* xq, int64_t xq_nstride, const void* wq,
+                             const float* bias, float* pooled, void* pooledq, int64_t pooledq_nstride, uint8_t* mask,
+                             int32_t act, float alpha, int32_t dtype) {
+    const LpIO io{nullptr, xq, (long)xq_nstride, pooled, pooledq, (long)pooledq_nstride};
+    if (int e = lp_check_io(io, "ghm_conv2d_fwd_pool_lp_q")) return e;
+    GHM_CHECK(lp_conv_pool_supported(d, act, dtype), "ghm_conv2d_fwd_pool_lp_q: geometry not served");
+    return lp_fwd_pool_io(ctx, d, io, wq, bias, mask, act, alpha, dtype);
 }
 
 int ghm_conv2d_wgrad_lp_workspace(const ghm_conv_desc* d, size_t* bytes) {

@@ -76,6 +76,60 @@ class DevTensor:
         return self
 
 
+class QTensor:
+    """bf16 / fp16 copy of a [N, C, H, W] tensor in HBM in the channel-block-of-8 layout of include/ghm.h ("q tensor"):
+    16-byte units = 8 channels of one pixel; ``nstride`` counts UNITS between samples, so a channel slice (multiple of 8)
+    of a wider buffer is a view."""
+    __slots__ = ("dev", "ptr", "shape", "nstride", "dtype", "base")
+
+    def __init__(self, dev, ptr, shape, dtype, nstride=None, base=None):
+        self.dev, self.ptr, self.dtype, self.base = dev, int(ptr), dtype, base
+        self.shape = tuple(int(v) for v in shape)
+        assert len(self.shape) == 4 and self.shape[1] % 8 == 0, self.shape
+        self.nstride = int(nstride) if nstride is not None else self.shape[1] // 8 * self.shape[2] * self.shape[3]
+
+    N = property(lambda s: s.shape[0])
+    Cc = property(lambda s: s.shape[1])
+    H = property(lambda s: s.shape[2])
+    W = property(lambda s: s.shape[3])
+    HW = property(lambda s: s.shape[2] * s.shape[3])
+    contiguous = property(lambda s: s.nstride == s.shape[1] // 8 * s.shape[2] * s.shape[3])
+    nbytes = property(lambda s: 16 * s.nstride * s.shape[0])
+
+    @staticmethod
+    def empty(dev, shape, dtype):
+        shape = tuple(int(v) for v in shape)
+        return QTensor(dev, dev.alloc(16 * shape[0] * (shape[1] // 8) * shape[2] * shape[3]), shape, dtype)
+
+    def channels(self, c0, c1):
+        assert 0 <= c0 < c1 <= self.shape[1] and c0 % 8 == 0 and (c1 - c0) % 8 == 0
+        return QTensor(self.dev, self.ptr + 16 * (c0 // 8) * self.HW, (self.N, c1 - c0, self.H, self.W), self.dtype,
+                       self.nstride, self.base if self.base is not None else self)
+
+    def samples(self, n0, n1):
+        assert 0 <= n0 < n1 <= self.shape[0]
+        return QTensor(self.dev, self.ptr + 16 * n0 * self.nstride, (n1 - n0,) + self.shape[1:], self.dtype, self.nstride,
+                       self.base if self.base is not None else self)
+
+    def reshape(self, shape):
+        """[N, 4K, H, W] <-> [4N, K, H, W] (the parity-planar view of the collapsed up-sample convolutions)"""
+        assert self.contiguous
+        t = QTensor(self.dev, self.ptr, shape, self.dtype, None, self.base if self.base is not None else self)
+        assert t.nbytes == self.nbytes
+        return t
+
+    def numpy(self):
+        """-> float32 [N, C, H, W] (the exact values of the stored halfwords)"""
+        raw = np.empty((self.N, self.Cc * self.HW), np.uint16)       # a sample's channel blocks are contiguous planes
+        for n in range(self.N):
+            self.dev.d2h(raw[n], self.ptr + 16 * n * self.nstride, raw[n].nbytes)
+        raw = raw.reshape(self.N, self.Cc // 8, self.HW, 8).transpose(0, 1, 3, 2)
+        raw = np.ascontiguousarray(raw).reshape(self.shape)
+        if self.dtype == 'bf16':
+            return (raw.astype(np.uint32) << 16).view(np.float32)
+        return raw.view(np.float16).astype(np.float32)
+
+
 class Device:
     def __init__(self, index=0):
         _lib.load()
@@ -396,6 +450,38 @@ class Ops:
     def conv2d_wgrad_lp(self, d, x, dy, dwp, ws, dtype, accumulate=False):
         call("ghm_conv2d_wgrad_lp", self.h, C.byref(d), _vp(x), _vp(dy), _vp(dwp), _vp(ws), int(accumulate),
              DTYPE_CODES[dtype])
+
+    # ---- q tensors (include/ghm.h): low-precision products on operands rounded once at their producer ----
+    def q_pack(self, x, q):
+        assert x.shape == q.shape
+        call("ghm_q_pack", self.h, _vp(x), x.nstride, x.N, x.Cc, x.HW, C.c_void_p(q.ptr), q.nstride, DTYPE_CODES[q.dtype])
+
+    def q_unpack(self, q, x):
+        assert x.shape == q.shape
+        call("ghm_q_unpack", self.h, C.c_void_p(q.ptr), q.nstride, q.N, q.Cc, q.HW, _vp(x), x.nstride, DTYPE_CODES[q.dtype])
+
+    def lp_q_direct(self, d, kind, dtype):
+        return bool(_lib.load().ghm_lp_q_direct(C.byref(d), int(kind), DTYPE_CODES[dtype]))
+
+    def conv2d_fwd_lp_q(self, d, xq, wq, bias, y, yq, dtype, act='linear', alpha=0.0, accumulate=False):
+        call("ghm_conv2d_fwd_lp_q", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, _vp(wq), _vp(bias), _vp(y),
+             C.c_void_p(yq.ptr if yq is not None else 0), yq.nstride if yq is not None else 0, ACT_CODES[act], alpha,
+             int(accumulate), DTYPE_CODES[dtype])
+
+    def conv2d_dgrad_lp_q(self, d, dyq, wqT, dx, dxq, dtype, bias=None, act='linear', alpha=0.0, accumulate=False):
+        call("ghm_conv2d_dgrad_lp_q", self.h, C.byref(d), C.c_void_p(dyq.ptr), dyq.nstride, _vp(wqT), _vp(bias), _vp(dx),
+             C.c_void_p(dxq.ptr if dxq is not None else 0), dxq.nstride if dxq is not None else 0, ACT_CODES[act], alpha,
+             int(accumulate), DTYPE_CODES[dtype])
+
+    def conv2d_dgrad_dact_lp_q(self, d, dyq, wqT, dx, dxq, y, act, alpha, dtype):
+        call("ghm_conv2d_dgrad_dact_lp_q", self.h, C.byref(d), C.c_void_p(dyq.ptr), dyq.nstride, _vp(wqT), _vp(dx),
+             C.c_void_p(dxq.ptr if dxq is not None else 0), dxq.nstride if dxq is not None else 0, _vp(y), y.nstride,
+             ACT_CODES[act], alpha, DTYPE_CODES[dtype])
+
+    def conv2d_fwd_pool_lp_q(self, d, xq, wq, bias, pooled, pooledq, mask_ptr, act, alpha, dtype):
+        call("ghm_conv2d_fwd_pool_lp_q", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, _vp(wq), _vp(bias), _vp(pooled),
+             C.c_void_p(pooledq.ptr if pooledq is not None else 0), pooledq.nstride if pooledq is not None else 0,
+             C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha, DTYPE_CODES[dtype])
 
     # ---- conv + activation + 2x2 max-pool fused (architectures/dcgan.py:42-47) ----
     def conv_pool_supported(self, d, act, dtype='f32'):

@@ -349,3 +349,138 @@ def test_fp16_overflow_skips_the_update_and_lowers_the_scale(gpu):
     assert all(np.isfinite(v).all() for v in p2.values())
     assert all(not np.array_equal(p0[k], p2[k]) for k in p0)
     assert all(np.isfinite(v).all() for vals in model_params(model).values() for v in vals)
+
+
+# ---- q tensors: operands rounded once at their producer, channel-block-of-8 layout (include/ghm.h) -------------------
+Q_CASES = [
+    # N, C,  H,  W,  K,  k, s, pad
+    (2, 32, 32, 64, 64, 3, 1, 1),
+    (2, 64, 16, 32, 32, 5, 1, 2),
+    (2, 32, 32, 64, 64, 3, 2, 1),
+    (1, 48, 16, 16, 96, 3, 1, 1),       # 16-wide map: the narrow tiles
+    (3, 32, 8, 8, 160, 3, 1, 1),        # 8-wide map, K not a multiple of the 128 / 64-row tile
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("case", Q_CASES)
+def test_q_tensor_products(gpu, case, dtype):
+    """ghm_q_pack / ghm_q_unpack round-trip the layout; the *_q products on a q operand equal the definition on the
+    rounded operand (what the fp32-input entry points compute); their q OUTPUT is exactly round(fp32 output), written
+    into a channel slice of a wider q buffer without touching its neighbours; with the fp32 output omitted the q
+    output is unchanged; accumulate and the fused activation go through both outputs."""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(7)
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    dy = rng.randn(N, K, d.Ho, d.Wo).astype(np.float32)
+    R = LP.ROUND[dtype]
+    # layout round trip through a channel slice of a wider q buffer
+    wide_q = D.QTensor.empty(dev, (N, C + 16, H, W), dtype)
+    dev.memset_zero(wide_q.ptr, wide_q.nbytes)
+    xq = wide_q.channels(8, 8 + C)
+    xd = dev.tensor(x)
+    ops.q_pack(xd, xq)
+    assert np.array_equal(xq.numpy(), R(x))
+    full = wide_q.numpy()
+    assert not full[:, :8].any() and not full[:, 8 + C:].any()
+    back = dev.zeros(x.shape)
+    ops.q_unpack(xq, back)
+    assert np.array_equal(back.numpy(), R(x))
+    # forward: q operand -> fp32 + q outputs
+    wp = dev.tensor(D.pack_conv_w(Wt).ravel())
+    wq, wqT = dev.alloc(ops.lp_weight_bytes(d, False)), dev.alloc(ops.lp_weight_bytes(d, True))
+    ops.lp_pack_weights(d, wp, wq, dtype, False)
+    ops.lp_pack_weights(d, wp, wqT, dtype, True)
+    bd = dev.tensor(b)
+    y32, y32b = dev.empty((N, K, d.Ho, d.Wo)), dev.empty((N, K, d.Ho, d.Wo))
+    yq_wide = D.QTensor.empty(dev, (N, K + 8, d.Ho, d.Wo), dtype)
+    dev.memset_zero(yq_wide.ptr, yq_wide.nbytes)
+    yq = yq_wide.channels(8, 8 + K)
+    ops.conv2d_fwd_lp_q(d, xq, wq, bd, y32, yq, dtype, act='lrelu', alpha=0.2)
+    ops.conv2d_fwd_lp(d, xd, wq, bd, y32b, dtype, act='lrelu', alpha=0.2)
+    y_ref = LP.conv2d_fwd(x, Wt, b, s, pad, dtype)
+    y_ref = np.where(y_ref > 0, y_ref, 0.2 * y_ref)
+    assert rel(y32.numpy(), y_ref) < EXACT
+    assert np.array_equal(y32.numpy(), y32b.numpy())              # the fp32-input entry point = pack + the same kernel
+    assert np.array_equal(yq.numpy(), R(y32.numpy()))
+    assert not yq_wide.numpy()[:, :8].any()
+    if ops.lp_q_direct(d, 0, dtype):                              # q output alone (no fp32 tensor written)
+        yq2 = D.QTensor.empty(dev, (N, K, d.Ho, d.Wo), dtype)
+        ops.conv2d_fwd_lp_q(d, xq, wq, bd, None, yq2, dtype, act='lrelu', alpha=0.2)
+        assert np.array_equal(yq2.numpy(), yq.numpy())
+    # data gradient: dy as a q tensor -> dx fp32 + q, then accumulate
+    dyd = dev.tensor(dy)
+    dyq = D.QTensor.empty(dev, dy.shape, dtype)
+    ops.q_pack(dyd, dyq)
+    dx32 = dev.empty(x.shape)
+    dxq = D.QTensor.empty(dev, x.shape, dtype)
+    ops.conv2d_dgrad_lp_q(d, dyq, wqT, dx32, dxq, dtype)
+    dx_ref = LP.conv2d_vjp(x, Wt, dy, s, pad, dtype)[0]
+    assert rel(dx32.numpy(), dx_ref) < EXACT
+    assert np.array_equal(dxq.numpy(), R(dx32.numpy()))
+    ops.conv2d_dgrad_lp_q(d, dyq, wqT, dx32, dxq, dtype, accumulate=True)
+    assert rel(dx32.numpy(), 2 * dx_ref) < EXACT
+    assert np.array_equal(dxq.numpy(), R(dx32.numpy()))
+    if ops.lp_q_direct(d, 1, dtype):
+        dxq2 = D.QTensor.empty(dev, x.shape, dtype)
+        ops.conv2d_dgrad_lp_q(d, dyq, wqT, None, dxq2, dtype)
+        assert rel(dxq2.numpy(), R(dx_ref.astype(np.float32))) < 2.0 ** -7
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_q_pooled_convolution_and_fused_activation_backward(gpu, dtype):
+    """conv + LeakyReLU + 2x2 max-pool from a q operand: pooled fp32, pooled q and the arg-max mask equal the fp32-input
+    form; the stride-2 data gradient with the producer's LeakyReLU backward in its epilogue writes dx as fp32 and q."""
+    dev, ops, D = gpu
+    R = LP.ROUND[dtype]
+    rng = np.random.RandomState(3)
+    N, C, H, W, K, k = 2, 32, 32, 64, 64, 5
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, k, k, 1, 2)
+    assert ops.conv_pool_supported(d, 'lrelu', dtype) == 2
+    xd, bd = dev.tensor(x), dev.tensor(b)
+    wq = dev.alloc(ops.lp_weight_bytes(d, False))
+    ops.lp_pack_weights(d, dev.tensor(D.pack_conv_w(Wt).ravel()), wq, dtype, False)
+    xq = D.QTensor.empty(dev, x.shape, dtype)
+    ops.q_pack(xd, xq)
+    pa, pb = dev.empty((N, K, H // 2, W // 2)), dev.empty((N, K, H // 2, W // 2))
+    ma, mb = dev.alloc(N * K * H * W // 4), dev.alloc(N * K * H * W // 4)
+    pq = D.QTensor.empty(dev, (N, K, H // 2, W // 2), dtype)
+    ops.conv2d_fwd_pool(d, xd, wq, bd, pa, ma, 'lrelu', 0.2, dtype)
+    ops.conv2d_fwd_pool_lp_q(d, xq, wq, bd, pb, pq, mb, 'lrelu', 0.2, dtype)
+    assert np.array_equal(pa.numpy(), pb.numpy())
+    assert np.array_equal(pq.numpy(), R(pa.numpy()))
+    m1, m2 = np.empty(N * K * H * W // 4, np.uint8), np.empty(N * K * H * W // 4, np.uint8)
+    dev.d2h(m1, ma, m1.nbytes)
+    dev.d2h(m2, mb, m2.nbytes)
+    assert np.array_equal(m1, m2)
+    pq2 = D.QTensor.empty(dev, (N, K, H // 2, W // 2), dtype)
+    ops.conv2d_fwd_pool_lp_q(d, xq, wq, bd, None, pq2, mb, 'lrelu', 0.2, dtype)      # q output alone
+    assert np.array_equal(pq2.numpy(), pq.numpy())
+    # stride-2 data gradient * lrelu'(y) with a q gradient operand
+    N, C, H, W, K = 8, 64, 64, 128, 64
+    d2 = D.conv_desc(N, C, H, W, K, 3, 3, 2, 1)
+    if ops.dgrad_dact_supported(d2, dtype) != 3:
+        pytest.skip("single-pass stride-2 data gradient not planned for this geometry")
+    Wt = (rng.randn(K, C, 3, 3) / np.sqrt(C * 9)).astype(np.float32)
+    dy = rng.randn(N, K, d2.Ho, d2.Wo).astype(np.float32)
+    y = rng.randn(N, C, H, W).astype(np.float32)
+    wqT = dev.alloc(ops.lp_weight_bytes(d2, True))
+    ops.lp_pack_weights(d2, dev.tensor(D.pack_conv_w(Wt).ravel()), wqT, dtype, True)
+    dyd, yd = dev.tensor(dy), dev.tensor(y)
+    dyq = D.QTensor.empty(dev, dy.shape, dtype)
+    ops.q_pack(dyd, dyq)
+    dxa, dxb = dev.empty(y.shape), dev.empty(y.shape)
+    dxq = D.QTensor.empty(dev, y.shape, dtype)
+    ops.conv2d_dgrad_dact(d2, dyd, wqT, dxa, yd, 'lrelu', 0.2, dtype)
+    ops.conv2d_dgrad_dact_lp_q(d2, dyq, wqT, dxb, dxq, yd, 'lrelu', 0.2, dtype)
+    assert np.array_equal(dxa.numpy(), dxb.numpy())
+    assert np.array_equal(dxq.numpy(), R(dxa.numpy()))
+    ref = LP.conv2d_vjp(np.zeros_like(y), Wt, dy, 2, 1, dtype)[0] * np.where(y > 0, 1.0, 0.2)
+    assert rel(dxa.numpy(), ref) < EXACT
