@@ -20,7 +20,7 @@ import numpy as np
 
 from . import layers as L
 from .architectures.layers import BilinearUpsample2DLayer
-from .device import DevTensor, Ops, conv_desc, pack_conv_w, unpack_conv_w
+from .device import DevTensor, Ops, QTensor, conv_desc, pack_conv_w, unpack_conv_w
 from .nonlinearities import linear
 
 ALIGN = 64      # elements; keeps every parameter 256-B aligned inside the flat buffers
@@ -300,6 +300,13 @@ class NetPlan:
         self._shapes()
         self._fuse_convpool()
         self._place(inputs or {}, out_tensor)
+        # q tensors (include/ghm.h): in the reduced-precision modes every tensor a low-precision product reads as an
+        # operand also exists as a bf16 / fp16 copy in channel-block-of-8 layout, written by its producer
+        self.use_q = self.dtype != 'f32' and os.environ.get("GHM_NO_Q") is None and hasattr(ops, 'q_pack')
+        for n in self.order:
+            n.outq = None
+        if self.use_q:
+            self._place_q()
         self._scratch = {}
         self.bn_ws = None
         cmax = max([n.shape[1] for n in self.order if n.op == 'bn'] + [0])
@@ -449,6 +456,39 @@ class NetPlan:
                     n.aux[name] = self.dev.empty((1, C * 9 * 4 * K, 1, 1))
                 n.aux['b4'] = self.dev.empty((1, 4 * K, 1, 1))
 
+    def _place_q(self):
+        """allocate the q copy of every node output that a low-precision forward product reads (the conv's input): the
+        same placement as the fp32 tensors -- inputs of a ConcatLayer are channel slices of the concat's q buffer"""
+        need = []
+        for n in self.order:
+            if n.op in ('conv', 'convpool'):
+                d = self._desc(n, n.inputs[0].out, self._full(n))
+            elif n.op == 'upconv':
+                d = self._upconv_desc(n, n.inputs[0].out)
+            else:
+                continue
+            if self._lp(d, 0) and n.inputs[0].shape[1] % 8 == 0:
+                need.append(n.inputs[0])
+
+        def get_outq(n):
+            if n.outq is not None:
+                return n.outq
+            if n.alias is not None:
+                cat, c0 = n.alias
+                if c0 % 8 == 0 and n.shape[1] % 8 == 0 and cat.shape[1] % 8 == 0:
+                    n.outq = get_outq(cat).channels(c0, c0 + n.shape[1])
+                    return n.outq
+            n.outq = QTensor.empty(self.dev, n.shape, self.dtype)
+            return n.outq
+
+        for n in need:
+            get_outq(n)
+            n.aux['q_whole'] = True
+            if n.op == 'concat':            # read as a whole: every input that lives inside it writes its q slice
+                for i in n.inputs:
+                    if i.alias is not None and i.alias[0] is n:
+                        get_outq(i)
+
     def input_tensor(self, layer):
         return self.node_of_layer[id(layer)].out
 
@@ -532,6 +572,7 @@ class NetPlan:
             prog.append(("collapse_w", lambda t=self._collapse_tab: ops.upconv_collapse_batched(t)))
         if self._lp_table is not None:
             prog.append(("lp_pack", lambda t=self._lp_table: ops.lp_pack_batched(t, self.dtype)))
+        qpack = lambda t, q: prog.append(("q_pack", lambda t=t, q=q: ops.q_pack(t, q)))
         for n in self.order:
             y = n.out
             if n.op in ('input', 'reshape', 'concat'):
@@ -541,18 +582,35 @@ class NetPlan:
                         if i.alias is None or i.alias[0] is not n:
                             dst = y.channels(c0, c0 + i.shape[1])
                             prog.append(("concat_copy", lambda a=i.out, b=dst: ops.copy_view(a, b)))
+                            if n.aux.get('q_whole'):
+                                qpack(dst, n.outq.channels(c0, c0 + i.shape[1]))
+                        elif n.aux.get('q_whole'):
+                            if i.outq is None or i.outq.base is not (n.outq.base if n.outq.base is not None else n.outq):
+                                raise NotImplementedError("ConcatLayer input at a channel offset that is not a multiple "
+                                                          "of 8 feeding a low-precision convolution")
                         c0 += i.shape[1]
+                elif n.aux.get('q_whole'):      # a net input / reshaped tensor that a low-precision product reads
+                    qpack(y, n.outq)
                 continue
             x = n.inputs[0].out
+            xq = n.inputs[0].outq
+            q_direct = False                # did the node's own kernel write n.outq?
             a = n.act
             if n.op in ('conv', 'dense'):
                 d = self._desc(n, x, y)
                 w, b = st.value(n.layer.W), st.value(n.layer.b)
                 if n.op == 'conv' and self._lp(d, 0):
                     wq = self._lp_pack_entry(prog, d, w, ('w', id(n.layer.W)), False, lp_done)
-                    prog.append(("conv_fwd", lambda d=d, x=x, wq=wq, b=b, y=y, a=a:
-                                 ops.conv2d_fwd_lp(d, x, wq, b, y, self.dtype, a.kind, a.alpha),
-                                 conv_meta(ops, d, 0, self.dtype)))
+                    if xq is not None:
+                        q_direct = n.outq is not None and ops.lp_q_direct(d, 0, self.dtype)
+                        yq = n.outq if q_direct else None
+                        prog.append(("conv_fwd", lambda d=d, xq=xq, wq=wq, b=b, y=y, yq=yq, a=a:
+                                     ops.conv2d_fwd_lp_q(d, xq, wq, b, y, yq, self.dtype, a.kind, a.alpha),
+                                     conv_meta(ops, d, 0, self.dtype)))
+                    else:
+                        prog.append(("conv_fwd", lambda d=d, x=x, wq=wq, b=b, y=y, a=a:
+                                     ops.conv2d_fwd_lp(d, x, wq, b, y, self.dtype, a.kind, a.alpha),
+                                     conv_meta(ops, d, 0, self.dtype)))
                 else:
                     prog.append(("%s_fwd" % n.op, lambda d=d, x=x, w=w, b=b, y=y, a=a:
                                  ops.conv2d_fwd(d, x, w, b, y, a.kind, a.alpha), conv_meta(ops, d, 0)))
@@ -564,9 +622,15 @@ class NetPlan:
                 wsrc, dt = w, 'f32'
                 if form == 2:
                     wsrc, dt = self._lp_pack_entry(prog, d, w, ('w', id(n.layer.W)), False, lp_done), self.dtype
-                prog.append(("convpool_fwd", lambda d=d, x=x, wsrc=wsrc, b=b, y=y, m=n.aux['mask'], a=a, dt=dt:
-                             ops.conv2d_fwd_pool(d, x, wsrc, b, y, m, a.kind, a.alpha, dt),
-                             conv_meta(ops, d, 0, dt, pooled=True)))
+                if form == 2 and xq is not None:
+                    q_direct = n.outq is not None
+                    prog.append(("convpool_fwd", lambda d=d, xq=xq, wsrc=wsrc, b=b, y=y, yq=n.outq, m=n.aux['mask'], a=a:
+                                 ops.conv2d_fwd_pool_lp_q(d, xq, wsrc, b, y, yq, m, a.kind, a.alpha, self.dtype),
+                                 conv_meta(ops, d, 0, dt, pooled=True)))
+                else:
+                    prog.append(("convpool_fwd", lambda d=d, x=x, wsrc=wsrc, b=b, y=y, m=n.aux['mask'], a=a, dt=dt:
+                                 ops.conv2d_fwd_pool(d, x, wsrc, b, y, m, a.kind, a.alpha, dt),
+                                 conv_meta(ops, d, 0, dt, pooled=True)))
             elif n.op == 'deconv':
                 d = self._desc(n, y, x)
                 w, b = st.value(n.layer.W), st.value(n.layer.b)
@@ -605,9 +669,14 @@ class NetPlan:
                 y4 = y.reshape((x.N, 4 * K, x.H, x.W))
                 if self._lp(d, 0):
                     wq = self._lp_pack_entry(prog, d, wpc, ('c', id(n.layer.W)), False, None)    # after collapse_w
-                    prog.append(("upconv_fwd", lambda d=d, x=x, wq=wq, b4=b4, y4=y4, a=a:
-                                 ops.conv2d_fwd_lp(d, x, wq, b4, y4, self.dtype, a.kind, a.alpha),
-                                 conv_meta(ops, d, 0, self.dtype)))
+                    if xq is not None:
+                        prog.append(("upconv_fwd", lambda d=d, xq=xq, wq=wq, b4=b4, y4=y4, a=a:
+                                     ops.conv2d_fwd_lp_q(d, xq, wq, b4, y4, None, self.dtype, a.kind, a.alpha),
+                                     conv_meta(ops, d, 0, self.dtype)))
+                    else:
+                        prog.append(("upconv_fwd", lambda d=d, x=x, wq=wq, b4=b4, y4=y4, a=a:
+                                     ops.conv2d_fwd_lp(d, x, wq, b4, y4, self.dtype, a.kind, a.alpha),
+                                     conv_meta(ops, d, 0, self.dtype)))
                 else:
                     prog.append(("upconv_fwd", lambda d=d, x=x, wpc=wpc, b4=b4, y4=y4, a=a:
                                  ops.conv2d_fwd(d, x, wpc, b4, y4, a.kind, a.alpha), conv_meta(ops, d, 0)))
@@ -631,6 +700,8 @@ class NetPlan:
                 prog.append(("avgpool_fwd", lambda x=x, y=y, p=n.attrs['p']: ops.avgpool_fwd(x, y, p)))
             else:
                 raise NotImplementedError(n.op)
+            if n.outq is not None and not q_direct:
+                qpack(y, n.outq)            # producers without a q epilogue of their own: one extra pass
 
     def emit_transposes(self, prog, transposed):
         """One launch that refreshes every transposed weight copy the data-gradient kernels of this net read
@@ -729,6 +800,35 @@ class NetPlan:
             if on_grads is not None and wgrad:
                 on_grads(prog, [p for p in params if p is not None])
 
+        gq_ready = set()        # nodes whose output-gradient q tensor was written by the kernel that produced the gradient
+
+        def gradq_of(n, G, pack=True):
+            """q copy of the (final) output gradient G of node n: the operand of its low-precision data / weight
+            gradient.  Written by G's producer where that kernel has a q epilogue, else packed here in one pass."""
+            if not self.use_q or G.Cc % 8:
+                return None
+            Gq = cache.get(('gq', id(n)))
+            if Gq is None:
+                Gq = cache[('gq', id(n))] = QTensor.empty(dev, G.shape, self.dtype)
+            if pack and id(n) not in gq_ready:
+                gq_ready.add(id(n))
+                prog.append(("q_pack", lambda G=G, Gq=Gq: ops.q_pack(G, Gq)))
+            return Gq
+
+        def fused_gq(xin, gi, acc):
+            """may the data-gradient kernel that writes gi (the gradient of xin's output) also write its q copy?  Only
+            when gi is final as written: single consumer, nothing accumulates into it, no activation backward runs on
+            it afterwards, and xin's own backward is a low-precision product that reads it."""
+            if not self.use_q or acc or xin.op != 'conv' or len(xin.consumers) != 1 or gi.Cc % 8:
+                return None
+            if xin.act != linear and not xin.aux.get(('grad_is_pre', key)):
+                return None
+            dq = self._desc(xin, sl(xin.inputs[0].out), gi)
+            if not (self._lp(dq, 1) or self._lp(dq, 2)):
+                return None
+            gq_ready.add(id(xin))
+            return gradq_of(xin, gi, pack=False)
+
         for n in reversed(self.order):
             if id(n) not in written or not req[id(n)]:
                 continue
@@ -817,10 +917,17 @@ class NetPlan:
                         else:
                             wsel, dt = self._lp_pack_entry(prog, d2, w, ('w', id(l.W)), True, transposed), self.dtype
                         xa = xin.act
-                        prog.append(("conv_dgrad", lambda d=d2, G=G, wsel=wsel, gi=gi, x=x, xa=xa, dt=dt:
-                                     ops.conv2d_dgrad_dact(d, G, wsel, gi, x, xa.kind, xa.alpha, dt),
-                                     conv_meta(ops, d2, 3 if form != 1 else 1, dt)))
                         xin.aux[('grad_is_pre', key)] = True
+                        Gq = gradq_of(n, G) if form == 3 else None
+                        if Gq is not None and ops.lp_q_direct(d2, 1, self.dtype):
+                            giq = fused_gq(xin, gi, acc)
+                            prog.append(("conv_dgrad", lambda d=d2, Gq=Gq, wsel=wsel, gi=gi, giq=giq, x=x, xa=xa:
+                                         ops.conv2d_dgrad_dact_lp_q(d, Gq, wsel, gi, giq, x, xa.kind, xa.alpha, self.dtype),
+                                         conv_meta(ops, d2, 3, dt)))
+                        else:
+                            prog.append(("conv_dgrad", lambda d=d2, G=G, wsel=wsel, gi=gi, x=x, xa=xa, dt=dt:
+                                         ops.conv2d_dgrad_dact(d, G, wsel, gi, x, xa.kind, xa.alpha, dt),
+                                         conv_meta(ops, d2, 3 if form != 1 else 1, dt)))
                     elif n.op == 'deconv':
                         d2 = self._desc(n, G, gi)
                         prog.append(("deconv_dgrad", lambda d=d2, G=G, w=w, gi=gi, acc=acc:
@@ -828,9 +935,18 @@ class NetPlan:
                     elif n.op in ('conv', 'convpool') and self._lp(self._desc(n, gi, G), 1):
                         d2 = self._desc(n, gi, G)
                         wqT = self._lp_pack_entry(prog, d2, w, ('w', id(l.W)), True, transposed)
-                        prog.append(("conv_dgrad", lambda d=d2, G=G, wqT=wqT, gi=gi, acc=acc:
-                                     ops.conv2d_dgrad_lp(d, G, wqT, gi, self.dtype, None, 'linear', 0.0, acc),
-                                     conv_meta(ops, d2, 3, self.dtype)))
+                        Gq = gradq_of(n, G)
+                        if Gq is not None:
+                            giq = fused_gq(xin, gi, acc) if ops.lp_q_direct(d2, 1, self.dtype) else None
+                            if giq is None:
+                                gq_ready.discard(id(xin))
+                            prog.append(("conv_dgrad", lambda d=d2, Gq=Gq, wqT=wqT, gi=gi, giq=giq, acc=acc:
+                                         ops.conv2d_dgrad_lp_q(d, Gq, wqT, gi, giq, self.dtype, None, 'linear', 0.0, acc),
+                                         conv_meta(ops, d2, 3, self.dtype)))
+                        else:
+                            prog.append(("conv_dgrad", lambda d=d2, G=G, wqT=wqT, gi=gi, acc=acc:
+                                         ops.conv2d_dgrad_lp(d, G, wqT, gi, self.dtype, None, 'linear', 0.0, acc),
+                                         conv_meta(ops, d2, 3, self.dtype)))
                     elif n.op in ('conv', 'convpool') and self._use_dgrad_t(self._desc(n, gi, G), l.W):
                         # data gradient as a forward-form conv on the transposed weights (LDS-patch kernels)
                         d2 = self._desc(n, gi, G)
@@ -880,9 +996,15 @@ class NetPlan:
                     gi, acc = target(xin)
                     if self._lp(d, 1):
                         wqT = self._lp_pack_entry(prog, d, wpc, ('c', id(l.W)), True, transposed)
-                        prog.append(("upconv_dgrad", lambda d=d, G4=G4, wqT=wqT, gi=gi, acc=acc:
-                                     ops.conv2d_dgrad_lp(d, G4, wqT, gi, self.dtype, None, 'linear', 0.0, acc),
-                                     conv_meta(ops, d, 3, self.dtype)))
+                        G4q = gradq_of(n, G4)
+                        if G4q is not None:
+                            prog.append(("upconv_dgrad", lambda d=d, G4q=G4q, wqT=wqT, gi=gi, acc=acc:
+                                         ops.conv2d_dgrad_lp_q(d, G4q, wqT, gi, None, self.dtype, None, 'linear', 0.0, acc),
+                                         conv_meta(ops, d, 3, self.dtype)))
+                        else:
+                            prog.append(("upconv_dgrad", lambda d=d, G4=G4, wqT=wqT, gi=gi, acc=acc:
+                                         ops.conv2d_dgrad_lp(d, G4, wqT, gi, self.dtype, None, 'linear', 0.0, acc),
+                                         conv_meta(ops, d, 3, self.dtype)))
                     elif C > 4 and ops.dgrad_t_supported(d):
                         if ('c', id(l.W)) not in transposed:
                             transposed.add(('c', id(l.W)))
