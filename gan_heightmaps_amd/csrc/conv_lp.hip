@@ -178,7 +178,7 @@ struct LpConvArgs {
     long dact_nstride;
     int dact;
     float dact_alpha;
-    int debug;                  // tuning only (GHM_ABLATE bits: 1 no patch loads after the first slab, 2 no MFMAs, 4 no stores)
+    int debug;                  // tuning only (GHM_ABLATE bits: 1 no patch loads after the first slab, 2 no MFMAs, 4 no stores, 8 no weight loads after the first tile)
 };
 
 template <int DT>
@@ -336,25 +336,44 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
         const bool next_slab = (s + 1) < s_end;
         for (int fa = 0; fa < KS; ++fa, ++it) {
             const int wbuf = it & 1;
-            if (fa + 1 < KS)
-                stage_weights(s, fa + 1, wbuf ^ 1);
-            else if (next_slab)
-                stage_weights(s + 1, 0, wbuf ^ 1);
+            if (!(a.debug & 8)) {
+                if (fa + 1 < KS)
+                    stage_weights(s, fa + 1, wbuf ^ 1);
+                else if (next_slab)
+                    stage_weights(s + 1, 0, wbuf ^ 1);
+            }
             if (fa == 0 && next_slab && !(a.debug & 1)) stage_patch(pbuf ^ 1);
             const u32x4* Wb = Wl + wbuf * WUNITS + wlane;
             const u32x4* Pb = Pl + pbuf * PUNITS + plane + fa * PW;
-            if (!(a.debug & 2))
+            if (!(a.debug & 2)) {
+                // fragments are read one filter column ahead of their MFMAs (the compiler, left alone, sinks every read to
+                // just before its use and the wave then eats the full LDS latency once per k-step: 54 % of the MFMA rate)
+                u32x4 af[2][TM], bf[2][TN];
 #pragma unroll
-            for (int b = 0; b < KS; ++b) {
-                u32x4 af[TM], bf[TN];
+                for (int i = 0; i < TM; ++i) af[0][i] = Wb[i * 32];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = Wb[b * BM + i * 32];
+                for (int j = 0; j < TN; ++j) bf[0][j] = Pb[j * RPF * ST * PW];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = Pb[j * RPF * ST * PW + b];
+                for (int b = 0; b < KS; ++b) {
+                    if (b + 1 < KS) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                        for (int i = 0; i < TM; ++i) af[(b + 1) & 1][i] = Wb[(b + 1) * BM + i * 32];
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = Lp<DT>::mfma(af[i], bf[j], acc[i][j]);
+                        for (int j = 0; j < TN; ++j) bf[(b + 1) & 1][j] = Pb[j * RPF * ST * PW + b + 1];
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = Lp<DT>::mfma(af[b & 1][i], bf[b & 1][j], acc[i][j]);
+                    if (b + 1 < KS) {                       // one of the next column's reads behind each of this column's MFMAs
+#pragma unroll
+                        for (int m_ = 0; m_ < TM + TN; ++m_) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // keep the one-column lead
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();

@@ -20,6 +20,9 @@ def main():
                     help="untimed warm-up: the GPU idles at ~160 MHz and takes milliseconds to reach its 2.4 GHz "
                          "shader clock, a 20-launch measurement from idle under-reports by 5-10 %%")
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    ap.add_argument("--q", default="", choices=["", "f32", "q", "both"],
+                    help="low-precision kinds through the *_q entry points: operands are pre-packed q tensors, the "
+                         "result is written as fp32, as a q tensor, or both")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
                     help="bf16 / f16: the *_lp entry points (kinds fwd, dgrad_t, wgrad)")
     args = ap.parse_args()
@@ -57,6 +60,16 @@ def main():
             fns["dgrad_t"] = lambda: ops.conv2d_dgrad_lp(d, y, wqT, dx, dt)
         if ops.lp_supported(d, 2, dt):
             fns["wgrad"] = lambda: ops.conv2d_wgrad_lp(d, x, y, dw, ws_lp, dt)
+        if args.q:
+            xq, yq, dxq = (D.QTensor.empty(dev, t.shape, dt) for t in (x, y, dx))
+            ops.q_pack(x, xq)
+            ops.q_pack(y, yq)
+            o32 = args.q in ("f32", "both")
+            oq = args.q in ("q", "both")
+            if "fwd" in fns:
+                fns["fwd"] = lambda: ops.conv2d_fwd_lp_q(d, xq, wq, b, y if o32 else None, yq if oq else None, dt, 'lrelu', 0.2)
+            if "dgrad_t" in fns:
+                fns["dgrad_t"] = lambda: ops.conv2d_dgrad_lp_q(d, yq, wqT, dx if o32 else None, dxq if oq else None, dt)
         fns["pack"] = lambda: ops.lp_pack_weights(d, w, wq, dt, False)
         fns["pack_t"] = lambda: ops.lp_pack_weights(d, w, wqT, dt, True)
     for i, kind in enumerate(args.kinds.split(",")):
