@@ -71,6 +71,7 @@ SIGNATURES = {
     "ghm_conv2d_fwd_lp_q": [_p, _D, _p, _i64, _p, _p, _p, _p, _i64, _i32, _f, _i32, _i32],
     "ghm_conv2d_dgrad_lp_q": [_p, _D, _p, _i64, _p, _p, _p, _p, _i64, _i32, _f, _i32, _i32],
     "ghm_conv2d_dgrad_dact_lp_q": [_p, _D, _p, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _f, _i32],
+    "ghm_conv2d_wgrad_lp_q": [_p, _D, _p, _i64, _p, _i64, _p, _p, _i32, _i32],
     "ghm_conv2d_fwd_pool_lp_q": [_p, _D, _p, _i64, _p, _p, _p, _p, _i64, _p, _i32, _f, _i32],
     "ghm_maxpool2_mask_bwd": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f],
     "ghm_maxpool2_mask_bwd_bias": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f, _p, _i32],
@@ -123,7 +124,8 @@ _SPECIAL = {"ghm_last_error": ([], C.c_char_p), "ghm_bn_workspace": ([_i32], C.c
             "ghm_dgrad_t_supported": ([_D], C.c_int), "ghm_lp_supported": ([_D, _i32, _i32], C.c_int),
             "ghm_conv2d_pool_supported": ([_D, _i32, _i32], C.c_int),
             "ghm_dgrad_dact_supported": ([_D, _i32], C.c_int),
-            "ghm_lp_q_direct": ([_D, _i32, _i32], C.c_int)}
+            "ghm_lp_q_direct": ([_D, _i32, _i32], C.c_int),
+            "ghm_lp_wgrad_q_supported": ([_D, _i32], C.c_int)}
 
 _lib = None
 

@@ -886,6 +886,185 @@ __global__ __launch_bounds__(256, 2) void lp_wgrad_kernel(const LpWgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight gradient of a 3x3 convolution (stride 1 or 2, pad 1) from q tensors: dwp[(c, tap)][k] = sum over pixels of
+// x[c, pixel * ST + tap - 1] * dy[k, pixel].  The contraction runs over pixels while a q unit holds 8 CHANNELS of one
+// pixel, so both MFMA operands are read from LDS with the transposing read ds_read_b64_tr_b16 (lane t of a 16-lane
+// group supplies the address of 4 channels of pixel t / 4; it receives channel t of 4 consecutive pixels):
+//   x image   [ring row][channel half][column parity (ST = 2)][pixel][32 channels]     (64 B per pixel)
+//   dy image  [buffer][filter tile][pixel][32 filters]                                  (64 B per pixel)
+// both staged global -> LDS by DMA as they lie in HBM (no conversion, no im2col expansion: a tap is an address offset).
+// Block = 8 waves: CHT groups of 32 channels x CT tiles of 32 filters (CHT * CT = 8); a wave owns the nine taps of one
+// (channel group, filter tile) = 9 accumulator tiles.  A block walks down ONE column strip of SPX output pixels, one
+// output row per slab; the x rows live in a ring (each slab brings ST new rows), the dy strip is double-buffered.
+// ------------------------------------------------------------------------------------------------
+struct LpWgradQArgs {
+    const u32x4* xq;
+    long xq_ns;            // units between samples of x  [N][C/8][H][W]
+    const u32x4* dyq;
+    long dyq_ns;           // units between samples of dy [N][K/8][Ho][Wo]
+    const u32x4* zeros;
+    float* out;
+    int N, C, H, W, K, Ho, Wo;
+    int rows_per_split, splits_per_col;
+    long split_stride;
+    int accumulate;
+    int debug;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4 lp_tr_read8(const char* lds_lo, const char* lds_hi) {
+    typedef s16x4 __attribute__((address_space(3))) * lp4_t;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4_t)lds_lo);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4_t)lds_hi);
+    u32x4 r;
+    r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+    r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+    r.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+    r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+    return r;
+}
+
+template <int DT, int ST, int CHT, int CT, int SPX>
+__global__ __launch_bounds__(512, 1) void lp_wgrad_q_kernel(const LpWgradQArgs a) {
+    static_assert(CHT * CT == 8 && (ST == 1 || ST == 2) && (SPX == 64 || SPX == 32), "8 waves");
+    constexpr int T = 9;
+    constexpr int NPAR = ST;                          // column-parity planes of an x row
+    constexpr int XPIX = ST == 1 ? SPX + 2 : SPX + 1; // pixels per plane: local columns 0 .. SPX*ST (+1): [xs0, xs0 + SPX*ST + 1]
+    constexpr int XCH = (XPIX + 15) / 16;             // 16-pixel DMA pieces per plane
+    constexpr int PLB = XCH * 16 * 64;                // bytes per plane
+    constexpr int ROWB = CHT * NPAR * PLB;            // bytes per ring row
+    constexpr int NR = 3 + ST;                        // ring rows: 3 live + ST arriving
+    constexpr int YTB = SPX * 64;                     // bytes per dy filter tile
+    constexpr int YB = CT * YTB;                      // bytes per dy buffer
+    constexpr int KSTEPS = SPX / 16;
+    __shared__ __attribute__((aligned(16))) char smem[NR * ROWB + 2 * YB];
+    char* const Xl = smem;
+    char* const Yl = smem + NR * ROWB;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = wave / CT, ww = wave % CT;         // this wave's channel group / filter tile
+    const int kg = lane >> 5, li = lane & 31;
+    const int c0 = blockIdx.x * (32 * CHT), k0 = blockIdx.y * (32 * CT);
+    const int strips = a.Wo / SPX;
+    const int col = blockIdx.z / a.splits_per_col, sp = blockIdx.z - col * a.splits_per_col;
+    const int n = col / strips, j0 = (col - n * strips) * SPX;
+    const int i_begin = sp * a.rows_per_split, i_end = min(a.Ho, i_begin + a.rows_per_split);
+    const int HWx = a.H * a.W, HWy = a.Ho * a.Wo;
+    const int xs0 = j0 * ST - 1;                      // image column of local column 0
+
+    // DMA lane roles inside a 16-pixel piece: pixel pxi, channel block cb4 of the 32-channel group
+    const int pxi = lane >> 2, cb4 = lane & 3;
+    const u32x4* const xbase = a.xq + (long)n * a.xq_ns + (long)(c0 / 8 + cb4) * HWx;
+    const u32x4* const ybase = a.dyq + (long)n * a.dyq_ns + (long)(k0 / 8 + cb4) * HWy;
+
+    // bring image row y of x (all channel groups, parities) into ring slot (y + NR) % NR; rows outside the image are zero
+    auto stage_xrow = [&](int y) {
+        const int slot = (y + NR) % NR;
+        const bool rok = (unsigned)y < (unsigned)a.H;
+#pragma unroll
+        for (int p0 = 0; p0 < CHT * NPAR * XCH; p0 += 8) {
+            const int p = p0 + wave;
+            if (p < CHT * NPAR * XCH) {
+                const int pl = p / XCH, ch = p - pl * XCH;        // plane = (channel group, parity)
+                const int g = pl / NPAR, par = pl - g * NPAR;
+                const int pp = ch * 16 + pxi;                        // pixel inside the plane
+                const int x = xs0 + (ST == 2 ? 2 * pp + par : pp);
+                const bool ok = rok && (unsigned)x < (unsigned)a.W;
+                const u32x4* src = ok ? xbase + (long)(g * 4) * HWx + (long)y * a.W + x : a.zeros;
+                if (pp < XPIX)
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xl + slot * ROWB + pl * PLB + ch * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_dy = [&](int i, int buf) {
+#pragma unroll
+        for (int p0 = 0; p0 < CT * (SPX / 16); p0 += 8) {
+            const int p = p0 + wave;
+            if (p < CT * (SPX / 16)) {
+                const int ct = p / (SPX / 16), ch = p - ct * (SPX / 16);
+                const u32x4* src = ybase + (long)(ct * 4) * HWy + (long)i * a.Wo + j0 + ch * 16 + pxi;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Yl + buf * YB + ct * YTB + ch * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    if (i_begin < i_end) {
+        // cold start: the three x rows of the first output row, its dy strip
+#pragma unroll
+        for (int fa = 0; fa < 3; ++fa) stage_xrow(i_begin * ST + fa - 1);
+        stage_dy(i_begin, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // fragment addressing (transposing reads): 16-lane group g16 -> rows (channels / filters) 16 * (g16 & 1) .. + 15;
+    // lane t of the group supplies the address of pixel key = t >> 2, channel quad t & 3
+    const int g16 = lane >> 4, lt = lane & 15;
+    const int key = lt >> 2, quad = lt & 3;
+    const int lane_off = (8 * kg + key) * 64 + (g16 & 1) * 32 + quad * 8;      // + 4 pixels (256 B) for the upper half
+    const char* const ylane = Yl + ww * YTB + lane_off;
+    const char* const xlane = Xl + hh * NPAR * PLB + lane_off;
+
+    for (int i = i_begin; i < i_end; ++i) {
+        const int buf = (i - i_begin) & 1;
+        if (i + 1 < i_end && !(a.debug & 1)) {
+#pragma unroll
+            for (int r = 0; r < ST; ++r) stage_xrow((i + 1) * ST + 2 - ST + r);     // the rows the next slab adds
+            stage_dy(i + 1, buf ^ 1);
+        }
+        const char* xr[3];
+#pragma unroll
+        for (int fa = 0; fa < 3; ++fa) xr[fa] = xlane + ((i * ST + fa - 1 + NR) % NR) * ROWB;
+        const char* const yb = ylane + buf * YB;
+        if (!(a.debug & 2))
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const u32x4 bf = lp_tr_read8(yb + ks * 1024, yb + ks * 1024 + 256);
+#pragma unroll
+            for (int fa = 0; fa < 3; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < 3; ++fb) {
+                    // local column of pixel t' and tap column fb: t' * ST + fb  ->  (parity plane, pixel in plane)
+                    const int par = ST == 2 ? (fb & 1) : 0;
+                    const int shift = ST == 2 ? (fb >> 1) : fb;
+                    const char* pa = xr[fa] + par * PLB + (ks * 16 + shift) * 64;
+                    const u32x4 af = lp_tr_read8(pa, pa + 256);
+                    acc[fa * 3 + fb] = Lp<DT>::mfma(af, bf, acc[fa * 3 + fb]);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = filter k0 + 32 ww + li; rows = channels c0 + 32 hh + (e & 3) + 8 (e >> 2) + 4 kg ----
+    if (a.debug & 4) return;
+    float* const ob = a.out + (long)blockIdx.z * a.split_stride;
+    const int kcol = k0 + ww * 32 + li;
+    if (kcol >= a.K) return;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = c0 + hh * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+            if (c < a.C) {
+                float* o = ob + ((long)c * T + t) * a.K + kcol;
+                float v = acc[t][e];
+                if (a.accumulate) v += *o;
+                *o = v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 namespace {
@@ -1133,6 +1312,74 @@ int lp_launch_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const LpWPlan& v, cons
     }
 #undef GHM_LPW_CASE
     if (v.splits > 1) return ghm_reduce_splits(ctx, (const float*)workspace, v.splits, n, n, dwp, accumulate);
+    return 0;
+}
+
+// ---- weight gradient from q tensors (lp_wgrad_q_kernel): 3x3, pad 1, stride 1 / 2 ----
+struct LpWQPlan {
+    bool ok;
+    int cht, ct, spx, splits_per_col, rows_per_split, ncols;
+};
+
+LpWQPlan lp_wqplan(const ghm_conv_desc* d, int num_cu) {
+    LpWQPlan v;
+    v.ok = false;
+    if (GHM_OPT("GHM_NO_LP") || GHM_OPT("GHM_NO_LP_WGRAD") || GHM_OPT("GHM_NO_LP_WGRAD_Q")) return v;
+    if (!(d->kh == 3 && d->kw == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2))) return v;
+    if (d->Ho != (d->H + d->stride - 1) / d->stride || d->Wo != (d->W + d->stride - 1) / d->stride) return v;
+    if (d->Wo % 32 || d->C % 8 || d->K % 8) return v;
+    if (d->K % 128 == 0 && d->C % 64 == 0) { v.cht = 2; v.ct = 4; }
+    else if (d->stride == 1 && d->K % 64 == 0 && d->C % 128 == 0) { v.cht = 4; v.ct = 2; }
+    else return v;
+    v.spx = d->Wo % 64 == 0 ? 64 : 32;
+    v.ncols = d->N * (d->Wo / v.spx);
+    const long tiles = (long)(d->C / (32 * v.cht)) * (d->K / (32 * v.ct)) * v.ncols;
+    long S = (2L * num_cu + tiles - 1) / tiles;              // about two rounds of one block per CU
+    if (const char* f = GHM_OPT("GHM_LP_WGRAD_SPLITS")) S = atol(f);
+    const long max_by_work = d->Ho / 4 > 0 ? d->Ho / 4 : 1;   // at least 4 output rows per split (3 x rows of cold start)
+    if (S > max_by_work) S = max_by_work;
+    if (S < 1) S = 1;
+    v.rows_per_split = (int)((d->Ho + S - 1) / S);
+    v.splits_per_col = (d->Ho + v.rows_per_split - 1) / v.rows_per_split;
+    v.ok = true;
+    return v;
+}
+
+template <int DT>
+int lp_launch_wgrad_q(ghm_ctx* ctx, const ghm_conv_desc* d, const LpWQPlan& v, const void* xq, long xq_ns, const void* dyq,
+                      long dyq_ns, float* dwp, void* workspace, int accumulate) {
+    LpWgradQArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xq = (const u32x4*)xq; a.xq_ns = xq_ns; a.dyq = (const u32x4*)dyq; a.dyq_ns = dyq_ns;
+    a.zeros = (const u32x4*)ctx->zeros;
+    a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.K = d->K; a.Ho = d->Ho; a.Wo = d->Wo;
+    a.rows_per_split = v.rows_per_split; a.splits_per_col = v.splits_per_col;
+    if (const char* f = GHM_OPT("GHM_ABLATE")) a.debug = atoi(f);
+    const long n = (long)d->C * 9 * d->K;
+    const int splits = v.ncols * v.splits_per_col;
+    if (splits > 1) {
+        GHM_CHECK(workspace != nullptr, "lp wgrad (q) needs a workspace for %d splits", splits);
+        a.out = (float*)workspace; a.split_stride = n; a.accumulate = 0;
+    } else {
+        a.out = dwp; a.split_stride = 0; a.accumulate = accumulate;
+    }
+    const dim3 grid(d->C / (32 * v.cht), d->K / (32 * v.ct), splits);
+#define GHM_LPWQ_CASE(ST_, CHT_, CT_, SPX_)                                                                              \
+    if (d->stride == ST_ && v.cht == CHT_ && v.ct == CT_ && v.spx == SPX_) {                                           \
+        hipLaunchKernelGGL((lp_wgrad_q_kernel<DT, ST_, CHT_, CT_, SPX_>), grid, dim3(512), 0, ctx->stream, a);         \
+        GHM_LAUNCH_CHECK();                                                                                            \
+    } else
+    GHM_LPWQ_CASE(1, 2, 4, 64)
+    GHM_LPWQ_CASE(1, 2, 4, 32)
+    GHM_LPWQ_CASE(1, 4, 2, 64)
+    GHM_LPWQ_CASE(1, 4, 2, 32)
+    GHM_LPWQ_CASE(2, 2, 4, 64)
+    GHM_LPWQ_CASE(2, 2, 4, 32) {
+        ghm_set_error("no lp_wgrad_q variant for s=%d cht=%d ct=%d spx=%d", d->stride, v.cht, v.ct, v.spx);
+        return -3;
+    }
+#undef GHM_LPWQ_CASE
+    if (splits > 1) return ghm_reduce_splits(ctx, (const float*)workspace, splits, n, n, dwp, accumulate);
     return 0;
 }
 
@@ -1430,8 +1677,25 @@ int ghm_conv2d_fwd_pool_lp_q(ghm_ctx* ctx, const ghm_conv_desc* d, const void* x
 int ghm_conv2d_wgrad_lp_workspace(const ghm_conv_desc* d, size_t* bytes) {
     const LpWPlan v = lp_wplan(d, ghm_plan_cus());
     const size_t n = (size_t)d->C * d->kh * d->kw * d->K;
-    *bytes = (v.ok && v.splits > 1) ? (size_t)v.splits * n * sizeof(float) : 16;
+    size_t b = (v.ok && v.splits > 1) ? (size_t)v.splits * n * sizeof(float) : 16;
+    const LpWQPlan q = lp_wqplan(d, ghm_plan_cus());          // the q-operand kernel splits by column strips
+    if (q.ok && (size_t)q.ncols * q.splits_per_col * n * sizeof(float) > b) b = (size_t)q.ncols * q.splits_per_col * n * sizeof(float);
+    *bytes = b;
     return 0;
+}
+
+int ghm_lp_wgrad_q_supported(const ghm_conv_desc* d, int32_t dtype) {
+    return (dtype == GHM_DTYPE_BF16 || dtype == GHM_DTYPE_F16) && lp_wqplan(d, ghm_plan_cus()).ok;
+}
+
+int ghm_conv2d_wgrad_lp_q(ghm_ctx* ctx, const ghm_conv_desc* d, const void* xq, int64_t xq_nstride, const void* dyq,
+                          int64_t dyq_nstride, float* dwp, void* workspace, int32_t accumulate, int32_t dtype) {
+    GHM_CHECK(ghm_lp_wgrad_q_supported(d, dtype), "ghm_conv2d_wgrad_lp_q: geometry / dtype not served (ask ghm_lp_wgrad_q_supported)");
+    GHM_CHECK((((uintptr_t)xq | (uintptr_t)dyq) & 15) == 0, "ghm_conv2d_wgrad_lp_q: q tensors are 16-byte aligned");
+    const LpWQPlan v = lp_wqplan(d, ghm_plan_cus());
+    return dtype == GHM_DTYPE_BF16
+               ? lp_launch_wgrad_q<GHM_DTYPE_BF16>(ctx, d, v, xq, (long)xq_nstride, dyq, (long)dyq_nstride, dwp, workspace, accumulate)
+               : lp_launch_wgrad_q<GHM_DTYPE_F16>(ctx, d, v, xq, (long)xq_nstride, dyq, (long)dyq_nstride, dwp, workspace, accumulate);
 }
 
 int ghm_conv2d_wgrad_lp(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* dy, float* dwp,

@@ -478,6 +478,13 @@ class Ops:
              C.c_void_p(dxq.ptr if dxq is not None else 0), dxq.nstride if dxq is not None else 0, _vp(y), y.nstride,
              ACT_CODES[act], alpha, DTYPE_CODES[dtype])
 
+    def lp_wgrad_q_supported(self, d, dtype):
+        return bool(_lib.load().ghm_lp_wgrad_q_supported(C.byref(d), DTYPE_CODES[dtype]))
+
+    def conv2d_wgrad_lp_q(self, d, xq, dyq, dwp, ws, dtype, accumulate=False):
+        call("ghm_conv2d_wgrad_lp_q", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, C.c_void_p(dyq.ptr), dyq.nstride,
+             _vp(dwp), _vp(ws), int(accumulate), DTYPE_CODES[dtype])
+
     def conv2d_fwd_pool_lp_q(self, d, xq, wq, bias, pooled, pooledq, mask_ptr, act, alpha, dtype):
         call("ghm_conv2d_fwd_pool_lp_q", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, _vp(wq), _vp(bias), _vp(pooled),
              C.c_void_p(pooledq.ptr if pooledq is not None else 0), pooledq.nstride if pooledq is not None else 0,

@@ -871,6 +871,14 @@ class NetPlan:
                     d = self._desc(n, G, x)          # conv input side = deconv output grad, output side = x
                 else:
                     d = self._desc(n, x, G)
+                # the q copy of the output gradient, for the low-precision weight gradient (before its stream forks off)
+                xq = None if (nslice is not None and xin.outq is None) else (xin.outq if nslice is None else
+                                                                             (xin.outq.samples(n0, n1) if xin.outq is not None else None))
+                # (stride 2 stays on the register-staged kernel: measured 290 / 321 TFLOP/s against 203 / 258 for the q form,
+                # whose two new x rows of twice the width per slab make it DMA-issue-bound; stride 1: 267-474 -> 594-666)
+                wq_form = (wgrad and n.op in ('conv', 'convpool') and self.use_q and xq is not None and self._lp(d, 2)
+                           and d.stride == 1 and ops.lp_wgrad_q_supported(d, self.dtype))
+                Gq_w = gradq_of(n, G) if wq_form else None
                 if wgrad:
                     self._need_wgrad_ws(d)
                     gw, gb = st.grad(l.W), st.grad(l.b)
@@ -879,7 +887,11 @@ class NetPlan:
                     if self.side is not None:
                         wdev, wo = self.side
                         prog.append(("fork", lambda wdev=wdev: wdev.wait_for(dev), None, wdev))
-                    if n.op == 'deconv':
+                    if Gq_w is not None:
+                        prog.append(("conv_wgrad", lambda d=d, xq=xq, Gq=Gq_w, gw=gw, aw=aw, wo=wo:
+                                     wo.conv2d_wgrad_lp_q(d, xq, Gq, gw, self.wgrad_ws, self.dtype, aw),
+                                     conv_meta(ops, d, 2, self.dtype), wdev))
+                    elif n.op == 'deconv':
                         prog.append(("deconv_wgrad", lambda d=d, G=G, x=x, gw=gw, aw=aw, wo=wo:
                                      wo.conv2d_wgrad(d, G, x, gw, self.wgrad_ws, aw), conv_meta(ops, d, 2), wdev))
                     elif n.op in ('conv', 'convpool') and self._lp(d, 2):
@@ -971,6 +983,9 @@ class NetPlan:
                 C, K = x.Cc, n.shape[1]
                 G4 = G.reshape((x.N, 4 * K, x.H, x.W))
                 wpc, wpcT, dwpc = n.aux['wpc'], n.aux['wpcT'], n.aux['dwpc']
+                xq = xin.outq
+                G4q_w = gradq_of(n, G4) if (wgrad and self.use_q and xq is not None and self._lp(d, 2)
+                                            and ops.lp_wgrad_q_supported(d, self.dtype)) else None
                 if wgrad:
                     self._need_wgrad_ws(d)
                     gw, gb = st.grad(l.W), st.grad(l.b)
@@ -979,7 +994,11 @@ class NetPlan:
                     if self.side is not None:
                         wdev, wo = self.side
                         prog.append(("fork", lambda wdev=wdev: wdev.wait_for(dev), None, wdev))
-                    if self._lp(d, 2):
+                    if G4q_w is not None:
+                        prog.append(("upconv_wgrad", lambda d=d, xq=xq, G4q=G4q_w, dwpc=dwpc, wo=wo:
+                                     wo.conv2d_wgrad_lp_q(d, xq, G4q, dwpc, self.wgrad_ws, self.dtype, False),
+                                     conv_meta(ops, d, 2, self.dtype), wdev))
+                    elif self._lp(d, 2):
                         prog.append(("upconv_wgrad", lambda d=d, x=x, G4=G4, dwpc=dwpc, wo=wo:
                                      wo.conv2d_wgrad_lp(d, x, G4, dwpc, self.wgrad_ws, self.dtype, False),
                                      conv_meta(ops, d, 2, self.dtype), wdev))

@@ -70,6 +70,8 @@ def main():
                 fns["fwd"] = lambda: ops.conv2d_fwd_lp_q(d, xq, wq, b, y if o32 else None, yq if oq else None, dt, 'lrelu', 0.2)
             if "dgrad_t" in fns:
                 fns["dgrad_t"] = lambda: ops.conv2d_dgrad_lp_q(d, yq, wqT, dx if o32 else None, dxq if oq else None, dt)
+            if ops.lp_wgrad_q_supported(d, dt):
+                fns["wgrad"] = lambda: ops.conv2d_wgrad_lp_q(d, xq, yq, dw, ws_lp, dt)
         fns["pack"] = lambda: ops.lp_pack_weights(d, w, wq, dt, False)
         fns["pack_t"] = lambda: ops.lp_pack_weights(d, w, wqT, dt, True)
     for i, kind in enumerate(args.kinds.split(",")):
