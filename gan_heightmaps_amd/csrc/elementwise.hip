@@ -1139,6 +1139,32 @@ int ghm_bn_forward(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t y
     return ghm_bn_apply(ctx, x, xs, y, ys, N, C, HW, mean, inv, gamma, beta, act, alpha);
 }
 
+// the reduction passes of the BatchNorm backward: dgamma / dbeta and, in the workspace tail, the two per-channel sums the
+// apply pass needs (shared with elementwise_q.hip)
+int ghm_bn_backward_sums(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y, int64_t ys, const float* x, int64_t xs,
+                         int32_t N, int32_t C, int32_t HW, const float* mean, const float* inv, float* dgamma, float* dbeta,
+                         int32_t act, float alpha, int32_t accumulate, void* ws) {
+    const long count = (long)N * HW;
+    int S = bn_split(C, count), seg_len = 0;
+    double* wsd = (double*)ws;
+    float* sums = (float*)((char*)ws + (size_t)C * BN_MAX_SPLIT * 2 * sizeof(double));
+    const bool vec = HW % 4 == 0 && ds % 4 == 0 && ys % 4 == 0 && xs % 4 == 0 && aligned16(dout) && aligned16(y) && aligned16(x);
+    const int segs = vec ? bn_row_segs(N, C, HW, &seg_len) : 0;
+    if (segs > 0) {
+        S = N * segs;
+        hipLaunchKernelGGL((bn_rows_partial<true>), dim3(S, C), dim3(256), 0, ctx->stream, x, (long)xs, dout, (long)ds, y,
+                           (long)ys, HW, segs, seg_len, mean, inv, act, alpha, wsd);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_partial, dim3(S, C), dim3(256), 0, ctx->stream, dout, (long)ds, y, (long)ys, x, (long)xs, N,
+                           HW, S, mean, inv, act, alpha, wsd);
+    }
+    GHM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_final, dim3(ceil_div(C, 256)), dim3(256), 0, ctx->stream, (const double*)wsd, C, S, sums,
+                       dgamma, dbeta, accumulate);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
 int ghm_bn_backward(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y, int64_t ys, const float* x, int64_t xs,
                     float* dx, int64_t dxs, int32_t N, int32_t C, int32_t HW, const float* mean, const float* inv,
                     const float* gamma, float* dgamma, float* dbeta, int32_t act, float alpha, int32_t accumulate,
@@ -1155,24 +1181,11 @@ int ghm_bn_backward(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y,
         GHM_LAUNCH_CHECK();
         return 0;
     }
-    int S = bn_split(C, count), seg_len = 0;
-    double* wsd = (double*)ws;
-    float* sums = (float*)((char*)ws + (size_t)C * BN_MAX_SPLIT * 2 * sizeof(double));
+    if (int e = ghm_bn_backward_sums(ctx, dout, ds, y, ys, x, xs, N, C, HW, mean, inv, dgamma, dbeta, act, alpha, accumulate, ws))
+        return e;
+    const float* sums = (const float*)((char*)ws + (size_t)C * BN_MAX_SPLIT * 2 * sizeof(double));
     const bool vec = HW % 4 == 0 && ds % 4 == 0 && ys % 4 == 0 && xs % 4 == 0 && dxs % 4 == 0 && aligned16(dout) &&
                      aligned16(y) && aligned16(x) && aligned16(dx);
-    const int segs = vec ? bn_row_segs(N, C, HW, &seg_len) : 0;
-    if (segs > 0) {
-        S = N * segs;
-        hipLaunchKernelGGL((bn_rows_partial<true>), dim3(S, C), dim3(256), 0, ctx->stream, x, (long)xs, dout, (long)ds, y,
-                           (long)ys, HW, segs, seg_len, mean, inv, act, alpha, wsd);
-    } else {
-        hipLaunchKernelGGL(bn_bwd_partial, dim3(S, C), dim3(256), 0, ctx->stream, dout, (long)ds, y, (long)ys, x, (long)xs, N,
-                           HW, S, mean, inv, act, alpha, wsd);
-    }
-    GHM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_final, dim3(ceil_div(C, 256)), dim3(256), 0, ctx->stream, (const double*)wsd, C, S, sums,
-                       dgamma, dbeta, accumulate);
-    GHM_LAUNCH_CHECK();
     const View v{N, C, HW};
     if (vec) {
         hipLaunchKernelGGL((bn_bwd_apply<4>), EW_GRID((long)N * C * (HW / 4)), dout, (long)ds, y, (long)ys, x, (long)xs, dx,

@@ -1,0 +1,309 @@
+// Element-wise producers with a q-tensor epilogue (include/ghm.h "q tensors"): the reduced-precision modes keep a bf16 /
+// fp16 copy of every tensor a low-precision product reads, in channel-block-of-8 layout, written by the kernel that
+// produces the tensor -- not by a conversion pass of its own.  A q unit is the 8 channels of one pixel, so these kernels
+// give one thread a channel BLOCK of 8 for one or two pixels: eight coalesced fp32 plane accesses, one 16-byte unit
+// store per pixel.  The fp32 result is optional: where every consumer reads the q copy it is never written.
+// (BatchNormLayer / BilinearUpsample2DLayer / MaxPool2DLayer backward / the parity interleave of the collapsed
+// up-sample convolutions: architectures/dcgan.py:17-31,42-47, architectures/p2p.py:146-268, architectures/layers.py:13-26.)
+#include "common.h"
+
+typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
+typedef float f32x2q __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2q __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2q __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ __forceinline__ unsigned q_pack2(float a, float b, int dt) {
+    const f32x2q v = {a, b};
+    return dt == GHM_DTYPE_BF16 ? __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2q))
+                                : __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2q));
+}
+__device__ __forceinline__ u32x4q q_pack8(const float* v, int dt) {
+    u32x4q w;
+    w.x = q_pack2(v[0], v[1], dt);
+    w.y = q_pack2(v[2], v[3], dt);
+    w.z = q_pack2(v[4], v[5], dt);
+    w.w = q_pack2(v[6], v[7], dt);
+    return w;
+}
+
+// decode idx -> (n, channel block, item) with ``items`` items per (n, block)
+__device__ __forceinline__ bool q_decode(long idx, int N, int C8, long items, int& n, int& cb, long& it) {
+    if (idx >= (long)N * C8 * items) return false;
+    it = idx % items;
+    const long nc = idx / items;
+    cb = (int)(nc % C8);
+    n = (int)(nc / C8);
+    return true;
+}
+
+// y = act((x - mean) * (gamma * inv) + beta): thread = 8 channels x 2 consecutive pixels
+__global__ __launch_bounds__(256) void bn_apply_q_kernel(const float* __restrict__ x, long xs, float* __restrict__ y, long ys,
+                                                         int N, int C8, int HW, const float* __restrict__ mean,
+                                                         const float* __restrict__ inv, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int act, float alpha,
+                                                         u32x4q* __restrict__ q, long qns, int dt) {
+    int n, cb;
+    long p2;
+    if (!q_decode((long)blockIdx.x * 256 + threadIdx.x, N, C8, HW / 2, n, cb, p2)) return;
+    float v0[8], v1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cb * 8 + j;
+        const float sc = gamma[c] * inv[c], m = mean[c], be = beta[c];
+        const float2 t = *reinterpret_cast<const float2*>(x + (long)n * xs + (long)c * HW + 2 * p2);
+        v0[j] = ghm_act(fmaf(t.x - m, sc, be), act, alpha);
+        v1[j] = ghm_act(fmaf(t.y - m, sc, be), act, alpha);
+        if (y) *reinterpret_cast<float2*>(y + (long)n * ys + (long)c * HW + 2 * p2) = make_float2(v0[j], v1[j]);
+    }
+    u32x4q* o = q + (long)n * qns + (long)cb * HW + 2 * p2;
+    o[0] = q_pack8(v0, dt);
+    o[1] = q_pack8(v1, dt);
+}
+
+// dx = gamma * inv * (dout * act'(y) - mean(dz) - xhat * mean(dz * xhat)): thread = 8 channels x 2 pixels
+__global__ __launch_bounds__(256) void bn_bwd_apply_q_kernel(const float* __restrict__ dout, long ds, const float* __restrict__ y,
+                                                             long ys, const float* __restrict__ x, long xs, float* __restrict__ dx,
+                                                             long dxs, int N, int C8, int HW, const float* __restrict__ mean,
+                                                             const float* __restrict__ inv, const float* __restrict__ gamma,
+                                                             const float* __restrict__ sums, float inv_count, int act,
+                                                             float alpha, u32x4q* __restrict__ q, long qns, int dt) {
+    int n, cb;
+    long p2;
+    if (!q_decode((long)blockIdx.x * 256 + threadIdx.x, N, C8, HW / 2, n, cb, p2)) return;
+    float v0[8], v1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cb * 8 + j;
+        const float m = mean[c], iv = inv[c], g = gamma[c] * iv;
+        const float mb = sums[2 * c] * inv_count, mg = sums[2 * c + 1] * inv_count;
+        const long o = (long)c * HW + 2 * p2;
+        const float2 d = *reinterpret_cast<const float2*>(dout + (long)n * ds + o);
+        const float2 yy = *reinterpret_cast<const float2*>(y + (long)n * ys + o);
+        const float2 xx = *reinterpret_cast<const float2*>(x + (long)n * xs + o);
+        v0[j] = g * (d.x * ghm_dact_from_out(yy.x, act, alpha) - mb - (xx.x - m) * iv * mg);
+        v1[j] = g * (d.y * ghm_dact_from_out(yy.y, act, alpha) - mb - (xx.y - m) * iv * mg);
+        if (dx) *reinterpret_cast<float2*>(dx + (long)n * dxs + o) = make_float2(v0[j], v1[j]);
+    }
+    u32x4q* o = q + (long)n * qns + (long)cb * HW + 2 * p2;
+    o[0] = q_pack8(v0, dt);
+    o[1] = q_pack8(v1, dt);
+}
+
+// Theano bilinear 2x (layers.py:13-26; elementwise.hip up_bilinear_fwd_kernel): thread = 8 channels x one coarse pixel,
+// writes its 2x2 fine pixels
+__global__ __launch_bounds__(256) void up_bilinear_fwd_q_kernel(const float* __restrict__ x, long xs, float* __restrict__ y,
+                                                                int N, int C8, int H, int W, u32x4q* __restrict__ q, long qns,
+                                                                int dt) {
+    int n, cb;
+    long px;
+    const long hw = (long)H * W;
+    if (!q_decode((long)blockIdx.x * 256 + threadIdx.x, N, C8, hw, n, cb, px)) return;
+    const int i = (int)(px / W), j = (int)(px - (long)i * W);
+    const int i1 = min(i + 1, H - 1), j1 = min(j + 1, W - 1);
+    float a00[8], a01[8], a10[8], a11[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long c = cb * 8 + k;
+        const float* xp = x + (long)n * xs + c * hw;
+        const float v00 = xp[i * W + j], v01 = xp[i * W + j1], v10 = xp[i1 * W + j], v11 = xp[i1 * W + j1];
+        const float c0 = 0.5f * (v00 + v10), c1 = 0.5f * (v01 + v11);
+        a00[k] = v00;
+        a01[k] = 0.5f * (v00 + v01);
+        a10[k] = c0;
+        a11[k] = 0.5f * (c0 + c1);
+        if (y) {
+            float* o = y + ((long)n * C8 * 8 + c) * 4 * hw + (long)(2 * i) * (2 * W) + 2 * j;
+            *reinterpret_cast<float2*>(o) = make_float2(a00[k], a01[k]);
+            *reinterpret_cast<float2*>(o + 2 * W) = make_float2(a10[k], a11[k]);
+        }
+    }
+    u32x4q* o = q + (long)n * qns + (long)cb * 4 * hw + (long)(2 * i) * (2 * W) + 2 * j;
+    o[0] = q_pack8(a00, dt);
+    o[1] = q_pack8(a01, dt);
+    o[2 * W] = q_pack8(a10, dt);
+    o[2 * W + 1] = q_pack8(a11, dt);
+}
+
+// pp [4N, K, H, W] (parity-planar output of a collapsed up-sample convolution) -> hi [N, K, 2H, 2W]
+__global__ __launch_bounds__(256) void pp_to_hi_q_kernel(const float* __restrict__ pp, float* __restrict__ hi, long hi_nstride,
+                                                         int N, int K8, int H, int W, u32x4q* __restrict__ q, long qns, int dt) {
+    int n, kb;
+    long px;
+    const long hw = (long)H * W;
+    if (!q_decode((long)blockIdx.x * 256 + threadIdx.x, N, K8, hw, n, kb, px)) return;
+    const int yy = (int)(px / W), xx = (int)(px - (long)yy * W);
+    const long plane = (long)K8 * 8 * hw;
+    float a[4][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float* src = pp + ((long)n * 4) * plane + ((long)(kb * 8 + k) * H + yy) * W + xx;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) a[p][k] = src[p * plane];
+        if (hi) {
+            float* dst = hi + (long)n * hi_nstride + ((long)(kb * 8 + k) * 2 * H + 2 * yy) * (2 * W) + 2 * xx;
+            *reinterpret_cast<float2*>(dst) = make_float2(a[0][k], a[1][k]);
+            *reinterpret_cast<float2*>(dst + 2 * W) = make_float2(a[2][k], a[3][k]);
+        }
+    }
+    u32x4q* o = q + (long)n * qns + (long)kb * 4 * hw + (long)(2 * yy) * (2 * W) + 2 * xx;
+    o[0] = q_pack8(a[0], dt);
+    o[1] = q_pack8(a[1], dt);
+    o[2 * W] = q_pack8(a[2], dt);
+    o[2 * W + 1] = q_pack8(a[3], dt);
+}
+
+// gradient of the (never materialised) full-resolution conv output behind a fused conv + act + 2x2 max-pool
+// (elementwise.hip maxpool2_mask_bwd_kernel): thread = 8 channels x one pooled pixel -> its 2x2 window; with ``part``
+// the per-channel sums of what it writes (the conv's bias gradient) as per-block partials part[c][n * bpp + block]
+template <bool BIAS>
+__global__ __launch_bounds__(256) void maxpool2_mask_bwd_q_kernel(const unsigned char* __restrict__ mask,
+                                                                  const float* __restrict__ y, const float* __restrict__ dy,
+                                                                  float* __restrict__ dx, int N, int C8, int H, int W, int act,
+                                                                  float alpha, float* __restrict__ part, int bpp,
+                                                                  u32x4q* __restrict__ q, long qns, int dt) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long hwp = (long)Ho * Wo, hw = (long)H * W;
+    // blocks never straddle a (sample, channel block): bpp blocks of 256 pooled pixels each
+    const int blk = blockIdx.x % bpp;
+    const long ncb = blockIdx.x / bpp;
+    const int cb = (int)(ncb % C8), n = (int)(ncb / C8);
+    const long px = (long)blk * 256 + threadIdx.x;
+    const bool live = px < hwp;
+    const int i = live ? (int)(px / Wo) : 0, j = live ? (int)(px - (long)i * Wo) : 0;
+    float a[4][8], csum[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long pl = (long)n * C8 * 8 + cb * 8 + k;
+        const long po = pl * hwp + (long)i * Wo + j;
+        const unsigned m = live ? mask[po] : 0u;
+        const float g = live ? dy[po] * ghm_dact_from_out(y[po], act, alpha) : 0.f;
+        a[0][k] = (m & 1u) ? g : 0.f;
+        a[1][k] = (m & 2u) ? g : 0.f;
+        a[2][k] = (m & 4u) ? g : 0.f;
+        a[3][k] = (m & 8u) ? g : 0.f;
+        csum[k] = g * (float)__popc(m & 15u);
+        if (dx && live) {
+            float* o = dx + pl * hw + (long)(2 * i) * W + 2 * j;
+            *reinterpret_cast<float2*>(o) = make_float2(a[0][k], a[1][k]);
+            *reinterpret_cast<float2*>(o + W) = make_float2(a[2][k], a[3][k]);
+        }
+    }
+    if (live) {
+        u32x4q* o = q + (long)n * qns + (long)cb * hw + (long)(2 * i) * W + 2 * j;
+        o[0] = q_pack8(a[0], dt);
+        o[1] = q_pack8(a[1], dt);
+        o[W] = q_pack8(a[2], dt);
+        o[W + 1] = q_pack8(a[3], dt);
+    }
+    if constexpr (BIAS) {
+        __shared__ float red[4][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float s = csum[k];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const int k = threadIdx.x;
+            part[(long)(cb * 8 + k) * ((long)N * bpp) + (long)n * bpp + blk] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        }
+    }
+}
+
+// out[c] (+)= fixed-order sum of part[c][0 .. S)
+__global__ __launch_bounds__(64) void q_rows_sum_kernel(const float* __restrict__ part, int C, int S, float* __restrict__ out,
+                                                        int accumulate) {
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < S; i += 64) s += part[(long)c * S + i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (threadIdx.x == 0) out[c] = (accumulate ? out[c] : 0.f) + s;
+}
+
+inline bool q_dtype_ok(int dt) { return dt == GHM_DTYPE_BF16 || dt == GHM_DTYPE_F16; }
+
+}  // namespace
+
+#define EWQ_GRID(total) dim3(ceil_div((long)(total), 256)), dim3(256), 0, ctx->stream
+
+extern "C" {
+
+int ghm_bn_apply_q(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t ys, int32_t N, int32_t C, int32_t HW,
+                   const float* mean, const float* inv, const float* gamma, const float* beta, int32_t act, float alpha,
+                   void* yq, int64_t yq_nstride, int32_t dtype) {
+    GHM_CHECK(q_dtype_ok(dtype) && yq && C % 8 == 0 && HW % 2 == 0 && xs % 2 == 0 && ys % 2 == 0 &&
+              (((uintptr_t)x | (uintptr_t)y) & 7) == 0 && ((uintptr_t)yq & 15) == 0,
+              "ghm_bn_apply_q: bf16 / f16, C %% 8 == 0, even HW and strides, aligned tensors");
+    hipLaunchKernelGGL(bn_apply_q_kernel, EWQ_GRID((long)N * (C / 8) * (HW / 2)), x, (long)xs, y, (long)ys, N, C / 8, HW, mean,
+                       inv, gamma, beta, act, alpha, (u32x4q*)yq, (long)yq_nstride, dtype);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_bn_backward_q(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y, int64_t ys, const float* x, int64_t xs,
+                      float* dx, int64_t dxs, int32_t N, int32_t C, int32_t HW, const float* mean, const float* inv,
+                      const float* gamma, float* dgamma, float* dbeta, int32_t act, float alpha, int32_t accumulate, void* ws,
+                      void* dxq, int64_t dxq_nstride, int32_t dtype) {
+    GHM_CHECK(q_dtype_ok(dtype) && dxq && C % 8 == 0 && HW % 2 == 0 && ds % 2 == 0 && ys % 2 == 0 && xs % 2 == 0 &&
+              dxs % 2 == 0 && (((uintptr_t)dout | (uintptr_t)y | (uintptr_t)x | (uintptr_t)dx) & 7) == 0 &&
+              ((uintptr_t)dxq & 15) == 0,
+              "ghm_bn_backward_q: bf16 / f16, C %% 8 == 0, even HW and strides, aligned tensors");
+    // the parameter gradients and the two per-channel means: the reduction passes of ghm_bn_backward (they need no dx)
+    if (int e = ghm_bn_backward_sums(ctx, dout, ds, y, ys, x, xs, N, C, HW, mean, inv, dgamma, dbeta, act, alpha, accumulate, ws))
+        return e;
+    const float* sums = (const float*)((const char*)ws + ghm_bn_workspace(C) - (size_t)C * 2 * sizeof(float));
+    hipLaunchKernelGGL(bn_bwd_apply_q_kernel, EWQ_GRID((long)N * (C / 8) * (HW / 2)), dout, (long)ds, y, (long)ys, x, (long)xs,
+                       dx, (long)dxs, N, C / 8, HW, mean, inv, gamma, sums, 1.f / (float)((long)N * HW), act, alpha,
+                       (u32x4q*)dxq, (long)dxq_nstride, dtype);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_upsample_bilinear2_fwd_q(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int32_t N, int32_t C, int32_t H, int32_t W,
+                                 void* yq, int64_t yq_nstride, int32_t dtype) {
+    GHM_CHECK(q_dtype_ok(dtype) && yq && C % 8 == 0 && ((uintptr_t)y & 7) == 0 && ((uintptr_t)yq & 15) == 0,
+              "ghm_upsample_bilinear2_fwd_q: bf16 / f16, C %% 8 == 0, aligned tensors");
+    hipLaunchKernelGGL(up_bilinear_fwd_q_kernel, EWQ_GRID((long)N * (C / 8) * H * W), x, (long)xs, y, N, C / 8, H, W,
+                       (u32x4q*)yq, (long)yq_nstride, dtype);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_pp_to_hi_q(ghm_ctx* ctx, const float* pp, float* hi, int64_t hi_nstride, int32_t N, int32_t K, int32_t H, int32_t W,
+                   void* hiq, int64_t hiq_nstride, int32_t dtype) {
+    GHM_CHECK(q_dtype_ok(dtype) && hiq && K % 8 == 0 && hi_nstride % 2 == 0 && ((uintptr_t)hi & 7) == 0 &&
+              ((uintptr_t)hiq & 15) == 0, "ghm_pp_to_hi_q: bf16 / f16, K %% 8 == 0, aligned tensors");
+    hipLaunchKernelGGL(pp_to_hi_q_kernel, EWQ_GRID((long)N * (K / 8) * H * W), pp, hi, (long)hi_nstride, N, K / 8, H, W,
+                       (u32x4q*)hiq, (long)hiq_nstride, dtype);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_maxpool2_mask_bwd_q(ghm_ctx* ctx, const uint8_t* mask, const float* y, const float* dy, float* dx, int32_t N, int32_t C,
+                            int32_t H, int32_t W, int32_t act, float alpha, float* dbias, int32_t accumulate, void* dxq,
+                            int64_t dxq_nstride, int32_t dtype) {
+    GHM_CHECK(q_dtype_ok(dtype) && dxq && C % 8 == 0 && H % 2 == 0 && W % 2 == 0 && ((uintptr_t)dx & 7) == 0 &&
+              ((uintptr_t)dxq & 15) == 0, "ghm_maxpool2_mask_bwd_q: bf16 / f16, C %% 8 == 0, even H and W, aligned tensors");
+    const long hwp = (long)(H / 2) * (W / 2);
+    const int bpp = (int)ceil_div(hwp, 256);
+    const long blocks = (long)N * (C / 8) * bpp;
+    if (dbias) {
+        const int S = N * bpp;
+        void* ws = nullptr;
+        if (int e = ghm_scratch(ctx, (size_t)C * S * sizeof(float), &ws)) return e;
+        hipLaunchKernelGGL((maxpool2_mask_bwd_q_kernel<true>), dim3(blocks), dim3(256), 0, ctx->stream, mask, y, dy, dx, N, C / 8,
+                           H, W, act, alpha, (float*)ws, bpp, (u32x4q*)dxq, (long)dxq_nstride, dtype);
+        GHM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(q_rows_sum_kernel, dim3(C), dim3(64), 0, ctx->stream, (const float*)ws, C, S, dbias, accumulate);
+    } else {
+        hipLaunchKernelGGL((maxpool2_mask_bwd_q_kernel<false>), dim3(blocks), dim3(256), 0, ctx->stream, mask, y, dy, dx, N,
+                           C / 8, H, W, act, alpha, (float*)nullptr, bpp, (u32x4q*)dxq, (long)dxq_nstride, dtype);
+    }
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

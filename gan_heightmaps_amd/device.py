@@ -478,6 +478,30 @@ class Ops:
              C.c_void_p(dxq.ptr if dxq is not None else 0), dxq.nstride if dxq is not None else 0, _vp(y), y.nstride,
              ACT_CODES[act], alpha, DTYPE_CODES[dtype])
 
+    def bn_apply_q(self, x, y, mean, inv, gamma, beta, yq, act='linear', alpha=0.0):
+        call("ghm_bn_apply_q", self.h, _vp(x), x.nstride, _vp(y), y.nstride if y is not None else 0, x.N, x.Cc, x.HW, _vp(mean),
+             _vp(inv), _vp(gamma), _vp(beta), ACT_CODES[act], alpha, C.c_void_p(yq.ptr), yq.nstride, DTYPE_CODES[yq.dtype])
+
+    def bn_backward_q(self, dout, y, x, dx, mean, inv, gamma, dgamma, dbeta, ws, dxq, act='linear', alpha=0.0, accumulate=False):
+        call("ghm_bn_backward_q", self.h, _vp(dout), dout.nstride, _vp(y), y.nstride, _vp(x), x.nstride, _vp(dx),
+             dx.nstride if dx is not None else 0, x.N, x.Cc, x.HW, _vp(mean), _vp(inv), _vp(gamma), _vp(dgamma), _vp(dbeta),
+             ACT_CODES[act], alpha, int(accumulate), _vp(ws), C.c_void_p(dxq.ptr), dxq.nstride, DTYPE_CODES[dxq.dtype])
+
+    def upsample_bilinear2_fwd_q(self, x, y, yq):
+        assert y is None or y.contiguous
+        call("ghm_upsample_bilinear2_fwd_q", self.h, _vp(x), x.nstride, _vp(y), x.N, x.Cc, x.H, x.W, C.c_void_p(yq.ptr),
+             yq.nstride, DTYPE_CODES[yq.dtype])
+
+    def pp_to_hi_q(self, pp, hi, hiq):
+        assert pp.contiguous and pp.N == 4 * hiq.N
+        call("ghm_pp_to_hi_q", self.h, _vp(pp), _vp(hi), hi.nstride if hi is not None else 0, hiq.N, pp.Cc, pp.H, pp.W,
+             C.c_void_p(hiq.ptr), hiq.nstride, DTYPE_CODES[hiq.dtype])
+
+    def maxpool2_mask_bwd_q(self, mask_ptr, y, dy, dx, dxq, act, alpha, dbias=None, accumulate=False):
+        N, Cc, H, W = dxq.shape
+        call("ghm_maxpool2_mask_bwd_q", self.h, C.c_void_p(int(mask_ptr)), _vp(y), _vp(dy), _vp(dx), N, Cc, H, W,
+             ACT_CODES[act], alpha, _vp(dbias), int(accumulate), C.c_void_p(dxq.ptr), dxq.nstride, DTYPE_CODES[dxq.dtype])
+
     def lp_wgrad_q_supported(self, d, dtype):
         return bool(_lib.load().ghm_lp_wgrad_q_supported(C.byref(d), DTYPE_CODES[dtype]))
 

@@ -489,6 +489,22 @@ class NetPlan:
                     if i.alias is not None and i.alias[0] is n:
                         get_outq(i)
 
+    def _fp32_needed(self, n):
+        """does anything read the fp32 output of node n (which also has a q copy)?  Not when every consumer is a
+        low-precision convolution whose forward AND weight gradient read the q copy."""
+        if n is self.out_node or n.outq is None or n.alias is not None or not n.consumers:
+            return True
+        for c in n.consumers:
+            if c.op in ('conv', 'convpool') and c.inputs[0] is n:
+                d = self._desc(c, n.out, self._full(c))
+            elif c.op == 'upconv' and c.inputs[0] is n:
+                d = self._upconv_desc(c, n.out)
+            else:
+                return True
+            if not (self._lp(d, 0) and d.stride == 1 and self._lp(d, 2) and self.ops.lp_wgrad_q_supported(d, self.dtype)):
+                return True
+        return False
+
     def input_tensor(self, layer):
         return self.node_of_layer[id(layer)].out
 
@@ -655,6 +671,15 @@ class NetPlan:
                         prog.append(("bn_fwd", lambda xs=xs, ys=ys, m=m, iv=iv, rm=rm, ri=ri, l=l, upd=upd, g=g, be=be, a=a:
                                      ops.bn_forward(xs, ys, m, iv, g, be, self.bn_ws, rm if upd else None,
                                                     ri if upd else None, l.epsilon, l.alpha, a.kind, a.alpha)))
+                elif n.outq is not None and x.HW % 2 == 0 and x.nstride % 2 == 0 and y.nstride % 2 == 0:
+                    # statistics, then normalise + activation writing the fp32 result AND its q copy in one pass
+                    m, iv = n.aux['mean'], n.aux['inv']
+                    upd = update_running
+                    q_direct = True
+                    prog.append(("bn_fwd", lambda x=x, m=m, iv=iv, rm=rm, ri=ri, l=l, upd=upd:
+                                 ops.bn_stats(x, m, iv, self.bn_ws, rm if upd else None, ri if upd else None, l.epsilon, l.alpha)))
+                    prog.append(("bn_fwd", lambda x=x, y=y, yq=n.outq, m=m, iv=iv, g=g, be=be, a=a:
+                                 ops.bn_apply_q(x, y, m, iv, g, be, yq, a.kind, a.alpha)))
                 else:
                     m, iv = n.aux['mean'], n.aux['inv']
                     upd = update_running
@@ -681,7 +706,12 @@ class NetPlan:
                     prog.append(("upconv_fwd", lambda d=d, x=x, wpc=wpc, b4=b4, y4=y4, a=a:
                                  ops.conv2d_fwd(d, x, wpc, b4, y4, a.kind, a.alpha), conv_meta(ops, d, 0)))
             elif n.op == 'pp_to_hi':
-                prog.append(("pp_to_hi", lambda x=x, y=y: ops.pp_to_hi(x, y)))
+                if n.outq is not None and y.nstride % 2 == 0:
+                    q_direct = True
+                    y32 = y if self._fp32_needed(n) else None      # every consumer reads the q copy: no fp32 tensor
+                    prog.append(("pp_to_hi", lambda x=x, y32=y32, yq=n.outq: ops.pp_to_hi_q(x, y32, yq)))
+                else:
+                    prog.append(("pp_to_hi", lambda x=x, y=y: ops.pp_to_hi(x, y)))
             elif n.op == 'dropout':
                 if deterministic:
                     prog.append(("dropout_det", lambda x=x, y=y: ops.copy_view(x, y)))
@@ -693,7 +723,12 @@ class NetPlan:
             elif n.op == 'up_nearest':
                 prog.append(("up_nearest_fwd", lambda x=x, y=y: ops.upsample_nearest2_fwd(x, y)))
             elif n.op == 'up_bilinear':
-                prog.append(("up_bilinear_fwd", lambda x=x, y=y: ops.upsample_bilinear2_fwd(x, y)))
+                if n.outq is not None:
+                    q_direct = True
+                    y32 = y if self._fp32_needed(n) else None
+                    prog.append(("up_bilinear_fwd", lambda x=x, y32=y32, yq=n.outq: ops.upsample_bilinear2_fwd_q(x, y32, yq)))
+                else:
+                    prog.append(("up_bilinear_fwd", lambda x=x, y=y: ops.upsample_bilinear2_fwd(x, y)))
             elif n.op == 'maxpool':
                 prog.append(("maxpool_fwd", lambda x=x, y=y: ops.maxpool2_fwd(x, y)))
             elif n.op == 'avgpool':
@@ -859,8 +894,14 @@ class NetPlan:
                 mptr = n.aux['mask'] + n0 * per
                 # with the weight gradients wanted, the same pass also sums what it writes per channel: the bias gradient
                 gb_fused = st.grad(n.layer.b) if wgrad else None
-                prog.append(("maxpool_mask_bwd", lambda m=mptr, y=y, G=G, Gf=Gf, a=a, gb=gb_fused, aw=accumulate_wgrad:
-                             ops.maxpool2_mask_bwd(m, y, G, Gf, a.kind, a.alpha, gb, aw)))
+                Gfq = gradq_of(n, Gf, pack=False) if (self.use_q and Gf.Cc % 8 == 0 and Gf.H % 2 == 0 and Gf.W % 2 == 0) else None
+                if Gfq is not None:         # the full-resolution gradient and its q copy in one pass
+                    gq_ready.add(id(n))
+                    prog.append(("maxpool_mask_bwd", lambda m=mptr, y=y, G=G, Gf=Gf, Gfq=Gfq, a=a, gb=gb_fused, aw=accumulate_wgrad:
+                                 ops.maxpool2_mask_bwd_q(m, y, G, Gf, Gfq, a.kind, a.alpha, gb, aw)))
+                else:
+                    prog.append(("maxpool_mask_bwd", lambda m=mptr, y=y, G=G, Gf=Gf, a=a, gb=gb_fused, aw=accumulate_wgrad:
+                                 ops.maxpool2_mask_bwd(m, y, G, Gf, a.kind, a.alpha, gb, aw)))
                 G, a = Gf, linear
             if n.op in ('conv', 'convpool', 'deconv', 'dense'):
                 if a != linear and not n.aux.get(('grad_is_pre', key)):
@@ -1063,7 +1104,30 @@ class NetPlan:
                 if acc:
                     dst = dev.empty(gi.shape) if ('bn_tmp', id(n)) not in cache else cache[('bn_tmp', id(n))]
                     cache[('bn_tmp', id(n))] = dst
-                if self.bn_groups == 2:
+                # the convolution in front of this BatchNorm reads gi as the operand of its low-precision data / weight
+                # gradients: the apply pass writes the q copy itself -- and no fp32 gradient at all when both read q
+                giq, gi32 = None, True
+                if (self.use_q and not acc and nslice is None and self.bn_groups == 1 and xin.op in ('conv', 'upconv')
+                        and len(xin.consumers) == 1 and xin.act == linear and gi.HW % 2 == 0 and gi.Cc % 8 == 0
+                        and gi.nstride % 2 == 0):
+                    xx = xin.inputs[0]
+                    if xin.op == 'conv':
+                        dq, gview = self._desc(xin, xx.out, gi), gi
+                    else:
+                        dq = self._upconv_desc(xin, xx.out)
+                        gview = gi.reshape((xx.out.N, 4 * xin.shape[1], xx.out.H, xx.out.W))
+                    w_q = self._lp(dq, 2) and dq.stride == 1 and xx.outq is not None and ops.lp_wgrad_q_supported(dq, self.dtype)
+                    d_q = self._lp(dq, 1) or not req[id(xx)]
+                    if (w_q or not wgrad) and (self._lp(dq, 1) or w_q):
+                        giq = gradq_of(xin, gview, pack=False).reshape(gi.shape)
+                        gq_ready.add(id(xin))
+                        gi32 = not ((w_q or not wgrad) and d_q)
+                if giq is not None:
+                    m, iv = n.aux['mean'], n.aux['inv']
+                    dst32 = dst if gi32 else None
+                    prog.append(("bn_bwd", lambda G=G, y=y, x=x, dst32=dst32, giq=giq, m=m, iv=iv, gam=gam, dg=dg, db=db, a=a, aw=aw:
+                                 ops.bn_backward_q(G, y, x, dst32, m, iv, gam, dg, db, self.bn_ws, giq, a.kind, a.alpha, aw)))
+                elif self.bn_groups == 2:
                     hb = self.batch // 2
                     halves = (0, 1) if nslice is None else ((n0 // hb,) if (n1 - n0) == hb and n0 % hb == 0 else None)
                     if halves is None:

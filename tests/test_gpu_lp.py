@@ -522,3 +522,97 @@ def test_q_weight_gradient(gpu, case, splits, dtype):
         assert rel(got, ref) < EXACT, rel(got, ref)
         ops.conv2d_wgrad_lp_q(d, xq, dyq, dwd, ws, dtype, accumulate=True)
         assert rel(D.unpack_conv_w(dwd.numpy().ravel(), K, C, 3, 3), 2 * ref) < EXACT
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_elementwise_producers_with_a_q_epilogue(gpu, dtype):
+    """ghm_bn_apply_q, ghm_bn_backward_q, ghm_upsample_bilinear2_fwd_q, ghm_pp_to_hi_q, ghm_maxpool2_mask_bwd_q: the fp32
+    result is bit-identical to the plain entry point's, the q result is exactly its rounding (also into a channel slice
+    of a wider q buffer), and with the fp32 pointer NULL the q result is unchanged."""
+    dev, ops, D = gpu
+    R = LP.ROUND[dtype]
+    rng = np.random.RandomState(12)
+    N, C, H, W = 3, 24, 10, 12
+
+    def qbuf(shape, pad=8):
+        wide = D.QTensor.empty(dev, (shape[0], shape[1] + 2 * pad, shape[2], shape[3]), dtype)
+        dev.memset_zero(wide.ptr, wide.nbytes)
+        return wide, wide.channels(pad, pad + shape[1])
+
+    def check_q(wide, q, ref32, pad=8):
+        assert np.array_equal(q.numpy(), R(ref32))
+        full = wide.numpy()
+        assert not full[:, :pad].any() and not full[:, pad + ref32.shape[1]:].any()
+
+    # ---- BatchNorm apply / backward (statistics from ghm_bn_stats: > BN_SMALL_MAX values per channel not needed) ----
+    x = rng.randn(N, C, H, W).astype(np.float32) * 2 + 0.5
+    g, b = (rng.rand(C) + 0.5).astype(np.float32), rng.randn(C).astype(np.float32)
+    xd, gd, bd = dev.tensor(x), dev.tensor(g), dev.tensor(b)
+    mean, inv = dev.empty((1, C, 1, 1)), dev.empty((1, C, 1, 1))
+    ws = dev.alloc(ops.bn_workspace(C))
+    ops.bn_stats(xd, mean, inv, ws)
+    y1, y2 = dev.empty(x.shape), dev.empty(x.shape)
+    ops.bn_apply(xd, y1, mean, inv, gd, bd, 'lrelu', 0.2)
+    wide, yq = qbuf(x.shape)
+    ops.bn_apply_q(xd, y2, mean, inv, gd, bd, yq, 'lrelu', 0.2)
+    assert np.array_equal(y1.numpy(), y2.numpy())
+    check_q(wide, yq, y1.numpy())
+    wide2, yq2 = qbuf(x.shape)
+    ops.bn_apply_q(xd, None, mean, inv, gd, bd, yq2, 'lrelu', 0.2)
+    assert np.array_equal(yq2.numpy(), yq.numpy())
+    dout = rng.randn(N, C, H, W).astype(np.float32)
+    dd = dev.tensor(dout)
+    dx1, dx2 = dev.empty(x.shape), dev.empty(x.shape)
+    dg1, db1, dg2, db2 = (dev.zeros((1, C, 1, 1)) for _ in range(4))
+    with tuning_env(GHM_NO_BN_SMALL="1"):                       # the three-pass form: the q form's reductions
+        ops.bn_backward(dd, y1, xd, dx1, mean, inv, gd, dg1, db1, ws, 'lrelu', 0.2)
+    wide, dxq = qbuf(x.shape)
+    ops.bn_backward_q(dd, y1, xd, dx2, mean, inv, gd, dg2, db2, ws, dxq, 'lrelu', 0.2)
+    # (the apply pass is a kernel of its own: the compiler contracts its multiply-adds differently -> last-bit differences)
+    assert rel(dx2.numpy(), dx1.numpy()) < 1e-6 and np.array_equal(dg1.numpy(), dg2.numpy()) and np.array_equal(db1.numpy(), db2.numpy())
+    check_q(wide, dxq, dx2.numpy())
+    wide2, dxq2 = qbuf(x.shape)
+    ops.bn_backward_q(dd, y1, xd, None, mean, inv, gd, dg2, db2, ws, dxq2, 'lrelu', 0.2)
+    assert np.array_equal(dxq2.numpy(), dxq.numpy())
+    # ---- Theano bilinear x2 ----
+    u1, u2 = dev.empty((N, C, 2 * H, 2 * W)), dev.empty((N, C, 2 * H, 2 * W))
+    ops.upsample_bilinear2_fwd(xd, u1)
+    wide, uq = qbuf((N, C, 2 * H, 2 * W))
+    ops.upsample_bilinear2_fwd_q(xd, u2, uq)
+    assert np.array_equal(u1.numpy(), u2.numpy())
+    check_q(wide, uq, u1.numpy())
+    wide2, uq2 = qbuf((N, C, 2 * H, 2 * W))
+    ops.upsample_bilinear2_fwd_q(xd, None, uq2)
+    assert np.array_equal(uq2.numpy(), uq.numpy())
+    # ---- parity-planar -> interleaved ----
+    pp = rng.randn(4 * N, C, H, W).astype(np.float32)
+    ppd = dev.tensor(pp)
+    h1, h2 = dev.empty((N, C, 2 * H, 2 * W)), dev.empty((N, C, 2 * H, 2 * W))
+    ops.pp_to_hi(ppd, h1)
+    wide, hq = qbuf((N, C, 2 * H, 2 * W))
+    ops.pp_to_hi_q(ppd, h2, hq)
+    assert np.array_equal(h1.numpy(), h2.numpy())
+    check_q(wide, hq, h1.numpy())
+    wide2, hq2 = qbuf((N, C, 2 * H, 2 * W))
+    ops.pp_to_hi_q(ppd, None, hq2)
+    assert np.array_equal(hq2.numpy(), hq.numpy())
+    # ---- backward of the fused conv + lrelu + 2x2 max-pool: full-resolution gradient from mask + pooled y + pooled dy ----
+    Hf, Wf = 2 * H, 2 * W + 4                                   # (W % 4 == 0 for the plain kernel)
+    Wp = Wf // 2
+    m = rng.randint(1, 16, (N, C, H, Wp)).astype(np.uint8)
+    yp = rng.randn(N, C, H, Wp).astype(np.float32)
+    dyp = rng.randn(N, C, H, Wp).astype(np.float32)
+    md = dev.alloc(m.size)
+    dev.h2d(md, m)
+    ypd, dypd = dev.tensor(yp), dev.tensor(dyp)
+    f1, f2 = dev.empty((N, C, Hf, Wf)), dev.empty((N, C, Hf, Wf))
+    ops.maxpool2_mask_bwd(md, ypd, dypd, f1, 'lrelu', 0.2)
+    wide, fq = qbuf((N, C, Hf, Wf))
+    gb = dev.zeros((1, C, 1, 1))
+    ops.maxpool2_mask_bwd_q(md, ypd, dypd, f2, fq, 'lrelu', 0.2, gb)
+    assert np.array_equal(f1.numpy(), f2.numpy())
+    check_q(wide, fq, f1.numpy())
+    assert rel(gb.numpy().ravel(), f1.numpy().astype(np.float64).sum(axis=(0, 2, 3))) < 1e-5
+    wide2, fq2 = qbuf((N, C, Hf, Wf))
+    ops.maxpool2_mask_bwd_q(md, ypd, dypd, None, fq2, 'lrelu', 0.2)
+    assert np.array_equal(fq2.numpy(), fq.numpy())
