@@ -925,16 +925,19 @@ __device__ __forceinline__ u32x4 lp_tr_read8(const char* lds_lo, const char* lds
     return r;
 }
 
-template <int DT, int ST, int CHT, int CT, int SPX>
-__global__ __launch_bounds__(512, 1) void lp_wgrad_q_kernel(const LpWgradQArgs a) {
-    static_assert(CHT * CT == 8 && (ST == 1 || ST == 2) && (SPX == 64 || SPX == 32), "8 waves");
-    constexpr int T = 9;
+template <int DT, int KS, int ST, int CHT, int CT, bool RS, int SPX>
+__global__ __launch_bounds__(CHT * CT * (RS ? KS : 1) * 64, 1) void lp_wgrad_q_kernel(const LpWgradQArgs a) {
+    // RS: the waves are additionally split over the KS filter ROWS (5x5: a wave owns the 5 taps of one row; 3x3: all 9 taps)
+    static_assert((ST == 1 || (ST == 2 && KS == 3)) && (SPX == 64 || SPX == 32) && (KS == 3 || KS == 5), "variants");
+    constexpr int T = KS * KS, PADK = KS / 2;
+    constexpr int NWAVES = CHT * CT * (RS ? KS : 1);
+    constexpr int TPW = RS ? KS : T;                  // accumulator tiles (taps) per wave
     constexpr int NPAR = ST;                          // column-parity planes of an x row
-    constexpr int XPIX = ST == 1 ? SPX + 2 : SPX + 1; // pixels per plane: local columns 0 .. SPX*ST (+1): [xs0, xs0 + SPX*ST + 1]
+    constexpr int XPIX = ST == 1 ? SPX + KS - 1 : SPX + 1;   // pixels per plane
     constexpr int XCH = (XPIX + 15) / 16;             // 16-pixel DMA pieces per plane
     constexpr int PLB = XCH * 16 * 64;                // bytes per plane
     constexpr int ROWB = CHT * NPAR * PLB;            // bytes per ring row
-    constexpr int NR = 3 + ST;                        // ring rows: 3 live + ST arriving
+    constexpr int NR = KS + ST;                       // ring rows: KS live + ST arriving
     constexpr int YTB = SPX * 64;                     // bytes per dy filter tile
     constexpr int YB = CT * YTB;                      // bytes per dy buffer
     constexpr int KSTEPS = SPX / 16;
@@ -945,7 +948,9 @@ __global__ __launch_bounds__(512, 1) void lp_wgrad_q_kernel(const LpWgradQArgs a
     typedef __attribute__((address_space(3))) void* lptr_t;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = wave / CT, ww = wave % CT;         // this wave's channel group / filter tile
+    const int wr = RS ? wave / (CHT * CT) : 0;        // this wave's filter row (RS)
+    const int wrem = wave % (CHT * CT);
+    const int hh = wrem / CT, ww = wrem % CT;         // this wave's channel group / filter tile
     const int kg = lane >> 5, li = lane & 31;
     const int c0 = blockIdx.x * (32 * CHT), k0 = blockIdx.y * (32 * CT);
     const int strips = a.Wo / SPX;
@@ -953,7 +958,7 @@ __global__ __launch_bounds__(512, 1) void lp_wgrad_q_kernel(const LpWgradQArgs a
     const int n = col / strips, j0 = (col - n * strips) * SPX;
     const int i_begin = sp * a.rows_per_split, i_end = min(a.Ho, i_begin + a.rows_per_split);
     const int HWx = a.H * a.W, HWy = a.Ho * a.Wo;
-    const int xs0 = j0 * ST - 1;                      // image column of local column 0
+    const int xs0 = j0 * ST - PADK;                   // image column of local column 0
 
     // DMA lane roles inside a 16-pixel piece: pixel pxi, channel block cb4 of the 32-channel group
     const int pxi = lane >> 2, cb4 = lane & 3;
@@ -965,7 +970,7 @@ __global__ __launch_bounds__(512, 1) void lp_wgrad_q_kernel(const LpWgradQArgs a
         const int slot = (y + NR) % NR;
         const bool rok = (unsigned)y < (unsigned)a.H;
 #pragma unroll
-        for (int p0 = 0; p0 < CHT * NPAR * XCH; p0 += 8) {
+        for (int p0 = 0; p0 < CHT * NPAR * XCH; p0 += NWAVES) {
             const int p = p0 + wave;
             if (p < CHT * NPAR * XCH) {
                 const int pl = p / XCH, ch = p - pl * XCH;        // plane = (channel group, parity)
@@ -981,7 +986,7 @@ __global__ __launch_bounds__(512, 1) void lp_wgrad_q_kernel(const LpWgradQArgs a
     };
     auto stage_dy = [&](int i, int buf) {
 #pragma unroll
-        for (int p0 = 0; p0 < CT * (SPX / 16); p0 += 8) {
+        for (int p0 = 0; p0 < CT * (SPX / 16); p0 += NWAVES) {
             const int p = p0 + wave;
             if (p < CT * (SPX / 16)) {
                 const int ct = p / (SPX / 16), ch = p - ct * (SPX / 16);
@@ -991,16 +996,16 @@ __global__ __launch_bounds__(512, 1) void lp_wgrad_q_kernel(const LpWgradQArgs a
         }
     };
 
-    f32x16 acc[T];
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
     if (i_begin < i_end) {
-        // cold start: the three x rows of the first output row, its dy strip
+        // cold start: the KS x rows of the first output row, its dy strip
 #pragma unroll
-        for (int fa = 0; fa < 3; ++fa) stage_xrow(i_begin * ST + fa - 1);
+        for (int fa = 0; fa < KS; ++fa) stage_xrow(i_begin * ST + fa - PADK);
         stage_dy(i_begin, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1018,27 +1023,27 @@ __global__ __launch_bounds__(512, 1) void lp_wgrad_q_kernel(const LpWgradQArgs a
         const int buf = (i - i_begin) & 1;
         if (i + 1 < i_end && !(a.debug & 1)) {
 #pragma unroll
-            for (int r = 0; r < ST; ++r) stage_xrow((i + 1) * ST + 2 - ST + r);     // the rows the next slab adds
+            for (int r = 0; r < ST; ++r) stage_xrow(i * ST - PADK + KS + r);        // the rows the next slab adds
             stage_dy(i + 1, buf ^ 1);
         }
-        const char* xr[3];
+        const char* xr[RS ? 1 : KS];
 #pragma unroll
-        for (int fa = 0; fa < 3; ++fa) xr[fa] = xlane + ((i * ST + fa - 1 + NR) % NR) * ROWB;
+        for (int fa = 0; fa < (RS ? 1 : KS); ++fa) xr[fa] = xlane + ((i * ST + (RS ? wr : fa) - PADK + NR) % NR) * ROWB;
         const char* const yb = ylane + buf * YB;
         if (!(a.debug & 2))
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const u32x4 bf = lp_tr_read8(yb + ks * 1024, yb + ks * 1024 + 256);
 #pragma unroll
-            for (int fa = 0; fa < 3; ++fa)
+            for (int fa = 0; fa < (RS ? 1 : KS); ++fa)
 #pragma unroll
-                for (int fb = 0; fb < 3; ++fb) {
+                for (int fb = 0; fb < KS; ++fb) {
                     // local column of pixel t' and tap column fb: t' * ST + fb  ->  (parity plane, pixel in plane)
                     const int par = ST == 2 ? (fb & 1) : 0;
                     const int shift = ST == 2 ? (fb >> 1) : fb;
                     const char* pa = xr[fa] + par * PLB + (ks * 16 + shift) * 64;
                     const u32x4 af = lp_tr_read8(pa, pa + 256);
-                    acc[fa * 3 + fb] = Lp<DT>::mfma(af, bf, acc[fa * 3 + fb]);
+                    acc[fa * KS + fb] = Lp<DT>::mfma(af, bf, acc[fa * KS + fb]);
                 }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1051,12 +1056,13 @@ __global__ __launch_bounds__(512, 1) void lp_wgrad_q_kernel(const LpWgradQArgs a
     const int kcol = k0 + ww * 32 + li;
     if (kcol >= a.K) return;
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int c = c0 + hh * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+            const int tap = RS ? wr * KS + t : t;
             if (c < a.C) {
-                float* o = ob + ((long)c * T + t) * a.K + kcol;
+                float* o = ob + ((long)c * T + tap) * a.K + kcol;
                 float v = acc[t][e];
                 if (a.accumulate) v += *o;
                 *o = v;
@@ -1325,10 +1331,15 @@ LpWQPlan lp_wqplan(const ghm_conv_desc* d, int num_cu) {
     LpWQPlan v;
     v.ok = false;
     if (GHM_OPT("GHM_NO_LP") || GHM_OPT("GHM_NO_LP_WGRAD") || GHM_OPT("GHM_NO_LP_WGRAD_Q")) return v;
-    if (!(d->kh == 3 && d->kw == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2))) return v;
+    const bool k3 = d->kh == 3 && d->kw == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2);
+    const bool k5 = d->kh == 5 && d->kw == 5 && d->pad == 2 && d->stride == 1;
+    if (!k3 && !k5) return v;
     if (d->Ho != (d->H + d->stride - 1) / d->stride || d->Wo != (d->W + d->stride - 1) / d->stride) return v;
     if (d->Wo % 32 || d->C % 8 || d->K % 8) return v;
-    if (d->K % 128 == 0 && d->C % 64 == 0) { v.cht = 2; v.ct = 4; }
+    if (k5) {                   // 10 waves: 5 filter rows x 2 filter tiles of one 32-channel group
+        if (d->K % 64 || d->C % 32) return v;
+        v.cht = 1; v.ct = 2;
+    } else if (d->K % 128 == 0 && d->C % 64 == 0) { v.cht = 2; v.ct = 4; }
     else if (d->stride == 1 && d->K % 64 == 0 && d->C % 128 == 0) { v.cht = 4; v.ct = 2; }
     else return v;
     v.spx = d->Wo % 64 == 0 ? 64 : 32;
@@ -1336,7 +1347,8 @@ LpWQPlan lp_wqplan(const ghm_conv_desc* d, int num_cu) {
     const long tiles = (long)(d->C / (32 * v.cht)) * (d->K / (32 * v.ct)) * v.ncols;
     long S = (2L * num_cu + tiles - 1) / tiles;              // about two rounds of one block per CU
     if (const char* f = GHM_OPT("GHM_LP_WGRAD_SPLITS")) S = atol(f);
-    const long max_by_work = d->Ho / 4 > 0 ? d->Ho / 4 : 1;   // at least 4 output rows per split (3 x rows of cold start)
+    const long minrows = d->kh == 5 ? 8 : 4;                 // rows per split >= the cold start's KS x rows (and then some)
+    const long max_by_work = d->Ho / minrows > 0 ? d->Ho / minrows : 1;
     if (S > max_by_work) S = max_by_work;
     if (S < 1) S = 1;
     v.rows_per_split = (int)((d->Ho + S - 1) / S);
@@ -1355,7 +1367,7 @@ int lp_launch_wgrad_q(ghm_ctx* ctx, const ghm_conv_desc* d, const LpWQPlan& v, c
     a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.K = d->K; a.Ho = d->Ho; a.Wo = d->Wo;
     a.rows_per_split = v.rows_per_split; a.splits_per_col = v.splits_per_col;
     if (const char* f = GHM_OPT("GHM_ABLATE")) a.debug = atoi(f);
-    const long n = (long)d->C * 9 * d->K;
+    const long n = (long)d->C * d->kh * d->kw * d->K;
     const int splits = v.ncols * v.splits_per_col;
     if (splits > 1) {
         GHM_CHECK(workspace != nullptr, "lp wgrad (q) needs a workspace for %d splits", splits);
@@ -1364,17 +1376,20 @@ int lp_launch_wgrad_q(ghm_ctx* ctx, const ghm_conv_desc* d, const LpWQPlan& v, c
         a.out = dwp; a.split_stride = 0; a.accumulate = accumulate;
     }
     const dim3 grid(d->C / (32 * v.cht), d->K / (32 * v.ct), splits);
-#define GHM_LPWQ_CASE(ST_, CHT_, CT_, SPX_)                                                                              \
-    if (d->stride == ST_ && v.cht == CHT_ && v.ct == CT_ && v.spx == SPX_) {                                           \
-        hipLaunchKernelGGL((lp_wgrad_q_kernel<DT, ST_, CHT_, CT_, SPX_>), grid, dim3(512), 0, ctx->stream, a);         \
+#define GHM_LPWQ_CASE(KS_, ST_, CHT_, CT_, RS_, SPX_)                                                                    \
+    if (d->kh == KS_ && d->stride == ST_ && v.cht == CHT_ && v.ct == CT_ && v.spx == SPX_) {                            \
+        hipLaunchKernelGGL((lp_wgrad_q_kernel<DT, KS_, ST_, CHT_, CT_, RS_, SPX_>), grid,                               \
+                           dim3(CHT_ * CT_ * (RS_ ? KS_ : 1) * 64), 0, ctx->stream, a);                                \
         GHM_LAUNCH_CHECK();                                                                                            \
     } else
-    GHM_LPWQ_CASE(1, 2, 4, 64)
-    GHM_LPWQ_CASE(1, 2, 4, 32)
-    GHM_LPWQ_CASE(1, 4, 2, 64)
-    GHM_LPWQ_CASE(1, 4, 2, 32)
-    GHM_LPWQ_CASE(2, 2, 4, 64)
-    GHM_LPWQ_CASE(2, 2, 4, 32) {
+    GHM_LPWQ_CASE(3, 1, 2, 4, false, 64)
+    GHM_LPWQ_CASE(3, 1, 2, 4, false, 32)
+    GHM_LPWQ_CASE(3, 1, 4, 2, false, 64)
+    GHM_LPWQ_CASE(3, 1, 4, 2, false, 32)
+    GHM_LPWQ_CASE(3, 2, 2, 4, false, 64)
+    GHM_LPWQ_CASE(3, 2, 2, 4, false, 32)
+    GHM_LPWQ_CASE(5, 1, 1, 2, true, 64)
+    GHM_LPWQ_CASE(5, 1, 1, 2, true, 32) {
         ghm_set_error("no lp_wgrad_q variant for s=%d cht=%d ct=%d spx=%d", d->stride, v.cht, v.ct, v.spx);
         return -3;
     }

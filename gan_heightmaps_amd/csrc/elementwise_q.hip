@@ -155,47 +155,50 @@ __global__ __launch_bounds__(256) void pp_to_hi_q_kernel(const float* __restrict
 }
 
 // gradient of the (never materialised) full-resolution conv output behind a fused conv + act + 2x2 max-pool
-// (elementwise.hip maxpool2_mask_bwd_kernel): thread = 8 channels x one pooled pixel -> its 2x2 window; with ``part``
-// the per-channel sums of what it writes (the conv's bias gradient) as per-block partials part[c][n * bpp + block]
+// (elementwise.hip maxpool2_mask_bwd_kernel): thread = 8 channels x TWO neighbouring pooled pixels -> a 2 x 4 window per
+// channel (16-byte fp32 rows, 64-byte q rows); with ``part`` the per-channel sums of what it writes (the conv's bias
+// gradient) as per-block partials part[c][n * bpp + block]
 template <bool BIAS>
 __global__ __launch_bounds__(256) void maxpool2_mask_bwd_q_kernel(const unsigned char* __restrict__ mask,
                                                                   const float* __restrict__ y, const float* __restrict__ dy,
                                                                   float* __restrict__ dx, int N, int C8, int H, int W, int act,
                                                                   float alpha, float* __restrict__ part, int bpp,
                                                                   u32x4q* __restrict__ q, long qns, int dt) {
-    const int Ho = H / 2, Wo = W / 2;
-    const long hwp = (long)Ho * Wo, hw = (long)H * W;
-    // blocks never straddle a (sample, channel block): bpp blocks of 256 pooled pixels each
+    const int Ho = H / 2, Wo = W / 2, Wo2 = W / 4;
+    const long hwp = (long)Ho * Wo, hw = (long)H * W, items = (long)Ho * Wo2;
+    // blocks never straddle a (sample, channel block): bpp blocks of 256 pooled-pixel pairs each
     const int blk = blockIdx.x % bpp;
     const long ncb = blockIdx.x / bpp;
     const int cb = (int)(ncb % C8), n = (int)(ncb / C8);
-    const long px = (long)blk * 256 + threadIdx.x;
-    const bool live = px < hwp;
-    const int i = live ? (int)(px / Wo) : 0, j = live ? (int)(px - (long)i * Wo) : 0;
-    float a[4][8], csum[8];
+    const long it = (long)blk * 256 + threadIdx.x;
+    const bool live = it < items;
+    const int i = live ? (int)(it / Wo2) : 0, j2 = live ? (int)(it - (long)i * Wo2) : 0;
+    float r0[4][8], r1[4][8], csum[8];          // [fine column][channel] of the window's two rows
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const long pl = (long)n * C8 * 8 + cb * 8 + k;
-        const long po = pl * hwp + (long)i * Wo + j;
-        const unsigned m = live ? mask[po] : 0u;
-        const float g = live ? dy[po] * ghm_dact_from_out(y[po], act, alpha) : 0.f;
-        a[0][k] = (m & 1u) ? g : 0.f;
-        a[1][k] = (m & 2u) ? g : 0.f;
-        a[2][k] = (m & 4u) ? g : 0.f;
-        a[3][k] = (m & 8u) ? g : 0.f;
-        csum[k] = g * (float)__popc(m & 15u);
+        const long po = pl * hwp + (long)i * Wo + 2 * j2;
+        const unsigned m2 = live ? *reinterpret_cast<const unsigned short*>(mask + po) : 0u;
+        const float2 yv = live ? *reinterpret_cast<const float2*>(y + po) : make_float2(0.f, 0.f);
+        const float2 gv = live ? *reinterpret_cast<const float2*>(dy + po) : make_float2(0.f, 0.f);
+        const float g0 = gv.x * ghm_dact_from_out(yv.x, act, alpha), g1 = gv.y * ghm_dact_from_out(yv.y, act, alpha);
+        const unsigned m0 = m2 & 0xffu, m1 = m2 >> 8;
+        r0[0][k] = (m0 & 1u) ? g0 : 0.f; r0[1][k] = (m0 & 2u) ? g0 : 0.f; r0[2][k] = (m1 & 1u) ? g1 : 0.f; r0[3][k] = (m1 & 2u) ? g1 : 0.f;
+        r1[0][k] = (m0 & 4u) ? g0 : 0.f; r1[1][k] = (m0 & 8u) ? g0 : 0.f; r1[2][k] = (m1 & 4u) ? g1 : 0.f; r1[3][k] = (m1 & 8u) ? g1 : 0.f;
+        csum[k] = g0 * (float)__popc(m0 & 15u) + g1 * (float)__popc(m1 & 15u);
         if (dx && live) {
-            float* o = dx + pl * hw + (long)(2 * i) * W + 2 * j;
-            *reinterpret_cast<float2*>(o) = make_float2(a[0][k], a[1][k]);
-            *reinterpret_cast<float2*>(o + W) = make_float2(a[2][k], a[3][k]);
+            float* o = dx + pl * hw + (long)(2 * i) * W + 4 * j2;
+            *reinterpret_cast<float4*>(o) = make_float4(r0[0][k], r0[1][k], r0[2][k], r0[3][k]);
+            *reinterpret_cast<float4*>(o + W) = make_float4(r1[0][k], r1[1][k], r1[2][k], r1[3][k]);
         }
     }
     if (live) {
-        u32x4q* o = q + (long)n * qns + (long)cb * hw + (long)(2 * i) * W + 2 * j;
-        o[0] = q_pack8(a[0], dt);
-        o[1] = q_pack8(a[1], dt);
-        o[W] = q_pack8(a[2], dt);
-        o[W + 1] = q_pack8(a[3], dt);
+        u32x4q* o = q + (long)n * qns + (long)cb * hw + (long)(2 * i) * W + 4 * j2;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            o[f] = q_pack8(r0[f], dt);
+            o[W + f] = q_pack8(r1[f], dt);
+        }
     }
     if constexpr (BIAS) {
         __shared__ float red[4][8];
@@ -285,10 +288,10 @@ int ghm_pp_to_hi_q(ghm_ctx* ctx, const float* pp, float* hi, int64_t hi_nstride,
 int ghm_maxpool2_mask_bwd_q(ghm_ctx* ctx, const uint8_t* mask, const float* y, const float* dy, float* dx, int32_t N, int32_t C,
                             int32_t H, int32_t W, int32_t act, float alpha, float* dbias, int32_t accumulate, void* dxq,
                             int64_t dxq_nstride, int32_t dtype) {
-    GHM_CHECK(q_dtype_ok(dtype) && dxq && C % 8 == 0 && H % 2 == 0 && W % 2 == 0 && ((uintptr_t)dx & 7) == 0 &&
-              ((uintptr_t)dxq & 15) == 0, "ghm_maxpool2_mask_bwd_q: bf16 / f16, C %% 8 == 0, even H and W, aligned tensors");
-    const long hwp = (long)(H / 2) * (W / 2);
-    const int bpp = (int)ceil_div(hwp, 256);
+    GHM_CHECK(q_dtype_ok(dtype) && dxq && C % 8 == 0 && H % 2 == 0 && W % 4 == 0 && ((uintptr_t)dx & 15) == 0 &&
+              ((uintptr_t)dxq & 15) == 0, "ghm_maxpool2_mask_bwd_q: bf16 / f16, C %% 8 == 0, even H, W %% 4 == 0, aligned tensors");
+    const long items = (long)(H / 2) * (W / 4);
+    const int bpp = (int)ceil_div(items, 256);
     const long blocks = (long)N * (C / 8) * bpp;
     if (dbias) {
         const int S = N * bpp;

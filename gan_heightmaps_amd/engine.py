@@ -894,11 +894,20 @@ class NetPlan:
                 mptr = n.aux['mask'] + n0 * per
                 # with the weight gradients wanted, the same pass also sums what it writes per channel: the bias gradient
                 gb_fused = st.grad(n.layer.b) if wgrad else None
-                Gfq = gradq_of(n, Gf, pack=False) if (self.use_q and Gf.Cc % 8 == 0 and Gf.H % 2 == 0 and Gf.W % 2 == 0) else None
-                if Gfq is not None:         # the full-resolution gradient and its q copy in one pass
+                # who reads the full-resolution gradient: the conv's low-precision data / weight gradients read its q copy;
+                # the fp32 tensor is written only if a fp32 kernel reads it (thin first layer, geometries not served)
+                dF = self._desc(n, x, Gf)
+                xq_ = xin.outq if nslice is None else (xin.outq.samples(n0, n1) if xin.outq is not None else None)
+                w_q = (self.use_q and xq_ is not None and self._lp(dF, 2) and dF.stride == 1
+                       and ops.lp_wgrad_q_supported(dF, self.dtype))
+                d_lp = self.use_q and need_dx and self._lp(self._desc(n, sl(xin.out), Gf), 1)
+                q_wanted = (wgrad and w_q) or d_lp
+                Gfq = gradq_of(n, Gf, pack=False) if (q_wanted and Gf.Cc % 8 == 0 and Gf.H % 2 == 0 and Gf.W % 4 == 0) else None
+                if Gfq is not None:         # the full-resolution gradient (if anybody reads it) and its q copy in one pass
                     gq_ready.add(id(n))
-                    prog.append(("maxpool_mask_bwd", lambda m=mptr, y=y, G=G, Gf=Gf, Gfq=Gfq, a=a, gb=gb_fused, aw=accumulate_wgrad:
-                                 ops.maxpool2_mask_bwd_q(m, y, G, Gf, Gfq, a.kind, a.alpha, gb, aw)))
+                    Gf32 = None if ((w_q or not wgrad) and (d_lp or not need_dx)) else Gf
+                    prog.append(("maxpool_mask_bwd", lambda m=mptr, y=y, G=G, Gf32=Gf32, Gfq=Gfq, a=a, gb=gb_fused, aw=accumulate_wgrad:
+                                 ops.maxpool2_mask_bwd_q(m, y, G, Gf32, Gfq, a.kind, a.alpha, gb, aw)))
                 else:
                     prog.append(("maxpool_mask_bwd", lambda m=mptr, y=y, G=G, Gf=Gf, a=a, gb=gb_fused, aw=accumulate_wgrad:
                                  ops.maxpool2_mask_bwd(m, y, G, Gf, a.kind, a.alpha, gb, aw)))

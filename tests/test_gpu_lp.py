@@ -487,12 +487,14 @@ def test_q_pooled_convolution_and_fused_activation_backward(gpu, dtype):
 
 
 WQ_CASES = [
-    # N, C,   H,  W,   K,  s
-    (2, 64,  16, 64,  128, 1),      # channel groups 2 x filter tiles 4, 64-pixel strips
-    (2, 128, 12, 32,  64,  1),      # 4 x 2 (K = 64), 32-pixel strips, Ho not a multiple of the split
-    (1, 64,  32, 128, 128, 2),      # stride 2: parity planes, two new x rows per slab
-    (3, 128, 16, 64,  256, 2),
-    (2, 64,  8,  96,  128, 1),      # Wo = 96: three 32-pixel strips
+    # N, C,   H,  W,   K,  s, k
+    (2, 64,  16, 64,  128, 1, 3),   # channel groups 2 x filter tiles 4, 64-pixel strips
+    (2, 128, 12, 32,  64,  1, 3),   # 4 x 2 (K = 64), 32-pixel strips, Ho not a multiple of the split
+    (1, 64,  32, 128, 128, 2, 3),   # stride 2: parity planes, two new x rows per slab
+    (3, 128, 16, 64,  256, 2, 3),
+    (2, 64,  8,  96,  128, 1, 3),   # Wo = 96: three 32-pixel strips
+    (2, 32,  24, 64,  64,  1, 5),   # 5x5: ten waves = five filter rows x two filter tiles
+    (1, 64,  16, 32,  128, 1, 5),
 ]
 
 
@@ -504,8 +506,8 @@ def test_q_weight_gradient(gpu, case, splits, dtype):
     over pixels, a q unit holds 8 channels): equals the definition on the rounded operands for every tile variant,
     stride, strip width and split of the rows (forced split counts include ones that do not divide Ho); accumulate."""
     dev, ops, D = gpu
-    N, C, H, W, K, s = case
-    d = D.conv_desc(N, C, H, W, K, 3, 3, s, 1)
+    N, C, H, W, K, s, k = case
+    d = D.conv_desc(N, C, H, W, K, k, k, s, k // 2)
     assert ops.lp_wgrad_q_supported(d, dtype)
     rng = np.random.RandomState(5)
     x = rng.randn(N, C, H, W).astype(np.float32)
@@ -513,15 +515,15 @@ def test_q_weight_gradient(gpu, case, splits, dtype):
     xq, dyq = D.QTensor.empty(dev, x.shape, dtype), D.QTensor.empty(dev, dy.shape, dtype)
     ops.q_pack(dev.tensor(x), xq)
     ops.q_pack(dev.tensor(dy), dyq)
-    ref = LP.conv2d_vjp(x, np.zeros((K, C, 3, 3), np.float32), dy, s, 1, dtype)[1]
+    ref = LP.conv2d_vjp(x, np.zeros((K, C, k, k), np.float32), dy, s, k // 2, dtype)[1]
     with tuning_env(**({"GHM_LP_WGRAD_SPLITS": splits} if splits else {})):
         ws = dev.alloc(max(ops.wgrad_lp_workspace(d), 16))
-        dwd = dev.zeros((1, C * 9 * K, 1, 1))
+        dwd = dev.zeros((1, C * k * k * K, 1, 1))
         ops.conv2d_wgrad_lp_q(d, xq, dyq, dwd, ws, dtype)
-        got = D.unpack_conv_w(dwd.numpy().ravel(), K, C, 3, 3)
+        got = D.unpack_conv_w(dwd.numpy().ravel(), K, C, k, k)
         assert rel(got, ref) < EXACT, rel(got, ref)
         ops.conv2d_wgrad_lp_q(d, xq, dyq, dwd, ws, dtype, accumulate=True)
-        assert rel(D.unpack_conv_w(dwd.numpy().ravel(), K, C, 3, 3), 2 * ref) < EXACT
+        assert rel(D.unpack_conv_w(dwd.numpy().ravel(), K, C, k, k), 2 * ref) < EXACT
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
