@@ -55,6 +55,7 @@ struct ghm_ctx {
     size_t retired_bytes = 0;
     float* ls_state = nullptr;     // dynamic loss scale {scale, 1/scale, clean steps, overflow flag, skipped steps, ...} or null
     float* zeros = nullptr;        // 256 B of zeros: the source of padding elements for LDS-DMA row staging
+    int* tickets = nullptr;        // zeroed arrival counters of the folded split-K reductions (self-resetting)
 };
 
 // Tuning / ablation switches (GHM_* environment variables) are read ONCE per call site and cached: nothing on the launch
@@ -82,6 +83,30 @@ int ghm_plan_cus();
 int ghm_scratch(ghm_ctx* ctx, size_t bytes, void** out);
 
 void ghm_set_error(const char* fmt, ...);
+
+// Split-K reductions folded into their producer kernel: every block writes its partial slice, then takes a ticket at
+// its output tile's counter; the block that draws the last ticket sums all slices in FIXED order (bit-repeatable whoever
+// arrives last) and finishes the tile.  ghm_tickets: the context's counter array (zero between launches: the last block
+// resets its counter) or null when the launch has more tiles than counters or the fold is not enabled (GHM_SPLITK_FOLD:
+// see ghm_tickets in ctx.hip for why it is opt-in).
+#define GHM_MAX_TICKETS (1 << 18)
+int* ghm_tickets(ghm_ctx* ctx, long tiles);
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool ghm_last_arrival(int* ticket, int nsplit) {
+    __shared__ int s_last_;
+    __threadfence();                    // release: this block's slice is visible device-wide before its ticket
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(ticket, 1);
+        s_last_ = (t == nsplit - 1);
+        if (s_last_) *ticket = 0;       // nobody else touches this counter in this launch any more
+    }
+    __syncthreads();
+    const bool last = s_last_ != 0;
+    if (last) __threadfence();          // acquire: the other blocks' slices
+    return last;
+}
+#endif
 
 #define GHM_HIP(expr)                                                                       \
     do {                                                                                    \

@@ -65,6 +65,8 @@ struct IgemmArgs {
     int accumulate;
     float* partial;        // split-K: raw accumulators go to partial[split][r][p] (no bias / act)
     int slabs_per_split;   // K slabs per blockIdx.y slice
+    int* tickets;          // split-K folded into this launch: one arrival counter per output tile (null: separate epilogue)
+    int nsplit;            // ... and the number of slices whose blocks arrive at it
     int debug;             // tuning only (GHM_ABLATE): 1 = skip global loads, 2 = also skip LDS stores
     int di[MAX_TAPS], dj[MAX_TAPS], wi[MAX_TAPS];
 };
@@ -76,6 +78,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
     const int q = nb >> 3, r = nb & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
+
+__device__ __forceinline__ void splitk_element(const IgemmArgs& a, int S, int r, long p);
 
 template <int BM, int BN, int WM, int WN, bool WT, bool FASTK>
 __device__ __forceinline__ void igemm_body(const IgemmArgs& a) {
@@ -300,6 +304,16 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a) {
                     const int r = r0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * frag_k;
                     if (r < a.R) pb[(long)r * P + p] = acc[i][j][e];
                 }
+            }
+        }
+        if (a.tickets) {
+            // split-K reduction folded into the producer: the LAST block to arrive at this output tile sums the slices
+            // (fixed order 0 .. S-1, whoever arrives last: bit-repeatable) and applies bias / accumulate / activation
+            if (!ghm_last_arrival(a.tickets + blockIdx.z * gridDim.x + blockIdx.x, a.nsplit)) return;
+            for (int idx = threadIdx.x; idx < BM * BN; idx += 256) {
+                const int r = r0 + idx / BN;
+                const long p = (long)p0 + idx % BN;
+                if (r < a.R && p < P) splitk_element(a, a.nsplit, r, p);
             }
         }
         return;
@@ -1003,13 +1017,9 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs a, 
 __global__ __launch_bounds__(256) void igemm_splitk_epilogue_x4(const IgemmArgs4 a4) {
     splitk_epilogue_body(a4.c[blockIdx.y], a4.nsplit[blockIdx.y]);
 }
-__device__ __forceinline__ void splitk_epilogue_body(const IgemmArgs& a, int S) {
+__device__ __forceinline__ void splitk_element(const IgemmArgs& a, int S, int r, long p) {
     const int hw_s = a.Hs * a.Ws;
     const long P = (long)a.N * hw_s;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P * a.R) return;
-    const int r = (int)(idx / P);
-    const long p = idx - (long)r * P;
     const float* pp = a.partial + (long)r * P + p;
     const long sstride = (long)a.R * P;
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
@@ -1029,6 +1039,13 @@ __device__ __forceinline__ void splitk_epilogue_body(const IgemmArgs& a, int S) 
     if (a.bias) v += a.bias[r];
     if (a.accumulate) v += *o;
     *o = ghm_act(v, a.act, a.alpha);
+}
+__device__ __forceinline__ void splitk_epilogue_body(const IgemmArgs& a, int S) {
+    const long P = (long)a.N * a.Hs * a.Ws;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P * a.R) return;
+    const int r = (int)(idx / P);
+    splitk_element(a, S, r, idx - (long)r * P);
 }
 
 // R <= 4 with few output pixels and a long reduction (d_out, pd_out): one WAVE per output pixel, the 64
@@ -1647,6 +1664,8 @@ int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
     const long P = (long)a.N * a.Hs * a.Ws;
     if (P == 0 || a.R == 0) return 0;
     a.partial = nullptr;
+    a.tickets = nullptr;
+    a.nsplit = 0;
     a.slabs_per_split = 1 << 30;
     if (const char* f = GHM_OPT("GHM_ABLATE")) a.debug = atoi(f);
     if (a.R <= 4) {
@@ -1694,7 +1713,10 @@ int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
         void* ws = nullptr;
         if (int e = ghm_scratch(ctx, (size_t)splits * a.R * P * sizeof(float), &ws)) return e;
         a.partial = (float*)ws;
+        a.nsplit = splits;
+        a.tickets = ghm_tickets(ctx, grid);
     }
+    const bool folded = a.tickets != nullptr;
     const dim3 g(grid, splits);
 #define GHM_IGEMM_CASE(BM_, BN_, WM_, WN_)                                                             \
     if (v.bm == BM_ && v.bn == BN_) {                                                                  \
@@ -1703,7 +1725,7 @@ int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
         else                                                                                           \
             hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, WT, false>), g, dim3(256), 0, ctx->stream, a); \
         GHM_LAUNCH_CHECK();                                                                            \
-        if (splits > 1) {                                                                              \
+        if (splits > 1 && !folded) {                                                                   \
             hipLaunchKernelGGL(igemm_splitk_epilogue, dim3(ceil_div(P * a.R, 256)), dim3(256), 0, ctx->stream, a, \
                                splits);                                                                \
             GHM_LAUNCH_CHECK();                                                                        \
@@ -1753,8 +1775,11 @@ int launch_igemm_x4(ghm_ctx* ctx, IgemmArgs4& a4) {
     void* ws = nullptr;
     if (int e = ghm_scratch(ctx, total * sizeof(float), &ws)) return e;
     float* part = (float*)ws;
-    for (int c = 0; c < 4; ++c) {                   // every class goes through its partial slices (one epilogue for all)
-        a4.c[c].partial = part;
+    int* const tk = ghm_tickets(ctx, 4 * grid);
+    for (int c = 0; c < 4; ++c) {                   // every class goes through its partial slices (reduced by the last block
+        a4.c[c].partial = part;                     // to arrive at each output tile, or by one epilogue launch for all)
+        a4.c[c].tickets = tk;
+        a4.c[c].nsplit = a4.nsplit[c];
         part += (size_t)a4.nsplit[c] * a4.c[c].R * P;
     }
     const dim3 g(grid, smax, 4);
@@ -1765,8 +1790,10 @@ int launch_igemm_x4(ghm_ctx* ctx, IgemmArgs4& a4) {
         else                                                                                                     \
             hipLaunchKernelGGL((igemm_kernel_x4<BM_, BN_, WM_, WN_, false>), g, dim3(256), 0, ctx->stream, a4);   \
         GHM_LAUNCH_CHECK();                                                                                      \
-        hipLaunchKernelGGL(igemm_splitk_epilogue_x4, dim3(ceil_div(P * a0.R, 256), 4), dim3(256), 0, ctx->stream, a4); \
-        GHM_LAUNCH_CHECK();                                                                                      \
+        if (!tk) {                                                                                               \
+            hipLaunchKernelGGL(igemm_splitk_epilogue_x4, dim3(ceil_div(P * a0.R, 256), 4), dim3(256), 0, ctx->stream, a4); \
+            GHM_LAUNCH_CHECK();                                                                                  \
+        }                                                                                                        \
         return 0;                                                                                                \
     }
     GHM_IGEMM4_CASE(128, 128, 2, 2)

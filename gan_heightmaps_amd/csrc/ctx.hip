@@ -25,6 +25,16 @@ bool ghm_skip_kernel(const char* name) {
     return false;
 }
 
+int* ghm_tickets(ghm_ctx* ctx, long tiles) {
+    // OFF unless GHM_SPLITK_FOLD is set.  Measured (round 3, joint fp32 step): 152.9 img/s folded against 169.0 with the
+    // separate reduction launches -- the release / acquire pair around the ticket is an L2 write-back + invalidate per
+    // block on this multi-XCD part (the eight L2s are not coherent with each other), and with three other streams resident
+    // it evicts THEIR working sets too.  The ~75 small reduction launches per step cost 0.6 ms (GHM_SKIP_KERNELS ablation:
+    // 23.61 -> 23.01 ms); the fold costs 2.5 ms.  Kept for single-stream use and as the record of why it is not the default.
+    if (tiles > GHM_MAX_TICKETS || !ctx->tickets || !GHM_OPT("GHM_SPLITK_FOLD")) return nullptr;
+    return ctx->tickets;
+}
+
 static int g_plan_cus = 256;
 int ghm_plan_cus() { return g_plan_cus; }
 
@@ -80,6 +90,8 @@ int ghm_ctx_create(int32_t device, ghm_ctx** out) {
     g_plan_cus = c->num_cu;
     GHM_HIP(hipMalloc((void**)&c->zeros, 256));
     GHM_HIP(hipMemset(c->zeros, 0, 256));
+    GHM_HIP(hipMalloc((void**)&c->tickets, GHM_MAX_TICKETS * sizeof(int)));
+    GHM_HIP(hipMemset(c->tickets, 0, GHM_MAX_TICKETS * sizeof(int)));
     *out = c;
     return 0;
 }
@@ -95,6 +107,7 @@ int ghm_ctx_destroy(ghm_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (void* p : ctx->retired) (void)hipFree(p);
     if (ctx->zeros) (void)hipFree(ctx->zeros);
+    if (ctx->tickets) (void)hipFree(ctx->tickets);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;

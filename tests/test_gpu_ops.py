@@ -462,6 +462,15 @@ def test_conv_split_k(gpu, case, splits):
         ops.conv2d_dgrad(d, dyd, wd, dxd)
         ops.conv2d_dgrad(d, dyd, wd, dxd, accumulate=True)
         assert rel(dxd.numpy(), 2 * dx_ref) < TOL
+    # the opt-in form that folds the reduction into the producer (last block to arrive at a tile sums the slices in
+    # fixed order): bit-identical to the separate reduction launch, launch after launch (the counters reset themselves)
+    y_sep, dx_sep = yd.numpy(), dxd.numpy()
+    with tuning_env(GHM_FORCE_SPLITK=splits, GHM_SPLITK_FOLD="1"):
+        for _ in range(3):
+            ops.conv2d_fwd(d, xd, wd, bd, yd, act='lrelu', alpha=0.01)
+            ops.conv2d_dgrad(d, dyd, wd, dxd)
+            ops.conv2d_dgrad(d, dyd, wd, dxd, accumulate=True)
+            assert np.array_equal(yd.numpy(), y_sep) and np.array_equal(dxd.numpy(), dx_sep)
 
 
 @pytest.mark.parametrize("case", [(2, 16, 128, 128, 1, 5, 1, 2), (1, 8, 192, 192, 3, 3, 1, 1)])
