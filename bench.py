@@ -315,7 +315,8 @@ def main():
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         traffic = None
         kdt_name = args.dtype if dominant.startswith("lp_") else "f32"
-        for pmc in ("r02_pmc_traffic_%s.json" % ("f32" if kdt_name == "f32" else "bf16"), "r01_pmc_traffic.json"):    # tools/pmc_traffic.py
+        sfx = "f32" if kdt_name == "f32" else "bf16"
+        for pmc in ("r03_pmc_traffic_%s.json" % sfx, "r02_pmc_traffic_%s.json" % sfx, "r01_pmc_traffic.json"):    # tools/pmc_traffic.py
             pmc = os.path.join(ROOT, "profiles", pmc)
             if traffic is None and os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get(dominant, {}).get("hbm_bytes_per_launch")

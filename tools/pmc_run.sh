@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes for profiles/: counter calibration, then FETCH_SIZE / WRITE_SIZE per kernel of the f32 and bf16 steps
-# (counters only: --pmc with --kernel-trace, nothing else).   gpurun --timeout 1500 -- 'tools/pmc_run.sh r02'
-R=${1:-r02}
+# (counters only: --pmc with --kernel-trace, nothing else).   gpurun --timeout 1500 -- 'tools/pmc_run.sh r03'
+R=${1:-r03}
 O=$GRAFT_REPO_ROOT/gpurun_out/pmc
 mkdir -p $O
 export TMPDIR=/tmp

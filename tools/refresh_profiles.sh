@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the files under profiles/ for the current round (run through gpurun from the repo root, then copy
-# gpurun_out/refresh/* into profiles/):   gpurun --timeout 2400 -- 'tools/refresh_profiles.sh r02'
-R=${1:-r02}
+# gpurun_out/refresh/* into profiles/):   gpurun --timeout 2400 -- 'tools/refresh_profiles.sh r03'
+R=${1:-r03}
 O=gpurun_out/refresh
 mkdir -p $O
 export TMPDIR=/tmp
