@@ -1030,21 +1030,40 @@ __global__ __launch_bounds__(CHT * CT * (RS ? KS : 1) * 64, 1) void lp_wgrad_q_k
 #pragma unroll
         for (int fa = 0; fa < (RS ? 1 : KS); ++fa) xr[fa] = xlane + ((i * ST + (RS ? wr : fa) - PADK + NR) % NR) * ROWB;
         const char* const yb = ylane + buf * YB;
-        if (!(a.debug & 2))
+        if (!(a.debug & 2)) {
+            // the fragments of k-step ks + 1 are read while the MFMAs of k-step ks run (two transposing reads behind each
+            // MFMA): left to the compiler every read sits right in front of its MFMA and the wave pays the LDS latency
+            // TPW times per k-step
+            constexpr int NF = RS ? KS : T;               // A fragments per k-step and wave
+            u32x4 af[2][NF], bf[2];
+            auto read_step = [&](int ks, int slot) {
+                bf[slot] = lp_tr_read8(yb + ks * 1024, yb + ks * 1024 + 256);
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const u32x4 bf = lp_tr_read8(yb + ks * 1024, yb + ks * 1024 + 256);
+                for (int fa = 0; fa < (RS ? 1 : KS); ++fa)
 #pragma unroll
-            for (int fa = 0; fa < (RS ? 1 : KS); ++fa)
+                    for (int fb = 0; fb < KS; ++fb) {
+                        // local column of pixel t' and tap column fb: t' * ST + fb  ->  (parity plane, pixel in plane)
+                        const int par = ST == 2 ? (fb & 1) : 0;
+                        const int shift = ST == 2 ? (fb >> 1) : fb;
+                        const char* pa = xr[fa] + par * PLB + (ks * 16 + shift) * 64;
+                        af[slot][fa * KS + fb] = lp_tr_read8(pa, pa + 256);
+                    }
+            };
+            read_step(0, 0);
 #pragma unroll
-                for (int fb = 0; fb < KS; ++fb) {
-                    // local column of pixel t' and tap column fb: t' * ST + fb  ->  (parity plane, pixel in plane)
-                    const int par = ST == 2 ? (fb & 1) : 0;
-                    const int shift = ST == 2 ? (fb >> 1) : fb;
-                    const char* pa = xr[fa] + par * PLB + (ks * 16 + shift) * 64;
-                    const u32x4 af = lp_tr_read8(pa, pa + 256);
-                    acc[fa * KS + fb] = Lp<DT>::mfma(af, bf, acc[fa * KS + fb]);
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                if (ks + 1 < KSTEPS) read_step(ks + 1, (ks + 1) & 1);
+#pragma unroll
+                for (int t = 0; t < NF; ++t) acc[t] = Lp<DT>::mfma(af[ks & 1][t], bf[ks & 1], acc[t]);
+                if (ks + 1 < KSTEPS) {
+#pragma unroll
+                    for (int m_ = 0; m_ < NF + 1; ++m_) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1345,7 +1364,10 @@ LpWQPlan lp_wqplan(const ghm_conv_desc* d, int num_cu) {
     v.spx = d->Wo % 64 == 0 ? 64 : 32;
     v.ncols = d->N * (d->Wo / v.spx);
     const long tiles = (long)(d->C / (32 * v.cht)) * (d->K / (32 * v.ct)) * v.ncols;
-    long S = (2L * num_cu + tiles - 1) / tiles;              // about two rounds of one block per CU
+    // ONE round of resident blocks (a block per CU: 8-10 waves, up to 135 KB of LDS): every further split writes and
+    // re-reads another partial copy of the weight gradient -- measured (N4 C256 256^2 K64): 256 blocks 797 TFLOP/s, 512
+    // blocks 601, 128 blocks 507; the same optimum at one round for the 128^2, 64^2 and 5x5 layers
+    long S = num_cu / tiles;
     if (const char* f = GHM_OPT("GHM_LP_WGRAD_SPLITS")) S = atol(f);
     const long minrows = d->kh == 5 ? 8 : 4;                 // rows per split >= the cold start's KS x rows (and then some)
     const long max_by_work = d->Ho / minrows > 0 ? d->Ho / minrows : 1;
