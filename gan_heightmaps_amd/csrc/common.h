@@ -189,7 +189,8 @@ __device__ __forceinline__ float ghm_dact_from_out(float y, int act, float alpha
 // elementwise.hip: the reduction passes of ghm_bn_backward (dgamma / dbeta + the sums in the workspace tail)
 extern "C" int ghm_bn_backward_sums(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y, int64_t ys, const float* x,
                                     int64_t xs, int32_t N, int32_t C, int32_t HW, const float* mean, const float* inv,
-                                    float* dgamma, float* dbeta, int32_t act, float alpha, int32_t accumulate, void* ws);
+                                    float* dgamma, float* dbeta, int32_t act, float alpha, int32_t accumulate, void* ws,
+                                    const float* gamma, const float* beta);
 
 // ---- conv_thin.hip: layers with <= 4 channels on one side and large maps (HBM-bound) ----
 bool thin_fanout_fwd_ok(const ghm_conv_desc* d, int act);   // the kernel's epilogue does linear / relu / lrelu

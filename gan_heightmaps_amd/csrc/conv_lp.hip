@@ -353,9 +353,15 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
                 for (int i = 0; i < TM; ++i) af[0][i] = Wb[i * 32];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[0][j] = Pb[j * RPF * ST * PW];
+                if (a.debug & 32) {          // tuning: no fragment reads after the first -- the bare MFMA + barrier loop
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[1][i] = af[0][i];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[1][j] = bf[0][j];
+                }
 #pragma unroll
                 for (int b = 0; b < KS; ++b) {
-                    if (b + 1 < KS) {
+                    if (b + 1 < KS && !(a.debug & 32)) {
 #pragma unroll
                         for (int i = 0; i < TM; ++i) af[(b + 1) & 1][i] = Wb[(b + 1) * BM + i * 32];
 #pragma unroll
@@ -375,8 +381,10 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
                     __builtin_amdgcn_sched_barrier(0);      // keep the one-column lead
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (!(a.debug & 16)) {           // (tuning bit 16: no waits / barriers in the loop)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
         }
     }
 

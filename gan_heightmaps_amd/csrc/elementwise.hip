@@ -69,6 +69,18 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     }
 }
 
+// The backward kernels need act'(y) of the layer output y = act((x - mean) * gamma * inv + beta).  With y == nullptr they
+// RECOMPUTE it from x with the forward pass's own expression (bit-identical: same fmaf, same activation code), so the
+// backward pass does not read the output tensor at all -- and the forward pass need not keep it for the backward.
+__device__ __forceinline__ float bn_y(const float* y, long off, float xv, float m, float sc, float be, int act, float alpha) {
+    return y ? y[off] : ghm_act(fmaf(xv - m, sc, be), act, alpha);
+}
+__device__ __forceinline__ float4 bn_y4(const float* y, long off, const float4 xx, float m, float sc, float be, int act, float alpha) {
+    if (y) return *reinterpret_cast<const float4*>(y + off);
+    return make_float4(ghm_act(fmaf(xx.x - m, sc, be), act, alpha), ghm_act(fmaf(xx.y - m, sc, be), act, alpha),
+                       ghm_act(fmaf(xx.z - m, sc, be), act, alpha), ghm_act(fmaf(xx.w - m, sc, be), act, alpha));
+}
+
 // Row-structured partials, grid (S = N * segs, C): block (n, seg) of channel c sums one contiguous run of the
 // (n, c) row with 16-byte loads and no per-element index arithmetic; sums and products in fp64.  BWD: sums of dz and dz * xhat (dz = dout * act'(y)); otherwise sums of x and x^2.
 template <bool BWD>
@@ -76,7 +88,8 @@ __global__ __launch_bounds__(256) void bn_rows_partial(const float* __restrict__
                                                        long ds, const float* __restrict__ y, long ys, int HW, int segs,
                                                        int seg_len, const float* __restrict__ mean,
                                                        const float* __restrict__ inv, int act, float alpha,
-                                                       double* __restrict__ ws) {
+                                                       double* __restrict__ ws, const float* __restrict__ gamma = nullptr,
+                                                       const float* __restrict__ beta = nullptr) {
     const int c = blockIdx.y, s = blockIdx.x;
     const int n = s / segs, seg = s - n * segs;
     const int lo = seg * seg_len, hi = min(lo + seg_len, HW);
@@ -85,13 +98,14 @@ __global__ __launch_bounds__(256) void bn_rows_partial(const float* __restrict__
     double a = 0.0, b = 0.0;
     if constexpr (BWD) {
         const float* dp = dout + n * ds + row;
-        const float* yp = y + n * ys + row;
+        const float* yp = y ? y + n * ys + row : nullptr;
         const float m = mean[c], iv = inv[c];
+        const float sc = y ? 0.f : gamma[c] * iv, be = y ? 0.f : beta[c];
 #pragma unroll 2
         for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
             const float4 d = *reinterpret_cast<const float4*>(dp + i);
-            const float4 yy = *reinterpret_cast<const float4*>(yp + i);
             const float4 xx = *reinterpret_cast<const float4*>(xp + i);
+            const float4 yy = bn_y4(yp, i, xx, m, sc, be, act, alpha);
             const float z0 = d.x * ghm_dact_from_out(yy.x, act, alpha), z1 = d.y * ghm_dact_from_out(yy.y, act, alpha);
             const float z2 = d.z * ghm_dact_from_out(yy.z, act, alpha), z3 = d.w * ghm_dact_from_out(yy.w, act, alpha);
             a += ((double)z0 + (double)z1) + ((double)z2 + (double)z3);
@@ -171,18 +185,22 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ dout, long ds, const float* __restrict__ y,
                                                       long ys, const float* __restrict__ x, long xs, int N, int HW, int S,
                                                       const float* __restrict__ mean, const float* __restrict__ inv,
-                                                      int act, float alpha, double* __restrict__ ws) {
+                                                      int act, float alpha, double* __restrict__ ws,
+                                                      const float* __restrict__ gamma = nullptr,
+                                                      const float* __restrict__ beta = nullptr) {
     const int c = blockIdx.y, s = blockIdx.x;
     const long total = (long)N * HW;
     const long chunk = (total + S - 1) / S;
     const long lo = s * chunk, hi = min(lo + chunk, total);
     const float m = mean[c], iv = inv[c];
+    const float sc = y ? 0.f : gamma[c] * iv, be = y ? 0.f : beta[c];
     double a = 0.0, b = 0.0;
     for (long e = lo + threadIdx.x; e < hi; e += 256) {
         const long n = e / HW, i = e - n * HW;
         const long o = (long)c * HW + i;
-        const float dz = dout[n * ds + o] * ghm_dact_from_out(y[n * ys + o], act, alpha);
-        const float xh = (x[n * xs + o] - m) * iv;
+        const float xv = x[n * xs + o];
+        const float dz = dout[n * ds + o] * ghm_dact_from_out(bn_y(y, n * ys + o, xv, m, sc, be, act, alpha), act, alpha);
+        const float xh = (xv - m) * iv;
         a += dz;
         b += (double)dz * xh;
     }
@@ -216,16 +234,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ do
                                                     long dxs, View v, const float* __restrict__ mean,
                                                     const float* __restrict__ inv, const float* __restrict__ gamma,
                                                     const float* __restrict__ sums, float inv_count, int act,
-                                                    float alpha) {
+                                                    float alpha, const float* __restrict__ beta = nullptr) {
     long n, c, i;
     if (!decode<VEC>(v, n, c, i)) return;
     const float m = mean[c], iv = inv[c], g = gamma[c] * iv;
+    const float be = y ? 0.f : beta[c];
     const float mb = sums[2 * c] * inv_count, mg = sums[2 * c + 1] * inv_count;
     const long o = c * v.HW + i;
     if constexpr (VEC == 4) {
         const float4 d = *reinterpret_cast<const float4*>(dout + n * ds + o);
-        const float4 yy = *reinterpret_cast<const float4*>(y + n * ys + o);
         const float4 xx = *reinterpret_cast<const float4*>(x + n * xs + o);
+        const float4 yy = bn_y4(y, n * ys + o, xx, m, g, be, act, alpha);
         float4 r;
         r.x = g * (d.x * ghm_dact_from_out(yy.x, act, alpha) - mb - (xx.x - m) * iv * mg);
         r.y = g * (d.y * ghm_dact_from_out(yy.y, act, alpha) - mb - (xx.y - m) * iv * mg);
@@ -233,8 +252,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ do
         r.w = g * (d.w * ghm_dact_from_out(yy.w, act, alpha) - mb - (xx.w - m) * iv * mg);
         *reinterpret_cast<float4*>(dx + n * dxs + o) = r;
     } else {
-        const float dz = dout[n * ds + o] * ghm_dact_from_out(y[n * ys + o], act, alpha);
-        const float xh = (x[n * xs + o] - m) * iv;
+        const float xv = x[n * xs + o];
+        const float dz = dout[n * ds + o] * ghm_dact_from_out(bn_y(y, n * ys + o, xv, m, g, be, act, alpha), act, alpha);
+        const float xh = (xv - m) * iv;
         dx[n * dxs + o] = g * (dz - mb - xh * mg);
     }
 }
@@ -994,26 +1014,29 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const float* __restri
                                                            float* __restrict__ dx, long dxs, int N, int HW,
                                                            const float* __restrict__ mean, const float* __restrict__ inv,
                                                            const float* __restrict__ gamma, float* dgamma, float* dbeta,
-                                                           int act, float alpha, int accumulate) {
+                                                           int act, float alpha, int accumulate,
+                                                           const float* __restrict__ beta = nullptr) {
     const int c = blockIdx.x;
     const int units = HW / VEC, total = N * units;
     const long row = (long)c * HW;
     const float m = mean[c], iv = inv[c];
+    const float sc = gamma[c] * iv, be = y ? 0.f : beta[c];
     double a = 0.0, b = 0.0;
     for (int e = threadIdx.x; e < total; e += 256) {
         const int n = e / units, i = (e - n * units) * VEC;
         if constexpr (VEC == 4) {
             const float4 d = *reinterpret_cast<const float4*>(dout + n * ds + row + i);
-            const float4 yy = *reinterpret_cast<const float4*>(y + n * ys + row + i);
             const float4 xx = *reinterpret_cast<const float4*>(x + n * xs + row + i);
+            const float4 yy = bn_y4(y, n * ys + row + i, xx, m, sc, be, act, alpha);
             const float z0 = d.x * ghm_dact_from_out(yy.x, act, alpha), z1 = d.y * ghm_dact_from_out(yy.y, act, alpha);
             const float z2 = d.z * ghm_dact_from_out(yy.z, act, alpha), z3 = d.w * ghm_dact_from_out(yy.w, act, alpha);
             a += ((double)z0 + (double)z1) + ((double)z2 + (double)z3);
             b += ((double)z0 * ((xx.x - m) * iv) + (double)z1 * ((xx.y - m) * iv)) +
                  ((double)z2 * ((xx.z - m) * iv) + (double)z3 * ((xx.w - m) * iv));
         } else {
-            const float dz = dout[n * ds + row + i] * ghm_dact_from_out(y[n * ys + row + i], act, alpha);
-            const float xh = (x[n * xs + row + i] - m) * iv;
+            const float xv = x[n * xs + row + i];
+            const float dz = dout[n * ds + row + i] * ghm_dact_from_out(bn_y(y, n * ys + row + i, xv, m, sc, be, act, alpha), act, alpha);
+            const float xh = (xv - m) * iv;
             a += dz;
             b += (double)dz * xh;
         }
@@ -1032,8 +1055,8 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const float* __restri
         const int n = e / units, i = (e - n * units) * VEC;
         if constexpr (VEC == 4) {
             const float4 d = *reinterpret_cast<const float4*>(dout + n * ds + row + i);
-            const float4 yy = *reinterpret_cast<const float4*>(y + n * ys + row + i);
             const float4 xx = *reinterpret_cast<const float4*>(x + n * xs + row + i);
+            const float4 yy = bn_y4(y, n * ys + row + i, xx, m, sc, be, act, alpha);
             float4 r;
             r.x = g * (d.x * ghm_dact_from_out(yy.x, act, alpha) - mb - (xx.x - m) * iv * mg);
             r.y = g * (d.y * ghm_dact_from_out(yy.y, act, alpha) - mb - (xx.y - m) * iv * mg);
@@ -1041,8 +1064,9 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const float* __restri
             r.w = g * (d.w * ghm_dact_from_out(yy.w, act, alpha) - mb - (xx.w - m) * iv * mg);
             *reinterpret_cast<float4*>(dx + n * dxs + row + i) = r;
         } else {
-            const float dz = dout[n * ds + row + i] * ghm_dact_from_out(y[n * ys + row + i], act, alpha);
-            const float xh = (x[n * xs + row + i] - m) * iv;
+            const float xv = x[n * xs + row + i];
+            const float dz = dout[n * ds + row + i] * ghm_dact_from_out(bn_y(y, n * ys + row + i, xv, m, sc, be, act, alpha), act, alpha);
+            const float xh = (xv - m) * iv;
             dx[n * dxs + row + i] = g * (dz - mb - xh * mg);
         }
     }
@@ -1143,20 +1167,21 @@ int ghm_bn_forward(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t y
 // apply pass needs (shared with elementwise_q.hip)
 int ghm_bn_backward_sums(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y, int64_t ys, const float* x, int64_t xs,
                          int32_t N, int32_t C, int32_t HW, const float* mean, const float* inv, float* dgamma, float* dbeta,
-                         int32_t act, float alpha, int32_t accumulate, void* ws) {
+                         int32_t act, float alpha, int32_t accumulate, void* ws, const float* gamma, const float* beta) {
+    GHM_CHECK(y != nullptr || (gamma != nullptr && beta != nullptr), "BatchNorm backward without y needs gamma and beta");
     const long count = (long)N * HW;
     int S = bn_split(C, count), seg_len = 0;
     double* wsd = (double*)ws;
     float* sums = (float*)((char*)ws + (size_t)C * BN_MAX_SPLIT * 2 * sizeof(double));
-    const bool vec = HW % 4 == 0 && ds % 4 == 0 && ys % 4 == 0 && xs % 4 == 0 && aligned16(dout) && aligned16(y) && aligned16(x);
+    const bool vec = HW % 4 == 0 && ds % 4 == 0 && (!y || ys % 4 == 0) && xs % 4 == 0 && aligned16(dout) && aligned16(y) && aligned16(x);
     const int segs = vec ? bn_row_segs(N, C, HW, &seg_len) : 0;
     if (segs > 0) {
         S = N * segs;
         hipLaunchKernelGGL((bn_rows_partial<true>), dim3(S, C), dim3(256), 0, ctx->stream, x, (long)xs, dout, (long)ds, y,
-                           (long)ys, HW, segs, seg_len, mean, inv, act, alpha, wsd);
+                           (long)ys, HW, segs, seg_len, mean, inv, act, alpha, wsd, gamma, beta);
     } else {
         hipLaunchKernelGGL(bn_bwd_partial, dim3(S, C), dim3(256), 0, ctx->stream, dout, (long)ds, y, (long)ys, x, (long)xs, N,
-                           HW, S, mean, inv, act, alpha, wsd);
+                           HW, S, mean, inv, act, alpha, wsd, gamma, beta);
     }
     GHM_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_final, dim3(ceil_div(C, 256)), dim3(256), 0, ctx->stream, (const double*)wsd, C, S, sums,
@@ -1165,37 +1190,55 @@ int ghm_bn_backward_sums(ghm_ctx* ctx, const float* dout, int64_t ds, const floa
     return 0;
 }
 
-int ghm_bn_backward(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y, int64_t ys, const float* x, int64_t xs,
-                    float* dx, int64_t dxs, int32_t N, int32_t C, int32_t HW, const float* mean, const float* inv,
-                    const float* gamma, float* dgamma, float* dbeta, int32_t act, float alpha, int32_t accumulate,
-                    void* ws) {
+static int bn_backward_impl(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y, int64_t ys, const float* x, int64_t xs,
+                            float* dx, int64_t dxs, int32_t N, int32_t C, int32_t HW, const float* mean, const float* inv,
+                            const float* gamma, const float* beta, float* dgamma, float* dbeta, int32_t act, float alpha,
+                            int32_t accumulate, void* ws) {
     const long count = (long)N * HW;
+    GHM_CHECK(y != nullptr || beta != nullptr, "BatchNorm backward without y needs beta");
     if (bn_small(count)) {
-        if (HW % 4 == 0 && ds % 4 == 0 && ys % 4 == 0 && xs % 4 == 0 && dxs % 4 == 0 && aligned16(dout) && aligned16(y) &&
+        if (HW % 4 == 0 && ds % 4 == 0 && (!y || ys % 4 == 0) && xs % 4 == 0 && dxs % 4 == 0 && aligned16(dout) && aligned16(y) &&
             aligned16(x) && aligned16(dx))
             hipLaunchKernelGGL((bn_bwd_small_kernel<4>), dim3(C), dim3(256), 0, ctx->stream, dout, (long)ds, y, (long)ys, x,
-                               (long)xs, dx, (long)dxs, N, HW, mean, inv, gamma, dgamma, dbeta, act, alpha, accumulate);
+                               (long)xs, dx, (long)dxs, N, HW, mean, inv, gamma, dgamma, dbeta, act, alpha, accumulate, beta);
         else
             hipLaunchKernelGGL((bn_bwd_small_kernel<1>), dim3(C), dim3(256), 0, ctx->stream, dout, (long)ds, y, (long)ys, x,
-                               (long)xs, dx, (long)dxs, N, HW, mean, inv, gamma, dgamma, dbeta, act, alpha, accumulate);
+                               (long)xs, dx, (long)dxs, N, HW, mean, inv, gamma, dgamma, dbeta, act, alpha, accumulate, beta);
         GHM_LAUNCH_CHECK();
         return 0;
     }
-    if (int e = ghm_bn_backward_sums(ctx, dout, ds, y, ys, x, xs, N, C, HW, mean, inv, dgamma, dbeta, act, alpha, accumulate, ws))
+    if (int e = ghm_bn_backward_sums(ctx, dout, ds, y, ys, x, xs, N, C, HW, mean, inv, dgamma, dbeta, act, alpha, accumulate, ws,
+                                     gamma, beta))
         return e;
     const float* sums = (const float*)((char*)ws + (size_t)C * BN_MAX_SPLIT * 2 * sizeof(double));
-    const bool vec = HW % 4 == 0 && ds % 4 == 0 && ys % 4 == 0 && xs % 4 == 0 && dxs % 4 == 0 && aligned16(dout) &&
+    const bool vec = HW % 4 == 0 && ds % 4 == 0 && (!y || ys % 4 == 0) && xs % 4 == 0 && dxs % 4 == 0 && aligned16(dout) &&
                      aligned16(y) && aligned16(x) && aligned16(dx);
     const View v{N, C, HW};
     if (vec) {
         hipLaunchKernelGGL((bn_bwd_apply<4>), EW_GRID((long)N * C * (HW / 4)), dout, (long)ds, y, (long)ys, x, (long)xs, dx,
-                           (long)dxs, v, mean, inv, gamma, sums, 1.f / (float)count, act, alpha);
+                           (long)dxs, v, mean, inv, gamma, sums, 1.f / (float)count, act, alpha, beta);
     } else {
         hipLaunchKernelGGL((bn_bwd_apply<1>), EW_GRID((long)N * C * HW), dout, (long)ds, y, (long)ys, x, (long)xs, dx,
-                           (long)dxs, v, mean, inv, gamma, sums, 1.f / (float)count, act, alpha);
+                           (long)dxs, v, mean, inv, gamma, sums, 1.f / (float)count, act, alpha, beta);
     }
     GHM_LAUNCH_CHECK();
     return 0;
+}
+
+int ghm_bn_backward(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y, int64_t ys, const float* x, int64_t xs,
+                    float* dx, int64_t dxs, int32_t N, int32_t C, int32_t HW, const float* mean, const float* inv,
+                    const float* gamma, float* dgamma, float* dbeta, int32_t act, float alpha, int32_t accumulate,
+                    void* ws) {
+    GHM_CHECK(y != nullptr, "ghm_bn_backward: y == NULL (use ghm_bn_backward_x, which recomputes it from x)");
+    return bn_backward_impl(ctx, dout, ds, y, ys, x, xs, dx, dxs, N, C, HW, mean, inv, gamma, nullptr, dgamma, dbeta, act, alpha,
+                            accumulate, ws);
+}
+
+int ghm_bn_backward_x(ghm_ctx* ctx, const float* dout, int64_t ds, const float* x, int64_t xs, float* dx, int64_t dxs,
+                      int32_t N, int32_t C, int32_t HW, const float* mean, const float* inv, const float* gamma,
+                      const float* beta, float* dgamma, float* dbeta, int32_t act, float alpha, int32_t accumulate, void* ws) {
+    return bn_backward_impl(ctx, dout, ds, nullptr, 0, x, xs, dx, dxs, N, C, HW, mean, inv, gamma, beta, dgamma, dbeta, act, alpha,
+                            accumulate, ws);
 }
 
 int ghm_act_fwd(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t ys, int32_t N, int32_t C, int32_t HW,

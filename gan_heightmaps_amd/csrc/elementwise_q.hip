@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_q_kernel(const float* __rest
                                                              long dxs, int N, int C8, int HW, const float* __restrict__ mean,
                                                              const float* __restrict__ inv, const float* __restrict__ gamma,
                                                              const float* __restrict__ sums, float inv_count, int act,
-                                                             float alpha, u32x4q* __restrict__ q, long qns, int dt) {
+                                                             float alpha, u32x4q* __restrict__ q, long qns, int dt,
+                                                             const float* __restrict__ beta) {
     int n, cb;
     long p2;
     if (!q_decode((long)blockIdx.x * 256 + threadIdx.x, N, C8, HW / 2, n, cb, p2)) return;
@@ -80,8 +81,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_q_kernel(const float* __rest
         const float mb = sums[2 * c] * inv_count, mg = sums[2 * c + 1] * inv_count;
         const long o = (long)c * HW + 2 * p2;
         const float2 d = *reinterpret_cast<const float2*>(dout + (long)n * ds + o);
-        const float2 yy = *reinterpret_cast<const float2*>(y + (long)n * ys + o);
         const float2 xx = *reinterpret_cast<const float2*>(x + (long)n * xs + o);
+        float2 yy;          // y == nullptr: recomputed from x with the forward pass's own expression (elementwise.hip bn_y)
+        if (y) {
+            yy = *reinterpret_cast<const float2*>(y + (long)n * ys + o);
+        } else {
+            const float be = beta[c];
+            yy = make_float2(ghm_act(fmaf(xx.x - m, g, be), act, alpha), ghm_act(fmaf(xx.y - m, g, be), act, alpha));
+        }
         v0[j] = g * (d.x * ghm_dact_from_out(yy.x, act, alpha) - mb - (xx.x - m) * iv * mg);
         v1[j] = g * (d.y * ghm_dact_from_out(yy.y, act, alpha) - mb - (xx.y - m) * iv * mg);
         if (dx) *reinterpret_cast<float2*>(dx + (long)n * dxs + o) = make_float2(v0[j], v1[j]);
@@ -248,19 +255,21 @@ int ghm_bn_apply_q(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t y
 
 int ghm_bn_backward_q(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y, int64_t ys, const float* x, int64_t xs,
                       float* dx, int64_t dxs, int32_t N, int32_t C, int32_t HW, const float* mean, const float* inv,
-                      const float* gamma, float* dgamma, float* dbeta, int32_t act, float alpha, int32_t accumulate, void* ws,
-                      void* dxq, int64_t dxq_nstride, int32_t dtype) {
+                      const float* gamma, const float* beta, float* dgamma, float* dbeta, int32_t act, float alpha,
+                      int32_t accumulate, void* ws, void* dxq, int64_t dxq_nstride, int32_t dtype) {
+    GHM_CHECK(y != nullptr || beta != nullptr, "ghm_bn_backward_q: y == NULL needs beta (y is then recomputed from x)");
     GHM_CHECK(q_dtype_ok(dtype) && dxq && C % 8 == 0 && HW % 2 == 0 && ds % 2 == 0 && ys % 2 == 0 && xs % 2 == 0 &&
               dxs % 2 == 0 && (((uintptr_t)dout | (uintptr_t)y | (uintptr_t)x | (uintptr_t)dx) & 7) == 0 &&
               ((uintptr_t)dxq & 15) == 0,
               "ghm_bn_backward_q: bf16 / f16, C %% 8 == 0, even HW and strides, aligned tensors");
     // the parameter gradients and the two per-channel means: the reduction passes of ghm_bn_backward (they need no dx)
-    if (int e = ghm_bn_backward_sums(ctx, dout, ds, y, ys, x, xs, N, C, HW, mean, inv, dgamma, dbeta, act, alpha, accumulate, ws))
+    if (int e = ghm_bn_backward_sums(ctx, dout, ds, y, ys, x, xs, N, C, HW, mean, inv, dgamma, dbeta, act, alpha, accumulate, ws,
+                                     gamma, beta))
         return e;
     const float* sums = (const float*)((const char*)ws + ghm_bn_workspace(C) - (size_t)C * 2 * sizeof(float));
     hipLaunchKernelGGL(bn_bwd_apply_q_kernel, EWQ_GRID((long)N * (C / 8) * (HW / 2)), dout, (long)ds, y, (long)ys, x, (long)xs,
                        dx, (long)dxs, N, C / 8, HW, mean, inv, gamma, sums, 1.f / (float)((long)N * HW), act, alpha,
-                       (u32x4q*)dxq, (long)dxq_nstride, dtype);
+                       (u32x4q*)dxq, (long)dxq_nstride, dtype, beta);
     GHM_LAUNCH_CHECK();
     return 0;
 }

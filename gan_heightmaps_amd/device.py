@@ -482,10 +482,18 @@ class Ops:
         call("ghm_bn_apply_q", self.h, _vp(x), x.nstride, _vp(y), y.nstride if y is not None else 0, x.N, x.Cc, x.HW, _vp(mean),
              _vp(inv), _vp(gamma), _vp(beta), ACT_CODES[act], alpha, C.c_void_p(yq.ptr), yq.nstride, DTYPE_CODES[yq.dtype])
 
-    def bn_backward_q(self, dout, y, x, dx, mean, inv, gamma, dgamma, dbeta, ws, dxq, act='linear', alpha=0.0, accumulate=False):
-        call("ghm_bn_backward_q", self.h, _vp(dout), dout.nstride, _vp(y), y.nstride, _vp(x), x.nstride, _vp(dx),
-             dx.nstride if dx is not None else 0, x.N, x.Cc, x.HW, _vp(mean), _vp(inv), _vp(gamma), _vp(dgamma), _vp(dbeta),
-             ACT_CODES[act], alpha, int(accumulate), _vp(ws), C.c_void_p(dxq.ptr), dxq.nstride, DTYPE_CODES[dxq.dtype])
+    def bn_backward_q(self, dout, y, x, dx, mean, inv, gamma, dgamma, dbeta, ws, dxq, act='linear', alpha=0.0, accumulate=False,
+                      beta=None):
+        """y may be None when beta is given: the layer output is recomputed from x"""
+        call("ghm_bn_backward_q", self.h, _vp(dout), dout.nstride, _vp(y), y.nstride if y is not None else 0, _vp(x), x.nstride,
+             _vp(dx), dx.nstride if dx is not None else 0, x.N, x.Cc, x.HW, _vp(mean), _vp(inv), _vp(gamma), _vp(beta),
+             _vp(dgamma), _vp(dbeta), ACT_CODES[act], alpha, int(accumulate), _vp(ws), C.c_void_p(dxq.ptr), dxq.nstride,
+             DTYPE_CODES[dxq.dtype])
+
+    def bn_backward_x(self, dout, x, dx, mean, inv, gamma, beta, dgamma, dbeta, ws, act='linear', alpha=0.0, accumulate=False):
+        """ghm_bn_backward without reading y (recomputed from x, bit-identical to the forward pass's value)"""
+        call("ghm_bn_backward_x", self.h, _vp(dout), dout.nstride, _vp(x), x.nstride, _vp(dx), dx.nstride, x.N, x.Cc, x.HW,
+             _vp(mean), _vp(inv), _vp(gamma), _vp(beta), _vp(dgamma), _vp(dbeta), ACT_CODES[act], alpha, int(accumulate), _vp(ws))
 
     def upsample_bilinear2_fwd_q(self, x, y, yq):
         assert y is None or y.contiguous

@@ -1102,7 +1102,9 @@ class NetPlan:
                     mark_written(xin)
             elif n.op == 'bn':
                 l = n.layer
-                gam = st.value(l.gamma)
+                # (the backward kernels recompute y = act(bn(x)) from x instead of reading the output tensor: bit-identical
+                # to the forward value, one tensor less to read in both of their passes)
+                gam, bet = st.value(l.gamma), st.value(l.beta)
                 if wgrad:
                     dg, db, aw = st.grad(l.gamma), st.grad(l.beta), accumulate_wgrad
                 else:
@@ -1134,8 +1136,8 @@ class NetPlan:
                 if giq is not None:
                     m, iv = n.aux['mean'], n.aux['inv']
                     dst32 = dst if gi32 else None
-                    prog.append(("bn_bwd", lambda G=G, y=y, x=x, dst32=dst32, giq=giq, m=m, iv=iv, gam=gam, dg=dg, db=db, a=a, aw=aw:
-                                 ops.bn_backward_q(G, y, x, dst32, m, iv, gam, dg, db, self.bn_ws, giq, a.kind, a.alpha, aw)))
+                    prog.append(("bn_bwd", lambda G=G, x=x, dst32=dst32, giq=giq, m=m, iv=iv, gam=gam, bet=bet, dg=dg, db=db, a=a, aw=aw:
+                                 ops.bn_backward_q(G, None, x, dst32, m, iv, gam, dg, db, self.bn_ws, giq, a.kind, a.alpha, aw, bet)))
                 elif self.bn_groups == 2:
                     hb = self.batch // 2
                     halves = (0, 1) if nslice is None else ((n0 // hb,) if (n1 - n0) == hb and n0 % hb == 0 else None)
@@ -1145,13 +1147,13 @@ class NetPlan:
                         sub = (lambda t, h=h: t.samples(h * hb, (h + 1) * hb)) if nslice is None else (lambda t: t)
                         m, iv = n.aux['mean_g'][h], n.aux['inv_g'][h]
                         awh = aw or idx > 0          # the second half adds to dgamma / dbeta
-                        prog.append(("bn_bwd", lambda G=sub(G), y=sub(y), x=sub(x), dst=sub(dst), m=m, iv=iv, gam=gam,
+                        prog.append(("bn_bwd", lambda G=sub(G), x=sub(x), dst=sub(dst), m=m, iv=iv, gam=gam, bet=bet,
                                      dg=dg, db=db, a=a, awh=awh:
-                                     ops.bn_backward(G, y, x, dst, m, iv, gam, dg, db, self.bn_ws, a.kind, a.alpha, awh)))
+                                     ops.bn_backward_x(G, x, dst, m, iv, gam, bet, dg, db, self.bn_ws, a.kind, a.alpha, awh)))
                 else:
                     m, iv = n.aux['mean'], n.aux['inv']
-                    prog.append(("bn_bwd", lambda G=G, y=y, x=x, dst=dst, m=m, iv=iv, gam=gam, dg=dg, db=db, a=a, aw=aw:
-                                 ops.bn_backward(G, y, x, dst, m, iv, gam, dg, db, self.bn_ws, a.kind, a.alpha, aw)))
+                    prog.append(("bn_bwd", lambda G=G, x=x, dst=dst, m=m, iv=iv, gam=gam, bet=bet, dg=dg, db=db, a=a, aw=aw:
+                                 ops.bn_backward_x(G, x, dst, m, iv, gam, bet, dg, db, self.bn_ws, a.kind, a.alpha, aw)))
                 if acc:
                     prog.append(("bn_bwd_acc", lambda dst=dst, gi=gi: ops.copy_view(dst, gi, True)))
                 done(l.gamma, l.beta)

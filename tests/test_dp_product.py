@@ -26,7 +26,7 @@ import torch.multiprocessing as tmp_  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = ['dcgan_gen', 'dcgan_disc', 'p2p_gen', 'p2p_disc']
-GRAD_WRITERS = ('conv2d_wgrad', 'channel_sum', 'bn_backward', 'upconv_expand_batched')
+GRAD_WRITERS = ('conv2d_wgrad', 'channel_sum', 'bn_backward_x', 'upconv_expand_batched')
 
 
 def _nets(seed):

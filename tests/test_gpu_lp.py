@@ -576,6 +576,9 @@ def test_elementwise_producers_with_a_q_epilogue(gpu, dtype):
     wide2, dxq2 = qbuf(x.shape)
     ops.bn_backward_q(dd, y1, xd, None, mean, inv, gd, dg2, db2, ws, dxq2, 'lrelu', 0.2)
     assert np.array_equal(dxq2.numpy(), dxq.numpy())
+    wide3, dxq3 = qbuf(x.shape)          # without y: recomputed from x (the form the step issues)
+    ops.bn_backward_q(dd, None, xd, None, mean, inv, gd, dg2, db2, ws, dxq3, 'lrelu', 0.2, beta=bd)
+    assert np.array_equal(dxq3.numpy(), dxq.numpy()) and np.array_equal(dg1.numpy(), dg2.numpy())
     # ---- Theano bilinear x2 ----
     u1, u2 = dev.empty((N, C, 2 * H, 2 * W)), dev.empty((N, C, 2 * H, 2 * W))
     ops.upsample_bilinear2_fwd(xd, u1)

@@ -285,6 +285,14 @@ def _check_batchnorm(gpu, shape, act, alpha):
     # accumulate on top of existing parameter gradients
     ops.bn_backward(dev.tensor(dout), yd, xd, dxd, md, ivd, gd, dgd, dbd, ws, act, alpha, accumulate=True)
     assert rel(dbd.numpy().ravel(), 2 * dbeta_ref) < 1e-4 and rel(dgd.numpy().ravel(), 2 * dgamma_ref) < 1e-4
+    # the form the step issues: no y -- the layer output is recomputed from x with the forward pass's own expression,
+    # so every result is bit-identical to the form that reads y (yd holds bn_apply's output for these statistics)
+    dx_y = dev.empty(shape)
+    dg_y, db_y, dg_x, db_x = (dev.empty((1, C, 1, 1)) for _ in range(4))
+    ops.bn_backward(dev.tensor(dout), yd, xd, dx_y, md, ivd, gd, dg_y, db_y, ws, act, alpha)
+    ops.bn_backward_x(dev.tensor(dout), xd, dxd, md, ivd, gd, bd, dg_x, db_x, ws, act, alpha)
+    assert np.array_equal(dxd.numpy(), dx_y.numpy())
+    assert np.array_equal(dg_x.numpy(), dg_y.numpy()) and np.array_equal(db_x.numpy(), db_y.numpy())
     # sample-strided views (a channel slice of a wider buffer, as the concat-in-place layers use)
     wide = dev.tensor(np.concatenate([x, rng.randn(*shape).astype(np.float32)], axis=1))
     view = wide.channels(0, C) if hasattr(wide, 'channels') else None
