@@ -165,6 +165,7 @@ def main():
     # ---- pick the dominant kernel from one instrumented (untimed) step ----
     dominant, launches_per_step, flops_per_step = None, 0, 0.0
     executed_flops_per_step = None
+    thin_rows = []
     if not args.graph:
         # three instrumented (untimed) steps, per-entry median: every entry runs alone between two HIP events
         runs = [eng.profile_train(B) for _ in range(3)]
@@ -190,6 +191,12 @@ def main():
             for label, ms, meta, lane_ in sorted(table, key=lambda t: -t[1])[:(400 if os.environ.get('GHM_PROFILE_ALL') else 40)]:
                 print("  %-2s %-18s %8.3f ms %s %s" % (lane_, label, ms, meta["kernel"] if meta else "",
                                                       meta["geom"] if meta else ""), file=sys.stderr)
+        # the thin first / last layers (<= 4 channels on one side) are HBM-bound: reported against their byte floor
+        # (input + output tensor once) and the 8 TB/s HBM peak, not against the MFMA peak
+        thin_rows = [{"entry": label, "kernel": meta["kernel"].split(" splits")[0], "geom": meta["geom"], "ms": round(ms, 4),
+                      "algorithmic_MB": round(meta["bytes"] / 1e6, 1), "GB/s": round(meta["bytes"] / ms / 1e6, 1),
+                      "frac_of_8TB/s": round(meta["bytes"] / ms / 1e6 / 8000.0, 3)}
+                     for label, ms, meta, _lane in table if meta and meta.get("thin") and ms > 0]
         dominant = max((k for k in by_kernel if by_kernel[k][2] > 0), key=lambda k: by_kernel[k][0])
         launches_per_step = by_kernel[dominant][1]
         flops_per_step = by_kernel[dominant][2]
@@ -291,6 +298,8 @@ def main():
         "losses": [float(x) for x in losses],
         # inputs uploaded from host arrays every step (the reference's train_fn(Z, X, Y) boundary); never ``value``
         "value_with_h2d": round(with_h2d, 3) if with_h2d else None,
+        "hbm_bound_layers": {"note": "thin first / last layers, each launch timed alone (cold clocks); bound = HBM 8 TB/s",
+                             "total_ms": round(sum(r["ms"] for r in thin_rows), 3), "launches": thin_rows} if thin_rows else None,
     }
     if world > 1:
         # data-parallel exchange, measured inside the timed region: the all-reduce of every (sub-)bucket on the

@@ -489,6 +489,12 @@ class NetPlan:
                     if i.alias is not None and i.alias[0] is n:
                         get_outq(i)
 
+    def _wq(self, d):
+        """is the weight gradient of this convolution the q-operand kernel (lp_wgrad_q: 3x3 stride 1 / 2, 5x5 stride 1)?
+        Measured against the register-staged lp_wgrad kernel at one round of resident blocks (bf16, TFLOP/s): 3x3 stride 1
+        594-830 vs 267-474, 5x5 1024-1115 vs 517-584, 3x3 stride 2 317-386 vs 277-319 (N4 C64 256^2: 193 vs 220)."""
+        return self.use_q and self._lp(d, 2) and self.ops.lp_wgrad_q_supported(d, self.dtype)
+
     def _fp32_needed(self, n):
         """does anything read the fp32 output of node n (which also has a q copy)?  Not when every consumer is a
         low-precision convolution whose forward AND weight gradient read the q copy."""
@@ -501,7 +507,7 @@ class NetPlan:
                 d = self._upconv_desc(c, n.out)
             else:
                 return True
-            if not (self._lp(d, 0) and d.stride == 1 and self._lp(d, 2) and self.ops.lp_wgrad_q_supported(d, self.dtype)):
+            if not (self._lp(d, 0) and self._wq(d)):
                 return True
         return False
 
@@ -898,8 +904,7 @@ class NetPlan:
                 # the fp32 tensor is written only if a fp32 kernel reads it (thin first layer, geometries not served)
                 dF = self._desc(n, x, Gf)
                 xq_ = xin.outq if nslice is None else (xin.outq.samples(n0, n1) if xin.outq is not None else None)
-                w_q = (self.use_q and xq_ is not None and self._lp(dF, 2) and dF.stride == 1
-                       and ops.lp_wgrad_q_supported(dF, self.dtype))
+                w_q = xq_ is not None and self._wq(dF)
                 d_lp = self.use_q and need_dx and self._lp(self._desc(n, sl(xin.out), Gf), 1)
                 q_wanted = (wgrad and w_q) or d_lp
                 Gfq = gradq_of(n, Gf, pack=False) if (q_wanted and Gf.Cc % 8 == 0 and Gf.H % 2 == 0 and Gf.W % 4 == 0) else None
@@ -924,10 +929,7 @@ class NetPlan:
                 # the q copy of the output gradient, for the low-precision weight gradient (before its stream forks off)
                 xq = None if (nslice is not None and xin.outq is None) else (xin.outq if nslice is None else
                                                                              (xin.outq.samples(n0, n1) if xin.outq is not None else None))
-                # (stride 2 stays on the register-staged kernel: measured 290 / 321 TFLOP/s against 203 / 258 for the q form,
-                # whose two new x rows of twice the width per slab make it DMA-issue-bound; stride 1: 267-474 -> 594-666)
-                wq_form = (wgrad and n.op in ('conv', 'convpool') and self.use_q and xq is not None and self._lp(d, 2)
-                           and d.stride == 1 and ops.lp_wgrad_q_supported(d, self.dtype))
+                wq_form = wgrad and n.op in ('conv', 'convpool') and xq is not None and self._wq(d)
                 Gq_w = gradq_of(n, G) if wq_form else None
                 if wgrad:
                     self._need_wgrad_ws(d)
@@ -1034,8 +1036,7 @@ class NetPlan:
                 G4 = G.reshape((x.N, 4 * K, x.H, x.W))
                 wpc, wpcT, dwpc = n.aux['wpc'], n.aux['wpcT'], n.aux['dwpc']
                 xq = xin.outq
-                G4q_w = gradq_of(n, G4) if (wgrad and self.use_q and xq is not None and self._lp(d, 2)
-                                            and ops.lp_wgrad_q_supported(d, self.dtype)) else None
+                G4q_w = gradq_of(n, G4) if (wgrad and xq is not None and self._wq(d)) else None
                 if wgrad:
                     self._need_wgrad_ws(d)
                     gw, gb = st.grad(l.W), st.grad(l.b)
@@ -1127,7 +1128,7 @@ class NetPlan:
                     else:
                         dq = self._upconv_desc(xin, xx.out)
                         gview = gi.reshape((xx.out.N, 4 * xin.shape[1], xx.out.H, xx.out.W))
-                    w_q = self._lp(dq, 2) and dq.stride == 1 and xx.outq is not None and ops.lp_wgrad_q_supported(dq, self.dtype)
+                    w_q = xx.outq is not None and self._wq(dq)
                     d_q = self._lp(dq, 1) or not req[id(xx)]
                     if (w_q or not wgrad) and (self._lp(dq, 1) or w_q):
                         giq = gradq_of(xin, gview, pack=False).reshape(gi.shape)
@@ -1225,7 +1226,12 @@ def conv_meta(ops, d, kind, dtype='f32', pooled=False):
         name = "lp_%s_kernel<%s, %d, %d>" % (fam, dtype, d.kh, d.stride)
     else:
         name = ops.conv_variant(d, kind)
-    return {"kernel": name, "dtype": dtype,
+    # algorithmic HBM bytes of the launch (the wide tensor(s) once): conv input + conv output, fp32; a fused
+    # conv + pool writes the pooled tensor and a 1-byte mask instead of the full-resolution output
+    xb, yb = 4.0 * d.N * d.C * d.H * d.W, 4.0 * d.N * d.K * d.Ho * d.Wo
+    if pooled:
+        yb = yb / 4 + yb / 16
+    return {"kernel": name, "dtype": dtype, "bytes": xb + yb, "thin": min(d.C, d.K) <= 4,
             "flops": 2.0 * d.N * d.K * d.Ho * d.Wo * d.C * d.kh * d.kw,
             "geom": "N%d C%d %dx%d K%d k%d s%d" % (d.N, d.C, d.H, d.W, d.K, d.kh, d.stride)}
 
