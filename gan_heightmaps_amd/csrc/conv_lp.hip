@@ -237,7 +237,7 @@ __device__ __forceinline__ float lp_pool2(float v0, float v1, unsigned& mask) {
 }
 
 template <int DT, int KS, int ST, int BM, int RT, int WM, int WN, int TW, bool POOL = false>
-__global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void lp_conv_kernel(const LpConvArgs a) {
     // TW = columns of the pixel tile (32, or 16 / 8 for narrow maps): the 32 pixel lanes of a fragment cover RPF = 32 / TW
     // consecutive rows of TW columns; the block's tile is (RT * RPF) rows x TW columns
     constexpr int T = KS * KS;
@@ -246,9 +246,11 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
     constexpr int PH = (ROWS - 1) * ST + KS, PW = (TW - 1) * ST + KS;
     constexpr int PUNITS = 2 * PH * PW;
     constexpr int WUNITS = 2 * KS * BM;
-    constexpr int NQ = (PUNITS + 255) / 256;
+    constexpr int NW = WM * WN, NT = NW * 64;       // waves / threads per block: 4 waves, or 8 for the 16-row tile (the
+                                                    // weight tile of a filter row is then staged once for twice the pixels)
+    constexpr int NQ = (PUNITS + NT - 1) / NT;
     constexpr int NI = WUNITS / 64;                 // DMA wave-instructions per weight tile
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
+    static_assert((NW == 4 || NW == 8) && TM >= 1 && TN >= 1, "4 or 8 waves");
     __shared__ __attribute__((aligned(16))) u32x4 smem[2 * WUNITS + 2 * PUNITS];
     u32x4* const Wl = smem;
     u32x4* const Pl = smem + 2 * WUNITS;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
     int p_off[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int e = tid + q * 256;
+        const int e = tid + q * NT;
         const int cb = e / (PH * PW), rem = e - cb * (PH * PW);
         const int py = rem / PW, px = rem - py * PW;
         const int y = y0 * ST + py - a.pad, x = x0 * ST + px - a.pad;
@@ -290,10 +292,10 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
     auto stage_patch = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            if (q * 256 + wave * 64 < PUNITS) {                  // wave-uniform: this wave has items in group q
+            if (q * NT + wave * 64 < PUNITS) {                   // wave-uniform: this wave has items in group q
                 const u32x4* g = p_off[q] >= 0 ? ibase + p_off[q] : a.zeros;
-                if (tid + q * 256 < PUNITS)
-                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Pl + buf * PUNITS + q * 256 + wave * 64), 16, 0, 0);
+                if (tid + q * NT < PUNITS)
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Pl + buf * PUNITS + q * NT + wave * 64), 16, 0, 0);
             }
         }
         ibase += 2 * HWin;
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void lp_conv_kernel(const LpConvArgs a) {
     auto stage_weights = [&](int s, int fa, int buf) {
         const u32x4* src = a.wq + ((long)(2 * s) * T + fa * KS) * a.Rpad + r0 + lane;
 #pragma unroll
-        for (int w0 = 0; w0 < NI; w0 += 4) {
+        for (int w0 = 0; w0 < NI; w0 += NW) {
             const int w = w0 + wave;
             if (w < NI) {
                 const int ci = w / (BM / 64), h = w - ci * (BM / 64);
@@ -1107,7 +1109,7 @@ struct LpPlan {
     int bm, rt, tw, splits, slabs_per_split, grid;
 };
 
-LpPlan lp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
+LpPlan lp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu, bool allow_rt16 = true) {
     LpPlan p;
     p.ok = false;
     if (GHM_OPT("GHM_NO_LP")) return p;
@@ -1116,6 +1118,14 @@ LpPlan lp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
     // pixel tile: 8 x 32 (stride 2: 4 x 32); narrow maps: 8 x 16 or 8 x 8 (fragments of 2 x 16 / 4 x 8 pixels)
     p.tw = W % 32 == 0 ? 32 : (W % 16 == 0 ? 16 : 8);
     p.rt = p.tw == 32 ? (st == 2 ? 4 : 8) : (p.tw == 16 ? 4 : 2);
+    // 16-row tile (8 waves, one block per CU): the weight tile of every filter row is staged once for twice the pixels.
+    // Measured (bf16, TFLOP/s, 8-row -> 16-row): 5x5 N8 C64 256^2 1172 -> 1248, N8 C128 128^2 1180 -> 1285; 3x3 layers
+    // 1097 -> 1095, 1068 -> 1025, 941 -> 898 (their weight tiles are small: the 8-wave barrier costs more than the
+    // staging saves) -> 5x5 only, from two rounds of 8-row blocks up.  GHM_LP_RT16 / GHM_LP_NO_RT16 force either.
+    if (allow_rt16 && p.tw == 32 && st == 1 && p.bm == 128 && H % 16 == 0 && GHM_OPT("GHM_LP_NO_RT16") == nullptr) {
+        const long g8 = (long)((R + p.bm - 1) / p.bm) * (W / 32) * (H / 8) * N;
+        if ((ks == 5 && g8 >= 2L * num_cu) || GHM_OPT("GHM_LP_RT16")) p.rt = 16;
+    }
     const int rows = p.rt * (32 / p.tw);
     if (R < 32 || (W % p.tw) || (H % rows) || (CH % 16) || CH < 16) return p;
     if (GHM_OPT("GHM_LP_NO_NARROW") && p.tw != 32) return p;
@@ -1187,9 +1197,11 @@ int lp_launch_conv(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a, int ks, int st,
     const dim3 g(pl.grid, pl.splits);
 #define GHM_LP_CASE(KS_, ST_, BM_, RT_, WM_, WN_, TW_)                                                              \
     if (ks == KS_ && st == ST_ && pl.bm == BM_ && pl.tw == TW_ && pl.rt == RT_) {                                   \
-        hipLaunchKernelGGL((lp_conv_kernel<DT, KS_, ST_, BM_, RT_, WM_, WN_, TW_>), g, dim3(256), 0, ctx->stream, a); \
+        hipLaunchKernelGGL((lp_conv_kernel<DT, KS_, ST_, BM_, RT_, WM_, WN_, TW_>), g, dim3(WM_ * WN_ * 64), 0, ctx->stream, a); \
         GHM_LAUNCH_CHECK();                                                                                         \
     } else
+    GHM_LP_CASE(5, 1, 128, 16, 2, 4, 32)
+    GHM_LP_CASE(3, 1, 128, 16, 2, 4, 32)
     GHM_LP_CASE(5, 1, 128, 8, 2, 2, 32)
     GHM_LP_CASE(5, 1, 64, 8, 1, 4, 32)
     GHM_LP_CASE(3, 1, 128, 8, 2, 2, 32)
@@ -1489,13 +1501,13 @@ static bool lp_pool_act_ok(int act) { return act == GHM_ACT_LINEAR || act == GHM
 bool lp_conv_pool_supported(const ghm_conv_desc* d, int act, int dtype) {
     if (dtype != GHM_DTYPE_BF16 && dtype != GHM_DTYPE_F16) return false;
     if (!(lp_pool_act_ok(act) && d->stride == 1 && d->kh == d->kw && d->Ho == d->H && d->Wo == d->W && d->H % 2 == 0)) return false;
-    const LpPlan pl = lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, ghm_plan_cus());
+    const LpPlan pl = lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, ghm_plan_cus(), false);
     return pl.ok && pl.tw == 32 && pl.splits == 1 && GHM_OPT("GHM_NO_POOL_FUSE") == nullptr;
 }
 
 static int lp_fwd_pool_io(ghm_ctx* ctx, const ghm_conv_desc* d, const LpIO& io, const void* wq, const float* bias,
                           unsigned char* mask, int act, float alpha, int dtype) {
-    const LpPlan pl = lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, ctx->num_cu);
+    const LpPlan pl = lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, ctx->num_cu, false);      // (pooled epilogue: 8-row tile)
     GHM_CHECK(pl.ok && pl.tw == 32 && pl.splits == 1, "lp_conv_fwd_pool: geometry not served");
     GHM_CHECK(!io.outq || d->K % 8 == 0, "q output needs a multiple of 8 channels");
     LpConvArgs a;
