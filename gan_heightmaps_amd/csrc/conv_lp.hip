@@ -1115,6 +1115,7 @@ LpPlan lp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu, b
     if (GHM_OPT("GHM_NO_LP")) return p;
     if (!((ks == 3 && (st == 1 || st == 2)) || (ks == 5 && st == 1))) return p;
     p.bm = R >= 96 ? 128 : 64;
+    if (const char* f = GHM_OPT("GHM_LP_BM")) p.bm = atoi(f) == 64 ? 64 : 128;       // tuning
     // pixel tile: 8 x 32 (stride 2: 4 x 32); narrow maps: 8 x 16 or 8 x 8 (fragments of 2 x 16 / 4 x 8 pixels)
     p.tw = W % 32 == 0 ? 32 : (W % 16 == 0 ? 16 : 8);
     p.rt = p.tw == 32 ? (st == 2 ? 4 : 8) : (p.tw == 16 ? 4 : 2);
