@@ -100,6 +100,10 @@ def main():
                     help="arithmetic of the convolution products.  f32 (default) = the reference's floatX=float32 and the "
                          "headline metric; bf16 / f16 = BASELINE configs 4 / 5 (matrix-core operands rounded, fp32 "
                          "accumulation, fp32 tensors / master weights / optimiser): an additional line, never the headline")
+    ap.add_argument("--config1", action="store_true",
+                    help="BASELINE config 1 instead of the headline workload: DCGAN 64x64 generator + discriminator "
+                         "(nch 64, div [2,2,4,4] / [8,4,2,1]), batch 16, train_mode='dcgan' -- an extra line for BASELINE.md, "
+                         "never the headline")
     ap.add_argument("--in-shp", type=int, default=512, choices=[512, 1024],
                     help="1024 = BASELINE config 5 geometry (one more U-Net level and DCGAN stage; beyond the reference)")
     args = ap.parse_args()
@@ -130,7 +134,20 @@ def main():
     backend = dict(device=dev, comm=comm, use_graph=issue, seed=0, verbose=False, two_streams=not args.one_stream,
                    side_streams=(not args.no_grad_streams) and not args.graph, dtype=args.dtype)
     S = args.in_shp
-    if S == 512:
+    if args.config1:
+        # the geometry tests/test_gpu_step.py::test_train_step_parity[config1_dcgan64_b16] checks against the oracle
+        from gan_heightmaps_amd.experiments import experiment_kwargs
+        from gan_heightmaps_amd.pix2pix import Pix2Pix
+        S, B = 64, 16
+        kw = experiment_kwargs('test1_nobn_bilin_both')
+        kw.update(in_shp=64, latent_dim=100, train_mode='dcgan', **backend)
+        kw['gen_params_dcgan'] = {'nch': 64, 'div': [2, 2, 4, 4], 'num_repeats': 0}
+        kw['disc_params_dcgan'] = dict(kw['disc_params_dcgan'], nch=64, div=[8, 4, 2, 1])
+        kw['gen_params_p2p'] = dict(kw['gen_params_p2p'], nf=4)
+        kw['disc_params_p2p'] = dict(kw['disc_params_p2p'], nf=4, mul_factor=[1, 2])
+        model = Pix2Pix(**kw)
+        args.mode = 'dcgan'
+    elif S == 512:
         model = make_model('test1_nobn_bilin_both', **backend)
     else:
         # config 5: the same architecture functions one level deeper (p2p.py:137 asserts 512 in the reference)
@@ -145,7 +162,7 @@ def main():
         # configs 2 / 3 of BASELINE.json: same nets, one stage trained
         model.engine.train_mode = args.mode
     eng = model.engine
-    Z, X, Y = synthetic_batch(B, 1000, S, seed=1000 + rank)
+    Z, X, Y = synthetic_batch(B, 100 if args.config1 else 1000, S, seed=1000 + rank)
     b = eng.built(B)
     if args.ablate:
         pats = [p for p in args.ablate.split(",") if p]
@@ -279,7 +296,8 @@ def main():
         "metric": "512px heightmap+texture train images/sec", "value": round(value, 3), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "test1_nobn_bilin_both joint DCGAN+pix2pix train step (train_mode=%s), %dx%d, "
+        "config": {"workload": ("BASELINE config 1: DCGAN 64x64 generator + discriminator, " if args.config1 else "") +
+                               "test1_nobn_bilin_both joint DCGAN+pix2pix train step (train_mode=%s), %dx%d, "
                                "batch %d per GPU, RMSprop lr 1e-4, LSGAN + 100*L1%s"
                                % (args.mode, S, S, B, "" if args.dtype == "f32" else
                                   "; convolution products in %s on the matrix cores, fp32 accumulation / tensors / "

@@ -1,10 +1,17 @@
 """Reduced-precision convolution semantics of the MI355X path (TEST INFRASTRUCTURE ONLY; beyond the reference, which
 computes in floatX=float32 -- experiment.5.sh:5 -- so there is nothing in /root/reference to pin this on).
 
-BASELINE configs 4 / 5 ask for bf16 / fp16 matrix-core arithmetic: the HIP kernels (csrc/conv_lp.hip) round the two
-operands of every convolution product to bf16 (or fp16) with round-to-nearest-even, multiply exactly and accumulate
-in float32; activations, gradients, BatchNorm, losses, master weights and the optimiser stay float32.  This module
-states that rule in numpy so the kernels can be checked bit-tightly: conv(round(x), round(W)) in float64.
+BASELINE configs 4 / 5 ask for bf16 / fp16 matrix-core arithmetic: the HIP kernels (csrc/conv_lp.hip) multiply operands
+rounded to bf16 (or fp16) with round-to-nearest-even exactly and accumulate in float32; BatchNorm statistics, losses,
+master weights and the optimiser stay float32.  This module states that rule in numpy so the kernels can be checked
+bit-tightly: conv(round(x), round(W)) in float64.
+
+Round 3: an operand is rounded ONCE, AT ITS PRODUCER, and stored as a "q tensor" (include/ghm.h) that every consumer
+reads -- forward convolution, data gradient and weight gradient see the identical rounded values.  Rounding is a
+function of the fp32 value alone, so this is the same arithmetic as rounding at each consumer: ROUND[dtype](t) below is
+both "what the kernel's operand is" and "what the producer's q epilogue must have stored" (tests: q == ROUND(fp32 result)
+bit for bit).  Where the fp32 copy of a tensor is no longer written at all (its only readers are low-precision
+products), nothing changes for this restatement: those readers never saw anything but the rounded value.
 """
 import numpy as np
 
