@@ -76,6 +76,8 @@ SIGNATURES = {
                           _p, _p, _i64, _i32],
     "ghm_bn_backward_x": [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _f, _i32, _p],
     "ghm_upsample_bilinear2_fwd_q": [_p, _p, _i64, _p, _i32, _i32, _i32, _i32, _p, _i64, _i32],
+    "ghm_bn_apply_hi": [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _f, _p, _i64, _i32],
+    "ghm_bn_backward_hi": [_p, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _f, _i32, _p, _p, _i32],
     "ghm_pp_to_hi_q": [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _i64, _i32],
     "ghm_maxpool2_mask_bwd_q": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f, _p, _i32, _p, _i64, _i32],
     "ghm_conv2d_wgrad_lp_q": [_p, _D, _p, _i64, _p, _i64, _p, _p, _i32, _i32],

@@ -192,6 +192,9 @@ extern "C" int ghm_bn_backward_sums(ghm_ctx* ctx, const float* dout, int64_t ds,
                                     float* dgamma, float* dbeta, int32_t act, float alpha, int32_t accumulate, void* ws,
                                     const float* gamma, const float* beta);
 
+extern "C" int ghm_bn_backward_finish(ghm_ctx* ctx, const double* wsd, int32_t C, int32_t S, float* sums, float* dgamma,
+                                      float* dbeta, int32_t accumulate);
+
 // ---- conv_thin.hip: layers with <= 4 channels on one side and large maps (HBM-bound) ----
 bool thin_fanout_fwd_ok(const ghm_conv_desc* d, int act);   // the kernel's epilogue does linear / relu / lrelu
 int thin_fanout_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,

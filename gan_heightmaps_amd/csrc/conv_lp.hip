@@ -612,27 +612,33 @@ __global__ __launch_bounds__(256, BM * RT >= 256 ? 2 : 3) void lp_dgrad_s2_kerne
             const int ta = (8 - tw) / 3, tb = (8 - tw) % 3;
             return (ta == 0 ? 1 : 0) * PW + (tb == 0 ? 1 : 0);
         };
-        u32x4 af[2][TM], bf[2][TN];
+        // the nine taps only ever read the dy fragment of a class pixel at (row, column) offsets {0, 1} x {0, 1}: the
+        // (TN + 1) x 2 distinct fragments of the wave's rows are read ONCE per slab and kept in registers (9 * TN LDS reads
+        // became 2 * (TN + 1): the loop was LDS-read-bound, 27 fragment reads for 18 MFMAs in the <64, 4> shape)
+        u32x4 af[2][TM], bf[TN + 1][2];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = Wb[i * 32];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = Pb[j * PW + p_off_of(0)];
+        for (int j = 0; j <= TN; ++j) {
+            bf[j][0] = Pb[j * PW];
+            bf[j][1] = Pb[j * PW + 1];
+        }
+        (void)p_off_of;
         if (!(a.debug & 2))
 #pragma unroll
         for (int tw = 0; tw < T; ++tw) {
             if (tw + 1 < T) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[(tw + 1) & 1][i] = Wb[(tw + 1) * BM + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[(tw + 1) & 1][j] = Pb[j * PW + p_off_of(tw + 1)];
             }
             const int ta = (8 - tw) / 3, tb = (8 - tw) % 3;
             const int cl = (ta == 1 ? 0 : 2) + (tb == 1 ? 0 : 1);
+            const int ro = ta == 0 ? 1 : 0, co = tb == 0 ? 1 : 0;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[cl][i][j] = Lp<DT>::mfma(af[tw & 1][i], bf[tw & 1][j], acc[cl][i][j]);
+                    acc[cl][i][j] = Lp<DT>::mfma(af[tw & 1][i], bf[j + ro][co], acc[cl][i][j]);
             __builtin_amdgcn_sched_barrier(0);      // keep the prefetch distance at one tap (register budget)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1236,21 +1242,22 @@ LpPlan lp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu) {
     if (GHM_OPT("GHM_NO_LP") || GHM_OPT("GHM_NO_LP_DGRAD_S2")) return p;
     if (!(d->stride == 2 && d->kh == 3 && d->kw == 3 && d->pad == 1 && d->H == 2 * d->Ho && d->W == 2 * d->Wo)) return p;
     if (d->Wo % 32 || d->K % 16 || d->K < 16 || d->C < 32 || (d->x_nstride & 1) || ((d->H * d->W) & 1)) return p;
-    // the split-K form writes and re-reads `splits` partial dx tensors -- more HBM traffic than the operands of these
-    // layers: a small grid first shrinks the tile (128 ch x 2 class rows -> 64 x 4 -> 64 x 2), then splits
+    // tile = (channels, class rows): 0 = 128 x 2, 1 = 64 x 4, 2 = 64 x 2.  Measured (tools/s2_dgrad_quick.sh, bf16, warm):
+    //   N8 C64 256^2 K128: 0.127 / 0.063 / 0.051 ms   N8 C128 128^2 K256: 0.047 / 0.040 / 0.042   N8 C256 64^2 K512: 0.053 / 0.045 / 0.032
+    // K is short on these layers (8 - 32 slabs): a block is mostly prologue + epilogue, and the smallest tile (3 blocks per
+    // CU, twice the blocks) hides them best; the larger tiles stay for the sweep (GHM_LP_DGRAD_S2_TILE)
     static const int tiles[3][2] = {{128, 2}, {64, 4}, {64, 2}};
+    static const int order[3] = {2, 1, 0};
     int forced = -1;
-    if (const char* f = GHM_OPT("GHM_LP_DGRAD_S2_TILE")) forced = atoi(f);
+    if (const char* f = GHM_OPT("GHM_LP_DGRAD_S2_TILE")) forced = *f ? atoi(f) : -1;
     bool found = false;
-    for (int t = d->C >= 96 ? 0 : 1; t < 3; ++t) {
-        if (forced >= 0) t = forced > 2 ? 2 : forced;
+    for (int o = 0; o < 3 && !found; ++o) {
+        const int t = forced >= 0 ? (forced > 2 ? 2 : forced) : order[o];
+        if (tiles[t][0] == 128 && d->C < 96 && forced < 0) continue;
         if (d->Ho % tiles[t][1] == 0) {
             p.bm = tiles[t][0]; p.rt = tiles[t][1];
             p.grid = ((d->C + p.bm - 1) / p.bm) * (d->Wo / 32) * (d->Ho / p.rt) * d->N;
             found = true;
-            // measured (tools/s2_sweep.sh): these layers are HBM-bound at this precision -- more, smaller blocks win
-            // over operand reuse; the 128-channel tile only pays on grids of several waves of blocks
-            if (p.grid >= (t == 0 ? 4 : 2) * num_cu) break;
         }
         if (forced >= 0) break;
     }

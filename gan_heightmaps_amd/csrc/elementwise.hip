@@ -1190,6 +1190,14 @@ int ghm_bn_backward_sums(ghm_ctx* ctx, const float* dout, int64_t ds, const floa
     return 0;
 }
 
+// the finishing pass of the BatchNorm backward reductions (S partials per channel in the workspace -> sums, dgamma, dbeta)
+int ghm_bn_backward_finish(ghm_ctx* ctx, const double* wsd, int32_t C, int32_t S, float* sums, float* dgamma, float* dbeta,
+                           int32_t accumulate) {
+    hipLaunchKernelGGL(bn_bwd_final, dim3(ceil_div(C, 256)), dim3(256), 0, ctx->stream, wsd, C, S, sums, dgamma, dbeta, accumulate);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
 static int bn_backward_impl(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y, int64_t ys, const float* x, int64_t xs,
                             float* dx, int64_t dxs, int32_t N, int32_t C, int32_t HW, const float* mean, const float* inv,
                             const float* gamma, const float* beta, float* dgamma, float* dbeta, int32_t act, float alpha,

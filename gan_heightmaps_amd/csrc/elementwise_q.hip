@@ -161,6 +161,126 @@ __global__ __launch_bounds__(256) void pp_to_hi_q_kernel(const float* __restrict
     o[2 * W + 1] = q_pack8(a[3], dt);
 }
 
+// ---- BatchNorm of a collapsed up-sample convolution fused with the parity interleave (dcgan.default_generator,
+// architectures/dcgan.py:22-31: Upscale2D -> conv -> BatchNorm -> rectify; DESIGN section 4 "collapsed").  The conv's
+// output x is parity-planar [4N, K, H, W]; the next layer wants hi [N, K, 2H, 2W].  Forward: normalise + activation and
+// the interleave in ONE pass (the parity-planar result is never written); backward: dout is read straight from the hi
+// layout through the inverse permutation (no hi_to_pp pass), y is recomputed from x.  Thread = 8 channels x one low-res
+// pixel = its 2x2 block.  pp sample 4n + p holds output parity p = 2*dy + dx.
+__global__ __launch_bounds__(256) void bn_apply_hi_kernel(const float* __restrict__ x, float* __restrict__ hi, long hi_nstride,
+                                                          int N, int K8, int H, int W, const float* __restrict__ mean,
+                                                          const float* __restrict__ inv, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int act, float alpha,
+                                                          u32x4q* __restrict__ q, long qns, int dt) {
+    int n, kb;
+    long px;
+    const long hw = (long)H * W;
+    if (!q_decode((long)blockIdx.x * 256 + threadIdx.x, N, K8, hw, n, kb, px)) return;
+    const int yy = (int)(px / W), xx = (int)(px - (long)yy * W);
+    const long plane = (long)K8 * 8 * hw;
+    float a[4][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = kb * 8 + k;
+        const float sc = gamma[c] * inv[c], m = mean[c], be = beta[c];
+        const float* src = x + ((long)n * 4) * plane + ((long)c * H + yy) * W + xx;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) a[p][k] = ghm_act(fmaf(src[p * plane] - m, sc, be), act, alpha);
+        if (hi) {
+            float* dst = hi + (long)n * hi_nstride + ((long)c * 2 * H + 2 * yy) * (2 * W) + 2 * xx;
+            *reinterpret_cast<float2*>(dst) = make_float2(a[0][k], a[1][k]);
+            *reinterpret_cast<float2*>(dst + 2 * W) = make_float2(a[2][k], a[3][k]);
+        }
+    }
+    if (q) {
+        u32x4q* o = q + (long)n * qns + (long)kb * 4 * hw + (long)(2 * yy) * (2 * W) + 2 * xx;
+        o[0] = q_pack8(a[0], dt);
+        o[1] = q_pack8(a[1], dt);
+        o[2 * W] = q_pack8(a[2], dt);
+        o[2 * W + 1] = q_pack8(a[3], dt);
+    }
+}
+
+// grid (S, K): partial sums of dz and dz * xhat over the channel's N * H * W low-res pixels x 4 parities (fp64)
+__global__ __launch_bounds__(256) void bn_bwd_hi_partial(const float* __restrict__ dhi, long dhi_nstride, const float* __restrict__ x,
+                                                         int N, int K, int H, int W, int S, const float* __restrict__ mean,
+                                                         const float* __restrict__ inv, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int act, float alpha,
+                                                         double* __restrict__ ws, int max_split) {
+    const int c = blockIdx.y, s = blockIdx.x;
+    const long hw = (long)H * W, total = (long)N * hw, plane = (long)K * hw;
+    const long chunk = (total + S - 1) / S;
+    const long lo = s * chunk, hi_e = min(lo + chunk, total);
+    const float m = mean[c], iv = inv[c], sc = gamma[c] * iv, be = beta[c];
+    double sa = 0.0, sb = 0.0;
+    for (long e = lo + threadIdx.x; e < hi_e; e += 256) {
+        const long n = e / hw, i = e - n * hw;
+        const int yy = (int)(i / W), xx = (int)(i - (long)yy * W);
+        const float* dp = dhi + n * dhi_nstride + ((long)c * 2 * H + 2 * yy) * (2 * W) + 2 * xx;
+        const float2 d0 = *reinterpret_cast<const float2*>(dp), d1 = *reinterpret_cast<const float2*>(dp + 2 * W);
+        const float d[4] = {d0.x, d0.y, d1.x, d1.y};
+        const float* xp = x + (n * 4) * plane + (long)c * hw + i;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float xv = xp[p * plane];
+            const float dz = d[p] * ghm_dact_from_out(ghm_act(fmaf(xv - m, sc, be), act, alpha), act, alpha);
+            sa += dz;
+            sb += (double)dz * ((xv - m) * iv);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sa += __shfl_down(sa, off, 64);
+        sb += __shfl_down(sb, off, 64);
+    }
+    __shared__ double ra[4], rb[4];
+    if ((threadIdx.x & 63) == 0) {
+        ra[threadIdx.x >> 6] = sa;
+        rb[threadIdx.x >> 6] = sb;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ws[((long)c * max_split + s) * 2 + 0] = (ra[0] + ra[1]) + (ra[2] + ra[3]);
+        ws[((long)c * max_split + s) * 2 + 1] = (rb[0] + rb[1]) + (rb[2] + rb[3]);
+    }
+}
+
+// dx (parity-planar, fp32 and / or q) from dout in hi layout: thread = 8 channels x one low-res pixel
+__global__ __launch_bounds__(256) void bn_bwd_hi_apply(const float* __restrict__ dhi, long dhi_nstride, const float* __restrict__ x,
+                                                       float* __restrict__ dx, int N, int K8, int H, int W,
+                                                       const float* __restrict__ mean, const float* __restrict__ inv,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ sums, float inv_count, int act, float alpha,
+                                                       u32x4q* __restrict__ q, int dt) {
+    int n, kb;
+    long px;
+    const long hw = (long)H * W;
+    if (!q_decode((long)blockIdx.x * 256 + threadIdx.x, N, K8, hw, n, kb, px)) return;
+    const int yy = (int)(px / W), xx = (int)(px - (long)yy * W);
+    const long plane = (long)K8 * 8 * hw;
+    float a[4][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = kb * 8 + k;
+        const float m = mean[c], iv = inv[c], g = gamma[c] * iv, be = beta[c];
+        const float mb = sums[2 * c] * inv_count, mg = sums[2 * c + 1] * inv_count;
+        const float* dp = dhi + (long)n * dhi_nstride + ((long)c * 2 * H + 2 * yy) * (2 * W) + 2 * xx;
+        const float2 d0 = *reinterpret_cast<const float2*>(dp), d1 = *reinterpret_cast<const float2*>(dp + 2 * W);
+        const float d[4] = {d0.x, d0.y, d1.x, d1.y};
+        const long off = ((long)n * 4) * plane + (long)c * hw + px;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float xv = x[off + p * plane];
+            const float dz = d[p] * ghm_dact_from_out(ghm_act(fmaf(xv - m, g, be), act, alpha), act, alpha);
+            a[p][k] = g * (dz - mb - (xv - m) * iv * mg);
+            if (dx) dx[off + p * plane] = a[p][k];
+        }
+    }
+    if (q) {        // the parity-planar tensor seen as [N, 4K, H, W]: sample n, channel block p * K8 + kb
+#pragma unroll
+        for (int p = 0; p < 4; ++p) q[((long)n * 4 + p) * K8 * hw + (long)kb * hw + px] = q_pack8(a[p], dt);
+    }
+}
+
 // gradient of the (never materialised) full-resolution conv output behind a fused conv + act + 2x2 max-pool
 // (elementwise.hip maxpool2_mask_bwd_kernel): thread = 8 channels x TWO neighbouring pooled pixels -> a 2 x 4 window per
 // channel (16-byte fp32 rows, 64-byte q rows); with ``part`` the per-channel sums of what it writes (the conv's bias
@@ -270,6 +390,41 @@ int ghm_bn_backward_q(ghm_ctx* ctx, const float* dout, int64_t ds, const float* 
     hipLaunchKernelGGL(bn_bwd_apply_q_kernel, EWQ_GRID((long)N * (C / 8) * (HW / 2)), dout, (long)ds, y, (long)ys, x, (long)xs,
                        dx, (long)dxs, N, C / 8, HW, mean, inv, gamma, sums, 1.f / (float)((long)N * HW), act, alpha,
                        (u32x4q*)dxq, (long)dxq_nstride, dtype, beta);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_bn_apply_hi(ghm_ctx* ctx, const float* x_pp, float* hi, int64_t hi_nstride, int32_t N, int32_t K, int32_t H, int32_t W,
+                    const float* mean, const float* inv, const float* gamma, const float* beta, int32_t act, float alpha,
+                    void* hiq, int64_t hiq_nstride, int32_t dtype) {
+    GHM_CHECK((hi || hiq) && K % 8 == 0 && hi_nstride % 2 == 0 && ((uintptr_t)hi & 7) == 0 && ((uintptr_t)hiq & 15) == 0 &&
+              (!hiq || q_dtype_ok(dtype)), "ghm_bn_apply_hi: K %% 8 == 0, an output, aligned tensors, bf16 / f16 for the q output");
+    hipLaunchKernelGGL(bn_apply_hi_kernel, EWQ_GRID((long)N * (K / 8) * H * W), x_pp, hi, (long)hi_nstride, N, K / 8, H, W, mean, inv,
+                       gamma, beta, act, alpha, (u32x4q*)hiq, (long)hiq_nstride, dtype);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_bn_backward_hi(ghm_ctx* ctx, const float* dhi, int64_t dhi_nstride, const float* x_pp, float* dx_pp, int32_t N, int32_t K,
+                       int32_t H, int32_t W, const float* mean, const float* inv, const float* gamma, const float* beta,
+                       float* dgamma, float* dbeta, int32_t act, float alpha, int32_t accumulate, void* ws, void* dxq,
+                       int32_t dtype) {
+    GHM_CHECK((dx_pp || dxq) && K % 8 == 0 && dhi_nstride % 2 == 0 && ((uintptr_t)dhi & 7) == 0 && ((uintptr_t)dxq & 15) == 0 &&
+              (!dxq || q_dtype_ok(dtype)), "ghm_bn_backward_hi: K %% 8 == 0, an output, aligned tensors, bf16 / f16 for the q output");
+    const long count = (long)N * H * W;                     // low-res pixels per channel (x 4 parities)
+    const int max_split = (int)((ghm_bn_workspace(K) - (size_t)K * 2 * sizeof(float)) / ((size_t)K * 2 * sizeof(double)));
+    long S = (2048 + K - 1) / K;                            // ~8 blocks per CU over the K channels
+    if (S > count / 512) S = count / 512;
+    if (S > max_split) S = max_split;
+    if (S < 1) S = 1;
+    double* wsd = (double*)ws;
+    float* sums = (float*)((char*)ws + ghm_bn_workspace(K) - (size_t)K * 2 * sizeof(float));
+    hipLaunchKernelGGL(bn_bwd_hi_partial, dim3((unsigned)S, K), dim3(256), 0, ctx->stream, dhi, (long)dhi_nstride, x_pp, N, K, H, W,
+                       (int)S, mean, inv, gamma, beta, act, alpha, wsd, max_split);
+    GHM_LAUNCH_CHECK();
+    if (int e = ghm_bn_backward_finish(ctx, wsd, K, (int)S, sums, dgamma, dbeta, accumulate)) return e;
+    hipLaunchKernelGGL(bn_bwd_hi_apply, EWQ_GRID((long)N * (K / 8) * H * W), dhi, (long)dhi_nstride, x_pp, dx_pp, N, K / 8, H, W, mean,
+                       inv, gamma, beta, sums, 1.f / (float)(4 * count), act, alpha, (u32x4q*)dxq, dtype);
     GHM_LAUNCH_CHECK();
     return 0;
 }

@@ -505,6 +505,23 @@ class Ops:
         call("ghm_pp_to_hi_q", self.h, _vp(pp), _vp(hi), hi.nstride if hi is not None else 0, hiq.N, pp.Cc, pp.H, pp.W,
              C.c_void_p(hiq.ptr), hiq.nstride, DTYPE_CODES[hiq.dtype])
 
+    def bn_apply_hi(self, x_pp, hi, hiq, mean, inv, gamma, beta, act='linear', alpha=0.0):
+        """BatchNorm + activation of a parity-planar tensor written straight in the interleaved layout (hi and / or hiq)"""
+        assert x_pp.contiguous and (hi is not None or hiq is not None)
+        call("ghm_bn_apply_hi", self.h, _vp(x_pp), _vp(hi), hi.nstride if hi is not None else 0, x_pp.N // 4, x_pp.Cc, x_pp.H,
+             x_pp.W, _vp(mean), _vp(inv), _vp(gamma), _vp(beta), ACT_CODES[act], alpha,
+             C.c_void_p(hiq.ptr if hiq is not None else 0), hiq.nstride if hiq is not None else 0,
+             DTYPE_CODES[hiq.dtype] if hiq is not None else 0)
+
+    def bn_backward_hi(self, dhi, x_pp, dx_pp, dxq, mean, inv, gamma, beta, dgamma, dbeta, ws, act='linear', alpha=0.0,
+                       accumulate=False):
+        """backward of bn_apply_hi: dhi in the interleaved layout, dx (fp32 and / or q) parity-planar"""
+        assert x_pp.contiguous and (dx_pp is None or dx_pp.contiguous) and (dx_pp is not None or dxq is not None)
+        assert dxq is None or dxq.contiguous
+        call("ghm_bn_backward_hi", self.h, _vp(dhi), dhi.nstride, _vp(x_pp), _vp(dx_pp), x_pp.N // 4, x_pp.Cc, x_pp.H, x_pp.W,
+             _vp(mean), _vp(inv), _vp(gamma), _vp(beta), _vp(dgamma), _vp(dbeta), ACT_CODES[act], alpha, int(accumulate), _vp(ws),
+             C.c_void_p(dxq.ptr if dxq is not None else 0), DTYPE_CODES[dxq.dtype] if dxq is not None else 0)
+
     def maxpool2_mask_bwd_q(self, mask_ptr, y, dy, dx, dxq, act, alpha, dbias=None, accumulate=False):
         N, Cc, H, W = dxq.shape
         call("ghm_maxpool2_mask_bwd_q", self.h, C.c_void_p(int(mask_ptr)), _vp(y), _vp(dy), _vp(dx), N, Cc, H, W,

@@ -566,6 +566,13 @@ class NetPlan:
                          self.ops.lp_pack_weights(d, w, wq, self.dtype, t)))
         return wq
 
+    def _bn_hi(self, n):
+        """is n the BatchNorm of a collapsed up-sample convolution whose only reader is the parity interleave?  Then the
+        two run as one pass in both directions (csrc/elementwise_q.hip: bn_apply_hi / bn_backward_hi)."""
+        return (n.op == 'bn' and self.bn_groups == 1 and os.environ.get("GHM_NO_BN_HI") is None
+                and len(n.consumers) == 1 and n.consumers[0].op == 'pp_to_hi' and n.inputs[0].op == 'upconv'
+                and n.shape[1] % 8 == 0 and n.consumers[0].out.nstride % 2 == 0)
+
     def _need_wgrad_ws(self, d):
         b = self.ops.wgrad_workspace(d)
         if self._lp(d, 2):
@@ -595,6 +602,7 @@ class NetPlan:
         if self._lp_table is not None:
             prog.append(("lp_pack", lambda t=self._lp_table: ops.lp_pack_batched(t, self.dtype)))
         qpack = lambda t, q: prog.append(("q_pack", lambda t=t, q=q: ops.q_pack(t, q)))
+        fused_hi = set()            # pp_to_hi nodes whose output the BatchNorm in front of them writes
         for n in self.order:
             y = n.out
             if n.op in ('input', 'reshape', 'concat'):
@@ -677,6 +685,19 @@ class NetPlan:
                         prog.append(("bn_fwd", lambda xs=xs, ys=ys, m=m, iv=iv, rm=rm, ri=ri, l=l, upd=upd, g=g, be=be, a=a:
                                      ops.bn_forward(xs, ys, m, iv, g, be, self.bn_ws, rm if upd else None,
                                                     ri if upd else None, l.epsilon, l.alpha, a.kind, a.alpha)))
+                elif self._bn_hi(n):
+                    # BatchNorm of a collapsed up-sample convolution: statistics, then normalise + activation written
+                    # straight in the interleaved layout of the pp_to_hi node behind it (fp32 and / or q); the parity-planar
+                    # result is never stored (the backward pass recomputes it from x)
+                    m, iv = n.aux['mean'], n.aux['inv']
+                    upd = update_running
+                    sh = n.consumers[0]
+                    fused_hi.add(id(sh))
+                    hi32 = sh.out if (sh.outq is None or self._fp32_needed(sh)) else None
+                    prog.append(("bn_fwd", lambda x=x, m=m, iv=iv, rm=rm, ri=ri, l=l, upd=upd:
+                                 ops.bn_stats(x, m, iv, self.bn_ws, rm if upd else None, ri if upd else None, l.epsilon, l.alpha)))
+                    prog.append(("bn_fwd", lambda x=x, hi32=hi32, hiq=sh.outq, m=m, iv=iv, g=g, be=be, a=a:
+                                 ops.bn_apply_hi(x, hi32, hiq, m, iv, g, be, a.kind, a.alpha)))
                 elif n.outq is not None and x.HW % 2 == 0 and x.nstride % 2 == 0 and y.nstride % 2 == 0:
                     # statistics, then normalise + activation writing the fp32 result AND its q copy in one pass
                     m, iv = n.aux['mean'], n.aux['inv']
@@ -712,7 +733,9 @@ class NetPlan:
                     prog.append(("upconv_fwd", lambda d=d, x=x, wpc=wpc, b4=b4, y4=y4, a=a:
                                  ops.conv2d_fwd(d, x, wpc, b4, y4, a.kind, a.alpha), conv_meta(ops, d, 0)))
             elif n.op == 'pp_to_hi':
-                if n.outq is not None and y.nstride % 2 == 0:
+                if id(n) in fused_hi:
+                    q_direct = True                                # written by the BatchNorm in front of it
+                elif n.outq is not None and y.nstride % 2 == 0:
                     q_direct = True
                     y32 = y if self._fp32_needed(n) else None      # every consumer reads the q copy: no fp32 tensor
                     prog.append(("pp_to_hi", lambda x=x, y32=y32, yq=n.outq: ops.pp_to_hi_q(x, y32, yq)))
@@ -841,6 +864,7 @@ class NetPlan:
             if on_grads is not None and wgrad:
                 on_grads(prog, [p for p in params if p is not None])
 
+        hi_grads = set()        # BatchNorm nodes whose output gradient is held in the interleaved layout of their pp_to_hi reader
         gq_ready = set()        # nodes whose output-gradient q tensor was written by the kernel that produced the gradient
 
         def gradq_of(n, G, pack=True):
@@ -1095,7 +1119,12 @@ class NetPlan:
                                  ops.dropout(G, gi, p, k, c)))
                     mark_written(xin)
             elif n.op == 'pp_to_hi':
-                if need_dx:
+                if need_dx and nslice is None and self._bn_hi(xin) and G.nstride % 2 == 0:
+                    # the BatchNorm backward reads this gradient through the inverse permutation: no hi_to_pp pass
+                    grads[id(xin)] = G
+                    hi_grads.add(id(xin))
+                    mark_written(xin)
+                elif need_dx:
                     gi, acc = target(xin)
                     if acc or nslice is not None:
                         raise NotImplementedError("parity-planar tensor with several consumers / sample slices")
@@ -1134,7 +1163,12 @@ class NetPlan:
                         giq = gradq_of(xin, gview, pack=False).reshape(gi.shape)
                         gq_ready.add(id(xin))
                         gi32 = not ((w_q or not wgrad) and d_q)
-                if giq is not None:
+                if id(n) in hi_grads:
+                    m, iv = n.aux['mean'], n.aux['inv']
+                    dst32 = dst if (giq is None or gi32) else None
+                    prog.append(("bn_bwd", lambda G=G, x=x, dst32=dst32, giq=giq, m=m, iv=iv, gam=gam, bet=bet, dg=dg, db=db, a=a, aw=aw:
+                                 ops.bn_backward_hi(G, x, dst32, giq, m, iv, gam, bet, dg, db, self.bn_ws, a.kind, a.alpha, aw)))
+                elif giq is not None:
                     m, iv = n.aux['mean'], n.aux['inv']
                     dst32 = dst if gi32 else None
                     prog.append(("bn_bwd", lambda G=G, x=x, dst32=dst32, giq=giq, m=m, iv=iv, gam=gam, bet=bet, dg=dg, db=db, a=a, aw=aw:

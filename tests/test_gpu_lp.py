@@ -601,6 +601,40 @@ def test_elementwise_producers_with_a_q_epilogue(gpu, dtype):
     wide2, hq2 = qbuf((N, C, 2 * H, 2 * W))
     ops.pp_to_hi_q(ppd, None, hq2)
     assert np.array_equal(hq2.numpy(), hq.numpy())
+    # ---- BatchNorm of a parity-planar tensor fused with the interleave (both directions) ----
+    mean4, inv4 = dev.empty((1, C, 1, 1)), dev.empty((1, C, 1, 1))
+    ops.bn_stats(ppd, mean4, inv4, ws)
+    ypp = dev.empty(pp.shape)
+    ops.bn_apply(ppd, ypp, mean4, inv4, gd, bd, 'relu', 0.0)
+    ops.pp_to_hi(ypp, h1)
+    wide, hq = qbuf((N, C, 2 * H, 2 * W))
+    ops.bn_apply_hi(ppd, h2, hq, mean4, inv4, gd, bd, 'relu', 0.0)
+    assert np.array_equal(h1.numpy(), h2.numpy())
+    check_q(wide, hq, h1.numpy())
+    wide2, hq2 = qbuf((N, C, 2 * H, 2 * W))
+    ops.bn_apply_hi(ppd, None, hq2, mean4, inv4, gd, bd, 'relu', 0.0)
+    assert np.array_equal(hq2.numpy(), hq.numpy())
+    h3 = dev.zeros((N, C, 2 * H, 2 * W))
+    ops.bn_apply_hi(ppd, h3, None, mean4, inv4, gd, bd, 'relu', 0.0)
+    assert np.array_equal(h3.numpy(), h1.numpy())
+    dhi = rng.randn(N, C, 2 * H, 2 * W).astype(np.float32)
+    dhd = dev.tensor(dhi)
+    dpp = dev.empty(pp.shape)
+    ops.hi_to_pp(dhd, dpp)
+    dxa, dxb = dev.empty(pp.shape), dev.empty(pp.shape)
+    with tuning_env(GHM_NO_BN_SMALL="1"):
+        ops.bn_backward_x(dpp, ppd, dxa, mean4, inv4, gd, bd, dg1, db1, ws, 'relu', 0.0)
+    dxq = D.QTensor.empty(dev, pp.shape, dtype)
+    ops.bn_backward_hi(dhd, ppd, dxb, dxq, mean4, inv4, gd, bd, dg2, db2, ws, 'relu', 0.0)
+    assert rel(dxb.numpy(), dxa.numpy()) < 1e-6
+    assert rel(dg2.numpy(), dg1.numpy()) < 1e-6 and rel(db2.numpy(), db1.numpy()) < 1e-6   # (another summation order)
+    assert np.array_equal(dxq.numpy(), R(dxb.numpy()))
+    dxq2 = D.QTensor.empty(dev, pp.shape, dtype)
+    ops.bn_backward_hi(dhd, ppd, None, dxq2, mean4, inv4, gd, bd, dg2, db2, ws, 'relu', 0.0, accumulate=True)
+    assert np.array_equal(dxq2.numpy(), dxq.numpy()) and rel(dg2.numpy(), 2 * dg1.numpy()) < 1e-6
+    dxc = dev.zeros(pp.shape)
+    ops.bn_backward_hi(dhd, ppd, dxc, None, mean4, inv4, gd, bd, dg2, db2, ws, 'relu', 0.0)
+    assert np.array_equal(dxc.numpy(), dxb.numpy())
     # ---- backward of the fused conv + lrelu + 2x2 max-pool: full-resolution gradient from mask + pooled y + pooled dy ----
     Hf, Wf = 2 * H, 2 * W + 4                                   # (W % 4 == 0 for the plain kernel)
     Wp = Wf // 2
