@@ -1120,8 +1120,17 @@ LpPlan lp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu, b
     p.ok = false;
     if (GHM_OPT("GHM_NO_LP")) return p;
     if (!((ks == 3 && (st == 1 || st == 2)) || (ks == 5 && st == 1))) return p;
-    p.bm = R >= 96 ? 128 : 64;
-    if (const char* f = GHM_OPT("GHM_LP_BM")) p.bm = atoi(f) == 64 ? 64 : 128;       // tuning
+    // 64-filter-row blocks (1 x 4 waves, two blocks per CU) everywhere.  In isolation the 128-row tile (and its 16-row /
+    // 8-wave form on the 5x5 layers) is the faster kernel on the big layers, but the train step runs three streams of
+    // kernels on the one GPU, and there the smaller blocks win on every class -- measured in the step (tools/instep_sweep.sh,
+    // bf16, ms per step, same box): 128-row rule 6.96; 64 on the 5x5 layers 6.80; on the 3x3 s1 layers 6.85; on the 3x3 s2
+    // layers 6.95; on all 6.74.  GHM_LP_BM=128 restores the old rule (128 rows from 96 filters up) for sweeps.
+    p.bm = 64;
+    if (const char* f = GHM_OPT("GHM_LP_BM")) p.bm = (atoi(f) == 128 && R >= 96) ? 128 : 64;
+    if (const char* f = GHM_OPT("GHM_LP_BM128_MASK")) {                               // tuning: 1 = 5x5, 2 = 3x3 s1, 4 = 3x3 s2
+        const int cls = ks == 5 ? 1 : (st == 1 ? 2 : 4);
+        if ((atoi(f) & cls) && R >= 96) p.bm = 128;
+    }
     // pixel tile: 8 x 32 (stride 2: 4 x 32); narrow maps: 8 x 16 or 8 x 8 (fragments of 2 x 16 / 4 x 8 pixels)
     p.tw = W % 32 == 0 ? 32 : (W % 16 == 0 ? 16 : 8);
     p.rt = p.tw == 32 ? (st == 2 ? 4 : 8) : (p.tw == 16 ? 4 : 2);
@@ -1396,6 +1405,7 @@ LpWQPlan lp_wqplan(const ghm_conv_desc* d, int num_cu) {
     // re-reads another partial copy of the weight gradient -- measured (N4 C256 256^2 K64): 256 blocks 797 TFLOP/s, 512
     // blocks 601, 128 blocks 507; the same optimum at one round for the 128^2, 64^2 and 5x5 layers
     long S = num_cu / tiles;
+    if (const char* f = GHM_OPT("GHM_LP_WGRAD_ROUNDS")) S = (long)(atof(f) * num_cu / tiles);      // tuning
     if (const char* f = GHM_OPT("GHM_LP_WGRAD_SPLITS")) S = atol(f);
     const long minrows = d->kh == 5 ? 8 : 4;                 // rows per split >= the cold start's KS x rows (and then some)
     const long max_by_work = d->Ho / minrows > 0 ? d->Ho / minrows : 1;

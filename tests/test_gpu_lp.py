@@ -104,9 +104,21 @@ def _tensors(case, seed):
     return x, Wt, b, dy
 
 
+# the plan's tiles (64 filter rows; the smallest stride-2 data-gradient tile) and the larger ones kept behind tuning
+# switches: 128 filter rows, the 16-row / 8-wave form, the 128 x 2 and 64 x 4 stride-2 data-gradient tiles
+TILES = {"plan": {}, "wide": {"GHM_LP_BM": "128", "GHM_LP_RT16": "1", "GHM_LP_DGRAD_S2_TILE": "0"},
+         "mid": {"GHM_LP_BM": "128", "GHM_LP_NO_RT16": "1", "GHM_LP_DGRAD_S2_TILE": "1"}}
+
+
+@pytest.mark.parametrize("tiles", list(TILES))
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("case", CASES)
-def test_lp_conv_forward_dgrad_wgrad(gpu, case, dtype):
+def test_lp_conv_forward_dgrad_wgrad(gpu, case, dtype, tiles):
+    with tuning_env(**TILES[tiles]):
+        _lp_conv_forward_dgrad_wgrad(gpu, case, dtype)
+
+
+def _lp_conv_forward_dgrad_wgrad(gpu, case, dtype):
     dev, ops, D = gpu
     N, C, H, W, K, k, s, pad = case
     x, Wt, b, dy = _tensors(case, sum(case))
