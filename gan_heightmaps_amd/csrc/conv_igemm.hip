@@ -1638,6 +1638,44 @@ __global__ __launch_bounds__(256) void shift_expand_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// Fully-connected layer on a handful of samples (the generator's first layer: z [N, 1000] -> [N, 8192], dcgan.py:17-20):
+// P = N <= 8 output "pixels", one tap, forward weight layout wp[ch][r].  The MFMA tiles have nothing to hold on to here
+// (4 pixels of a 64-pixel tile, 64 blocks walking 1000 channels each: 0.12 ms, latency-bound, at the head of the step);
+// this is a weight-streaming GEMV: thread = output row r (lanes along r: 256-byte rows of W per wave and channel), the
+// sample values are wave-uniform scalar loads, the channel range is sliced over blockIdx.y and the slices are summed in
+// fixed order by the split-K epilogue (bias, activation, scatter).  Algorithmic bytes: the weight matrix once.
+template <int PMAX>
+__global__ __launch_bounds__(256) void dense_smallp_kernel(const IgemmArgs a) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int P = a.N * a.Hs * a.Ws, hw_s = a.Hs * a.Ws;
+    const int ch_begin = blockIdx.y * a.slabs_per_split;
+    const int ch_end = min(a.CH, ch_begin + a.slabs_per_split);
+    const long HinWin = (long)a.Hin * a.Win;
+    long src[PMAX];
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) {
+        const int n = p / hw_s, rem = p - n * hw_s, uu = rem / a.Ws, vv = rem - uu * a.Ws;
+        src[p] = p < P ? (long)n * a.in_nstride + (long)(uu * a.ss + a.di[0]) * a.Win + (vv * a.ss + a.dj[0]) : 0;
+    }
+    float acc[PMAX];
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) acc[p] = 0.f;
+    if (r < a.R) {
+        const float* w = a.wp + ((long)ch_begin * a.T + a.wi[0]) * a.R + r;
+        const long wstep = (long)a.T * a.R;
+#pragma unroll 8
+        for (int ch = ch_begin; ch < ch_end; ++ch, w += wstep) {
+            const float wv = *w;
+#pragma unroll
+            for (int p = 0; p < PMAX; ++p) acc[p] = fmaf(wv, a.in[src[p] + ch * HinWin], acc[p]);
+        }
+        float* o = a.partial + ((long)blockIdx.y * a.R + r) * P;
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p)
+            if (p < P) o[p] = acc[p];
+    }
+}
+
 struct Variant {
     int bm, bn;
 };
@@ -1692,6 +1730,28 @@ int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
         } else {
             hipLaunchKernelGGL((direct_smallr_kernel<WT>), dim3(ceil_div(P, 256)), dim3(256), 0, ctx->stream, a);
         }
+        GHM_LAUNCH_CHECK();
+        return 0;
+    }
+    if (!WT && a.ntaps == 1 && P <= 8 && a.R >= 1024 && a.CH >= 64 && a.os == 1 && GHM_OPT("GHM_NO_DENSE_SMALLP") == nullptr) {
+        // in range by construction (a 1x1 'valid' tap): no bounds test in the kernel
+        GHM_CHECK(a.di[0] >= 0 && a.dj[0] >= 0 && (a.Hs - 1) * a.ss + a.di[0] < a.Hin && (a.Ws - 1) * a.ss + a.dj[0] < a.Win,
+                  "dense_smallp: tap outside the input");
+        int S = (3 * ctx->num_cu) / ceil_div(a.R, 256);                 // ~3 blocks per CU
+        if (S > a.CH / 16) S = a.CH / 16;
+        if (S < 1) S = 1;
+        a.slabs_per_split = ceil_div(a.CH, S);
+        S = ceil_div(a.CH, a.slabs_per_split);
+        void* ws = nullptr;
+        if (int e = ghm_scratch(ctx, (size_t)S * a.R * P * sizeof(float), &ws)) return e;
+        a.partial = (float*)ws;
+        const dim3 g(ceil_div(a.R, 256), S);
+        if (P <= 4)
+            hipLaunchKernelGGL((dense_smallp_kernel<4>), g, dim3(256), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((dense_smallp_kernel<8>), g, dim3(256), 0, ctx->stream, a);
+        GHM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(igemm_splitk_epilogue, dim3(ceil_div(P * a.R, 256)), dim3(256), 0, ctx->stream, a, S);
         GHM_LAUNCH_CHECK();
         return 0;
     }
@@ -2575,6 +2635,8 @@ int ghm_conv2d_variant(const ghm_conv_desc* d, int32_t kind, char* out, int32_t 
         const long P = kind == 0 ? (long)d->N * d->Ho * d->Wo : (long)d->N * d->H * d->W / (d->stride * d->stride);
         if (R <= 4) {
             snprintf(out, out_len, "direct_smallr_kernel");
+        } else if (kind == 0 && d->kh == 1 && d->kw == 1 && P <= 8 && R >= 1024 && d->C >= 64 && !GHM_OPT("GHM_NO_DENSE_SMALLP")) {
+            snprintf(out, out_len, "dense_smallp_kernel");
         } else {
             const Variant v = pick_variant(R, P, ghm_plan_cus());
             snprintf(out, out_len, "igemm_kernel<%d,%d,%s>", v.bm, v.bn, kind == 0 ? "fwd" : "wt");

@@ -559,6 +559,25 @@ class Ops:
             call("ghm_maxpool2_mask_bwd_bias", self.h, C.c_void_p(int(mask_ptr)), _vp(y), _vp(dy), _vp(dx), dx.N, dx.Cc,
                  dx.H, dx.W, ACT_CODES[act], alpha, _vp(dbias), int(accumulate))
 
+    def pool_bwd_sparse_supported(self, d, act):
+        """bit 0: weight + bias gradient, bit 1: data gradient of a fused conv + act + pool layer from the pooled operands"""
+        return int(_lib.load().ghm_conv2d_pool_bwd_sparse_supported(C.byref(d), ACT_CODES[act]))
+
+    def pool_wgrad_sparse_workspace(self, d):
+        n = C.c_size_t()
+        call("ghm_conv2d_pool_wgrad_sparse_workspace", C.byref(d), C.byref(n))
+        return n.value
+
+    def conv2d_pool_wgrad_sparse(self, d, x, mask_ptr, yp, gp, dwp, dbias, ws, act, alpha, accumulate=False):
+        assert yp.contiguous and gp.contiguous
+        call("ghm_conv2d_pool_wgrad_sparse", self.h, C.byref(d), _vp(x), C.c_void_p(int(mask_ptr)), _vp(yp), _vp(gp), _vp(dwp),
+             _vp(dbias), ACT_CODES[act], alpha, int(accumulate), _vp(ws))
+
+    def conv2d_pool_dgrad_sparse(self, d, mask_ptr, yp, gp, wp, dx, act, alpha, accumulate=False):
+        assert yp.contiguous and gp.contiguous
+        call("ghm_conv2d_pool_dgrad_sparse", self.h, C.byref(d), C.c_void_p(int(mask_ptr)), _vp(yp), _vp(gp), _vp(wp), _vp(dx),
+             ACT_CODES[act], alpha, int(accumulate))
+
     def channel_sum(self, x, out, accumulate=False):
         call("ghm_channel_sum", self.h, _vp(x), x.N, x.Cc, x.HW, x.nstride, _vp(out), int(accumulate))
 

@@ -914,10 +914,41 @@ class NetPlan:
             a = n.act
             need_dx = req[id(xin)]
             if n.op == 'convpool':
-                # gradient of the conv's (never materialised) full-resolution output from the arg-max mask, the pooled
-                # value (sign -> activation derivative) and the pooled gradient; then an ordinary conv backward
                 fs = n.aux['full_shape']
                 per = int(np.prod(n.shape[1:]))                  # mask bytes per sample
+                # the discriminator's first block (one input channel): both gradients straight from the pooled operands
+                # (csrc/conv_pool_bwd.hip) -- the 537 MB full-resolution gradient is neither written nor read
+                dS = self._desc(n, x, self._full(n, nb))
+                sparse = int(ops.pool_bwd_sparse_supported(dS, a.kind) or 0)
+                if (sparse & 1 or not wgrad) and (sparse & 2 or not need_dx) and sparse:
+                    l = n.layer
+                    mptr = n.aux['mask'] + n0 * per
+                    if wgrad:
+                        b_ws = ops.pool_wgrad_sparse_workspace(dS)
+                        if b_ws > self._wgrad_ws_bytes:
+                            if self.wgrad_ws is not None:
+                                dev.free(self.wgrad_ws)
+                            self.wgrad_ws = dev.alloc(b_ws)
+                            self._wgrad_ws_bytes = b_ws
+                        gw, gb = st.grad(l.W), st.grad(l.b)
+                        wo, wdev = ops, None
+                        if self.side is not None:
+                            wdev, wo = self.side
+                            prog.append(("fork", lambda wdev=wdev: wdev.wait_for(dev), None, wdev))
+                        prog.append(("conv_wgrad", lambda dS=dS, x=x, m=mptr, y=y, G=G, gw=gw, gb=gb, a=a, aw=accumulate_wgrad, wo=wo:
+                                     wo.conv2d_pool_wgrad_sparse(dS, x, m, y, G, gw, gb, self.wgrad_ws, a.kind, a.alpha, aw),
+                                     pool_sparse_meta(dS, 2), wdev))
+                        done(l.W, l.b)
+                    if need_dx:
+                        gi, acc = target(xin)
+                        w = st.value(l.W)
+                        prog.append(("conv_dgrad", lambda dS=dS, m=mptr, y=y, G=G, w=w, gi=gi, a=a, acc=acc:
+                                     ops.conv2d_pool_dgrad_sparse(dS, m, y, G, w, gi, a.kind, a.alpha, acc), pool_sparse_meta(dS, 1)))
+                        mark_written(xin)
+                    continue
+                # otherwise: the gradient of the conv's (never materialised in the forward pass) full-resolution output from
+                # the arg-max mask, the pooled value (sign -> activation derivative) and the pooled gradient; then an
+                # ordinary conv backward
                 Gf = cache.get(('full', id(n)))
                 if Gf is None:
                     Gf = cache[('full', id(n))] = dev.empty((nb,) + tuple(fs[1:]))
@@ -1267,6 +1298,16 @@ def conv_meta(ops, d, kind, dtype='f32', pooled=False):
         yb = yb / 4 + yb / 16
     return {"kernel": name, "dtype": dtype, "bytes": xb + yb, "thin": min(d.C, d.K) <= 4,
             "flops": 2.0 * d.N * d.K * d.Ho * d.Wo * d.C * d.kh * d.kw,
+            "geom": "N%d C%d %dx%d K%d k%d s%d" % (d.N, d.C, d.H, d.W, d.K, d.kh, d.stride)}
+
+
+def pool_sparse_meta(d, kind):
+    """metadata of the d_conv1 gradients computed from the pooled operands (csrc/conv_pool_bwd.hip): algorithmic bytes =
+    pooled gradient + pooled activation (fp32) + mask (1 B) per pooled element (+ the thin tensor), flops = the 25
+    multiply-adds per pooled value the gather does (a quarter of the dense convolution's)"""
+    pooled = float(d.N) * d.K * (d.H // 2) * (d.W // 2)
+    return {"kernel": "pool_thin_wgrad_kernel" if kind == 2 else "pool_thin_dgrad_kernel", "dtype": 'f32',
+            "bytes": 9.0 * pooled + 4.0 * d.N * d.C * d.H * d.W, "thin": True, "flops": 2.0 * pooled * d.kh * d.kw,
             "geom": "N%d C%d %dx%d K%d k%d s%d" % (d.N, d.C, d.H, d.W, d.K, d.kh, d.stride)}
 
 

@@ -110,6 +110,12 @@ class PolicyOps(RecordingOps):
         self.calls.append(("lp_pack_table", tuple((int(t[2]), int(t[3]), int(t[4]), bool(t[5])) for t in items), {}))
         return (0, len(items), 1)
 
+    def pool_bwd_sparse_supported(self, d, act):
+        return 3 if (d.C == 1 and d.kh == 5 and d.kw == 5 and d.stride == 1 and d.K <= 64 and act in ('linear', 'relu', 'lrelu')) else 0
+
+    def pool_wgrad_sparse_workspace(self, d):
+        return 2048
+
     def conv_pool_supported(self, d, act, dtype='f32'):
         if act not in ('linear', 'relu', 'lrelu') or d.stride != 1 or d.Ho != d.H or d.W % 4:
             return 0

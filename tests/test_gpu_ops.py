@@ -44,6 +44,8 @@ CONV_CASES = [
     (2, 128, 24, 24, 128, 3, 1, 1),   # 128-wide tiles
     (1, 16, 7, 7, 16, 3, 2, 1),       # odd input with stride 2
     (4, 1000, 1, 1, 96, 1, 1, 0),     # DenseLayer as 1x1 conv (1000 % 16 != 0)
+    (4, 1000, 1, 1, 2048, 1, 1, 0),   # the generator's first layer, narrower (dense_smallp_kernel<4>: GEMV + slice sums)
+    (7, 200, 1, 1, 1100, 1, 1, 0),    # dense_smallp_kernel<8>, ragged row block (1100 = 4 * 256 + 76), 12 slices
     # geometries that take the LDS-patch kernels (Wo % 16 == 0, C*k*k >= 96)
     (2, 16, 32, 32, 128, 5, 1, 2),    # 5x5 s1, ragged channel tile (16 = 3*5 + 1)
     (1, 40, 32, 48, 64, 3, 1, 1),     # 3x3 s1, rectangular, 64 filters
@@ -727,6 +729,78 @@ def test_conv_lrelu_maxpool_fused(gpu, case, dtype):
     for t in (xd, bd, pooled, yd, pd, dpd, dx_mask, dx_ref, wp):
         dev.free(t.ptr)
     dev.free(mask)
+
+
+@pytest.mark.parametrize("case", [(4, 64, 64, 64), (3, 96, 128, 64), (2, 40, 256, 24), (2, 64, 1024, 8), (2, 32, 64, 72)])
+def test_conv_pool_backward_from_the_pooled_operands(gpu, case):
+    """ghm_conv2d_pool_wgrad_sparse / ghm_conv2d_pool_dgrad_sparse (d_conv1: 1 -> K, 5x5, LeakyRectify, MaxPool 2) against
+    (a) the float64 oracle VJP of conv -> lrelu -> max-pool and (b) the materialised device path they replace
+    (ghm_maxpool2_mask_bwd_bias + ghm_conv2d_wgrad / ghm_conv2d_dgrad).  The input has constant patches, so windows whose
+    maximum is tied (several mask bits set: the gradient goes to every arg-max position) are exercised too."""
+    dev, ops, D = gpu
+    N, H, W, K = case
+    rng = np.random.RandomState(sum(case))
+    x = rng.randn(N, 1, H, W).astype(np.float32)
+    x[:, :, : H // 4, : W // 4] = 0.25                     # constant patch: conv output constant -> 4-way ties
+    x[-1] = 0.0                                            # a whole image of ties (output = bias everywhere)
+    Wt = (rng.randn(K, 1, 5, 5) / 5.0).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    d = D.conv_desc(N, 1, H, W, K, 5, 5, 1, 2)
+    served = ops.pool_bwd_sparse_supported(d, 'lrelu')
+    assert served & 1 and bool(served & 2) == (K <= 64)
+    wp = dev.tensor(D.pack_conv_w(Wt).ravel())
+    xd, bd = dev.tensor(x), dev.tensor(b)
+    pooled = dev.empty((N, K, H // 2, W // 2))
+    mask = dev.alloc(N * K * (H // 2) * (W // 2))
+    if ops.conv_pool_supported(d, 'lrelu', 'f32'):
+        ops.conv2d_fwd_pool(d, xd, wp, bd, pooled, mask, 'lrelu', 0.2, 'f32')
+    else:                                                  # geometry the fused forward does not take: build its outputs
+        y = O.lrelu_fwd(O.conv2d_fwd(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), 1, 2), 0.2).astype(np.float32)
+        yp = y.reshape(N, K, H // 2, 2, W // 2, 2).max(axis=(3, 5))
+        bits = np.zeros(yp.shape, np.uint8)
+        for bb, (r, c) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+            bits |= ((y[:, :, r::2, c::2] == yp).astype(np.uint8) << bb)
+        pooled.set(yp)
+        dev.h2d(mask, bits)
+    gp = rng.randn(N, K, H // 2, W // 2).astype(np.float32)
+    gpd = dev.tensor(gp)
+    # (b) the materialised path
+    Gf = dev.empty((N, K, H, W))
+    db_ref = dev.zeros((1, K, 1, 1))
+    ops.maxpool2_mask_bwd(mask, pooled, gpd, Gf, 'lrelu', 0.2, db_ref)
+    assert (np.count_nonzero(Gf.numpy().reshape(N, K, H // 2, 2, W // 2, 2), axis=(3, 5)) > 1).any(), "no tied window in the test"
+    dw_ref = dev.zeros((1, 25 * K, 1, 1))
+    ws = dev.alloc(max(ops.wgrad_workspace(d), 16))
+    ops.conv2d_wgrad(d, xd, Gf, dw_ref, ws)
+    # (a) the oracle on the materialised gradient (itself checked against the oracle VJP in test_conv_lrelu_maxpool_fused)
+    dx64, dW64, db64 = O.conv2d_vjp(x.astype(np.float64), Wt.astype(np.float64), Gf.numpy().astype(np.float64), 1, 2)
+    ws2 = dev.alloc(max(ops.pool_wgrad_sparse_workspace(d), 16))
+    dw, db = dev.zeros((1, 25 * K, 1, 1)), dev.zeros((1, K, 1, 1))
+    ops.conv2d_pool_wgrad_sparse(d, xd, mask, pooled, gpd, dw, db, ws2, 'lrelu', 0.2)
+    assert rel(D.unpack_conv_w(dw.numpy().ravel(), K, 1, 5, 5), dW64) < TOL
+    assert rel(dw.numpy(), dw_ref.numpy()) < TOL
+    assert rel(db.numpy().ravel(), db64) < TOL and rel(db.numpy(), db_ref.numpy()) < TOL
+    ops.conv2d_pool_wgrad_sparse(d, xd, mask, pooled, gpd, dw, db, ws2, 'lrelu', 0.2, accumulate=True)
+    assert rel(dw.numpy(), 2 * dw_ref.numpy()) < TOL and rel(db.numpy().ravel(), 2 * db64) < TOL
+    dw2 = dev.zeros((1, 25 * K, 1, 1))
+    ops.conv2d_pool_wgrad_sparse(d, xd, mask, pooled, gpd, dw2, None, ws2, 'lrelu', 0.2)       # no bias gradient asked
+    ops.conv2d_pool_wgrad_sparse(d, xd, mask, pooled, gpd, dw, None, ws2, 'lrelu', 0.2)
+    assert np.array_equal(dw.numpy(), dw2.numpy())                                           # bit-repeatable
+    if served & 2:
+        dx_ref = dev.empty(x.shape)
+        ops.conv2d_dgrad(d, Gf, wp, dx_ref)
+        dx = dev.zeros(x.shape)
+        ops.conv2d_pool_dgrad_sparse(d, mask, pooled, gpd, wp, dx, 'lrelu', 0.2)
+        assert rel(dx.numpy(), dx64) < TOL and rel(dx.numpy(), dx_ref.numpy()) < TOL
+        ops.conv2d_pool_dgrad_sparse(d, mask, pooled, gpd, wp, dx, 'lrelu', 0.2, accumulate=True)
+        assert rel(dx.numpy(), 2 * dx64) < TOL
+        # a sample slice (the generator's gradient only needs the fake half of the batch)
+        if N >= 2:
+            ds = D.conv_desc(1, 1, H, W, K, 5, 5, 1, 2)
+            per = K * (H // 2) * (W // 2)
+            dxs = dev.zeros((1, 1, H, W))
+            ops.conv2d_pool_dgrad_sparse(ds, mask + per, pooled.samples(1, 2), gpd.samples(1, 2), wp, dxs, 'lrelu', 0.2)
+            assert rel(dxs.numpy(), dx64[1:2]) < TOL
 
 
 def test_conv_pool_not_served_is_refused(gpu):

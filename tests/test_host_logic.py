@@ -159,12 +159,16 @@ def test_discriminator_conv_lrelu_maxpool_is_fused_when_the_library_serves_it():
     bwd = []
     plan.emit_backward(bwd, seed, wgrad=True, tag="dloss")
     labels = [e[0] for e in bwd]
-    assert labels.count('maxpool_mask_bwd') == 3 and 'maxpool_bwd' not in labels
+    # (the first block, one input channel, takes both gradients straight from the pooled operands: no mask pass at all)
+    assert labels.count('maxpool_mask_bwd') == 2 and 'maxpool_bwd' not in labels
     assert labels.count('conv_wgrad') == 4 and labels.count('bias_grad') == 1       # only d_out's bias is a separate sum
     for e in bwd:
         e[1]()
     unpool = [c for c in ops.calls if c[0] == 'maxpool2_mask_bwd']
     assert all(c[1][6] is not None for c in unpool)                # the bias-gradient slice rides along
+    sparse = [c for c in ops.calls if c[0] == 'conv2d_pool_wgrad_sparse']
+    assert len(sparse) == 1 and sparse[0][1][2] == cp[0].aux['mask'] and sparse[0][1][6] is not None   # weights + bias
+    assert not [c for c in ops.calls if c[0] == 'conv2d_pool_dgrad_sparse']       # the D-loss pass needs no input gradient
     ops.calls.clear()
     g2 = []
     gin = plan.emit_backward(g2, dev.empty((2, 1, 1, 1)), nslice=(2, 4), wgrad=False,
@@ -172,10 +176,13 @@ def test_discriminator_conv_lrelu_maxpool_is_fused_when_the_library_serves_it():
     for e in g2:
         e[1]()
     unpool = [c for c in ops.calls if c[0] == 'maxpool2_mask_bwd']
-    assert len(unpool) == 3 and all(c[1][6] is None for c in unpool)
+    assert len(unpool) == 2 and all(c[1][6] is None for c in unpool)
     # the fake half's masks: byte offset = 2 samples into each mask buffer
     for c, n in zip(unpool, reversed(cp)):
         assert c[1][0] == n.aux['mask'] + 2 * int(np.prod(n.shape[1:]))
+    sparse = [c for c in ops.calls if c[0] == 'conv2d_pool_dgrad_sparse']
+    assert len(sparse) == 1 and sparse[0][1][1] == cp[0].aux['mask'] + 2 * int(np.prod(cp[0].shape[1:]))
+    assert sparse[0][1][0].N == 2 and not [c for c in ops.calls if c[0] == 'conv2d_pool_wgrad_sparse']
     assert gin[plan.input_nodes[0].layer].shape == (2, 1, 64, 64)
     # with GHM_NO_POOL_FUSE the graph keeps its max-pool nodes
     os.environ["GHM_NO_POOL_FUSE"] = "1"
