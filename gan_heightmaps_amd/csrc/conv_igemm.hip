@@ -1533,6 +1533,73 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
     }
 }
 
+// the same sum for MANY slices (the low-precision weight gradient splits a layer into up to 256 of them): one thread per
+// four elements walked S strided loads in a row, four in flight -- 64 dependent round trips to L2 / HBM, 30-60 us of pure
+// latency on a gradient of 0.6 MB.  Here G threads share the four elements: thread (tx, ty) sums slices ty, ty + G, ...
+// (four in flight), the G partial sums meet in LDS and are added in fixed order (ty = 0 .. G-1): bit-repeatable.
+template <int G>
+__global__ __launch_bounds__(256) void reduce_splits_wide_kernel(const float* __restrict__ part, int S, long n, long split_stride,
+                                                                 float* __restrict__ out, int accumulate) {
+    constexpr int EPB = 256 / G;
+    __shared__ float4 red[G][EPB];
+    const int tx = threadIdx.x % EPB, ty = threadIdx.x / EPB;
+    const long i = ((long)blockIdx.x * EPB + tx) * 4;
+    const bool vec = i + 3 < n && (split_stride & 3) == 0;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    if (vec) {
+        int k = ty;
+        for (; k + 3 * G < S; k += 4 * G) {
+            const float4 a = *reinterpret_cast<const float4*>(part + (long)(k + 0 * G) * split_stride + i);
+            const float4 b = *reinterpret_cast<const float4*>(part + (long)(k + 1 * G) * split_stride + i);
+            const float4 c = *reinterpret_cast<const float4*>(part + (long)(k + 2 * G) * split_stride + i);
+            const float4 d = *reinterpret_cast<const float4*>(part + (long)(k + 3 * G) * split_stride + i);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+            s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+            s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+        }
+        for (; k < S; k += G) {
+            const float4 a = *reinterpret_cast<const float4*>(part + (long)k * split_stride + i);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+    } else if (i < n) {
+        float* acc = &s0.x;
+        for (int e = 0; e < 4 && i + e < n; ++e)
+            for (int k = ty; k < S; k += G) acc[e] += part[(long)k * split_stride + i + e];
+    }
+    red[ty][tx] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                              (s0.w + s1.w) + (s2.w + s3.w));
+    __syncthreads();
+    if (ty == 0 && i < n) {
+        float4 r = red[0][tx];
+#pragma unroll
+        for (int g = 1; g < G; ++g) { const float4 t = red[g][tx]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+        if (vec) {
+            float4* o = reinterpret_cast<float4*>(out + i);
+            if (accumulate) { const float4 t = *o; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+            *o = r;
+        } else {
+            const float* rr = &r.x;
+            for (int e = 0; e < 4 && i + e < n; ++e) out[i + e] = (accumulate ? out[i + e] : 0.f) + rr[e];
+        }
+    }
+}
+
+static int launch_reduce_splits(ghm_ctx* ctx, const float* part, int S, long n, long split_stride, float* out, int accumulate) {
+    const long groups = (n + 3) / 4;
+    if (S >= 64 && !GHM_OPT("GHM_NO_WIDE_REDUCE"))
+        hipLaunchKernelGGL((reduce_splits_wide_kernel<8>), dim3(ceil_div(groups, 32)), dim3(256), 0, ctx->stream, part, S, n,
+                           split_stride, out, accumulate);
+    else if (S >= 16 && !GHM_OPT("GHM_NO_WIDE_REDUCE"))
+        hipLaunchKernelGGL((reduce_splits_wide_kernel<4>), dim3(ceil_div(groups, 64)), dim3(256), 0, ctx->stream, part, S, n,
+                           split_stride, out, accumulate);
+    else
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3(ceil_div(groups, 256)), dim3(256), 0, ctx->stream, part, S, n, split_stride,
+                           out, accumulate);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
 // per-channel sum over (n, hw): bias gradients. grid (S, C) partials, then one thread per channel.
 __global__ __launch_bounds__(256) void channel_sum_partial(const float* __restrict__ x, int N, int HW, long nstride,
                                                            int S, float* __restrict__ part, float* out, int accumulate) {
@@ -2050,10 +2117,7 @@ int ghm_splitk_finish(ghm_ctx* ctx, const float* partial, int S, float* out, con
 }
 
 int ghm_reduce_splits(ghm_ctx* ctx, const float* part, int S, long n, long split_stride, float* out, int accumulate) {
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(ceil_div((n + 3) / 4, 256)), dim3(256), 0, ctx->stream, part, S, n,
-                       split_stride, out, accumulate);
-    GHM_LAUNCH_CHECK();
-    return 0;
+    return launch_reduce_splits(ctx, part, S, n, split_stride, out, accumulate);
 }
 
 extern "C" {
@@ -2503,11 +2567,8 @@ static int wgrad_impl(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, cons
         return -3;
     }
 #undef GHM_WGRAD_CASE
-    if (v.splits > 1) {
-        hipLaunchKernelGGL(reduce_splits_kernel, dim3(ceil_div((n + 3) / 4, 256)), dim3(256), 0, ctx->stream,
-                           (const float*)workspace, v.splits, n, n, dwp, accumulate);
-        GHM_LAUNCH_CHECK();
-    }
+    if (v.splits > 1)
+        return launch_reduce_splits(ctx, (const float*)workspace, v.splits, n, n, dwp, accumulate);
     return 0;
 }
 

@@ -40,6 +40,7 @@ struct PoolThinArgs {
     int accumulate;
     int rb;                         // pooled rows per band (weight gradient)
     int ldp;                        // floats per (row, column parity) plane of the LDS tile, a multiple of 64
+    int debug;                      // tuning only (GHM_ABLATE): 1 = no x tile fill, 2 = no operand loads, 4 = no multiply-adds
 };
 
 // ---- weight + bias gradient: block = one image x one band of RB pooled rows x NW filters (one per wave) ----
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(NW * 64) void pool_thin_wgrad_kernel(const PoolThin
     const float* xn = a.x + (long)n * a.x_nstride;
     const int half = a.W / 2 + PADW;                     // indices per plane that hold data or padding
     const int fill = rows * 2 * half;
+    if (!(a.debug & 1))
     for (int e0 = tid; e0 < fill; e0 += NW * 64 * 8) {   // eight loads in flight per thread
         float v[8];
 #pragma unroll
@@ -86,30 +88,43 @@ __global__ __launch_bounds__(NW * 64) void pool_thin_wgrad_kernel(const PoolThin
 #pragma unroll
         for (int t = 0; t <= T; ++t) acc[t] = 0.f;
         const long base = (((long)n * a.K + k) * Hp + py0) * Wp;
+        // work items = (pooled row, 64-pixel segment) pairs, walked with wave-uniform counters (no per-lane division)
+        const int nseg = (Wp + 63) / 64, items = a.rb * nseg;
         float g[U], y[U], gn[U], yn[U];
         unsigned m[U], mn[U];
-        auto load = [&](int e0, float* gg, float* yy, unsigned* mm) {
+        auto load = [&](int j0, int row, int seg, float* gg, float* yy, unsigned* mm) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int e = e0 + 64 * u;
-                const bool ok = e < total;
-                gg[u] = ok ? a.gp[base + e] : 0.f;
-                yy[u] = ok ? a.yp[base + e] : 0.f;
-                mm[u] = ok ? (unsigned)a.mask[base + e] : 0u;
+                const int px = seg * 64 + lane;
+                const bool ok = j0 + u < items && px < Wp && !(a.debug & 2);
+                const long i = base + (long)row * Wp + px;
+                gg[u] = ok ? a.gp[i] : 0.f;
+                yy[u] = ok ? a.yp[i] : 1.f;
+                mm[u] = (ok && !(a.debug & 8)) ? (unsigned)a.mask[i] : ((a.debug & 10) ? 1u : 0u);
+                if (++seg == nseg) { seg = 0; ++row; }
             }
         };
-        load(lane, gn, yn, mn);
-        for (int e0 = lane; e0 < total; e0 += 64 * U) {
+        int nrow = 0, nsg = 0;                          // position of the batch being prefetched
+        auto advance = [&](int& row, int& seg) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (++seg == nseg) { seg = 0; ++row; }
+        };
+        load(0, nrow, nsg, gn, yn, mn);
+        for (int j0 = 0; j0 < items; j0 += U) {
+            int row = nrow, seg = nsg;
 #pragma unroll
             for (int u = 0; u < U; ++u) { g[u] = gn[u]; y[u] = yn[u]; m[u] = mn[u] & 15u; }
-            load(e0 + 64 * U, gn, yn, mn);              // the next batch is in flight during this one's multiply-adds
+            advance(nrow, nsg);
+            load(j0 + U, nrow, nsg, gn, yn, mn);        // the next batch is in flight during this one's multiply-adds
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int e = e0 + 64 * u;
                 const float v = g[u] * ghm_dact_from_out(y[u], a.act, a.alpha);
-                const int pyl = e / Wp, px = e - pyl * Wp;
+                const int pyl = row, px = seg * 64 + lane;
+                if (++seg == nseg) { seg = 0; ++row; }
                 unsigned mm = m[u];
                 acc[T] += v * (float)__popc(mm);
+                if (a.debug & 4) mm = 0;
                 while (mm) {                            // one iteration unless the window's maximum is tied
                     const int b = __ffs(mm) - 1, by = b >> 1, bx = b & 1;
                     mm &= mm - 1;
@@ -140,29 +155,24 @@ __global__ __launch_bounds__(NW * 64) void pool_thin_wgrad_kernel(const PoolThin
     }
 }
 
-// dwp[t * K + k] (+)= sum_s part[s][k][t], db[k] (+)= sum_s part[s][k][T]; fixed order, one thread per output
-__global__ __launch_bounds__(256) void pool_thin_wgrad_final(const float* __restrict__ part, int S, int K, float* __restrict__ dwp,
-                                                             float* __restrict__ dbias, int accumulate) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= K * (T + 1)) return;
+// dwp[t * K + k] (+)= sum_s part[s][k][t], db[k] (+)= sum_s part[s][k][T]; one wave per output, fixed order (lane l sums
+// slices l, l + 64, ..., then a butterfly) -- one THREAD per output walked S = 256 strided loads in a row: 60 us of latency
+__global__ __launch_bounds__(64) void pool_thin_wgrad_final(const float* __restrict__ part, int S, int K, float* __restrict__ dwp,
+                                                            float* __restrict__ dbias, int accumulate) {
+    const int idx = blockIdx.x, lane = threadIdx.x;
     const int k = idx / (T + 1), t = idx - k * (T + 1);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     const float* p = part + (long)k * (T + 1) + t;
     const long stride = (long)K * (T + 1);
-    int s = 0;
-    for (; s + 3 < S; s += 4) {
-        s0 += p[(long)s * stride];
-        s1 += p[(long)(s + 1) * stride];
-        s2 += p[(long)(s + 2) * stride];
-        s3 += p[(long)(s + 3) * stride];
-    }
-    for (; s < S; ++s) s0 += p[(long)s * stride];
-    const float v = (s0 + s1) + (s2 + s3);
-    if (t < T) {
-        float* o = dwp + (long)t * K + k;
-        *o = (accumulate ? *o : 0.f) + v;
-    } else if (dbias) {
-        dbias[k] = (accumulate ? dbias[k] : 0.f) + v;
+    float v = 0.f;
+    for (int s = lane; s < S; s += 64) v += p[(long)s * stride];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) {
+        if (t < T) {
+            float* o = dwp + (long)t * K + k;
+            *o = (accumulate ? *o : 0.f) + v;
+        } else if (dbias) {
+            dbias[k] = (accumulate ? dbias[k] : 0.f) + v;
+        }
     }
 }
 
@@ -307,13 +317,26 @@ int ghm_conv2d_pool_wgrad_sparse(ghm_ctx* ctx, const ghm_conv_desc* d, const flo
     a.N = d->N; a.K = d->K; a.H = d->H; a.W = d->W; a.act = act; a.alpha = alpha;
     a.rb = wgrad_rb(d);
     a.ldp = wgrad_ldp(d);
+    if (const char* f = GHM_OPT("GHM_ABLATE")) a.debug = atoi(f);
     const int bands = d->H / 2 / a.rb;
-    constexpr int NW = 8, KPW = 2;                       // 16 filters share one x tile
+    constexpr int NW = 8;
+    int U = 4, KPW = 2;                                  // operand batches in flight per wave; NW * KPW filters share one x tile
+    if (const char* f = GHM_OPT("GHM_POOLW_U")) U = atoi(f);
+    if (const char* f = GHM_OPT("GHM_POOLW_KPW")) KPW = atoi(f);
     const size_t lds = (size_t)(2 * a.rb + 2 * PADW) * 2 * a.ldp * sizeof(float);
-    hipLaunchKernelGGL((pool_thin_wgrad_kernel<NW, 4, KPW>), dim3(bands, d->N, (d->K + NW * KPW - 1) / (NW * KPW)), dim3(NW * 64), lds,
-                       ctx->stream, a);
+    const dim3 grid(bands, d->N, (d->K + NW * KPW - 1) / (NW * KPW));
+#define GHM_POOLW_CASE(U_, KPW_)                                                                                              \
+    if (U == U_ && KPW == KPW_)                                                                                               \
+        hipLaunchKernelGGL((pool_thin_wgrad_kernel<NW, U_, KPW_>), grid, dim3(NW * 64), lds, ctx->stream, a);                 \
+    else
+    GHM_POOLW_CASE(4, 1) GHM_POOLW_CASE(4, 2) GHM_POOLW_CASE(4, 4) GHM_POOLW_CASE(8, 1) GHM_POOLW_CASE(8, 2) GHM_POOLW_CASE(8, 4)
+    GHM_POOLW_CASE(2, 2) {
+        ghm_set_error("ghm_conv2d_pool_wgrad_sparse: no variant U=%d KPW=%d", U, KPW);
+        return -3;
+    }
+#undef GHM_POOLW_CASE
     GHM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(pool_thin_wgrad_final, dim3(ceil_div(d->K * (T + 1), 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(pool_thin_wgrad_final, dim3(d->K * (T + 1)), dim3(64), 0, ctx->stream,
                        (const float*)workspace, d->N * bands, d->K, dwp, dbias, accumulate);
     GHM_LAUNCH_CHECK();
     return 0;
