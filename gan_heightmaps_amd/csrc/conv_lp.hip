@@ -944,7 +944,7 @@ __device__ __forceinline__ u32x4 lp_tr_read8(const char* lds_lo, const char* lds
 template <int DT, int KS, int ST, int CHT, int CT, bool RS, int SPX>
 __global__ __launch_bounds__(CHT * CT * (RS ? KS : 1) * 64, 1) void lp_wgrad_q_kernel(const LpWgradQArgs a) {
     // RS: the waves are additionally split over the KS filter ROWS (5x5: a wave owns the 5 taps of one row; 3x3: all 9 taps)
-    static_assert((ST == 1 || (ST == 2 && KS == 3)) && (SPX == 64 || SPX == 32) && (KS == 3 || KS == 5), "variants");
+    static_assert((ST == 1 || (ST == 2 && KS == 3)) && (SPX == 64 || SPX == 32 || SPX == 16) && (KS == 3 || KS == 5), "variants");
     constexpr int T = KS * KS, PADK = KS / 2;
     constexpr int NWAVES = CHT * CT * (RS ? KS : 1);
     constexpr int TPW = RS ? KS : T;                  // accumulator tiles (taps) per wave
@@ -1391,14 +1391,17 @@ LpWQPlan lp_wqplan(const ghm_conv_desc* d, int num_cu) {
     const bool k5 = d->kh == 5 && d->kw == 5 && d->pad == 2 && d->stride == 1;
     if (!k3 && !k5) return v;
     if (d->Ho != (d->H + d->stride - 1) / d->stride || d->Wo != (d->W + d->stride - 1) / d->stride) return v;
-    if (d->Wo % 32 || d->C % 8 || d->K % 8) return v;
+    // 16-wide maps: strips of 16 pixels, ONE 16-pixel k-step per output row and barrier -- latency-bound (a slab waits for
+    // its DMA about as long as it computes), and still several times the fp32 kernels these layers ran on before
+    const bool narrow = d->Wo % 32 != 0;
+    if (d->Wo % 16 || d->C % 8 || d->K % 8 || (narrow && GHM_OPT("GHM_LP_NO_NARROW_WGRAD"))) return v;
     if (k5) {                   // 10 waves: 5 filter rows x 2 filter tiles of one 32-channel group
         if (d->K % 64 || d->C % 32) return v;
         v.cht = 1; v.ct = 2;
     } else if (d->K % 128 == 0 && d->C % 64 == 0) { v.cht = 2; v.ct = 4; }
     else if (d->stride == 1 && d->K % 64 == 0 && d->C % 128 == 0) { v.cht = 4; v.ct = 2; }
     else return v;
-    v.spx = d->Wo % 64 == 0 ? 64 : 32;
+    v.spx = d->Wo % 64 == 0 ? 64 : (narrow ? 16 : 32);
     v.ncols = d->N * (d->Wo / v.spx);
     const long tiles = (long)(d->C / (32 * v.cht)) * (d->K / (32 * v.ct)) * v.ncols;
     // ONE round of resident blocks (a block per CU: 8-10 waves, up to 135 KB of LDS): every further split writes and
@@ -1449,6 +1452,10 @@ int lp_launch_wgrad_q(ghm_ctx* ctx, const ghm_conv_desc* d, const LpWQPlan& v, c
     GHM_LPWQ_CASE(3, 2, 2, 4, false, 64)
     GHM_LPWQ_CASE(3, 2, 2, 4, false, 32)
     GHM_LPWQ_CASE(5, 1, 1, 2, true, 64)
+    GHM_LPWQ_CASE(3, 1, 2, 4, false, 16)
+    GHM_LPWQ_CASE(3, 1, 4, 2, false, 16)
+    GHM_LPWQ_CASE(3, 2, 2, 4, false, 16)
+    GHM_LPWQ_CASE(5, 1, 1, 2, true, 16)
     GHM_LPWQ_CASE(5, 1, 1, 2, true, 32) {
         ghm_set_error("no lp_wgrad_q variant for s=%d cht=%d ct=%d spx=%d", d->stride, v.cht, v.ct, v.spx);
         return -3;

@@ -601,7 +601,7 @@ class NetPlan:
             prog.append(("collapse_w", lambda t=self._collapse_tab: ops.upconv_collapse_batched(t)))
         if self._lp_table is not None:
             prog.append(("lp_pack", lambda t=self._lp_table: ops.lp_pack_batched(t, self.dtype)))
-        qpack = lambda t, q: prog.append(("q_pack", lambda t=t, q=q: ops.q_pack(t, q)))
+        qpack = lambda t, q: prog.append(("q_pack", lambda t=t, q=q: ops.q_pack(t, q), pack_meta(t)))
         fused_hi = set()            # pp_to_hi nodes whose output the BatchNorm in front of them writes
         for n in self.order:
             y = n.out
@@ -877,7 +877,7 @@ class NetPlan:
                 Gq = cache[('gq', id(n))] = QTensor.empty(dev, G.shape, self.dtype)
             if pack and id(n) not in gq_ready:
                 gq_ready.add(id(n))
-                prog.append(("q_pack", lambda G=G, Gq=Gq: ops.q_pack(G, Gq)))
+                prog.append(("q_pack", lambda G=G, Gq=Gq: ops.q_pack(G, Gq), pack_meta(G)))
             return Gq
 
         def fused_gq(xin, gi, acc):
@@ -1299,6 +1299,13 @@ def conv_meta(ops, d, kind, dtype='f32', pooled=False):
     return {"kernel": name, "dtype": dtype, "bytes": xb + yb, "thin": min(d.C, d.K) <= 4,
             "flops": 2.0 * d.N * d.K * d.Ho * d.Wo * d.C * d.kh * d.kw,
             "geom": "N%d C%d %dx%d K%d k%d s%d" % (d.N, d.C, d.H, d.W, d.K, d.kh, d.stride)}
+
+
+def pack_meta(t):
+    """metadata of a separate q_pack pass (a producer without a q epilogue): fp32 read + 2-byte write per element"""
+    n = float(np.prod(t.shape))
+    return {"kernel": "q_pack_kernel", "dtype": 'f32', "bytes": 6.0 * n, "thin": False, "flops": 0.0,
+            "geom": "N%d C%d %dx%d" % tuple(t.shape)}
 
 
 def pool_sparse_meta(d, kind):

@@ -507,6 +507,10 @@ WQ_CASES = [
     (2, 64,  8,  96,  128, 1, 3),   # Wo = 96: three 32-pixel strips
     (2, 32,  24, 64,  64,  1, 5),   # 5x5: ten waves = five filter rows x two filter tiles
     (1, 64,  16, 32,  128, 1, 5),
+    (3, 128, 16, 16,  128, 1, 3),   # 16-wide maps: one 16-pixel k-step per output row
+    (2, 256, 16, 48,  64,  1, 3),   # 4 x 2 tile, three 16-pixel strips
+    (2, 64,  32, 32,  128, 2, 3),   # stride 2 -> 16 x 16
+    (2, 64,  16, 16,  64,  1, 5),   # 5x5 on a 16-wide map
 ]
 
 
