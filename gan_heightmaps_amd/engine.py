@@ -493,7 +493,7 @@ class NetPlan:
         """is the weight gradient of this convolution the q-operand kernel (lp_wgrad_q: 3x3 stride 1 / 2, 5x5 stride 1)?
         Measured against the register-staged lp_wgrad kernel at one round of resident blocks (bf16, TFLOP/s): 3x3 stride 1
         594-830 vs 267-474, 5x5 1024-1115 vs 517-584, 3x3 stride 2 317-386 vs 277-319 (N4 C64 256^2: 193 vs 220)."""
-        return self.use_q and self._lp(d, 2) and self.ops.lp_wgrad_q_supported(d, self.dtype)
+        return bool(self.use_q and self.dtype != 'f32' and self.ops.lp_wgrad_q_supported(d, self.dtype))
 
     def _fp32_needed(self, n):
         """does anything read the fp32 output of node n (which also has a q copy)?  Not when every consumer is a
@@ -575,7 +575,7 @@ class NetPlan:
 
     def _need_wgrad_ws(self, d):
         b = self.ops.wgrad_workspace(d)
-        if self._lp(d, 2):
+        if self._lp(d, 2) or self._wq(d):
             b = max(b, self.ops.wgrad_lp_workspace(d))
         if b > self._wgrad_ws_bytes:
             if self.wgrad_ws is not None:
