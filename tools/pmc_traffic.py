@@ -34,9 +34,13 @@ def per_kernel(d, counter):
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     m = re.match(r"void (\w+<[^>]*>)", name)
-    s = m.group(1) if m else name.split("(")[0]
-    m = re.match(r"(lp_(?:conv|wgrad|wgrad_q|dgrad_s2)_kernel)<(\d), (\d+), (\d+)", s)
+    s = m.group(1) if m else re.sub(r"^void ", "", name).split("(")[0]
+    m = re.match(r"(lp_dgrad_s2_kernel)<(\d)", s)
+    if m:
+        return "%s<%s, 3, 2>" % (m.group(1), LP_DT.get(m.group(2), m.group(2)))
+    m = re.match(r"(lp_(?:conv|wgrad|wgrad_q)_kernel)<(\d), (\d+), (\d+)", s)
     if m:                                   # the label bench.py / engine.conv_meta use: <dtype, k, stride>
         return "%s<%s, %s, %s>" % (m.group(1).replace("wgrad_q", "wgrad"), LP_DT.get(m.group(2), m.group(2)), m.group(3), m.group(4))
     m = re.match(r"(lp_dgrad_s2_kernel)<(\d)", s)
