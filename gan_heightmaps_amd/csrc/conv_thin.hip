@@ -292,10 +292,15 @@ __global__ __launch_bounds__(320, 2) void fanout_kernel(const FanoutArgs a) {
     }
 }
 
+static int fanout_blocks_per_cu() {
+    if (const char* f = GHM_OPT("GHM_FANOUT_BPC")) return atoi(f) > 0 ? atoi(f) : 1;
+    return 1;
+}
+
 template <int KSTEPS, int RB, int NS>
 static int launch_fanout_t(ghm_ctx* ctx, const FanoutArgs& a) {
     const int NI = a.N * (a.Hout / a.RPI);
-    int blocks = ctx->num_cu;              // one 5-wave block per CU (256 VGPRs per wave), NI / blocks iterations each
+    int blocks = ctx->num_cu * fanout_blocks_per_cu();      // persistent 5-wave blocks, NI / blocks iterations each
     if (blocks > NI) blocks = NI;
     const size_t lds = (size_t)(RB * 32 + 4 * KSTEPS + 2 * a.CS * a.KRT * a.LW) * sizeof(float);
     static bool opted_in[2] = {false, false};
@@ -368,7 +373,7 @@ static int launch_fanout(ghm_ctx* ctx, FanoutArgs& a, int kh, int kw) {
 template <int KSTEPS>
 static int launch_fanout_pool_t(ghm_ctx* ctx, const FanoutArgs& a) {
     const int NI = a.N * (a.Hout / a.RPI);
-    int blocks = ctx->num_cu;
+    int blocks = ctx->num_cu * fanout_blocks_per_cu();
     if (blocks > NI) blocks = NI;
     const size_t lds = (size_t)(2 * 32 + 4 * KSTEPS + 2 * a.CS * a.KRT * a.LW) * sizeof(float);
     static bool opted_in = false;

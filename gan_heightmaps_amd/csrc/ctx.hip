@@ -83,7 +83,24 @@ int ghm_ctx_create(int32_t device, ghm_ctx** out) {
     GHM_HIP(hipSetDevice(device));
     ghm_ctx* c = new ghm_ctx();
     c->device = device;
-    GHM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // tuning: GHM_STREAM_PRIO = comma-separated HIP stream priorities by order of context creation (lower = more urgent)
+    int prio = 0;
+    static int created = 0;
+    if (const char* f = getenv("GHM_STREAM_PRIO")) {
+        const char* p = f;
+        for (int i = 0; i < created && p; ++i) { p = strchr(p, ','); if (p) ++p; }
+        if (p) prio = atoi(p);
+    }
+    ++created;
+    if (prio != 0) {
+        int lo = 0, hi = 0;
+        GHM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        if (prio < hi) prio = hi;
+        if (prio > lo) prio = lo;
+        GHM_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio));
+    } else {
+        GHM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
     hipDeviceProp_t prop;
     GHM_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount;

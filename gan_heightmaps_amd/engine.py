@@ -577,6 +577,11 @@ class NetPlan:
         b = self.ops.wgrad_workspace(d)
         if self._lp(d, 2) or self._wq(d):
             b = max(b, self.ops.wgrad_lp_workspace(d))
+        self._grow_wgrad_ws(b)
+
+    def _grow_wgrad_ws(self, b):
+        """one weight-gradient workspace per plan, sized while its programs are emitted (i.e. before any of them is
+        recorded: a recorded step holds the pointer by value)"""
         if b > self._wgrad_ws_bytes:
             if self.wgrad_ws is not None:
                 self.dev.free(self.wgrad_ws)
@@ -924,12 +929,7 @@ class NetPlan:
                     l = n.layer
                     mptr = n.aux['mask'] + n0 * per
                     if wgrad:
-                        b_ws = ops.pool_wgrad_sparse_workspace(dS)
-                        if b_ws > self._wgrad_ws_bytes:
-                            if self.wgrad_ws is not None:
-                                dev.free(self.wgrad_ws)
-                            self.wgrad_ws = dev.alloc(b_ws)
-                            self._wgrad_ws_bytes = b_ws
+                        self._grow_wgrad_ws(ops.pool_wgrad_sparse_workspace(dS))
                         gw, gb = st.grad(l.W), st.grad(l.b)
                         wo, wdev = ops, None
                         if self.side is not None:
