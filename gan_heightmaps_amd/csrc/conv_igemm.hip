@@ -2088,9 +2088,16 @@ WVariant pick_wgrad(const ghm_conv_desc* d, int num_cu) {
     v.bkp = (v.patch && d->Wo % 32 == 0 && d->kh == 5 && GHM_OPT("GHM_WGRAD_BKP16") == nullptr) ? 32 : 16;
     if (v.patch && d->Wo % 32 == 0 && GHM_OPT("GHM_WGRAD_BKP32")) v.bkp = 32;
     const long slabs = (P + v.bkp - 1) / v.bkp;
-    // one FULL round of resident blocks (a second, partly filled round costs up to 2x): blocks/CU is 3 for the
-    // 128-filter tile, 4 otherwise
-    const long slots = (long)num_cu * (v.bn >= 128 ? 3 : 4);
+    // whole rounds of resident blocks (a partly filled last round costs up to 2x): blocks/CU is 3 for the 128-filter tile,
+    // 4 otherwise.  ALONE one round is the optimum (every further split writes and re-reads another partial dW); in the
+    // step, where the stage streams' kernels want CUs too, TWO rounds of half-length blocks interleave better -- joint
+    // fp32 step, same box (tools/instep_sweep.sh, GHM_WGRAD_ROUNDS): 0.5 rounds 25.3 ms, 1 23.69, 1.5 23.49, 2 23.39,
+    // 3 23.41, 4 23.50, 6 23.56.
+    long minp = 4096;                                                        // the small maps keep one round
+    if (const char* f = GHM_OPT("GHM_WGRAD_ROUNDS_MINP")) minp = atol(f);    // tuning
+    double rounds = P >= minp ? 2.0 : 1.0;
+    if (const char* f = GHM_OPT("GHM_WGRAD_ROUNDS")) rounds = atof(f);       // tuning
+    const long slots = (long)(num_cu * (v.bn >= 128 ? 3 : 4) * rounds);
     long want = slots / tiles;
     if (const char* f = GHM_OPT("GHM_WGRAD_SPLITS")) want = atol(f);
     long max_by_work = slabs / (256 / v.bkp) > 0 ? slabs / (256 / v.bkp) : 1;   // at least 256 pixels per split
