@@ -1402,6 +1402,8 @@ LpWQPlan lp_wqplan(const ghm_conv_desc* d, int num_cu) {
     else if (d->stride == 1 && d->K % 64 == 0 && d->C % 128 == 0) { v.cht = 4; v.ct = 2; }
     else return v;
     v.spx = d->Wo % 64 == 0 ? 64 : (narrow ? 16 : 32);
+    if (const char* f = GHM_OPT("GHM_LP_WGRAD_SPX"))                                  // tuning: narrower strips (less LDS per block)
+        if (atoi(f) == 32 && v.spx == 64) v.spx = 32;
     v.ncols = d->N * (d->Wo / v.spx);
     const long tiles = (long)(d->C / (32 * v.cht)) * (d->K / (32 * v.ct)) * v.ncols;
     // ONE round of resident blocks (a block per CU: 8-10 waves, up to 135 KB of LDS): every further split writes and

@@ -75,17 +75,24 @@ template <> struct StoreVec<2> { typedef float2 type; };
 //   (NS = 2): the lane that owns pixels (2l, 2l+1) of both rows owns one whole pooling window, so the epilogue takes
 //   the maximum in registers and stores the pooled value (4 B, 128 contiguous bytes per 32 lanes) and the 4-bit arg-max
 //   mask -- the 537 MB full-resolution activation is never written.
-template <int KSTEPS, int RB, int NS, bool ACC, bool POOL = false>
-__global__ __launch_bounds__(320, 2) void fanout_kernel(const FanoutArgs a) {
+// WS = 2: EIGHT MFMA waves; the waves (2g, 2g + 1) work on the same pixel group and own RB of its 2 * RB row blocks
+// each.  With four waves (one per SIMD) a wave's MFMA burst (64 cycles each in fp32) and its VALU epilogue (bias,
+// activation, pooling, stores: as many cycles again -- SQ counters, d_conv1: 1.7 M MFMAs = 44 us of matrix pipe, 22.7 M
+// VALU instructions = 37 us of vector pipe, kernel 127 us) run one after the other; two waves per SIMD with half the
+// accumulators each (<= 170 VGPRs) let one wave's epilogue run under the other's MFMAs.
+template <int KSTEPS, int RB, int NS, bool ACC, bool POOL = false, int WS = 1>
+__global__ __launch_bounds__((4 * WS + 1) * 64, WS == 2 ? 1 : 2) void fanout_kernel(const FanoutArgs a) {
+    constexpr int NMW = 4 * WS;                                   // MFMA waves; wave NMW is the loader
     typedef typename StoreVec<NS>::type vec_t;
     extern __shared__ float lds[];
-    float* sbias = lds;                                           // [RB*32]
-    int* stab = reinterpret_cast<int*>(lds + RB * 32);            // [2][2*KSTEPS]: LDS offset, weight offset
-    float* rows = lds + RB * 32 + 4 * KSTEPS;                     // [2][CS*KRT*LW]
+    float* sbias = lds;                                           // [RB*WS*32]
+    int* stab = reinterpret_cast<int*>(lds + RB * WS * 32);       // [2][2*KSTEPS]: LDS offset, weight offset
+    float* rows = lds + RB * WS * 32 + 4 * KSTEPS;                // [2][CS*KRT*LW]
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, l = lane & 31;
     const int rowsz = a.CS * a.KRT * a.LW;
-    if (threadIdx.x < RB * 32) sbias[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
+    if (threadIdx.x < RB * WS * 32) sbias[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
+    const int rbo = WS == 2 ? (wv & 1) * RB : 0;                  // this wave's first row block
     if (threadIdx.x < 2 * KSTEPS) {
         const int q = threadIdx.x;
         const bool live = q < a.Q;
@@ -117,20 +124,20 @@ __global__ __launch_bounds__(320, 2) void fanout_kernel(const FanoutArgs a) {
     };
 
     int r = blockIdx.x;
-    if (wv == 4 && r < NI) produce(r, rows);
+    if (wv == NMW && r < NI) produce(r, rows);
     __syncthreads();          // tables + first rows (nothing else is in flight yet)
 
     // MFMA waves: the whole weight matrix as A fragments, lane (l, h) holds A[rb*32 + l][2j + h]
     float A[RB][KSTEPS];
     int off[KSTEPS];
-    if (wv < 4) {
+    if (wv < NMW) {
 #pragma unroll
         for (int j = 0; j < KSTEPS; ++j) {
             off[j] = stab[2 * j + h] + NS * l * a.ss;      // this lane's first pixel of a group
             const int wi = stab[2 * KSTEPS + 2 * j + h];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                const float w = a.wp[wi >= 0 ? (rb * 32 + l) * a.w_rs + wi : 0];      // branch-free: clamp, mask
+                const float w = a.wp[wi >= 0 ? ((rb + rbo) * 32 + l) * a.w_rs + wi : 0];      // branch-free: clamp, mask
                 A[rb][j] = wi >= 0 ? w : 0.f;
             }
         }
@@ -146,11 +153,11 @@ __global__ __launch_bounds__(320, 2) void fanout_kernel(const FanoutArgs a) {
 
     for (int it = 0; r < NI; ++it, r += gridDim.x) {
         const float* cur = rows + (it & 1) * rowsz;
-        if (wv == 4) {
+        if (wv == NMW) {
             if (r + (int)gridDim.x < NI) produce(r + gridDim.x, rows + ((it + 1) & 1) * rowsz);
         } else {
             const int n = r / IPI, u0 = (r - n * IPI) * a.RPI;
-            for (int g = wv; g < G; g += 4) {
+            for (int g = wv / WS; g < G; g += 4) {
                 if constexpr (POOL) {
                     static_assert(!POOL || (NS == 2 && !ACC), "pooled fan-out: 2 pixels x 2 rows per lane");
                     const int rp = g / GPR, x0 = (g - rp * GPR) * (NS * 32);
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(320, 2) void fanout_kernel(const FanoutArgs a) {
                         float bv[16];
 #pragma unroll
                         for (int e4 = 0; e4 < 4; ++e4) {
-                            const float4 t = *reinterpret_cast<const float4*>(sbias + rb * 32 + 8 * e4 + 4 * h);
+                            const float4 t = *reinterpret_cast<const float4*>(sbias + (rb + rbo) * 32 + 8 * e4 + 4 * h);
                             bv[4 * e4] = t.x; bv[4 * e4 + 1] = t.y; bv[4 * e4 + 2] = t.z; bv[4 * e4 + 3] = t.w;
                         }
                         // a lane owns one window per channel row; lanes (2t, 2t+1) trade every other row so that each
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(320, 2) void fanout_kernel(const FanoutArgs a) {
                             const float recv = __shfl_xor(send, 1, 64);
                             const unsigned recvk = (unsigned)__shfl_xor((int)sendk, 1, 64);
                             const int e = odd ? eb : ea;
-                            const int row = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            const int row = (rb + rbo) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                             const long o = pbase - (odd ? 1 : 0) + (long)row * HWp;      // first pixel of the lane pair
                             *reinterpret_cast<float2*>(a.pool_out + o) = odd ? make_float2(recv, keep) : make_float2(keep, recv);
                             *reinterpret_cast<unsigned short*>(a.pool_mask + o) =
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(320, 2) void fanout_kernel(const FanoutArgs a) {
                     float bv[16];
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4) {
-                        const float4 t = *reinterpret_cast<const float4*>(sbias + rb * 32 + 8 * e4 + 4 * h);
+                        const float4 t = *reinterpret_cast<const float4*>(sbias + (rb + rbo) * 32 + 8 * e4 + 4 * h);
                         bv[4 * e4] = t.x; bv[4 * e4 + 1] = t.y; bv[4 * e4 + 2] = t.z; bv[4 * e4 + 3] = t.w;
                     }
 #pragma unroll
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(320, 2) void fanout_kernel(const FanoutArgs a) {
                         if (ACC) {
 #pragma unroll
                             for (int e = 0; e < 16; ++e) {
-                                const unsigned row = rb * 32 + (e & 3) + 8 * (e >> 2);
+                                const unsigned row = (rb + rbo) * 32 + (e & 3) + 8 * (e >> 2);
                                 vals[e] += reinterpret_cast<const float*>(ob + (lo + row * plane))[k];
                             }
                         }
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(320, 2) void fanout_kernel(const FanoutArgs a) {
                     }
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const unsigned row = rb * 32 + (e & 3) + 8 * (e >> 2);
+                        const unsigned row = (rb + rbo) * 32 + (e & 3) + 8 * (e >> 2);
                         vec_t v;
                         float* vp = reinterpret_cast<float*>(&v);
 #pragma unroll
@@ -297,25 +304,39 @@ static int fanout_blocks_per_cu() {
     return 1;
 }
 
-template <int KSTEPS, int RB, int NS>
-static int launch_fanout_t(ghm_ctx* ctx, const FanoutArgs& a) {
+static bool fanout_wave_split() { return GHM_OPT("GHM_FANOUT_NO_SPLIT") == nullptr; }
+
+// RB = row blocks of the layer (filters / 32); WS = 2: eight MFMA waves with RB / 2 row blocks each (see the kernel)
+template <int KSTEPS, int RB, int NS, int WS>
+static int launch_fanout_ws(ghm_ctx* ctx, const FanoutArgs& a) {
+    constexpr int RBW = RB / WS;
     const int NI = a.N * (a.Hout / a.RPI);
-    int blocks = ctx->num_cu * fanout_blocks_per_cu();      // persistent 5-wave blocks, NI / blocks iterations each
+    int blocks = ctx->num_cu * fanout_blocks_per_cu();      // persistent blocks, NI / blocks iterations each
     if (blocks > NI) blocks = NI;
     const size_t lds = (size_t)(RB * 32 + 4 * KSTEPS + 2 * a.CS * a.KRT * a.LW) * sizeof(float);
     static bool opted_in[2] = {false, false};
     if (!opted_in[a.accumulate ? 1 : 0]) {
-        const void* fn = a.accumulate ? (const void*)fanout_kernel<KSTEPS, RB, NS, true>
-                                      : (const void*)fanout_kernel<KSTEPS, RB, NS, false>;
+        const void* fn = a.accumulate ? (const void*)fanout_kernel<KSTEPS, RBW, NS, true, false, WS>
+                                      : (const void*)fanout_kernel<KSTEPS, RBW, NS, false, false, WS>;
         GHM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         opted_in[a.accumulate ? 1 : 0] = true;
     }
+    const dim3 threads((4 * WS + 1) * 64);
     if (a.accumulate)
-        hipLaunchKernelGGL((fanout_kernel<KSTEPS, RB, NS, true>), dim3(blocks), dim3(320), lds, ctx->stream, a);
+        hipLaunchKernelGGL((fanout_kernel<KSTEPS, RBW, NS, true, false, WS>), dim3(blocks), threads, lds, ctx->stream, a);
     else
-        hipLaunchKernelGGL((fanout_kernel<KSTEPS, RB, NS, false>), dim3(blocks), dim3(320), lds, ctx->stream, a);
+        hipLaunchKernelGGL((fanout_kernel<KSTEPS, RBW, NS, false, false, WS>), dim3(blocks), threads, lds, ctx->stream, a);
     GHM_LAUNCH_CHECK();
     return 0;
+}
+
+template <int KSTEPS, int RB, int NS>
+static int launch_fanout_t(ghm_ctx* ctx, const FanoutArgs& a) {
+    // the full-resolution forms are bound by their stores (0.135 ms for 537 MB): eight waves measured 5-10 % slower there;
+    // the split serves the pooled form (0.166 -> 0.137 ms), GHM_FANOUT_SPLIT_ALL=1 forces it everywhere
+    if (RB % 2 == 0 && fanout_wave_split() && GHM_OPT("GHM_FANOUT_SPLIT_ALL"))
+        return launch_fanout_ws<KSTEPS, RB, NS, (RB % 2 == 0 ? 2 : 1)>(ctx, a);
+    return launch_fanout_ws<KSTEPS, RB, NS, 1>(ctx, a);
 }
 
 // geometry shared by the eligibility checks and the launcher: pixels per group, output rows per iteration
@@ -370,21 +391,26 @@ static int launch_fanout(ghm_ctx* ctx, FanoutArgs& a, int kh, int kw) {
     return -3;
 }
 
-template <int KSTEPS>
-static int launch_fanout_pool_t(ghm_ctx* ctx, const FanoutArgs& a) {
+template <int KSTEPS, int WS>
+static int launch_fanout_pool_ws(ghm_ctx* ctx, const FanoutArgs& a) {
     const int NI = a.N * (a.Hout / a.RPI);
     int blocks = ctx->num_cu * fanout_blocks_per_cu();
     if (blocks > NI) blocks = NI;
     const size_t lds = (size_t)(2 * 32 + 4 * KSTEPS + 2 * a.CS * a.KRT * a.LW) * sizeof(float);
     static bool opted_in = false;
     if (!opted_in) {
-        GHM_HIP(hipFuncSetAttribute((const void*)fanout_kernel<KSTEPS, 2, 2, false, true>,
+        GHM_HIP(hipFuncSetAttribute((const void*)fanout_kernel<KSTEPS, 2 / WS, 2, false, true, WS>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         opted_in = true;
     }
-    hipLaunchKernelGGL((fanout_kernel<KSTEPS, 2, 2, false, true>), dim3(blocks), dim3(320), lds, ctx->stream, a);
+    hipLaunchKernelGGL((fanout_kernel<KSTEPS, 2 / WS, 2, false, true, WS>), dim3(blocks), dim3((4 * WS + 1) * 64), lds, ctx->stream, a);
     GHM_LAUNCH_CHECK();
     return 0;
+}
+
+template <int KSTEPS>
+static int launch_fanout_pool_t(ghm_ctx* ctx, const FanoutArgs& a) {
+    return fanout_wave_split() ? launch_fanout_pool_ws<KSTEPS, 2>(ctx, a) : launch_fanout_pool_ws<KSTEPS, 1>(ctx, a);
 }
 
 static bool thin_enabled() { return GHM_OPT("GHM_NO_THIN") == nullptr; }
