@@ -77,6 +77,9 @@ def cpu_baseline(sample_batch=2, config1_steps=3):
                                   "oracle's step are 4-filter stubs, train_mode='dcgan'), %.1f s" % (config1_steps, dt1)}}
 
 
+MAX_TIMERS = 4096       # csrc/common.h GHM_MAX_TIMERS: recorded timer slots wrap modulo this
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,7 +275,7 @@ def main():
         # replay r (1-based; replay 0 was the recording call) used slots [r * L, (r + 1) * L)
         L_ = len(rec_devs)
         first = args.steps - inst_steps + 1
-        every = [(d, i + r * L_, slot_labels[i]) for r in range(first, args.steps + 1) for i, d in enumerate(rec_devs)]
+        every = [(d, (i + r * L_) % MAX_TIMERS, slot_labels[i]) for r in range(first, args.steps + 1) for i, d in enumerate(rec_devs)]
     else:
         every = [(d, i, slot_labels[i]) for i, d in enumerate(slots)]
     timed = [(d, i) for d, i, lab in every if lab is None]
