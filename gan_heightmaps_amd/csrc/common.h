@@ -198,10 +198,12 @@ extern "C" int ghm_bn_backward_finish(ghm_ctx* ctx, const double* wsd, int32_t C
 // ---- conv_thin.hip: layers with <= 4 channels on one side and large maps (HBM-bound) ----
 bool thin_fanout_fwd_ok(const ghm_conv_desc* d, int act);   // the kernel's epilogue does linear / relu / lrelu
 int thin_fanout_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,
-                    float* y, int act, float alpha, int accumulate);
+                    float* y, int act, float alpha, int accumulate, void* yq = nullptr, long yq_nstride = 0, int q_dt = 0);
 bool thin_fanout_fwd_pool_ok(const ghm_conv_desc* d, int act);    // + activation + 2x2 max-pool in the epilogue
 int thin_fanout_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,
-                         float* pooled, unsigned char* mask, int act, float alpha);
+                         float* pooled, unsigned char* mask, int act, float alpha, void* yq = nullptr, long yq_nstride = 0,
+                         int q_dt = 0);
+bool thin_fanout_pool_q_ok(const ghm_conv_desc* d);      // may the pooled forward also write its q copy?
 bool thin_fanout_dgrad_ok(const ghm_conv_desc* d, int act);
 int thin_fanout_dgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const float* wp, const float* bias,
                       float* dx, int act, float alpha, int accumulate);

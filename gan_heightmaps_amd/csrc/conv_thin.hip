@@ -49,7 +49,19 @@ struct FanoutArgs {
     int loff[THIN_MAX_Q], widx[THIN_MAX_Q];
     float* pool_out;            // POOL: dense [N, R, Hout/2, Wout/2] maximum of act(conv + bias) over 2x2 windows ...
     unsigned char* pool_mask;   // ... and the 4-bit arg-max mask of every window (bit 2*dr + dc; all ties set)
+    uint2* out_q;               // optional q copy of the result (of the POOLED result when POOL): half-units of 4 channels
+    long out_q_nstride;         // 16-byte units between samples
+    int q_dt;                   // GHM_DTYPE_BF16 / GHM_DTYPE_F16
 };
+
+typedef float f32x2t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned thin_pack2(float a, float b, int dt) {
+    const f32x2t v = {a, b};
+    return dt == GHM_DTYPE_BF16 ? __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2t))
+                                : __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2t));
+}
 
 // LDS hand-over between the loader wave and the MFMA waves: wait for this wave's LDS traffic only.  A
 // __syncthreads() would also drain vmcnt, i.e. make every MFMA wave wait for its output stores to be
@@ -80,7 +92,7 @@ template <> struct StoreVec<2> { typedef float2 type; };
 // activation, pooling, stores: as many cycles again -- SQ counters, d_conv1: 1.7 M MFMAs = 44 us of matrix pipe, 22.7 M
 // VALU instructions = 37 us of vector pipe, kernel 127 us) run one after the other; two waves per SIMD with half the
 // accumulators each (<= 170 VGPRs) let one wave's epilogue run under the other's MFMAs.
-template <int KSTEPS, int RB, int NS, bool ACC, bool POOL = false, int WS = 1>
+template <int KSTEPS, int RB, int NS, bool ACC, bool POOL = false, int WS = 1, bool QOUT = false>
 __global__ __launch_bounds__((4 * WS + 1) * 64, WS == 2 ? 1 : 2) void fanout_kernel(const FanoutArgs a) {
     constexpr int NMW = 4 * WS;                                   // MFMA waves; wave NMW is the loader
     typedef typename StoreVec<NS>::type vec_t;
@@ -201,6 +213,7 @@ __global__ __launch_bounds__((4 * WS + 1) * 64, WS == 2 ? 1 : 2) void fanout_ker
                         // a lane owns one window per channel row; lanes (2t, 2t+1) trade every other row so that each
                         // stores TWO adjacent pooled pixels of one row: 8-byte value + 2-byte mask stores, half as many
                         const bool odd = l & 1;
+                        float qv[4];                    // pooled values of rows 4g .. 4g+3 (+ 4h) of this lane's OWN window
 #pragma unroll
                         for (int e2 = 0; e2 < 8; ++e2) {
                             // rows ea (kept by even lanes) and eb (kept by odd lanes): two registers live at a time
@@ -221,6 +234,15 @@ __global__ __launch_bounds__((4 * WS + 1) * 64, WS == 2 ? 1 : 2) void fanout_ker
                                 pm[z] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                                 pk[z] = (v[0] == pm[z] ? 1u : 0u) | (v[1] == pm[z] ? 2u : 0u) | (v[2] == pm[z] ? 4u : 0u) |
                                         (v[3] == pm[z] ? 8u : 0u);
+                            }
+                            if (QOUT) {
+                                qv[2 * (e2 & 1)] = pm[0];
+                                qv[2 * (e2 & 1) + 1] = pm[1];
+                            }
+                            if (QOUT && (e2 & 1)) {         // q unit (channel block, pooled pixel), half h: 4 consecutive channels
+                                uint2* qo = a.out_q + 2 * ((long)n * a.out_q_nstride + (long)((rb + rbo) * 4 + (e2 >> 1)) * HWp +
+                                                           (long)((u0 + ri) / 2) * Wp + x0 / 2 + l) + h;
+                                *qo = make_uint2(thin_pack2(qv[0], qv[1], a.q_dt), thin_pack2(qv[2], qv[3], a.q_dt));
                             }
                             const float keep = odd ? pm[1] : pm[0], send = odd ? pm[0] : pm[1];
                             const unsigned keepk = odd ? pk[1] : pk[0], sendk = odd ? pk[0] : pk[1];
@@ -292,6 +314,16 @@ __global__ __launch_bounds__((4 * WS + 1) * 64, WS == 2 ? 1 : 2) void fanout_ker
                         for (int k = 0; k < NS; ++k) vp[k] = acc[k][rb][e];
                         *reinterpret_cast<vec_t*>(ob + (lo + row * plane)) = v;
                     }
+                    if constexpr (QOUT) {   // rows 4g .. 4g+3 (+ 4h) of pixel NS*l + k: one half unit per (g, k)
+                        uint2* qb = a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(u0 + ri) * a.Wout + x0 + NS * l) + h;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int k = 0; k < NS; ++k)
+                                qb[2 * ((long)((rb + rbo) * 4 + g) * HWout + k)] =
+                                    make_uint2(thin_pack2(acc[k][rb][4 * g], acc[k][rb][4 * g + 1], a.q_dt),
+                                               thin_pack2(acc[k][rb][4 * g + 2], acc[k][rb][4 * g + 3], a.q_dt));
+                    }
                 }
             }
         }
@@ -314,16 +346,21 @@ static int launch_fanout_ws(ghm_ctx* ctx, const FanoutArgs& a) {
     int blocks = ctx->num_cu * fanout_blocks_per_cu();      // persistent blocks, NI / blocks iterations each
     if (blocks > NI) blocks = NI;
     const size_t lds = (size_t)(RB * 32 + 4 * KSTEPS + 2 * a.CS * a.KRT * a.LW) * sizeof(float);
-    static bool opted_in[2] = {false, false};
-    if (!opted_in[a.accumulate ? 1 : 0]) {
-        const void* fn = a.accumulate ? (const void*)fanout_kernel<KSTEPS, RBW, NS, true, false, WS>
-                                      : (const void*)fanout_kernel<KSTEPS, RBW, NS, false, false, WS>;
-        GHM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        opted_in[a.accumulate ? 1 : 0] = true;
-    }
     const dim3 threads((4 * WS + 1) * 64);
-    if (a.accumulate)
+    const int which = a.accumulate ? 1 : (a.out_q ? 2 : 0);         // (the q epilogue is its own instantiation: registers)
+    GHM_CHECK(!(a.accumulate && a.out_q), "fanout: accumulate and a q output are not combined");
+    const void* fn = which == 1 ? (const void*)fanout_kernel<KSTEPS, RBW, NS, true, false, WS>
+                   : which == 2 ? (const void*)fanout_kernel<KSTEPS, RBW, NS, false, false, WS, true>
+                                : (const void*)fanout_kernel<KSTEPS, RBW, NS, false, false, WS>;
+    static bool opted_in[3] = {false, false, false};
+    if (!opted_in[which]) {
+        GHM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        opted_in[which] = true;
+    }
+    if (which == 1)
         hipLaunchKernelGGL((fanout_kernel<KSTEPS, RBW, NS, true, false, WS>), dim3(blocks), threads, lds, ctx->stream, a);
+    else if (which == 2)
+        hipLaunchKernelGGL((fanout_kernel<KSTEPS, RBW, NS, false, false, WS, true>), dim3(blocks), threads, lds, ctx->stream, a);
     else
         hipLaunchKernelGGL((fanout_kernel<KSTEPS, RBW, NS, false, false, WS>), dim3(blocks), threads, lds, ctx->stream, a);
     GHM_LAUNCH_CHECK();
@@ -391,7 +428,7 @@ static int launch_fanout(ghm_ctx* ctx, FanoutArgs& a, int kh, int kw) {
     return -3;
 }
 
-template <int KSTEPS, int WS>
+template <int KSTEPS, int WS, bool QOUT>
 static int launch_fanout_pool_ws(ghm_ctx* ctx, const FanoutArgs& a) {
     const int NI = a.N * (a.Hout / a.RPI);
     int blocks = ctx->num_cu * fanout_blocks_per_cu();
@@ -399,19 +436,31 @@ static int launch_fanout_pool_ws(ghm_ctx* ctx, const FanoutArgs& a) {
     const size_t lds = (size_t)(2 * 32 + 4 * KSTEPS + 2 * a.CS * a.KRT * a.LW) * sizeof(float);
     static bool opted_in = false;
     if (!opted_in) {
-        GHM_HIP(hipFuncSetAttribute((const void*)fanout_kernel<KSTEPS, 2 / WS, 2, false, true, WS>,
+        GHM_HIP(hipFuncSetAttribute((const void*)fanout_kernel<KSTEPS, 2 / WS, 2, false, true, WS, QOUT>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         opted_in = true;
     }
-    hipLaunchKernelGGL((fanout_kernel<KSTEPS, 2 / WS, 2, false, true, WS>), dim3(blocks), dim3((4 * WS + 1) * 64), lds, ctx->stream, a);
+    hipLaunchKernelGGL((fanout_kernel<KSTEPS, 2 / WS, 2, false, true, WS, QOUT>), dim3(blocks), dim3((4 * WS + 1) * 64), lds,
+                       ctx->stream, a);
     GHM_LAUNCH_CHECK();
     return 0;
 }
 
 template <int KSTEPS>
 static int launch_fanout_pool_t(ghm_ctx* ctx, const FanoutArgs& a) {
-    return fanout_wave_split() ? launch_fanout_pool_ws<KSTEPS, 2>(ctx, a) : launch_fanout_pool_ws<KSTEPS, 1>(ctx, a);
+    if (a.out_q) {          // (eight-wave form only, up to 26 reduction rows: the others have no registers left for it)
+        if constexpr (KSTEPS <= 13) {
+            GHM_CHECK(fanout_wave_split(), "pooled thin forward with a q output needs the eight-wave form");
+            return launch_fanout_pool_ws<KSTEPS, 2, true>(ctx, a);
+        } else {
+            ghm_set_error("pooled thin forward with a q output: %d reduction rows not served", a.Q);
+            return -3;
+        }
+    }
+    return fanout_wave_split() ? launch_fanout_pool_ws<KSTEPS, 2, false>(ctx, a) : launch_fanout_pool_ws<KSTEPS, 1, false>(ctx, a);
 }
+
+bool thin_fanout_pool_q_ok(const ghm_conv_desc* d) { return fanout_wave_split() && (d->C * d->kh * d->kw + 1) / 2 <= 13; }
 
 static bool thin_enabled() { return GHM_OPT("GHM_NO_THIN") == nullptr; }
 static bool fanout_act_ok(int act) { return act == GHM_ACT_LINEAR || act == GHM_ACT_RELU || act == GHM_ACT_LRELU; }
@@ -423,10 +472,13 @@ bool thin_fanout_fwd_ok(const ghm_conv_desc* d, int act) {
 }
 
 int thin_fanout_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,
-                    float* y, int act, float alpha, int accumulate) {
+                    float* y, int act, float alpha, int accumulate, void* yq, long yq_nstride, int q_dt) {
     FanoutArgs a;
     memset(&a, 0, sizeof(a));
     const int T = d->kh * d->kw;
+    GHM_CHECK(!yq || (d->K % 8 == 0 && ((uintptr_t)yq & 15) == 0 && (q_dt == GHM_DTYPE_BF16 || q_dt == GHM_DTYPE_F16)),
+              "thin forward with a q output: filters %% 8 == 0, 16-byte aligned q tensor, bf16 / f16");
+    a.out_q = (uint2*)yq; a.out_q_nstride = yq_nstride; a.q_dt = q_dt;
     a.in = x; a.wp = wp; a.bias = bias; a.out = y; a.zeros = ctx->zeros;
     a.N = d->N; a.CS = d->C; a.Hin = d->H; a.Win = d->W; a.in_nstride = d->x_nstride;
     a.R = d->K; a.Hout = d->Ho; a.Wout = d->Wo; a.out_nstride = d->y_nstride;
@@ -452,9 +504,12 @@ bool thin_fanout_fwd_pool_ok(const ghm_conv_desc* d, int act) {
 }
 
 int thin_fanout_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,
-                         float* pooled, unsigned char* mask, int act, float alpha) {
+                         float* pooled, unsigned char* mask, int act, float alpha, void* yq, long yq_nstride, int q_dt) {
     FanoutArgs a;
     memset(&a, 0, sizeof(a));
+    GHM_CHECK(!yq || (((uintptr_t)yq & 15) == 0 && (q_dt == GHM_DTYPE_BF16 || q_dt == GHM_DTYPE_F16)),
+              "thin pooled forward with a q output: 16-byte aligned q tensor, bf16 / f16");
+    a.out_q = (uint2*)yq; a.out_q_nstride = yq_nstride; a.q_dt = q_dt;
     const int T = d->kh * d->kw;
     a.in = x; a.wp = wp; a.bias = bias; a.out = nullptr; a.zeros = ctx->zeros;
     a.pool_out = pooled; a.pool_mask = mask;

@@ -559,6 +559,19 @@ class Ops:
             call("ghm_maxpool2_mask_bwd_bias", self.h, C.c_void_p(int(mask_ptr)), _vp(y), _vp(dy), _vp(dx), dx.N, dx.Cc,
                  dx.H, dx.W, ACT_CODES[act], alpha, _vp(dbias), int(accumulate))
 
+    def thin_fwd_q_supported(self, d, act, pooled, dtype):
+        return bool(_lib.load().ghm_thin_fwd_q_supported(C.byref(d), ACT_CODES[act], int(pooled), DTYPE_CODES[dtype]))
+
+    def conv2d_fwd_thin_q(self, d, x, w, bias, y, yq, act='linear', alpha=0.0):
+        """first-layer forward (<= 4 input channels) writing its fp32 result and the q copy in one pass"""
+        call("ghm_conv2d_fwd_thin_q", self.h, C.byref(d), _vp(x), _vp(w), _vp(bias), _vp(y), ACT_CODES[act], alpha,
+             C.c_void_p(yq.ptr), yq.nstride, DTYPE_CODES[yq.dtype])
+
+    def conv2d_fwd_pool_thin_q(self, d, x, w, bias, pooled, mask_ptr, yq, act, alpha):
+        assert pooled.contiguous
+        call("ghm_conv2d_fwd_pool_thin_q", self.h, C.byref(d), _vp(x), _vp(w), _vp(bias), _vp(pooled),
+             C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha, C.c_void_p(yq.ptr), yq.nstride, DTYPE_CODES[yq.dtype])
+
     def pool_bwd_sparse_supported(self, d, act):
         """bit 0: weight + bias gradient, bit 1: data gradient of a fused conv + act + pool layer from the pooled operands"""
         return int(_lib.load().ghm_conv2d_pool_bwd_sparse_supported(C.byref(d), ACT_CODES[act]))

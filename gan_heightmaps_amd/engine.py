@@ -646,6 +646,10 @@ class NetPlan:
                         prog.append(("conv_fwd", lambda d=d, x=x, wq=wq, b=b, y=y, a=a:
                                      ops.conv2d_fwd_lp(d, x, wq, b, y, self.dtype, a.kind, a.alpha),
                                      conv_meta(ops, d, 0, self.dtype)))
+                elif n.op == 'conv' and n.outq is not None and ops.thin_fwd_q_supported(d, a.kind, False, self.dtype):
+                    q_direct = True         # a first layer (fp32 operands) whose epilogue also writes the q copy
+                    prog.append(("conv_fwd", lambda d=d, x=x, w=w, b=b, y=y, yq=n.outq, a=a:
+                                 ops.conv2d_fwd_thin_q(d, x, w, b, y, yq, a.kind, a.alpha), conv_meta(ops, d, 0)))
                 else:
                     prog.append(("%s_fwd" % n.op, lambda d=d, x=x, w=w, b=b, y=y, a=a:
                                  ops.conv2d_fwd(d, x, w, b, y, a.kind, a.alpha), conv_meta(ops, d, 0)))
@@ -662,6 +666,11 @@ class NetPlan:
                     prog.append(("convpool_fwd", lambda d=d, xq=xq, wsrc=wsrc, b=b, y=y, yq=n.outq, m=n.aux['mask'], a=a:
                                  ops.conv2d_fwd_pool_lp_q(d, xq, wsrc, b, y, yq, m, a.kind, a.alpha, self.dtype),
                                  conv_meta(ops, d, 0, dt, pooled=True)))
+                elif form == 1 and n.outq is not None and ops.thin_fwd_q_supported(d, a.kind, True, self.dtype):
+                    q_direct = True
+                    prog.append(("convpool_fwd", lambda d=d, x=x, w=w, b=b, y=y, yq=n.outq, m=n.aux['mask'], a=a:
+                                 ops.conv2d_fwd_pool_thin_q(d, x, w, b, y, m, yq, a.kind, a.alpha),
+                                 conv_meta(ops, d, 0, 'f32', pooled=True)))
                 else:
                     prog.append(("convpool_fwd", lambda d=d, x=x, wsrc=wsrc, b=b, y=y, m=n.aux['mask'], a=a, dt=dt:
                                  ops.conv2d_fwd_pool(d, x, wsrc, b, y, m, a.kind, a.alpha, dt),

@@ -543,6 +543,47 @@ def test_q_weight_gradient(gpu, case, splits, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("case", [(8, 1, 64, 64, 64, 5, 1, 2, True), (2, 4, 256, 256, 64, 3, 2, 1, False),
+                                  (2, 1, 256, 256, 64, 3, 2, 1, False), (4, 1, 128, 128, 64, 5, 1, 2, True),
+                                  (2, 3, 128, 256, 64, 3, 1, 1, False)])
+def test_thin_first_layer_forward_writes_its_q_copy(gpu, case, dtype):
+    """ghm_conv2d_fwd_thin_q / ghm_conv2d_fwd_pool_thin_q (<= 4 input channels, fp32 operands): the fp32 result (and the
+    mask of the pooled form) is bit-identical to the plain entry point's, the q copy is exactly its rounding, written into a
+    channel slice of a wider q buffer without touching the neighbours."""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad, pooled = case
+    rng = np.random.RandomState(sum(case[:8]))
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    assert ops.thin_fwd_q_supported(d, 'lrelu', pooled, dtype)
+    R = LP.ROUND[dtype]
+    wp = dev.tensor(D.pack_conv_w(Wt).ravel())
+    xd, bd = dev.tensor(x), dev.tensor(b)
+    Ho, Wo = (d.Ho // 2, d.Wo // 2) if pooled else (d.Ho, d.Wo)
+    y1, y2 = dev.empty((N, K, Ho, Wo)), dev.empty((N, K, Ho, Wo))
+    wide = D.QTensor.empty(dev, (N, K + 16, Ho, Wo), dtype)
+    dev.memset_zero(wide.ptr, wide.nbytes)
+    yq = wide.channels(8, 8 + K)
+    if pooled:
+        m1, m2 = dev.alloc(N * K * Ho * Wo), dev.alloc(N * K * Ho * Wo)
+        ops.conv2d_fwd_pool(d, xd, wp, bd, y1, m1, 'lrelu', 0.2, 'f32')
+        ops.conv2d_fwd_pool_thin_q(d, xd, wp, bd, y2, m2, yq, 'lrelu', 0.2)
+        a, bb = np.empty(N * K * Ho * Wo, np.uint8), np.empty(N * K * Ho * Wo, np.uint8)
+        dev.d2h(a, m1, a.nbytes)
+        dev.d2h(bb, m2, bb.nbytes)
+        assert np.array_equal(a, bb)
+    else:
+        ops.conv2d_fwd(d, xd, wp, bd, y1, 'lrelu', 0.2)
+        ops.conv2d_fwd_thin_q(d, xd, wp, bd, y2, yq, 'lrelu', 0.2)
+    assert np.array_equal(y1.numpy(), y2.numpy())
+    assert np.array_equal(yq.numpy(), R(y1.numpy()))
+    full = wide.numpy()
+    assert not full[:, :8].any() and not full[:, 8 + K:].any()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_elementwise_producers_with_a_q_epilogue(gpu, dtype):
     """ghm_bn_apply_q, ghm_bn_backward_q, ghm_upsample_bilinear2_fwd_q, ghm_pp_to_hi_q, ghm_maxpool2_mask_bwd_q: the fp32
     result is bit-identical to the plain entry point's, the q result is exactly its rounding (also into a channel slice
