@@ -176,6 +176,13 @@ __device__ __forceinline__ float ghm_act(float v, int act, float alpha) {
         default: return v;
     }
 }
+// bit 4 of a pooling mask byte: the pooled activation is > 0 (all the backward pass needs of it for relu / leaky relu,
+// so the pooled fp32 tensor itself need not be read -- or written, when every consumer reads its q copy)
+#define GHM_POOL_SIGN 16u
+__device__ __forceinline__ float ghm_dact_from_sign(unsigned mask_byte, int act, float alpha) {
+    return (act == GHM_ACT_LINEAR || (mask_byte & GHM_POOL_SIGN)) ? 1.f : (act == GHM_ACT_RELU ? 0.f : alpha);
+}
+
 __device__ __forceinline__ float ghm_dact_from_out(float y, int act, float alpha) {
     switch (act) {
         case GHM_ACT_RELU: return y > 0.f ? 1.f : 0.f;

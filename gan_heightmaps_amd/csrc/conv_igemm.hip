@@ -517,7 +517,8 @@ __device__ __forceinline__ void pool2_store(float v0, float v1, bool col_even, b
     const float m = fmaxf(fmaxf(v0, v1), fmaxf(w0, w1));
     if (col_even && live) {
         *po = m;
-        *pm = (unsigned char)((v0 == m ? 1u : 0u) | (w0 == m ? 2u : 0u) | (v1 == m ? 4u : 0u) | (w1 == m ? 8u : 0u));
+        *pm = (unsigned char)((v0 == m ? 1u : 0u) | (w0 == m ? 2u : 0u) | (v1 == m ? 4u : 0u) | (w1 == m ? 8u : 0u) |
+                              (m > 0.f ? GHM_POOL_SIGN : 0u));
     }
 }
 

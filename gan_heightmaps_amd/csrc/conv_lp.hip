@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void q_unpack_kernel(const u32x4* __restrict__
 __device__ __forceinline__ float lp_pool2(float v0, float v1, unsigned& mask) {
     const float w0 = __shfl_xor(v0, 1, 64), w1 = __shfl_xor(v1, 1, 64);      // the neighbour column's two rows
     const float m = fmaxf(fmaxf(v0, v1), fmaxf(w0, w1));
-    mask = (v0 == m ? 1u : 0u) | (w0 == m ? 2u : 0u) | (v1 == m ? 4u : 0u) | (w1 == m ? 8u : 0u);
+    mask = (v0 == m ? 1u : 0u) | (w0 == m ? 2u : 0u) | (v1 == m ? 4u : 0u) | (w1 == m ? 8u : 0u) | (m > 0.f ? GHM_POOL_SIGN : 0u);
     return m;
 }
 

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(NW * 64) void pool_thin_wgrad_kernel(const PoolThin
         const long base = (((long)n * a.K + k) * Hp + py0) * Wp;
         // work items = (pooled row, 64-pixel segment) pairs, walked with wave-uniform counters (no per-lane division)
         const int nseg = (Wp + 63) / 64, items = a.rb * nseg;
-        float g[U], y[U], gn[U], yn[U];
+        float g[U], gn[U], yn[U];
         unsigned m[U], mn[U];
         auto load = [&](int j0, int row, int seg, float* gg, float* yy, unsigned* mm) {
 #pragma unroll
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(NW * 64) void pool_thin_wgrad_kernel(const PoolThin
                 const bool ok = j0 + u < items && px < Wp && !(a.debug & 2);
                 const long i = base + (long)row * Wp + px;
                 gg[u] = ok ? a.gp[i] : 0.f;
-                yy[u] = ok ? a.yp[i] : 1.f;
+                yy[u] = (ok && a.yp) ? a.yp[i] : 1.f;
                 mm[u] = (ok && !(a.debug & 8)) ? (unsigned)a.mask[i] : ((a.debug & 10) ? 1u : 0u);
                 if (++seg == nseg) { seg = 0; ++row; }
             }
@@ -114,12 +114,15 @@ __global__ __launch_bounds__(NW * 64) void pool_thin_wgrad_kernel(const PoolThin
         for (int j0 = 0; j0 < items; j0 += U) {
             int row = nrow, seg = nsg;
 #pragma unroll
-            for (int u = 0; u < U; ++u) { g[u] = gn[u]; y[u] = yn[u]; m[u] = mn[u] & 15u; }
+            for (int u = 0; u < U; ++u) {           // yp == nullptr: the slope from the mask's sign bit
+                g[u] = gn[u] * (a.yp ? ghm_dact_from_out(yn[u], a.act, a.alpha) : ghm_dact_from_sign(mn[u], a.act, a.alpha));
+                m[u] = mn[u] & 15u;
+            }
             advance(nrow, nsg);
             load(j0 + U, nrow, nsg, gn, yn, mn);        // the next batch is in flight during this one's multiply-adds
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float v = g[u] * ghm_dact_from_out(y[u], a.act, a.alpha);
+                const float v = g[u];
                 const int pyl = row, px = seg * 64 + lane;
                 if (++seg == nseg) { seg = 0; ++row; }
                 unsigned mm = m[u];
@@ -206,15 +209,15 @@ __global__ __launch_bounds__(DCH * DCW) void pool_thin_dgrad_kernel(const PoolTh
             const int e = tid + q * DCH * DCW;
             const int kk = e / CELLS, rem = e - kk * CELLS, r = rem / (DCW + 2), c = rem - r * (DCW + 2);
             const int cy = cy0 - 1 + r, cx = cx0 - 1 + c, k = k0 + kk;
-            float g = 0.f, y = 1.f;
+            float g = 0.f;
             unsigned char m = 0;
             if (e < KC * CELLS && (unsigned)cy < (unsigned)Hp && (unsigned)cx < (unsigned)Wp && k < a.K) {
                 const long i = (((long)n * a.K + k) * Hp + cy) * Wp + cx;
-                g = a.gp[i];
-                y = a.yp[i];
-                m = a.mask[i] & 15u;
+                const unsigned mb = a.mask[i];
+                g = a.gp[i] * (a.yp ? ghm_dact_from_out(a.yp[i], a.act, a.alpha) : ghm_dact_from_sign(mb, a.act, a.alpha));
+                m = mb & 15u;
             }
-            sv[q] = g * ghm_dact_from_out(y, a.act, a.alpha);
+            sv[q] = g;
             sm[q] = m;
         }
     };

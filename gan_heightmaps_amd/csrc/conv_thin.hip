@@ -233,7 +233,7 @@ __global__ __launch_bounds__((4 * WS + 1) * 64, WS == 2 ? 1 : 2) void fanout_ker
                                     }
                                 pm[z] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                                 pk[z] = (v[0] == pm[z] ? 1u : 0u) | (v[1] == pm[z] ? 2u : 0u) | (v[2] == pm[z] ? 4u : 0u) |
-                                        (v[3] == pm[z] ? 8u : 0u);
+                                        (v[3] == pm[z] ? 8u : 0u) | (pm[z] > 0.f ? GHM_POOL_SIGN : 0u);
                             }
                             if (QOUT) {
                                 qv[2 * (e2 & 1)] = pm[0];
@@ -251,7 +251,7 @@ __global__ __launch_bounds__((4 * WS + 1) * 64, WS == 2 ? 1 : 2) void fanout_ker
                             const int e = odd ? eb : ea;
                             const int row = (rb + rbo) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                             const long o = pbase - (odd ? 1 : 0) + (long)row * HWp;      // first pixel of the lane pair
-                            *reinterpret_cast<float2*>(a.pool_out + o) = odd ? make_float2(recv, keep) : make_float2(keep, recv);
+                            if (a.pool_out) *reinterpret_cast<float2*>(a.pool_out + o) = odd ? make_float2(recv, keep) : make_float2(keep, recv);
                             *reinterpret_cast<unsigned short*>(a.pool_mask + o) =
                                 (unsigned short)(odd ? (recvk | (keepk << 8)) : (keepk | (recvk << 8)));
                         }

@@ -383,10 +383,17 @@ __global__ __launch_bounds__(256) void maxpool2_mask_bwd_kernel(const unsigned c
     const int rem = (int)(idx - pl * Ho * Wo2), i = rem / Wo2, j2 = rem - i * Wo2;
     const long po = pl * Ho * (W / 2) + (long)i * (W / 2) + 2 * j2;
     const unsigned m2 = *reinterpret_cast<const unsigned short*>(mask + po);
-    const float2 yv = *reinterpret_cast<const float2*>(y + po);
     const float2 gv = *reinterpret_cast<const float2*>(dy + po);
-    const float g0 = gv.x * ghm_dact_from_out(yv.x, act, alpha), g1 = gv.y * ghm_dact_from_out(yv.y, act, alpha);
     const unsigned m0 = m2 & 0xffu, m1 = m2 >> 8;
+    float g0, g1;               // y == nullptr: the slope from the mask's sign bit (relu / leaky relu / linear)
+    if (y) {
+        const float2 yv = *reinterpret_cast<const float2*>(y + po);
+        g0 = gv.x * ghm_dact_from_out(yv.x, act, alpha);
+        g1 = gv.y * ghm_dact_from_out(yv.y, act, alpha);
+    } else {
+        g0 = gv.x * ghm_dact_from_sign(m0, act, alpha);
+        g1 = gv.y * ghm_dact_from_sign(m1, act, alpha);
+    }
     const long o = pl * H * W + (long)(2 * i) * W + 4 * j2;
     *reinterpret_cast<float4*>(dx + o) = make_float4((m0 & 1u) ? g0 : 0.f, (m0 & 2u) ? g0 : 0.f, (m1 & 1u) ? g1 : 0.f, (m1 & 2u) ? g1 : 0.f);
     *reinterpret_cast<float4*>(dx + o + W) = make_float4((m0 & 4u) ? g0 : 0.f, (m0 & 8u) ? g0 : 0.f, (m1 & 4u) ? g1 : 0.f, (m1 & 8u) ? g1 : 0.f);

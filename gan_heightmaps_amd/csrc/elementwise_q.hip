@@ -306,10 +306,17 @@ __global__ __launch_bounds__(256) void maxpool2_mask_bwd_q_kernel(const unsigned
         const long pl = (long)n * C8 * 8 + cb * 8 + k;
         const long po = pl * hwp + (long)i * Wo + 2 * j2;
         const unsigned m2 = live ? *reinterpret_cast<const unsigned short*>(mask + po) : 0u;
-        const float2 yv = live ? *reinterpret_cast<const float2*>(y + po) : make_float2(0.f, 0.f);
         const float2 gv = live ? *reinterpret_cast<const float2*>(dy + po) : make_float2(0.f, 0.f);
-        const float g0 = gv.x * ghm_dact_from_out(yv.x, act, alpha), g1 = gv.y * ghm_dact_from_out(yv.y, act, alpha);
         const unsigned m0 = m2 & 0xffu, m1 = m2 >> 8;
+        float g0, g1;           // y == nullptr: the slope from the mask's sign bit
+        if (y) {
+            const float2 yv = live ? *reinterpret_cast<const float2*>(y + po) : make_float2(0.f, 0.f);
+            g0 = gv.x * ghm_dact_from_out(yv.x, act, alpha);
+            g1 = gv.y * ghm_dact_from_out(yv.y, act, alpha);
+        } else {
+            g0 = gv.x * ghm_dact_from_sign(m0, act, alpha);
+            g1 = gv.y * ghm_dact_from_sign(m1, act, alpha);
+        }
         r0[0][k] = (m0 & 1u) ? g0 : 0.f; r0[1][k] = (m0 & 2u) ? g0 : 0.f; r0[2][k] = (m1 & 1u) ? g1 : 0.f; r0[3][k] = (m1 & 2u) ? g1 : 0.f;
         r1[0][k] = (m0 & 4u) ? g0 : 0.f; r1[1][k] = (m0 & 8u) ? g0 : 0.f; r1[2][k] = (m1 & 4u) ? g1 : 0.f; r1[3][k] = (m1 & 8u) ? g1 : 0.f;
         csum[k] = g0 * (float)__popc(m0 & 15u) + g1 * (float)__popc(m1 & 15u);

@@ -551,7 +551,7 @@ class Ops:
 
     def maxpool2_mask_bwd(self, mask_ptr, y, dy, dx, act, alpha, dbias=None, accumulate=False):
         """y, dy: pooled [N,C,H/2,W/2]; dx: full-resolution [N,C,H,W]; dbias: also (+)= the per-channel sum of dx"""
-        assert y.contiguous and dy.contiguous and dx.contiguous
+        assert (y is None or y.contiguous) and dy.contiguous and dx.contiguous      # y None: slope from the mask's sign bit
         if dbias is None:
             call("ghm_maxpool2_mask_bwd", self.h, C.c_void_p(int(mask_ptr)), _vp(y), _vp(dy), _vp(dx), dx.N, dx.Cc, dx.H,
                  dx.W, ACT_CODES[act], alpha)
@@ -568,7 +568,7 @@ class Ops:
              C.c_void_p(yq.ptr), yq.nstride, DTYPE_CODES[yq.dtype])
 
     def conv2d_fwd_pool_thin_q(self, d, x, w, bias, pooled, mask_ptr, yq, act, alpha):
-        assert pooled.contiguous
+        assert pooled is None or pooled.contiguous      # None: only the q copy and the mask are written
         call("ghm_conv2d_fwd_pool_thin_q", self.h, C.byref(d), _vp(x), _vp(w), _vp(bias), _vp(pooled),
              C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha, C.c_void_p(yq.ptr), yq.nstride, DTYPE_CODES[yq.dtype])
 
@@ -582,12 +582,12 @@ class Ops:
         return n.value
 
     def conv2d_pool_wgrad_sparse(self, d, x, mask_ptr, yp, gp, dwp, dbias, ws, act, alpha, accumulate=False):
-        assert yp.contiguous and gp.contiguous
+        assert (yp is None or yp.contiguous) and gp.contiguous       # yp None: slope from the mask's sign bit
         call("ghm_conv2d_pool_wgrad_sparse", self.h, C.byref(d), _vp(x), C.c_void_p(int(mask_ptr)), _vp(yp), _vp(gp), _vp(dwp),
              _vp(dbias), ACT_CODES[act], alpha, int(accumulate), _vp(ws))
 
     def conv2d_pool_dgrad_sparse(self, d, mask_ptr, yp, gp, wp, dx, act, alpha, accumulate=False):
-        assert yp.contiguous and gp.contiguous
+        assert (yp is None or yp.contiguous) and gp.contiguous
         call("ghm_conv2d_pool_dgrad_sparse", self.h, C.byref(d), C.c_void_p(int(mask_ptr)), _vp(yp), _vp(gp), _vp(wp), _vp(dx),
              ACT_CODES[act], alpha, int(accumulate))
 

@@ -511,6 +511,19 @@ class NetPlan:
                 return True
         return False
 
+    def _pool_y_dropped(self, n):
+        """fused conv + activation + max-pool node whose pooled fp32 tensor is never written: every consumer reads the q
+        copy, and the backward pass takes the activation slope from the sign bit the forward kernel leaves in the mask"""
+        if n.op != 'convpool' or not self.use_q or os.environ.get("GHM_KEEP_POOL_Y") is not None:
+            return False
+        if n.act.kind not in ('linear', 'relu', 'lrelu') or self._fp32_needed(n):
+            return False
+        d = self._desc(n, n.inputs[0].out, self._full(n))
+        form = self.ops.conv_pool_supported(d, n.act.kind, self.dtype)
+        if form == 2:
+            return n.inputs[0].outq is not None                      # the q-operand pooled kernel writes n.outq itself
+        return form == 1 and bool(self.ops.thin_fwd_q_supported(d, n.act.kind, True, self.dtype))
+
     def input_tensor(self, layer):
         return self.node_of_layer[id(layer)].out
 
@@ -661,6 +674,8 @@ class NetPlan:
                 wsrc, dt = w, 'f32'
                 if form == 2:
                     wsrc, dt = self._lp_pack_entry(prog, d, w, ('w', id(n.layer.W)), False, lp_done), self.dtype
+                if self._pool_y_dropped(n):
+                    y = None                # (pooled fp32 tensor not written: see _pool_y_dropped)
                 if form == 2 and xq is not None:
                     q_direct = n.outq is not None
                     prog.append(("convpool_fwd", lambda d=d, xq=xq, wsrc=wsrc, b=b, y=y, yq=n.outq, m=n.aux['mask'], a=a:
@@ -925,6 +940,8 @@ class NetPlan:
                 continue
             xin = n.inputs[0]
             x, y = sl(xin.out), sl(n.out)
+            if self._pool_y_dropped(n):
+                y = None                    # the mask carries the sign of the pooled activation
             a = n.act
             need_dx = req[id(xin)]
             if n.op == 'convpool':

@@ -574,6 +574,12 @@ def test_thin_first_layer_forward_writes_its_q_copy(gpu, case, dtype):
         dev.d2h(a, m1, a.nbytes)
         dev.d2h(bb, m2, bb.nbytes)
         assert np.array_equal(a, bb)
+        assert np.array_equal((a >> 4) & 1, (y1.numpy().ravel() > 0).astype(np.uint8))      # bit 4: sign of the pooled value
+        wide3 = D.QTensor.empty(dev, (N, K, Ho, Wo), dtype)                                 # q copy and mask only
+        m3 = dev.alloc(N * K * Ho * Wo)
+        ops.conv2d_fwd_pool_thin_q(d, xd, wp, bd, None, m3, wide3, 'lrelu', 0.2)
+        dev.d2h(bb, m3, bb.nbytes)
+        assert np.array_equal(a, bb) and np.array_equal(wide3.numpy(), R(y1.numpy()))
     else:
         ops.conv2d_fwd(d, xd, wp, bd, y1, 'lrelu', 0.2)
         ops.conv2d_fwd_thin_q(d, xd, wp, bd, y2, yq, 'lrelu', 0.2)

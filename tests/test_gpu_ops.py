@@ -760,6 +760,7 @@ def test_conv_pool_backward_from_the_pooled_operands(gpu, case):
         bits = np.zeros(yp.shape, np.uint8)
         for bb, (r, c) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
             bits |= ((y[:, :, r::2, c::2] == yp).astype(np.uint8) << bb)
+        bits |= ((yp > 0).astype(np.uint8) << 4)           # the sign bit the fused forward kernels leave
         pooled.set(yp)
         dev.h2d(mask, bits)
     gp = rng.randn(N, K, H // 2, W // 2).astype(np.float32)
@@ -782,6 +783,14 @@ def test_conv_pool_backward_from_the_pooled_operands(gpu, case):
     assert rel(db.numpy().ravel(), db64) < TOL and rel(db.numpy(), db_ref.numpy()) < TOL
     ops.conv2d_pool_wgrad_sparse(d, xd, mask, pooled, gpd, dw, db, ws2, 'lrelu', 0.2, accumulate=True)
     assert rel(dw.numpy(), 2 * dw_ref.numpy()) < TOL and rel(db.numpy().ravel(), 2 * db64) < TOL
+    # without the pooled activation: the slope comes from the mask's sign bit -- the same bits
+    dw3, db3 = dev.zeros((1, 25 * K, 1, 1)), dev.zeros((1, K, 1, 1))
+    ops.conv2d_pool_wgrad_sparse(d, xd, mask, pooled, gpd, dw, db, ws2, 'lrelu', 0.2)
+    ops.conv2d_pool_wgrad_sparse(d, xd, mask, None, gpd, dw3, db3, ws2, 'lrelu', 0.2)
+    assert np.array_equal(dw.numpy(), dw3.numpy()) and np.array_equal(db.numpy(), db3.numpy())
+    Gf2 = dev.empty((N, K, H, W))
+    ops.maxpool2_mask_bwd(mask, None, gpd, Gf2, 'lrelu', 0.2)
+    assert np.array_equal(Gf2.numpy(), Gf.numpy())
     dw2 = dev.zeros((1, 25 * K, 1, 1))
     ops.conv2d_pool_wgrad_sparse(d, xd, mask, pooled, gpd, dw2, None, ws2, 'lrelu', 0.2)       # no bias gradient asked
     ops.conv2d_pool_wgrad_sparse(d, xd, mask, pooled, gpd, dw, None, ws2, 'lrelu', 0.2)
@@ -792,6 +801,9 @@ def test_conv_pool_backward_from_the_pooled_operands(gpu, case):
         dx = dev.zeros(x.shape)
         ops.conv2d_pool_dgrad_sparse(d, mask, pooled, gpd, wp, dx, 'lrelu', 0.2)
         assert rel(dx.numpy(), dx64) < TOL and rel(dx.numpy(), dx_ref.numpy()) < TOL
+        dxn = dev.zeros(x.shape)
+        ops.conv2d_pool_dgrad_sparse(d, mask, None, gpd, wp, dxn, 'lrelu', 0.2)
+        assert np.array_equal(dxn.numpy(), dx.numpy())
         ops.conv2d_pool_dgrad_sparse(d, mask, pooled, gpd, wp, dx, 'lrelu', 0.2, accumulate=True)
         assert rel(dx.numpy(), 2 * dx64) < TOL
         # a sample slice (the generator's gradient only needs the fake half of the batch)
