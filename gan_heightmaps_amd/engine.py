@@ -734,8 +734,9 @@ class NetPlan:
                     q_direct = True
                     prog.append(("bn_fwd", lambda x=x, m=m, iv=iv, rm=rm, ri=ri, l=l, upd=upd:
                                  ops.bn_stats(x, m, iv, self.bn_ws, rm if upd else None, ri if upd else None, l.epsilon, l.alpha)))
-                    prog.append(("bn_fwd", lambda x=x, y=y, yq=n.outq, m=m, iv=iv, g=g, be=be, a=a:
-                                 ops.bn_apply_q(x, y, m, iv, g, be, yq, a.kind, a.alpha)))
+                    y32 = y if (self._fp32_needed(n) or os.environ.get("GHM_BN_FP32") is not None) else None
+                    prog.append(("bn_fwd", lambda x=x, y32=y32, yq=n.outq, m=m, iv=iv, g=g, be=be, a=a:
+                                 ops.bn_apply_q(x, y32, m, iv, g, be, yq, a.kind, a.alpha)))
                 else:
                     m, iv = n.aux['mean'], n.aux['inv']
                     upd = update_running
