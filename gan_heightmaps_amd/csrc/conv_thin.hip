@@ -382,6 +382,7 @@ static void fanout_plan(int rows_out, int thin_ch, int kh, int kw, int stride, i
     *NS = rows_out <= 64 ? 4 : 2;
     const int gpr = Wout / (*NS * 32);
     int rpi = gpr >= 4 ? 1 : (4 + gpr - 1) / (gpr > 0 ? gpr : 1);      // >= 4 groups per iteration: one per MFMA wave
+    if (const char* f = GHM_OPT("GHM_FANOUT_RPI")) rpi = atoi(f) > 0 ? atoi(f) : rpi;      // tuning: output rows per iteration
     while (rpi > 1 && Hout % rpi != 0) --rpi;
     *RPI = rpi;
     *KRT = kh + (rpi - 1) * stride;
