@@ -941,8 +941,8 @@ class NetPlan:
                 continue
             xin = n.inputs[0]
             x, y = sl(xin.out), sl(n.out)
-            if self._pool_y_dropped(n):
-                y = None                    # the mask carries the sign of the pooled activation
+            if n.op == 'convpool' and n.act.kind in ('linear', 'relu', 'lrelu') and os.environ.get("GHM_POOL_READ_Y") is None:
+                y = None                    # the mask carries the sign of the pooled activation: its backward never reads it
             a = n.act
             need_dx = req[id(xin)]
             if n.op == 'convpool':
