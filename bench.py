@@ -27,6 +27,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2
 LP_MFMA_PEAK_TFLOPS = 2500.0           # MI355X_MICROARCH.md: dense bf16 / fp16 v_mfma_f32_32x32x16 (not the 2:1-sparse 5 PF)
 PEAK = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16": LP_MFMA_PEAK_TFLOPS, "f16": LP_MFMA_PEAK_TFLOPS}
 JOINT_GFLOP_PER_IMG = 683.29           # algorithmic 2 x MACs of the joint train step
+DCGAN_GFLOP_PER_IMG = 391.26           # config 2: DCGAN stage trained (fwd 115.26 + bwd 276.00)
+P2P_GFLOP_PER_IMG = 292.03             # config 3: pix2pix stage trained (fwd 95.05 + bwd 196.98)
 
 
 def synthetic_batch(B, latent_dim, in_shp, seed):
@@ -80,7 +82,18 @@ def cpu_baseline(sample_batch=2, config1_steps=3):
 MAX_TIMERS = 4096       # csrc/common.h GHM_MAX_TIMERS: recorded timer slots wrap modulo this
 
 
-def main():
+SECONDARY = [
+    # (name, overrides): BASELINE.json configs 1-5 beside the fp32 headline, each a short timed loop of its own AFTER the
+    # headline's timed region (never inside it), printed under one "secondary" key of the same JSON line
+    ("config4_per_gpu_bf16_512_b4", dict(dtype="bf16")),
+    ("config5_per_gpu_f16_1024_b2", dict(dtype="f16", in_shp=1024, batch_per_gpu=2)),
+    ("config2_dcgan_512_b4_f32", dict(mode="dcgan")),
+    ("config3_p2p_512_b4_f32", dict(mode="p2p")),
+    ("config1_dcgan64_b16_f32", dict(config1=True)),
+]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -109,7 +122,34 @@ def main():
                          "never the headline")
     ap.add_argument("--in-shp", type=int, default=512, choices=[512, 1024],
                     help="1024 = BASELINE config 5 geometry (one more U-Net level and DCGAN stage; beyond the reference)")
-    args = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline only: skip the short extra loops of BASELINE configs 1-5 (\"secondary\" key)")
+    ap.add_argument("--secondary-steps", type=int, default=12)
+    return ap.parse_args(argv)
+
+
+def nominal_flops_per_step(b):
+    """ALGORITHMIC 2 x MACs of one train step, summed over the plan's convolution launches (SURVEY 8d prices every layer
+    in the reference's own form): an Upscale2D -> 5x5 convolution executes as a collapsed 3x3 with 4K filters (9 MACs per
+    output instead of 25), and the first discriminator layer's gradients gather over pooled elements (a quarter of the
+    dense products) -- both are counted at the reference's dense figure here."""
+    tot = 0.0
+    for lane in b.train_compute:
+        for e in lane:
+            meta = e[2] if len(e) > 2 else None
+            if not meta or not meta.get("flops"):
+                continue
+            f = meta["flops"]
+            if e[0].startswith("upconv"):
+                f *= 25.0 / 9.0
+            if meta["kernel"].startswith("pool_thin"):
+                f *= 4.0
+            tot += f
+    return tot
+
+
+def measure(args, secondary_name=None):
+    """one workload: build, warm up, time ``args.steps`` steps -> the JSON object of bench.py's contract"""
 
     from gan_heightmaps_amd import device, dist
     from gan_heightmaps_amd.experiments import make_model
@@ -151,7 +191,9 @@ def main():
         model = Pix2Pix(**kw)
         args.mode = 'dcgan'
     elif S == 512:
-        model = make_model('test1_nobn_bilin_both', **backend)
+        # configs 2 / 3 of BASELINE.json: the same nets with train_mode='dcgan' / 'p2p' (pix2pix.py:136-141), passed to
+        # the constructor as the reference's experiments pass it
+        model = make_model('test1_nobn_bilin_both', **backend, **({} if args.mode == 'both' else {'train_mode': args.mode}))
     else:
         # config 5: the same architecture functions one level deeper (p2p.py:137 asserts 512 in the reference)
         from gan_heightmaps_amd.experiments import experiment_kwargs
@@ -161,8 +203,7 @@ def main():
         kw['gen_params_dcgan'] = {'num_repeats': 0, 'div': [2, 2, 4, 4, 8, 8, 8, 8], 'final_size': S}
         kw['disc_params_dcgan'] = dict(kw['disc_params_dcgan'], div=[8, 8, 4, 4, 4, 2, 2, 2], nch=1024)
         model = Pix2Pix(**kw)
-    if args.mode != 'both':
-        # configs 2 / 3 of BASELINE.json: same nets, one stage trained
+    if args.mode != 'both' and S != 512:
         model.engine.train_mode = args.mode
     eng = model.engine
     Z, X, Y = synthetic_batch(B, 100 if args.config1 else 1000, S, seed=1000 + rank)
@@ -280,6 +321,10 @@ def main():
         every = [(d, i, slot_labels[i]) for i, d in enumerate(slots)]
     timed = [(d, i) for d, i, lab in every if lab is None]
     slot = len(timed)
+    # read every bracket of the timed region NOW: the host-boundary loop below replays the bracketed step and the
+    # recorded timer slots wrap modulo MAX_TIMERS, so later replays would overwrite these event pairs
+    timed_ms = [d.timer_ms(i) for d, i in timed]
+    every_ms = {(id(d), i): d.timer_ms(i) for d, i, lab in every if lab is not None}
     # ---- the same loop with the reference's host-array boundary (pix2pix.py:142: train_fn(Z, X, Y) takes numpy
     # arrays): every step uploads its 16 KB + 4 MB + 12 MB batch over PCIe before it is enqueued ----
     with_h2d = None
@@ -294,6 +339,13 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = B * world * args.steps / elapsed
+    plan_gflop_per_img = nominal_flops_per_step(b) / B / 1e9
+    if S == 512 and not args.config1 and B > 0:
+        gflop_per_img = {'both': JOINT_GFLOP_PER_IMG, 'dcgan': DCGAN_GFLOP_PER_IMG, 'p2p': P2P_GFLOP_PER_IMG}[args.mode]
+        flops_source = "SURVEY.md 8(d) constant for train_mode=%s (the loss-only forward of the other stage excluded)" % args.mode
+    else:
+        gflop_per_img = plan_gflop_per_img
+        flops_source = "summed over the plan's convolution launches (bench.py nominal_flops_per_step)"
     out = {
         **({"INVALID": "ablation run (--ablate %s): kernels skipped, results wrong" % args.ablate} if args.ablate else {}),
         "metric": "512px heightmap+texture train images/sec", "value": round(value, 3), "unit": "images/s",
@@ -309,9 +361,15 @@ def main():
                    "hip_graph": bool(args.graph), "issue": "graph" if args.graph else args.issue,
                    "host_calls_per_step": 1 if issue == 'recorded' else None,
                    "streams": len({id(d) for d in list(eng.devs) + [sd[0] for sd in eng.side if sd is not None]})},
-        "step_algorithmic_tflops": round(JOINT_GFLOP_PER_IMG * value / 1e3, 2) if args.mode == 'both' and S == 512 else None,
-        "step_frac_of_fp32_mfma_peak": round(JOINT_GFLOP_PER_IMG * value / world / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)
-        if args.mode == 'both' and S == 512 else None,
+        # ALGORITHMIC work of the step: the survey's own per-image constants for the 512x512 configs, the
+        # plan-derived count (nominal_flops_per_step: same rules, summed over the plan's convolution launches) elsewhere
+        "step_algorithmic_tflops": round(gflop_per_img * value / 1e3, 2),
+        "step_algorithmic_gflop_per_img": round(gflop_per_img, 2), "step_flops_source": flops_source,
+        "step_plan_gflop_per_img": round(plan_gflop_per_img, 2),
+        "step_frac_of_peak": round(gflop_per_img * value / world / 1e3 / PEAK[args.dtype], 4),
+        "step_peak_tflops": PEAK[args.dtype],
+        "step_frac_of_fp32_mfma_peak": round(gflop_per_img * value / world / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)
+        if args.dtype == 'f32' else None,
         # the nominal count above prices Upscale2D -> 5x5 convs at 25 MACs per output; they execute 9 (collapsed
         # 3x3 form): this is what the matrix cores actually do per second
         "step_executed_tflops": round(executed_flops_per_step / (ms_per_step * 1e-3) / 1e12 * world, 2)
@@ -329,7 +387,7 @@ def main():
         per = {}
         for d, i, lab in every:
             if lab is not None:
-                per.setdefault(lab, []).append(d.timer_ms(i))
+                per.setdefault(lab, []).append(every_ms[(id(d), i)])
         out["exchange"] = {
             "rccl_nranks": comm.nranks(), "bucket_mb": eng.bucket_bytes / 2 ** 20,
             "collectives_per_step": len([k for k in per if k.startswith("allreduce_")]),
@@ -339,7 +397,7 @@ def main():
             "exposed_wait_ms_per_step": {k[-1]: round(sum(v) / len(v), 4) for k, v in per.items() if k.startswith("wait_comm")},
         }
     if dominant and slot:
-        tot_ms = sum(d.timer_ms(i) for d, i in timed)
+        tot_ms = sum(timed_ms)
         avg_ms = tot_ms / slot                           # in the timed region (the other stream keeps running)
         flops_per_launch = flops_per_step / launches_per_step
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
@@ -365,17 +423,45 @@ def main():
                            "share_of_step_time": round(avg_ms * launches_per_step / ms_per_step, 3)}
     else:
         out["roofline"] = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and S == 512:
-        out["cpu_baseline"] = cpu_baseline(2)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    if secondary_name:
+        out = {"name": secondary_name, **{k: out[k] for k in (
+            "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "step_algorithmic_tflops",
+            "step_algorithmic_gflop_per_img", "step_flops_source", "step_frac_of_peak", "step_peak_tflops", "step_executed_tflops",
+            "losses", "value_with_h2d", "roofline")}}
     if comm is not None:
         comm.close()
         cdev.close()
-    for d in set(eng.devs):
+    for d in {id(d): d for d in list(eng.devs) + [sd[0] for sd in eng.side if sd is not None]}.values():
         if d is not dev:
             d.close()
     dev.close()
+    return out
+
+
+def main():
+    args = parse_args()
+    from gan_heightmaps_amd import dist
+    rank, _, world = dist.env_rank_world()
+    out = measure(args)
+    headline = (args.mode == "both" and args.dtype == "f32" and not args.config1 and args.in_shp == 512
+                and args.batch_per_gpu == 4 and not args.graph and not args.one_stream and not args.no_grad_streams)
+    if rank == 0 and world == 1 and headline and not args.no_secondary and not args.ablate:
+        import copy
+        sec = []
+        for name, ov in SECONDARY:
+            a2 = copy.copy(args)
+            a2.steps, a2.warmup, a2.profile, a2.no_cpu_baseline = args.secondary_steps, 3, False, True
+            for k, v in ov.items():
+                setattr(a2, k, v)
+            try:
+                sec.append(measure(a2, name))
+            except Exception as ex:           # a secondary line must never take the headline down with it
+                sec.append({"name": name, "error": "%s: %s" % (type(ex).__name__, ex)})
+        out["secondary"] = sec
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.in_shp == 512 and not args.config1:
+        out["cpu_baseline"] = cpu_baseline(2)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -12,9 +12,12 @@
 
 #define GHM_MAX_TIMERS 4096
 
+struct ghm_ctx;
+
 struct ghm_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    ghm_ctx* owner = nullptr;       // the context whose workspace pointers the captured launches carry (pinned while the graph lives)
 };
 
 struct ghm_ctx;
@@ -53,6 +56,7 @@ struct ghm_ctx {
     int pinned = 0;
     std::vector<void*> retired;
     size_t retired_bytes = 0;
+    std::vector<ghm_graph*> graphs;   // live captured graphs of this context (their ``owner`` is cleared if the context dies first)
     float* ls_state = nullptr;     // dynamic loss scale {scale, 1/scale, clean steps, overflow flag, skipped steps, ...} or null
     float* zeros = nullptr;        // 256 B of zeros: the source of padding elements for LDS-DMA row staging
     int* tickets = nullptr;        // zeroed arrival counters of the folded split-K reductions (self-resetting)
@@ -81,6 +85,7 @@ int ghm_plan_cus();
 
 // grow-only workspace owned by the ctx; growing is illegal while a graph is being captured
 int ghm_scratch(ghm_ctx* ctx, size_t bytes, void** out);
+void ghm_unpin(ghm_ctx* ctx);     // a graph / recorded step that pinned the context's workspace is gone
 
 void ghm_set_error(const char* fmt, ...);
 

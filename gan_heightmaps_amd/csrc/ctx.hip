@@ -59,6 +59,18 @@ int ghm_scratch(ghm_ctx* ctx, size_t bytes, void** out) {
     return 0;
 }
 
+// the last graph / recorded step that replays this context's workspace pointers is gone: the outgrown blocks that were
+// kept alive for it can be freed
+void ghm_unpin(ghm_ctx* ctx) {
+    if (ctx->pinned > 0) --ctx->pinned;
+    if (ctx->pinned == 0 && !ctx->retired.empty()) {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void* p : ctx->retired) (void)hipFree(p);
+        ctx->retired.clear();
+        ctx->retired_bytes = 0;
+    }
+}
+
 extern "C" {
 
 const char* ghm_last_error(void) { return g_err; }
@@ -117,6 +129,7 @@ int ghm_ctx_destroy(ghm_ctx* ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     if (ctx->comm) ghm_comm_destroy(ctx);
+    for (ghm_graph* g : ctx->graphs) g->owner = nullptr;       // graphs may outlive their context: they just stop pinning it
     for (int i = 0; i < GHM_MAX_TIMERS; ++i) {
         if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
         if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
@@ -260,6 +273,8 @@ int ghm_capture_end(ghm_ctx* ctx, ghm_graph** out) {
         return -1;
     }
     ++ctx->pinned;
+    g->owner = ctx;
+    ctx->graphs.push_back(g);
     *out = g;
     return 0;
 }
@@ -273,6 +288,12 @@ int ghm_graph_destroy(ghm_graph* g) {
     if (!g) return 0;
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
+    if (g->owner) {
+        auto& v = g->owner->graphs;
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i] == g) { v.erase(v.begin() + i); break; }
+        ghm_unpin(g->owner);
+    }
     delete g;
     return 0;
 }
@@ -345,7 +366,7 @@ int ghm_step_run(ghm_step* s) {
 int ghm_step_destroy(ghm_step* s) {
     if (s && s->recording) ghm_step_record_end(s);
     if (s && s->recorded)
-        for (int i = 0; i < s->n; ++i) --s->ctx[i]->pinned;
+        for (int i = 0; i < s->n; ++i) ghm_unpin(s->ctx[i]);
     delete s;          // graphs stay owned by their creator (ghm_graph_destroy)
     return 0;
 }

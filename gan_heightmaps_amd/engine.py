@@ -514,7 +514,8 @@ class NetPlan:
     def _pool_y_dropped(self, n):
         """fused conv + activation + max-pool node whose pooled fp32 tensor is never written: every consumer reads the q
         copy, and the backward pass takes the activation slope from the sign bit the forward kernel leaves in the mask"""
-        if n.op != 'convpool' or not self.use_q or os.environ.get("GHM_KEEP_POOL_Y") is not None:
+        if (n.op != 'convpool' or not self.use_q or os.environ.get("GHM_KEEP_POOL_Y") is not None
+                or os.environ.get("GHM_POOL_READ_Y") is not None):      # (the A/B switch of the backward reads it back)
             return False
         if n.act.kind not in ('linear', 'relu', 'lrelu') or self._fp32_needed(n):
             return False
@@ -969,8 +970,9 @@ class NetPlan:
                     if need_dx:
                         gi, acc = target(xin)
                         w = st.value(l.W)
-                        prog.append(("conv_dgrad", lambda dS=dS, m=mptr, y=y, G=G, w=w, gi=gi, a=a, acc=acc:
-                                     ops.conv2d_pool_dgrad_sparse(dS, m, y, G, w, gi, a.kind, a.alpha, acc), pool_sparse_meta(dS, 1)))
+                        dG = self._desc(n, gi, self._full(n, nb))        # the kernel strides dx by ITS sample stride, not x's
+                        prog.append(("conv_dgrad", lambda dG=dG, m=mptr, y=y, G=G, w=w, gi=gi, a=a, acc=acc:
+                                     ops.conv2d_pool_dgrad_sparse(dG, m, y, G, w, gi, a.kind, a.alpha, acc), pool_sparse_meta(dG, 1)))
                         mark_written(xin)
                     continue
                 # otherwise: the gradient of the conv's (never materialised in the forward pass) full-resolution output from

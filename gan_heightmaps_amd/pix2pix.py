@@ -121,13 +121,16 @@ class Pix2Pix:
     def save_model(self, filename):
         if not self._is_writer():
             return
+        dd = {'dcgan': {'gen': L.get_all_param_values(self.dcgan['gen']),
+                        'disc': L.get_all_param_values(self.dcgan['disc'])},
+              'p2p': {'gen': L.get_all_param_values(self.p2p['gen']),
+                      'disc': L.get_all_param_values(self.p2p['disc'])}}
+        eng = getattr(self, 'engine', None)
+        ls = eng.loss_scale_state() if hasattr(eng, 'loss_scale_state') else []
+        if ls:          # fp16 only: the dynamic loss scale is training state (an extra key; the reference's loader ignores it)
+            dd['loss_scale'] = [{k: float(v) for k, v in st.items()} for st in ls]
         with gzip.open(filename, "wb") as g:
-            _Py2CompatPickler(g, 2).dump({      # protocol 2 == py2 HIGHEST_PROTOCOL, readable by the reference
-                'dcgan': {'gen': L.get_all_param_values(self.dcgan['gen']),
-                          'disc': L.get_all_param_values(self.dcgan['disc'])},
-                'p2p': {'gen': L.get_all_param_values(self.p2p['gen']),
-                        'disc': L.get_all_param_values(self.p2p['disc'])}
-            })
+            _Py2CompatPickler(g, 2).dump(dd)      # protocol 2 == py2 HIGHEST_PROTOCOL, readable by the reference
 
     def load_model(self, filename, mode='both'):
         assert mode in ['both', 'dcgan', 'p2p']
@@ -139,6 +142,8 @@ class Pix2Pix:
         if mode in ('both', 'p2p'):
             L.set_all_param_values(self.p2p['gen'], dd['p2p']['gen'])
             L.set_all_param_values(self.p2p['disc'], dd['p2p']['disc'])
+        if dd.get('loss_scale') and mode == 'both':
+            self.engine.restore_loss_scale_state(dd['loss_scale'])
 
     # ---- training loop (pix2pix.py:187-275) ----------------------------------------------------------------
     def train(self, it_train, it_val, batch_size, num_epochs, out_dir, model_dir=None, save_every=10, resume=False,
@@ -199,6 +204,7 @@ class Pix2Pix:
                 print(line)
             f.write(line + "\n")
             f.flush()
+            self._check_loss_scale(e + 1)
             if dump_images:
                 with util_writes(writer):
                     if self.train_mode in ['both', 'p2p']:
@@ -212,6 +218,27 @@ class Pix2Pix:
             if model_dir is not None and (e + 1) % save_every == 0:
                 self.save_model("%s/%i.model" % (model_dir, e + 1))
         f.close()
+
+    def _check_loss_scale(self, epoch):
+        """fp16 only: one line per epoch with the dynamic loss scale and the updates it skipped, and a warning when
+        training has stalled on it -- a scale at its floor with every step still flagged means the FORWARD activations
+        exceed the fp16 range, which no loss scale can fix (use bf16)"""
+        eng = getattr(self, 'engine', None)
+        ls = eng.loss_scale_state() if hasattr(eng, 'loss_scale_state') else []
+        if not ls:
+            return
+        prev = getattr(self, '_ls_prev', [0] * len(ls))
+        skipped = [st['skipped_steps'] - p for st, p in zip(ls, prev)]
+        self._ls_prev = [st['skipped_steps'] for st in ls]
+        if self.verbose:
+            print("epoch %d: fp16 loss scale %s, updates skipped this epoch %s"
+                  % (epoch, [st['scale'] for st in ls], skipped))
+        for st, sk in zip(ls, skipped):
+            if st['scale'] <= self.engine.ls_min and sk > 0:
+                import warnings
+                warnings.warn("fp16 loss scale is at its minimum (%g) and %d updates were skipped in epoch %d: the "
+                              "activations overflow fp16; training is stalled -- use dtype='bf16'"
+                              % (st['scale'], sk, epoch), RuntimeWarning)
 
     # ---- sampling helpers (pix2pix.py:276-425): forward-only, PNG output through util.imsave (PIL) --------
     @staticmethod

@@ -150,6 +150,14 @@ class GanStep:
             out.append({'scale': float(v[0]), 'clean_steps': int(v[2]), 'skipped_steps': int(v[4])})
         return out
 
+    def restore_loss_scale_state(self, states):
+        """checkpointed [{scale, clean_steps, skipped_steps}] per stage stream back into the device records"""
+        self.sync()
+        for (d, t), st in zip(self._ls_state, states):
+            v = t.numpy().ravel()
+            v[0], v[1], v[2], v[3], v[4] = st['scale'], 1.0 / st['scale'], st.get('clean_steps', 0), 0, st.get('skipped_steps', 0)
+            t.set(v)
+
     def set_loss_scale(self, scale):
         self.sync()
         for d, t in self._ls_state:

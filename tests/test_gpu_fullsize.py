@@ -231,6 +231,67 @@ def test_full_size_batch4_step_against_the_float64_fixture(gpu):
     del model
 
 
+@pytest.mark.parametrize("mode", ["dcgan", "p2p"])
+def test_full_size_batch4_single_stage_modes_against_the_fixture(gpu, mode):
+    """BASELINE configs 2 / 3: the same 512x512 nets with ``train_mode='dcgan'`` / ``'p2p'`` (pix2pix.py:136-141) given
+    to the constructor, as bench.py --mode does.  Every loss and gradient root of the reference's step is evaluated at the
+    pre-update parameters, so the trained stage's half of tests/golden/reference_step_fullsize_b4.npz (the JOINT step)
+    is this mode's answer: all five losses, the trained stage's outputs, gradients and post-step parameters equal the
+    fixture's; the other stage's parameters do not move (its fixture rows are the PRE-step norms + an update, so they
+    must differ from the fixture's "after" rows by the RMSprop step that was not taken)."""
+    import os
+    dev, ops, D = gpu
+    from gan_heightmaps_amd.experiments import make_model
+    from gan_heightmaps_amd import layers as L
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_step_fullsize_b4.npz"))
+    seed, batch, dseed, stride, win = (int(v) for v in fix["meta"])
+    cfg = ostep.default_cfg()
+    model = make_model('test1_nobn_bilin_both', device=dev, seed=seed, verbose=False, use_graph=False, train_mode=mode)
+    assert model.engine.train_mode == mode
+    Z, X, Y = ostep.synthetic_batch(batch, cfg, seed=dseed)
+    frozen = ('p2p', 'dcgan')[mode == 'p2p']
+    before = {(frozen, h): [v.copy() for v in L.get_all_param_values(getattr(model, frozen)[h])] for h in ('gen', 'disc')}
+    got = model.train_fn(Z, X, Y)
+    assert rel(got, fix["losses64"]) < 1e-5, (got, fix["losses64"])          # all five losses (pix2pix.py:142)
+    b = model.engine.built(batch)
+    key, t = (("gz", b.G.out), ("ux", b.U.out))[mode == 'p2p']
+    a = t.numpy().astype(np.float64)
+    assert rel(a[:, :, ::stride, ::stride], fix[key + "_sample64"]) < 1e-4
+
+    def summary(v):
+        v64 = np.asarray(v, np.float64).ravel()
+        idx = np.linspace(0, v64.size - 1, 8).astype(np.int64)
+        return np.concatenate([[v64.sum(), np.sqrt((v64 * v64).sum())], v64[idx]])
+
+    for b_ in ('gen', 'disc'):
+        k = "%s_%s" % (mode, b_)
+        st = model.engine.stores[k]
+        params = L.get_all_params(getattr(model, mode)[b_], trainable=True)
+        keys = sorted(q for q in fix.files if q.startswith("grad/%s/" % k))
+        assert len(keys) == len(params)
+        mine = [summary(st.download_grad(p)) for p in params]
+        ref = [fix[q] for q in keys]
+        r32 = [fix["grad32/" + q[5:]] for q in keys]
+        live = [i for i, r in enumerate(ref) if r[1] > 1e-12]
+
+        def cat(rows, sl):
+            return np.concatenate([rows[i][sl] for i in live])
+        spread = max(rel(cat(r32, slice(2, None)), cat(ref, slice(2, None))), rel(cat(r32, slice(1, 2)), cat(ref, slice(1, 2))))
+        tol = 2e-4 if b_ == 'disc' else 2 * spread + 1e-4
+        assert rel(cat(mine, slice(2, None)), cat(ref, slice(2, None))) < tol, (k, tol)
+        after = [summary(v) for v in L.get_all_param_values(getattr(model, mode)[b_])]
+        akeys = sorted(q for q in fix.files if q.startswith("after/%s/" % k))
+        n_mine, n_ref = np.array([v[1] for v in after]), np.array([fix[q][1] for q in akeys])
+        assert np.all(np.abs(n_mine - n_ref) <= 1e-5 * n_ref + 3e-6), k
+    for (a_, h), vals in before.items():                    # the other stage is evaluated, never updated
+        now = L.get_all_param_values(getattr(model, a_)[h])
+        trainable = {id(p) for p in L.get_all_params(getattr(model, a_)[h], trainable=True)}
+        for p, v0, v1 in zip(L.get_all_params(getattr(model, a_)[h]), vals, now):
+            if id(p) in trainable:
+                assert np.array_equal(v0, v1), (a_, h, p.name)
+    del model
+
+
 # Bounds of the reduced-precision full-size step against the float64 fixture (rel-L2; "cos" = cosine of the sampled
 # gradient elements to the exact ones).  ~2x what the MI355X measures (the test prints the measured values): operand
 # rounding is 2^-9 (bf16) / 2^-12 (fp16) per product, accumulated over 9..25 x C products in fp32; the generators' deep
