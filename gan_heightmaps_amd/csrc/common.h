@@ -231,6 +231,32 @@ int lp_conv_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const
 bool lp_dgrad_s2_single_pass(const ghm_conv_desc* d, int dtype);
 int lp_dgrad_s2_dact(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* wqT, float* dx, const float* dact_y,
                      long dact_nstride, int dact, float dact_alpha, int dtype);
+// conv_small.hip: layers whose maps are at most 16 x 16 pixels (the U-Net's inner half, the first DCGAN generator stages,
+// the last discriminator stages) on the bf16 / fp16 matrix cores as TWO launches per layer: a gather GEMM over (row tile,
+// pixel group, split) and a finishing kernel per 8 channels that also runs the BatchNorm behind the convolution.
+// conv_lp.hip routes the forward products (kind 0) and data gradients (kind 1) served there.
+struct SmBn {           // BatchNorm behind the convolution, folded into the finishing kernel (training statistics)
+    const float* gamma;
+    const float* beta;
+    float* mean;
+    float* inv;
+    float* run_mean;    // or null
+    float* run_inv;
+    float eps, run_alpha;
+    float* y;           // fp32 act(bn(conv)) or null (the q copy goes to sm_conv's outq)
+    long y_nstride;
+};
+bool sm_use(const ghm_conv_desc* d, int kind, int dtype);
+int sm_finish_launch(ghm_ctx* ctx, const float* partial, int splits, int R, int N, int HW, const float* bias, float* out32,
+                     long out_nstride, int accumulate, int act, float alpha, void* outq, long outq_ns, int dtype, const SmBn* bn);
+// conv_lp.hip: a forward convolution that lp_conv_kernel runs in split-K form (16 x 16 maps) can end in the same finishing
+// kernel, BatchNorm included
+bool lp_fwd_splitk_bn_ok(const ghm_conv_desc* d, int dtype);
+int lp_fwd_splitk_bn(ghm_ctx* ctx, const ghm_conv_desc* d, const void* xq, long xq_ns, const void* wq, const float* bias,
+                     float* conv_out, void* yq, long yq_ns, int act, float alpha, int dtype, const SmBn* bn);
+int sm_conv(ghm_ctx* ctx, const ghm_conv_desc* d, int kind, const void* inq, long inq_ns, const float* in32, const void* wq,
+            const float* bias, float* out32, long out_nstride, void* outq, long outq_ns, int act, float alpha, int accumulate,
+            int dtype, const SmBn* bn);
 // split-K epilogue of a forward-form convolution: out = act(sum of S partial slices [S][R][N*H*W] + bias (+ out))
 int ghm_splitk_finish(ghm_ctx* ctx, const float* partial, int S, float* out, const float* bias, int N, int R, int H,
                       int W, long out_nstride, int act, float alpha, int accumulate);

@@ -1193,8 +1193,14 @@ int lp_prepare(ghm_ctx* ctx, LpConvArgs& a, int splits, const float* x32, long x
 }
 
 // after a split-K launch: the fixed-order reduction writes the fp32 output; a requested q output is packed from it
+static bool lp_sm_finish_ok(int R, long pixels) { return R % 8 == 0 && pixels <= 8192 && GHM_OPT("GHM_NO_SM_FINISH") == nullptr; }
+
 template <int DT>
-int lp_finish_splits(ghm_ctx* ctx, const LpConvArgs& a, int splits) {
+int lp_finish_splits(ghm_ctx* ctx, const LpConvArgs& a, int splits, const SmBn* bn = nullptr) {
+    if (lp_sm_finish_ok(a.R, (long)a.N * a.H * a.W))     // sum + bias + activation + fp32 / q outputs (+ BatchNorm) in ONE launch
+        return sm_finish_launch(ctx, a.partial, splits, a.R, a.N, a.H * a.W, a.bias, a.out, a.out_nstride, a.accumulate, a.act,
+                                a.alpha, a.out_q, a.out_q_nstride, DT, bn);
+    GHM_CHECK(bn == nullptr, "split-K low-precision convolution: BatchNorm epilogue not served for this geometry");
     GHM_CHECK(a.out != nullptr, "split-K low-precision convolution needs an fp32 output (ask ghm_lp_q_direct)");
     if (int e = ghm_splitk_finish(ctx, a.partial, splits, a.out, a.bias, a.N, a.R, a.H, a.W, a.out_nstride, a.act, a.alpha,
                                   a.accumulate))
@@ -1204,7 +1210,9 @@ int lp_finish_splits(ghm_ctx* ctx, const LpConvArgs& a, int splits) {
 }
 
 template <int DT>
-int lp_launch_conv(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a, int ks, int st, const float* x32 = nullptr, long x32_nstride = 0) {
+int lp_launch_conv(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a, int ks, int st, const float* x32 = nullptr, long x32_nstride = 0,
+                   const SmBn* bn = nullptr) {
+    GHM_CHECK(bn == nullptr || pl.splits > 1, "lp_launch_conv: the BatchNorm epilogue belongs to the split-K form");
     a.slabs_per_split = pl.slabs_per_split;
     if (const char* f = GHM_OPT("GHM_ABLATE")) a.debug = atoi(f);
     GHM_CHECK(!(a.accumulate && !a.out), "accumulate needs the fp32 output");
@@ -1240,7 +1248,7 @@ int lp_launch_conv(ghm_ctx* ctx, const LpPlan& pl, LpConvArgs a, int ks, int st,
         return -3;
     }
 #undef GHM_LP_CASE
-    if (pl.splits > 1) return lp_finish_splits<DT>(ctx, a, pl.splits);
+    if (pl.splits > 1) return lp_finish_splits<DT>(ctx, a, pl.splits, bn);
     return 0;
 }
 
@@ -1578,10 +1586,13 @@ int lp_conv_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const
 }
 
 static int lp_fwd_io(ghm_ctx* ctx, const ghm_conv_desc* d, const LpIO& io, const void* wq, const float* bias, int act,
-                     float alpha, int accumulate, int dtype) {
+                     float alpha, int accumulate, int dtype, const SmBn* bn = nullptr) {
     GHM_CHECK(ghm_lp_supported(d, 0, dtype), "low-precision forward convolution: geometry / dtype not served by the "
               "matrix-core kernels (ask ghm_lp_supported first)");
     GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    if (sm_use(d, 0, dtype))            // small maps: gather GEMM + finishing kernel (conv_small.hip)
+        return sm_conv(ctx, d, 0, io.inq, io.inq_ns, io.in32, wq, bias, io.out32, d->y_nstride, io.outq, io.outq_ns, act, alpha,
+                       accumulate, dtype, nullptr);
     const LpPlan pl = lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ctx->num_cu);
     LpConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -1590,14 +1601,31 @@ static int lp_fwd_io(ghm_ctx* ctx, const ghm_conv_desc* d, const LpIO& io, const
     a.N = d->N; a.CH = d->C; a.H = d->Ho; a.W = d->Wo; a.Hin = d->H; a.Win = d->W;
     a.R = d->K; a.Rpad = rpad128(d->K); a.out_nstride = d->y_nstride; a.pad = d->pad;
     a.act = act; a.alpha = alpha; a.accumulate = accumulate;
-    return dtype == GHM_DTYPE_BF16 ? lp_launch_conv<GHM_DTYPE_BF16>(ctx, pl, a, d->kh, d->stride, io.in32, d->x_nstride)
-                                   : lp_launch_conv<GHM_DTYPE_F16>(ctx, pl, a, d->kh, d->stride, io.in32, d->x_nstride);
+    return dtype == GHM_DTYPE_BF16 ? lp_launch_conv<GHM_DTYPE_BF16>(ctx, pl, a, d->kh, d->stride, io.in32, d->x_nstride, bn)
+                                   : lp_launch_conv<GHM_DTYPE_F16>(ctx, pl, a, d->kh, d->stride, io.in32, d->x_nstride, bn);
+}
+
+bool lp_fwd_splitk_bn_ok(const ghm_conv_desc* d, int dtype) {
+    if ((dtype != GHM_DTYPE_BF16 && dtype != GHM_DTYPE_F16) || !lp_fwd_geom(d)) return false;
+    const LpPlan pl = lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ghm_plan_cus());
+    // (the BatchNorm form of the finishing kernel walks the whole map of its 8 channels in one block: 16 x 16 maps, not more)
+    return pl.ok && pl.splits > 1 && (long)d->N * d->Ho * d->Wo <= 1024 && lp_sm_finish_ok(d->K, (long)d->N * d->Ho * d->Wo);
+}
+
+int lp_fwd_splitk_bn(ghm_ctx* ctx, const ghm_conv_desc* d, const void* xq, long xq_ns, const void* wq, const float* bias,
+                     float* conv_out, void* yq, long yq_ns, int act, float alpha, int dtype, const SmBn* bn) {
+    GHM_CHECK(lp_fwd_splitk_bn_ok(d, dtype), "lp_fwd_splitk_bn: not served");
+    const LpIO io{nullptr, xq, xq_ns, conv_out, yq, yq_ns};
+    return lp_fwd_io(ctx, d, io, wq, bias, act, alpha, 0, dtype, bn);
 }
 
 static int lp_dgrad_io(ghm_ctx* ctx, const ghm_conv_desc* d, const LpIO& io, const void* wqT, const float* bias, int act,
                        float alpha, int accumulate, int dtype) {
     GHM_CHECK(ghm_lp_supported(d, 1, dtype), "low-precision data gradient: geometry / dtype not served (ask ghm_lp_supported)");
     GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    if (sm_use(d, 1, dtype))
+        return sm_conv(ctx, d, 1, io.inq, io.inq_ns, io.in32, wqT, bias, io.out32, d->x_nstride, io.outq, io.outq_ns, act, alpha,
+                       accumulate, dtype, nullptr);
     if (d->stride == 2)
         return lp_dgrad_s2_io(ctx, d, io, wqT, bias, act, alpha, accumulate, nullptr, 0, 0, 0.f, dtype, false);
     // the data gradient of a stride-1 conv is the forward conv K -> C with flipped taps (folded into the
@@ -1618,6 +1646,7 @@ extern "C" {
 
 int ghm_lp_supported(const ghm_conv_desc* d, int32_t kind, int32_t dtype) {
     if (dtype != GHM_DTYPE_BF16 && dtype != GHM_DTYPE_F16) return 0;
+    if ((kind == 0 || kind == 1) && sm_use(d, kind, dtype)) return 1;
     if (kind == 0) return lp_fwd_geom(d) && lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ghm_plan_cus()).ok;
     if (kind == 1) {
         if (d->stride == 2) return lp_plan_dgrad_s2(d, ghm_plan_cus()).ok;
@@ -1699,11 +1728,14 @@ int ghm_q_unpack(ghm_ctx* ctx, const void* q, int64_t q_nstride, int32_t N, int3
 int ghm_lp_q_direct(const ghm_conv_desc* d, int32_t kind, int32_t dtype) {
     // does the kernel of this product write its q output (and may it skip the fp32 one)?  Not in the split-K form.
     if (!ghm_lp_supported(d, kind, dtype)) return 0;
-    if (kind == 0) return (d->K % 8 == 0) && lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ghm_plan_cus()).splits == 1;
+    if ((kind == 0 || kind == 1) && sm_use(d, kind, dtype)) return 1;      // the finishing kernel writes the q copy
+    if (kind == 0)
+        return (d->K % 8 == 0) && (lp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ghm_plan_cus()).splits == 1 ||
+                                   lp_sm_finish_ok(d->K, (long)d->N * d->Ho * d->Wo));
     if (kind == 1) {
         if (d->C % 8) return 0;
         if (d->stride == 2) return lp_plan_dgrad_s2(d, ghm_plan_cus()).splits == 1;
-        return lp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ghm_plan_cus()).splits == 1;
+        return lp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ghm_plan_cus()).splits == 1 || lp_sm_finish_ok(d->C, (long)d->N * d->H * d->W);
     }
     return 0;
 }

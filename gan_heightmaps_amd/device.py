@@ -463,6 +463,24 @@ class Ops:
     def lp_q_direct(self, d, kind, dtype):
         return bool(_lib.load().ghm_lp_q_direct(C.byref(d), int(kind), DTYPE_CODES[dtype]))
 
+    def conv_variant_lp(self, d, kind, dtype):
+        """kernel family serving low-precision product ``kind`` (0 forward, 1 data gradient, 2 weight gradient)"""
+        out = C.create_string_buffer(128)
+        call("ghm_lp_variant", C.byref(d), int(kind), DTYPE_CODES[dtype], out, 128)
+        return out.value.decode()
+
+    def conv_bn_fused_supported(self, d, dtype):
+        return bool(_lib.load().ghm_conv_bn_fused_supported(C.byref(d), DTYPE_CODES[dtype]))
+
+    def conv2d_bn_fwd_lp_q(self, d, xq, wq, bias, conv_out, y, yq, gamma, beta, mean, inv, run_mean, run_inv, eps, run_alpha,
+                           dtype, act='linear', alpha=0.0):
+        """y / yq = act(bn(conv(xq) + bias)) with batch statistics; conv_out (fp32) keeps conv(xq) + bias for the backward"""
+        assert conv_out.nstride == d.y_nstride
+        call("ghm_conv2d_bn_fwd_lp_q", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, _vp(wq), _vp(bias), _vp(conv_out),
+             _vp(y), y.nstride if y is not None else 0, C.c_void_p(yq.ptr if yq is not None else 0),
+             yq.nstride if yq is not None else 0, _vp(gamma), _vp(beta), _vp(mean), _vp(inv), _vp(run_mean), _vp(run_inv),
+             eps, run_alpha, ACT_CODES[act], alpha, DTYPE_CODES[dtype])
+
     def conv2d_fwd_lp_q(self, d, xq, wq, bias, y, yq, dtype, act='linear', alpha=0.0, accumulate=False):
         call("ghm_conv2d_fwd_lp_q", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, _vp(wq), _vp(bias), _vp(y),
              C.c_void_p(yq.ptr if yq is not None else 0), yq.nstride if yq is not None else 0, ACT_CODES[act], alpha,

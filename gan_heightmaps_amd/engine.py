@@ -580,6 +580,18 @@ class NetPlan:
                          self.ops.lp_pack_weights(d, w, wq, self.dtype, t)))
         return wq
 
+    def _conv_bn_fusable(self, n, d, xq, deterministic):
+        """-> the BatchNorm node behind convolution n when the pair runs as one product (ghm_conv2d_bn_fwd_lp_q), else None"""
+        if (n.op != 'conv' or xq is None or deterministic or self.bn_groups != 1 or n.act != linear or len(n.consumers) != 1
+                or os.environ.get("GHM_NO_CONV_BN_FUSE") is not None or not hasattr(self.ops, 'conv_bn_fused_supported')):
+            return None
+        bnn = n.consumers[0]
+        if bnn.op != 'bn' or self._bn_hi(bnn) or n.out.nstride != d.y_nstride:
+            return None
+        if not (self._lp(d, 0) and self.ops.conv_bn_fused_supported(d, self.dtype)):
+            return None
+        return bnn
+
     def _bn_hi(self, n):
         """is n the BatchNorm of a collapsed up-sample convolution whose only reader is the parity interleave?  Then the
         two run as one pass in both directions (csrc/elementwise_q.hip: bn_apply_hi / bn_backward_hi)."""
@@ -622,7 +634,10 @@ class NetPlan:
             prog.append(("lp_pack", lambda t=self._lp_table: ops.lp_pack_batched(t, self.dtype)))
         qpack = lambda t, q: prog.append(("q_pack", lambda t=t, q=q: ops.q_pack(t, q), pack_meta(t)))
         fused_hi = set()            # pp_to_hi nodes whose output the BatchNorm in front of them writes
+        fused_bn = set()            # BatchNorm nodes that ran inside the finishing kernel of the convolution in front of them
         for n in self.order:
+            if id(n) in fused_bn:
+                continue
             y = n.out
             if n.op in ('input', 'reshape', 'concat'):
                 if n.op == 'concat':
@@ -648,7 +663,21 @@ class NetPlan:
             if n.op in ('conv', 'dense'):
                 d = self._desc(n, x, y)
                 w, b = st.value(n.layer.W), st.value(n.layer.b)
-                if n.op == 'conv' and self._lp(d, 0):
+                bnn = self._conv_bn_fusable(n, d, xq, deterministic)
+                if bnn is not None:
+                    # small maps: Conv2DLayer -> BatchNormLayer (-> nonlinearity) as ONE product -- the finishing kernel of
+                    # the convolution holds the whole map of its channels (csrc/conv_small.hip)
+                    wq = self._lp_pack_entry(prog, d, w, ('w', id(n.layer.W)), False, lp_done)
+                    lb = bnn.layer
+                    fused_bn.add(id(bnn))
+                    y32 = bnn.out if (bnn.outq is None or self._fp32_needed(bnn)) else None
+                    rm, ri = (st.value(lb.mean), st.value(lb.inv_std)) if update_running else (None, None)
+                    prog.append(("conv_bn_fwd", lambda d=d, xq=xq, wq=wq, b=b, co=y, y32=y32, yq=bnn.outq, lb=lb, rm=rm, ri=ri,
+                                 m=bnn.aux['mean'], iv=bnn.aux['inv'], ba=bnn.act:
+                                 ops.conv2d_bn_fwd_lp_q(d, xq, wq, b, co, y32, yq, st.value(lb.gamma), st.value(lb.beta), m, iv,
+                                                        rm, ri, lb.epsilon, lb.alpha, self.dtype, ba.kind, ba.alpha),
+                                 conv_meta(ops, d, 0, self.dtype)))
+                elif n.op == 'conv' and self._lp(d, 0):
                     wq = self._lp_pack_entry(prog, d, w, ('w', id(n.layer.W)), False, lp_done)
                     if xq is not None:
                         q_direct = n.outq is not None and ops.lp_q_direct(d, 0, self.dtype)
@@ -1318,6 +1347,8 @@ def conv_meta(ops, d, kind, dtype='f32', pooled=False):
     elif dtype != 'f32':
         fam = "wgrad" if kind == 2 else ("dgrad_s2" if kind in (1, 3) and d.stride == 2 else "conv")
         name = "lp_%s_kernel<%s, %d, %d>" % (fam, dtype, d.kh, d.stride)
+        if hasattr(ops, 'conv_variant_lp'):         # (small maps run their own kernel family behind the same entry points)
+            name = ops.conv_variant_lp(d, {0: 0, 1: 1, 3: 1, 2: 2}[kind], dtype)
     else:
         name = ops.conv_variant(d, kind)
     # algorithmic HBM bytes of the launch (the wide tensor(s) once): conv input + conv output, fp32; a fused

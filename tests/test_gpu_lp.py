@@ -206,8 +206,8 @@ def test_lp_unsupported_geometries_are_refused(gpu):
     from gan_heightmaps_amd._lib import GhmError
     for case in [(2, 1, 32, 32, 64, 5, 1, 2),      # 1 input channel (thin layer)
                  (2, 24, 32, 32, 64, 3, 1, 1),     # channels % 16 != 0
-                 (2, 32, 4, 4, 64, 3, 1, 1),       # 4-wide map
-                 (2, 32, 32, 32, 64, 1, 1, 0)]:    # 1x1
+                 (2, 32, 12, 12, 64, 3, 1, 1),     # 12-wide map (neither a 8 / 16 / 32-column tile nor a small map)
+                 (2, 32, 32, 32, 64, 1, 1, 0)]:    # 1x1 filter on a large map
         N, C, H, W, K, k, s, pad = case
         d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
         assert not ops.lp_supported(d, 0, 'bf16')
@@ -228,7 +228,9 @@ LP_STEP = dict(in_shp=128, latent_dim=32,
 #   nearly the same functional at every pixel), so the relative noise of what remains is amplified (the fp32 path shows
 #   the same amplification of ITS rounding: 1e-7 -> 1e-4, tests/test_gpu_step.py).  Bounded by the cosine to the exact
 #   gradient and by the fp16 run of the same kernels landing ~8x closer (a defect would not scale with the mantissa).
-STEP_TOL = {'bf16': dict(loss=1.5e-2, disc=6e-2, gen=0.6, cos=0.85), 'f16': dict(loss=2e-3, disc=8e-3, gen=0.1, cos=0.995)}
+STEP_TOL = {'bf16': dict(loss=1.5e-2, disc=6e-2, gen=0.6, cos=0.85), 'f16': dict(loss=2e-3, disc=1.3e-2, gen=0.2, cos=0.99)}
+# (round 4, maps below 8 columns on the matrix cores too: measured bf16 2.4e-4 / 1.9e-2 / 0.29 (cosine 0.956), fp16 1.0e-5 / 6.2e-3 /
+# 9.9e-2 (cosine 0.995); the generator figure moves by +-30 % with WHICH layers round -- the batch-4 BatchNorm chains again)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
@@ -372,6 +374,143 @@ Q_CASES = [
     (1, 48, 16, 16, 96, 3, 1, 1),       # 16-wide map: the narrow tiles
     (3, 32, 8, 8, 160, 3, 1, 1),        # 8-wide map, K not a multiple of the 128 / 64-row tile
 ]
+
+
+# small maps (csrc/conv_small.hip: gather GEMM + finishing kernel): 16 x 16 down to 1 x 1, 3x3 / 5x5 / 2x2 filters, stride 1
+# and 2 (forward and both data-gradient forms), ragged batch / filter counts, more pixels than one block (N * H * W > 128)
+SMALL_CASES = [
+    # N, C,  H,  W,  K,  k, s, pad
+    (4, 64, 16, 16, 64, 3, 1, 1),       # U-Net decoder level (16 x 16)
+    (4, 32, 32, 32, 96, 3, 2, 1),       # encoder 32 -> 16: the stride-2 data gradient walks 16 x 16 parity classes
+    (4, 64, 16, 16, 48, 3, 2, 1),       # 16 -> 8, 48 filters (ragged row tile)
+    (3, 48, 8, 8, 64, 3, 2, 1),         # 8 -> 4, three images
+    (4, 32, 4, 4, 80, 3, 2, 1),         # 4 -> 2
+    (4, 32, 2, 2, 64, 2, 1, 0),         # conv9 of the U-Net: 2 x 2 -> 1 x 1, 2x2 filter, no padding
+    (4, 32, 4, 4, 64, 3, 1, 1),         # 4 x 4 decoder level
+    (2, 16, 4, 4, 32, 5, 1, 2),         # the DCGAN generator's first 5x5 convolution
+    (8, 32, 8, 8, 64, 5, 1, 2),         # discriminator tail, batch 8
+    (8, 16, 16, 16, 32, 5, 1, 2),       # 2048 pixels per channel
+    (1, 16, 8, 8, 16, 3, 1, 1),         # one image, 16 filters
+]
+
+
+@pytest.mark.parametrize("splits", [None, "1", "3"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_small_map_products(gpu, case, dtype, splits):
+    """forward product and data gradient of the small-map path against oracle/lp.py (exact given the rounding), q operand in,
+    fp32 + q out (q == round(fp32) bit for bit, written into a channel slice of a wider buffer), accumulate, fp32-operand
+    entry point = pack + the same kernels, forced split counts (the partial slices are summed in a fixed order: the result
+    is a pure function of the split count)"""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    env = {"GHM_SM_MAXM": "4096"}          # (every case on the small-map kernels, whatever the plan's own size rule says)
+    if splits is not None:
+        env["GHM_SM_SPLITS"] = splits
+    with tuning_env(**env):
+        rng = np.random.RandomState(11)
+        x = rng.randn(N, C, H, W).astype(np.float32)
+        Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+        b = rng.randn(K).astype(np.float32)
+        d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+        dy = rng.randn(N, K, d.Ho, d.Wo).astype(np.float32)
+        R = LP.ROUND[dtype]
+        assert ops.lp_supported(d, 0, dtype) and ops.lp_supported(d, 1, dtype)
+        assert ops.lp_q_direct(d, 0, dtype) and ops.lp_q_direct(d, 1, dtype)
+        xd, bd, dyd = dev.tensor(x), dev.tensor(b), dev.tensor(dy)
+        xq = D.QTensor.empty(dev, x.shape, dtype)
+        ops.q_pack(xd, xq)
+        wp = dev.tensor(D.pack_conv_w(Wt).ravel())
+        wq, wqT = dev.alloc(ops.lp_weight_bytes(d, False)), dev.alloc(ops.lp_weight_bytes(d, True))
+        ops.lp_pack_weights(d, wp, wq, dtype, False)
+        ops.lp_pack_weights(d, wp, wqT, dtype, True)
+        y32, y32b = dev.empty((N, K, d.Ho, d.Wo)), dev.empty((N, K, d.Ho, d.Wo))
+        yq_wide = D.QTensor.empty(dev, (N, K + 8, d.Ho, d.Wo), dtype)
+        dev.memset_zero(yq_wide.ptr, yq_wide.nbytes)
+        yq = yq_wide.channels(8, 8 + K)
+        ops.conv2d_fwd_lp_q(d, xq, wq, bd, y32, yq, dtype, act='lrelu', alpha=0.2)
+        ops.conv2d_fwd_lp(d, xd, wq, bd, y32b, dtype, act='lrelu', alpha=0.2)
+        y_ref = LP.conv2d_fwd(x, Wt, b, s, pad, dtype)
+        y_ref = np.where(y_ref > 0, y_ref, 0.2 * y_ref)
+        assert rel(y32.numpy(), y_ref) < EXACT, rel(y32.numpy(), y_ref)
+        assert np.array_equal(y32.numpy(), y32b.numpy())
+        assert np.array_equal(yq.numpy(), R(y32.numpy()))
+        assert not yq_wide.numpy()[:, :8].any()
+        yq2 = D.QTensor.empty(dev, (N, K, d.Ho, d.Wo), dtype)
+        ops.conv2d_fwd_lp_q(d, xq, wq, bd, None, yq2, dtype, act='lrelu', alpha=0.2)          # q output alone
+        assert np.array_equal(yq2.numpy(), yq.numpy())
+        ops.conv2d_fwd_lp_q(d, xq, wq, None, y32, None, dtype, accumulate=True)              # y += conv (no bias, linear)
+        assert rel(y32.numpy(), y_ref + LP.conv2d_fwd(x, Wt, 0 * b, s, pad, dtype)) < EXACT
+        # data gradient
+        dyq = D.QTensor.empty(dev, dy.shape, dtype)
+        ops.q_pack(dyd, dyq)
+        dx32 = dev.empty(x.shape)
+        dxq = D.QTensor.empty(dev, x.shape, dtype) if C % 8 == 0 else None
+        ops.conv2d_dgrad_lp_q(d, dyq, wqT, dx32, dxq, dtype)
+        dx_ref = LP.conv2d_vjp(x, Wt, dy, s, pad, dtype)[0]
+        assert rel(dx32.numpy(), dx_ref) < EXACT, rel(dx32.numpy(), dx_ref)
+        assert np.array_equal(dxq.numpy(), R(dx32.numpy()))
+        ops.conv2d_dgrad_lp_q(d, dyq, wqT, dx32, dxq, dtype, accumulate=True)
+        assert rel(dx32.numpy(), 2 * dx_ref) < EXACT
+        assert np.array_equal(dxq.numpy(), R(dx32.numpy()))
+        dx32b = dev.empty(x.shape)
+        ops.conv2d_dgrad_lp(d, dyd, wqT, dx32b, dtype)
+        assert rel(dx32b.numpy(), dx_ref) < EXACT
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("case", [SMALL_CASES[i] for i in (2, 3, 4, 5, 6, 7, 10)] + [(4, 256, 16, 16, 64, 3, 1, 1), (4, 512, 32, 32, 32, 3, 2, 1)])
+def test_small_map_convolution_with_the_batchnorm_in_its_finishing_kernel(gpu, case, dtype):
+    """ghm_conv2d_bn_fwd_lp_q: Conv2DLayer -> BatchNormLayer -> nonlinearity (every BatchNorm-fed layer of
+    architectures/p2p.py:169-240, dcgan.py:22-24) as one product on the small maps: conv_out = conv + bias (exact given the
+    rounding), batch statistics (biased variance, eps 1e-4, running mean / inv_std blended with alpha 0.1),
+    y = lrelu(bn(conv_out)) in fp32 and as a q tensor (== round(y) bit for bit), equal to the unfused launches"""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case          # (the last two: 16 x 16 maps, lp_conv_kernel in split-K form + the same finishing kernel)
+    rng = np.random.RandomState(5)
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    gamma, beta = (1 + 0.2 * rng.randn(K)).astype(np.float32), (0.3 * rng.randn(K)).astype(np.float32)
+    rm0, ri0 = rng.randn(K).astype(np.float32), (1 + 0.1 * rng.rand(K)).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    assert ops.conv_bn_fused_supported(d, dtype)
+    R = LP.ROUND[dtype]
+    xq = D.QTensor.empty(dev, x.shape, dtype)
+    ops.q_pack(dev.tensor(x), xq)
+    wq = dev.alloc(ops.lp_weight_bytes(d, False))
+    ops.lp_pack_weights(d, dev.tensor(D.pack_conv_w(Wt).ravel()), wq, dtype, False)
+    shp = (N, K, d.Ho, d.Wo)
+    co, y32 = dev.empty(shp), dev.empty(shp)
+    yq = D.QTensor.empty(dev, shp, dtype)
+    mean, inv = dev.empty((1, K, 1, 1)), dev.empty((1, K, 1, 1))
+    rm, ri = dev.tensor(rm0), dev.tensor(ri0)
+    ops.conv2d_bn_fwd_lp_q(d, xq, wq, dev.tensor(b), co, y32, yq, dev.tensor(gamma), dev.tensor(beta), mean, inv, rm, ri,
+                           1e-4, 0.1, dtype, act='lrelu', alpha=0.01)
+    c_ref = LP.conv2d_fwd(x, Wt, b, s, pad, dtype)
+    assert rel(co.numpy(), c_ref) < EXACT
+    # the BatchNorm of the kernel's own fp32 conv output, in float64
+    c32 = co.numpy().astype(np.float64)
+    yb, mu, iv = O.bn_train_fwd(c32, beta.astype(np.float64), gamma.astype(np.float64))
+    y_ref = O.lrelu_fwd(yb, 0.01)
+    assert rel(mean.numpy().ravel(), mu.ravel()) < 1e-6 and rel(inv.numpy().ravel(), iv.ravel()) < 1e-6
+    assert rel(y32.numpy(), y_ref) < 1e-5, rel(y32.numpy(), y_ref)
+    assert np.array_equal(yq.numpy(), R(y32.numpy()))
+    nm, ni = O.bn_running_update(rm0.astype(np.float64), ri0.astype(np.float64), mu.ravel(), iv.ravel())
+    assert rel(rm.numpy().ravel(), nm) < 1e-6 and rel(ri.numpy().ravel(), ni) < 1e-6
+    # the unfused launches (product, then the one-launch BatchNorm) land on the same values
+    co2, y2 = dev.empty(shp), dev.empty(shp)
+    ops.conv2d_fwd_lp_q(d, xq, wq, dev.tensor(b), co2, None, dtype)
+    assert np.array_equal(co2.numpy(), co.numpy())
+    m2, i2 = dev.empty((1, K, 1, 1)), dev.empty((1, K, 1, 1))
+    ops.bn_forward(co2, y2, m2, i2, dev.tensor(gamma), dev.tensor(beta), dev.alloc(ops.bn_workspace(K)), None, None, 1e-4, 0.1,
+                   'lrelu', 0.01)
+    assert rel(y32.numpy(), y2.numpy()) < 1e-6
+    # q output alone
+    yq2 = D.QTensor.empty(dev, shp, dtype)
+    ops.conv2d_bn_fwd_lp_q(d, xq, wq, dev.tensor(b), co, None, yq2, dev.tensor(gamma), dev.tensor(beta), mean, inv, None, None,
+                           1e-4, 0.1, dtype, act='lrelu', alpha=0.01)
+    assert np.array_equal(yq2.numpy(), yq.numpy())
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
