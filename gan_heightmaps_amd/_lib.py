@@ -33,6 +33,14 @@ SIGNATURES = {
     "ghm_free": [_p, _p],
     "ghm_h2d": [_p, _p, _p, C.c_size_t],
     "ghm_d2h": [_p, _p, _p, C.c_size_t],
+    "ghm_event_create": [_p, C.POINTER(_p)],
+    "ghm_event_destroy": [_p],
+    "ghm_event_record": [_p, _p],
+    "ghm_event_wait": [_p, _p],
+    "ghm_event_sync": [_p],
+    "ghm_host_alloc": [C.c_size_t, C.POINTER(_p)],
+    "ghm_host_free": [_p],
+    "ghm_h2d_async": [_p, _p, _p, C.c_size_t],
     "ghm_d2d": [_p, _p, _p, C.c_size_t],
     "ghm_memset_zero": [_p, _p, C.c_size_t],
     "ghm_sync": [_p],

@@ -183,6 +183,58 @@ int ghm_h2d(ghm_ctx* ctx, void* dst, const void* src_host, size_t bytes) {
     return 0;
 }
 
+// ---- asynchronous input path (no reference counterpart: pix2pix.py:201-212 hands train_fn pageable numpy arrays and
+// waits): page-locked host staging + a copy that does NOT synchronise, so the batch of step i+1 travels while step i runs ----
+int ghm_host_alloc(size_t bytes, void** out) {
+    GHM_HIP(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+    return 0;
+}
+
+int ghm_host_free(void* ptr) {
+    if (ptr) GHM_HIP(hipHostFree(ptr));
+    return 0;
+}
+
+int ghm_h2d_async(ghm_ctx* ctx, void* dst, const void* src_pinned, size_t bytes) {
+    // src_pinned must come from ghm_host_alloc and stay untouched until the context's stream has passed this copy
+    GHM_CHECK(!ctx->capturing && !ctx->rec, "ghm_h2d_async inside a capture / recording");
+    GHM_HIP(hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+// persistent events: a point of one context's stream that other contexts wait for LATER (ghm_stream_wait can only name
+// "everything enqueued so far").  The input pipeline needs exactly that: the stage streams of step i wait for the upload of
+// ITS batch, not for whatever the copy stream was told to do after it.
+int ghm_event_create(ghm_ctx* ctx, void** out) {
+    GHM_HIP(hipSetDevice(ctx->device));
+    hipEvent_t ev;
+    GHM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    *out = (void*)ev;
+    return 0;
+}
+
+int ghm_event_destroy(void* ev) {
+    if (ev) GHM_HIP(hipEventDestroy((hipEvent_t)ev));
+    return 0;
+}
+
+int ghm_event_record(ghm_ctx* ctx, void* ev) {
+    GHM_CHECK(!ctx->capturing && !ctx->rec, "ghm_event_record inside a capture / recording");
+    GHM_HIP(hipEventRecord((hipEvent_t)ev, ctx->stream));
+    return 0;
+}
+
+int ghm_event_wait(ghm_ctx* ctx, void* ev) {
+    GHM_CHECK(!ctx->capturing && !ctx->rec, "ghm_event_wait inside a capture / recording");
+    GHM_HIP(hipStreamWaitEvent(ctx->stream, (hipEvent_t)ev, 0));
+    return 0;
+}
+
+int ghm_event_sync(void* ev) {
+    GHM_HIP(hipEventSynchronize((hipEvent_t)ev));
+    return 0;
+}
+
 int ghm_d2h(ghm_ctx* ctx, void* dst_host, const void* src, size_t bytes) {
     GHM_CHECK(!ctx->capturing, "ghm_d2h inside graph capture");
     GHM_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));

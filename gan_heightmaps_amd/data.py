@@ -105,21 +105,37 @@ class Hdf5Iterator:
             self._bufs[name] = cur
         return cur[0]
 
-    def next_into(self, x_dst, y_dst):
-        """produce the next batch directly into two device tensors [n, C, H, W] (n = this slice's length)"""
+    def next_into(self, x_dst, y_dst, via=None, pinned=None):
+        """produce the next batch directly into two device tensors [n, C, H, W] (n = this slice's length).
+        ``via`` / ``pinned``: issue the uploads and the augmentation kernel on that context (a copy stream) from page-locked
+        staging kept in the dict ``pinned`` WITHOUT waiting for them (GanStep.produce_async: the batch of step i+1 is made
+        while step i runs); default: on the destination's own context, synchronously."""
         if self.dev is None:
             self.dev = x_dst.dev
         sl, perm, table = self.plan_next()
         n = len(perm)
+        dev = via if via is not None else None
         for name, arr, dst, gray in (("a", self.X, x_dst, self.ga), ("b", self.Y, y_dst, self.gb)):
             batch = np.ascontiguousarray(np.asarray(arr[sl])[perm])          # uint8 NHWC, permuted like flow()
             _, h, w, c = batch.shape
             assert dst.shape[1:] == (c, h, w) and dst.shape[0] >= n, (dst.shape, batch.shape)
             src = self._staging(name, batch.nbytes)
             xf = self._staging(name + "_xf", table.nbytes)
-            dst.dev.h2d(src, batch)
-            dst.dev.h2d(xf, table)
-            call("ghm_image_batch", dst.dev.h, C.c_void_p(src), n, h, w, c, C.c_void_p(xf), 0 if gray else 1,
+            d = dev if dev is not None else dst.dev
+            if dev is None:
+                d.h2d(src, batch)
+                d.h2d(xf, table)
+            else:
+                from .device import PinnedArray
+                for key, a, ptr in ((name, batch, src), (name + "_xf", np.ascontiguousarray(table), xf)):
+                    pa = pinned.get(key)
+                    if pa is None or pa.array.shape != a.shape or pa.array.dtype != a.dtype:
+                        if pa is not None:
+                            pa.close()
+                        pa = pinned[key] = PinnedArray(a.shape, a.dtype)
+                    np.copyto(pa.array, a)
+                    d.h2d_async(ptr, pa)
+            call("ghm_image_batch", d.h, C.c_void_p(src), n, h, w, c, C.c_void_p(xf), 0 if gray else 1,
                  C.c_void_p(dst.ptr), dst.nstride)
         return n
 

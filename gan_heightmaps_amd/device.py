@@ -130,6 +130,26 @@ class QTensor:
         return raw.view(np.float16).astype(np.float32)
 
 
+class PinnedArray:
+    """page-locked host memory seen as a numpy array (ghm_host_alloc): the source of asynchronous uploads"""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.shape = tuple(int(s) for s in shape)
+        dt = np.dtype(dtype)
+        n = int(np.prod(self.shape))
+        p = C.c_void_p()
+        call("ghm_host_alloc", max(n * dt.itemsize, 16), C.byref(p))
+        self.ptr = p.value
+        raw = np.ctypeslib.as_array(C.cast(C.c_void_p(self.ptr), C.POINTER(C.c_uint8)), shape=(max(n * dt.itemsize, 16),))
+        self.array = raw[:n * dt.itemsize].view(dt).reshape(self.shape)
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            call("ghm_host_free", C.c_void_p(self.ptr))
+            self.ptr = None
+
+
 class Device:
     def __init__(self, index=0):
         _lib.load()
@@ -179,6 +199,30 @@ class Device:
     def h2d(self, ptr, arr):
         arr = np.ascontiguousarray(arr)
         call("ghm_h2d", self.h, C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes)
+
+    def event_create(self):
+        e = C.c_void_p()
+        call("ghm_event_create", self.h, C.byref(e))
+        return e
+
+    def event_record(self, ev):
+        call("ghm_event_record", self.h, ev)
+
+    def event_wait(self, ev):
+        """later work on this context's stream waits for the point ``ev`` marks (on whichever stream it was recorded)"""
+        call("ghm_event_wait", self.h, ev)
+
+    @staticmethod
+    def event_sync(ev):
+        call("ghm_event_sync", ev)
+
+    @staticmethod
+    def event_destroy(ev):
+        call("ghm_event_destroy", ev)
+
+    def h2d_async(self, ptr, pinned):
+        """copy a PinnedArray to the device, ordered on this context's stream, without waiting for it"""
+        call("ghm_h2d_async", self.h, C.c_void_p(ptr), C.c_void_p(pinned.ptr), pinned.array.nbytes)
 
     def d2h(self, arr, ptr, nbytes):
         assert arr.flags['C_CONTIGUOUS']

@@ -54,7 +54,7 @@ class Pix2Pix:
                  alpha=100, opt=adam, opt_args=None,
                  train_mode='both', reconstruction='l1', sampler=np.random.rand, lsgan=False, verbose=True,
                  device=None, comm=None, use_graph=True, seed=None, two_streams=True, force_exchange=False,
-                 side_streams=None, dtype='f32', bucket_mb=None):
+                 side_streams=None, dtype='f32', bucket_mb=None, prefetch=True):
         """Two-stage DCGAN / pix2pix GAN (see the reference docstring, pix2pix.py:32-64).
         gen_fn_dcgan(latent_dim, is_a_grayscale, **gen_params_dcgan) -> output layer
         disc_fn_dcgan(in_shp, is_a_grayscale, **disc_params_dcgan) -> output layer
@@ -73,6 +73,9 @@ class Pix2Pix:
         self.in_shp = in_shp
         self.verbose = verbose
         self.train_mode = train_mode
+        # train(): with host-array iterators the batch of step i+1 is drawn and uploaded (copy stream + page-locked staging)
+        # while step i runs (GanStep.train_pipelined); False keeps the reference's strictly sequential upload -> step -> read
+        self.prefetch = bool(prefetch)
         if seed is not None:
             _init.set_rng(np.random.RandomState(seed))
         # construction order fixes the RNG draw order of the initial weights (pix2pix.py:73-77)
@@ -161,6 +164,28 @@ class Pix2Pix:
         def _loop(fn, itr, src):
             rec = [[] for _ in self.train_keys]
             on_device = hasattr(src, 'next_into')          # gan_heightmaps_amd.data.Hdf5Iterator: batch stays in HBM
+            eng = getattr(self, 'engine', None)
+            if (fn is getattr(self, 'train_fn', None) and not on_device and getattr(self, 'prefetch', False)
+                    and hasattr(eng, 'train_pipelined')):
+                # host arrays: the same draws in the same order, but batch i+1 is drawn, sampled and uploaded (copy stream,
+                # page-locked staging) while step i runs; losses bit-identical to the call-by-call form
+                def batches():
+                    for _ in range(itr.N // batch_size):
+                        X_batch, Y_batch = _next(src)
+                        yield floatX(self.sampler(X_batch.shape[0], self.latent_dim)), floatX(X_batch), floatX(Y_batch)
+                        if quick_run:
+                            break
+                for results in eng.train_pipelined(batches()):
+                    for i, r in enumerate(results):
+                        rec[i].append(r)
+                return tuple(np.mean(elem) for elem in rec)
+            if (fn is getattr(self, 'train_fn', None) and on_device and getattr(self, 'prefetch', False)
+                    and hasattr(eng, 'train_pipelined_from_iterator')):
+                steps = 1 if quick_run else itr.N // batch_size
+                for results in eng.train_pipelined_from_iterator(src, lambda n: floatX(self.sampler(n, self.latent_dim)), steps):
+                    for i, r in enumerate(results):
+                        rec[i].append(r)
+                return tuple(np.mean(elem) for elem in rec)
             for _ in range(itr.N // batch_size):
                 if on_device:
                     results = self.engine.run_from_iterator(

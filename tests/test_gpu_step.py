@@ -270,6 +270,59 @@ def test_train_loop_with_device_iterator(dev, tmp_path):
     assert rel(m2.loss_fn(Zb, Xb, Yb), m.loss_fn(Zb, Xb, Yb)) < 1e-6
 
 
+@pytest.mark.parametrize("issue", ["recorded", False])
+def test_pipelined_upload_is_bit_identical_to_the_sequential_loop(dev, tmp_path, issue):
+    """The asynchronous input pipeline (GanStep.train_pipelined: page-locked staging, a copy stream, the batch of step i+1
+    uploaded while step i runs) against the reference's strictly sequential train_fn(Z, X, Y) calls (pix2pix.py:201-212):
+    the same losses for every step bit for bit, the same parameters afterwards -- including a ragged last batch -- and the
+    whole Pix2Pix.train loop on host-array iterators writes the same results.txt with prefetch on and off."""
+    cfg = ostep.default_cfg(**SMALL)
+    batches = [ostep.synthetic_batch(n, cfg, seed=10 + i) for i, n in enumerate([4, 4, 4, 2])]
+    a = build_model(cfg, 7, dev, use_graph=issue)
+    seq = [a.train_fn(*bt) for bt in batches]
+    b = build_model(cfg, 7, dev, use_graph=issue)
+    pip = list(b.engine.train_pipelined(iter(batches)))
+    assert len(pip) == len(seq)
+    for x, y in zip(seq, pip):
+        assert np.array_equal(np.asarray(x), np.asarray(y)), (x, y)
+    pa, pb = model_params(a), model_params(b)
+    assert all(np.array_equal(u, v) for k in pa for u, v in zip(pa[k], pb[k]))
+
+    class It:                       # a host-array iterator with the reference's surface (util.py:45-62: .N, next())
+        def __init__(self):
+            self.N, self.i = 12, 0
+
+        def __next__(self):
+            _, X, Y = ostep.synthetic_batch(4, cfg, seed=100 + self.i)
+            self.i += 1
+            return X, Y
+        next = __next__
+
+    rows = []
+    for prefetch in (True, False):
+        m = build_model(cfg, 3, dev, use_graph=issue, prefetch=prefetch)
+        m.sampler = np.random.RandomState(5).rand
+        out = str(tmp_path / ("out%d" % prefetch))
+        m.train(It(), It(), batch_size=4, num_epochs=2, out_dir=out, dump_images=False)
+        rows.append([l.split(",")[:11] for l in open(out + "/results.txt").read().strip().split("\n")])
+    assert rows[0] == rows[1]
+    # the device-side iterator (uint8 rows + augmentation kernel) through the same pipeline: identical CSV rows again
+    from gan_heightmaps_amd import data as D
+    rng = np.random.RandomState(0)
+    Xu = rng.randint(0, 256, (10, 32, 32, 1)).astype(np.uint8)          # 10 samples: the last slice of a pass is ragged
+    Yu = rng.randint(0, 256, (10, 32, 32, 3)).astype(np.uint8)
+    imgen = D.ImageDataGenerator(horizontal_flip=True, vertical_flip=True, rotation_range=360, fill_mode="reflect")
+    rows = []
+    for prefetch in (True, False):
+        m = build_model(cfg, 3, dev, use_graph=issue, prefetch=prefetch)
+        m.sampler = np.random.RandomState(5).rand
+        it_t, it_v = (D.Hdf5Iterator(Xu, Yu, 4, imgen, True, False, device=dev) for _ in range(2))
+        out = str(tmp_path / ("dout%d" % prefetch))
+        m.train(it_t, it_v, batch_size=4, num_epochs=3, out_dir=out, dump_images=False)
+        rows.append([l.split(",")[:11] for l in open(out + "/results.txt").read().strip().split("\n")])
+    assert rows[0] == rows[1]
+
+
 def test_sampling_utilities_on_device(dev, tmp_path):
     """f3 (pix2pix.py:276-425): the in-HBM G -> U chain equals z_fn_det followed by gen_fn_det bit for bit, one
     batched interpolation pass equals the reference's batch-1 calls, and the frame files appear."""

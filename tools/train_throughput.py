@@ -31,5 +31,16 @@ hist = np.asarray(hist)
 assert np.isfinite(hist).all(), "non-finite loss at step %d" % int(np.argwhere(~np.isfinite(hist))[0][0])
 print("%s through the data path: %.1f img/s (%.2f ms/step, synchronous: upload -> augment -> step -> read losses)"
       % (dtype, 4 * steps / dt, 1e3 * dt / steps))
+# the product's loop (Pix2Pix.train with prefetch=True): batch i+1 is drawn, uploaded (page-locked staging, copy stream) and
+# augmented while step i runs; the five losses are still read back every step
+it2 = data.Hdf5Iterator(X, Y, 4, imgen, True, False, device=dev)
+for _ in model.engine.train_pipelined_from_iterator(it2, z, 6):
+    pass
+t0 = time.perf_counter()
+hist2 = [[float(v) for v in l] for l in model.engine.train_pipelined_from_iterator(it2, z, steps)]
+dt = time.perf_counter() - t0
+assert np.isfinite(np.asarray(hist2)).all()
+print("%s through the data path, pipelined: %.1f img/s (%.2f ms/step: batch i+1 uploaded + augmented under step i)"
+      % (dtype, 4 * steps / dt, 1e3 * dt / steps))
 print("  losses first  %s\n  losses last   %s\n  mean of last 20 %s" % (hist[0].round(4).tolist(), hist[-1].round(4).tolist(),
                                                                         hist[-20:].mean(0).round(4).tolist()))
