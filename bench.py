@@ -122,6 +122,9 @@ def parse_args(argv=None):
                          "never the headline")
     ap.add_argument("--in-shp", type=int, default=512, choices=[512, 1024],
                     help="1024 = BASELINE config 5 geometry (one more U-Net level and DCGAN stage; beyond the reference)")
+    ap.add_argument("--exchange", default=None, choices=["allreduce", "rs_ag"],
+                    help="N > 1: form of the gradient exchange (default allreduce; rs_ag = reduce-scatter, sharded optimiser "
+                         "update, all-gather of the updated parameters)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="headline only: skip the short extra loops of BASELINE configs 1-5 (\"secondary\" key)")
     ap.add_argument("--secondary-steps", type=int, default=12)
@@ -175,7 +178,7 @@ def measure(args, secondary_name=None):
     B = args.batch_per_gpu
     issue = True if args.graph else ('recorded' if args.issue == 'recorded' else False)
     backend = dict(device=dev, comm=comm, use_graph=issue, seed=0, verbose=False, two_streams=not args.one_stream,
-                   side_streams=(not args.no_grad_streams) and not args.graph, dtype=args.dtype)
+                   side_streams=(not args.no_grad_streams) and not args.graph, dtype=args.dtype, exchange_mode=args.exchange)
     S = args.in_shp
     if args.config1:
         # the geometry tests/test_gpu_step.py::test_train_step_parity[config1_dcgan64_b16] checks against the oracle
@@ -268,7 +271,8 @@ def measure(args, secondary_name=None):
         return len(e) > 2 and e[2] is not None and e[2]["kernel"].split(" splits")[0] == dominant
 
     def is_comm(e):          # data-parallel runs: every (sub-)bucket all-reduce and each stage stream's wait for them
-        return world > 1 and (e[0].startswith("allreduce_") or e[0] == "wait_comm")
+        return world > 1 and (e[0].startswith(("allreduce_", "reducescatter_", "allgather_", "rmsprop_shard_", "adam_shard_"))
+                              or e[0] == "wait_comm")
 
     slots = []          # device of every bracketed entry, in slot order
     slot_labels = []    # None = a launch of the dominant kernel, else the exchange entry's label
@@ -410,7 +414,10 @@ def measure(args, secondary_name=None):
                 per.setdefault(lab, []).append(every_ms[(id(d), i)])
         out["exchange"] = {
             "rccl_nranks": comm.nranks(), "bucket_mb": eng.bucket_bytes / 2 ** 20,
-            "collectives_per_step": len([k for k in per if k.startswith("allreduce_")]),
+            "form": eng.exchange_mode,
+            "collectives_per_step": len([k for k in per if k.startswith(("allreduce_", "reducescatter_", "allgather_"))]),
+            "sharded_update_ms_per_step": round(sum(sum(v) / len(v) for k, v in per.items() if k.startswith(("rmsprop_shard_", "adam_shard_"))), 4),
+            "allgather_ms_per_step": round(sum(sum(v) / len(v) for k, v in per.items() if k.startswith("allgather_")), 4),
             "buckets": [{"label": lab, "net": k, "MB": round(4 * n / 2 ** 20, 2),
                          "avg_ms": round(sum(per[lab]) / len(per[lab]), 4) if lab in per else None}
                         for lab, k, lo, n in b.xchg_order],

@@ -144,6 +144,8 @@ SIGNATURES = {
     "ghm_comm_count": [_p, C.POINTER(_i32)],
     "ghm_allreduce_sum": [_p, _p, _i64],
     "ghm_allreduce_max": [_p, _p, _i64],
+    "ghm_reduce_scatter_sum": [_p, _p, _i64],
+    "ghm_all_gather": [_p, _p, _i64],
     "ghm_conv2d_variant": [_D, _i32, C.c_char_p, _i32],
 }
 _SPECIAL = {"ghm_last_error": ([], C.c_char_p), "ghm_bn_workspace": ([_i32], C.c_size_t),

@@ -22,6 +22,8 @@ struct RcclApi {
     int (*CommDestroy)(rccl_comm) = nullptr;
     int (*CommCount)(rccl_comm, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, rccl_comm, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, rccl_comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 
@@ -64,6 +66,8 @@ int load_rccl() {
     RCCL_SYM(CommDestroy, "ncclCommDestroy");
     RCCL_SYM(CommCount, "ncclCommCount");
     RCCL_SYM(AllReduce, "ncclAllReduce");
+    RCCL_SYM(ReduceScatter, "ncclReduceScatter");
+    RCCL_SYM(AllGather, "ncclAllGather");
     RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef RCCL_SYM
     return 0;
@@ -147,6 +151,44 @@ int ghm_allreduce_sum(ghm_ctx* ctx, float* buf, int64_t n) {
         return 0;
     }
     GHM_RCCL(g_api.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT32, RCCL_SUM, (rccl_comm)ctx->comm, ctx->stream));
+    return 0;
+}
+
+// Sharded update (SURVEY 8e gives the all-reduce form; this is the reduce-scatter / all-gather form of the same exchange):
+// buf holds world x shard elements; after ghm_reduce_scatter_sum rank r's shard [r * shard, (r + 1) * shard) holds the sum
+// over the ranks (the other shards are unspecified), after ghm_all_gather every rank holds every rank's shard.  Both in
+// place (RCCL's in-place forms: recv = send + rank * shard / send = recv + rank * shard), both recordable in a step.
+int ghm_reduce_scatter_sum(ghm_ctx* ctx, float* buf, int64_t shard) {
+    GHM_CHECK(ctx->comm != nullptr, "ghm_reduce_scatter_sum on a context without a communicator (ghm_comm_init)");
+    rccl_comm comm = (rccl_comm)ctx->comm;
+    float* mine = buf + (size_t)ctx->rank * shard;
+    if (ctx->rec) {
+        ghm_step* st = ctx->rec;
+        hipStream_t s = ctx->stream;
+        st->cmds.emplace_back([=]() {
+            if (g_api.ReduceScatter(buf, mine, (size_t)shard, RCCL_FLOAT32, RCCL_SUM, comm, s) != 0 && st->err == hipSuccess)
+                st->err = hipErrorUnknown;
+        });
+        return 0;
+    }
+    GHM_RCCL(g_api.ReduceScatter(buf, mine, (size_t)shard, RCCL_FLOAT32, RCCL_SUM, comm, ctx->stream));
+    return 0;
+}
+
+int ghm_all_gather(ghm_ctx* ctx, float* buf, int64_t shard) {
+    GHM_CHECK(ctx->comm != nullptr, "ghm_all_gather on a context without a communicator (ghm_comm_init)");
+    rccl_comm comm = (rccl_comm)ctx->comm;
+    const float* mine = buf + (size_t)ctx->rank * shard;
+    if (ctx->rec) {
+        ghm_step* st = ctx->rec;
+        hipStream_t s = ctx->stream;
+        st->cmds.emplace_back([=]() {
+            if (g_api.AllGather(mine, buf, (size_t)shard, RCCL_FLOAT32, comm, s) != 0 && st->err == hipSuccess)
+                st->err = hipErrorUnknown;
+        });
+        return 0;
+    }
+    GHM_RCCL(g_api.AllGather(mine, buf, (size_t)shard, RCCL_FLOAT32, comm, ctx->stream));
     return 0;
 }
 

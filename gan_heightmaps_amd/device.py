@@ -786,6 +786,14 @@ class Ops:
     def allreduce_sum(self, buf, n):
         call("ghm_allreduce_sum", self.h, _vp(buf), int(n))
 
+    def reduce_scatter_sum(self, buf, shard):
+        """buf = world x shard elements: this rank's shard receives the sum over the ranks (in place)"""
+        call("ghm_reduce_scatter_sum", self.h, _vp(buf), int(shard))
+
+    def all_gather(self, buf, shard):
+        """buf = world x shard elements: every rank's shard is made whole on every rank (in place)"""
+        call("ghm_all_gather", self.h, _vp(buf), int(shard))
+
     def allreduce_max(self, buf, n):
         call("ghm_allreduce_max", self.h, _vp(buf), int(n))
 

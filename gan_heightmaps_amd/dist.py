@@ -124,9 +124,17 @@ def shard_batch(arrays, rank, world):
 class Comm:
     """RCCL communicator bound to a Device's stream."""
 
-    def __init__(self, dev, rank, world, path=None):
+    def __init__(self, dev, rank, world, path=None, channels=None):
+        """``channels=(min, max)`` (or GHM_RCCL_CHANNELS="min,max"): RCCL's channel count = the CUs its kernels occupy beside
+        the three compute streams of the step (NCCL_MIN_NCHANNELS / NCCL_MAX_NCHANNELS, read by RCCL when the communicator
+        is created) -- unmeasured on hardware, plumbed so that the first multi-GPU run can sweep it"""
         self.dev, self.rank, self.world = dev, rank, world
         self._path = path or rendezvous_path()
+        if channels is None and os.environ.get("GHM_RCCL_CHANNELS"):
+            channels = tuple(int(v) for v in os.environ["GHM_RCCL_CHANNELS"].split(","))
+        if channels is not None:
+            os.environ["NCCL_MIN_NCHANNELS"], os.environ["NCCL_MAX_NCHANNELS"] = str(int(channels[0])), str(int(channels[1]))
+        self.channels = channels
 
         def make_id():
             buf = (C.c_uint8 * 128)()

@@ -35,7 +35,9 @@ class ParamStore:
     gradients ``g`` (same layout) and non-trainable state ``s`` (BN mean / inv_std).  The flat layout
     makes the optimiser one kernel and the data-parallel exchange one all-reduce per network."""
 
-    def __init__(self, dev, params):
+    def __init__(self, dev, params, pad_to=1):
+        """``pad_to``: the flat buffers are allocated with a multiple of this many elements (the sharded data-parallel
+        update cuts them into world equal, 256-byte-aligned shards); n_train stays the number of elements in use"""
         self.dev = dev
         self.params = list(params)
         nt = ns = 0
@@ -48,8 +50,9 @@ class ParamStore:
                 p.index = ('s', ns)
                 ns += _align(n)
         self.n_train, self.n_state = nt, ns
-        self.w = dev.zeros((1, max(nt, 1), 1, 1))
-        self.g = dev.zeros((1, max(nt, 1), 1, 1))
+        self.n_pad = (max(nt, 1) + pad_to - 1) // pad_to * pad_to
+        self.w = dev.zeros((1, self.n_pad, 1, 1))
+        self.g = dev.zeros((1, self.n_pad, 1, 1))
         self.s = dev.zeros((1, max(ns, 1), 1, 1))
         self.opt_state = {}
         for p in self.params:

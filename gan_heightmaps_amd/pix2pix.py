@@ -54,7 +54,7 @@ class Pix2Pix:
                  alpha=100, opt=adam, opt_args=None,
                  train_mode='both', reconstruction='l1', sampler=np.random.rand, lsgan=False, verbose=True,
                  device=None, comm=None, use_graph=True, seed=None, two_streams=True, force_exchange=False,
-                 side_streams=None, dtype='f32', bucket_mb=None, prefetch=True):
+                 side_streams=None, dtype='f32', bucket_mb=None, prefetch=True, exchange_mode=None):
         """Two-stage DCGAN / pix2pix GAN (see the reference docstring, pix2pix.py:32-64).
         gen_fn_dcgan(latent_dim, is_a_grayscale, **gen_params_dcgan) -> output layer
         disc_fn_dcgan(in_shp, is_a_grayscale, **disc_params_dcgan) -> output layer
@@ -103,7 +103,7 @@ class Pix2Pix:
         self.engine = GanStep(self.device, dcgan_gen, dcgan_disc, p2p_gen, p2p_disc, alpha, lsgan, reconstruction,
                               spec, train_mode, comm=comm, use_graph=use_graph, two_streams=two_streams,
                               force_exchange=force_exchange, side_streams=side_streams, dtype=dtype,
-                              bucket_mb=bucket_mb)
+                              bucket_mb=bucket_mb, exchange_mode=exchange_mode)
         self.train_keys = list(TRAIN_KEYS)
         eng = self.engine
         eng.broadcast_parameters()          # replicas start from rank 0's (possibly unseeded) initial weights

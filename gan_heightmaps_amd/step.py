@@ -51,8 +51,14 @@ def _interleave(a, b):
 class GanStep:
     def __init__(self, dev, dcgan_gen, dcgan_disc, p2p_gen, p2p_disc, alpha, lsgan, reconstruction, opt_spec,
                  train_mode='both', comm=None, use_graph=True, two_streams=True, force_exchange=False,
-                 side_streams=None, dtype='f32', bucket_mb=None):
+                 side_streams=None, dtype='f32', bucket_mb=None, exchange_mode=None):
         self.dev = dev
+        # form of the data-parallel exchange: 'allreduce' (every rank sums every gradient and runs the whole
+        # optimiser) or 'rs_ag' (sharded update: a sub-bucket is reduce-SCATTERED, each rank runs RMSprop / Adam on its 1 / world
+        # slice of parameters + state, and the updated slices are all-gathered -- the same bytes on the links, 1 / world of
+        # the optimiser's 1.13 GB / step per rank)
+        self.exchange_mode = exchange_mode or os.environ.get('GHM_EXCHANGE', 'allreduce')
+        assert self.exchange_mode in ('allreduce', 'rs_ag'), self.exchange_mode
         # data-parallel exchange: a net's gradient bucket travels as sub-buckets of at least this many bytes, each
         # all-reduced as soon as the backward pass has completed it (_build: bucketer)
         self.bucket_bytes = int(float(bucket_mb if bucket_mb is not None else os.environ.get('GHM_BUCKET_MB', 32)) * 2 ** 20)
@@ -120,7 +126,13 @@ class GanStep:
         # lets a single-GPU box exercise exactly what N ranks run
         self.exchange = self.world > 1 or (force_exchange and comm is not None)
         self.use_graph = use_graph
-        self.stores = {k: ParamStore(self.devs[LANE_OF[k]], L.get_all_params(v)) for k, v in self.nets.items()}
+        self.sharded = self.exchange and self.exchange_mode == 'rs_ag'
+        if self.sharded and dtype == 'f16':
+            raise NotImplementedError("exchange_mode='rs_ag' with the fp16 dynamic loss scale: every rank would check only its "
+                                      "own gradient shard for overflow; use bf16 (no scale) or the all-reduce form")
+        self.shard_unit = 64 * self.world if self.sharded else 1       # elements: world shards of whole 256-byte lines
+        self.stores = {k: ParamStore(self.devs[LANE_OF[k]], L.get_all_params(v), pad_to=self.shard_unit)
+                       for k, v in self.nets.items()}
         # per-net optimiser state + hyper-parameter scalars [lr, t] in HBM
         self.hyper = {}
         lr = float(opt_spec.learning_rate.get_value()) if hasattr(opt_spec.learning_rate, 'get_value') \
@@ -128,7 +140,7 @@ class GanStep:
         for k, st in self.stores.items():
             d = self.devs[LANE_OF[k]]
             self.hyper[k] = d.tensor(np.array([lr, 0.0], np.float32))
-            n = max(st.n_train, 1)
+            n = st.n_pad
             if opt_spec.kind == 'rmsprop':
                 st.opt_state = {'acc': d.zeros((1, n, 1, 1))}
             elif opt_spec.kind == 'adam':
@@ -328,36 +340,50 @@ class GanStep:
             srcs = [self.devs[lane]] + ([self.side[lane][0]] if self.side[lane] is not None else [])
             tr = sorted((p for p in st.params if p.index[0] == 'w'), key=lambda p: p.index[1])
             offs = [p.index[1] for p in tr] + [st.n_train]
-            buckets, hi, pend = [], st.n_train, []
+            unit = self.shard_unit
+            buckets, hi, pend = [], (st.n_pad if self.sharded else st.n_train), []
             for i in range(len(tr) - 1, -1, -1):
                 pend.append(tr[i])
-                if 4 * (hi - offs[i]) >= self.bucket_bytes or i == 0:
-                    buckets.append({'lo': offs[i], 'hi': hi, 'pending': {id(p) for p in pend}, 'sent': False})
-                    hi, pend = offs[i], []
-            of = {pid: bk for bk in buckets for pid in bk['pending']}
+                # sharded form: a bucket starts on a multiple of world x 64 elements (world equal, line-aligned shards); the
+                # parameter that straddles the cut belongs to BOTH neighbours' pending sets (it completes last anyway)
+                lo = offs[i] // unit * unit if i else 0
+                if (4 * (hi - lo) >= self.bucket_bytes and lo < hi) or i == 0:
+                    straddle = [q for q in tr[:i] if q.index[1] + int(np.prod(q.shape)) > lo] if lo < offs[i] else []
+                    if hi > lo:
+                        buckets.append({'lo': lo, 'hi': hi, 'pending': {id(p) for p in pend + straddle}, 'sent': False})
+                    hi, pend = lo, list(straddle)
+            of = {}
+            for bk in buckets:
+                for pid in bk['pending']:
+                    of.setdefault(pid, []).append(bk)
+            b.net_buckets = getattr(b, 'net_buckets', {})
+            b.net_buckets[k] = buckets
 
             def send(bk):
                 bk['sent'] = True
                 lo, n = bk['lo'], bk['hi'] - bk['lo']
                 view = st.g.channels(lo, bk['hi'])
-                label = "allreduce_%s_%d" % (k, buckets.index(bk)) if len(buckets) > 1 else "allreduce_" + k
+                sharded = self.sharded
+                label = ("reducescatter_" if sharded else "allreduce_") + \
+                    ("%s_%d" % (k, buckets.index(bk)) if len(buckets) > 1 else k)
 
                 def fn():
                     for d in srcs:
                         cdev.wait_for(d)
-                    cops.allreduce_sum(view, n)
+                    if sharded:
+                        cops.reduce_scatter_sum(view, n // self.world)
+                    else:
+                        cops.allreduce_sum(view, n)
                 e = (label, fn, None, cdev)
                 b.xchg_order.append((label, k, lo, n))
                 (prog if embed else b.exchange_late).append(e)
 
             def on_grads(_prog, params):
                 for p in params:
-                    bk = of.get(id(p))
-                    if bk is None:
-                        continue
-                    bk['pending'].discard(id(p))
-                    if not bk['pending'] and not bk['sent']:
-                        send(bk)
+                    for bk in of.get(id(p), ()):
+                        bk['pending'].discard(id(p))
+                        if not bk['pending'] and not bk['sent']:
+                            send(bk)
 
             def flush():                # parameters no launch reported (none today): their bucket still travels
                 for bk in buckets:
@@ -411,6 +437,29 @@ class GanStep:
                     cdev.wait_for(dB)
                 cops.allreduce_sum(lo, 8)
             b.exchange.append(("allreduce_losses", reduce_losses, None, cdev))
+            if self.sharded:
+                # (the communication stream has just waited for both stage streams: every kernel that reads the pre-update
+                # weights is behind it.)  Per sub-bucket, in the order it was reduced: this rank's shard of the optimiser
+                # update, then the all-gather of the updated parameter shards.
+                gs_, hp_ = 1.0 / self.world, self.opt_spec.hp
+                for label, k, blo, n in list(b.xchg_order):
+                    st, hy, sh = self.stores[k], self.hyper[k], n // self.world
+                    a0 = blo + self.rank * sh
+                    wv, gv = st.w.channels(a0, a0 + sh), st.g.channels(a0, a0 + sh)
+                    if self.opt_spec.kind == 'rmsprop':
+                        av = st.opt_state['acc'].channels(a0, a0 + sh)
+                        b.exchange.append(("rmsprop_shard_" + label, lambda wv=wv, gv=gv, av=av, hy=hy, sh=sh: cops.rmsprop(
+                            wv, gv, av, sh, hy, hp_['rho'], hp_['epsilon'], gs_), None, cdev))
+                    else:
+                        mv, vv = st.opt_state['m'].channels(a0, a0 + sh), st.opt_state['v'].channels(a0, a0 + sh)
+                        b.exchange.append(("adam_shard_" + label, lambda wv=wv, gv=gv, mv=mv, vv=vv, hy=hy, sh=sh: cops.adam(
+                            wv, gv, mv, vv, sh, hy, hp_['beta1'], hp_['beta2'], hp_['epsilon'], gs_), None, cdev))
+                    full = st.w.channels(blo, blo + n)
+                    b.exchange.append(("allgather_" + label[len("reducescatter_"):], lambda full=full, sh=sh: cops.all_gather(full, sh),
+                                       None, cdev))
+                if self.opt_spec.kind == 'adam':
+                    for k in keys:
+                        b.exchange.append(("adam_tick_" + k, lambda hy=self.hyper[k]: cops.adam_tick(hy), None, cdev))
 
             # one entry per stage stream, so that bench.py can bracket each with HIP events: the time a stage stream
             # spends in this wait is the EXPOSED part of the exchange
@@ -428,7 +477,7 @@ class GanStep:
             for k in keys:
                 st, lane = self.stores[k], ulane(k)
                 b.update[lane].append(("grad_check_" + k, lambda st=st, o=self.ops[lane]: o.grad_check(st.g, st.n_train)))
-        for k in keys:
+        for k in ([] if self.sharded else keys):       # (sharded form: the updates ran on the communication stream, above)
             st, hy = self.stores[k], self.hyper[k]
             lane = ulane(k)
             o = self.ops[lane]

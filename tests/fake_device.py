@@ -171,6 +171,29 @@ def host_device_class():
             tdist.all_reduce(t)
             Shared.log.append((self.dev.name, "allreduce_sum", int(buf.ptr), int(n)))
 
+        def reduce_scatter_sum(self, buf, shard):
+            # gloo has no reduce-scatter: all-reduce a copy and keep this rank's shard (the other shards stay as they were,
+            # like RCCL's in-place form leaves them unspecified)
+            import torch
+            import torch.distributed as tdist
+            world, rank = tdist.get_world_size(), tdist.get_rank()
+            v = self.dev.view(buf.ptr, shard * world)
+            t = torch.from_numpy(v.copy())
+            tdist.all_reduce(t)
+            v[rank * shard:(rank + 1) * shard] = t.numpy()[rank * shard:(rank + 1) * shard]
+            Shared.log.append((self.dev.name, "reduce_scatter_sum", int(buf.ptr), int(shard * world)))
+
+        def all_gather(self, buf, shard):
+            import torch
+            import torch.distributed as tdist
+            world, rank = tdist.get_world_size(), tdist.get_rank()
+            v = self.dev.view(buf.ptr, shard * world)
+            parts = [torch.empty(shard, dtype=torch.float32) for _ in range(world)]
+            tdist.all_gather(parts, torch.from_numpy(v[rank * shard:(rank + 1) * shard].copy()))
+            for r, part in enumerate(parts):
+                v[r * shard:(r + 1) * shard] = part.numpy()
+            Shared.log.append((self.dev.name, "all_gather", int(buf.ptr), int(shard * world)))
+
         def rmsprop(self, p, g, acc, n, hyper, rho=0.9, eps=1e-6, grad_scale=1.0):
             pv, gv, av = (self.dev.view(t.ptr, n) for t in (p, g, acc))
             lr = self.dev.view(hyper.ptr, 1)[0]

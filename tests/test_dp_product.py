@@ -56,7 +56,7 @@ def _pairs(n):
     return rng.rand(n, 1, 32, 32), rng.randn(n, 3, 32, 32)
 
 
-def _worker(rank, world, port, out_dir, bucket_mb):
+def _worker(rank, world, port, out_dir, bucket_mb, exchange_mode='allreduce'):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -81,7 +81,7 @@ def _worker(rank, world, port, out_dir, bucket_mb):
     G, D, U, P = _nets(seed=7 if rank == 0 else 1000 + rank)       # unseeded replicas differ
     spec = updates.rmsprop(learning_rate=updates.shared(1e-2))
     eng = GanStep(dev, G, D, U, P, 100, True, 'l1', spec, 'both', comm=GlooComm(), use_graph=False,
-                  two_streams=True, side_streams=True, bucket_mb=bucket_mb)
+                  two_streams=True, side_streams=True, bucket_mb=bucket_mb, exchange_mode=exchange_mode)
     before = eng.replica_checksums()
     eng.broadcast_parameters()
     after = eng.replica_checksums()
@@ -93,7 +93,7 @@ def _worker(rank, world, port, out_dir, bucket_mb):
     for k in KEYS:
         st = eng.stores[k]
         v = rng.randn(st.n_train).astype(np.float32)
-        st.g.set(v)
+        st.g.set(np.concatenate([v, np.zeros(st.n_pad - st.n_train, np.float32)]))     # (n_pad > n_train in the sharded form only)
         sent[k] = v
     A, B = dist.shard_batch(list(_pairs(4 * world)), rank, world)
     pparams = L.get_all_params(P["out"], trainable=True)
@@ -117,6 +117,8 @@ def _worker(rank, world, port, out_dir, bucket_mb):
                   "sideB": eng.side[1][0].name, "comm": cdev.name},
         "pgrad_avg": [stp.download_grad(p).astype(np.float64) / world for p in pparams],
         "pvalues": pvalues, "xchg_order": list(b.xchg_order),
+        "w_range": {k: (eng.stores[k].w.ptr, eng.stores[k].n_pad) for k in KEYS},
+        "acc": {k: eng.stores[k].opt_state['acc'].numpy().ravel()[:eng.stores[k].n_train].copy() for k in KEYS},
     }
     with open(os.path.join(out_dir, "r%d.pkl" % rank), "wb") as f:
         pickle.dump(out, f)
@@ -237,3 +239,69 @@ def test_averaged_bucket_equals_the_full_batch_gradient_without_batchnorm(ranks)
     for got, want in zip(ranks[0]["pgrad_avg"], full):
         assert got.shape == want.shape
         assert np.linalg.norm(got - want) <= 2e-6 * np.linalg.norm(want) + 1e-12      # float32 buckets
+
+
+# ---- the sharded-update form of the same exchange (exchange_mode='rs_ag'): reduce-scatter per sub-bucket, this rank's
+# ---- 1 / world slice of the optimiser update on the communication stream, all-gather of the updated parameters -------
+@pytest.fixture(scope="module")
+def sharded(tmp_path_factory):
+    out = {}
+    for i, mode in enumerate(("allreduce", "rs_ag")):
+        d = tmp_path_factory.mktemp("dp_sharded_" + mode)
+        world, port = 2, 35500 + (os.getpid() % 2000) + i
+        tmp_.spawn(_worker, args=(world, port, str(d), 2048.0 / 2 ** 20, mode), nprocs=world, join=True)
+        out[mode] = [pickle.load(open(os.path.join(str(d), "r%d.pkl" % r), "rb")) for r in range(world)]
+    return out
+
+
+def test_sharded_update_equals_the_allreduce_form_and_keeps_the_replicas_identical(sharded):
+    ar, sh = sharded["allreduce"], sharded["rs_ag"]
+    for r in sh:
+        assert r["crc_end"][0] == r["crc_end"][1]                      # replicas identical after the step
+    for k in KEYS:
+        assert np.array_equal(sh[0]["w"][k], sh[1]["w"][k])
+        assert np.array_equal(sh[0]["w0"][k], ar[0]["w0"][k])          # (same seeds: the two runs start from the same weights)
+        # every element was updated exactly once, by the rank that owns its shard, with the same arithmetic
+        assert np.array_equal(sh[0]["w"][k], ar[0]["w"][k]), k
+        assert not np.array_equal(sh[0]["w"][k], sh[0]["w0"][k])
+        # the optimiser state is SHARDED: a rank's accumulator is the all-reduce form's on its own shards, untouched (zero)
+        # on the other rank's; together the two ranks hold it exactly once
+        a0, a1, full = sh[0]["acc"][k], sh[1]["acc"][k], ar[0]["acc"][k]
+        assert np.array_equal(np.where(a0 != 0, a0, a1), full)
+        assert not np.any((a0 != 0) & (a1 != 0))
+
+
+def test_sharded_collective_sequence_and_stream_discipline(sharded):
+    sh = sharded["rs_ag"]
+    seqs = [[e for e in r["log"] if e[1] in ("reduce_scatter_sum", "all_gather", "allreduce_sum")] for r in sh]
+    assert seqs[0] == seqs[1]                                          # identical on both ranks
+    r = sh[0]
+    nm = r["names"]
+    assert all(e[0] == nm["comm"] for e in seqs[0])
+    names = [e[1] for e in seqs[0]]
+    # every reduce-scatter precedes the loss all-reduce, every all-gather follows it (the updates wait for all compute)
+    i_loss = names.index("allreduce_sum")
+    assert set(names[:i_loss]) == {"reduce_scatter_sum"} and set(names[i_loss + 1:]) == {"all_gather"}
+    rs = [(e[2], e[3]) for e in seqs[0] if e[1] == "reduce_scatter_sum"]
+    ag = [(e[2], e[3]) for e in seqs[0] if e[1] == "all_gather"]
+    # one all-gather per reduce-scatter, same element ranges (of w instead of g), world equal 256-byte-aligned shards
+    for k in KEYS:
+        g0, _ = r["g_range"][k]
+        w0, n_pad = r["w_range"][k]
+        rk = sorted((p - g0, n) for p, n in rs if g0 <= p < g0 + 4 * n_pad)
+        ak = sorted((p - w0, n) for p, n in ag if w0 <= p < w0 + 4 * n_pad)
+        assert rk == ak and len(rk) >= 1
+        assert rk[0][0] == 0 and all(a[0] + 4 * a[1] == b_[0] for a, b_ in zip(rk, rk[1:])) and rk[-1][0] + 4 * rk[-1][1] == 4 * n_pad
+        assert all(n % (2 * 64) == 0 for _, n in rk)
+    # a shard update sits between its bucket's reduce-scatter and its all-gather, on the communication stream, and no stage
+    # stream runs an optimiser kernel in this form; the stage streams wait for the communication stream after the last gather
+    log = r["log"]
+    upd = [i for i, e in enumerate(log) if e[1] == "rmsprop"]
+    assert upd and all(log[i][0] == nm["comm"] for i in upd)
+    last_gather = max(i for i, e in enumerate(log) if e[1] == "all_gather")
+    for lane in (nm["A"], nm["B"]):
+        assert any(i > last_gather and e == (lane, "wait_for", nm["comm"]) for i, e in enumerate(log))
+    first_gather = min(i for i, e in enumerate(log) if e[1] == "all_gather")
+    waits = [i for i, e in enumerate(log[:first_gather]) if e[0] == nm["comm"] and e[1] == "wait_for"]
+    for lane in (nm["A"], nm["B"]):                                    # ... and the gathers wait for every reader of the old weights
+        assert any(log[i][2] == lane for i in waits)

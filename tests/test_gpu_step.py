@@ -233,6 +233,39 @@ def test_data_parallel_code_path_with_one_rank(dev, mode):
             cdev.close()
 
 
+@pytest.mark.parametrize("issue", [False, "recorded"])
+def test_sharded_update_code_path_with_one_rank(dev, issue):
+    """exchange_mode='rs_ag' on a world-1 RCCL communicator: ncclReduceScatter per sub-bucket inside the stage programs, the
+    (whole, at one rank) optimiser update and ncclAllGather on the communication stream -- the N-rank program, which at one
+    rank must reproduce the single-process step bit for bit, eager and as a recorded step (the collectives replay inside
+    ghm_step_run); tests/test_dp_product.py runs the same program with two ranks on CPU"""
+    from gan_heightmaps_amd import device, dist
+    cfg = ostep.default_cfg(**SMALL)
+    Zs = [ostep.synthetic_batch(4, cfg, seed=40 + i) for i in range(4)]
+    ref_model = build_model(cfg, 7, dev)
+    ref = [ref_model.train_fn(*b) for b in Zs]
+    ref_params = model_params(ref_model)
+    cdev = device.Device(dev.index)
+    comm = dist.Comm(cdev, 0, 1, channels=(2, 4))
+    try:
+        m = build_model(cfg, 7, dev, comm=comm, force_exchange=True, use_graph=issue, exchange_mode='rs_ag', bucket_mb=2048.0 / 2 ** 20)
+        b = m.engine.built(4)
+        assert m.engine.sharded
+        inside = [e[0] for lane in b.train_compute for e in lane if e[0].startswith("reducescatter_")]
+        after = [e[0] for e in b.exchange]
+        assert len(inside) >= 6 and not any(e[0].startswith("rmsprop") for lane in b.update for e in lane)
+        assert sum(l.startswith("allgather_") for l in after) == len(inside) == sum(l.startswith("rmsprop_shard_") for l in after)
+        got = [m.train_fn(*b_) for b_ in Zs]
+        assert np.array_equal(np.asarray(got), np.asarray(ref))
+        p = model_params(m)
+        for key in ref_params:
+            for a, b_ in zip(p[key], ref_params[key]):
+                assert np.array_equal(a, b_)
+    finally:
+        comm.close()
+        cdev.close()
+
+
 def test_allreduce_without_a_communicator_is_an_error(dev):
     """the C ABI has no identity shortcut: reducing on a context that has no communicator fails loudly
     (a step whose gradients silently stayed local would still scale them by 1/world)"""
