@@ -80,6 +80,7 @@ SIGNATURES = {
     "ghm_conv2d_dgrad_lp_q": [_p, _D, _p, _i64, _p, _p, _p, _p, _i64, _i32, _f, _i32, _i32],
     "ghm_conv2d_dgrad_dact_lp_q": [_p, _D, _p, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _f, _i32],
     "ghm_lp_variant": [_D, _i32, _i32, C.c_char_p, _i32],
+    "ghm_conv2d_bn_fwd": [_p, _D, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _f, _f, _i32, _f],
     "ghm_conv2d_bn_fwd_lp_q": [_p, _D, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _f, _f, _i32, _f, _i32],
     "ghm_bn_apply_q": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _f, _p, _i64, _i32],
     "ghm_bn_backward_q": [_p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _f, _i32,
@@ -154,6 +155,7 @@ _SPECIAL = {"ghm_last_error": ([], C.c_char_p), "ghm_bn_workspace": ([_i32], C.c
             "ghm_dgrad_dact_supported": ([_D, _i32], C.c_int),
             "ghm_lp_q_direct": ([_D, _i32, _i32], C.c_int),
             "ghm_conv_bn_fused_supported": ([_D, _i32], C.c_int),
+            "ghm_conv_bn_fused_supported_f32": ([_D], C.c_int),
             "ghm_lp_wgrad_q_supported": ([_D, _i32], C.c_int)}
 # (ghm_conv_bn_fused_supported returns its answer as the int return value: typed with the plain signatures)
 

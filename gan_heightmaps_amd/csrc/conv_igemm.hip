@@ -1764,8 +1764,15 @@ Variant pick_variant(int R, long P, int num_cu) {
     return {bm, bn};
 }
 
+// may the split-K form of this launch end in the shared finishing kernel of conv_small.hip with the BatchNorm inside it?
+// (forward convolution on its own output grid, whole map of a channel <= 1024 pixels, rows in whole q-unit groups)
+static bool igemm_bn_geometry(const IgemmArgs& a) {
+    const long P = (long)a.N * a.Hs * a.Ws;
+    return a.os == 1 && a.Hs == a.Hout && a.Ws == a.Wout && a.R % 8 == 0 && a.R > 4 && P <= 1024 && P > 0;
+}
+
 template <bool WT>
-int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
+int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in, const SmBn* bn = nullptr) {
     IgemmArgs a = a_in;
     const long P = (long)a.N * a.Hs * a.Ws;
     if (P == 0 || a.R == 0) return 0;
@@ -1835,6 +1842,10 @@ int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
         if (splits > max_by_work) splits = max_by_work;
     }
     if (const char* f = GHM_OPT("GHM_FORCE_SPLITK")) splits = atoi(f) < nslabs ? atoi(f) : nslabs;
+    if (bn) {           // the BatchNorm epilogue lives in the finishing kernel: at least two slices
+        GHM_CHECK(igemm_bn_geometry(a) && nslabs >= 2, "igemm: BatchNorm epilogue not served for this geometry");
+        if (splits < 2) splits = 2;
+    }
     if (splits > 1) {
         a.slabs_per_split = ceil_div(nslabs, splits);
         splits = ceil_div(nslabs, a.slabs_per_split);
@@ -1842,7 +1853,7 @@ int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
         if (int e = ghm_scratch(ctx, (size_t)splits * a.R * P * sizeof(float), &ws)) return e;
         a.partial = (float*)ws;
         a.nsplit = splits;
-        a.tickets = ghm_tickets(ctx, grid);
+        a.tickets = bn ? nullptr : ghm_tickets(ctx, grid);
     }
     const bool folded = a.tickets != nullptr;
     const dim3 g(grid, splits);
@@ -1853,6 +1864,9 @@ int launch_igemm(ghm_ctx* ctx, const IgemmArgs& a_in) {
         else                                                                                           \
             hipLaunchKernelGGL((igemm_kernel<BM_, BN_, WM_, WN_, WT, false>), g, dim3(256), 0, ctx->stream, a); \
         GHM_LAUNCH_CHECK();                                                                            \
+        if (bn)         /* sum of the slices + bias, batch statistics, normalise, activation: ONE launch */ \
+            return sm_finish_launch(ctx, a.partial, splits, a.R, a.N, a.Hs * a.Ws, a.bias, a.out, a.out_nstride, 0, a.act,  \
+                                    a.alpha, nullptr, 0, GHM_DTYPE_BF16, bn);                          \
         if (splits > 1 && !folded) {                                                                   \
             hipLaunchKernelGGL(igemm_splitk_epilogue, dim3(ceil_div(P * a.R, 256)), dim3(256), 0, ctx->stream, a, \
                                splits);                                                                \
@@ -2130,6 +2144,24 @@ int ghm_reduce_splits(ghm_ctx* ctx, const float* part, int S, long n, long split
 
 extern "C" {
 
+static IgemmArgs igemm_fwd_args(const ghm_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act,
+                                float alpha, int accumulate) {
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = x; a.wp = wp; a.bias = bias; a.out = y;
+    a.N = d->N; a.CH = d->C; a.Hin = d->H; a.Win = d->W; a.in_nstride = d->x_nstride;
+    a.R = d->K; a.Hout = d->Ho; a.Wout = d->Wo; a.out_nstride = d->y_nstride;
+    a.Hs = d->Ho; a.Ws = d->Wo; a.os = 1; a.ou = 0; a.ov = 0; a.ss = d->stride;
+    a.T = d->kh * d->kw; a.ntaps = a.T;
+    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
+    for (int ta = 0; ta < d->kh; ++ta)
+        for (int tb = 0; tb < d->kw; ++tb) {
+            const int t = ta * d->kw + tb;
+            a.di[t] = ta - d->pad; a.dj[t] = tb - d->pad; a.wi[t] = t;
+        }
+    return a;
+}
+
 int ghm_conv2d_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias,
                    float* y, int32_t act, float alpha, int32_t accumulate) {
     if (int e = check_desc(d)) return e;
@@ -2170,20 +2202,40 @@ int ghm_conv2d_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const f
             return launch_patch(ctx, pl, pa, d->kh, d->stride);
         }
     }
-    IgemmArgs a;
-    memset(&a, 0, sizeof(a));
-    a.in = x; a.wp = wp; a.bias = bias; a.out = y;
-    a.N = d->N; a.CH = d->C; a.Hin = d->H; a.Win = d->W; a.in_nstride = d->x_nstride;
-    a.R = d->K; a.Hout = d->Ho; a.Wout = d->Wo; a.out_nstride = d->y_nstride;
-    a.Hs = d->Ho; a.Ws = d->Wo; a.os = 1; a.ou = 0; a.ov = 0; a.ss = d->stride;
-    a.T = d->kh * d->kw; a.ntaps = a.T;
-    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
-    for (int ta = 0; ta < d->kh; ++ta)
-        for (int tb = 0; tb < d->kw; ++tb) {
-            const int t = ta * d->kw + tb;
-            a.di[t] = ta - d->pad; a.dj[t] = tb - d->pad; a.wi[t] = t;
-        }
+    const IgemmArgs a = igemm_fwd_args(d, x, wp, bias, y, act, alpha, accumulate);
     return launch_igemm<false>(ctx, a);
+}
+
+// which forward convolutions run on the generic gather kernel (none of the thin / taps-as-rows / LDS-patch forms above)
+static bool igemm_fwd_generic(const ghm_conv_desc* d, int act) {
+    if (d->C <= 4 && thin_fanout_fwd_ok(d, act)) return false;
+    if (d->K <= 4 && thin_fanin_s1_fwd_ok(d)) return false;
+    if (taps_as_rows(d, d->K)) return false;
+    if (d->kh == d->kw && ((d->stride == 1 && d->Ho == d->H && d->Wo == d->W) ||
+                           (d->stride == 2 && d->Ho * 2 == d->H && d->Wo * 2 == d->W)) &&
+        plan_patch(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, ghm_plan_cus(), d->stride).ok)
+        return false;
+    return d->kh * d->kw <= MAX_TAPS;
+}
+
+// fp32 Conv2DLayer -> BatchNormLayer -> nonlinearity as ONE product on small maps (the fp32 counterpart of
+// ghm_conv2d_bn_fwd_lp_q): the generic gather kernel in split-K form, ending in the finishing kernel of conv_small.hip
+int ghm_conv_bn_fused_supported_f32(const ghm_conv_desc* d) {
+    if (GHM_OPT("GHM_NO_CONV_BN_F32") || d->kh * d->kw > MAX_TAPS || (d->stride != 1 && d->stride != 2)) return 0;
+    if (!igemm_fwd_generic(d, GHM_ACT_LINEAR)) return 0;
+    const IgemmArgs a = igemm_fwd_args(d, nullptr, nullptr, nullptr, nullptr, GHM_ACT_LINEAR, 0.f, 0);
+    return igemm_bn_geometry(a) && ceil_div((long)a.ntaps * a.CH, 16) >= 2 ? 1 : 0;
+}
+
+int ghm_conv2d_bn_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias, float* conv_out,
+                      float* y, int64_t y_nstride, const float* gamma, const float* beta, float* mean, float* inv,
+                      float* run_mean, float* run_inv, float eps, float run_alpha, int32_t act, float alpha) {
+    if (int e = check_desc(d)) return e;
+    GHM_CHECK(ghm_conv_bn_fused_supported_f32(d), "ghm_conv2d_bn_fwd: geometry not served (ask ghm_conv_bn_fused_supported_f32)");
+    GHM_CHECK(conv_out != nullptr && y != nullptr, "ghm_conv2d_bn_fwd: conv_out and y are required");
+    const IgemmArgs a = igemm_fwd_args(d, x, wp, bias, conv_out, act, alpha, 0);
+    const SmBn bn{gamma, beta, mean, inv, run_mean, run_inv, eps, run_alpha, y, (long)y_nstride};
+    return launch_igemm<false>(ctx, a, &bn);
 }
 
 struct DactArg {

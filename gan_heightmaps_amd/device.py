@@ -514,7 +514,16 @@ class Ops:
         return out.value.decode()
 
     def conv_bn_fused_supported(self, d, dtype):
+        if dtype == 'f32':
+            return bool(_lib.load().ghm_conv_bn_fused_supported_f32(C.byref(d)))
         return bool(_lib.load().ghm_conv_bn_fused_supported(C.byref(d), DTYPE_CODES[dtype]))
+
+    def conv2d_bn_fwd(self, d, x, wp, bias, conv_out, y, gamma, beta, mean, inv, run_mean, run_inv, eps, run_alpha,
+                      act='linear', alpha=0.0):
+        """fp32: y = act(bn(conv(x) + bias)) with batch statistics; conv_out keeps conv(x) + bias for the backward"""
+        assert conv_out.nstride == d.y_nstride
+        call("ghm_conv2d_bn_fwd", self.h, C.byref(d), _vp(x), _vp(wp), _vp(bias), _vp(conv_out), _vp(y), y.nstride, _vp(gamma),
+             _vp(beta), _vp(mean), _vp(inv), _vp(run_mean), _vp(run_inv), eps, run_alpha, ACT_CODES[act], alpha)
 
     def conv2d_bn_fwd_lp_q(self, d, xq, wq, bias, conv_out, y, yq, gamma, beta, mean, inv, run_mean, run_inv, eps, run_alpha,
                            dtype, act='linear', alpha=0.0):

@@ -585,15 +585,20 @@ class NetPlan:
 
     def _conv_bn_fusable(self, n, d, xq, deterministic):
         """-> the BatchNorm node behind convolution n when the pair runs as one product (ghm_conv2d_bn_fwd_lp_q), else None"""
-        if (n.op != 'conv' or xq is None or deterministic or self.bn_groups != 1 or n.act != linear or len(n.consumers) != 1
+        if (n.op != 'conv' or deterministic or self.bn_groups != 1 or n.act != linear or len(n.consumers) != 1
                 or os.environ.get("GHM_NO_CONV_BN_FUSE") is not None or not hasattr(self.ops, 'conv_bn_fused_supported')):
             return None
         bnn = n.consumers[0]
         if bnn.op != 'bn' or self._bn_hi(bnn) or n.out.nstride != d.y_nstride:
             return None
-        if not (self._lp(d, 0) and self.ops.conv_bn_fused_supported(d, self.dtype)):
+        if self._lp(d, 0):
+            return bnn if (xq is not None and self.ops.conv_bn_fused_supported(d, self.dtype)) else None
+        # fp32 product (ghm_conv2d_bn_fwd: the generic gather kernel in split-K form + the same finishing kernel).  Built,
+        # parity-tested, and NOT the default: in the fp32 step it measured 169.4 img/s against 171.5 for the split-K
+        # epilogue + one-launch BatchNorm it replaces (two runs each, same box) -- GHM_CONV_BN_F32=1 turns it on
+        if os.environ.get("GHM_CONV_BN_F32") is None:
             return None
-        return bnn
+        return bnn if (bnn.outq is None and self.ops.conv_bn_fused_supported(d, 'f32')) else None
 
     def _bn_hi(self, n):
         """is n the BatchNorm of a collapsed up-sample convolution whose only reader is the parity interleave?  Then the
@@ -670,11 +675,17 @@ class NetPlan:
                 if bnn is not None:
                     # small maps: Conv2DLayer -> BatchNormLayer (-> nonlinearity) as ONE product -- the finishing kernel of
                     # the convolution holds the whole map of its channels (csrc/conv_small.hip)
-                    wq = self._lp_pack_entry(prog, d, w, ('w', id(n.layer.W)), False, lp_done)
                     lb = bnn.layer
                     fused_bn.add(id(bnn))
                     y32 = bnn.out if (bnn.outq is None or self._fp32_needed(bnn)) else None
                     rm, ri = (st.value(lb.mean), st.value(lb.inv_std)) if update_running else (None, None)
+                    if not self._lp(d, 0):
+                        prog.append(("conv_bn_fwd", lambda d=d, x=x, w=w, b=b, co=y, y32=bnn.out, lb=lb, rm=rm, ri=ri,
+                                     m=bnn.aux['mean'], iv=bnn.aux['inv'], ba=bnn.act:
+                                     ops.conv2d_bn_fwd(d, x, w, b, co, y32, st.value(lb.gamma), st.value(lb.beta), m, iv, rm, ri,
+                                                       lb.epsilon, lb.alpha, ba.kind, ba.alpha), conv_meta(ops, d, 0)))
+                        continue
+                    wq = self._lp_pack_entry(prog, d, w, ('w', id(n.layer.W)), False, lp_done)
                     prog.append(("conv_bn_fwd", lambda d=d, xq=xq, wq=wq, b=b, co=y, y32=y32, yq=bnn.outq, lb=lb, rm=rm, ri=ri,
                                  m=bnn.aux['mean'], iv=bnn.aux['inv'], ba=bnn.act:
                                  ops.conv2d_bn_fwd_lp_q(d, xq, wq, b, co, y32, yq, st.value(lb.gamma), st.value(lb.beta), m, iv,

@@ -932,3 +932,41 @@ def test_weight_gradient_split_ranges_cross_strips_and_images(gpu, case, splits)
         assert rel(D.unpack_conv_w(dwd.numpy().ravel(), K, C, k, k), dW_ref) < TOL
         ops.conv2d_wgrad(d, xd, dyd, dwd, ws, accumulate=True)
         assert rel(D.unpack_conv_w(dwd.numpy().ravel(), K, C, k, k), 2 * dW_ref) < TOL
+
+
+@pytest.mark.parametrize("case", [(4, 64, 16, 16, 64, 3, 1, 1), (4, 32, 32, 32, 96, 3, 2, 1), (3, 48, 8, 8, 64, 3, 2, 1),
+                                  (4, 32, 2, 2, 64, 2, 1, 0), (2, 16, 4, 4, 32, 5, 1, 2), (4, 24, 4, 4, 40, 3, 1, 1)])
+def test_fp32_convolution_with_the_batchnorm_in_its_finishing_kernel(gpu, case):
+    """ghm_conv2d_bn_fwd: fp32 Conv2DLayer -> BatchNormLayer -> nonlinearity on small maps as ONE product (the generic
+    gather kernel in split-K form + the finishing kernel that holds the whole map of its channels): conv output, batch
+    statistics, running update and y against the float64 oracle; equal to conv + ghm_bn_forward."""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(3)
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    gamma, beta = (1 + 0.2 * rng.randn(K)).astype(np.float32), (0.3 * rng.randn(K)).astype(np.float32)
+    rm0, ri0 = rng.randn(K).astype(np.float32), (1 + 0.1 * rng.rand(K)).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    assert ops.conv_bn_fused_supported(d, 'f32')
+    wp = dev.tensor(D.pack_conv_w(Wt).ravel())
+    shp = (N, K, d.Ho, d.Wo)
+    co, y = dev.empty(shp), dev.empty(shp)
+    mean, inv = dev.empty((1, K, 1, 1)), dev.empty((1, K, 1, 1))
+    rm, ri = dev.tensor(rm0), dev.tensor(ri0)
+    ops.conv2d_bn_fwd(d, dev.tensor(x), wp, dev.tensor(b), co, y, dev.tensor(gamma), dev.tensor(beta), mean, inv, rm, ri,
+                      1e-4, 0.1, 'lrelu', 0.01)
+    c64 = O.conv2d_fwd(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), s, pad)
+    assert rel(co.numpy(), c64) < 1e-5
+    yb, mu, iv = O.bn_train_fwd(co.numpy().astype(np.float64), beta.astype(np.float64), gamma.astype(np.float64))
+    assert rel(mean.numpy().ravel(), mu.ravel()) < 1e-6 and rel(inv.numpy().ravel(), iv.ravel()) < 1e-6
+    assert rel(y.numpy(), O.lrelu_fwd(yb, 0.01)) < 1e-5
+    nm, ni = O.bn_running_update(rm0.astype(np.float64), ri0.astype(np.float64), mu.ravel(), iv.ravel())
+    assert rel(rm.numpy().ravel(), nm) < 1e-6 and rel(ri.numpy().ravel(), ni) < 1e-6
+    co2, y2 = dev.empty(shp), dev.empty(shp)
+    ops.conv2d_fwd(d, dev.tensor(x), wp, dev.tensor(b), co2, 'linear', 0.0)
+    m2, i2 = dev.empty((1, K, 1, 1)), dev.empty((1, K, 1, 1))
+    ops.bn_forward(co2, y2, m2, i2, dev.tensor(gamma), dev.tensor(beta), dev.alloc(ops.bn_workspace(K)), None, None, 1e-4, 0.1,
+                   'lrelu', 0.01)
+    assert rel(co.numpy(), co2.numpy()) < 1e-6 and rel(y.numpy(), y2.numpy()) < 2e-6
