@@ -38,6 +38,7 @@ SIGNATURES = {
     "ghm_event_record": [_p, _p],
     "ghm_event_wait": [_p, _p],
     "ghm_event_sync": [_p],
+    "ghm_queue_interference": [_p, _p, _p, _i32, C.POINTER(_f)],
     "ghm_host_alloc": [C.c_size_t, C.POINTER(_p)],
     "ghm_host_free": [_p],
     "ghm_h2d_async": [_p, _p, _p, C.c_size_t],

@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <chrono>
+
 #include "common.h"
 
 static thread_local char g_err[1024] = "";
@@ -232,6 +234,48 @@ int ghm_event_wait(ghm_ctx* ctx, void* ev) {
 
 int ghm_event_sync(void* ev) {
     GHM_HIP(hipEventSynchronize((hipEvent_t)ev));
+    return 0;
+}
+
+// ---- hardware-queue probe ----
+// ROCm multiplexes HIP streams onto a few hardware queues, and a stream that is blocked (or busy copying) stalls every
+// stream that shares its queue.  ghm_queue_interference(a, b, probe) measures it: a long spin kernel runs on ``probe``,
+// ``a`` is made to wait for it (hipStreamWaitEvent: a is now blocked for the spin's length), and a trivial kernel is timed
+// on ``b``: *delay_us is how long b's kernel waited -- a few microseconds on its own queue, the spin's length on a's.
+namespace {
+__global__ void spin_kernel(long ticks) {           // wall_clock64(): the constant 100 MHz counter (10 ns per tick)
+    const long t0 = (long)wall_clock64();
+    long t = t0;
+    for (int i = 0; i < (1 << 20) && t - t0 < ticks; ++i) {      // (bounded: can never hang the GPU)
+        __builtin_amdgcn_s_sleep(64);
+        t = (long)wall_clock64();
+    }
+}
+__global__ void nop_kernel() {}
+}  // namespace
+
+int ghm_queue_interference(ghm_ctx* a, ghm_ctx* b, ghm_ctx* probe, int32_t spin_us, float* delay_us) {
+    GHM_CHECK(a->device == b->device && a->device == probe->device, "ghm_queue_interference: one device");
+    GHM_CHECK(!a->rec && !b->rec && !probe->rec && !a->capturing && !b->capturing, "ghm_queue_interference inside a recording");
+    GHM_HIP(hipSetDevice(a->device));
+    GHM_HIP(hipStreamSynchronize(a->stream));
+    GHM_HIP(hipStreamSynchronize(b->stream));
+    GHM_HIP(hipStreamSynchronize(probe->stream));
+    hipEvent_t gate;
+    GHM_HIP(hipEventCreateWithFlags(&gate, hipEventDisableTiming));
+    // (the shader clock paces the spin: ~2.4 GHz when busy, lower from idle -- the spin is then LONGER than asked for,
+    // which only sharpens the measurement)
+    spin_kernel<<<1, 64, 0, probe->stream>>>((long)spin_us * 100L);
+    GHM_HIP(hipEventRecord(gate, probe->stream));
+    GHM_HIP(hipStreamWaitEvent(a->stream, gate, 0));         // a sits in this wait until the spin ends
+    const auto h0 = std::chrono::steady_clock::now();
+    nop_kernel<<<1, 64, 0, b->stream>>>();
+    GHM_HIP(hipStreamSynchronize(b->stream));                // returns at once on b's own queue, after the spin on a's
+    const auto h1 = std::chrono::steady_clock::now();
+    GHM_HIP(hipStreamSynchronize(a->stream));
+    GHM_HIP(hipStreamSynchronize(probe->stream));
+    *delay_us = std::chrono::duration<float, std::micro>(h1 - h0).count();
+    (void)hipEventDestroy(gate);
     return 0;
 }
 

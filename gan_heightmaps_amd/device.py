@@ -200,6 +200,13 @@ class Device:
         arr = np.ascontiguousarray(arr)
         call("ghm_h2d", self.h, C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes)
 
+    def queue_interference(self, other, probe, spin_us=1500):
+        """microseconds a trivial kernel on ``other`` needs to finish while THIS context's stream sits in a wait for a
+        ~spin_us spin kernel on ``probe``: ~spin_us if the two streams share a hardware queue, a few microseconds if not"""
+        us = C.c_float()
+        call("ghm_queue_interference", self.h, other.h, probe.h, int(spin_us), C.byref(us))
+        return us.value
+
     def event_create(self):
         e = C.c_void_p()
         call("ghm_event_create", self.h, C.byref(e))

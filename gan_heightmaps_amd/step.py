@@ -532,8 +532,31 @@ class GanStep:
     def _pipe(self):
         if not hasattr(self, '_pipe_state'):
             mk = type(self.devs[0])
-            cp = mk(self.devs[0].index)
-            self._pipe_state = {'dev': cp, 'slots': {}}
+            # the copy stream must not share a HARDWARE queue with a compute stream (a 16 MB upload in flight on a shared queue
+            # holds that stream's kernels back for its whole duration: bf16 611 instead of 638 img/s on the boxes where ROCm
+            # happened to map them together): probe candidates, keep the first one every compute stream is free of
+            compute = [d for d in self._all_devs() if d is not None]
+            cp, rejects, report = None, [], []
+            if hasattr(mk, 'queue_interference') and os.environ.get("GHM_NO_QUEUE_PROBE") is None:
+                self.sync()
+                probe = mk(self.devs[0].index)
+                for _ in range(6):
+                    cand = mk(self.devs[0].index)
+                    worst = max(max(cand.queue_interference(d, probe), d.queue_interference(cand, probe)) for d in compute)
+                    report.append(round(worst, 1))
+                    if worst < 300.0:               # (the spin is 1500 us; an unshared queue answers in tens of microseconds)
+                        cp = cand
+                        break
+                    rejects.append(cand)
+                for r in rejects[1:] + [probe]:
+                    r.close()
+                if cp is None:                      # every candidate shares a queue with somebody: take the first
+                    cp = rejects[0]
+                elif rejects:
+                    rejects[0].close()
+            else:
+                cp = mk(self.devs[0].index)
+            self._pipe_state = {'dev': cp, 'slots': {}, 'queue_probe_us': report}
         return self._pipe_state
 
     def _pipe_slot(self, b):
