@@ -27,6 +27,7 @@ SIGNATURES = {
     "ghm_options_reload": [],
     "ghm_device_count": [C.POINTER(_i32)],
     "ghm_ctx_create": [_i32, C.POINTER(_p)],
+    "ghm_ctx_create_prio": [_i32, _i32, C.POINTER(_p)],
     "ghm_ctx_destroy": [_p],
     "ghm_device_info": [_p, C.c_char_p, _i32, C.POINTER(_i32), C.POINTER(_i64)],
     "ghm_alloc": [_p, C.c_size_t, C.POINTER(_p)],

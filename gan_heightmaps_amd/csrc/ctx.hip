@@ -93,17 +93,26 @@ int ghm_device_count(int32_t* n) {
     return 0;
 }
 
-int ghm_ctx_create(int32_t device, ghm_ctx** out) {
+static int ctx_create_impl(int32_t device, int prio_arg, bool prio_given, ghm_ctx** out);
+
+int ghm_ctx_create(int32_t device, ghm_ctx** out) { return ctx_create_impl(device, 0, false, out); }
+
+// a context whose stream has the given HIP priority (negative = more urgent, clamped to the device's range)
+int ghm_ctx_create_prio(int32_t device, int32_t priority, ghm_ctx** out) { return ctx_create_impl(device, priority, true, out); }
+
+}  // extern "C"
+
+static int ctx_create_impl(int32_t device, int prio_arg, bool prio_given, ghm_ctx** out) {
     GHM_HIP(hipSetDevice(device));
     ghm_ctx* c = new ghm_ctx();
     c->device = device;
     // tuning: GHM_STREAM_PRIO = comma-separated HIP stream priorities by order of context creation (lower = more urgent)
-    int prio = 0;
+    int prio = prio_arg;
     static int created = 0;
     if (const char* f = getenv("GHM_STREAM_PRIO")) {
         const char* p = f;
         for (int i = 0; i < created && p; ++i) { p = strchr(p, ','); if (p) ++p; }
-        if (p) prio = atoi(p);
+        if (p && !prio_given) prio = atoi(p);
     }
     ++created;
     if (prio != 0) {
@@ -126,6 +135,8 @@ int ghm_ctx_create(int32_t device, ghm_ctx** out) {
     *out = c;
     return 0;
 }
+
+extern "C" {
 
 int ghm_ctx_destroy(ghm_ctx* ctx) {
     if (!ctx) return 0;

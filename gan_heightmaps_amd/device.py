@@ -160,6 +160,16 @@ class Device:
         self._allocs = {}
         self.bytes_allocated = 0
 
+    @classmethod
+    def with_priority(cls, index, priority):
+        """a context whose stream has the given HIP priority (negative = more urgent)"""
+        self = cls.__new__(cls)
+        _lib.load()
+        h = C.c_void_p()
+        call("ghm_ctx_create_prio", int(index), int(priority), C.byref(h))
+        self.h, self.index, self._allocs, self.bytes_allocated = h, index, {}, 0
+        return self
+
     # ---- memory ----
     def alloc(self, nbytes):
         p = C.c_void_p()
