@@ -37,6 +37,16 @@ int* ghm_tickets(ghm_ctx* ctx, long tiles) {
     return ctx->tickets;
 }
 
+// flags of the events that order one stream of the GPU behind another: every consumer is a kernel on the SAME device, so a
+// device-scope release is enough (hipEventReleaseToDevice); HIP's default is a system-scope release (visible to the host),
+// i.e. a heavier cache write-back at every one of the ~100 cross-stream dependencies of a step.  GHM_EVENT_SYSTEM_SCOPE=1
+// restores the default for A/B.
+static unsigned ghm_event_flags() {
+    static int sys_ = -1;
+    if (sys_ < 0) sys_ = getenv("GHM_EVENT_SYSTEM_SCOPE") ? 1 : 0;
+    return hipEventDisableTiming | (sys_ ? 0u : (unsigned)hipEventReleaseToDevice);
+}
+
 static int g_plan_cus = 256;
 int ghm_plan_cus() { return g_plan_cus; }
 
@@ -221,7 +231,7 @@ int ghm_h2d_async(ghm_ctx* ctx, void* dst, const void* src_pinned, size_t bytes)
 int ghm_event_create(ghm_ctx* ctx, void** out) {
     GHM_HIP(hipSetDevice(ctx->device));
     hipEvent_t ev;
-    GHM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    GHM_HIP(hipEventCreateWithFlags(&ev, ghm_event_flags()));
     *out = (void*)ev;
     return 0;
 }
@@ -339,7 +349,7 @@ int ghm_stream_wait(ghm_ctx* ctx, ghm_ctx* other) {
         hipStream_t mine = ctx->stream, theirs = other->stream;
         st->cmds.emplace_back([=]() {
             hipEvent_t ev;
-            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            hipError_t e = hipEventCreateWithFlags(&ev, ghm_event_flags());
             if (e == hipSuccess) e = hipEventRecord(ev, theirs);
             if (e == hipSuccess) e = hipStreamWaitEvent(mine, ev, 0);
             if (e == hipSuccess) e = hipEventDestroy(ev);
@@ -348,7 +358,7 @@ int ghm_stream_wait(ghm_ctx* ctx, ghm_ctx* other) {
         return 0;
     }
     hipEvent_t ev;
-    GHM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    GHM_HIP(hipEventCreateWithFlags(&ev, ghm_event_flags()));
     GHM_HIP(hipEventRecord(ev, other->stream));
     GHM_HIP(hipStreamWaitEvent(ctx->stream, ev, 0));
     GHM_HIP(hipEventDestroy(ev));       // destruction is deferred by the runtime until the event has fired
