@@ -194,6 +194,16 @@ int ghm_all_gather(ghm_ctx* ctx, float* buf, int64_t shard) {
 
 int ghm_allreduce_max(ghm_ctx* ctx, float* buf, int64_t n) {
     GHM_CHECK(ctx->comm != nullptr, "ghm_allreduce_max on a context without a communicator (ghm_comm_init)");
+    if (ctx->rec) {         // recordable like the sum (a fp16 overflow flag agreed on by every rank of the sharded update)
+        ghm_step* st = ctx->rec;
+        rccl_comm comm = (rccl_comm)ctx->comm;
+        hipStream_t s = ctx->stream;
+        st->cmds.emplace_back([=]() {
+            if (g_api.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT32, RCCL_MAX, comm, s) != 0 && st->err == hipSuccess)
+                st->err = hipErrorUnknown;
+        });
+        return 0;
+    }
     GHM_RCCL(g_api.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT32, RCCL_MAX, (rccl_comm)ctx->comm, ctx->stream));
     return 0;
 }

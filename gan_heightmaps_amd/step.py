@@ -563,8 +563,9 @@ class GanStep:
         pipe = self._pipe()
         if id(b) not in pipe['slots']:
             from .device import PinnedArray
+            mkpin = getattr(type(self.devs[0]), 'pinned_array', PinnedArray)       # (host-memory test devices bring their own)
             assert b.z.contiguous and b.x.contiguous and b.y.contiguous
-            pipe['slots'][id(b)] = {'host': {k: PinnedArray(t.shape) for k, t in (('z', b.z), ('x', b.x), ('y', b.y))},
+            pipe['slots'][id(b)] = {'host': {k: mkpin(t.shape) for k, t in (('z', b.z), ('x', b.x), ('y', b.y))},
                                     'landed': pipe['dev'].event_create(), 'uploads': 0,
                                     'done': [(d, d.event_create()) for d in self._all_devs()], 'used': False}
         return pipe['slots'][id(b)]

@@ -59,6 +59,44 @@ class FakeDevice:
     def wait_for(self, other):
         pass
 
+    # ---- the asynchronous input pipeline's device surface: events and uploads are logged, nothing is asynchronous ----
+    class pinned_array:
+        def __init__(self, shape, dtype=np.float32):
+            self.shape, self.array, self.ptr = tuple(shape), np.zeros(shape, dtype), 1
+
+        def close(self):
+            self.array = None
+
+    def event_create(self):
+        self._nev = getattr(self, '_nev', 0) + 1
+        return ("ev", id(self), self._nev)
+
+    def event_record(self, ev):
+        FakeDevice.pipe_log.append(("record", ev[2], self.name()))
+
+    def event_wait(self, ev):
+        FakeDevice.pipe_log.append(("wait", ev[2], self.name()))
+
+    @staticmethod
+    def event_sync(ev):
+        FakeDevice.pipe_log.append(("host_sync", ev[2]))
+
+    @staticmethod
+    def event_destroy(ev):
+        pass
+
+    def h2d_async(self, ptr, pinned):
+        FakeDevice.pipe_log.append(("h2d_async", int(ptr), float(np.asarray(pinned.array).ravel()[0]), self.name()))
+
+    def name(self):
+        return "dev%x" % (id(self) & 0xffff)
+
+    def close(self):
+        pass
+
+
+FakeDevice.pipe_log = []
+
 
 class RecordingOps:
     def __init__(self, dev):

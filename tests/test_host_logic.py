@@ -137,6 +137,59 @@ def test_gan_step_program_structure_on_fake_device():
     assert d_wgrads == n_convs
 
 
+def test_input_pipeline_protocol_on_fake_device():
+    """GanStep.train_pipelined without a GPU: consecutive steps alternate between two plans, the upload of batch i+1 is
+    issued after step i was enqueued and before its losses are read, a plan's inputs are overwritten only after a host-side
+    wait for the step that last used it, the stage stream waits for the event behind ITS batch's upload, and a page-locked set
+    is reused only after its upload has passed.  (Bit-identity with the sequential loop is the GPU test
+    test_pipelined_upload_is_bit_identical_to_the_sequential_loop.)"""
+    dev = FakeDevice()
+    G = dcgan.default_generator(24, True, nch=16, div=[2, 2, 4])
+    Dn = dcgan.default_discriminator(32, True, nch=16, div=[4, 2, 2], nonlinearity=linear)
+    U = p2p.g_unet(32, True, False, nf=4, act=tanh, bilinear_upsample=True)
+    P = p2p.discriminator(32, True, False, nf=4, act=linear, mul_factor=[1, 2])
+    spec = updates.rmsprop(learning_rate=updates.shared(1e-4))
+    import gan_heightmaps_amd.step as step_mod
+    orig = step_mod.Ops
+    step_mod.Ops = RecordingOps
+    try:
+        eng = GanStep(dev, G, Dn, U, P, 100, True, 'l1', spec, 'both', use_graph=False, two_streams=False)
+        FakeDevice.pipe_log.clear()
+        drawn = []
+
+        def batches():
+            for i in range(5):
+                drawn.append(i)
+                yield (np.full((4, 24), i, np.float32), np.full((4, 1, 32, 32), i, np.float32), np.full((4, 3, 32, 32), i, np.float32))
+        seen = []
+        for i, losses in enumerate(eng.train_pipelined(batches())):
+            assert len(losses) == 5
+            seen.append(list(drawn))          # which batches had been drawn when step i's losses came back
+    finally:
+        step_mod.Ops = orig
+    assert seen == [[0, 1], [0, 1, 2], [0, 1, 2, 3], [0, 1, 2, 3, 4], [0, 1, 2, 3, 4]]     # one batch ahead, never more
+    b0, b1 = eng.built(4, 0), eng.built(4, 1)
+    assert b0 is not b1 and b0.x.ptr != b1.x.ptr and b0.G.store is b1.G.store            # own inputs, shared parameters
+    log = FakeDevice.pipe_log
+    ups = [e for e in log if e[0] == "h2d_async"]
+    assert [e[2] for e in ups[0::3]] == [0.0, 1.0, 2.0, 3.0, 4.0]                        # z of batch i ...
+    assert [e[1] for e in ups[0::3]] == [b0.z.ptr, b1.z.ptr, b0.z.ptr, b1.z.ptr, b0.z.ptr]   # ... into alternating plans
+    # before the THIRD upload (plan 0 again) the host waited for the events recorded behind step 0 on that plan, and for the
+    # event behind the first upload from the same page-locked set
+    i3 = log.index(ups[6])
+    syncs = [e for e in log[:i3] if e[0] == "host_sync"]
+    recs0 = [e[1] for e in log[:i3] if e[0] == "record"]
+    assert syncs and all(e[1] in recs0 for e in syncs)
+    # every step's stage stream waits for an event recorded (on the copy stream) after that batch's three uploads
+    waits = [i for i, e in enumerate(log) if e[0] == "wait"]
+    assert len(waits) == 5
+    for k, wi in enumerate(waits):
+        ev = log[wi][1]
+        ri = max(i for i, e in enumerate(log[:wi]) if e[0] == "record" and e[1] == ev)
+        assert sum(1 for e in log[:ri] if e[0] == "h2d_async") == 3 * (k + 1)
+    eng.close_pipeline()
+
+
 def test_discriminator_conv_lrelu_maxpool_is_fused_when_the_library_serves_it():
     """Conv2DLayer -> LeakyRectify -> MaxPool2DLayer (dcgan.py:42-47) becomes one 'convpool' node: pooled output, a
     byte mask, and in the backward the mask pass (which also sums the bias gradient) in front of an ordinary conv

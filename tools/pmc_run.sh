@@ -1,6 +1,8 @@
 #!/bin/bash
 # PMC passes for profiles/: counter calibration, then FETCH_SIZE / WRITE_SIZE per kernel of the f32 and bf16 steps
-# (counters only: --pmc with --kernel-trace, nothing else).   gpurun --timeout 1500 -- 'tools/pmc_run.sh r03'
+# (counters only: --pmc with --kernel-trace, nothing else).  NOTE: these passes run the step with --one-stream --issue eager, not
+# the three-stream recorded step bench.py times (rocprofv3 serialises dispatches under --pmc either way); tools/pmc_mfma.sh
+# re-takes FETCH / WRITE in the bench's own form (profiles/r04_pmc_traffic_3stream_*.json).   gpurun --timeout 1500 -- 'tools/pmc_run.sh r03'
 R=${1:-r03}
 O=$GRAFT_REPO_ROOT/gpurun_out/pmc
 mkdir -p $O
