@@ -99,6 +99,7 @@ SIGNATURES = {
     "ghm_thin_fwd_q_supported": [_D, _i32, _i32, _i32],
     "ghm_conv2d_fwd_thin_q": [_p, _D, _p, _p, _p, _p, _i32, _f, _p, _i64, _i32],
     "ghm_conv2d_fwd_pool_thin_q": [_p, _D, _p, _p, _p, _p, _p, _i32, _f, _p, _i64, _i32],
+    "ghm_thin_pool_lp_served": [_D, _i32, _f, _i32],
     "ghm_conv2d_pool_bwd_sparse_supported": [_D, _i32],
     "ghm_conv2d_pool_wgrad_sparse_workspace": [_D, C.POINTER(C.c_size_t)],
     "ghm_conv2d_pool_wgrad_sparse": [_p, _D, _p, _p, _p, _p, _p, _p, _i32, _f, _i32, _p],

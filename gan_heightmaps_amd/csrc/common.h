@@ -257,6 +257,11 @@ int lp_fwd_splitk_bn(ghm_ctx* ctx, const ghm_conv_desc* d, const void* xq, long 
 int sm_conv(ghm_ctx* ctx, const ghm_conv_desc* d, int kind, const void* inq, long inq_ns, const float* in32, const void* wq,
             const float* bias, float* out32, long out_nstride, void* outq, long outq_ns, int act, float alpha, int accumulate,
             int dtype, const SmBn* bn);
+// conv_thin_lp.hip: the fused first-layer forward (<= 4 channels -> 64 filters, activation, 2x2 max-pool) on the bf16 / fp16
+// matrix cores for the reduced-precision modes
+bool thin_pool_lp_ok(const ghm_conv_desc* d, int act, float alpha, int dtype);
+int thin_pool_lp(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias, float* pooled,
+                 unsigned char* mask, int act, float alpha, void* yq, long yq_nstride, int dtype);
 // split-K epilogue of a forward-form convolution: out = act(sum of S partial slices [S][R][N*H*W] + bias (+ out))
 int ghm_splitk_finish(ghm_ctx* ctx, const float* partial, int S, float* out, const float* bias, int N, int R, int H,
                       int W, long out_nstride, int act, float alpha, int accumulate);

@@ -2313,7 +2313,8 @@ int ghm_conv2d_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, co
 // the thin (<= 4 input channels) forward kernels with a q copy of their result written by their own epilogue
 int ghm_thin_fwd_q_supported(const ghm_conv_desc* d, int32_t act, int32_t pooled, int32_t dtype) {
     if (!(dtype == GHM_DTYPE_BF16 || dtype == GHM_DTYPE_F16) || d->C > 4 || d->K % 8 || GHM_OPT("GHM_NO_THIN_Q")) return 0;
-    return pooled ? (thin_fanout_fwd_pool_ok(d, act) && thin_fanout_pool_q_ok(d) ? 1 : 0) : (thin_fanout_fwd_ok(d, act) ? 1 : 0);
+    if (pooled) return (thin_fanout_fwd_pool_ok(d, act) && thin_fanout_pool_q_ok(d)) || thin_pool_lp_ok(d, act, 0.f, dtype) ? 1 : 0;
+    return thin_fanout_fwd_ok(d, act) ? 1 : 0;
 }
 
 int ghm_conv2d_fwd_thin_q(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const float* wp, const float* bias, float* y,
@@ -2328,6 +2329,8 @@ int ghm_conv2d_fwd_pool_thin_q(ghm_ctx* ctx, const ghm_conv_desc* d, const float
                                int32_t dtype) {
     if (int e = check_desc(d)) return e;
     GHM_CHECK(yq && ghm_thin_fwd_q_supported(d, act, 1, dtype), "ghm_conv2d_fwd_pool_thin_q: not served (ask ghm_thin_fwd_q_supported)");
+    if (thin_pool_lp_ok(d, act, alpha, dtype))        // reduced-precision modes: the taps on the bf16 / fp16 matrix cores
+        return thin_pool_lp(ctx, d, x, wp, bias, pooled, mask, act, alpha, yq, (long)yq_nstride, dtype);
     return thin_fanout_fwd_pool(ctx, d, x, wp, bias, pooled, mask, act, alpha, yq, (long)yq_nstride, dtype);
 }
 

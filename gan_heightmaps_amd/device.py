@@ -650,6 +650,10 @@ class Ops:
     def thin_fwd_q_supported(self, d, act, pooled, dtype):
         return bool(_lib.load().ghm_thin_fwd_q_supported(C.byref(d), ACT_CODES[act], int(pooled), DTYPE_CODES[dtype]))
 
+    def thin_pool_lp_served(self, d, act, alpha, dtype):
+        """the pooled first-layer forward runs on the bf16 / fp16 matrix cores (rounded operands) for this layer"""
+        return bool(_lib.load().ghm_thin_pool_lp_served(C.byref(d), ACT_CODES[act], alpha, DTYPE_CODES[dtype]))
+
     def conv2d_fwd_thin_q(self, d, x, w, bias, y, yq, act='linear', alpha=0.0):
         """first-layer forward (<= 4 input channels) writing its fp32 result and the q copy in one pass"""
         call("ghm_conv2d_fwd_thin_q", self.h, C.byref(d), _vp(x), _vp(w), _vp(bias), _vp(y), ACT_CODES[act], alpha,

@@ -706,19 +706,21 @@ def test_thin_first_layer_forward_writes_its_q_copy(gpu, case, dtype):
     dev.memset_zero(wide.ptr, wide.nbytes)
     yq = wide.channels(8, 8 + K)
     if pooled:
-        m1, m2 = dev.alloc(N * K * Ho * Wo), dev.alloc(N * K * Ho * Wo)
-        ops.conv2d_fwd_pool(d, xd, wp, bd, y1, m1, 'lrelu', 0.2, 'f32')
-        ops.conv2d_fwd_pool_thin_q(d, xd, wp, bd, y2, m2, yq, 'lrelu', 0.2)
-        a, bb = np.empty(N * K * Ho * Wo, np.uint8), np.empty(N * K * Ho * Wo, np.uint8)
-        dev.d2h(a, m1, a.nbytes)
-        dev.d2h(bb, m2, bb.nbytes)
-        assert np.array_equal(a, bb)
-        assert np.array_equal((a >> 4) & 1, (y1.numpy().ravel() > 0).astype(np.uint8))      # bit 4: sign of the pooled value
-        wide3 = D.QTensor.empty(dev, (N, K, Ho, Wo), dtype)                                 # q copy and mask only
-        m3 = dev.alloc(N * K * Ho * Wo)
-        ops.conv2d_fwd_pool_thin_q(d, xd, wp, bd, None, m3, wide3, 'lrelu', 0.2)
-        dev.d2h(bb, m3, bb.nbytes)
-        assert np.array_equal(a, bb) and np.array_equal(wide3.numpy(), R(y1.numpy()))
+        # (the fp32-operand kernel: what the pooled entry point runs where the matrix-core kernel of the next test refuses)
+        with tuning_env(GHM_NO_THIN_LP="1"):
+            m1, m2 = dev.alloc(N * K * Ho * Wo), dev.alloc(N * K * Ho * Wo)
+            ops.conv2d_fwd_pool(d, xd, wp, bd, y1, m1, 'lrelu', 0.2, 'f32')
+            ops.conv2d_fwd_pool_thin_q(d, xd, wp, bd, y2, m2, yq, 'lrelu', 0.2)
+            a, bb = np.empty(N * K * Ho * Wo, np.uint8), np.empty(N * K * Ho * Wo, np.uint8)
+            dev.d2h(a, m1, a.nbytes)
+            dev.d2h(bb, m2, bb.nbytes)
+            assert np.array_equal(a, bb)
+            assert np.array_equal((a >> 4) & 1, (y1.numpy().ravel() > 0).astype(np.uint8))      # bit 4: sign of the pooled value
+            wide3 = D.QTensor.empty(dev, (N, K, Ho, Wo), dtype)                                 # q copy and mask only
+            m3 = dev.alloc(N * K * Ho * Wo)
+            ops.conv2d_fwd_pool_thin_q(d, xd, wp, bd, None, m3, wide3, 'lrelu', 0.2)
+            dev.d2h(bb, m3, bb.nbytes)
+            assert np.array_equal(a, bb) and np.array_equal(wide3.numpy(), R(y1.numpy()))
     else:
         ops.conv2d_fwd(d, xd, wp, bd, y1, 'lrelu', 0.2)
         ops.conv2d_fwd_thin_q(d, xd, wp, bd, y2, yq, 'lrelu', 0.2)
@@ -726,6 +728,64 @@ def test_thin_first_layer_forward_writes_its_q_copy(gpu, case, dtype):
     assert np.array_equal(yq.numpy(), R(y1.numpy()))
     full = wide.numpy()
     assert not full[:, :8].any() and not full[:, 8 + K:].any()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("case", [(8, 1, 64, 64, 5, 'lrelu'), (2, 1, 128, 256, 5, 'lrelu'), (3, 1, 64, 128, 3, 'relu'),
+                                  (2, 3, 32, 64, 3, 'lrelu'), (2, 2, 40, 64, 3, 'linear')])
+def test_pooled_first_layer_on_the_matrix_cores(gpu, case, dtype):
+    """thin_pool_lp (csrc/conv_thin_lp.hip) behind ghm_conv2d_fwd_pool_thin_q: Conv2DLayer(<= 4 -> 64) -> nonlinearity ->
+    MaxPool2DLayer(2) (architectures/dcgan.py:42-47) with the taps on the bf16 / fp16 matrix cores.  The convolution is
+    oracle/lp.py's conv(round(x), round(W)) + b; the q copy is exactly the rounding of the kernel's own fp32 result (also
+    when the fp32 result is not written, and into a channel slice of a wider buffer); the mask marks every tie of the
+    window, agrees with the oracle's arg-max wherever the window has a clear winner, and carries the sign of the pooled
+    value in bit 4."""
+    dev, ops, D = gpu
+    N, C, H, W, k, act = case
+    K, pad = 64, k // 2
+    rng = np.random.RandomState(sum(case[:5]))
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, k, k, 1, pad)
+    assert ops.thin_fwd_q_supported(d, act, True, dtype)
+    assert ops.thin_pool_lp_served(d, act, 0.2, dtype)
+    R = LP.ROUND[dtype]
+    wp, xd, bd = dev.tensor(D.pack_conv_w(Wt).ravel()), dev.tensor(x), dev.tensor(b)
+    Hp, Wp = H // 2, W // 2
+    y = dev.empty((N, K, Hp, Wp))
+    wide = D.QTensor.empty(dev, (N, K + 16, Hp, Wp), dtype)
+    dev.memset_zero(wide.ptr, wide.nbytes)
+    yq = wide.channels(8, 8 + K)
+    m = dev.alloc(N * K * Hp * Wp)
+    ops.conv2d_fwd_pool_thin_q(d, xd, wp, bd, y, m, yq, act, 0.2)
+    mask = np.empty(N * K * Hp * Wp, np.uint8)
+    dev.d2h(mask, m, mask.nbytes)
+    mask = mask.reshape(N, K, Hp, Wp)
+    ref = LP.conv2d_fwd(x, Wt, b, 1, pad, dtype)
+    ref = {'lrelu': lambda v: np.where(v > 0, v, 0.2 * v), 'relu': lambda v: np.maximum(v, 0), 'linear': lambda v: v}[act](ref)
+    win = ref.reshape(N, K, Hp, 2, Wp, 2).transpose(0, 1, 2, 4, 3, 5).reshape(N, K, Hp, Wp, 4)
+    got = y.numpy()
+    assert rel(got, win.max(-1)) < EXACT, rel(got, win.max(-1))
+    assert np.array_equal(yq.numpy(), R(got))
+    full = wide.numpy()
+    assert not full[:, :8].any() and not full[:, 8 + K:].any()
+    assert np.array_equal((mask >> 4) & 1, (got > 0).astype(np.uint8))
+    assert not (mask >> 5).any() and (mask & 15).all()
+    srt = np.sort(win, -1)
+    clear = (srt[..., 3] - srt[..., 2]) > 1e-4 * np.abs(ref).max()
+    assert clear.mean() > 0.5
+    assert np.array_equal((mask & 15)[clear], (1 << win.argmax(-1))[clear].astype(np.uint8))
+    if act == 'relu':                       # an all-negative window is a four-way tie at zero
+        dead = (win.max(-1) == 0) & (srt[..., 3] - srt[..., 0] == 0)
+        assert dead.any() and ((mask & 15)[dead] == 15).all()
+    # q copy and mask only (what the engine asks for when every consumer of the pooled tensor reads q)
+    only = D.QTensor.empty(dev, (N, K, Hp, Wp), dtype)
+    m2 = dev.alloc(N * K * Hp * Wp)
+    ops.conv2d_fwd_pool_thin_q(d, xd, wp, bd, None, m2, only, act, 0.2)
+    mask2 = np.empty(N * K * Hp * Wp, np.uint8)
+    dev.d2h(mask2, m2, mask2.nbytes)
+    assert np.array_equal(mask2.reshape(mask.shape), mask) and np.array_equal(only.numpy(), R(got))
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])

@@ -19,8 +19,7 @@ def bench(name, fn, nbytes, reps=100):
     ms = dev.timer_ms(0) / reps
     print("%-34s %8.1f us   %6.0f GB/s of %5.1f MB written+read" % (name, ms * 1e3, nbytes / ms / 1e6, nbytes / 1e6))
 for (N, C, H, K, k, s, pad, pooled, q, f32) in [(8, 1, 512, 64, 5, 1, 2, True, True, False), (8, 1, 512, 64, 5, 1, 2, True, True, True),
-                                                (4, 1, 512, 64, 3, 2, 1, False, False, True), (8, 4, 512, 64, 3, 2, 1, False, True, True),
-                                                (8, 4, 512, 64, 3, 2, 1, False, True, False)]:
+                                                (4, 1, 512, 64, 3, 2, 1, False, False, True), (8, 4, 512, 64, 3, 2, 1, False, True, True)]:
     d = D.conv_desc(N, C, H, H, K, k, k, s, pad)
     x = dev.tensor(rng.randn(N, C, H, H).astype(np.float32))
     w = dev.tensor((rng.randn(C * k * k * K) * 0.05).astype(np.float32))
