@@ -1,0 +1,566 @@
+// fp32 convolutions on the bf16 matrix cores by operand splitting (gfx950 has no fast fp32 MFMA: v_mfma_f32_32x32x2_f32 runs
+// at 1/16 of the bf16 rate).  An fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8 significant bits, bf16 has the
+// exponent range of fp32):
+//     x = x0 + x1 + x2,   x0 = bf16(x), x1 = bf16(x - x0), x2 = x - x0 - x1
+// and the product of two bf16 values is exact in fp32, so
+//     x * w = sum over (i, j) of x_i * w_j.
+// The kernels here run the six products with i + j <= 2 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the three that
+// are dropped are below 2^-24 |x w| each -- the size of the rounding fp32 arithmetic itself commits on every product.  This
+// is the operand-splitting form of fp32 emulation (BF16x9 in vendor BLAS libraries keeps all nine products; six is the
+// fp32-accurate subset): nothing about the data is rounded to 8 bits.  Measured against the float64 oracle the results carry
+// the same error as the fp32 MFMA kernels (tests/test_gpu_split.py states the bound), at 6/16 of their matrix-core time.
+//
+// Layouts: a "split q tensor" is three planes (pieces 0, 1, 2), each a bf16 q tensor as include/ghm.h describes it
+// ([N][C/8][H][W][8 channels], 16-byte units); a "split weight pack" is three planes of the low-precision pack
+// wq[c/8][tap][Rpad][8] (conv_lp.hip).  ghm_split_pack / ghm_split_pack_weights produce them from fp32.
+//
+// Reference: the convolutions of architectures/dcgan.py:16-50 and architectures/p2p.py:139-290 in floatX=float32
+// (experiment.5.sh:5).  An OPT-IN arithmetic form of the fp32 mode (GanStep(split_fp32=True) / GHM_SPLIT_F32=1).
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x16 sp_mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// two fp32 values -> their three bf16 pieces, packed pairwise (low half = first value)
+__device__ __forceinline__ void sp_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    f32x2 v = {a, b};
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));          // RNE
+    f32x2 r = {a - __uint_as_float(p0 << 16), b - __uint_as_float(p0 & 0xffff0000u)};      // exact
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    f32x2 r2 = {r[0] - __uint_as_float(p1 << 16), r[1] - __uint_as_float(p1 & 0xffff0000u)};  // exact, <= 8 significant bits
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));         // exact
+}
+
+__device__ __forceinline__ void sp_split8(const float* v, u32x4& q0, u32x4& q1, u32x4& q2) {
+    unsigned a[4], b[4], c[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sp_split2(v[2 * t], v[2 * t + 1], a[t], b[t], c[t]);
+    q0 = u32x4{a[0], a[1], a[2], a[3]};
+    q1 = u32x4{b[0], b[1], b[2], b[3]};
+    q2 = u32x4{c[0], c[1], c[2], c[3]};
+}
+
+__device__ __forceinline__ int sp_xcd_remap(int bid, int nb) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// fp32 NCHW view -> split q tensor: one thread per 16-byte unit (8 channels of one pixel), three stores
+__global__ __launch_bounds__(256) void sp_pack_kernel(const float* __restrict__ x, long x_nstride, int N, int C8, int HW,
+                                                      u32x4* __restrict__ q, long q_nstride, long q_pstride) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)N * C8 * HW) return;
+    const int p = (int)(idx % HW);
+    const long nc = idx / HW;
+    const int cb = (int)(nc % C8), n = (int)(nc / C8);
+    const float* g = x + (long)n * x_nstride + (long)cb * 8 * HW + p;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = g[(long)j * HW];
+    u32x4 q0, q1, q2;
+    sp_split8(v, q0, q1, q2);
+    u32x4* o = q + (long)n * q_nstride + (long)cb * HW + p;
+    o[0] = q0;
+    o[q_pstride] = q1;
+    o[2 * q_pstride] = q2;
+}
+
+// packed fp32 weights wp[c][tap][r] -> split pack (three planes of wq[c/8][tap][Rpad][8]); transposed: the data-gradient
+// operand wqT[k/8][T-1-tap][Cpad][8 k] = wp[c][tap][k] (conv_lp.hip, lp_pack_batched_kernel)
+__global__ __launch_bounds__(256) void sp_pack_w_kernel(const float* __restrict__ wp, u32x4* __restrict__ wq, int red, int T,
+                                                        int rows, int nblk, int rpad, int transposed, long pstride) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)nblk * T * rpad) return;
+    const int r = (int)(idx % rpad);
+    const long bt = idx / rpad;
+    const int tap = (int)(bt % T), cb = (int)(bt / T);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cb * 8 + j;
+        const bool ok = c < red && r < rows;
+        const long src = transposed ? ((long)r * T + (T - 1 - tap)) * red + c : ((long)c * T + tap) * rows + r;
+        v[j] = ok ? wp[src] : 0.f;
+    }
+    u32x4 q0, q1, q2;
+    sp_split8(v, q0, q1, q2);
+    wq[idx] = q0;
+    wq[idx + pstride] = q1;
+    wq[idx + 2 * pstride] = q2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward-form convolution (forward; stride-1 data gradient on the transposed pack; 3x3 stride-2 forward), the structure of
+// lp_conv_kernel (conv_lp.hip) with three pieces of each operand in LDS.  A block owns BM output channels x (RT rows x 32
+// columns) of one image.  K loop: slabs of 16 input channels; inside a slab one iteration per filter row (KS k-steps, one
+// per filter column).  A k-step reads 3 A fragments per row tile and 3 B fragments per pixel tile and runs SIX MFMAs per
+// (row tile, pixel tile): half the LDS reads per MFMA of the one-piece kernel.
+// ------------------------------------------------------------------------------------------------
+struct SpConvArgs {
+    const u32x4* in_q;     // split q tensor of the conv input (forward) / output gradient (data gradient)
+    long in_q_nstride;     // units between samples
+    long in_q_pstride;     // units between pieces
+    const u32x4* zeros;    // >= 16 bytes of zeros in HBM: the DMA source of padding pixels
+    const u32x4* wq;       // split weight pack
+    long wq_pstride;
+    const float* bias;
+    float* out;            // fp32 NCHW output
+    float* partial;
+    int N, CH, H, W;       // OUTPUT grid
+    int Hin, Win;
+    int R, Rpad;
+    long out_nstride;
+    int pad, act;
+    float alpha;
+    int accumulate;
+    int slabs_per_split;
+    float* pool_out;            // POOL: [N, R, H/2, W/2] maximum of act(conv + bias) over 2x2 windows ...
+    unsigned char* pool_mask;   // ... and the arg-max mask of every window (bit 2*dr + dc; all ties set; bit 4: sign)
+};
+
+constexpr int NP = 3;
+
+template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL = false>
+__global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvArgs a) {
+    constexpr int T = KS * KS;
+    constexpr int TM = BM / (WM * 32), TN = RT / WN;
+    constexpr int PH = (RT - 1) * ST + KS, PW = 31 * ST + KS;
+    constexpr int PU1 = 2 * PH * PW, PUNITS = NP * PU1;          // one piece / all pieces of a slab's patch
+    constexpr int WU1 = 2 * KS * BM, WUNITS = NP * WU1;          // one piece / all pieces of a filter row's weights
+    constexpr int NW = WM * WN, NT = NW * 64;
+    constexpr int NQ = (PU1 + NT - 1) / NT;
+    constexpr int NI = WU1 / 64;                                  // DMA wave-instructions per weight tile and piece
+    static_assert((NW == 4 || NW == 8) && TM >= 1 && TN >= 1, "4 or 8 waves");
+    extern __shared__ __attribute__((aligned(16))) u32x4 sp_smem[];
+    u32x4* const Wl = sp_smem;                         // [2 buffers][piece][2 ch-blocks][KS][BM]
+    u32x4* const Pl = sp_smem + 2 * WUNITS;            // [2 buffers][piece][2 ch-blocks][PH][PW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int kg = lane >> 5, li = lane & 31;
+    const int ntr = (a.R + BM - 1) / BM;
+    const int tiles_x = a.W / 32, tiles_y = a.H / RT;
+    int L = sp_xcd_remap(blockIdx.x, gridDim.x);
+    const int r0 = (L % ntr) * BM;
+    L /= ntr;
+    const int tx = L % tiles_x;
+    L /= tiles_x;
+    const int ty = L % tiles_y;
+    const int n = L / tiles_y;
+    const int y0 = ty * RT, x0 = tx * 32;
+    const int HW = a.H * a.W, HWin = a.Hin * a.Win;
+    const int nslabs = a.CH / 16;
+    const int s_begin = blockIdx.y * a.slabs_per_split;
+    const int s_end = min(nslabs, s_begin + a.slabs_per_split);
+
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    int p_off[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = tid + q * NT;
+        const int cb = e / (PH * PW), rem = e - cb * (PH * PW);
+        const int py = rem / PW, px = rem - py * PW;
+        const int y = y0 * ST + py - a.pad, x = x0 * ST + px - a.pad;
+        const bool ok = e < PU1 && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
+        p_off[q] = ok ? cb * HWin + y * a.Win + x : -1;
+    }
+    const u32x4* ibase = a.in_q + (long)n * a.in_q_nstride + (long)s_begin * 2 * HWin;
+    auto stage_patch = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q * NT + wave * 64 < PU1) {
+                    const u32x4* g = p_off[q] >= 0 ? ibase + p * a.in_q_pstride + p_off[q] : a.zeros;
+                    if (tid + q * NT < PU1)
+                        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Pl + buf * PUNITS + p * PU1 + q * NT + wave * 64), 16, 0, 0);
+                }
+            }
+        ibase += 2 * HWin;
+    };
+    auto stage_weights = [&](int s, int fa, int buf) {
+        const u32x4* src = a.wq + ((long)(2 * s) * T + fa * KS) * a.Rpad + r0 + lane;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int w0 = 0; w0 < NI; w0 += NW) {
+                const int w = w0 + wave;
+                if (w < NI) {
+                    const int ci = w / (BM / 64), h = w - ci * (BM / 64);
+                    const int cb = ci / KS, b = ci - cb * KS;
+                    const u32x4* g = src + p * a.wq_pstride + ((long)cb * T + b) * a.Rpad + h * 64;
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Wl + buf * WUNITS + p * WU1 + ci * BM + h * 64), 16, 0, 0);
+                }
+            }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (s_begin < s_end) {
+        stage_weights(s_begin, 0, 0);
+        stage_patch(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int wlane = kg * KS * BM + wm * (BM / WM) + li;
+    const int plane = kg * PH * PW + (wn * TN * ST) * PW + li * ST;
+    int it = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int pbuf = (s - s_begin) & 1;
+        const bool next_slab = (s + 1) < s_end;
+        for (int fa = 0; fa < KS; ++fa, ++it) {
+            const int wbuf = it & 1;
+            if (fa + 1 < KS)
+                stage_weights(s, fa + 1, wbuf ^ 1);
+            else if (next_slab)
+                stage_weights(s + 1, 0, wbuf ^ 1);
+            if (fa == 0 && next_slab) stage_patch(pbuf ^ 1);
+            const u32x4* Wb = Wl + wbuf * WUNITS + wlane;
+            const u32x4* Pb = Pl + pbuf * PUNITS + plane + fa * PW;
+            // fragments of filter column b + 1 are read behind the MFMAs of column b
+            u32x4 af[2][NP][TM], bf[2][NP][TN];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[0][p][i] = Wb[p * WU1 + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[0][p][j] = Pb[p * PU1 + j * ST * PW];
+            }
+#pragma unroll
+            for (int b = 0; b < KS; ++b) {
+                if (b + 1 < KS) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) af[(b + 1) & 1][p][i] = Wb[p * WU1 + (b + 1) * BM + i * 32];
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) bf[(b + 1) & 1][p][j] = Pb[p * PU1 + j * ST * PW + b + 1];
+                    }
+                }
+                // the six products, small terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr) {
+                    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = sp_mfma(af[b & 1][PA[pr]][i], bf[b & 1][PB[pr]][j], acc[i][j]);
+                }
+                if (b + 1 < KS) {
+#pragma unroll
+                    for (int m_ = 0; m_ < NP * (TM + TN); ++m_) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (fp32): lanes along pixels; row of element e of tile i: i*32 + (e&3) + 8*(e>>2) + 4*kg ----
+    const long P = (long)a.N * HW;
+    const int ru = r0 + wm * (BM / WM);
+    const int rl = ru + 4 * kg;
+    if (a.partial) {
+        float* const pb = a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HW + (long)(y0 + wn * TN) * a.W + x0;
+        const unsigned lo = 4u * kg * (unsigned)P + li;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    float* rowp = pb + (long)k * P + j * a.W;
+                    if (rl + k < a.R) rowp[lo] = acc[i][j][e];
+                }
+        return;
+    }
+    float* const sb = reinterpret_cast<float*>(sp_smem);          // bias through LDS (free after the last barrier)
+    if (tid < BM) sb[tid] = (a.bias && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
+    __syncthreads();
+    const float* const lb = sb + wm * (BM / WM) + 4 * kg;
+    const float slope = a.act == GHM_ACT_LINEAR ? 1.f : (a.act == GHM_ACT_RELU ? 0.f : a.alpha);
+    const bool pwl = a.act == GHM_ACT_LINEAR || a.act == GHM_ACT_RELU || a.act == GHM_ACT_LRELU;
+    if constexpr (POOL) {
+        // 2x2 max-pool of act(conv + bias): the row pair of a window is in one lane, the column pair in lanes (2t, 2t+1)
+        static_assert(!POOL || (TN % 2 == 0 && ST == 1), "pooled epilogue: row pairs inside a wave");
+        const int Wp = a.W / 2;
+        const long HWp = (long)(a.H / 2) * Wp;
+        const long pix = (long)((y0 + wn * TN) / 2) * Wp + (x0 + li) / 2;
+        const long base = ((long)n * a.R + rl) * HWp + pix;
+        const bool even = (li & 1) == 0;
+#pragma unroll
+        for (int j2 = 0; j2 < TN / 2; ++j2)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    float v0 = acc[i][2 * j2][e] + lb[k], v1 = acc[i][2 * j2 + 1][e] + lb[k];
+                    v0 = v0 > 0.f ? v0 : slope * v0;
+                    v1 = v1 > 0.f ? v1 : slope * v1;
+                    const float w0 = __shfl_xor(v0, 1, 64), w1 = __shfl_xor(v1, 1, 64);
+                    const float m = fmaxf(fmaxf(v0, v1), fmaxf(w0, w1));
+                    const unsigned mk = (v0 == m ? 1u : 0u) | (w0 == m ? 2u : 0u) | (v1 == m ? 4u : 0u) | (w1 == m ? 8u : 0u) |
+                                        (m > 0.f ? GHM_POOL_SIGN : 0u);
+                    if (even && rl + k < a.R) {
+                        const long o = base + (long)k * HWp + j2 * Wp;
+                        if (a.pool_out) a.pool_out[o] = m;
+                        a.pool_mask[o] = (unsigned char)mk;
+                    }
+                }
+        return;
+    }
+    float* const ub = a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN) * a.W + x0;
+    const unsigned lo = 4u * kg * (unsigned)HW + li;
+    const bool full = r0 + BM <= a.R;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                v[e] = acc[i][j][e] + lb[k];
+            }
+            if (a.accumulate) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    if (full || rl + k < a.R) v[e] += (ub + (long)k * HW + j * a.W)[lo];
+                }
+            }
+            if (pwl) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = ghm_act(v[e], a.act, a.alpha);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                if (full || rl + k < a.R) (ub + (long)k * HW + j * a.W)[lo] = v[e];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct SpPlan {
+    bool ok;
+    int bm, rt, wm, wn, splits, slabs_per_split, grid;
+    size_t lds;
+};
+
+int sp_rpad(int r) { return (r + 127) / 128 * 128; }
+
+size_t sp_lds_bytes(int ks, int st, int bm, int rt) {
+    const int ph = (rt - 1) * st + ks, pw = 31 * st + ks;
+    return (size_t)2 * NP * (2 * ks * bm + 2 * ph * pw) * 16;
+}
+
+// forward form: CH reduction channels, R output channels, (H, W) output grid
+SpPlan sp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
+    SpPlan p;
+    memset(&p, 0, sizeof(p));
+    if (GHM_OPT("GHM_NO_SPLIT")) return p;
+    if (!((ks == 3 && (st == 1 || st == 2)) || (ks == 5 && st == 1))) return p;
+    // one block per CU (three pieces of both operands, double-buffered, fill the LDS): 3x3 stride 1 takes 128 filters x 8 rows
+    // with eight waves; 5x5 and stride 2 take 64 filters with four
+    if (ks == 3 && st == 1) { p.bm = R >= 96 ? 128 : 64; p.rt = 8; p.wm = p.bm == 128 ? 2 : 1; p.wn = 4; }
+    else if (ks == 5) { p.bm = 64; p.rt = 8; p.wm = 1; p.wn = 4; }
+    else { p.bm = 64; p.rt = 4; p.wm = 2; p.wn = 2; }
+    if (R < 32 || (W % 32) || (H % p.rt) || (CH % 16) || CH < 16) return p;
+    p.lds = sp_lds_bytes(ks, st, p.bm, p.rt);
+    if (p.lds > 160 * 1024) return p;
+    const int ntr = (R + p.bm - 1) / p.bm;
+    p.grid = ntr * (W / 32) * (H / p.rt) * N;
+    const int nslabs = CH / 16;
+    p.splits = 1;
+    if (p.grid < num_cu / 2) {
+        p.splits = (num_cu + p.grid - 1) / p.grid;
+        const int maxs = nslabs / 2 > 0 ? nslabs / 2 : 1;
+        if (p.splits > maxs) p.splits = maxs;
+    }
+    if (const char* f = GHM_OPT("GHM_SPLIT_SPLITS")) p.splits = atoi(f) < nslabs ? (atoi(f) > 0 ? atoi(f) : 1) : nslabs;
+    p.slabs_per_split = (nslabs + p.splits - 1) / p.splits;
+    p.splits = (nslabs + p.slabs_per_split - 1) / p.slabs_per_split;
+    p.ok = true;
+    return p;
+}
+
+static inline size_t align256(size_t n) { return (n + 255) / 256 * 256; }
+
+int sp_pack(ghm_ctx* ctx, const float* x, long x_nstride, int N, int C, int HW, void* q, long q_nstride, long q_pstride) {
+    const long total = (long)N * (C / 8) * HW;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(sp_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, x, x_nstride, N, C / 8, HW,
+                       (u32x4*)q, q_nstride, q_pstride);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename K>
+int sp_set_lds(K kernel, size_t lds) {
+    if (lds > 64 * 1024) GHM_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
+}
+
+// in32 != null: the fp32 operand is split into the launch's workspace first
+int sp_launch_conv(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, int ks, int st, const float* in32, long in32_nstride, bool pool) {
+    a.slabs_per_split = pl.slabs_per_split;
+    a.zeros = (const u32x4*)ctx->zeros;
+    a.partial = nullptr;
+    const long plane = (long)a.N * (a.CH / 8) * a.Hin * a.Win;
+    const size_t qbytes = in32 ? align256((size_t)NP * plane * 16) : 0;
+    const size_t pbytes = pl.splits > 1 ? (size_t)pl.splits * a.R * a.N * a.H * a.W * sizeof(float) : 0;
+    if (qbytes + pbytes) {
+        void* ws = nullptr;
+        if (int e = ghm_scratch(ctx, qbytes + pbytes, &ws)) return e;
+        if (in32) {
+            a.in_q = (const u32x4*)ws;
+            a.in_q_nstride = (long)(a.CH / 8) * a.Hin * a.Win;
+            a.in_q_pstride = plane;
+            if (int e = sp_pack(ctx, in32, in32_nstride, a.N, a.CH, a.Hin * a.Win, ws, a.in_q_nstride, plane)) return e;
+        }
+        if (pbytes) a.partial = (float*)((char*)ws + qbytes);
+    }
+    GHM_CHECK(!(pool && pl.splits > 1), "split-fp32 pooled convolution needs a single-pass plan");
+    const dim3 g(pl.grid, pl.splits);
+#define GHM_SP_CASE(KS_, ST_, BM_, RT_, WM_, WN_, POOL_)                                                         \
+    if (ks == KS_ && st == ST_ && pl.bm == BM_ && pl.rt == RT_ && pool == POOL_) {                               \
+        if (int e = sp_set_lds(sp_conv_kernel<KS_, ST_, BM_, RT_, WM_, WN_, POOL_>, pl.lds)) return e;           \
+        hipLaunchKernelGGL((sp_conv_kernel<KS_, ST_, BM_, RT_, WM_, WN_, POOL_>), g, dim3(WM_ * WN_ * 64), pl.lds, \
+                           ctx->stream, a);                                                                      \
+        GHM_LAUNCH_CHECK();                                                                                      \
+    } else
+    GHM_SP_CASE(5, 1, 64, 8, 1, 4, false)
+    GHM_SP_CASE(5, 1, 64, 8, 1, 4, true)
+    GHM_SP_CASE(3, 1, 128, 8, 2, 4, false)
+    GHM_SP_CASE(3, 1, 64, 8, 1, 4, false)
+    GHM_SP_CASE(3, 1, 128, 8, 2, 4, true)
+    GHM_SP_CASE(3, 1, 64, 8, 1, 4, true)
+    GHM_SP_CASE(3, 2, 64, 4, 2, 2, false) {
+        ghm_set_error("no split-fp32 convolution variant for k=%d s=%d bm=%d rt=%d pool=%d", ks, st, pl.bm, pl.rt, (int)pool);
+        return -3;
+    }
+#undef GHM_SP_CASE
+    if (pl.splits > 1)
+        return ghm_splitk_finish(ctx, a.partial, pl.splits, a.out, a.bias, a.N, a.R, a.H, a.W, a.out_nstride, a.act, a.alpha,
+                                 a.accumulate);
+    return 0;
+}
+
+bool sp_fwd_geom(const ghm_conv_desc* d) {
+    return d->kh == d->kw && 2 * d->pad == d->kh - 1 && ((d->stride == 1 && d->Ho == d->H && d->Wo == d->W) ||
+                                                          (d->stride == 2 && d->H == 2 * d->Ho && d->W == 2 * d->Wo));
+}
+
+}  // namespace
+
+// ---- C ABI (include/ghm.h) ----
+extern "C" {
+
+// kind 0: forward, 1: data gradient (stride 1, on the transposed pack)
+int ghm_split_supported(const ghm_conv_desc* d, int32_t kind) {
+    if (!d) return 0;
+    if (kind == 0) return sp_fwd_geom(d) && sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ghm_plan_cus()).ok;
+    if (kind == 1)
+        return d->stride == 1 && sp_fwd_geom(d) && sp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ghm_plan_cus()).ok;
+    return 0;
+}
+
+int ghm_split_weight_bytes(const ghm_conv_desc* d, int32_t transposed, size_t* bytes) {
+    GHM_CHECK(d && bytes, "null argument");
+    const int red = transposed ? d->K : d->C, rows = transposed ? d->C : d->K;
+    *bytes = (size_t)NP * ((red + 7) / 8) * d->kh * d->kw * sp_rpad(rows) * 16;
+    return 0;
+}
+
+int ghm_split_pack_weights(ghm_ctx* ctx, const ghm_conv_desc* d, const float* wp, void* wq, int32_t transposed) {
+    GHM_CHECK(ctx && d && wp && wq, "null argument");
+    const int red = transposed ? d->K : d->C, rows = transposed ? d->C : d->K;
+    const int T = d->kh * d->kw, nblk = (red + 7) / 8, rpad = sp_rpad(rows);
+    const long plane = (long)nblk * T * rpad;
+    hipLaunchKernelGGL(sp_pack_w_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0, ctx->stream, wp, (u32x4*)wq, red, T, rows,
+                       nblk, rpad, transposed ? 1 : 0, plane);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+// fp32 NCHW view -> split q tensor (three planes of q_pstride units)
+int ghm_split_pack(ghm_ctx* ctx, const float* x, int64_t x_nstride, int32_t N, int32_t C, int32_t HW, void* q, int64_t q_nstride,
+                   int64_t q_pstride) {
+    GHM_CHECK(ctx && x && q && C % 8 == 0, "ghm_split_pack: null argument or channels not a multiple of 8");
+    return sp_pack(ctx, x, x_nstride, N, C, HW, q, q_nstride, q_pstride);
+}
+
+// y = act(conv(x, W) + b) with fp32 operands and results; wq = ghm_split_pack_weights(transposed = 0).  xq != null: the
+// input as a split q tensor (ghm_split_pack) instead of x.
+int ghm_conv2d_fwd_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* xq, int64_t xq_nstride,
+                         int64_t xq_pstride, const void* wq, const float* bias, float* y, int32_t act, float alpha,
+                         int32_t accumulate) {
+    GHM_CHECK(ctx && d && (x || xq) && wq && y, "null argument");
+    GHM_CHECK(ghm_split_supported(d, 0), "ghm_conv2d_fwd_split: geometry not served (ask ghm_split_supported)");
+    GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    const SpPlan pl = sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ctx->num_cu);
+    SpConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in_q = (const u32x4*)xq; a.in_q_nstride = xq_nstride; a.in_q_pstride = xq_pstride;
+    a.wq = (const u32x4*)wq; a.bias = bias; a.out = y;
+    a.N = d->N; a.CH = d->C; a.H = d->Ho; a.W = d->Wo; a.Hin = d->H; a.Win = d->W;
+    a.R = d->K; a.Rpad = sp_rpad(d->K); a.wq_pstride = (long)((d->C + 7) / 8) * d->kh * d->kw * a.Rpad;
+    a.out_nstride = d->y_nstride; a.pad = d->pad;
+    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
+    return sp_launch_conv(ctx, pl, a, d->kh, d->stride, xq ? nullptr : x, d->x_nstride, false);
+}
+
+// dx = act(conv^T(dy, W) + b) of a stride-1 'same' convolution; wqT = ghm_split_pack_weights(transposed = 1)
+int ghm_conv2d_dgrad_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* dyq, int64_t dyq_nstride,
+                           int64_t dyq_pstride, const void* wqT, const float* bias, float* dx, int32_t act, float alpha,
+                           int32_t accumulate) {
+    GHM_CHECK(ctx && d && (dy || dyq) && wqT && dx, "null argument");
+    GHM_CHECK(ghm_split_supported(d, 1), "ghm_conv2d_dgrad_split: geometry not served (ask ghm_split_supported)");
+    GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    const SpPlan pl = sp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ctx->num_cu);
+    SpConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in_q = (const u32x4*)dyq; a.in_q_nstride = dyq_nstride; a.in_q_pstride = dyq_pstride;
+    a.wq = (const u32x4*)wqT; a.bias = bias; a.out = dx;
+    a.N = d->N; a.CH = d->K; a.H = d->H; a.W = d->W; a.Hin = d->H; a.Win = d->W;
+    a.R = d->C; a.Rpad = sp_rpad(d->C); a.wq_pstride = (long)((d->K + 7) / 8) * d->kh * d->kw * a.Rpad;
+    a.out_nstride = d->x_nstride; a.pad = d->kh - 1 - d->pad;
+    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
+    return sp_launch_conv(ctx, pl, a, d->kh, 1, dyq ? nullptr : dy, d->y_nstride, false);
+}
+
+}  // extern "C"

@@ -469,6 +469,36 @@ class Ops:
     def lp_supported(self, d, kind, dtype):
         return bool(_lib.load().ghm_lp_supported(C.byref(d), int(kind), DTYPE_CODES[dtype]))
 
+    # ---- fp32 on the bf16 matrix cores by operand splitting (csrc/conv_split.hip; opt-in) ----
+    def split_supported(self, d, kind):
+        return bool(_lib.load().ghm_split_supported(C.byref(d), int(kind)))
+
+    def split_weight_bytes(self, d, transposed=False):
+        n = C.c_size_t()
+        call("ghm_split_weight_bytes", C.byref(d), int(transposed), C.byref(n))
+        return n.value
+
+    def split_pack_weights(self, d, wp, wq, transposed=False):
+        call("ghm_split_pack_weights", self.h, C.byref(d), _vp(wp), _vp(wq), int(transposed))
+
+    def split_pack(self, x, q_ptr, q_nstride=None, q_pstride=None):
+        """fp32 view -> split q tensor (three planes) at q_ptr; returns (nstride, pstride) in 16-byte units"""
+        ns = (x.Cc // 8) * x.HW if q_nstride is None else q_nstride
+        ps = x.N * ns if q_pstride is None else q_pstride
+        call("ghm_split_pack", self.h, _vp(x), x.nstride, x.N, x.Cc, x.HW, C.c_void_p(int(q_ptr)), ns, ps)
+        return ns, ps
+
+    def conv2d_fwd_split(self, d, x, wq, bias, y, act='linear', alpha=0.0, accumulate=False, xq=None):
+        """xq = (ptr, nstride, pstride) of the input already split, or None (the entry point splits x)"""
+        q = xq or (None, 0, 0)
+        call("ghm_conv2d_fwd_split", self.h, C.byref(d), _vp(x), C.c_void_p(int(q[0])) if q[0] else None, q[1], q[2],
+             _vp(wq), _vp(bias), _vp(y), ACT_CODES[act], alpha, int(accumulate))
+
+    def conv2d_dgrad_split(self, d, dy, wqT, dx, bias=None, act='linear', alpha=0.0, accumulate=False, dyq=None):
+        q = dyq or (None, 0, 0)
+        call("ghm_conv2d_dgrad_split", self.h, C.byref(d), _vp(dy), C.c_void_p(int(q[0])) if q[0] else None, q[1], q[2],
+             _vp(wqT), _vp(bias), _vp(dx), ACT_CODES[act], alpha, int(accumulate))
+
     def lp_weight_bytes(self, d, transposed=False):
         n = C.c_size_t()
         call("ghm_lp_weight_bytes", C.byref(d), int(transposed), C.byref(n))

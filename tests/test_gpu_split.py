@@ -1,0 +1,139 @@
+"""fp32 convolutions on the bf16 matrix cores by operand splitting (csrc/conv_split.hip) through the C ABI, op by op.
+
+The claim under test: splitting each fp32 operand into three bf16 pieces and running the six leading piece products with
+fp32 accumulation is fp32 arithmetic -- not a reduced-precision mode.  So every case is held to the bound of the fp32
+path (rel-L2 <= 2e-6 against the float64 oracle of the SAME unrounded operands, tests/test_gpu_ops.py) and, next to it, to
+the error the v_mfma_f32_32x32x2_f32 kernels commit on the same inputs (not more than twice that, with a floor of 3e-7).
+For scale: rounding the operands to bf16 once costs 4e-3 on these cases (tests/test_gpu_lp.py, PREC).
+"""
+import numpy as np
+import pytest
+
+from gan_heightmaps_amd._lib import tuning_env
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+FP32_BOUND = 2e-6
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from gan_heightmaps_amd import device
+    if device.device_count() == 0:
+        pytest.fail("no HIP device visible: GPU tests must run on the MI355X box")
+    dev = device.Device(0)
+    yield dev, device.Ops(dev), device
+    dev.close()
+
+
+def test_three_bf16_pieces_are_the_fp32_value(gpu):
+    """ghm_split_pack: piece0 + piece1 + piece2 == x bit for bit (values across the fp32 exponent range, both signs,
+    zeros), piece0 is the nearest bf16, and every piece is a bf16 value"""
+    dev, ops, D = gpu
+    rng = np.random.RandomState(0)
+    N, C, H, W = 2, 16, 8, 32
+    x = (rng.randn(N, C, H, W) * np.exp2(rng.randint(-60, 60, size=(N, C, H, W)))).astype(np.float32)
+    x[0, 0, 0, :8] = [0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1.0000001, 0.33333334]
+    xd = dev.tensor(x)
+    buf = dev.alloc(3 * x.size * 2)
+    ns, ps = ops.split_pack(xd, buf)
+    raw = np.empty(3 * x.size, np.uint16)
+    dev.d2h(raw, buf, raw.nbytes)
+    pieces = (raw.astype(np.uint32) << 16).view(np.float32).reshape(3, N, C // 8, H * W, 8)
+    pieces = pieces.transpose(0, 1, 2, 4, 3).reshape(3, N, C, H, W)
+    total = (pieces[0].astype(np.float64) + pieces[1].astype(np.float64) + pieces[2].astype(np.float64)).astype(np.float32)
+    assert np.array_equal(total.view(np.uint32) & 0x7fffffff, x.view(np.uint32) & 0x7fffffff) or np.array_equal(total, x)
+    assert np.array_equal(total, x)
+    from oracle import lp as LP
+    assert np.array_equal(pieces[0], LP.round_bf16(x))
+
+
+CASES = [
+    # N, C, H, W, K, k, s, pad
+    (2, 16, 32, 32, 64, 5, 1, 2),      # one slab, 5x5
+    (1, 32, 32, 64, 96, 5, 1, 2),      # ragged filter tile (64 + 32), rectangular
+    (2, 48, 32, 32, 160, 3, 1, 1),     # 128-row tile + ragged, 3 slabs, eight waves
+    (1, 64, 64, 32, 40, 3, 1, 1),      # 40 filters on the 64-row tile (masked rows)
+    (2, 32, 64, 64, 128, 3, 2, 1),     # 3x3 stride 2 -> 32x32
+    (1, 16, 64, 128, 64, 3, 2, 1),     # 3x3 stride 2, rectangular
+    (1, 128, 32, 32, 96, 3, 1, 1),     # 8 slabs
+    (3, 80, 32, 32, 32, 5, 1, 2),      # 5 slabs, 32 filters
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("presplit", [False, True])
+def test_split_forward_is_fp32_arithmetic(gpu, case, presplit):
+    """ghm_conv2d_fwd_split (forward of Conv2DLayer, architectures/dcgan.py:22,42 / p2p.py:20-21) against the float64
+    oracle, beside ghm_conv2d_fwd (fp32 MFMA) on the same inputs; with the input given as fp32 and as a split q tensor"""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(sum(case))
+    x = (rng.randn(N, C, H, W) * np.exp(rng.randn(N, C, 1, 1))).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    assert ops.split_supported(d, 0)
+    ref = O.conv2d_fwd(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), s, pad)
+    ref = np.where(ref > 0, ref, 0.2 * ref)
+    xd, bd = dev.tensor(x), dev.tensor(b)
+    wp = dev.tensor(D.pack_conv_w(Wt).ravel())
+    wq = dev.alloc(ops.split_weight_bytes(d, False))
+    ops.split_pack_weights(d, wp, wq, False)
+    y = dev.empty((N, K, d.Ho, d.Wo))
+    xq = None
+    if presplit:
+        buf = dev.alloc(3 * x.size * 2)
+        xq = (buf,) + ops.split_pack(xd, buf)
+    ops.conv2d_fwd_split(d, xd, wq, bd, y, 'lrelu', 0.2, xq=xq)
+    got = y.numpy()
+    y32 = dev.empty((N, K, d.Ho, d.Wo))
+    ops.conv2d_fwd(d, xd, wp, bd, y32, 'lrelu', 0.2)
+    e_split, e_f32 = rel(got, ref), rel(y32.numpy(), ref)
+    print("split %.2e   fp32 MFMA %.2e   %s" % (e_split, e_f32, case))
+    assert e_split < FP32_BOUND and e_split < max(2 * e_f32, 3e-7), (e_split, e_f32)
+    # accumulate form (a data gradient summed into an existing one)
+    ops.conv2d_fwd_split(d, xd, wq, None, y, 'linear', 0.0, accumulate=True, xq=xq)
+    lin = O.conv2d_fwd(x.astype(np.float64), Wt.astype(np.float64), np.zeros(K), s, pad)
+    assert rel(y.numpy(), ref + lin) < FP32_BOUND
+    for ptr in ([wq] + ([xq[0]] if xq else [])):
+        dev.free(ptr)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[6] == 1])
+def test_split_data_gradient_is_fp32_arithmetic(gpu, case):
+    """ghm_conv2d_dgrad_split (stride-1 data gradient on the transposed split pack) against the float64 oracle, beside the
+    fp32 MFMA data gradient"""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(sum(case) + 1)
+    dy = (rng.randn(N, K, H, W) * np.exp(rng.randn(N, K, 1, 1))).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    if not ops.split_supported(d, 1):
+        pytest.skip("data gradient geometry not served (fewer than 32 input channels)")
+    ref = O.conv2d_vjp(np.zeros((N, C, H, W)), Wt.astype(np.float64), dy.astype(np.float64), s, pad)[0]
+    dyd = dev.tensor(dy)
+    wp = dev.tensor(D.pack_conv_w(Wt).ravel())
+    wqT = dev.alloc(ops.split_weight_bytes(d, True))
+    ops.split_pack_weights(d, wp, wqT, True)
+    dx = dev.empty((N, C, H, W))
+    ops.conv2d_dgrad_split(d, dyd, wqT, dx)
+    dx32 = dev.empty((N, C, H, W))
+    if ops.dgrad_t_supported(d):
+        wT = dev.empty((1, C * k * k * K, 1, 1))
+        ops.transpose_weights(d, wp, wT)
+        ops.conv2d_dgrad_t(d, dyd, wT, dx32)
+    else:
+        ops.conv2d_dgrad(d, dyd, wp, dx32)
+    e_split, e_f32 = rel(dx.numpy(), ref), rel(dx32.numpy(), ref)
+    print("split %.2e   fp32 MFMA %.2e   %s" % (e_split, e_f32, case))
+    assert e_split < FP32_BOUND and e_split < max(2 * e_f32, 3e-7), (e_split, e_f32)
+    dev.free(wqT)

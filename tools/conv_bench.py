@@ -23,8 +23,9 @@ def main():
     ap.add_argument("--q", default="", choices=["", "f32", "q", "both"],
                     help="low-precision kinds through the *_q entry points: operands are pre-packed q tensors, the "
                          "result is written as fp32, as a q tensor, or both")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
-                    help="bf16 / f16: the *_lp entry points (kinds fwd, dgrad_t, wgrad)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16", "split"],
+                    help="bf16 / f16: the *_lp entry points (kinds fwd, dgrad_t, wgrad); split: fp32 on the bf16 matrix "
+                         "cores by operand splitting (kinds fwd, dgrad_t, pack_x; --q q: operands already split)")
     args = ap.parse_args()
     N, C, H, W, K, k, s, pad = args.geom
     dev = D.Device(0)
@@ -46,7 +47,22 @@ def main():
            "dgrad_t": lambda: ops.conv2d_dgrad_t(d, y, wT, dx),
            "dgrad": lambda: ops.conv2d_dgrad(d, y, w, dx),
            "wgrad": lambda: ops.conv2d_wgrad(d, x, y, dw, ws)}
-    if args.dtype != "f32":
+    if args.dtype == "split":
+        wq = dev.alloc(ops.split_weight_bytes(d, False))
+        wqT = dev.alloc(ops.split_weight_bytes(d, True))
+        ops.split_pack_weights(d, w, wq, False)
+        ops.split_pack_weights(d, w, wqT, True)
+        xs = dev.alloc(3 * N * C * H * W * 2)
+        ys = dev.alloc(3 * N * K * d.Ho * d.Wo * 2)
+        xq = (xs,) + ops.split_pack(x, xs)
+        yq = (ys,) + ops.split_pack(y, ys)
+        pre = args.q == "q"
+        fns = {"pack_x": lambda: ops.split_pack(x, xs), "pack": lambda: ops.split_pack_weights(d, w, wq, False)}
+        if ops.split_supported(d, 0):
+            fns["fwd"] = lambda: ops.conv2d_fwd_split(d, x, wq, b, y, 'lrelu', 0.2, xq=xq if pre else None)
+        if ops.split_supported(d, 1):
+            fns["dgrad_t"] = lambda: ops.conv2d_dgrad_split(d, y, wqT, dx, dyq=yq if pre else None)
+    elif args.dtype != "f32":
         dt = args.dtype
         wq = dev.alloc(ops.lp_weight_bytes(d, False))
         wqT = dev.alloc(ops.lp_weight_bytes(d, True))
@@ -92,7 +108,7 @@ def main():
             fn()
         dev.timer_stop(0)
         ms = dev.timer_ms(0) / args.reps
-        name = ("lp<%s>" % args.dtype) if args.dtype != "f32" else \
+        name = ("split" if args.dtype == "split" else "lp<%s>" % args.dtype) if args.dtype != "f32" else \
             ops.conv_variant(d, ["fwd", "dgrad", "wgrad", "dgrad_t"].index(kind))
         print("%-7s %-34s %8.3f ms  %7.1f TFLOP/s  (%.1f GFLOP)  N%d C%d %dx%d K%d k%d s%d" %
               (kind, name, ms, flops / ms / 1e9, flops / 1e9, N, C, H, W, K, k, s))
