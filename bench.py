@@ -25,7 +25,9 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 LP_MFMA_PEAK_TFLOPS = 2500.0           # MI355X_MICROARCH.md: dense bf16 / fp16 v_mfma_f32_32x32x16 (not the 2:1-sparse 5 PF)
-PEAK = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16": LP_MFMA_PEAK_TFLOPS, "f16": LP_MFMA_PEAK_TFLOPS}
+PEAK = {"f32": FP32_MFMA_PEAK_TFLOPS, "bf16": LP_MFMA_PEAK_TFLOPS, "f16": LP_MFMA_PEAK_TFLOPS,
+        # fp32 by operand splitting: six bf16 MFMAs per fp32 multiply-add (csrc/conv_split.hip)
+        "bf16x3": LP_MFMA_PEAK_TFLOPS / 6.0}
 JOINT_GFLOP_PER_IMG = 683.29           # algorithmic 2 x MACs of the joint train step
 DCGAN_GFLOP_PER_IMG = 391.26           # config 2: DCGAN stage trained (fwd 115.26 + bwd 276.00)
 P2P_GFLOP_PER_IMG = 292.03             # config 3: pix2pix stage trained (fwd 95.05 + bwd 196.98)
@@ -112,10 +114,12 @@ def parse_args(argv=None):
     ap.add_argument("--ablate", default="", help="TUNING ONLY (results are wrong): comma-separated program-entry labels or "
                     "kernel-name prefixes whose launches are skipped, to see what a class of kernels costs inside the "
                     "overlapped schedule; the JSON line is marked invalid")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16", "bf16x3"],
                     help="arithmetic of the convolution products.  f32 (default) = the reference's floatX=float32 and the "
                          "headline metric; bf16 / f16 = BASELINE configs 4 / 5 (matrix-core operands rounded, fp32 "
-                         "accumulation, fp32 tensors / master weights / optimiser): an additional line, never the headline")
+                         "accumulation, fp32 tensors / master weights / optimiser): an additional line, never the headline; "
+                         "bf16x3 = fp32 arithmetic on the bf16 matrix cores by operand splitting (three bf16 pieces per "
+                         "fp32 value, six products, fp32 accumulation: fp32-accurate, opt-in, an additional line)")
     ap.add_argument("--config1", action="store_true",
                     help="BASELINE config 1 instead of the headline workload: DCGAN 64x64 generator + discriminator "
                          "(nch 64, div [2,2,4,4] / [8,4,2,1]), batch 16, train_mode='dcgan' -- an extra line for BASELINE.md, "
@@ -378,8 +382,11 @@ def measure(args, secondary_name=None):
                                "test1_nobn_bilin_both joint DCGAN+pix2pix train step (train_mode=%s), %dx%d, "
                                "batch %d per GPU, RMSprop lr 1e-4, LSGAN + 100*L1%s"
                                % (args.mode, S, S, B, "" if args.dtype == "f32" else
-                                  "; convolution products in %s on the matrix cores, fp32 accumulation / tensors / "
-                                  "master weights / optimiser" % args.dtype),
+                                  ("; fp32 convolution products by operand splitting on the bf16 matrix cores (three "
+                                   "bf16 pieces per fp32 operand, six products, fp32 accumulation: fp32-accurate)"
+                                   if args.dtype == "bf16x3" else
+                                   "; convolution products in %s on the matrix cores, fp32 accumulation / tensors / "
+                                   "master weights / optimiser" % args.dtype)),
                    "global_batch": B * world, "in_shp": S, "parallelism": "dp%d" % world,
                    "hip_graph": bool(args.graph), "issue": "graph" if args.graph else args.issue,
                    "host_calls_per_step": 1 if issue == 'recorded' else None,
@@ -429,7 +436,7 @@ def measure(args, secondary_name=None):
         flops_per_launch = flops_per_step / launches_per_step
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         traffic = None
-        kdt_name = args.dtype if dominant.startswith("lp_") else "f32"
+        kdt_name = args.dtype if dominant.startswith(("lp_", "sp_")) else "f32"
         sfx = "f32" if kdt_name == "f32" else "bf16"
         for pmc in ("r03_pmc_traffic_%s.json" % sfx, "r02_pmc_traffic_%s.json" % sfx, "r01_pmc_traffic.json"):    # tools/pmc_traffic.py
             pmc = os.path.join(ROOT, "profiles", pmc)
@@ -438,7 +445,7 @@ def measure(args, secondary_name=None):
         iso = flops_per_launch / (isolated_ms * 1e-3) / 1e12
         # the dominant kernel is priced against the peak of the arithmetic IT runs in (a thin / small-map kernel that
         # stays fp32 in a bf16 step is an fp32 kernel)
-        kdt = args.dtype if dominant.startswith("lp_") else "f32"
+        kdt = args.dtype if dominant.startswith(("lp_", "sp_")) else "f32"
         peak = PEAK[kdt]
         out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "kernel_dtype": kdt,
                            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,

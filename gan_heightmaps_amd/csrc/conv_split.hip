@@ -102,6 +102,39 @@ __global__ __launch_bounds__(256) void sp_pack_w_kernel(const float* __restrict_
     wq[idx + 2 * pstride] = q2;
 }
 
+// every pack of a net in ONE launch: the device table of ghm_lp_pack_batched (48-byte items, include/ghm.h); an item's three
+// planes are nblk * T * rpad units apart
+struct SpPackItem {
+    const float* wp;
+    u32x4* wq;
+    int red, T, rows, nblk, rpad, transposed, block_begin, pad_;
+};
+
+__global__ __launch_bounds__(256) void sp_pack_w_batched_kernel(const SpPackItem* __restrict__ items, int n) {
+    int li = 0;
+    while (li + 1 < n && (int)blockIdx.x >= items[li + 1].block_begin) ++li;
+    const SpPackItem it = items[li];
+    const long idx = (long)(blockIdx.x - it.block_begin) * 256 + threadIdx.x;
+    const long plane = (long)it.nblk * it.T * it.rpad;
+    if (idx >= plane) return;
+    const int r = (int)(idx % it.rpad);
+    const long bt = idx / it.rpad;
+    const int tap = (int)(bt % it.T), cb = (int)(bt / it.T);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cb * 8 + j;
+        const bool ok = c < it.red && r < it.rows;
+        const long src = it.transposed ? ((long)r * it.T + (it.T - 1 - tap)) * it.red + c : ((long)c * it.T + tap) * it.rows + r;
+        v[j] = ok ? it.wp[src] : 0.f;
+    }
+    u32x4 q0, q1, q2;
+    sp_split8(v, q0, q1, q2);
+    it.wq[idx] = q0;
+    it.wq[idx + plane] = q1;
+    it.wq[idx + 2 * plane] = q2;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Forward-form convolution (forward; stride-1 data gradient on the transposed pack; 3x3 stride-2 forward), the structure of
 // lp_conv_kernel (conv_lp.hip) with three pieces of each operand in LDS.  A block owns BM output channels x (RT rows x 32
@@ -382,6 +415,7 @@ struct SpPlan {
 };
 
 int sp_rpad(int r) { return (r + 127) / 128 * 128; }
+int sp_nblk(int red) { return (red + 15) / 16 * 2; }      // channel blocks of a pack (as the low-precision packs: whole slabs)
 
 size_t sp_lds_bytes(int ks, int st, int bm, int rt) {
     const int ph = (rt - 1) * st + ks, pw = 31 * st + ks;
@@ -502,14 +536,14 @@ int ghm_split_supported(const ghm_conv_desc* d, int32_t kind) {
 int ghm_split_weight_bytes(const ghm_conv_desc* d, int32_t transposed, size_t* bytes) {
     GHM_CHECK(d && bytes, "null argument");
     const int red = transposed ? d->K : d->C, rows = transposed ? d->C : d->K;
-    *bytes = (size_t)NP * ((red + 7) / 8) * d->kh * d->kw * sp_rpad(rows) * 16;
+    *bytes = (size_t)NP * sp_nblk(red) * d->kh * d->kw * sp_rpad(rows) * 16;
     return 0;
 }
 
 int ghm_split_pack_weights(ghm_ctx* ctx, const ghm_conv_desc* d, const float* wp, void* wq, int32_t transposed) {
     GHM_CHECK(ctx && d && wp && wq, "null argument");
     const int red = transposed ? d->K : d->C, rows = transposed ? d->C : d->K;
-    const int T = d->kh * d->kw, nblk = (red + 7) / 8, rpad = sp_rpad(rows);
+    const int T = d->kh * d->kw, nblk = sp_nblk(red), rpad = sp_rpad(rows);
     const long plane = (long)nblk * T * rpad;
     hipLaunchKernelGGL(sp_pack_w_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0, ctx->stream, wp, (u32x4*)wq, red, T, rows,
                        nblk, rpad, transposed ? 1 : 0, plane);
@@ -522,6 +556,40 @@ int ghm_split_pack(ghm_ctx* ctx, const float* x, int64_t x_nstride, int32_t N, i
                    int64_t q_pstride) {
     GHM_CHECK(ctx && x && q && C % 8 == 0, "ghm_split_pack: null argument or channels not a multiple of 8");
     return sp_pack(ctx, x, x_nstride, N, C, HW, q, q_nstride, q_pstride);
+}
+
+int ghm_split_pack_batched(ghm_ctx* ctx, const void* table, int32_t n_items, int32_t total_blocks) {
+    static_assert(sizeof(SpPackItem) == 48, "table layout is part of the ABI (see ghm.h)");
+    GHM_CHECK(ctx && table, "null argument");
+    if (n_items <= 0 || total_blocks <= 0) return 0;
+    hipLaunchKernelGGL(sp_pack_w_batched_kernel, dim3(total_blocks), dim3(256), 0, ctx->stream, (const SpPackItem*)table, n_items);
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+// Conv2DLayer -> {linear, relu, lrelu} -> MaxPool2DLayer(2) as one kernel (architectures/dcgan.py:42-47): the contract of
+// ghm_conv2d_fwd_pool (pooled fp32 tensor or NULL, arg-max mask with the sign bit)
+int ghm_split_pool_supported(const ghm_conv_desc* d, int32_t act) {
+    if (!d || !(act == GHM_ACT_LINEAR || act == GHM_ACT_RELU || act == GHM_ACT_LRELU)) return 0;
+    if (d->stride != 1 || !sp_fwd_geom(d) || (d->Ho & 1) || (d->Wo & 1)) return 0;
+    const SpPlan pl = sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, ghm_plan_cus());
+    return pl.ok && pl.splits == 1;
+}
+
+int ghm_conv2d_fwd_pool_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* xq, int64_t xq_nstride,
+                              int64_t xq_pstride, const void* wq, const float* bias, float* pooled, uint8_t* mask,
+                              int32_t act, float alpha) {
+    GHM_CHECK(ctx && d && (x || xq) && wq && mask, "null argument");
+    GHM_CHECK(ghm_split_pool_supported(d, act), "ghm_conv2d_fwd_pool_split: not served (ask ghm_split_pool_supported)");
+    const SpPlan pl = sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, ctx->num_cu);
+    SpConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in_q = (const u32x4*)xq; a.in_q_nstride = xq_nstride; a.in_q_pstride = xq_pstride;
+    a.wq = (const u32x4*)wq; a.bias = bias; a.pool_out = pooled; a.pool_mask = mask;
+    a.N = d->N; a.CH = d->C; a.H = d->Ho; a.W = d->Wo; a.Hin = d->H; a.Win = d->W;
+    a.R = d->K; a.Rpad = sp_rpad(d->K); a.wq_pstride = (long)sp_nblk(d->C) * d->kh * d->kw * a.Rpad;
+    a.pad = d->pad; a.act = act; a.alpha = alpha;
+    return sp_launch_conv(ctx, pl, a, d->kh, 1, xq ? nullptr : x, d->x_nstride, true);
 }
 
 // y = act(conv(x, W) + b) with fp32 operands and results; wq = ghm_split_pack_weights(transposed = 0).  xq != null: the
@@ -538,7 +606,7 @@ int ghm_conv2d_fwd_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, c
     a.in_q = (const u32x4*)xq; a.in_q_nstride = xq_nstride; a.in_q_pstride = xq_pstride;
     a.wq = (const u32x4*)wq; a.bias = bias; a.out = y;
     a.N = d->N; a.CH = d->C; a.H = d->Ho; a.W = d->Wo; a.Hin = d->H; a.Win = d->W;
-    a.R = d->K; a.Rpad = sp_rpad(d->K); a.wq_pstride = (long)((d->C + 7) / 8) * d->kh * d->kw * a.Rpad;
+    a.R = d->K; a.Rpad = sp_rpad(d->K); a.wq_pstride = (long)sp_nblk(d->C) * d->kh * d->kw * a.Rpad;
     a.out_nstride = d->y_nstride; a.pad = d->pad;
     a.act = act; a.alpha = alpha; a.accumulate = accumulate;
     return sp_launch_conv(ctx, pl, a, d->kh, d->stride, xq ? nullptr : x, d->x_nstride, false);
@@ -557,7 +625,7 @@ int ghm_conv2d_dgrad_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy
     a.in_q = (const u32x4*)dyq; a.in_q_nstride = dyq_nstride; a.in_q_pstride = dyq_pstride;
     a.wq = (const u32x4*)wqT; a.bias = bias; a.out = dx;
     a.N = d->N; a.CH = d->K; a.H = d->H; a.W = d->W; a.Hin = d->H; a.Win = d->W;
-    a.R = d->C; a.Rpad = sp_rpad(d->C); a.wq_pstride = (long)((d->K + 7) / 8) * d->kh * d->kw * a.Rpad;
+    a.R = d->C; a.Rpad = sp_rpad(d->C); a.wq_pstride = (long)sp_nblk(d->K) * d->kh * d->kw * a.Rpad;
     a.out_nstride = d->x_nstride; a.pad = d->kh - 1 - d->pad;
     a.act = act; a.alpha = alpha; a.accumulate = accumulate;
     return sp_launch_conv(ctx, pl, a, d->kh, 1, dyq ? nullptr : dy, d->y_nstride, false);

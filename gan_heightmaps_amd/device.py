@@ -8,6 +8,9 @@ from ._lib import ConvDesc, call
 
 ACT_CODES = {'linear': 0, 'relu': 1, 'lrelu': 2, 'sigmoid': 3, 'tanh': 4}
 DTYPE_CODES = {'f32': 0, 'bf16': 1, 'f16': 2}       # GHM_DTYPE_* (include/ghm.h)
+# 'bf16x3': fp32 arithmetic on the bf16 matrix cores by operand splitting (csrc/conv_split.hip) -- a host-side name: Ops
+# routes the *_lp / *_lp_q calls made with it to the ghm_*_split entry points, and a QTensor of this dtype is three planes
+SPLIT = 'bf16x3'
 
 
 def device_count():
@@ -80,13 +83,15 @@ class QTensor:
     """bf16 / fp16 copy of a [N, C, H, W] tensor in HBM in the channel-block-of-8 layout of include/ghm.h ("q tensor"):
     16-byte units = 8 channels of one pixel; ``nstride`` counts UNITS between samples, so a channel slice (multiple of 8)
     of a wider buffer is a view."""
-    __slots__ = ("dev", "ptr", "shape", "nstride", "dtype", "base")
+    __slots__ = ("dev", "ptr", "shape", "nstride", "dtype", "base", "pstride")
 
-    def __init__(self, dev, ptr, shape, dtype, nstride=None, base=None):
+    def __init__(self, dev, ptr, shape, dtype, nstride=None, base=None, pstride=None):
         self.dev, self.ptr, self.dtype, self.base = dev, int(ptr), dtype, base
         self.shape = tuple(int(v) for v in shape)
         assert len(self.shape) == 4 and self.shape[1] % 8 == 0, self.shape
         self.nstride = int(nstride) if nstride is not None else self.shape[1] // 8 * self.shape[2] * self.shape[3]
+        # 'bf16x3' (split fp32): units between the three piece planes -- a property of the allocation, kept by every view
+        self.pstride = int(pstride) if pstride is not None else self.shape[0] * self.nstride
 
     N = property(lambda s: s.shape[0])
     Cc = property(lambda s: s.shape[1])
@@ -99,33 +104,37 @@ class QTensor:
     @staticmethod
     def empty(dev, shape, dtype):
         shape = tuple(int(v) for v in shape)
-        return QTensor(dev, dev.alloc(16 * shape[0] * (shape[1] // 8) * shape[2] * shape[3]), shape, dtype)
+        planes = 3 if dtype == SPLIT else 1
+        return QTensor(dev, dev.alloc(planes * 16 * shape[0] * (shape[1] // 8) * shape[2] * shape[3]), shape, dtype)
 
     def channels(self, c0, c1):
         assert 0 <= c0 < c1 <= self.shape[1] and c0 % 8 == 0 and (c1 - c0) % 8 == 0
         return QTensor(self.dev, self.ptr + 16 * (c0 // 8) * self.HW, (self.N, c1 - c0, self.H, self.W), self.dtype,
-                       self.nstride, self.base if self.base is not None else self)
+                       self.nstride, self.base if self.base is not None else self, self.pstride)
 
     def samples(self, n0, n1):
         assert 0 <= n0 < n1 <= self.shape[0]
         return QTensor(self.dev, self.ptr + 16 * n0 * self.nstride, (n1 - n0,) + self.shape[1:], self.dtype, self.nstride,
-                       self.base if self.base is not None else self)
+                       self.base if self.base is not None else self, self.pstride)
 
     def reshape(self, shape):
         """[N, 4K, H, W] <-> [4N, K, H, W] (the parity-planar view of the collapsed up-sample convolutions)"""
         assert self.contiguous
-        t = QTensor(self.dev, self.ptr, shape, self.dtype, None, self.base if self.base is not None else self)
+        t = QTensor(self.dev, self.ptr, shape, self.dtype, None, self.base if self.base is not None else self, self.pstride)
         assert t.nbytes == self.nbytes
         return t
 
-    def numpy(self):
-        """-> float32 [N, C, H, W] (the exact values of the stored halfwords)"""
+    def numpy(self, piece=None):
+        """-> float32 [N, C, H, W] (the exact values of the stored halfwords); 'bf16x3': the sum of the three pieces (in
+        float64, rounded once: the fp32 value that was split), or one piece"""
+        if self.dtype == SPLIT and piece is None:
+            return sum(self.numpy(p).astype(np.float64) for p in range(3)).astype(np.float32)
         raw = np.empty((self.N, self.Cc * self.HW), np.uint16)       # a sample's channel blocks are contiguous planes
         for n in range(self.N):
-            self.dev.d2h(raw[n], self.ptr + 16 * n * self.nstride, raw[n].nbytes)
+            self.dev.d2h(raw[n], self.ptr + 16 * ((piece or 0) * self.pstride + n * self.nstride), raw[n].nbytes)
         raw = raw.reshape(self.N, self.Cc // 8, self.HW, 8).transpose(0, 1, 3, 2)
         raw = np.ascontiguousarray(raw).reshape(self.shape)
-        if self.dtype == 'bf16':
+        if self.dtype in ('bf16', SPLIT):
             return (raw.astype(np.uint32) << 16).view(np.float32)
         return raw.view(np.float16).astype(np.float32)
 
@@ -449,7 +458,7 @@ class Ops:
 
     def dgrad_dact_supported(self, d, dtype='f32'):
         """0: not served; 1 / 2 / 3: served, reading the fp32 packed wp / the fp32 wpT / the low-precision wqT"""
-        return int(_lib.load().ghm_dgrad_dact_supported(C.byref(d), DTYPE_CODES[dtype]))
+        return int(_lib.load().ghm_dgrad_dact_supported(C.byref(d), DTYPE_CODES['f32' if dtype == SPLIT else dtype]))
 
     def conv2d_dgrad_dact(self, d, dy, w, dx, y, act, alpha, dtype='f32'):
         """dx = conv^T(dy) * act'(y): the data gradient with the producer's activation backward in its epilogue"""
@@ -467,6 +476,8 @@ class Ops:
 
     # ---- bf16 / fp16 matrix-core convolutions (fp32 tensors in HBM; include/ghm.h GHM_DTYPE_*) ----
     def lp_supported(self, d, kind, dtype):
+        if dtype == SPLIT:
+            return self.split_supported(d, kind)
         return bool(_lib.load().ghm_lp_supported(C.byref(d), int(kind), DTYPE_CODES[dtype]))
 
     # ---- fp32 on the bf16 matrix cores by operand splitting (csrc/conv_split.hip; opt-in) ----
@@ -499,12 +510,16 @@ class Ops:
         call("ghm_conv2d_dgrad_split", self.h, C.byref(d), _vp(dy), C.c_void_p(int(q[0])) if q[0] else None, q[1], q[2],
              _vp(wqT), _vp(bias), _vp(dx), ACT_CODES[act], alpha, int(accumulate))
 
-    def lp_weight_bytes(self, d, transposed=False):
+    def lp_weight_bytes(self, d, transposed=False, dtype=None):
+        if dtype == SPLIT:
+            return self.split_weight_bytes(d, transposed)
         n = C.c_size_t()
         call("ghm_lp_weight_bytes", C.byref(d), int(transposed), C.byref(n))
         return n.value
 
     def lp_pack_weights(self, d, wp, wq, dtype, transposed=False):
+        if dtype == SPLIT:
+            return self.split_pack_weights(d, wp, wq, transposed)
         call("ghm_lp_pack_weights", self.h, C.byref(d), _vp(wp), _vp(wq), DTYPE_CODES[dtype], int(transposed))
 
     def lp_pack_table(self, items):
@@ -523,13 +538,19 @@ class Ops:
 
     def lp_pack_batched(self, table, dtype):
         ptr, n, blocks = table
+        if dtype == SPLIT:
+            return call("ghm_split_pack_batched", self.h, C.c_void_p(ptr), n, blocks)
         call("ghm_lp_pack_batched", self.h, C.c_void_p(ptr), n, blocks, DTYPE_CODES[dtype])
 
     def conv2d_fwd_lp(self, d, x, wq, bias, y, dtype, act='linear', alpha=0.0, accumulate=False):
+        if dtype == SPLIT:
+            return self.conv2d_fwd_split(d, x, wq, bias, y, act, alpha, accumulate)
         call("ghm_conv2d_fwd_lp", self.h, C.byref(d), _vp(x), _vp(wq), _vp(bias), _vp(y), ACT_CODES[act], alpha,
              int(accumulate), DTYPE_CODES[dtype])
 
     def conv2d_dgrad_lp(self, d, dy, wqT, dx, dtype, bias=None, act='linear', alpha=0.0, accumulate=False):
+        if dtype == SPLIT:
+            return self.conv2d_dgrad_split(d, dy, wqT, dx, bias, act, alpha, accumulate)
         call("ghm_conv2d_dgrad_lp", self.h, C.byref(d), _vp(dy), _vp(wqT), _vp(bias), _vp(dx), ACT_CODES[act], alpha,
              int(accumulate), DTYPE_CODES[dtype])
 
@@ -545,6 +566,8 @@ class Ops:
     # ---- q tensors (include/ghm.h): low-precision products on operands rounded once at their producer ----
     def q_pack(self, x, q):
         assert x.shape == q.shape
+        if q.dtype == SPLIT:
+            return self.split_pack(x, q.ptr, q.nstride, q.pstride)
         call("ghm_q_pack", self.h, _vp(x), x.nstride, x.N, x.Cc, x.HW, C.c_void_p(q.ptr), q.nstride, DTYPE_CODES[q.dtype])
 
     def q_unpack(self, q, x):
@@ -552,15 +575,21 @@ class Ops:
         call("ghm_q_unpack", self.h, C.c_void_p(q.ptr), q.nstride, q.N, q.Cc, q.HW, _vp(x), x.nstride, DTYPE_CODES[q.dtype])
 
     def lp_q_direct(self, d, kind, dtype):
+        if dtype == SPLIT:
+            return False            # the split kernels write fp32 results only: their readers' operands are split in a pass
         return bool(_lib.load().ghm_lp_q_direct(C.byref(d), int(kind), DTYPE_CODES[dtype]))
 
     def conv_variant_lp(self, d, kind, dtype):
         """kernel family serving low-precision product ``kind`` (0 forward, 1 data gradient, 2 weight gradient)"""
+        if dtype == SPLIT:
+            return ("sp_wgrad_kernel<%d, %d>" if kind == 2 else "sp_conv_kernel<%d, %d>") % (d.kh, d.stride)
         out = C.create_string_buffer(128)
         call("ghm_lp_variant", C.byref(d), int(kind), DTYPE_CODES[dtype], out, 128)
         return out.value.decode()
 
     def conv_bn_fused_supported(self, d, dtype):
+        if dtype == SPLIT:
+            return False
         if dtype == 'f32':
             return bool(_lib.load().ghm_conv_bn_fused_supported_f32(C.byref(d)))
         return bool(_lib.load().ghm_conv_bn_fused_supported(C.byref(d), DTYPE_CODES[dtype]))
@@ -582,11 +611,18 @@ class Ops:
              eps, run_alpha, ACT_CODES[act], alpha, DTYPE_CODES[dtype])
 
     def conv2d_fwd_lp_q(self, d, xq, wq, bias, y, yq, dtype, act='linear', alpha=0.0, accumulate=False):
+        if dtype == SPLIT:
+            assert yq is None
+            return self.conv2d_fwd_split(d, None, wq, bias, y, act, alpha, accumulate, xq=(xq.ptr, xq.nstride, xq.pstride))
         call("ghm_conv2d_fwd_lp_q", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, _vp(wq), _vp(bias), _vp(y),
              C.c_void_p(yq.ptr if yq is not None else 0), yq.nstride if yq is not None else 0, ACT_CODES[act], alpha,
              int(accumulate), DTYPE_CODES[dtype])
 
     def conv2d_dgrad_lp_q(self, d, dyq, wqT, dx, dxq, dtype, bias=None, act='linear', alpha=0.0, accumulate=False):
+        if dtype == SPLIT:
+            assert dxq is None
+            return self.conv2d_dgrad_split(d, None, wqT, dx, bias, act, alpha, accumulate,
+                                           dyq=(dyq.ptr, dyq.nstride, dyq.pstride))
         call("ghm_conv2d_dgrad_lp_q", self.h, C.byref(d), C.c_void_p(dyq.ptr), dyq.nstride, _vp(wqT), _vp(bias), _vp(dx),
              C.c_void_p(dxq.ptr if dxq is not None else 0), dxq.nstride if dxq is not None else 0, ACT_CODES[act], alpha,
              int(accumulate), DTYPE_CODES[dtype])
@@ -646,6 +682,8 @@ class Ops:
              ACT_CODES[act], alpha, _vp(dbias), int(accumulate), C.c_void_p(dxq.ptr), dxq.nstride, DTYPE_CODES[dxq.dtype])
 
     def lp_wgrad_q_supported(self, d, dtype):
+        if dtype == SPLIT:
+            return self.split_supported(d, 2)
         return bool(_lib.load().ghm_lp_wgrad_q_supported(C.byref(d), DTYPE_CODES[dtype]))
 
     def conv2d_wgrad_lp_q(self, d, xq, dyq, dwp, ws, dtype, accumulate=False):
@@ -653,6 +691,10 @@ class Ops:
              _vp(dwp), _vp(ws), int(accumulate), DTYPE_CODES[dtype])
 
     def conv2d_fwd_pool_lp_q(self, d, xq, wq, bias, pooled, pooledq, mask_ptr, act, alpha, dtype):
+        if dtype == SPLIT:
+            assert pooledq is None
+            return call("ghm_conv2d_fwd_pool_split", self.h, C.byref(d), None, C.c_void_p(xq.ptr), xq.nstride, xq.pstride,
+                        _vp(wq), _vp(bias), _vp(pooled), C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha)
         call("ghm_conv2d_fwd_pool_lp_q", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, _vp(wq), _vp(bias), _vp(pooled),
              C.c_void_p(pooledq.ptr if pooledq is not None else 0), pooledq.nstride if pooledq is not None else 0,
              C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha, DTYPE_CODES[dtype])
@@ -660,10 +702,17 @@ class Ops:
     # ---- conv + activation + 2x2 max-pool fused (architectures/dcgan.py:42-47) ----
     def conv_pool_supported(self, d, act, dtype='f32'):
         """0: not served; 1: served with the fp32 packed weights; 2: served with the low-precision pack"""
+        if dtype == SPLIT:
+            if d.C > 4 and _lib.load().ghm_split_pool_supported(C.byref(d), ACT_CODES[act]):
+                return 2
+            dtype = 'f32'
         return int(_lib.load().ghm_conv2d_pool_supported(C.byref(d), ACT_CODES[act], DTYPE_CODES[dtype]))
 
     def conv2d_fwd_pool(self, d, x, w, bias, pooled, mask_ptr, act, alpha, dtype='f32'):
         assert pooled.contiguous
+        if dtype == SPLIT:
+            return call("ghm_conv2d_fwd_pool_split", self.h, C.byref(d), _vp(x), None, 0, 0, _vp(w), _vp(bias), _vp(pooled),
+                        C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha)
         call("ghm_conv2d_fwd_pool", self.h, C.byref(d), _vp(x), _vp(w), _vp(bias), _vp(pooled), C.c_void_p(int(mask_ptr)),
              ACT_CODES[act], alpha, DTYPE_CODES[dtype])
 
@@ -678,6 +727,8 @@ class Ops:
                  dx.H, dx.W, ACT_CODES[act], alpha, _vp(dbias), int(accumulate))
 
     def thin_fwd_q_supported(self, d, act, pooled, dtype):
+        if dtype == SPLIT:
+            return False
         return bool(_lib.load().ghm_thin_fwd_q_supported(C.byref(d), ACT_CODES[act], int(pooled), DTYPE_CODES[dtype]))
 
     def thin_pool_lp_served(self, d, act, alpha, dtype):

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import layers as L
 from .architectures.layers import BilinearUpsample2DLayer
-from .device import DevTensor, Ops, QTensor, conv_desc, pack_conv_w, unpack_conv_w
+from .device import SPLIT, DevTensor, Ops, QTensor, conv_desc, pack_conv_w, unpack_conv_w
 from .nonlinearities import linear
 
 ALIGN = 64      # elements; keeps every parameter 256-B aligned inside the flat buffers
@@ -290,7 +290,7 @@ class NetPlan:
         self.side = side
         # arithmetic of the convolution products: 'f32' (the reference's floatX) or 'bf16' / 'f16' on the matrix cores
         # for every geometry the low-precision kernels serve; tensors in HBM are fp32 either way (include/ghm.h)
-        assert dtype in ('f32', 'bf16', 'f16')
+        assert dtype in ('f32', 'bf16', 'f16', SPLIT)
         self.dtype = dtype
         # bn_groups=2: the batch is [real | fake] (two get_output calls of the reference, pix2pix.py:94-95,98-101):
         # every BatchNormLayer normalises each half with its own statistics
@@ -306,6 +306,9 @@ class NetPlan:
         # q tensors (include/ghm.h): in the reduced-precision modes every tensor a low-precision product reads as an
         # operand also exists as a bf16 / fp16 copy in channel-block-of-8 layout, written by its producer
         self.use_q = self.dtype != 'f32' and os.environ.get("GHM_NO_Q") is None and hasattr(ops, 'q_pack')
+        # do the producers of this mode write q copies from their own epilogues (and may fp32 tensors nobody reads be
+        # dropped)?  Not in the split-fp32 mode: its operands are split in a pass of their own (ghm_split_pack)
+        self.q_epi = self.use_q and self.dtype != SPLIT
         for n in self.order:
             n.outq = None
         if self.use_q:
@@ -347,7 +350,7 @@ class NetPlan:
             T = d.kh * d.kw
             for transposed, kind in ((False, 0), (True, 1)):
                 if self._lp(d, kind) and (key, transposed) not in self._lp_wq:
-                    wq = self.store.lp_pack((key, transposed, self.dtype), self.ops.lp_weight_bytes(d, transposed))
+                    wq = self.store.lp_pack((key, transposed, self.dtype), self.ops.lp_weight_bytes(d, transposed, self.dtype))
                     self._lp_wq[(key, transposed)] = wq
                     items.append((src, wq, d.K if transposed else d.C, T, d.C if transposed else d.K, transposed))
         if items:
@@ -501,7 +504,7 @@ class NetPlan:
     def _fp32_needed(self, n):
         """does anything read the fp32 output of node n (which also has a q copy)?  Not when every consumer is a
         low-precision convolution whose forward AND weight gradient read the q copy."""
-        if n is self.out_node or n.outq is None or n.alias is not None or not n.consumers:
+        if n is self.out_node or n.outq is None or n.alias is not None or not n.consumers or not self.q_epi:
             return True
         for c in n.consumers:
             if c.op in ('conv', 'convpool') and c.inputs[0] is n:
@@ -517,7 +520,7 @@ class NetPlan:
     def _pool_y_dropped(self, n):
         """fused conv + activation + max-pool node whose pooled fp32 tensor is never written: every consumer reads the q
         copy, and the backward pass takes the activation slope from the sign bit the forward kernel leaves in the mask"""
-        if (n.op != 'convpool' or not self.use_q or os.environ.get("GHM_KEEP_POOL_Y") is not None
+        if (n.op != 'convpool' or not self.q_epi or os.environ.get("GHM_KEEP_POOL_Y") is not None
                 or os.environ.get("GHM_POOL_READ_Y") is not None):      # (the A/B switch of the backward reads it back)
             return False
         if n.act.kind not in ('linear', 'relu', 'lrelu') or self._fp32_needed(n):
@@ -575,7 +578,7 @@ class NetPlan:
         """-> device pointer of the bf16 / fp16 pack of ``w_src``; emits the refresh once per program set ``done``"""
         if (key, transposed) in self._lp_wq:
             return self._lp_wq[(key, transposed)]         # refreshed by the batched pack at the start of the forward
-        wq = self.store.lp_pack((key, transposed, self.dtype), self.ops.lp_weight_bytes(d, transposed))
+        wq = self.store.lp_pack((key, transposed, self.dtype), self.ops.lp_weight_bytes(d, transposed, self.dtype))
         if done is None or (key, transposed) not in done:
             if done is not None:
                 done.add((key, transposed))
@@ -721,8 +724,8 @@ class NetPlan:
                 if self._pool_y_dropped(n):
                     y = None                # (pooled fp32 tensor not written: see _pool_y_dropped)
                 if form == 2 and xq is not None:
-                    q_direct = n.outq is not None
-                    prog.append(("convpool_fwd", lambda d=d, xq=xq, wsrc=wsrc, b=b, y=y, yq=n.outq, m=n.aux['mask'], a=a:
+                    q_direct = n.outq is not None and self.q_epi
+                    prog.append(("convpool_fwd", lambda d=d, xq=xq, wsrc=wsrc, b=b, y=y, yq=n.outq if self.q_epi else None, m=n.aux['mask'], a=a:
                                  ops.conv2d_fwd_pool_lp_q(d, xq, wsrc, b, y, yq, m, a.kind, a.alpha, self.dtype),
                                  conv_meta(ops, d, 0, dt, pooled=True)))
                 elif form == 1 and n.outq is not None and ops.thin_fwd_q_supported(d, a.kind, True, self.dtype):
@@ -769,9 +772,9 @@ class NetPlan:
                     hi32 = sh.out if (sh.outq is None or self._fp32_needed(sh)) else None
                     prog.append(("bn_fwd", lambda x=x, m=m, iv=iv, rm=rm, ri=ri, l=l, upd=upd:
                                  ops.bn_stats(x, m, iv, self.bn_ws, rm if upd else None, ri if upd else None, l.epsilon, l.alpha)))
-                    prog.append(("bn_fwd", lambda x=x, hi32=hi32, hiq=sh.outq, m=m, iv=iv, g=g, be=be, a=a:
+                    prog.append(("bn_fwd", lambda x=x, hi32=hi32, hiq=sh.outq if self.q_epi else None, m=m, iv=iv, g=g, be=be, a=a:
                                  ops.bn_apply_hi(x, hi32, hiq, m, iv, g, be, a.kind, a.alpha)))
-                elif n.outq is not None and x.HW % 2 == 0 and x.nstride % 2 == 0 and y.nstride % 2 == 0:
+                elif n.outq is not None and self.q_epi and x.HW % 2 == 0 and x.nstride % 2 == 0 and y.nstride % 2 == 0:
                     # statistics, then normalise + activation writing the fp32 result AND its q copy in one pass
                     m, iv = n.aux['mean'], n.aux['inv']
                     upd = update_running
@@ -808,8 +811,8 @@ class NetPlan:
                                  ops.conv2d_fwd(d, x, wpc, b4, y4, a.kind, a.alpha), conv_meta(ops, d, 0)))
             elif n.op == 'pp_to_hi':
                 if id(n) in fused_hi:
-                    q_direct = True                                # written by the BatchNorm in front of it
-                elif n.outq is not None and y.nstride % 2 == 0:
+                    q_direct = self.q_epi                          # written by the BatchNorm in front of it
+                elif n.outq is not None and self.q_epi and y.nstride % 2 == 0:
                     q_direct = True
                     y32 = y if self._fp32_needed(n) else None      # every consumer reads the q copy: no fp32 tensor
                     prog.append(("pp_to_hi", lambda x=x, y32=y32, yq=n.outq: ops.pp_to_hi_q(x, y32, yq)))
@@ -826,7 +829,7 @@ class NetPlan:
             elif n.op == 'up_nearest':
                 prog.append(("up_nearest_fwd", lambda x=x, y=y: ops.upsample_nearest2_fwd(x, y)))
             elif n.op == 'up_bilinear':
-                if n.outq is not None:
+                if n.outq is not None and self.q_epi:
                     q_direct = True
                     y32 = y if self._fp32_needed(n) else None
                     prog.append(("up_bilinear_fwd", lambda x=x, y32=y32, yq=n.outq: ops.upsample_bilinear2_fwd_q(x, y32, yq)))
@@ -1034,7 +1037,8 @@ class NetPlan:
                 w_q = xq_ is not None and self._wq(dF)
                 d_lp = self.use_q and need_dx and self._lp(self._desc(n, sl(xin.out), Gf), 1)
                 q_wanted = (wgrad and w_q) or d_lp
-                Gfq = gradq_of(n, Gf, pack=False) if (q_wanted and Gf.Cc % 8 == 0 and Gf.H % 2 == 0 and Gf.W % 4 == 0) else None
+                Gfq = gradq_of(n, Gf, pack=False) if (q_wanted and self.q_epi and Gf.Cc % 8 == 0 and Gf.H % 2 == 0
+                                                      and Gf.W % 4 == 0) else None
                 if Gfq is not None:         # the full-resolution gradient (if anybody reads it) and its q copy in one pass
                     gq_ready.add(id(n))
                     Gf32 = None if ((w_q or not wgrad) and (d_lp or not need_dx)) else Gf
@@ -1251,7 +1255,7 @@ class NetPlan:
                 # the convolution in front of this BatchNorm reads gi as the operand of its low-precision data / weight
                 # gradients: the apply pass writes the q copy itself -- and no fp32 gradient at all when both read q
                 giq, gi32 = None, True
-                if (self.use_q and not acc and nslice is None and self.bn_groups == 1 and xin.op in ('conv', 'upconv')
+                if (self.q_epi and not acc and nslice is None and self.bn_groups == 1 and xin.op in ('conv', 'upconv')
                         and len(xin.consumers) == 1 and xin.act == linear and gi.HW % 2 == 0 and gi.Cc % 8 == 0
                         and gi.nstride % 2 == 0):
                     xx = xin.inputs[0]

@@ -138,7 +138,7 @@ class PolicyOps(RecordingOps):
             return d.Wo % 32 == 0 and d.K >= 32 and d.C * d.kh * d.kw >= 96
         return red % 16 == 0 and rows >= 32 and (d.Wo if kind == 0 else d.W) % 32 == 0
 
-    def lp_weight_bytes(self, d, transposed=False):
+    def lp_weight_bytes(self, d, transposed=False, dtype=None):
         return 256
 
     def wgrad_lp_workspace(self, d):

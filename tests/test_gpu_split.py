@@ -137,3 +137,51 @@ def test_split_data_gradient_is_fp32_arithmetic(gpu, case):
     print("split %.2e   fp32 MFMA %.2e   %s" % (e_split, e_f32, case))
     assert e_split < FP32_BOUND and e_split < max(2 * e_f32, 3e-7), (e_split, e_f32)
     dev.free(wqT)
+
+
+def test_split_train_step_meets_the_fp32_bounds(gpu):
+    """Pix2Pix(dtype='bf16x3'): the joint train step with its served convolutions on the bf16 matrix cores by operand
+    splitting, against the float64 oracle of the same step, at the size where the 5x5 / 3x3 stride-1 and 3x3 stride-2
+    forward and the stride-1 data gradients take the split kernels; beside it the fp32 model (v_mfma_f32_32x32x2_f32) on the
+    same inputs.  Bounds: losses 1e-5 (the fp32 step test's); gradients north_star's 1e-3 AND not worse than the fp32 model's
+    own error on this configuration (its batch-4 BatchNorm chains amplify ANY fp32 rounding to a few 1e-4: measured
+    4.4e-4 split, 6.8e-4 fp32 MFMA)."""
+    from oracle import step as ostep
+    from tests.test_gpu_step import build_model, model_grads, model_params
+    from tests.test_gpu_lp import LP_STEP
+    from gan_heightmaps_amd import layers as L
+    dev, ops, D = gpu
+    cfg = ostep.default_cfg(**LP_STEP)
+    model = build_model(cfg, 7, dev, dtype='bf16x3', use_graph=False)
+    f32 = build_model(cfg, 7, dev, use_graph=False)
+    assert model.engine.loss_scale == 1.0
+    b = model.engine.built(4)
+    kinds = {}
+    for lane in b.train_compute:
+        for e in lane:
+            if len(e) > 2 and e[2] is not None and e[2].get("dtype") == 'bf16x3':
+                kinds[(e[0], e[2]["kernel"])] = kinds.get((e[0], e[2]["kernel"]), 0) + 1
+    labels = {k[0] for k in kinds}
+    assert {"conv_fwd", "conv_dgrad", "upconv_fwd", "upconv_dgrad"} <= labels, kinds
+    state = ostep.init_state(cfg, 7, np.float32)
+    worst = dict(loss=0.0, grad=0.0, loss32=0.0, grad32=0.0)
+    for it in range(3):
+        Z, X, Y = ostep.synthetic_batch(4, cfg, seed=200 + it)
+        ref = ostep.train_step(state, Z, X, Y, dtype=np.float64)
+        got = model.train_fn(Z, X, Y)
+        exact = f32.train_fn(Z, X, Y)
+        worst['loss'] = max(worst['loss'], rel(got, ref['losses']))
+        worst['loss32'] = max(worst['loss32'], rel(exact, ref['losses']))
+        mg, mg32 = model_grads(model), model_grads(f32)
+        for key in ref['grads']:
+            flat_r = np.concatenate([g.ravel() for g in ref['grads'][key]])
+            worst['grad'] = max(worst['grad'], rel(np.concatenate([g.ravel() for g in mg[key]]), flat_r))
+            worst['grad32'] = max(worst['grad32'], rel(np.concatenate([g.ravel() for g in mg32[key]]), flat_r))
+        mp = model_params(f32)
+        for key in ostep.NET_ORDER:
+            state['params'][key[0]][key[1]] = [a.copy() for a in mp[key]]
+        for (a_, b_), vals in mp.items():
+            L.set_all_param_values(getattr(model, a_)[b_], vals)
+    print("split step: worst rel-L2 -- losses %.2e (fp32 MFMA %.2e), gradients %.2e (fp32 MFMA %.2e); kernels %s"
+          % (worst['loss'], worst['loss32'], worst['grad'], worst['grad32'], sorted(kinds)))
+    assert worst['loss'] < 1e-5 and worst['grad'] < 1e-3 and worst['grad'] < 1.5 * worst['grad32'] + 1e-4, worst
