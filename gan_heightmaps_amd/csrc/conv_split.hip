@@ -405,6 +405,213 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient (3x3 stride 1 / 2, 5x5 stride 1; 'same') from split q tensors: dwp[(c, tap)][k] = sum over pixels of
+// x[c, pixel * ST + tap - pad] * dy[k, pixel] -- the structure of lp_wgrad_q_kernel (conv_lp.hip): the contraction runs over
+// pixels while a q unit holds 8 channels of one pixel, so both MFMA operands are read from LDS with the transposing read
+// ds_read_b64_tr_b16; x rows live in a ring (each output row brings ST new rows), the dy strip is double-buffered, both
+// staged global -> LDS by DMA as they lie in HBM, three pieces each.  Block = CHT x CT x KS waves: a wave owns the KS taps
+// of ONE filter row of one (32 channels, 32 filters) tile; per 16-pixel k-step it reads 3 dy fragments and 3 KS x fragments
+// and runs 6 KS MFMAs.
+// ------------------------------------------------------------------------------------------------
+struct SpWgradArgs {
+    const u32x4* xq;
+    long xq_ns, xq_ps;     // units between samples / pieces of x  [piece][N][C/8][H][W]
+    const u32x4* dyq;
+    long dyq_ns, dyq_ps;
+    const u32x4* zeros;
+    float* out;
+    int N, C, H, W, K, Ho, Wo;
+    int rows_per_split, splits_per_col;
+    long split_stride;
+    int accumulate;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4 sp_tr_read8(const char* lds_lo, const char* lds_hi) {
+    typedef s16x4 __attribute__((address_space(3))) * lp4_t;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4_t)lds_lo);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4_t)lds_hi);
+    u32x4 r;
+    r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+    r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+    r.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+    r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+    return r;
+}
+
+template <int KS, int ST, int CHT, int CT, int SPX>
+__global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const SpWgradArgs a) {
+    static_assert((ST == 1 || (ST == 2 && KS == 3)) && (SPX == 64 || SPX == 32 || SPX == 16) && (KS == 3 || KS == 5), "variants");
+    constexpr int T = KS * KS, PADK = KS / 2;
+    constexpr int NWAVES = CHT * CT * KS;
+    constexpr int NPAR = ST;                          // column-parity planes of an x row
+    constexpr int XPIX = ST == 1 ? SPX + KS - 1 : SPX + 1;   // pixels per plane
+    constexpr int XCH = (XPIX + 15) / 16;             // 16-pixel DMA pieces per plane
+    constexpr int PLB = XCH * 16 * 64;                // bytes per plane
+    constexpr int ROWB = CHT * NPAR * PLB;            // bytes per ring row and piece
+    constexpr int NR = KS + ST;                       // ring rows: KS live + ST arriving
+    constexpr int YTB = SPX * 64;                     // bytes per dy filter tile
+    constexpr int YB = CT * YTB;                      // bytes per dy buffer and piece
+    constexpr int KSTEPS = SPX / 16;
+    extern __shared__ __attribute__((aligned(16))) char sp_wsmem[];
+    char* const Xl = sp_wsmem;                        // [ring slot][piece][ROWB]
+    char* const Yl = sp_wsmem + NR * NP * ROWB;       // [buffer][piece][YB]
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / (CHT * CT);                 // this wave's filter row
+    const int wrem = wave % (CHT * CT);
+    const int hh = wrem / CT, ww = wrem % CT;         // this wave's channel group / filter tile
+    const int kg = lane >> 5, li = lane & 31;
+    const int c0 = blockIdx.x * (32 * CHT), k0 = blockIdx.y * (32 * CT);
+    const int strips = a.Wo / SPX;
+    const int col = blockIdx.z / a.splits_per_col, sp = blockIdx.z - col * a.splits_per_col;
+    const int n = col / strips, j0 = (col - n * strips) * SPX;
+    const int i_begin = sp * a.rows_per_split, i_end = min(a.Ho, i_begin + a.rows_per_split);
+    const int HWx = a.H * a.W, HWy = a.Ho * a.Wo;
+    const int xs0 = j0 * ST - PADK;                   // image column of local column 0
+
+    // DMA lane roles inside a 16-pixel piece: pixel pxi, channel block cb4 of the 32-channel group
+    const int pxi = lane >> 2, cb4 = lane & 3;
+    const u32x4* const xbase = a.xq + (long)n * a.xq_ns + (long)(c0 / 8 + cb4) * HWx;
+    const u32x4* const ybase = a.dyq + (long)n * a.dyq_ns + (long)(k0 / 8 + cb4) * HWy;
+
+    auto stage_xrow = [&](int y) {
+        const int slot = (y + NR) % NR;
+        const bool rok = (unsigned)y < (unsigned)a.H;
+#pragma unroll
+        for (int p0 = 0; p0 < NP * CHT * NPAR * XCH; p0 += NWAVES) {
+            const int pq = p0 + wave;
+            if (pq < NP * CHT * NPAR * XCH) {
+                const int piece = pq / (CHT * NPAR * XCH), p = pq - piece * (CHT * NPAR * XCH);
+                const int pl = p / XCH, ch = p - pl * XCH;        // plane = (channel group, parity)
+                const int g = pl / NPAR, par = pl - g * NPAR;
+                const int pp = ch * 16 + pxi;                        // pixel inside the plane
+                const int x = xs0 + (ST == 2 ? 2 * pp + par : pp);
+                const bool ok = rok && (unsigned)x < (unsigned)a.W;
+                const u32x4* src = ok ? xbase + piece * a.xq_ps + (long)(g * 4) * HWx + (long)y * a.W + x : a.zeros;
+                if (pp < XPIX)
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xl + (slot * NP + piece) * ROWB + pl * PLB + ch * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_dy = [&](int i, int buf) {
+#pragma unroll
+        for (int p0 = 0; p0 < NP * CT * (SPX / 16); p0 += NWAVES) {
+            const int pq = p0 + wave;
+            if (pq < NP * CT * (SPX / 16)) {
+                const int piece = pq / (CT * (SPX / 16)), p = pq - piece * (CT * (SPX / 16));
+                const int ct = p / (SPX / 16), ch = p - ct * (SPX / 16);
+                const u32x4* src = ybase + piece * a.dyq_ps + (long)(ct * 4) * HWy + (long)i * a.Wo + j0 + ch * 16 + pxi;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Yl + (buf * NP + piece) * YB + ct * YTB + ch * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[KS];
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    if (i_begin < i_end) {
+#pragma unroll
+        for (int fa = 0; fa < KS; ++fa) stage_xrow(i_begin * ST + fa - PADK);
+        stage_dy(i_begin, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // fragment addressing (transposing reads): 16-lane group g16 -> rows (channels / filters) 16 * (g16 & 1) .. + 15;
+    // lane t of the group supplies the address of pixel key = t >> 2, channel quad t & 3
+    const int g16 = lane >> 4, lt = lane & 15;
+    const int key = lt >> 2, quad = lt & 3;
+    const int lane_off = (8 * kg + key) * 64 + (g16 & 1) * 32 + quad * 8;      // + 4 pixels (256 B) for the upper half
+    const char* const ylane = Yl + ww * YTB + lane_off;
+    const char* const xlane = Xl + hh * NPAR * PLB + lane_off;
+
+    for (int i = i_begin; i < i_end; ++i) {
+        const int buf = (i - i_begin) & 1;
+        if (i + 1 < i_end) {
+#pragma unroll
+            for (int r = 0; r < ST; ++r) stage_xrow(i * ST - PADK + KS + r);        // the rows the next output row adds
+            stage_dy(i + 1, buf ^ 1);
+        }
+        const char* const xr = xlane + (((i * ST + wr - PADK + NR) % NR) * NP) * ROWB;
+        const char* const yb = ylane + buf * NP * YB;
+        // phases (k-step, x piece p = 2, 1, 0): the KS x fragments of piece p meet the dy pieces q <= 2 - p (small terms
+        // first); the next phase's fragments are read behind this phase's MFMAs
+        u32x4 af[2][KS], bf[2][NP];
+        auto read_x = [&](int ks, int p, int slot) {
+#pragma unroll
+            for (int fb = 0; fb < KS; ++fb) {
+                // local column of pixel t' and tap column fb: t' * ST + fb  ->  (parity plane, pixel in plane)
+                const int par = ST == 2 ? (fb & 1) : 0;
+                const int shift = ST == 2 ? (fb >> 1) : fb;
+                const char* pa = xr + p * ROWB + par * PLB + (ks * 16 + shift) * 64;
+                af[slot][fb] = sp_tr_read8(pa, pa + 256);
+            }
+        };
+        auto read_dy = [&](int ks, int slot) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) bf[slot][q] = sp_tr_read8(yb + q * YB + ks * 1024, yb + q * YB + ks * 1024 + 256);
+        };
+        read_dy(0, 0);
+        read_x(0, 2, 0);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+            for (int pi = 0; pi < NP; ++pi) {
+                const int p = 2 - pi, ph = ks * NP + pi;
+                int nreads = 0;
+                if (pi + 1 < NP) {
+                    read_x(ks, p - 1, (ph + 1) & 1);
+                    nreads = KS;
+                } else if (ks + 1 < KSTEPS) {
+                    read_dy(ks + 1, (ks + 1) & 1);
+                    read_x(ks + 1, 2, (ph + 1) & 1);
+                    nreads = KS + NP;
+                }
+#pragma unroll
+                for (int q = 0; q <= 2 - p; ++q)
+#pragma unroll
+                    for (int t = 0; t < KS; ++t) acc[t] = sp_mfma(af[ph & 1][t], bf[ks & 1][q], acc[t]);
+                // spread the next phase's reads (two transposing reads per fragment) behind this phase's MFMAs
+#pragma unroll
+                for (int m_ = 0; m_ < nreads; ++m_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = filter k0 + 32 ww + li; rows = channels c0 + 32 hh + (e & 3) + 8 (e >> 2) + 4 kg ----
+    float* const ob = a.out + (long)blockIdx.z * a.split_stride;
+    const int kcol = k0 + ww * 32 + li;
+    if (kcol >= a.K) return;
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = c0 + hh * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+            const int tap = wr * KS + t;
+            if (c < a.C) {
+                float* o = ob + ((long)c * T + tap) * a.K + kcol;
+                float v = acc[t][e];
+                if (a.accumulate) v += *o;
+                *o = v;
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -514,6 +721,90 @@ int sp_launch_conv(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, int ks, int st,
     return 0;
 }
 
+// ---- weight gradient plan: one round of resident blocks (a block per CU) ----
+struct SpWPlan {
+    bool ok;
+    int cht, ct, spx, splits_per_col, rows_per_split, ncols;
+    size_t lds;
+};
+
+size_t sp_wgrad_lds(int ks, int st, int cht, int ct, int spx) {
+    const int xpix = st == 1 ? spx + ks - 1 : spx + 1, xch = (xpix + 15) / 16;
+    const size_t rowb = (size_t)cht * st * xch * 16 * 64, yb = (size_t)ct * spx * 64;
+    return NP * ((ks + st) * rowb + 2 * yb);
+}
+
+SpWPlan sp_wplan(const ghm_conv_desc* d, int num_cu) {
+    SpWPlan v;
+    memset(&v, 0, sizeof(v));
+    if (GHM_OPT("GHM_NO_SPLIT") || GHM_OPT("GHM_NO_SPLIT_WGRAD")) return v;
+    const bool k3 = d->kh == 3 && d->kw == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2);
+    const bool k5 = d->kh == 5 && d->kw == 5 && d->pad == 2 && d->stride == 1;
+    if (!k3 && !k5) return v;
+    if (d->Ho != (d->H + d->stride - 1) / d->stride || d->Wo != (d->W + d->stride - 1) / d->stride) return v;
+    if (d->Wo % 32 || d->C % 8 || d->K % 8) return v;
+    if (k5) {                                   // 10 waves: 5 filter rows x 2 filter tiles of one 32-channel group
+        if (d->K % 64 || d->C % 32) return v;
+        v.cht = 1; v.ct = 2; v.spx = d->Wo % 64 == 0 ? 64 : 32;
+    } else if (d->stride == 1) {                // 12 waves: 3 filter rows x (2 channel groups x 2 filter tiles)
+        if (d->K % 64 || d->C % 64) return v;
+        v.cht = 2; v.ct = 2; v.spx = 32;
+    } else {                                    // stride 2 (two parity planes per x row): 12 waves, 1 x 4
+        if (d->K % 128 || d->C % 32) return v;
+        v.cht = 1; v.ct = 4; v.spx = 32;
+    }
+    v.lds = sp_wgrad_lds(d->kh, d->stride, v.cht, v.ct, v.spx);
+    if (v.lds > 160 * 1024) return v;
+    v.ncols = d->N * (d->Wo / v.spx);
+    const long tiles = (long)(d->C / (32 * v.cht)) * (d->K / (32 * v.ct)) * v.ncols;
+    long S = num_cu / tiles;
+    if (const char* f = GHM_OPT("GHM_SPLIT_WGRAD_ROUNDS")) S = (long)(atof(f) * num_cu / tiles);      // tuning
+    const long minrows = d->kh == 5 ? 8 : 4;
+    const long max_by_work = d->Ho / minrows > 0 ? d->Ho / minrows : 1;
+    if (S > max_by_work) S = max_by_work;
+    if (S < 1) S = 1;
+    v.rows_per_split = (int)((d->Ho + S - 1) / S);
+    v.splits_per_col = (d->Ho + v.rows_per_split - 1) / v.rows_per_split;
+    v.ok = true;
+    return v;
+}
+
+int sp_launch_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const SpWPlan& v, const void* xq, long xq_ns, long xq_ps,
+                    const void* dyq, long dyq_ns, long dyq_ps, float* dwp, void* workspace, int accumulate) {
+    SpWgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xq = (const u32x4*)xq; a.xq_ns = xq_ns; a.xq_ps = xq_ps; a.dyq = (const u32x4*)dyq; a.dyq_ns = dyq_ns; a.dyq_ps = dyq_ps;
+    a.zeros = (const u32x4*)ctx->zeros;
+    a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.K = d->K; a.Ho = d->Ho; a.Wo = d->Wo;
+    a.rows_per_split = v.rows_per_split; a.splits_per_col = v.splits_per_col;
+    const long n = (long)d->C * d->kh * d->kw * d->K;
+    const int splits = v.ncols * v.splits_per_col;
+    if (splits > 1) {
+        GHM_CHECK(workspace != nullptr, "split-fp32 weight gradient needs a workspace for %d splits", splits);
+        a.out = (float*)workspace; a.split_stride = n; a.accumulate = 0;
+    } else {
+        a.out = dwp; a.split_stride = 0; a.accumulate = accumulate;
+    }
+    const dim3 grid(d->C / (32 * v.cht), d->K / (32 * v.ct), splits);
+#define GHM_SPW_CASE(KS_, ST_, CHT_, CT_, SPX_)                                                                     \
+    if (d->kh == KS_ && d->stride == ST_ && v.cht == CHT_ && v.ct == CT_ && v.spx == SPX_) {                       \
+        if (int e = sp_set_lds(sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_>, v.lds)) return e;                        \
+        hipLaunchKernelGGL((sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_>), grid, dim3(CHT_ * CT_ * KS_ * 64), v.lds, \
+                           ctx->stream, a);                                                                       \
+        GHM_LAUNCH_CHECK();                                                                                       \
+    } else
+    GHM_SPW_CASE(3, 1, 2, 2, 32)
+    GHM_SPW_CASE(3, 2, 1, 4, 32)
+    GHM_SPW_CASE(5, 1, 1, 2, 64)
+    GHM_SPW_CASE(5, 1, 1, 2, 32) {
+        ghm_set_error("no split-fp32 weight gradient variant for k=%d s=%d cht=%d ct=%d spx=%d", d->kh, d->stride, v.cht, v.ct, v.spx);
+        return -3;
+    }
+#undef GHM_SPW_CASE
+    if (splits > 1) return ghm_reduce_splits(ctx, (const float*)workspace, splits, n, n, dwp, accumulate);
+    return 0;
+}
+
 bool sp_fwd_geom(const ghm_conv_desc* d) {
     return d->kh == d->kw && 2 * d->pad == d->kh - 1 && ((d->stride == 1 && d->Ho == d->H && d->Wo == d->W) ||
                                                           (d->stride == 2 && d->H == 2 * d->Ho && d->W == 2 * d->Wo));
@@ -530,7 +821,29 @@ int ghm_split_supported(const ghm_conv_desc* d, int32_t kind) {
     if (kind == 0) return sp_fwd_geom(d) && sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ghm_plan_cus()).ok;
     if (kind == 1)
         return d->stride == 1 && sp_fwd_geom(d) && sp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ghm_plan_cus()).ok;
+    if (kind == 2) return sp_wplan(d, ghm_plan_cus()).ok;
     return 0;
+}
+
+// bytes of the workspace ghm_conv2d_wgrad_split needs (split partials, summed in fixed order)
+int ghm_conv2d_wgrad_split_workspace(const ghm_conv_desc* d, size_t* bytes) {
+    GHM_CHECK(d && bytes, "null argument");
+    const SpWPlan v = sp_wplan(d, ghm_plan_cus());
+    const size_t n = (size_t)d->C * d->kh * d->kw * d->K;
+    *bytes = v.ok ? (size_t)v.ncols * v.splits_per_col * n * sizeof(float) : 16;
+    return 0;
+}
+
+// dwp (+)= the weight gradient in the packed layout wp[c][tap][k], from the split q tensors of x and dy
+int ghm_conv2d_wgrad_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void* xq, int64_t xq_nstride, int64_t xq_pstride,
+                           const void* dyq, int64_t dyq_nstride, int64_t dyq_pstride, float* dwp, void* workspace,
+                           int32_t accumulate) {
+    GHM_CHECK(ctx && d && xq && dyq && dwp, "null argument");
+    GHM_CHECK(ghm_split_supported(d, 2), "ghm_conv2d_wgrad_split: geometry not served (ask ghm_split_supported)");
+    GHM_CHECK((((uintptr_t)xq | (uintptr_t)dyq) & 15) == 0, "ghm_conv2d_wgrad_split: q tensors are 16-byte aligned");
+    const SpWPlan v = sp_wplan(d, ghm_plan_cus());
+    return sp_launch_wgrad(ctx, d, v, xq, (long)xq_nstride, (long)xq_pstride, dyq, (long)dyq_nstride, (long)dyq_pstride, dwp,
+                           workspace, accumulate);
 }
 
 int ghm_split_weight_bytes(const ghm_conv_desc* d, int32_t transposed, size_t* bytes) {

@@ -555,9 +555,10 @@ class Ops:
              int(accumulate), DTYPE_CODES[dtype])
 
     def wgrad_lp_workspace(self, d):
-        n = C.c_size_t()
+        n, m = C.c_size_t(), C.c_size_t()
         call("ghm_conv2d_wgrad_lp_workspace", C.byref(d), C.byref(n))
-        return n.value
+        call("ghm_conv2d_wgrad_split_workspace", C.byref(d), C.byref(m))
+        return max(n.value, m.value)
 
     def conv2d_wgrad_lp(self, d, x, dy, dwp, ws, dtype, accumulate=False):
         call("ghm_conv2d_wgrad_lp", self.h, C.byref(d), _vp(x), _vp(dy), _vp(dwp), _vp(ws), int(accumulate),
@@ -687,6 +688,9 @@ class Ops:
         return bool(_lib.load().ghm_lp_wgrad_q_supported(C.byref(d), DTYPE_CODES[dtype]))
 
     def conv2d_wgrad_lp_q(self, d, xq, dyq, dwp, ws, dtype, accumulate=False):
+        if dtype == SPLIT:
+            return call("ghm_conv2d_wgrad_split", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, xq.pstride,
+                        C.c_void_p(dyq.ptr), dyq.nstride, dyq.pstride, _vp(dwp), _vp(ws), int(accumulate))
         call("ghm_conv2d_wgrad_lp_q", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, C.c_void_p(dyq.ptr), dyq.nstride,
              _vp(dwp), _vp(ws), int(accumulate), DTYPE_CODES[dtype])
 

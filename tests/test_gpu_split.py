@@ -139,6 +139,47 @@ def test_split_data_gradient_is_fp32_arithmetic(gpu, case):
     dev.free(wqT)
 
 
+WGRAD_CASES = [
+    # N, C, H, W, K, k, s, pad
+    (2, 64, 32, 32, 64, 3, 1, 1),      # 3x3 stride 1: 12 waves, one strip
+    (1, 128, 16, 64, 192, 3, 1, 1),    # two strips, several channel / filter tiles
+    (2, 32, 64, 64, 128, 3, 2, 1),     # 3x3 stride 2 (two parity planes per x row)
+    (1, 64, 32, 128, 256, 3, 2, 1),    # stride 2, rectangular
+    (2, 32, 32, 64, 64, 5, 1, 2),      # 5x5: ten waves, 64-pixel strips
+    (1, 64, 16, 32, 128, 5, 1, 2),     # 5x5, 32-pixel strips
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_split_weight_gradient_is_fp32_arithmetic(gpu, case):
+    """ghm_conv2d_wgrad_split (from the split q tensors of x and dy) against the float64 oracle, beside ghm_conv2d_wgrad
+    (fp32 MFMA) on the same inputs; also the accumulate form"""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(sum(case) + 2)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    assert ops.split_supported(d, 2)
+    x = (rng.randn(N, C, H, W) * np.exp(rng.randn(N, C, 1, 1))).astype(np.float32)
+    dy = (rng.randn(N, K, d.Ho, d.Wo) * np.exp(rng.randn(N, K, 1, 1))).astype(np.float32)
+    ref = O.conv2d_vjp(x.astype(np.float64), np.zeros((K, C, k, k)), dy.astype(np.float64), s, pad)[1]
+    xd, dyd = dev.tensor(x), dev.tensor(dy)
+    xq, dyq = D.QTensor.empty(dev, x.shape, 'bf16x3'), D.QTensor.empty(dev, dy.shape, 'bf16x3')
+    ops.q_pack(xd, xq)
+    ops.q_pack(dyd, dyq)
+    assert np.array_equal(xq.numpy(), x) and np.array_equal(dyq.numpy(), dy)
+    ws = dev.alloc(max(ops.wgrad_lp_workspace(d), ops.wgrad_workspace(d), 16))
+    dw = dev.zeros((1, C * k * k * K, 1, 1))
+    ops.conv2d_wgrad_lp_q(d, xq, dyq, dw, ws, 'bf16x3')
+    got = D.unpack_conv_w(dw.numpy().ravel(), K, C, k, k)
+    dw32 = dev.zeros((1, C * k * k * K, 1, 1))
+    ops.conv2d_wgrad(d, xd, dyd, dw32, ws)
+    e_split, e_f32 = rel(got, ref), rel(D.unpack_conv_w(dw32.numpy().ravel(), K, C, k, k), ref)
+    print("split %.2e   fp32 MFMA %.2e   %s" % (e_split, e_f32, case))
+    assert e_split < FP32_BOUND and e_split < max(2 * e_f32, 3e-7), (e_split, e_f32)
+    ops.conv2d_wgrad_lp_q(d, xq, dyq, dw, ws, 'bf16x3', accumulate=True)
+    assert rel(D.unpack_conv_w(dw.numpy().ravel(), K, C, k, k), 2 * ref) < FP32_BOUND
+
+
 def test_split_train_step_meets_the_fp32_bounds(gpu):
     """Pix2Pix(dtype='bf16x3'): the joint train step with its served convolutions on the bf16 matrix cores by operand
     splitting, against the float64 oracle of the same step, at the size where the 5x5 / 3x3 stride-1 and 3x3 stride-2
@@ -162,7 +203,7 @@ def test_split_train_step_meets_the_fp32_bounds(gpu):
             if len(e) > 2 and e[2] is not None and e[2].get("dtype") == 'bf16x3':
                 kinds[(e[0], e[2]["kernel"])] = kinds.get((e[0], e[2]["kernel"]), 0) + 1
     labels = {k[0] for k in kinds}
-    assert {"conv_fwd", "conv_dgrad", "upconv_fwd", "upconv_dgrad"} <= labels, kinds
+    assert {"conv_fwd", "conv_dgrad", "conv_wgrad", "upconv_fwd", "upconv_dgrad"} <= labels, kinds
     state = ostep.init_state(cfg, 7, np.float32)
     worst = dict(loss=0.0, grad=0.0, loss32=0.0, grad32=0.0)
     for it in range(3):

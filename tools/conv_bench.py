@@ -62,6 +62,11 @@ def main():
             fns["fwd"] = lambda: ops.conv2d_fwd_split(d, x, wq, b, y, 'lrelu', 0.2, xq=xq if pre else None)
         if ops.split_supported(d, 1):
             fns["dgrad_t"] = lambda: ops.conv2d_dgrad_split(d, y, wqT, dx, dyq=yq if pre else None)
+        if ops.split_supported(d, 2):
+            xQ = D.QTensor(dev, xs, x.shape, 'bf16x3')
+            yQ = D.QTensor(dev, ys, y.shape, 'bf16x3')
+            ws_sp = dev.alloc(max(ops.wgrad_lp_workspace(d), 16))
+            fns["wgrad"] = lambda: ops.conv2d_wgrad_lp_q(d, xQ, yQ, dw, ws_sp, 'bf16x3')
     elif args.dtype != "f32":
         dt = args.dtype
         wq = dev.alloc(ops.lp_weight_bytes(d, False))
