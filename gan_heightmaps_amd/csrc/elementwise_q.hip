@@ -28,6 +28,29 @@ __device__ __forceinline__ u32x4q q_pack8(const float* v, int dt) {
     return w;
 }
 
+// dt == 3 (host side 'bf16x3', the split-fp32 mode of csrc/conv_split.hip): the fp32 value as three bf16 pieces, in three
+// planes ``ps`` units apart (a producer writes whole tensors: ps = samples x sample stride of the q tensor)
+__device__ __forceinline__ void q_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    f32x2q v = {a, b};
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2q));
+    f32x2q r = {a - __uint_as_float(p0 << 16), b - __uint_as_float(p0 & 0xffff0000u)};
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2q));
+    f32x2q r2 = {r[0] - __uint_as_float(p1 << 16), r[1] - __uint_as_float(p1 & 0xffff0000u)};
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2q));
+}
+__device__ __forceinline__ void q_store8(u32x4q* o, const float* v, int dt, long ps) {
+    if (dt == 3) {
+        unsigned a[4], b[4], c[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q_split2(v[2 * t], v[2 * t + 1], a[t], b[t], c[t]);
+        o[0] = u32x4q{a[0], a[1], a[2], a[3]};
+        o[ps] = u32x4q{b[0], b[1], b[2], b[3]};
+        o[2 * ps] = u32x4q{c[0], c[1], c[2], c[3]};
+    } else {
+        *o = q_pack8(v, dt);
+    }
+}
+
 // decode idx -> (n, channel block, item) with ``items`` items per (n, block)
 __device__ __forceinline__ bool q_decode(long idx, int N, int C8, long items, int& n, int& cb, long& it) {
     if (idx >= (long)N * C8 * items) return false;
@@ -57,9 +80,10 @@ __global__ __launch_bounds__(256) void bn_apply_q_kernel(const float* __restrict
         v1[j] = ghm_act(fmaf(t.y - m, sc, be), act, alpha);
         if (y) *reinterpret_cast<float2*>(y + (long)n * ys + (long)c * HW + 2 * p2) = make_float2(v0[j], v1[j]);
     }
+    const long ps = (long)N * qns;
     u32x4q* o = q + (long)n * qns + (long)cb * HW + 2 * p2;
-    o[0] = q_pack8(v0, dt);
-    o[1] = q_pack8(v1, dt);
+    q_store8(o, v0, dt, ps);
+    q_store8(o + 1, v1, dt, ps);
 }
 
 // dx = gamma * inv * (dout * act'(y) - mean(dz) - xhat * mean(dz * xhat)): thread = 8 channels x 2 pixels
@@ -93,9 +117,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_q_kernel(const float* __rest
         v1[j] = g * (d.y * ghm_dact_from_out(yy.y, act, alpha) - mb - (xx.y - m) * iv * mg);
         if (dx) *reinterpret_cast<float2*>(dx + (long)n * dxs + o) = make_float2(v0[j], v1[j]);
     }
+    const long ps = (long)N * qns;
     u32x4q* o = q + (long)n * qns + (long)cb * HW + 2 * p2;
-    o[0] = q_pack8(v0, dt);
-    o[1] = q_pack8(v1, dt);
+    q_store8(o, v0, dt, ps);
+    q_store8(o + 1, v1, dt, ps);
 }
 
 // Theano bilinear 2x (layers.py:13-26; elementwise.hip up_bilinear_fwd_kernel): thread = 8 channels x one coarse pixel,
@@ -126,11 +151,12 @@ __global__ __launch_bounds__(256) void up_bilinear_fwd_q_kernel(const float* __r
             *reinterpret_cast<float2*>(o + 2 * W) = make_float2(a10[k], a11[k]);
         }
     }
+    const long ps = (long)N * qns;
     u32x4q* o = q + (long)n * qns + (long)cb * 4 * hw + (long)(2 * i) * (2 * W) + 2 * j;
-    o[0] = q_pack8(a00, dt);
-    o[1] = q_pack8(a01, dt);
-    o[2 * W] = q_pack8(a10, dt);
-    o[2 * W + 1] = q_pack8(a11, dt);
+    q_store8(o, a00, dt, ps);
+    q_store8(o + 1, a01, dt, ps);
+    q_store8(o + 2 * W, a10, dt, ps);
+    q_store8(o + 2 * W + 1, a11, dt, ps);
 }
 
 // pp [4N, K, H, W] (parity-planar output of a collapsed up-sample convolution) -> hi [N, K, 2H, 2W]
@@ -154,11 +180,12 @@ __global__ __launch_bounds__(256) void pp_to_hi_q_kernel(const float* __restrict
             *reinterpret_cast<float2*>(dst + 2 * W) = make_float2(a[2][k], a[3][k]);
         }
     }
+    const long ps = (long)N * qns;
     u32x4q* o = q + (long)n * qns + (long)kb * 4 * hw + (long)(2 * yy) * (2 * W) + 2 * xx;
-    o[0] = q_pack8(a[0], dt);
-    o[1] = q_pack8(a[1], dt);
-    o[2 * W] = q_pack8(a[2], dt);
-    o[2 * W + 1] = q_pack8(a[3], dt);
+    q_store8(o, a[0], dt, ps);
+    q_store8(o + 1, a[1], dt, ps);
+    q_store8(o + 2 * W, a[2], dt, ps);
+    q_store8(o + 2 * W + 1, a[3], dt, ps);
 }
 
 // ---- BatchNorm of a collapsed up-sample convolution fused with the parity interleave (dcgan.default_generator,
@@ -193,11 +220,12 @@ __global__ __launch_bounds__(256) void bn_apply_hi_kernel(const float* __restric
         }
     }
     if (q) {
-        u32x4q* o = q + (long)n * qns + (long)kb * 4 * hw + (long)(2 * yy) * (2 * W) + 2 * xx;
-        o[0] = q_pack8(a[0], dt);
-        o[1] = q_pack8(a[1], dt);
-        o[2 * W] = q_pack8(a[2], dt);
-        o[2 * W + 1] = q_pack8(a[3], dt);
+        const long ps = (long)N * qns;
+    u32x4q* o = q + (long)n * qns + (long)kb * 4 * hw + (long)(2 * yy) * (2 * W) + 2 * xx;
+        q_store8(o, a[0], dt, ps);
+        q_store8(o + 1, a[1], dt, ps);
+        q_store8(o + 2 * W, a[2], dt, ps);
+        q_store8(o + 2 * W + 1, a[3], dt, ps);
     }
 }
 
@@ -277,7 +305,7 @@ __global__ __launch_bounds__(256) void bn_bwd_hi_apply(const float* __restrict__
     }
     if (q) {        // the parity-planar tensor seen as [N, 4K, H, W]: sample n, channel block p * K8 + kb
 #pragma unroll
-        for (int p = 0; p < 4; ++p) q[((long)n * 4 + p) * K8 * hw + (long)kb * hw + px] = q_pack8(a[p], dt);
+        for (int p = 0; p < 4; ++p) q_store8(q + ((long)n * 4 + p) * K8 * hw + (long)kb * hw + px, a[p], dt, (long)N * 4 * K8 * hw);
     }
 }
 
@@ -327,11 +355,12 @@ __global__ __launch_bounds__(256) void maxpool2_mask_bwd_q_kernel(const unsigned
         }
     }
     if (live) {
-        u32x4q* o = q + (long)n * qns + (long)cb * hw + (long)(2 * i) * W + 4 * j2;
+        const long ps = (long)N * qns;
+    u32x4q* o = q + (long)n * qns + (long)cb * hw + (long)(2 * i) * W + 4 * j2;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            o[f] = q_pack8(r0[f], dt);
-            o[W + f] = q_pack8(r1[f], dt);
+            q_store8(o + f, r0[f], dt, ps);
+            q_store8(o + W + f, r1[f], dt, ps);
         }
     }
     if constexpr (BIAS) {
@@ -360,7 +389,7 @@ __global__ __launch_bounds__(64) void q_rows_sum_kernel(const float* __restrict_
     if (threadIdx.x == 0) out[c] = (accumulate ? out[c] : 0.f) + s;
 }
 
-inline bool q_dtype_ok(int dt) { return dt == GHM_DTYPE_BF16 || dt == GHM_DTYPE_F16; }
+inline bool q_dtype_ok(int dt) { return dt == GHM_DTYPE_BF16 || dt == GHM_DTYPE_F16 || dt == 3; }
 
 }  // namespace
 

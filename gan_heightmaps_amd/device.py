@@ -11,6 +11,7 @@ DTYPE_CODES = {'f32': 0, 'bf16': 1, 'f16': 2}       # GHM_DTYPE_* (include/ghm.h
 # 'bf16x3': fp32 arithmetic on the bf16 matrix cores by operand splitting (csrc/conv_split.hip) -- a host-side name: Ops
 # routes the *_lp / *_lp_q calls made with it to the ghm_*_split entry points, and a QTensor of this dtype is three planes
 SPLIT = 'bf16x3'
+DTYPE_CODES[SPLIT] = 3     # understood by the q-epilogue producers (csrc/elementwise_q.hip) only
 
 
 def device_count():
