@@ -87,6 +87,10 @@ MAX_TIMERS = 4096       # csrc/common.h GHM_MAX_TIMERS: recorded timer slots wra
 SECONDARY = [
     # (name, overrides): BASELINE.json configs 1-5 beside the fp32 headline, each a short timed loop of its own AFTER the
     # headline's timed region (never inside it), printed under one "secondary" key of the same JSON line
+    # the headline workload with the fp32 convolution products on the bf16 matrix cores by operand splitting (three bf16
+    # pieces per fp32 operand, six products, fp32 accumulation: fp32-accurate, tests/test_gpu_split.py) -- opt-in, so a
+    # secondary line; the headline stays on v_mfma_f32_32x32x2_f32
+    ("headline_workload_fp32_by_bf16x3_splitting", dict(dtype="bf16x3")),
     ("config4_per_gpu_bf16_512_b4", dict(dtype="bf16")),
     ("config5_per_gpu_f16_1024_b2", dict(dtype="f16", in_shp=1024, batch_per_gpu=2)),
     ("config2_dcgan_512_b4_f32", dict(mode="dcgan")),

@@ -166,11 +166,14 @@ struct SpConvArgs {
 
 constexpr int NP = 3;
 
-template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL = false>
+template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL = false, int TW = 32>
 __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvArgs a) {
+    // TW = columns of the pixel tile (32, or 16 / 8 for narrow maps): the 32 pixel lanes of a fragment cover RPF = 32 / TW
+    // consecutive rows of TW columns; the block's tile is (RT * RPF) rows x TW columns
     constexpr int T = KS * KS;
+    constexpr int RPF = 32 / TW, ROWS = RT * RPF;
     constexpr int TM = BM / (WM * 32), TN = RT / WN;
-    constexpr int PH = (RT - 1) * ST + KS, PW = 31 * ST + KS;
+    constexpr int PH = (ROWS - 1) * ST + KS, PW = (TW - 1) * ST + KS;
     constexpr int PU1 = 2 * PH * PW, PUNITS = NP * PU1;          // one piece / all pieces of a slab's patch
     constexpr int WU1 = 2 * KS * BM, WUNITS = NP * WU1;          // one piece / all pieces of a filter row's weights
     constexpr int NW = WM * WN, NT = NW * 64;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
     const int wm = wave / WN, wn = wave % WN;
     const int kg = lane >> 5, li = lane & 31;
     const int ntr = (a.R + BM - 1) / BM;
-    const int tiles_x = a.W / 32, tiles_y = a.H / RT;
+    const int tiles_x = a.W / TW, tiles_y = a.H / ROWS;
     int L = sp_xcd_remap(blockIdx.x, gridDim.x);
     const int r0 = (L % ntr) * BM;
     L /= ntr;
@@ -193,7 +196,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
     L /= tiles_x;
     const int ty = L % tiles_y;
     const int n = L / tiles_y;
-    const int y0 = ty * RT, x0 = tx * 32;
+    const int y0 = ty * ROWS, x0 = tx * TW;
+    const int lx = li % TW, ly = li / TW;                 // this lane's pixel inside a fragment
     const int HW = a.H * a.W, HWin = a.Hin * a.Win;
     const int nslabs = a.CH / 16;
     const int s_begin = blockIdx.y * a.slabs_per_split;
@@ -241,13 +245,16 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
             }
     };
 
-    f32x16 acc[TM][TN];
+    // two accumulators per tile: the leading product x0 w0, and the five correction products (2^-8 ... 2^-16 of it).  Every
+    // MFMA rounds its sum to the magnitude of ITS accumulator: with one accumulator the five small products would each add a
+    // rounding error the size of the big sum's (measured 1.8x the fp32 MFMA kernel's error on the 5x5 layers)
+    f32x16 acc[TM][TN], accc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = accc[i][j][e] = 0.f;
 
     if (s_begin < s_end) {
         stage_weights(s_begin, 0, 0);
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
     __syncthreads();
 
     const int wlane = kg * KS * BM + wm * (BM / WM) + li;
-    const int plane = kg * PH * PW + (wn * TN * ST) * PW + li * ST;
+    const int plane = kg * PH * PW + ((wn * TN * RPF + ly) * ST) * PW + lx * ST;
     int it = 0;
     for (int s = s_begin; s < s_end; ++s) {
         const int pbuf = (s - s_begin) & 1;
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[0][p][i] = Wb[p * WU1 + i * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[0][p][j] = Pb[p * PU1 + j * ST * PW];
+                for (int j = 0; j < TN; ++j) bf[0][p][j] = Pb[p * PU1 + j * RPF * ST * PW];
             }
 #pragma unroll
             for (int b = 0; b < KS; ++b) {
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
 #pragma unroll
                         for (int i = 0; i < TM; ++i) af[(b + 1) & 1][p][i] = Wb[p * WU1 + (b + 1) * BM + i * 32];
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) bf[(b + 1) & 1][p][j] = Pb[p * PU1 + j * ST * PW + b + 1];
+                        for (int j = 0; j < TN; ++j) bf[(b + 1) & 1][p][j] = Pb[p * PU1 + j * RPF * ST * PW + b + 1];
                     }
                 }
                 // the six products, small terms first; consecutive MFMAs go to different accumulators
@@ -298,8 +305,12 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = sp_mfma(af[b & 1][PA[pr]][i], bf[b & 1][PB[pr]][j], acc[i][j]);
+                        for (int j = 0; j < TN; ++j) {
+                            if (pr < 5)
+                                accc[i][j] = sp_mfma(af[b & 1][PA[pr]][i], bf[b & 1][PB[pr]][j], accc[i][j]);
+                            else
+                                acc[i][j] = sp_mfma(af[b & 1][0][i], bf[b & 1][0][j], acc[i][j]);
+                        }
                 }
                 if (b + 1 < KS) {
 #pragma unroll
@@ -316,12 +327,18 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
     }
 
     // ---- epilogue (fp32): lanes along pixels; row of element e of tile i: i*32 + (e&3) + 8*(e>>2) + 4*kg ----
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] += accc[i][j][e];
     const long P = (long)a.N * HW;
     const int ru = r0 + wm * (BM / WM);
     const int rl = ru + 4 * kg;
     if (a.partial) {
-        float* const pb = a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HW + (long)(y0 + wn * TN) * a.W + x0;
-        const unsigned lo = 4u * kg * (unsigned)P + li;
+        float* const pb = a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HW + (long)(y0 + wn * TN * RPF) * a.W + x0;
+        const unsigned lo = 4u * kg * (unsigned)P + ly * a.W + lx;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -329,7 +346,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                    float* rowp = pb + (long)k * P + j * a.W;
+                    float* rowp = pb + (long)k * P + j * RPF * a.W;
                     if (rl + k < a.R) rowp[lo] = acc[i][j][e];
                 }
         return;
@@ -342,7 +359,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
     const bool pwl = a.act == GHM_ACT_LINEAR || a.act == GHM_ACT_RELU || a.act == GHM_ACT_LRELU;
     if constexpr (POOL) {
         // 2x2 max-pool of act(conv + bias): the row pair of a window is in one lane, the column pair in lanes (2t, 2t+1)
-        static_assert(!POOL || (TN % 2 == 0 && ST == 1), "pooled epilogue: row pairs inside a wave");
+        static_assert(!POOL || (TN % 2 == 0 && ST == 1 && TW == 32), "pooled epilogue: row pairs inside a wave, 32-column tiles");
         const int Wp = a.W / 2;
         const long HWp = (long)(a.H / 2) * Wp;
         const long pix = (long)((y0 + wn * TN) / 2) * Wp + (x0 + li) / 2;
@@ -370,8 +387,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
                 }
         return;
     }
-    float* const ub = a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN) * a.W + x0;
-    const unsigned lo = 4u * kg * (unsigned)HW + li;
+    float* const ub = a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN * RPF) * a.W + x0;
+    const unsigned lo = 4u * kg * (unsigned)HW + ly * a.W + lx;
     const bool full = r0 + BM <= a.R;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -387,7 +404,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                    if (full || rl + k < a.R) v[e] += (ub + (long)k * HW + j * a.W)[lo];
+                    if (full || rl + k < a.R) v[e] += (ub + (long)k * HW + j * RPF * a.W)[lo];
                 }
             }
             if (pwl) {
@@ -400,7 +417,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                if (full || rl + k < a.R) (ub + (long)k * HW + j * a.W)[lo] = v[e];
+                if (full || rl + k < a.R) (ub + (long)k * HW + j * RPF * a.W)[lo] = v[e];
             }
         }
 }
@@ -612,20 +629,218 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Data gradient of a 3x3 / stride-2 / pad-1 convolution (U-Net encoder, PatchGAN; architectures/p2p.py:20-21) from the split
+// q tensor of dy -- the structure of lp_dgrad_s2_kernel (conv_lp.hip): dx[c, 2i+pu, 2j+pv] only receives the taps whose
+// parity matches, so the four output parity classes are four small stride-1 gathers over the SAME dy patch; a block
+// computes all four classes of BM channels x (RT x 32) class pixels, every k-step (16 dy channels, one tap) feeds exactly
+// one class.  The (TN + 1) x 2 distinct dy fragments of a wave's rows are read once per slab (three pieces each) and kept
+// in registers; a tap reads the three pieces of its weight fragment and runs six MFMAs per pixel tile.
+// a.in_q = dy [N, CH=K, Hc, Wc], a.out = dx [N, R=C, 2Hc, 2Wc] (a.H, a.W = dx grid; a.Hin, a.Win = class grid).
+// ------------------------------------------------------------------------------------------------
+struct SpDgradS2Extra {
+    const float* dact_y;      // out *= act'(dact_y): the backward of the producer's nonlinearity in this epilogue (or null)
+    long dact_nstride;
+    float dact_alpha;
+};
+
+template <int BM, int RT>
+__global__ __launch_bounds__(256, 1) void sp_dgrad_s2_kernel(const SpConvArgs a, const SpDgradS2Extra x) {
+    constexpr int T = 9, WM = 2, WN = 2;
+    constexpr int TM = BM / (WM * 32), TN = RT / WN;
+    constexpr int PH = RT + 1, PW = 33;
+    constexpr int PU1 = 2 * PH * PW, PUNITS = NP * PU1;
+    constexpr int WU1 = 2 * T * BM, WUNITS = NP * WU1;
+    constexpr int NQ = (PU1 + 255) / 256;
+    constexpr int NI = WU1 / 64;
+    extern __shared__ __attribute__((aligned(16))) u32x4 sp_smem[];
+    u32x4* const Wl = sp_smem;
+    u32x4* const Pl = sp_smem + 2 * WUNITS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int kg = lane >> 5, li = lane & 31;
+    const int Hc = a.Hin, Wc = a.Win;
+    const int ntr = (a.R + BM - 1) / BM;
+    const int tiles_x = Wc / 32, tiles_y = Hc / RT;
+    int L = sp_xcd_remap(blockIdx.x, gridDim.x);
+    const int r0 = (L % ntr) * BM;
+    L /= ntr;
+    const int tx = L % tiles_x;
+    L /= tiles_x;
+    const int ty = L % tiles_y;
+    const int n = L / tiles_y;
+    const int i0 = ty * RT, j0 = tx * 32;
+    const int HWc = Hc * Wc, HWx = a.H * a.W;
+    const int nslabs = a.CH / 16;
+    const int s_begin = blockIdx.y * a.slabs_per_split;
+    const int s_end = min(nslabs, s_begin + a.slabs_per_split);
+
+    int p_off[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = tid + q * 256;
+        const int cb = e / (PH * PW), rem = e - cb * (PH * PW);
+        const int py = rem / PW, px = rem - py * PW;
+        const int y = i0 + py, xx = j0 + px;
+        const bool ok = e < PU1 && y < Hc && xx < Wc;
+        p_off[q] = ok ? cb * HWc + y * Wc + xx : -1;
+    }
+    const u32x4* ibase = a.in_q + (long)n * a.in_q_nstride + (long)s_begin * 2 * HWc;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto stage_patch = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q * 256 + wave * 64 < PU1) {
+                    const u32x4* g = p_off[q] >= 0 ? ibase + p * a.in_q_pstride + p_off[q] : a.zeros;
+                    if (tid + q * 256 < PU1)
+                        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Pl + buf * PUNITS + p * PU1 + q * 256 + wave * 64), 16, 0, 0);
+                }
+            }
+        ibase += 2 * HWc;
+    };
+    auto stage_weights = [&](int s, int buf) {
+        const u32x4* src = a.wq + (long)(2 * s) * T * a.Rpad + r0 + lane;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int w0 = 0; w0 < NI; w0 += 4) {
+                const int w = w0 + wave;
+                if (w < NI) {
+                    const int ci = w / (BM / 64), h = w - ci * (BM / 64);        // ci = cb * T + tap
+                    const u32x4* g = src + p * a.wq_pstride + (long)ci * a.Rpad + h * 64;
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Wl + buf * WUNITS + p * WU1 + ci * BM + h * 64), 16, 0, 0);
+                }
+            }
+    };
+
+    f32x16 acc[4][TM][TN];                          // [parity class pu*2+pv]
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[cl][i][j][e] = 0.f;
+
+    if (s_begin < s_end) {
+        stage_weights(s_begin, 0);
+        stage_patch(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int wlane = kg * T * BM + wm * (BM / WM) + li;
+    const int plane = kg * PH * PW + (wn * TN) * PW + li;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if ((s + 1) < s_end) {
+            stage_weights(s + 1, buf ^ 1);
+            stage_patch(buf ^ 1);
+        }
+        const u32x4* Wb = Wl + buf * WUNITS + wlane;
+        const u32x4* Pb = Pl + buf * PUNITS + plane;
+        u32x4 af[2][NP][TM], bf[NP][TN + 1][2];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[0][p][i] = Wb[p * WU1 + i * 32];
+#pragma unroll
+            for (int j = 0; j <= TN; ++j) {
+                bf[p][j][0] = Pb[p * PU1 + j * PW];
+                bf[p][j][1] = Pb[p * PU1 + j * PW + 1];
+            }
+        }
+        // tw: tap index in the transposed pack = 8 - original tap (ta, tb); the tap feeds class (ta != 1, tb != 1) from
+        // dy[i + (ta == 0)][j + (tb == 0)].  Weight fragments are read one tap ahead of their MFMAs.
+#pragma unroll
+        for (int tw = 0; tw < T; ++tw) {
+            if (tw + 1 < T) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[(tw + 1) & 1][p][i] = Wb[p * WU1 + (tw + 1) * BM + i * 32];
+            }
+            const int ta = (8 - tw) / 3, tb = (8 - tw) % 3;
+            const int cl = (ta == 1 ? 0 : 2) + (tb == 1 ? 0 : 1);
+            const int ro = ta == 0 ? 1 : 0, co = tb == 0 ? 1 : 0;
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[cl][i][j] = sp_mfma(af[tw & 1][PA[pr]][i], bf[PB[pr]][j + ro][co], acc[cl][i][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = class pixel (row i0 + wn*TN + j, column j0 + li); its two column parities are adjacent:
+    // one 8-byte store per (row parity, channel) ----
+    const long P = (long)a.N * HWx;
+    const int ru = r0 + wm * (BM / WM), rl = ru + 4 * kg;
+    float* const sb = reinterpret_cast<float*>(sp_smem);
+    if (tid < BM) sb[tid] = (a.bias && !a.partial && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
+    __syncthreads();
+    const float* const lb = sb + wm * (BM / WM) + 4 * kg;
+    const long rstride = a.partial ? P : (long)HWx;
+    const unsigned lo = 4u * kg * (unsigned)rstride + 2u * li;
+    const bool plain = a.partial != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const long rowpix = (long)(2 * (i0 + wn * TN + j)) * a.W + 2 * j0;
+        float* const ub = a.partial ? a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HWx + rowpix
+                                    : a.out + (long)n * a.out_nstride + (long)ru * HWx + rowpix;
+        const float* const yb = x.dact_y ? x.dact_y + (long)n * x.dact_nstride + (long)ru * HWx + rowpix : nullptr;
+#pragma unroll
+        for (int pu = 0; pu < 2; ++pu)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    if (rl + k >= a.R) continue;
+                    float2 v = make_float2(acc[pu * 2 + 0][i][j][e], acc[pu * 2 + 1][i][j][e]);
+                    float2* o = reinterpret_cast<float2*>(ub + (long)k * rstride + pu * a.W + lo);
+                    if (!plain) {
+                        v.x += lb[k]; v.y += lb[k];
+                        if (a.accumulate) { const float2 old = *o; v.x += old.x; v.y += old.y; }
+                        v.x = ghm_act(v.x, a.act, a.alpha);
+                        v.y = ghm_act(v.y, a.act, a.alpha);
+                        if (yb) {                       // relu / leaky relu: the slope of the producer
+                            const float2 yy = *reinterpret_cast<const float2*>(yb + (long)k * HWx + pu * a.W + lo);
+                            v.x *= yy.x > 0.f ? 1.f : x.dact_alpha;
+                            v.y *= yy.y > 0.f ? 1.f : x.dact_alpha;
+                        }
+                    }
+                    *o = v;
+                }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 struct SpPlan {
     bool ok;
-    int bm, rt, wm, wn, splits, slabs_per_split, grid;
+    int bm, rt, wm, wn, tw, splits, slabs_per_split, grid;
     size_t lds;
 };
 
 int sp_rpad(int r) { return (r + 127) / 128 * 128; }
 int sp_nblk(int red) { return (red + 15) / 16 * 2; }      // channel blocks of a pack (as the low-precision packs: whole slabs)
 
-size_t sp_lds_bytes(int ks, int st, int bm, int rt) {
-    const int ph = (rt - 1) * st + ks, pw = 31 * st + ks;
+size_t sp_lds_bytes(int ks, int st, int bm, int rt, int tw = 32) {
+    const int rows = rt * (32 / tw);
+    const int ph = (rows - 1) * st + ks, pw = (tw - 1) * st + ks;
     return (size_t)2 * NP * (2 * ks * bm + 2 * ph * pw) * 16;
 }
 
@@ -637,14 +852,21 @@ SpPlan sp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
     if (!((ks == 3 && (st == 1 || st == 2)) || (ks == 5 && st == 1))) return p;
     // one block per CU (three pieces of both operands, double-buffered, fill the LDS): 3x3 stride 1 takes 128 filters x 8 rows
     // with eight waves; 5x5 and stride 2 take 64 filters with four
-    if (ks == 3 && st == 1) { p.bm = R >= 96 ? 128 : 64; p.rt = 8; p.wm = p.bm == 128 ? 2 : 1; p.wn = 4; }
-    else if (ks == 5) { p.bm = 64; p.rt = 8; p.wm = 1; p.wn = 4; }
-    else { p.bm = 64; p.rt = 4; p.wm = 2; p.wn = 2; }
-    if (R < 32 || (W % 32) || (H % p.rt) || (CH % 16) || CH < 16) return p;
-    p.lds = sp_lds_bytes(ks, st, p.bm, p.rt);
+    p.tw = W % 32 == 0 ? 32 : (W % 16 == 0 ? 16 : 8);
+    if (p.tw != 32 && GHM_OPT("GHM_SPLIT_NO_NARROW")) return p;
+    if (p.tw == 32) {
+        if (ks == 3 && st == 1) { p.bm = R >= 96 ? 128 : 64; p.rt = 8; p.wm = p.bm == 128 ? 2 : 1; p.wn = 4; }
+        else if (ks == 5) { p.bm = 64; p.rt = 8; p.wm = 1; p.wn = 4; }
+        else { p.bm = 64; p.rt = 4; p.wm = 2; p.wn = 2; }
+    } else {        // narrow maps: 64 filters x (8 rows x 16 columns | 8 x 8): fragments of 2 x 16 / 4 x 8 pixels, four waves
+        p.bm = 64; p.rt = p.tw == 16 ? 4 : 2; p.wm = 2; p.wn = 2;
+    }
+    const int rows = p.rt * (32 / p.tw);
+    if (R < 32 || (W % p.tw) || (H % rows) || (CH % 16) || CH < 16) return p;
+    p.lds = sp_lds_bytes(ks, st, p.bm, p.rt, p.tw);
     if (p.lds > 160 * 1024) return p;
     const int ntr = (R + p.bm - 1) / p.bm;
-    p.grid = ntr * (W / 32) * (H / p.rt) * N;
+    p.grid = ntr * (W / p.tw) * (H / rows) * N;
     const int nslabs = CH / 16;
     p.splits = 1;
     if (p.grid < num_cu / 2) {
@@ -697,20 +919,26 @@ int sp_launch_conv(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, int ks, int st,
     }
     GHM_CHECK(!(pool && pl.splits > 1), "split-fp32 pooled convolution needs a single-pass plan");
     const dim3 g(pl.grid, pl.splits);
-#define GHM_SP_CASE(KS_, ST_, BM_, RT_, WM_, WN_, POOL_)                                                         \
-    if (ks == KS_ && st == ST_ && pl.bm == BM_ && pl.rt == RT_ && pool == POOL_) {                               \
-        if (int e = sp_set_lds(sp_conv_kernel<KS_, ST_, BM_, RT_, WM_, WN_, POOL_>, pl.lds)) return e;           \
-        hipLaunchKernelGGL((sp_conv_kernel<KS_, ST_, BM_, RT_, WM_, WN_, POOL_>), g, dim3(WM_ * WN_ * 64), pl.lds, \
+#define GHM_SP_CASE(KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_)                                                    \
+    if (ks == KS_ && st == ST_ && pl.bm == BM_ && pl.rt == RT_ && pool == POOL_ && pl.tw == TW_) {               \
+        if (int e = sp_set_lds(sp_conv_kernel<KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_>, pl.lds)) return e;      \
+        hipLaunchKernelGGL((sp_conv_kernel<KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_>), g, dim3(WM_ * WN_ * 64), pl.lds, \
                            ctx->stream, a);                                                                      \
         GHM_LAUNCH_CHECK();                                                                                      \
     } else
-    GHM_SP_CASE(5, 1, 64, 8, 1, 4, false)
-    GHM_SP_CASE(5, 1, 64, 8, 1, 4, true)
-    GHM_SP_CASE(3, 1, 128, 8, 2, 4, false)
-    GHM_SP_CASE(3, 1, 64, 8, 1, 4, false)
-    GHM_SP_CASE(3, 1, 128, 8, 2, 4, true)
-    GHM_SP_CASE(3, 1, 64, 8, 1, 4, true)
-    GHM_SP_CASE(3, 2, 64, 4, 2, 2, false) {
+    GHM_SP_CASE(5, 1, 64, 8, 1, 4, false, 32)
+    GHM_SP_CASE(5, 1, 64, 8, 1, 4, true, 32)
+    GHM_SP_CASE(3, 1, 128, 8, 2, 4, false, 32)
+    GHM_SP_CASE(3, 1, 64, 8, 1, 4, false, 32)
+    GHM_SP_CASE(3, 1, 128, 8, 2, 4, true, 32)
+    GHM_SP_CASE(3, 1, 64, 8, 1, 4, true, 32)
+    GHM_SP_CASE(3, 2, 64, 4, 2, 2, false, 32)
+    GHM_SP_CASE(5, 1, 64, 4, 2, 2, false, 16)
+    GHM_SP_CASE(3, 1, 64, 4, 2, 2, false, 16)
+    GHM_SP_CASE(3, 2, 64, 4, 2, 2, false, 16)
+    GHM_SP_CASE(5, 1, 64, 2, 2, 2, false, 8)
+    GHM_SP_CASE(3, 1, 64, 2, 2, 2, false, 8)
+    GHM_SP_CASE(3, 2, 64, 2, 2, 2, false, 8) {
         ghm_set_error("no split-fp32 convolution variant for k=%d s=%d bm=%d rt=%d pool=%d", ks, st, pl.bm, pl.rt, (int)pool);
         return -3;
     }
@@ -742,16 +970,17 @@ SpWPlan sp_wplan(const ghm_conv_desc* d, int num_cu) {
     const bool k5 = d->kh == 5 && d->kw == 5 && d->pad == 2 && d->stride == 1;
     if (!k3 && !k5) return v;
     if (d->Ho != (d->H + d->stride - 1) / d->stride || d->Wo != (d->W + d->stride - 1) / d->stride) return v;
-    if (d->Wo % 32 || d->C % 8 || d->K % 8) return v;
+    if (d->Wo % 16 || d->C % 8 || d->K % 8 || (d->Wo % 32 && GHM_OPT("GHM_SPLIT_NO_NARROW"))) return v;
+    const int narrow = d->Wo % 32 ? 16 : 32;    // 16-wide maps: strips of 16 pixels, one k-step per output row
     if (k5) {                                   // 10 waves: 5 filter rows x 2 filter tiles of one 32-channel group
         if (d->K % 64 || d->C % 32) return v;
-        v.cht = 1; v.ct = 2; v.spx = d->Wo % 64 == 0 ? 64 : 32;
+        v.cht = 1; v.ct = 2; v.spx = d->Wo % 64 == 0 ? 64 : narrow;
     } else if (d->stride == 1) {                // 12 waves: 3 filter rows x (2 channel groups x 2 filter tiles)
         if (d->K % 64 || d->C % 64) return v;
-        v.cht = 2; v.ct = 2; v.spx = 32;
+        v.cht = 2; v.ct = 2; v.spx = narrow;
     } else {                                    // stride 2 (two parity planes per x row): 12 waves, 1 x 4
         if (d->K % 128 || d->C % 32) return v;
-        v.cht = 1; v.ct = 4; v.spx = 32;
+        v.cht = 1; v.ct = 4; v.spx = narrow;
     }
     v.lds = sp_wgrad_lds(d->kh, d->stride, v.cht, v.ct, v.spx);
     if (v.lds > 160 * 1024) return v;
@@ -796,7 +1025,10 @@ int sp_launch_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const SpWPlan& v, cons
     GHM_SPW_CASE(3, 1, 2, 2, 32)
     GHM_SPW_CASE(3, 2, 1, 4, 32)
     GHM_SPW_CASE(5, 1, 1, 2, 64)
-    GHM_SPW_CASE(5, 1, 1, 2, 32) {
+    GHM_SPW_CASE(5, 1, 1, 2, 32)
+    GHM_SPW_CASE(3, 1, 2, 2, 16)
+    GHM_SPW_CASE(3, 2, 1, 4, 16)
+    GHM_SPW_CASE(5, 1, 1, 2, 16) {
         ghm_set_error("no split-fp32 weight gradient variant for k=%d s=%d cht=%d ct=%d spx=%d", d->kh, d->stride, v.cht, v.ct, v.spx);
         return -3;
     }
@@ -805,9 +1037,90 @@ int sp_launch_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const SpWPlan& v, cons
     return 0;
 }
 
+// ---- 3x3 stride-2 data gradient ----
+SpPlan sp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu) {
+    SpPlan p;
+    memset(&p, 0, sizeof(p));
+    // OPT-IN (GHM_SPLIT_DGRAD_S2=1): alone the kernel is 2-25 % faster than dgrad_s2_patch_kernel on the step's layers (K is
+    // short there: 8-32 slabs, a block is mostly prologue + epilogue), and with its 142 KB of LDS it shuts the other streams'
+    // kernels out of its CU -- the joint step measured 237.9 img/s with it against 241.9 without
+    if (GHM_OPT("GHM_NO_SPLIT") || !GHM_OPT("GHM_SPLIT_DGRAD_S2")) return p;
+    if (!(d->stride == 2 && d->kh == 3 && d->kw == 3 && d->pad == 1 && d->H == 2 * d->Ho && d->W == 2 * d->Wo)) return p;
+    if (d->Wo % 32 || d->K % 16 || d->K < 16 || d->C < 32 || (d->x_nstride & 1) || ((d->H * d->W) & 1)) return p;
+    p.bm = 64;
+    p.rt = d->Ho % 4 == 0 ? 4 : 2;
+    if (const char* f = GHM_OPT("GHM_SPLIT_DGRAD_S2_RT")) p.rt = atoi(f) == 2 ? 2 : p.rt;
+    if (d->Ho % p.rt) return p;
+    p.lds = (size_t)2 * NP * (2 * 9 * p.bm + 2 * (p.rt + 1) * 33) * 16;
+    p.grid = ((d->C + p.bm - 1) / p.bm) * (d->Wo / 32) * (d->Ho / p.rt) * d->N;
+    const int nslabs = d->K / 16;
+    p.splits = 1;
+    if (p.grid < num_cu / 2) {
+        p.splits = (num_cu + p.grid - 1) / p.grid;
+        const int maxs = nslabs / 2 > 0 ? nslabs / 2 : 1;
+        if (p.splits > maxs) p.splits = maxs;
+    }
+    p.slabs_per_split = (nslabs + p.splits - 1) / p.splits;
+    p.splits = (nslabs + p.slabs_per_split - 1) / p.slabs_per_split;
+    p.ok = true;
+    return p;
+}
+
+int sp_launch_dgrad_s2(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, const SpDgradS2Extra& x, const float* dy32, long dy32_nstride) {
+    a.slabs_per_split = pl.slabs_per_split;
+    a.zeros = (const u32x4*)ctx->zeros;
+    a.partial = nullptr;
+    const long plane = (long)a.N * (a.CH / 8) * a.Hin * a.Win;
+    const size_t qbytes = dy32 ? align256((size_t)NP * plane * 16) : 0;
+    const size_t pbytes = pl.splits > 1 ? (size_t)pl.splits * a.R * a.N * a.H * a.W * sizeof(float) : 0;
+    if (qbytes + pbytes) {
+        void* ws = nullptr;
+        if (int e = ghm_scratch(ctx, qbytes + pbytes, &ws)) return e;
+        if (dy32) {
+            a.in_q = (const u32x4*)ws;
+            a.in_q_nstride = (long)(a.CH / 8) * a.Hin * a.Win;
+            a.in_q_pstride = plane;
+            if (int e = sp_pack(ctx, dy32, dy32_nstride, a.N, a.CH, a.Hin * a.Win, ws, a.in_q_nstride, plane)) return e;
+        }
+        if (pbytes) a.partial = (float*)((char*)ws + qbytes);
+    }
+    GHM_CHECK(!(x.dact_y && pl.splits > 1), "split-fp32 stride-2 data gradient + activation derivative needs a single-pass plan");
+    const dim3 g(pl.grid, pl.splits);
+    if (pl.rt == 4) {
+        if (int e = sp_set_lds(sp_dgrad_s2_kernel<64, 4>, pl.lds)) return e;
+        hipLaunchKernelGGL((sp_dgrad_s2_kernel<64, 4>), g, dim3(256), pl.lds, ctx->stream, a, x);
+    } else {
+        if (int e = sp_set_lds(sp_dgrad_s2_kernel<64, 2>, pl.lds)) return e;
+        hipLaunchKernelGGL((sp_dgrad_s2_kernel<64, 2>), g, dim3(256), pl.lds, ctx->stream, a, x);
+    }
+    GHM_LAUNCH_CHECK();
+    if (pl.splits > 1)
+        return ghm_splitk_finish(ctx, a.partial, pl.splits, a.out, a.bias, a.N, a.R, a.H, a.W, a.out_nstride, a.act, a.alpha,
+                                 a.accumulate);
+    return 0;
+}
+
 bool sp_fwd_geom(const ghm_conv_desc* d) {
     return d->kh == d->kw && 2 * d->pad == d->kh - 1 && ((d->stride == 1 && d->Ho == d->H && d->Wo == d->W) ||
                                                           (d->stride == 2 && d->H == 2 * d->Ho && d->W == 2 * d->Wo));
+}
+
+
+static int sp_dgrad_s2(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* dyq, long dyq_ns, long dyq_ps,
+                       const void* wqT, const float* bias, float* dx, int act, float alpha, int accumulate, const float* dact_y,
+                       long dact_nstride, float dact_alpha) {
+    const SpPlan pl = sp_plan_dgrad_s2(d, ctx->num_cu);
+    GHM_CHECK(pl.ok, "split-fp32 stride-2 data gradient: geometry not served");
+    SpConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in_q = (const u32x4*)dyq; a.in_q_nstride = dyq_ns; a.in_q_pstride = dyq_ps;
+    a.wq = (const u32x4*)wqT; a.bias = bias; a.out = dx;
+    a.N = d->N; a.CH = d->K; a.H = d->H; a.W = d->W; a.Hin = d->Ho; a.Win = d->Wo;
+    a.R = d->C; a.Rpad = sp_rpad(d->C); a.wq_pstride = (long)sp_nblk(d->K) * 9 * a.Rpad;
+    a.out_nstride = d->x_nstride; a.pad = d->pad;
+    a.act = act; a.alpha = alpha; a.accumulate = accumulate;
+    const SpDgradS2Extra x{dact_y, dact_nstride, dact_alpha};
+    return sp_launch_dgrad_s2(ctx, pl, a, x, dyq ? nullptr : dy, d->y_nstride);
 }
 
 }  // namespace
@@ -819,8 +1132,10 @@ extern "C" {
 int ghm_split_supported(const ghm_conv_desc* d, int32_t kind) {
     if (!d) return 0;
     if (kind == 0) return sp_fwd_geom(d) && sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ghm_plan_cus()).ok;
-    if (kind == 1)
+    if (kind == 1) {
+        if (d->stride == 2) return sp_plan_dgrad_s2(d, ghm_plan_cus()).ok;
         return d->stride == 1 && sp_fwd_geom(d) && sp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ghm_plan_cus()).ok;
+    }
     if (kind == 2) return sp_wplan(d, ghm_plan_cus()).ok;
     return 0;
 }
@@ -886,7 +1201,7 @@ int ghm_split_pool_supported(const ghm_conv_desc* d, int32_t act) {
     if (!d || !(act == GHM_ACT_LINEAR || act == GHM_ACT_RELU || act == GHM_ACT_LRELU)) return 0;
     if (d->stride != 1 || !sp_fwd_geom(d) || (d->Ho & 1) || (d->Wo & 1)) return 0;
     const SpPlan pl = sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, ghm_plan_cus());
-    return pl.ok && pl.splits == 1;
+    return pl.ok && pl.splits == 1 && pl.tw == 32;
 }
 
 int ghm_conv2d_fwd_pool_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* xq, int64_t xq_nstride,
@@ -932,6 +1247,7 @@ int ghm_conv2d_dgrad_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy
     GHM_CHECK(ctx && d && (dy || dyq) && wqT && dx, "null argument");
     GHM_CHECK(ghm_split_supported(d, 1), "ghm_conv2d_dgrad_split: geometry not served (ask ghm_split_supported)");
     GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
+    if (d->stride == 2) return sp_dgrad_s2(ctx, d, dy, dyq, dyq_nstride, dyq_pstride, wqT, bias, dx, act, alpha, accumulate, nullptr, 0, 0.f);
     const SpPlan pl = sp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ctx->num_cu);
     SpConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -942,6 +1258,23 @@ int ghm_conv2d_dgrad_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy
     a.out_nstride = d->x_nstride; a.pad = d->kh - 1 - d->pad;
     a.act = act; a.alpha = alpha; a.accumulate = accumulate;
     return sp_launch_conv(ctx, pl, a, d->kh, 1, dyq ? nullptr : dy, d->y_nstride, false);
+}
+
+// dx = conv^T(dy, W) * act'(y) of a 3x3 stride-2 convolution: the producer's relu / leaky-relu backward in the epilogue (the
+// PatchGAN's conv -> LeakyRectify -> conv chains, p2p.py:285-286); 1 where served (single-pass plans)
+int ghm_split_dgrad_dact_supported(const ghm_conv_desc* d) {
+    if (!d || d->stride != 2) return 0;
+    const SpPlan pl = sp_plan_dgrad_s2(d, ghm_plan_cus());
+    return pl.ok && pl.splits == 1;
+}
+
+int ghm_conv2d_dgrad_dact_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void* dyq, int64_t dyq_nstride, int64_t dyq_pstride,
+                                const void* wqT, float* dx, const float* y, int64_t y_nstride, int32_t act, float alpha) {
+    GHM_CHECK(ctx && d && dyq && wqT && dx && y, "null argument");
+    GHM_CHECK(ghm_split_dgrad_dact_supported(d), "ghm_conv2d_dgrad_dact_split: not served (ask ghm_split_dgrad_dact_supported)");
+    GHM_CHECK(act == GHM_ACT_RELU || act == GHM_ACT_LRELU, "ghm_conv2d_dgrad_dact_split: relu / leaky relu");
+    return sp_dgrad_s2(ctx, d, nullptr, dyq, (long)dyq_nstride, (long)dyq_pstride, wqT, nullptr, dx, GHM_ACT_LINEAR, 0.f, 0, y,
+                       (long)y_nstride, act == GHM_ACT_RELU ? 0.f : alpha);
 }
 
 }  // extern "C"

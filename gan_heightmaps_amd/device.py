@@ -459,7 +459,11 @@ class Ops:
 
     def dgrad_dact_supported(self, d, dtype='f32'):
         """0: not served; 1 / 2 / 3: served, reading the fp32 packed wp / the fp32 wpT / the low-precision wqT"""
-        return int(_lib.load().ghm_dgrad_dact_supported(C.byref(d), DTYPE_CODES['f32' if dtype == SPLIT else dtype]))
+        if dtype == SPLIT:
+            if _lib.load().ghm_split_dgrad_dact_supported(C.byref(d)):
+                return 3
+            dtype = 'f32'
+        return int(_lib.load().ghm_dgrad_dact_supported(C.byref(d), DTYPE_CODES[dtype]))
 
     def conv2d_dgrad_dact(self, d, dy, w, dx, y, act, alpha, dtype='f32'):
         """dx = conv^T(dy) * act'(y): the data gradient with the producer's activation backward in its epilogue"""
@@ -630,6 +634,10 @@ class Ops:
              int(accumulate), DTYPE_CODES[dtype])
 
     def conv2d_dgrad_dact_lp_q(self, d, dyq, wqT, dx, dxq, y, act, alpha, dtype):
+        if dtype == SPLIT:
+            assert dxq is None
+            return call("ghm_conv2d_dgrad_dact_split", self.h, C.byref(d), C.c_void_p(dyq.ptr), dyq.nstride, dyq.pstride,
+                        _vp(wqT), _vp(dx), _vp(y), y.nstride, ACT_CODES[act], alpha)
         call("ghm_conv2d_dgrad_dact_lp_q", self.h, C.byref(d), C.c_void_p(dyq.ptr), dyq.nstride, _vp(wqT), _vp(dx),
              C.c_void_p(dxq.ptr if dxq is not None else 0), dxq.nstride if dxq is not None else 0, _vp(y), y.nstride,
              ACT_CODES[act], alpha, DTYPE_CODES[dtype])

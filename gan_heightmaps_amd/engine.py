@@ -1114,8 +1114,8 @@ class NetPlan:
                         xa = xin.act
                         xin.aux[('grad_is_pre', key)] = True
                         Gq = gradq_of(n, G) if form == 3 else None
-                        if Gq is not None and ops.lp_q_direct(d2, 1, self.dtype):
-                            giq = fused_gq(xin, gi, acc)
+                        if Gq is not None and (ops.lp_q_direct(d2, 1, self.dtype) or self.dtype == SPLIT):
+                            giq = fused_gq(xin, gi, acc) if self.dtype != SPLIT else None
                             prog.append(("conv_dgrad", lambda d=d2, Gq=Gq, wsel=wsel, gi=gi, giq=giq, x=x, xa=xa:
                                          ops.conv2d_dgrad_dact_lp_q(d, Gq, wsel, gi, giq, x, xa.kind, xa.alpha, self.dtype),
                                          conv_meta(ops, d2, 3, dt)))

@@ -251,7 +251,8 @@ class GanStep:
         # small weight gradients stay inline on stage A (measured img/s, fp32 / bf16 / fp32 batch 2 / 1024^2 fp16:
         # DPU 169.4 / 492.3 / 153.0 / 98.9, PU 169.3 / 498.8 / 150.5 / 97.2, GDPU 167.7 / 471.9 / 150.4 / 97.2,
         # none 164.5 / 467.1, GD 164.0).  GHM_SIDE_NETS overrides (tuning).
-        _sn = os.environ.get('GHM_SIDE_NETS', 'DPU' if self.dtype == 'f32' else 'PU')      # reduced precision: +1 % with D inline too
+        # (reduced precision: +1 % with D inline too; the split-fp32 mode, whose kernels are as long as the fp32 ones: 253 -> 261 img/s with D on the side)
+        _sn = os.environ.get('GHM_SIDE_NETS', 'DPU' if self.dtype in ('f32', 'bf16x3') else 'PU')
         _side = lambda k, lane: self.side[lane] if k in _sn else None
         b.G = NetPlan(dA, oA, G, B, self.stores['dcgan_gen'], out_tensor=b.d_in.samples(B, 2 * B), name="G",
                       side=_side('G', 0), rng_seed=self.rank, dtype=self.dtype,       # replicas draw different dropout masks

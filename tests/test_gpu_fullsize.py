@@ -172,8 +172,11 @@ def test_full_size_step_matches_oracle_at_batch_2(gpu):
     del model
 
 
-def test_full_size_batch4_step_against_the_float64_fixture(gpu):
-    """tests/golden/reference_step_fullsize_b4.npz (make_reference_step_fullsize_b4.py, build container): ONE joint
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3"])
+def test_full_size_batch4_step_against_the_float64_fixture(gpu, dtype):
+    """(dtype 'bf16x3': the SAME test with the SAME bounds for the split-fp32 mode, csrc/conv_split.hip -- fp32 products as six
+    bf16 piece products; it is held to everything the fp32 path is held to.)
+    tests/golden/reference_step_fullsize_b4.npz (make_reference_step_fullsize_b4.py, build container): ONE joint
     train step of the four 512x512 test1_nobn_bilin_both networks at the reference's batch size 4 (experiments.py:121)
     on the float64 oracle.  No oracle runs on the GPU box.  Bounds (rel-L2; north_star: outputs within 1e-3):
       losses <= 1e-5;  G(z) and U(X) <= 1e-4 on a 64x64 lattice + one 64x64 full-resolution window per image;
@@ -188,11 +191,14 @@ def test_full_size_batch4_step_against_the_float64_fixture(gpu):
     seed, batch, dseed, stride, win = (int(v) for v in fix["meta"])
     assert batch == 4
     cfg = ostep.default_cfg()
-    model = make_model('test1_nobn_bilin_both', device=dev, seed=seed, verbose=False, use_graph=False)
+    model = make_model('test1_nobn_bilin_both', device=dev, seed=seed, verbose=False, use_graph=False, dtype=dtype)
     Z, X, Y = ostep.synthetic_batch(batch, cfg, seed=dseed)
     got = model.train_fn(Z, X, Y)
     assert rel(got, fix["losses64"]) < 1e-5, (got, fix["losses64"])
     b = model.engine.built(batch)
+    if dtype != 'f32':          # the split kernels really are in the program
+        names = {e[2]["kernel"] for lane in b.train_compute for e in lane if len(e) > 2 and e[2] is not None and e[2].get("dtype") == dtype}
+        assert any(n.startswith("sp_conv_kernel") for n in names) and any(n.startswith("sp_wgrad_kernel") for n in names), names
     for key, t in (("gz", b.G.out), ("ux", b.U.out)):          # the step's own forward outputs (pre-update parameters)
         a = t.numpy().astype(np.float64)
         lat = a[:, :, ::stride, ::stride]

@@ -65,6 +65,12 @@ CASES = [
     (1, 16, 64, 128, 64, 3, 2, 1),     # 3x3 stride 2, rectangular
     (1, 128, 32, 32, 96, 3, 1, 1),     # 8 slabs
     (3, 80, 32, 32, 32, 5, 1, 2),      # 5 slabs, 32 filters
+    (2, 64, 16, 16, 128, 3, 1, 1),     # narrow maps: 16 columns (fragments of 2 x 16 pixels) ...
+    (3, 32, 16, 16, 64, 5, 1, 2),
+    (2, 64, 8, 8, 160, 3, 1, 1),       # ... and 8 columns (4 x 8)
+    (4, 48, 8, 8, 64, 5, 1, 2),
+    (2, 32, 32, 32, 64, 3, 2, 1),      # stride 2 -> 16 x 16
+    (4, 512, 16, 16, 512, 3, 1, 1),    # split-K (few blocks, 32 slabs)
 ]
 
 
@@ -139,6 +145,51 @@ def test_split_data_gradient_is_fp32_arithmetic(gpu, case):
     dev.free(wqT)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 64, 48, 3, 2, 1), (1, 48, 128, 64, 32, 3, 2, 1), (2, 128, 64, 128, 256, 3, 2, 1),
+                                  (1, 32, 24, 64, 16, 3, 2, 1)])
+def test_split_stride2_data_gradient_is_fp32_arithmetic(gpu, case):
+    """ghm_conv2d_dgrad_split on a 3x3 stride-2 convolution (four parity classes over one dy patch) against the float64
+    oracle, beside the fp32 MFMA kernel; the accumulate form; and ghm_conv2d_dgrad_dact_split (the producer's LeakyRectify
+    backward in the epilogue, p2p.py:285-286)"""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(sum(case) + 3)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    assert not ops.split_supported(d, 1)                # opt-in (csrc/conv_split.hip, sp_plan_dgrad_s2)
+    with tuning_env(GHM_SPLIT_DGRAD_S2="1"):
+        assert ops.split_supported(d, 1)
+        _stride2_dgrad_checks(dev, ops, D, case, rng, d)
+
+
+def _stride2_dgrad_checks(dev, ops, D, case, rng, d):
+    N, C, H, W, K, k, s, pad = case
+    dy = (rng.randn(N, K, d.Ho, d.Wo) * np.exp(rng.randn(N, K, 1, 1))).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    ref = O.conv2d_vjp(np.zeros((N, C, H, W)), Wt.astype(np.float64), dy.astype(np.float64), s, pad)[0]
+    dyd = dev.tensor(dy)
+    wp = dev.tensor(D.pack_conv_w(Wt).ravel())
+    wqT = dev.alloc(ops.split_weight_bytes(d, True))
+    ops.split_pack_weights(d, wp, wqT, True)
+    dx, dx32 = dev.empty((N, C, H, W)), dev.empty((N, C, H, W))
+    ops.conv2d_dgrad_split(d, dyd, wqT, dx)
+    wT = dev.empty((1, C * k * k * K, 1, 1))
+    ops.transpose_weights(d, wp, wT)
+    ops.conv2d_dgrad_t(d, dyd, wT, dx32)
+    e_split, e_f32 = rel(dx.numpy(), ref), rel(dx32.numpy(), ref)
+    print("split %.2e   fp32 MFMA %.2e   %s" % (e_split, e_f32, case))
+    assert e_split < FP32_BOUND and e_split < max(2 * e_f32, 3e-7), (e_split, e_f32)
+    ops.conv2d_dgrad_split(d, dyd, wqT, dx, accumulate=True)
+    assert rel(dx.numpy(), 2 * ref) < FP32_BOUND
+    if ops.dgrad_dact_supported(d, 'bf16x3') == 3:
+        y = rng.randn(N, C, H, W).astype(np.float32)
+        dyq = D.QTensor.empty(dev, dy.shape, 'bf16x3')
+        ops.q_pack(dyd, dyq)
+        out = dev.empty((N, C, H, W))
+        ops.conv2d_dgrad_dact_lp_q(d, dyq, wqT, out, None, dev.tensor(y), 'lrelu', 0.2, 'bf16x3')
+        assert rel(out.numpy(), ref * np.where(y > 0, 1.0, 0.2)) < FP32_BOUND
+    dev.free(wqT)
+
+
 WGRAD_CASES = [
     # N, C, H, W, K, k, s, pad
     (2, 64, 32, 32, 64, 3, 1, 1),      # 3x3 stride 1: 12 waves, one strip
@@ -147,6 +198,9 @@ WGRAD_CASES = [
     (1, 64, 32, 128, 256, 3, 2, 1),    # stride 2, rectangular
     (2, 32, 32, 64, 64, 5, 1, 2),      # 5x5: ten waves, 64-pixel strips
     (1, 64, 16, 32, 128, 5, 1, 2),     # 5x5, 32-pixel strips
+    (4, 128, 16, 16, 128, 3, 1, 1),    # 16-wide maps: 16-pixel strips, one k-step per output row
+    (2, 64, 32, 32, 128, 3, 2, 1),     # stride 2 -> 16 x 16
+    (4, 64, 16, 16, 64, 5, 1, 2),
 ]
 
 

@@ -32,6 +32,10 @@ def main():
     ops = D.Ops(dev)
     d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
     rng = np.random.RandomState(0)
+    if os.environ.get('GHM_BENCH_ZERO'):        # all-zero operands: the same instruction stream without data toggling (power / clock probe)
+        class _Z:
+            randn = staticmethod(lambda *s: np.zeros(s))
+        rng = _Z()
     x = dev.tensor(rng.randn(N, C, H, W).astype(np.float32))
     y = dev.tensor(rng.randn(N, K, d.Ho, d.Wo).astype(np.float32))
     w = dev.tensor((rng.randn(C * k * k * K) * 0.05).astype(np.float32))
