@@ -1360,7 +1360,8 @@ class NetPlan:
 def conv_meta(ops, d, kind, dtype='f32', pooled=False):
     """roofline metadata of one conv launch: kernel variant name and ALGORITHMIC flops (2 x MACs)."""
     if pooled:
-        name = ("lp_conv_kernel<%s, %d, %d>" % (dtype, d.kh, d.stride)) if dtype != 'f32' else \
+        name = ("sp_conv_kernel<%d, %d> fwd+pool" % (d.kh, d.stride)) if dtype == SPLIT else \
+            ("lp_conv_kernel<%s, %d, %d>" % (dtype, d.kh, d.stride)) if dtype != 'f32' else \
             ("fanout_kernel<fwd+pool>" if d.C <= 4 else ops.conv_variant(d, 0).split(" splits")[0])   # same kernel, pooled epilogue
     elif dtype != 'f32':
         fam = "wgrad" if kind == 2 else ("dgrad_s2" if kind in (1, 3) and d.stride == 2 else "conv")

@@ -8,7 +8,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
 B="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary"
-for dt in f32 bf16; do
+for dt in ${2:-f32 bf16 bf16x3}; do
   rm -rf /tmp/mf_$dt /tmp/mf2_$dt
   timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE \
       --output-format csv -d /tmp/mf_$dt -- $B --dtype $dt > $O/${R}_pmc_mfma_$dt.log 2>&1
