@@ -646,12 +646,14 @@ struct SpDgradS2Extra {
 };
 
 template <int BM, int RT>
-__global__ __launch_bounds__(256, 1) void sp_dgrad_s2_kernel(const SpConvArgs a, const SpDgradS2Extra x) {
+__global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a, const SpDgradS2Extra x) {
+    // weights staged per filter ROW (3 taps x 2 channel blocks x BM rows x 3 pieces, double-buffered: 36 KB) and the dy patch
+    // per slab (double-buffered): 68 KB in the 64 x 4 shape -- two blocks per CU, and room left for the other streams' kernels
     constexpr int T = 9, WM = 2, WN = 2;
     constexpr int TM = BM / (WM * 32), TN = RT / WN;
     constexpr int PH = RT + 1, PW = 33;
     constexpr int PU1 = 2 * PH * PW, PUNITS = NP * PU1;
-    constexpr int WU1 = 2 * T * BM, WUNITS = NP * WU1;
+    constexpr int WU1 = 2 * 3 * BM, WUNITS = NP * WU1;           // one filter row: [cb][3 taps][BM]
     constexpr int NQ = (PU1 + 255) / 256;
     constexpr int NI = WU1 / 64;
     extern __shared__ __attribute__((aligned(16))) u32x4 sp_smem[];
@@ -703,22 +705,25 @@ __global__ __launch_bounds__(256, 1) void sp_dgrad_s2_kernel(const SpConvArgs a,
             }
         ibase += 2 * HWc;
     };
-    auto stage_weights = [&](int s, int buf) {
-        const u32x4* src = a.wq + (long)(2 * s) * T * a.Rpad + r0 + lane;
+    // filter row fa of slab s in the transposed pack: taps tw = 3 fa .. 3 fa + 2
+    auto stage_weights = [&](int s, int fa, int buf) {
+        const u32x4* src = a.wq + ((long)(2 * s) * T + 3 * fa) * a.Rpad + r0 + lane;
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int w0 = 0; w0 < NI; w0 += 4) {
                 const int w = w0 + wave;
                 if (w < NI) {
-                    const int ci = w / (BM / 64), h = w - ci * (BM / 64);        // ci = cb * T + tap
-                    const u32x4* g = src + p * a.wq_pstride + (long)ci * a.Rpad + h * 64;
+                    const int ci = w / (BM / 64), h = w - ci * (BM / 64);        // ci = cb * 3 + tap in the row
+                    const int cb = ci / 3, b = ci - cb * 3;
+                    const u32x4* g = src + p * a.wq_pstride + ((long)cb * T + b) * a.Rpad + h * 64;
                     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Wl + buf * WUNITS + p * WU1 + ci * BM + h * 64), 16, 0, 0);
                 }
             }
     };
 
-    f32x16 acc[4][TM][TN];                          // [parity class pu*2+pv]
+    // [parity class pu*2+pv]; leading product and correction products apart (see sp_conv_kernel)
+    f32x16 acc[4][TM][TN], accc[4][TM][TN];
 #pragma unroll
     for (int cl = 0; cl < 4; ++cl)
 #pragma unroll
@@ -726,62 +731,86 @@ __global__ __launch_bounds__(256, 1) void sp_dgrad_s2_kernel(const SpConvArgs a,
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[cl][i][j][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[cl][i][j][e] = accc[cl][i][j][e] = 0.f;
 
     if (s_begin < s_end) {
-        stage_weights(s_begin, 0);
+        stage_weights(s_begin, 0, 0);
         stage_patch(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int wlane = kg * T * BM + wm * (BM / WM) + li;
+    const int wlane = kg * 3 * BM + wm * (BM / WM) + li;
     const int plane = kg * PH * PW + (wn * TN) * PW + li;
+    int it = 0;
     for (int s = s_begin; s < s_end; ++s) {
-        const int buf = (s - s_begin) & 1;
-        if ((s + 1) < s_end) {
-            stage_weights(s + 1, buf ^ 1);
-            stage_patch(buf ^ 1);
-        }
-        const u32x4* Wb = Wl + buf * WUNITS + wlane;
-        const u32x4* Pb = Pl + buf * PUNITS + plane;
-        u32x4 af[2][NP][TM], bf[NP][TN + 1][2];
+        const int pbuf = (s - s_begin) & 1;
+        const bool more = (s + 1) < s_end;
+        const u32x4* Pb = Pl + pbuf * PUNITS + plane;
+        // the nine taps only ever read the dy fragment of a class pixel at (row, column) offsets {0, 1} x {0, 1}: the
+        // (TN + 1) x 2 distinct fragments of the wave's rows are read once per slab (three pieces) and kept in registers
+        u32x4 bf[NP][TN + 1][2];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[0][p][i] = Wb[p * WU1 + i * 32];
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int j = 0; j <= TN; ++j) {
                 bf[p][j][0] = Pb[p * PU1 + j * PW];
                 bf[p][j][1] = Pb[p * PU1 + j * PW + 1];
             }
-        }
-        // tw: tap index in the transposed pack = 8 - original tap (ta, tb); the tap feeds class (ta != 1, tb != 1) from
-        // dy[i + (ta == 0)][j + (tb == 0)].  Weight fragments are read one tap ahead of their MFMAs.
 #pragma unroll
-        for (int tw = 0; tw < T; ++tw) {
-            if (tw + 1 < T) {
+        for (int fa = 0; fa < 3; ++fa, ++it) {
+            const int wbuf = it & 1;
+            if (fa + 1 < 3)
+                stage_weights(s, fa + 1, wbuf ^ 1);
+            else if (more)
+                stage_weights(s + 1, 0, wbuf ^ 1);
+            if (fa == 0 && more) stage_patch(pbuf ^ 1);
+            const u32x4* Wb = Wl + wbuf * WUNITS + wlane;
+            u32x4 af[2][NP][TM];
 #pragma unroll
-                for (int p = 0; p < NP; ++p)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) af[(tw + 1) & 1][p][i] = Wb[p * WU1 + (tw + 1) * BM + i * 32];
+                for (int i = 0; i < TM; ++i) af[0][p][i] = Wb[p * WU1 + i * 32];
+            // tw = 3 fa + b: tap index in the transposed pack = 8 - original tap (ta, tb); the tap feeds class
+            // (ta != 1, tb != 1) from dy[i + (ta == 0)][j + (tb == 0)].  Weight fragments are read one tap ahead.
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                if (b + 1 < 3) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) af[(b + 1) & 1][p][i] = Wb[p * WU1 + (b + 1) * BM + i * 32];
+                }
+                const int tw = 3 * fa + b;
+                const int ta = (8 - tw) / 3, tb = (8 - tw) % 3;
+                const int cl = (ta == 1 ? 0 : 2) + (tb == 1 ? 0 : 1);
+                const int ro = ta == 0 ? 1 : 0, co = tb == 0 ? 1 : 0;
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr) {
+                    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            if (pr < 5)
+                                accc[cl][i][j] = sp_mfma(af[b & 1][PA[pr]][i], bf[PB[pr]][j + ro][co], accc[cl][i][j]);
+                            else
+                                acc[cl][i][j] = sp_mfma(af[b & 1][0][i], bf[0][j + ro][co], acc[cl][i][j]);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            const int ta = (8 - tw) / 3, tb = (8 - tw) % 3;
-            const int cl = (ta == 1 ? 0 : 2) + (tb == 1 ? 0 : 1);
-            const int ro = ta == 0 ? 1 : 0, co = tb == 0 ? 1 : 0;
-#pragma unroll
-            for (int pr = 0; pr < 6; ++pr) {
-                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[cl][i][j] = sp_mfma(af[tw & 1][PA[pr]][i], bf[PB[pr]][j + ro][co], acc[cl][i][j]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[cl][i][j][e] += accc[cl][i][j][e];
 
     // ---- epilogue: lane = class pixel (row i0 + wn*TN + j, column j0 + li); its two column parities are adjacent:
     // one 8-byte store per (row parity, channel) ----
@@ -1041,17 +1070,17 @@ int sp_launch_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const SpWPlan& v, cons
 SpPlan sp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu) {
     SpPlan p;
     memset(&p, 0, sizeof(p));
-    // OPT-IN (GHM_SPLIT_DGRAD_S2=1): alone the kernel is 2-25 % faster than dgrad_s2_patch_kernel on the step's layers (K is
-    // short there: 8-32 slabs, a block is mostly prologue + epilogue), and with its 142 KB of LDS it shuts the other streams'
-    // kernels out of its CU -- the joint step measured 237.9 img/s with it against 241.9 without
-    if (GHM_OPT("GHM_NO_SPLIT") || !GHM_OPT("GHM_SPLIT_DGRAD_S2")) return p;
+    // (a first form with all nine taps of a slab staged at once -- 142 KB of LDS, one block per CU -- was 2-25 % faster than
+    // dgrad_s2_patch_kernel alone and 1.6 % SLOWER in the step: it shut the other streams' kernels out of its CU.  This one
+    // stages a filter row at a time: 55 KB, two blocks per CU; alone 154-177 TFLOP/s fp32-equivalent against 107-115, joint
+    // step 254.2 -> 269.5 img/s.  GHM_NO_SPLIT_DGRAD_S2 switches it off.)
+    if (GHM_OPT("GHM_NO_SPLIT") || GHM_OPT("GHM_NO_SPLIT_DGRAD_S2")) return p;
     if (!(d->stride == 2 && d->kh == 3 && d->kw == 3 && d->pad == 1 && d->H == 2 * d->Ho && d->W == 2 * d->Wo)) return p;
     if (d->Wo % 32 || d->K % 16 || d->K < 16 || d->C < 32 || (d->x_nstride & 1) || ((d->H * d->W) & 1)) return p;
     p.bm = 64;
-    p.rt = d->Ho % 4 == 0 ? 4 : 2;
-    if (const char* f = GHM_OPT("GHM_SPLIT_DGRAD_S2_RT")) p.rt = atoi(f) == 2 ? 2 : p.rt;
+    p.rt = 2;           // 64 channels x 2 class rows: eight accumulator tiles per wave (leading + correction) -> two blocks per CU
     if (d->Ho % p.rt) return p;
-    p.lds = (size_t)2 * NP * (2 * 9 * p.bm + 2 * (p.rt + 1) * 33) * 16;
+    p.lds = (size_t)2 * NP * (2 * 3 * p.bm + 2 * (p.rt + 1) * 33) * 16;
     p.grid = ((d->C + p.bm - 1) / p.bm) * (d->Wo / 32) * (d->Ho / p.rt) * d->N;
     const int nslabs = d->K / 16;
     p.splits = 1;
@@ -1086,13 +1115,8 @@ int sp_launch_dgrad_s2(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, const SpDgr
     }
     GHM_CHECK(!(x.dact_y && pl.splits > 1), "split-fp32 stride-2 data gradient + activation derivative needs a single-pass plan");
     const dim3 g(pl.grid, pl.splits);
-    if (pl.rt == 4) {
-        if (int e = sp_set_lds(sp_dgrad_s2_kernel<64, 4>, pl.lds)) return e;
-        hipLaunchKernelGGL((sp_dgrad_s2_kernel<64, 4>), g, dim3(256), pl.lds, ctx->stream, a, x);
-    } else {
-        if (int e = sp_set_lds(sp_dgrad_s2_kernel<64, 2>, pl.lds)) return e;
-        hipLaunchKernelGGL((sp_dgrad_s2_kernel<64, 2>), g, dim3(256), pl.lds, ctx->stream, a, x);
-    }
+    if (int e = sp_set_lds(sp_dgrad_s2_kernel<64, 2>, pl.lds)) return e;
+    hipLaunchKernelGGL((sp_dgrad_s2_kernel<64, 2>), g, dim3(256), pl.lds, ctx->stream, a, x);
     GHM_LAUNCH_CHECK();
     if (pl.splits > 1)
         return ghm_splitk_finish(ctx, a.partial, pl.splits, a.out, a.bias, a.N, a.R, a.H, a.W, a.out_nstride, a.act, a.alpha,

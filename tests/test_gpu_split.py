@@ -155,10 +155,10 @@ def test_split_stride2_data_gradient_is_fp32_arithmetic(gpu, case):
     N, C, H, W, K, k, s, pad = case
     rng = np.random.RandomState(sum(case) + 3)
     d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
-    assert not ops.split_supported(d, 1)                # opt-in (csrc/conv_split.hip, sp_plan_dgrad_s2)
-    with tuning_env(GHM_SPLIT_DGRAD_S2="1"):
-        assert ops.split_supported(d, 1)
-        _stride2_dgrad_checks(dev, ops, D, case, rng, d)
+    assert ops.split_supported(d, 1)
+    with tuning_env(GHM_NO_SPLIT_DGRAD_S2="1"):
+        assert not ops.split_supported(d, 1)
+    _stride2_dgrad_checks(dev, ops, D, case, rng, d)
 
 
 def _stride2_dgrad_checks(dev, ops, D, case, rng, d):
