@@ -48,3 +48,22 @@ def conv2d_vjp(x, W, dy, stride, pad, dtype):
     dx, dW, _ = ops.conv2d_vjp(x64, W64, dy64, stride, pad)
     db = np.asarray(dy, np.float64).sum(axis=(0, 2, 3))
     return dx, dW, db
+
+
+def split_bf16x3(a):
+    """float32 -> three bfloat16 pieces (returned as float32 arrays) with p0 + p1 + p2 == a EXACTLY: the operand form of
+    the split-fp32 kernels (csrc/conv_split.hip; beyond the reference, which computes in floatX=float32).
+    p0 = bf16(a), p1 = bf16(a - p0), p2 = a - p0 - p1: both subtractions are exact in float32 (the residual of a
+    round-to-nearest has fewer significant bits than its operand), and p2 has at most 8 significant bits."""
+    a = np.ascontiguousarray(a, np.float32)
+    p0 = round_bf16(a)
+    r1 = (a - p0).astype(np.float32)
+    p1 = round_bf16(r1)
+    p2 = (r1 - p1).astype(np.float32)
+    return p0, p1, p2
+
+
+def split_product_terms():
+    """the (operand-A piece, operand-B piece) pairs the kernels multiply: i + j <= 2; the three they drop are each below
+    2^-24 |a b| (piece i is at most 2^-8i of the value, up to rounding)"""
+    return [(i, j) for i in range(3) for j in range(3) if i + j <= 2]

@@ -52,7 +52,8 @@ def test_three_bf16_pieces_are_the_fp32_value(gpu):
     assert np.array_equal(total.view(np.uint32) & 0x7fffffff, x.view(np.uint32) & 0x7fffffff) or np.array_equal(total, x)
     assert np.array_equal(total, x)
     from oracle import lp as LP
-    assert np.array_equal(pieces[0], LP.round_bf16(x))
+    for got, want in zip(pieces, LP.split_bf16x3(x)):          # each piece is the oracle's piece, bit for bit
+        assert np.array_equal(got, want)
 
 
 CASES = [
