@@ -921,9 +921,16 @@ int sp_pack(ghm_ctx* ctx, const float* x, long x_nstride, int N, int C, int HW, 
     return 0;
 }
 
+// > 64 KB of dynamic LDS needs the attribute once per kernel (not per launch: it is a driver call on the step's issue path)
 template <typename K>
 int sp_set_lds(K kernel, size_t lds) {
-    if (lds > 64 * 1024) GHM_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (lds <= 64 * 1024) return 0;
+    static const void* seen[64];
+    static int nseen = 0;
+    for (int i = 0; i < nseen; ++i)
+        if (seen[i] == (const void*)kernel) return 0;
+    GHM_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (nseen < 64) seen[nseen++] = (const void*)kernel;
     return 0;
 }
 

@@ -63,6 +63,29 @@ __device__ __forceinline__ unsigned thin_pack2(float a, float b, int dt) {
                                 : __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2t));
 }
 
+// a half unit (4 consecutive channels of one pixel) of a q tensor; dt == 3 ('bf16x3', the split-fp32 mode): the three bf16
+// pieces of each value in three planes ``ps2`` half-units apart (csrc/conv_split.hip, elementwise_q.hip q_store8)
+__device__ __forceinline__ void thin_qstore4(uint2* qo, float v0, float v1, float v2, float v3, int dt, long ps2) {
+    if (dt == 3) {
+        unsigned p[2][3];
+        const float in[2][2] = {{v0, v1}, {v2, v3}};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x2t v = {in[t][0], in[t][1]};
+            p[t][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2t));
+            f32x2t r = {v[0] - __uint_as_float(p[t][0] << 16), v[1] - __uint_as_float(p[t][0] & 0xffff0000u)};
+            p[t][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2t));
+            f32x2t r2 = {r[0] - __uint_as_float(p[t][1] << 16), r[1] - __uint_as_float(p[t][1] & 0xffff0000u)};
+            p[t][2] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2t));
+        }
+        qo[0] = make_uint2(p[0][0], p[1][0]);
+        qo[ps2] = make_uint2(p[0][1], p[1][1]);
+        qo[2 * ps2] = make_uint2(p[0][2], p[1][2]);
+    } else {
+        *qo = make_uint2(thin_pack2(v0, v1, dt), thin_pack2(v2, v3, dt));
+    }
+}
+
 // LDS hand-over between the loader wave and the MFMA waves: wait for this wave's LDS traffic only.  A
 // __syncthreads() would also drain vmcnt, i.e. make every MFMA wave wait for its output stores to be
 // acknowledged once per iteration -- the stall this kernel is organised to avoid.
@@ -242,7 +265,7 @@ __global__ __launch_bounds__((4 * WS + 1) * 64, WS == 2 ? 1 : 2) void fanout_ker
                             if (QOUT && (e2 & 1)) {         // q unit (channel block, pooled pixel), half h: 4 consecutive channels
                                 uint2* qo = a.out_q + 2 * ((long)n * a.out_q_nstride + (long)((rb + rbo) * 4 + (e2 >> 1)) * HWp +
                                                            (long)((u0 + ri) / 2) * Wp + x0 / 2 + l) + h;
-                                *qo = make_uint2(thin_pack2(qv[0], qv[1], a.q_dt), thin_pack2(qv[2], qv[3], a.q_dt));
+                                thin_qstore4(qo, qv[0], qv[1], qv[2], qv[3], a.q_dt, 2 * (long)a.N * a.out_q_nstride);
                             }
                             const float keep = odd ? pm[1] : pm[0], send = odd ? pm[0] : pm[1];
                             const unsigned keepk = odd ? pk[1] : pk[0], sendk = odd ? pk[0] : pk[1];
@@ -320,9 +343,8 @@ __global__ __launch_bounds__((4 * WS + 1) * 64, WS == 2 ? 1 : 2) void fanout_ker
                         for (int g = 0; g < 4; ++g)
 #pragma unroll
                             for (int k = 0; k < NS; ++k)
-                                qb[2 * ((long)((rb + rbo) * 4 + g) * HWout + k)] =
-                                    make_uint2(thin_pack2(acc[k][rb][4 * g], acc[k][rb][4 * g + 1], a.q_dt),
-                                               thin_pack2(acc[k][rb][4 * g + 2], acc[k][rb][4 * g + 3], a.q_dt));
+                                thin_qstore4(qb + 2 * ((long)((rb + rbo) * 4 + g) * HWout + k), acc[k][rb][4 * g], acc[k][rb][4 * g + 1],
+                                             acc[k][rb][4 * g + 2], acc[k][rb][4 * g + 3], a.q_dt, 2 * (long)a.N * a.out_q_nstride);
                     }
                 }
             }
@@ -477,7 +499,7 @@ int thin_fanout_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const 
     FanoutArgs a;
     memset(&a, 0, sizeof(a));
     const int T = d->kh * d->kw;
-    GHM_CHECK(!yq || (d->K % 8 == 0 && ((uintptr_t)yq & 15) == 0 && (q_dt == GHM_DTYPE_BF16 || q_dt == GHM_DTYPE_F16)),
+    GHM_CHECK(!yq || (d->K % 8 == 0 && ((uintptr_t)yq & 15) == 0 && (q_dt == GHM_DTYPE_BF16 || q_dt == GHM_DTYPE_F16 || q_dt == 3)),
               "thin forward with a q output: filters %% 8 == 0, 16-byte aligned q tensor, bf16 / f16");
     a.out_q = (uint2*)yq; a.out_q_nstride = yq_nstride; a.q_dt = q_dt;
     a.in = x; a.wp = wp; a.bias = bias; a.out = y; a.zeros = ctx->zeros;
@@ -508,7 +530,7 @@ int thin_fanout_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, c
                          float* pooled, unsigned char* mask, int act, float alpha, void* yq, long yq_nstride, int q_dt) {
     FanoutArgs a;
     memset(&a, 0, sizeof(a));
-    GHM_CHECK(!yq || (((uintptr_t)yq & 15) == 0 && (q_dt == GHM_DTYPE_BF16 || q_dt == GHM_DTYPE_F16)),
+    GHM_CHECK(!yq || (((uintptr_t)yq & 15) == 0 && (q_dt == GHM_DTYPE_BF16 || q_dt == GHM_DTYPE_F16 || q_dt == 3)),
               "thin pooled forward with a q output: 16-byte aligned q tensor, bf16 / f16");
     a.out_q = (uint2*)yq; a.out_q_nstride = yq_nstride; a.q_dt = q_dt;
     const int T = d->kh * d->kw;

@@ -588,7 +588,11 @@ class Ops:
     def conv_variant_lp(self, d, kind, dtype):
         """kernel family serving low-precision product ``kind`` (0 forward, 1 data gradient, 2 weight gradient)"""
         if dtype == SPLIT:
-            return ("sp_wgrad_kernel<%d, %d>" if kind == 2 else "sp_conv_kernel<%d, %d>") % (d.kh, d.stride)
+            w = d.W if kind == 1 and d.stride == 1 else d.Wo          # width of the pixel grid the kernel tiles
+            if kind == 1 and d.stride == 2:
+                return "sp_dgrad_s2_kernel"
+            return ("sp_wgrad_kernel<%d, %d>%s" if kind == 2 else "sp_conv_kernel<%d, %d>%s") % (
+                d.kh, d.stride, "" if w % 32 == 0 else " narrow")
         out = C.create_string_buffer(128)
         call("ghm_lp_variant", C.byref(d), int(kind), DTYPE_CODES[dtype], out, 128)
         return out.value.decode()
@@ -740,8 +744,6 @@ class Ops:
                  dx.H, dx.W, ACT_CODES[act], alpha, _vp(dbias), int(accumulate))
 
     def thin_fwd_q_supported(self, d, act, pooled, dtype):
-        if dtype == SPLIT:
-            return False
         return bool(_lib.load().ghm_thin_fwd_q_supported(C.byref(d), ACT_CODES[act], int(pooled), DTYPE_CODES[dtype]))
 
     def thin_pool_lp_served(self, d, act, alpha, dtype):

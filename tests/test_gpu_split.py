@@ -191,6 +191,39 @@ def _stride2_dgrad_checks(dev, ops, D, case, rng, d):
     dev.free(wqT)
 
 
+@pytest.mark.parametrize("case", [(4, 1, 128, 128, 64, 5, 1, 2, True), (2, 4, 256, 256, 64, 3, 2, 1, False),
+                                  (2, 1, 256, 256, 64, 3, 2, 1, False), (2, 3, 128, 256, 64, 3, 1, 1, False)])
+def test_thin_first_layers_write_the_split_q_copy(gpu, case):
+    """ghm_conv2d_fwd_thin_q / ghm_conv2d_fwd_pool_thin_q with dtype 3: the first layers (<= 4 input channels: fp32 operands
+    on the fp32 kernels) write their result as three exact bf16 pieces from their own epilogue -- the fp32 result is
+    bit-identical to the plain entry point's and the pieces sum to it bit for bit (also inside a channel slice)"""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad, pooled = case
+    rng = np.random.RandomState(sum(case[:8]))
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    assert ops.thin_fwd_q_supported(d, 'lrelu', pooled, 'bf16x3')
+    wp, xd, bd = dev.tensor(D.pack_conv_w(Wt).ravel()), dev.tensor(x), dev.tensor(b)
+    Ho, Wo = (d.Ho // 2, d.Wo // 2) if pooled else (d.Ho, d.Wo)
+    y1, y2 = dev.empty((N, K, Ho, Wo)), dev.empty((N, K, Ho, Wo))
+    wide = D.QTensor.empty(dev, (N, K + 16, Ho, Wo), 'bf16x3')
+    dev.memset_zero(wide.ptr, 3 * wide.nbytes)
+    yq = wide.channels(8, 8 + K)
+    if pooled:
+        m1, m2 = dev.alloc(N * K * Ho * Wo), dev.alloc(N * K * Ho * Wo)
+        ops.conv2d_fwd_pool(d, xd, wp, bd, y1, m1, 'lrelu', 0.2, 'f32')
+        ops.conv2d_fwd_pool_thin_q(d, xd, wp, bd, y2, m2, yq, 'lrelu', 0.2)
+    else:
+        ops.conv2d_fwd(d, xd, wp, bd, y1, 'lrelu', 0.2)
+        ops.conv2d_fwd_thin_q(d, xd, wp, bd, y2, yq, 'lrelu', 0.2)
+    assert np.array_equal(y1.numpy(), y2.numpy())
+    assert np.array_equal(yq.numpy(), y1.numpy())
+    full = wide.numpy()
+    assert not full[:, :8].any() and not full[:, 8 + K:].any()
+
+
 WGRAD_CASES = [
     # N, C, H, W, K, k, s, pad
     (2, 64, 32, 32, 64, 3, 1, 1),      # 3x3 stride 1: 12 waves, one strip
