@@ -9,7 +9,8 @@ __device__ __forceinline__ f32x16 mf(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 // MODE bit 0: fragments re-read from LDS every k-step (12 ds_read_b128 per 24 MFMAs); bit 1: barrier every 5 k-steps;
-// bit 2: random operand data instead of zeros
+// bit 2: random operand data instead of zeros; bit 3: 10 global_load_lds (16 B / lane) per wave and iteration into a spare
+// LDS region, waited for (vmcnt(0)) in front of the iteration's barrier -- the staging traffic of sp_conv_kernel
 template <int MODE, int NACC>
 __global__ __launch_bounds__(256, 1) void probe(const u32x4* src, float* out, int iters) {
     extern __shared__ u32x4 lds[];
@@ -57,7 +58,16 @@ __global__ __launch_bounds__(256, 1) void probe(const u32x4* src, float* out, in
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if ((MODE & 8) && b == 0) {
+                typedef const __attribute__((address_space(1))) void* gptr_t;
+                typedef __attribute__((address_space(3))) void* lptr_t;
+                const u32x4* g = src + ((it * 2560 + blockIdx.x * 64 + threadIdx.x) & 0x1ffff);
+#pragma unroll
+                for (int q = 0; q < 10; ++q)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(g + q * 256), (lptr_t)(lds + 4096 + (threadIdx.x / 64) * 640 + q * 64), 16, 0, 0);
+            }
         }
+        if (MODE & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (MODE & 2) __syncthreads();
     }
     float s = 0.f;
@@ -65,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void probe(const u32x4* src, float* out, in
     if (s == 12345.678f) out[0] = s;
 }
 template <int MODE, int NACC>
-void run(const char* name, const u32x4* src, float* d) {
+void run(const char* name, const u32x4* src, float* d, int reps = 4) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int iters = 2000, blocks = 256;
@@ -73,7 +83,6 @@ void run(const char* name, const u32x4* src, float* d) {
     for (int w = 0; w < 4; ++w) hipLaunchKernelGGL((probe<MODE, NACC>), dim3(blocks), dim3(256), 140 * 1024, 0, src, d, iters);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    const int reps = 4;
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((probe<MODE, NACC>), dim3(blocks), dim3(256), 140 * 1024, 0, src, d, iters);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
@@ -84,7 +93,7 @@ void run(const char* name, const u32x4* src, float* d) {
 }
 int main() {
     u32x4* src; float* d;
-    (void)hipMalloc(&src, 4096 * 16); (void)hipMalloc(&d, 64);
+    (void)hipMalloc(&src, (size_t)0x20000 * 16 + 4096 * 16); (void)hipMalloc(&d, 64);
     unsigned* h = (unsigned*)malloc(4096 * 16);
     for (int i = 0; i < 4096 * 4; ++i) { unsigned r = (unsigned)rand(); h[i] = (r & 0x807f807f) | 0x3f003f00; }   // bf16 values near 1
     (void)hipMemcpy(src, h, 4096 * 16, hipMemcpyHostToDevice);
@@ -95,5 +104,8 @@ int main() {
     run<5, 8>("+ 12 ds_read_b128 per 24 MFMAs, random data", src, d);
     run<3, 8>("+ reads + barrier every 120 MFMAs, zero data", src, d);
     run<7, 8>("+ reads + barrier every 120 MFMAs, random data", src, d);
+    run<15, 8>("+ 40 KB of LDS DMA per block and iteration, random data", src, d, 50);
+    run<7, 8>("the same, SUSTAINED (0.6 s of launches), random data", src, d, 200);
+    run<3, 8>("the same, SUSTAINED (0.6 s of launches), zero data", src, d, 200);
     return 0;
 }
