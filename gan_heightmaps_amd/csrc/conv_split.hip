@@ -884,7 +884,7 @@ SpPlan sp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
     p.tw = W % 32 == 0 ? 32 : (W % 16 == 0 ? 16 : 8);
     if (p.tw != 32 && GHM_OPT("GHM_SPLIT_NO_NARROW")) return p;
     if (p.tw == 32) {
-        if (ks == 3 && st == 1) { p.bm = R >= 96 ? 128 : 64; p.rt = 8; p.wm = p.bm == 128 ? 2 : 1; p.wn = 4; }
+        if (ks == 3 && st == 1) { p.bm = (R >= 96 && !GHM_OPT("GHM_SPLIT_BM64")) ? 128 : 64; p.rt = 8; p.wm = p.bm == 128 ? 2 : 1; p.wn = 4; }
         else if (ks == 5) { p.bm = 64; p.rt = 8; p.wm = 1; p.wn = 4; }
         else { p.bm = 64; p.rt = 4; p.wm = 2; p.wn = 2; }
     } else {        // narrow maps: 64 filters x (8 rows x 16 columns | 8 x 8): fragments of 2 x 16 / 4 x 8 pixels, four waves
