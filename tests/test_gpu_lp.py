@@ -288,7 +288,7 @@ def test_reduced_precision_train_step(gpu, dtype):
     assert all(v.dtype == np.float32 for vals in model_params(model).values() for v in vals)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "bf16x3"])
 def test_reduced_precision_training_follows_the_fp32_trajectory(gpu, dtype):
     """Evidence that a reduced-precision run TRAINS (the single-step gradient bounds above are loose for the deep
     BatchNorm generators): 40 consecutive joint train steps at 128x128 from identical parameters on identical batches,
@@ -319,7 +319,9 @@ def test_reduced_precision_training_follows_the_fp32_trajectory(gpu, dtype):
     # measured (MI355X): bf16 worst per-step 0.030 / last-10 means 0.0034; fp16 0.020 / 0.0018 -- the per-step figure
     # is dominated by how fast two GAN trajectories separate from ANY perturbation (fp16's 8x smaller rounding only
     # buys a factor 1.5), the window means by the rounding itself
-    band = {'bf16': (8e-2, 1e-2), 'f16': (6e-2, 6e-3)}[dtype]
+    # ('bf16x3', the split-fp32 mode of csrc/conv_split.hip: fp32-accurate products, so its curves separate from the fp32
+    # MFMA run's only as two fp32 runs with different summation orders do)
+    band = {'bf16': (8e-2, 1e-2), 'f16': (6e-2, 6e-3), 'bf16x3': (2e-2, 3e-3)}[dtype]        # measured 9.9e-3 / 1.5e-3
     assert per_step < band[0] and tail < band[1], (per_step, tail)
     assert drop_a > 0 and abs(drop_b - drop_a) < 0.1 * drop_a, (drop_a, drop_b)
 
