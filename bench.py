@@ -497,6 +497,15 @@ def main():
             except Exception as ex:           # a secondary line must never take the headline down with it
                 sec.append({"name": name, "error": "%s: %s" % (type(ex).__name__, ex)})
         out["secondary"] = sec
+        sp = next((r for r in sec if r.get("name") == "headline_workload_fp32_by_bf16x3_splitting" and "value" in r), None)
+        if sp is not None:
+            # the same workload, same fp32 accuracy, on the bf16 matrix cores: opt-in, so NOT ``value``
+            out["value_fp32_by_operand_splitting"] = sp["value"]
+            out["fp32_by_operand_splitting_note"] = (
+                "headline workload with each fp32 operand split into three bf16 pieces that sum to it exactly and the six "
+                "leading piece products on v_mfma_f32_32x32x16_bf16 (fp32 accumulation): passes the fp32 path's parity tests "
+                "with the fp32 path's bounds (tests/test_gpu_split.py, test_gpu_fullsize.py [bf16x3]); opt-in "
+                "(--dtype bf16x3), kept out of `value`")
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.in_shp == 512 and not args.config1:
         out["cpu_baseline"] = cpu_baseline(2)
     if rank == 0:

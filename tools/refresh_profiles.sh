@@ -28,4 +28,5 @@ bash tools/upper_bounds.sh bf16 > $O/${R}_instep_skip_sweep_bf16.txt 2>&1
 bash tools/upper_bounds.sh f32 > $O/${R}_instep_skip_sweep_f32.txt 2>&1
 python tools/train_throughput.py 100 bf16 > $O/${R}_train_throughput.txt 2>&1
 python tools/train_throughput.py 60 f32 >> $O/${R}_train_throughput.txt 2>&1
+python tools/train_throughput.py 100 bf16x3 >> $O/${R}_train_throughput.txt 2>&1
 ls -la $O
