@@ -2451,12 +2451,15 @@ static DgradS2Plan dgrad_s2_plan(const ghm_conv_desc* d, int num_cu) {
     DgradS2Plan p;
     int first = d->C >= 96 ? 0 : 1, forced = -1;
     if (const char* f = GHM_OPT("GHM_DGRAD_S2_TILE")) forced = atoi(f);
-    for (int t = first; t < 3; ++t) {
+    // round 4 (tools/s2_f32_quick.sh, isolated, TFLOP/s for tiles 0 / 1 / 2): N8 C64 256^2 K128 57 / 107 / 113, N8 C128 128^2 K256
+    // 111 / 114 / 117, N8 C256 64^2 K512 102 / 103 / 113, N4 variants 54-92 / 94-103 / 93-109: the 64 x 2 tile (three blocks
+    // per CU, twice the blocks) is the best or equal everywhere -> first choice; the others stay for GHM_DGRAD_S2_TILE
+    (void)first;
+    for (int t = 2; t >= 0; --t) {
         if (forced >= 0) t = forced > 2 ? 2 : forced;
         p.bm = tiles[t][0]; p.wm = tiles[t][1]; p.rt = 4 / p.wm;
         p.grid = ((d->C + p.bm - 1) / p.bm) * (d->Wo / 32) * ((d->Ho + p.rt - 1) / p.rt) * d->N;
-        // measured (tools/s2_sweep.sh): the 128-channel tile only pays on grids of several waves of blocks
-        if (forced >= 0 || p.grid >= (t == 0 ? 4 : 2) * num_cu) break;
+        break;
     }
     const int nslabs = d->K / 4;
     p.splits = 1;
