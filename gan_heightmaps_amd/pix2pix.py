@@ -4,7 +4,9 @@ Same constructor arguments, attributes (train_fn, loss_fn, gen_fn, gen_fn_det, z
 train_keys) and methods (save_model, load_model, train, generate_*); compiled functions take numpy float32
 arrays and return lists of numpy scalars / arrays, synchronously.
 Extra keyword arguments (device, comm, use_graph, seed, dtype) configure the MI355X backend; ``dtype`` is the
-arithmetic of the convolution products: 'f32' (default = the reference's floatX=float32) or 'bf16' / 'f16'.
+arithmetic of the convolution products: 'f32' (default = the reference's floatX=float32, on the fp32 matrix instruction),
+'bf16x3' (the same fp32 arithmetic as six exact bf16 piece products per multiply-add: csrc/conv_split.hip, fp32-accurate,
+1.5x the speed) or 'bf16' / 'f16' (operands rounded).
 """
 import gzip
 import os

@@ -63,7 +63,8 @@ class GanStep:
         # all-reduced as soon as the backward pass has completed it (_build: bucketer)
         self.bucket_bytes = int(float(bucket_mb if bucket_mb is not None else os.environ.get('GHM_BUCKET_MB', 32)) * 2 ** 20)
         # arithmetic of the convolution products (include/ghm.h GHM_DTYPE_*): 'f32' = the reference's floatX; 'bf16' /
-        # 'f16' = BASELINE configs 4 / 5 (matrix-core operands rounded, fp32 accumulation, fp32 tensors and optimiser)
+        # 'f16' = BASELINE configs 4 / 5 (matrix-core operands rounded, fp32 accumulation, fp32 tensors and optimiser);
+        # 'bf16x3' = fp32 by operand splitting (three exact bf16 pieces per operand, csrc/conv_split.hip: fp32-accurate)
         self.dtype = dtype
         # fp16 operands underflow below 6e-8 and the per-pixel gradients of the 512x512 layers sit around 1e-6..1e-9:
         # the loss-gradient seeds are scaled (initially by 2^15) and the optimiser divides the scale out again (every
