@@ -8,14 +8,15 @@
 // are dropped are below 2^-24 |x w| each -- the size of the rounding fp32 arithmetic itself commits on every product.  This
 // is the operand-splitting form of fp32 emulation (BF16x9 in vendor BLAS libraries keeps all nine products; six is the
 // fp32-accurate subset): nothing about the data is rounded to 8 bits.  Measured against the float64 oracle the results carry
-// the same error as the fp32 MFMA kernels (tests/test_gpu_split.py states the bound), at 6/16 of their matrix-core time.
+// LESS error than the fp32 MFMA kernels' (tests/test_gpu_split.py: 0.7-2.2e-7 against 1.4-2.7e-7 -- sixteen exact products
+// are summed per instruction before the first rounding), at 6/16 of their matrix-core time.
 //
 // Layouts: a "split q tensor" is three planes (pieces 0, 1, 2), each a bf16 q tensor as include/ghm.h describes it
 // ([N][C/8][H][W][8 channels], 16-byte units); a "split weight pack" is three planes of the low-precision pack
 // wq[c/8][tap][Rpad][8] (conv_lp.hip).  ghm_split_pack / ghm_split_pack_weights produce them from fp32.
 //
 // Reference: the convolutions of architectures/dcgan.py:16-50 and architectures/p2p.py:139-290 in floatX=float32
-// (experiment.5.sh:5).  An OPT-IN arithmetic form of the fp32 mode (GanStep(split_fp32=True) / GHM_SPLIT_F32=1).
+// (experiment.5.sh:5).  An OPT-IN arithmetic form of the fp32 mode: Pix2Pix / GanStep(dtype='bf16x3'), bench.py --dtype bf16x3.
 #include <stdlib.h>
 #include <string.h>
 
