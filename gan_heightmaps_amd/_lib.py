@@ -104,12 +104,12 @@ SIGNATURES = {
     "ghm_split_pack_weights": [_p, _D, _p, _p, _i32],
     "ghm_split_pack": [_p, _p, _i64, _i32, _i32, _i32, _p, _i64, _i64],
     "ghm_split_pack_batched": [_p, _p, _i32, _i32],
-    "ghm_conv2d_dgrad_dact_split": [_p, _D, _p, _i64, _i64, _p, _p, _p, _i64, _i32, _f],
+    "ghm_conv2d_dgrad_dact_split": [_p, _D, _p, _i64, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _f],
     "ghm_conv2d_wgrad_split_workspace": [_D, _p],
     "ghm_conv2d_wgrad_split": [_p, _D, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i32],
-    "ghm_conv2d_fwd_pool_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _p, _i32, _f],
-    "ghm_conv2d_fwd_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _i32, _f, _i32],
-    "ghm_conv2d_dgrad_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _i32, _f, _i32],
+    "ghm_conv2d_fwd_pool_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _i32, _f],
+    "ghm_conv2d_fwd_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i32, _f, _i32],
+    "ghm_conv2d_dgrad_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i32, _f, _i32],
     "ghm_conv2d_pool_bwd_sparse_supported": [_D, _i32],
     "ghm_conv2d_pool_wgrad_sparse_workspace": [_D, C.POINTER(C.c_size_t)],
     "ghm_conv2d_pool_wgrad_sparse": [_p, _D, _p, _p, _p, _p, _p, _p, _i32, _f, _i32, _p],
@@ -172,6 +172,7 @@ _SPECIAL = {"ghm_last_error": ([], C.c_char_p), "ghm_bn_workspace": ([_i32], C.c
             "ghm_lp_wgrad_q_supported": ([_D, _i32], C.c_int),
             "ghm_split_supported": ([_D, _i32], C.c_int),
             "ghm_split_pool_supported": ([_D, _i32], C.c_int),
+            "ghm_split_q_direct": ([_D, _i32], C.c_int),
             "ghm_split_dgrad_dact_supported": ([_D], C.c_int)}
 # (ghm_conv_bn_fused_supported returns its answer as the int return value: typed with the plain signatures)
 

@@ -53,6 +53,17 @@ __device__ __forceinline__ void sp_split8(const float* v, u32x4& q0, u32x4& q1, 
     q2 = u32x4{c[0], c[1], c[2], c[3]};
 }
 
+// a half unit (4 consecutive channels of one pixel) of a split q tensor: the three pieces of each value, three planes
+// ``ps2`` half-units apart (the producer writes whole tensors: plane stride = samples x sample stride)
+__device__ __forceinline__ void sp_qstore4(uint2* qo, float v0, float v1, float v2, float v3, long ps2) {
+    unsigned a0, a1, a2, b0, b1, b2;
+    sp_split2(v0, v1, a0, a1, a2);
+    sp_split2(v2, v3, b0, b1, b2);
+    qo[0] = make_uint2(a0, b0);
+    qo[ps2] = make_uint2(a1, b1);
+    qo[2 * ps2] = make_uint2(a2, b2);
+}
+
 __device__ __forceinline__ int sp_xcd_remap(int bid, int nb) {
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = nb >> 3, r = nb & 7;
@@ -151,7 +162,9 @@ struct SpConvArgs {
     const u32x4* wq;       // split weight pack
     long wq_pstride;
     const float* bias;
-    float* out;            // fp32 NCHW output
+    float* out;            // fp32 NCHW output (or null when only the split q copy is wanted)
+    uint2* out_q;          // split q tensor of the result (half units; of the POOLED result when POOL) or null
+    long out_q_nstride;    // 16-byte units between samples (planes: N x this apart)
     float* partial;
     int N, CH, H, W;       // OUTPUT grid
     int Hin, Win;
@@ -366,31 +379,43 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
         const long pix = (long)((y0 + wn * TN) / 2) * Wp + (x0 + li) / 2;
         const long base = ((long)n * a.R + rl) * HWp + pix;
         const bool even = (li & 1) == 0;
+        uint2* const qb = a.out_q ? a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(ru / 8) * HWp + pix) + kg : nullptr;
+        const long ps2 = 2 * (long)a.N * a.out_q_nstride;
 #pragma unroll
         for (int j2 = 0; j2 < TN / 2; ++j2)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                    float v0 = acc[i][2 * j2][e] + lb[k], v1 = acc[i][2 * j2 + 1][e] + lb[k];
-                    v0 = v0 > 0.f ? v0 : slope * v0;
-                    v1 = v1 > 0.f ? v1 : slope * v1;
-                    const float w0 = __shfl_xor(v0, 1, 64), w1 = __shfl_xor(v1, 1, 64);
-                    const float m = fmaxf(fmaxf(v0, v1), fmaxf(w0, w1));
-                    const unsigned mk = (v0 == m ? 1u : 0u) | (w0 == m ? 2u : 0u) | (v1 == m ? 4u : 0u) | (w1 == m ? 8u : 0u) |
-                                        (m > 0.f ? GHM_POOL_SIGN : 0u);
-                    if (even && rl + k < a.R) {
-                        const long o = base + (long)k * HWp + j2 * Wp;
-                        if (a.pool_out) a.pool_out[o] = m;
-                        a.pool_mask[o] = (unsigned char)mk;
+                for (int g = 0; g < 4; ++g) {
+                    float mq[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int e = 4 * g + t, k = i * 32 + t + 8 * g;
+                        float v0 = acc[i][2 * j2][e] + lb[k], v1 = acc[i][2 * j2 + 1][e] + lb[k];
+                        v0 = v0 > 0.f ? v0 : slope * v0;
+                        v1 = v1 > 0.f ? v1 : slope * v1;
+                        const float w0 = __shfl_xor(v0, 1, 64), w1 = __shfl_xor(v1, 1, 64);
+                        const float m = fmaxf(fmaxf(v0, v1), fmaxf(w0, w1));
+                        const unsigned mk = (v0 == m ? 1u : 0u) | (w0 == m ? 2u : 0u) | (v1 == m ? 4u : 0u) | (w1 == m ? 8u : 0u) |
+                                            (m > 0.f ? GHM_POOL_SIGN : 0u);
+                        mq[t] = m;
+                        if (even && rl + k < a.R) {
+                            const long o = base + (long)k * HWp + j2 * Wp;
+                            if (a.pool_out) a.pool_out[o] = m;
+                            a.pool_mask[o] = (unsigned char)mk;
+                        }
                     }
+                    if (qb && even && rl + i * 32 + 8 * g < a.R)
+                        sp_qstore4(qb + 2 * ((long)(i * 4 + g) * HWp + j2 * Wp), mq[0], mq[1], mq[2], mq[3], ps2);
                 }
         return;
     }
-    float* const ub = a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN * RPF) * a.W + x0;
+    float* const ub = a.out ? a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN * RPF) * a.W + x0 : nullptr;
     const unsigned lo = 4u * kg * (unsigned)HW + ly * a.W + lx;
     const bool full = r0 + BM <= a.R;
+    uint2* const qb = a.out_q ? a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(ru / 8) * HW +
+                                                 (long)(y0 + wn * TN * RPF + ly) * a.W + x0 + lx) + kg : nullptr;
+    const long ps2 = 2 * (long)a.N * a.out_q_nstride;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -415,10 +440,18 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = ghm_act(v[e], a.act, a.alpha);
             }
+            if (ub) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                if (full || rl + k < a.R) (ub + (long)k * HW + j * RPF * a.W)[lo] = v[e];
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    if (full || rl + k < a.R) (ub + (long)k * HW + j * RPF * a.W)[lo] = v[e];
+                }
+            }
+            if (qb) {       // e = 4g .. 4g+3: four consecutive channels of this lane's pixel = half a q unit (kg picks the half)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (full || rl + i * 32 + 8 * g < a.R)
+                        sp_qstore4(qb + 2 * ((long)(i * 4 + g) * HW + j * RPF * a.W), v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], ps2);
             }
         }
 }
@@ -828,8 +861,13 @@ __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a,
     for (int j = 0; j < TN; ++j) {
         const long rowpix = (long)(2 * (i0 + wn * TN + j)) * a.W + 2 * j0;
         float* const ub = a.partial ? a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HWx + rowpix
-                                    : a.out + (long)n * a.out_nstride + (long)ru * HWx + rowpix;
+                                    : (a.out ? a.out + (long)n * a.out_nstride + (long)ru * HWx + rowpix : nullptr);
         const float* const yb = x.dact_y ? x.dact_y + (long)n * x.dact_nstride + (long)ru * HWx + rowpix : nullptr;
+        // q output: unit (channel block ru/8 + 4i + g, pixel (2*(i0+..)+pu, 2*(j0+li) + {0, 1})), half kg
+        uint2* const qrow = (a.out_q && !a.partial) ? a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(ru / 8) * HWx + rowpix + 2 * li) + kg
+                                                     : nullptr;
+        const long ps2 = 2 * (long)a.N * a.out_q_nstride;
+        float2 qv[4];
 #pragma unroll
         for (int pu = 0; pu < 2; ++pu)
 #pragma unroll
@@ -839,10 +877,10 @@ __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a,
                     const int k = i * 32 + (e & 3) + 8 * (e >> 2);
                     if (rl + k >= a.R) continue;
                     float2 v = make_float2(acc[pu * 2 + 0][i][j][e], acc[pu * 2 + 1][i][j][e]);
-                    float2* o = reinterpret_cast<float2*>(ub + (long)k * rstride + pu * a.W + lo);
+                    float2* o = ub ? reinterpret_cast<float2*>(ub + (long)k * rstride + pu * a.W + lo) : nullptr;
                     if (!plain) {
                         v.x += lb[k]; v.y += lb[k];
-                        if (a.accumulate) { const float2 old = *o; v.x += old.x; v.y += old.y; }
+                        if (a.accumulate) { const float2 old = *o; v.x += old.x; v.y += old.y; }      // (fp32 output present)
                         v.x = ghm_act(v.x, a.act, a.alpha);
                         v.y = ghm_act(v.y, a.act, a.alpha);
                         if (yb) {                       // relu / leaky relu: the slope of the producer
@@ -851,7 +889,15 @@ __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a,
                             v.y *= yy.y > 0.f ? 1.f : x.dact_alpha;
                         }
                     }
-                    *o = v;
+                    if (ub) *o = v;
+                    if (qrow) {           // four consecutive channels (e = 4g .. 4g+3) of the lane's two pixels
+                        qv[e & 3] = v;
+                        if ((e & 3) == 3) {
+                            uint2* qo = qrow + 2 * ((long)(i * 4 + (e >> 2)) * HWx + pu * a.W);
+                            sp_qstore4(qo, qv[0].x, qv[1].x, qv[2].x, qv[3].x, ps2);
+                            sp_qstore4(qo + 2, qv[0].y, qv[1].y, qv[2].y, qv[3].y, ps2);
+                        }
+                    }
                 }
     }
 }
@@ -955,6 +1001,10 @@ int sp_launch_conv(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, int ks, int st,
         if (pbytes) a.partial = (float*)((char*)ws + qbytes);
     }
     GHM_CHECK(!(pool && pl.splits > 1), "split-fp32 pooled convolution needs a single-pass plan");
+    GHM_CHECK(!(a.out_q && pl.splits > 1), "split-fp32 convolution: a q output needs a single-pass plan (ask ghm_split_q_direct)");
+    GHM_CHECK(pool || a.out || a.out_q, "split-fp32 convolution: no output");
+    GHM_CHECK(!(a.accumulate && !a.out), "accumulate needs the fp32 output");
+    GHM_CHECK(!a.out_q || (a.R % 8 == 0 && ((uintptr_t)a.out_q & 15) == 0), "q output: a multiple of 8 channels, 16-byte aligned");
     const dim3 g(pl.grid, pl.splits);
 #define GHM_SP_CASE(KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_)                                                    \
     if (ks == KS_ && st == ST_ && pl.bm == BM_ && pl.rt == RT_ && pool == POOL_ && pl.tw == TW_) {               \
@@ -1122,6 +1172,10 @@ int sp_launch_dgrad_s2(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, const SpDgr
         if (pbytes) a.partial = (float*)((char*)ws + qbytes);
     }
     GHM_CHECK(!(x.dact_y && pl.splits > 1), "split-fp32 stride-2 data gradient + activation derivative needs a single-pass plan");
+    GHM_CHECK(!(a.out_q && pl.splits > 1), "split-fp32 stride-2 data gradient: a q output needs a single-pass plan");
+    GHM_CHECK(a.out || a.out_q, "split-fp32 stride-2 data gradient: no output");
+    GHM_CHECK(!(a.accumulate && !a.out), "accumulate needs the fp32 output");
+    GHM_CHECK(!a.out_q || (a.R % 8 == 0 && ((uintptr_t)a.out_q & 15) == 0), "q output: a multiple of 8 channels, 16-byte aligned");
     const dim3 g(pl.grid, pl.splits);
     if (int e = sp_set_lds(sp_dgrad_s2_kernel<64, 2>, pl.lds)) return e;
     hipLaunchKernelGGL((sp_dgrad_s2_kernel<64, 2>), g, dim3(256), pl.lds, ctx->stream, a, x);
@@ -1140,13 +1194,13 @@ bool sp_fwd_geom(const ghm_conv_desc* d) {
 
 static int sp_dgrad_s2(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* dyq, long dyq_ns, long dyq_ps,
                        const void* wqT, const float* bias, float* dx, int act, float alpha, int accumulate, const float* dact_y,
-                       long dact_nstride, float dact_alpha) {
+                       long dact_nstride, float dact_alpha, void* dxq = nullptr, long dxq_ns = 0) {
     const SpPlan pl = sp_plan_dgrad_s2(d, ctx->num_cu);
     GHM_CHECK(pl.ok, "split-fp32 stride-2 data gradient: geometry not served");
     SpConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in_q = (const u32x4*)dyq; a.in_q_nstride = dyq_ns; a.in_q_pstride = dyq_ps;
-    a.wq = (const u32x4*)wqT; a.bias = bias; a.out = dx;
+    a.wq = (const u32x4*)wqT; a.bias = bias; a.out = dx; a.out_q = (uint2*)dxq; a.out_q_nstride = dxq_ns;
     a.N = d->N; a.CH = d->K; a.H = d->H; a.W = d->W; a.Hin = d->Ho; a.Win = d->Wo;
     a.R = d->C; a.Rpad = sp_rpad(d->C); a.wq_pstride = (long)sp_nblk(d->K) * 9 * a.Rpad;
     a.out_nstride = d->x_nstride; a.pad = d->pad;
@@ -1169,6 +1223,19 @@ int ghm_split_supported(const ghm_conv_desc* d, int32_t kind) {
         return d->stride == 1 && sp_fwd_geom(d) && sp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ghm_plan_cus()).ok;
     }
     if (kind == 2) return sp_wplan(d, ghm_plan_cus()).ok;
+    return 0;
+}
+
+// may the product write the split q copy of its result from its own epilogue (a single-pass plan, whole q units)?
+// kind 0 forward, 1 data gradient
+int ghm_split_q_direct(const ghm_conv_desc* d, int32_t kind) {
+    if (!d || !ghm_split_supported(d, kind)) return 0;
+    if (kind == 0) return d->K % 8 == 0 && sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ghm_plan_cus()).splits == 1;
+    if (kind == 1) {
+        if (d->C % 8) return 0;
+        if (d->stride == 2) return sp_plan_dgrad_s2(d, ghm_plan_cus()).splits == 1;
+        return sp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ghm_plan_cus()).splits == 1;
+    }
     return 0;
 }
 
@@ -1237,8 +1304,8 @@ int ghm_split_pool_supported(const ghm_conv_desc* d, int32_t act) {
 }
 
 int ghm_conv2d_fwd_pool_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* xq, int64_t xq_nstride,
-                              int64_t xq_pstride, const void* wq, const float* bias, float* pooled, uint8_t* mask,
-                              int32_t act, float alpha) {
+                              int64_t xq_pstride, const void* wq, const float* bias, float* pooled, void* pooledq,
+                              int64_t pooledq_nstride, uint8_t* mask, int32_t act, float alpha) {
     GHM_CHECK(ctx && d && (x || xq) && wq && mask, "null argument");
     GHM_CHECK(ghm_split_pool_supported(d, act), "ghm_conv2d_fwd_pool_split: not served (ask ghm_split_pool_supported)");
     const SpPlan pl = sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, ctx->num_cu);
@@ -1246,6 +1313,7 @@ int ghm_conv2d_fwd_pool_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float*
     memset(&a, 0, sizeof(a));
     a.in_q = (const u32x4*)xq; a.in_q_nstride = xq_nstride; a.in_q_pstride = xq_pstride;
     a.wq = (const u32x4*)wq; a.bias = bias; a.pool_out = pooled; a.pool_mask = mask;
+    a.out_q = (uint2*)pooledq; a.out_q_nstride = pooledq_nstride;
     a.N = d->N; a.CH = d->C; a.H = d->Ho; a.W = d->Wo; a.Hin = d->H; a.Win = d->W;
     a.R = d->K; a.Rpad = sp_rpad(d->K); a.wq_pstride = (long)sp_nblk(d->C) * d->kh * d->kw * a.Rpad;
     a.pad = d->pad; a.act = act; a.alpha = alpha;
@@ -1255,16 +1323,16 @@ int ghm_conv2d_fwd_pool_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float*
 // y = act(conv(x, W) + b) with fp32 operands and results; wq = ghm_split_pack_weights(transposed = 0).  xq != null: the
 // input as a split q tensor (ghm_split_pack) instead of x.
 int ghm_conv2d_fwd_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* xq, int64_t xq_nstride,
-                         int64_t xq_pstride, const void* wq, const float* bias, float* y, int32_t act, float alpha,
-                         int32_t accumulate) {
-    GHM_CHECK(ctx && d && (x || xq) && wq && y, "null argument");
+                         int64_t xq_pstride, const void* wq, const float* bias, float* y, void* yq, int64_t yq_nstride,
+                         int32_t act, float alpha, int32_t accumulate) {
+    GHM_CHECK(ctx && d && (x || xq) && wq && (y || yq), "null argument");
     GHM_CHECK(ghm_split_supported(d, 0), "ghm_conv2d_fwd_split: geometry not served (ask ghm_split_supported)");
     GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
     const SpPlan pl = sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ctx->num_cu);
     SpConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in_q = (const u32x4*)xq; a.in_q_nstride = xq_nstride; a.in_q_pstride = xq_pstride;
-    a.wq = (const u32x4*)wq; a.bias = bias; a.out = y;
+    a.wq = (const u32x4*)wq; a.bias = bias; a.out = y; a.out_q = (uint2*)yq; a.out_q_nstride = yq_nstride;
     a.N = d->N; a.CH = d->C; a.H = d->Ho; a.W = d->Wo; a.Hin = d->H; a.Win = d->W;
     a.R = d->K; a.Rpad = sp_rpad(d->K); a.wq_pstride = (long)sp_nblk(d->C) * d->kh * d->kw * a.Rpad;
     a.out_nstride = d->y_nstride; a.pad = d->pad;
@@ -1274,17 +1342,19 @@ int ghm_conv2d_fwd_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, c
 
 // dx = act(conv^T(dy, W) + b) of a stride-1 'same' convolution; wqT = ghm_split_pack_weights(transposed = 1)
 int ghm_conv2d_dgrad_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* dyq, int64_t dyq_nstride,
-                           int64_t dyq_pstride, const void* wqT, const float* bias, float* dx, int32_t act, float alpha,
-                           int32_t accumulate) {
-    GHM_CHECK(ctx && d && (dy || dyq) && wqT && dx, "null argument");
+                           int64_t dyq_pstride, const void* wqT, const float* bias, float* dx, void* dxq, int64_t dxq_nstride,
+                           int32_t act, float alpha, int32_t accumulate) {
+    GHM_CHECK(ctx && d && (dy || dyq) && wqT && (dx || dxq), "null argument");
     GHM_CHECK(ghm_split_supported(d, 1), "ghm_conv2d_dgrad_split: geometry not served (ask ghm_split_supported)");
     GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
-    if (d->stride == 2) return sp_dgrad_s2(ctx, d, dy, dyq, dyq_nstride, dyq_pstride, wqT, bias, dx, act, alpha, accumulate, nullptr, 0, 0.f);
+    if (d->stride == 2)
+        return sp_dgrad_s2(ctx, d, dy, dyq, dyq_nstride, dyq_pstride, wqT, bias, dx, act, alpha, accumulate, nullptr, 0, 0.f, dxq,
+                           (long)dxq_nstride);
     const SpPlan pl = sp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ctx->num_cu);
     SpConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in_q = (const u32x4*)dyq; a.in_q_nstride = dyq_nstride; a.in_q_pstride = dyq_pstride;
-    a.wq = (const u32x4*)wqT; a.bias = bias; a.out = dx;
+    a.wq = (const u32x4*)wqT; a.bias = bias; a.out = dx; a.out_q = (uint2*)dxq; a.out_q_nstride = dxq_nstride;
     a.N = d->N; a.CH = d->K; a.H = d->H; a.W = d->W; a.Hin = d->H; a.Win = d->W;
     a.R = d->C; a.Rpad = sp_rpad(d->C); a.wq_pstride = (long)sp_nblk(d->K) * d->kh * d->kw * a.Rpad;
     a.out_nstride = d->x_nstride; a.pad = d->kh - 1 - d->pad;
@@ -1301,12 +1371,13 @@ int ghm_split_dgrad_dact_supported(const ghm_conv_desc* d) {
 }
 
 int ghm_conv2d_dgrad_dact_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void* dyq, int64_t dyq_nstride, int64_t dyq_pstride,
-                                const void* wqT, float* dx, const float* y, int64_t y_nstride, int32_t act, float alpha) {
-    GHM_CHECK(ctx && d && dyq && wqT && dx && y, "null argument");
+                                const void* wqT, float* dx, void* dxq, int64_t dxq_nstride, const float* y, int64_t y_nstride,
+                                int32_t act, float alpha) {
+    GHM_CHECK(ctx && d && dyq && wqT && (dx || dxq) && y, "null argument");
     GHM_CHECK(ghm_split_dgrad_dact_supported(d), "ghm_conv2d_dgrad_dact_split: not served (ask ghm_split_dgrad_dact_supported)");
     GHM_CHECK(act == GHM_ACT_RELU || act == GHM_ACT_LRELU, "ghm_conv2d_dgrad_dact_split: relu / leaky relu");
     return sp_dgrad_s2(ctx, d, nullptr, dyq, (long)dyq_nstride, (long)dyq_pstride, wqT, nullptr, dx, GHM_ACT_LINEAR, 0.f, 0, y,
-                       (long)y_nstride, act == GHM_ACT_RELU ? 0.f : alpha);
+                       (long)y_nstride, act == GHM_ACT_RELU ? 0.f : alpha, dxq, (long)dxq_nstride);
 }
 
 }  // extern "C"

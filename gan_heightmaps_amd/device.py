@@ -504,16 +504,24 @@ class Ops:
         call("ghm_split_pack", self.h, _vp(x), x.nstride, x.N, x.Cc, x.HW, C.c_void_p(int(q_ptr)), ns, ps)
         return ns, ps
 
-    def conv2d_fwd_split(self, d, x, wq, bias, y, act='linear', alpha=0.0, accumulate=False, xq=None):
-        """xq = (ptr, nstride, pstride) of the input already split, or None (the entry point splits x)"""
-        q = xq or (None, 0, 0)
-        call("ghm_conv2d_fwd_split", self.h, C.byref(d), _vp(x), C.c_void_p(int(q[0])) if q[0] else None, q[1], q[2],
-             _vp(wq), _vp(bias), _vp(y), ACT_CODES[act], alpha, int(accumulate))
+    def split_q_direct(self, d, kind):
+        return bool(_lib.load().ghm_split_q_direct(C.byref(d), int(kind)))
 
-    def conv2d_dgrad_split(self, d, dy, wqT, dx, bias=None, act='linear', alpha=0.0, accumulate=False, dyq=None):
+    def conv2d_fwd_split(self, d, x, wq, bias, y, act='linear', alpha=0.0, accumulate=False, xq=None, yq=None):
+        """xq = (ptr, nstride, pstride) of the input already split, or None (the entry point splits x); yq: a whole split
+        QTensor (or a channel slice of one) that also receives the result; y may then be None"""
+        q = xq or (None, 0, 0)
+        assert yq is None or yq.pstride == yq.N * yq.nstride
+        call("ghm_conv2d_fwd_split", self.h, C.byref(d), _vp(x), C.c_void_p(int(q[0])) if q[0] else None, q[1], q[2],
+             _vp(wq), _vp(bias), _vp(y), C.c_void_p(yq.ptr) if yq is not None else None, yq.nstride if yq is not None else 0,
+             ACT_CODES[act], alpha, int(accumulate))
+
+    def conv2d_dgrad_split(self, d, dy, wqT, dx, bias=None, act='linear', alpha=0.0, accumulate=False, dyq=None, dxq=None):
         q = dyq or (None, 0, 0)
+        assert dxq is None or dxq.pstride == dxq.N * dxq.nstride
         call("ghm_conv2d_dgrad_split", self.h, C.byref(d), _vp(dy), C.c_void_p(int(q[0])) if q[0] else None, q[1], q[2],
-             _vp(wqT), _vp(bias), _vp(dx), ACT_CODES[act], alpha, int(accumulate))
+             _vp(wqT), _vp(bias), _vp(dx), C.c_void_p(dxq.ptr) if dxq is not None else None,
+             dxq.nstride if dxq is not None else 0, ACT_CODES[act], alpha, int(accumulate))
 
     def lp_weight_bytes(self, d, transposed=False, dtype=None):
         if dtype == SPLIT:
@@ -582,7 +590,7 @@ class Ops:
 
     def lp_q_direct(self, d, kind, dtype):
         if dtype == SPLIT:
-            return False            # the split kernels write fp32 results only: their readers' operands are split in a pass
+            return self.split_q_direct(d, kind)
         return bool(_lib.load().ghm_lp_q_direct(C.byref(d), int(kind), DTYPE_CODES[dtype]))
 
     def conv_variant_lp(self, d, kind, dtype):
@@ -622,26 +630,25 @@ class Ops:
 
     def conv2d_fwd_lp_q(self, d, xq, wq, bias, y, yq, dtype, act='linear', alpha=0.0, accumulate=False):
         if dtype == SPLIT:
-            assert yq is None
-            return self.conv2d_fwd_split(d, None, wq, bias, y, act, alpha, accumulate, xq=(xq.ptr, xq.nstride, xq.pstride))
+            return self.conv2d_fwd_split(d, None, wq, bias, y, act, alpha, accumulate, xq=(xq.ptr, xq.nstride, xq.pstride), yq=yq)
         call("ghm_conv2d_fwd_lp_q", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, _vp(wq), _vp(bias), _vp(y),
              C.c_void_p(yq.ptr if yq is not None else 0), yq.nstride if yq is not None else 0, ACT_CODES[act], alpha,
              int(accumulate), DTYPE_CODES[dtype])
 
     def conv2d_dgrad_lp_q(self, d, dyq, wqT, dx, dxq, dtype, bias=None, act='linear', alpha=0.0, accumulate=False):
         if dtype == SPLIT:
-            assert dxq is None
             return self.conv2d_dgrad_split(d, None, wqT, dx, bias, act, alpha, accumulate,
-                                           dyq=(dyq.ptr, dyq.nstride, dyq.pstride))
+                                           dyq=(dyq.ptr, dyq.nstride, dyq.pstride), dxq=dxq)
         call("ghm_conv2d_dgrad_lp_q", self.h, C.byref(d), C.c_void_p(dyq.ptr), dyq.nstride, _vp(wqT), _vp(bias), _vp(dx),
              C.c_void_p(dxq.ptr if dxq is not None else 0), dxq.nstride if dxq is not None else 0, ACT_CODES[act], alpha,
              int(accumulate), DTYPE_CODES[dtype])
 
     def conv2d_dgrad_dact_lp_q(self, d, dyq, wqT, dx, dxq, y, act, alpha, dtype):
         if dtype == SPLIT:
-            assert dxq is None
+            assert dxq is None or dxq.pstride == dxq.N * dxq.nstride
             return call("ghm_conv2d_dgrad_dact_split", self.h, C.byref(d), C.c_void_p(dyq.ptr), dyq.nstride, dyq.pstride,
-                        _vp(wqT), _vp(dx), _vp(y), y.nstride, ACT_CODES[act], alpha)
+                        _vp(wqT), _vp(dx), C.c_void_p(dxq.ptr) if dxq is not None else None,
+                        dxq.nstride if dxq is not None else 0, _vp(y), y.nstride, ACT_CODES[act], alpha)
         call("ghm_conv2d_dgrad_dact_lp_q", self.h, C.byref(d), C.c_void_p(dyq.ptr), dyq.nstride, _vp(wqT), _vp(dx),
              C.c_void_p(dxq.ptr if dxq is not None else 0), dxq.nstride if dxq is not None else 0, _vp(y), y.nstride,
              ACT_CODES[act], alpha, DTYPE_CODES[dtype])
@@ -709,9 +716,10 @@ class Ops:
 
     def conv2d_fwd_pool_lp_q(self, d, xq, wq, bias, pooled, pooledq, mask_ptr, act, alpha, dtype):
         if dtype == SPLIT:
-            assert pooledq is None
+            assert pooledq is None or pooledq.pstride == pooledq.N * pooledq.nstride
             return call("ghm_conv2d_fwd_pool_split", self.h, C.byref(d), None, C.c_void_p(xq.ptr), xq.nstride, xq.pstride,
-                        _vp(wq), _vp(bias), _vp(pooled), C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha)
+                        _vp(wq), _vp(bias), _vp(pooled), C.c_void_p(pooledq.ptr) if pooledq is not None else None,
+                        pooledq.nstride if pooledq is not None else 0, C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha)
         call("ghm_conv2d_fwd_pool_lp_q", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, _vp(wq), _vp(bias), _vp(pooled),
              C.c_void_p(pooledq.ptr if pooledq is not None else 0), pooledq.nstride if pooledq is not None else 0,
              C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha, DTYPE_CODES[dtype])
@@ -729,7 +737,7 @@ class Ops:
         assert pooled.contiguous
         if dtype == SPLIT:
             return call("ghm_conv2d_fwd_pool_split", self.h, C.byref(d), _vp(x), None, 0, 0, _vp(w), _vp(bias), _vp(pooled),
-                        C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha)
+                        None, 0, C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha)
         call("ghm_conv2d_fwd_pool", self.h, C.byref(d), _vp(x), _vp(w), _vp(bias), _vp(pooled), C.c_void_p(int(mask_ptr)),
              ACT_CODES[act], alpha, DTYPE_CODES[dtype])
 

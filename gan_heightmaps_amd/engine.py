@@ -306,8 +306,7 @@ class NetPlan:
         # q tensors (include/ghm.h): in the reduced-precision modes every tensor a low-precision product reads as an
         # operand also exists as a bf16 / fp16 copy in channel-block-of-8 layout, written by its producer
         self.use_q = self.dtype != 'f32' and os.environ.get("GHM_NO_Q") is None and hasattr(ops, 'q_pack')
-        # the element-wise producers write q copies from their own epilogues in every q mode (and fp32 tensors nobody reads are
-        # dropped); the split-fp32 CONVOLUTION kernels write fp32 only: a conv -> conv edge is split by a pass (ghm_split_pack)
+        # every producer with a q epilogue writes its q copy itself in every q mode (and fp32 tensors nobody reads are dropped)
         self.q_epi = self.use_q
         for n in self.order:
             n.outq = None
@@ -520,7 +519,7 @@ class NetPlan:
     def _pool_y_dropped(self, n):
         """fused conv + activation + max-pool node whose pooled fp32 tensor is never written: every consumer reads the q
         copy, and the backward pass takes the activation slope from the sign bit the forward kernel leaves in the mask"""
-        if (n.op != 'convpool' or not self.q_epi or self.dtype == SPLIT or os.environ.get("GHM_KEEP_POOL_Y") is not None
+        if (n.op != 'convpool' or not self.q_epi or os.environ.get("GHM_KEEP_POOL_Y") is not None
                 or os.environ.get("GHM_POOL_READ_Y") is not None):      # (the A/B switch of the backward reads it back)
             return False
         if n.act.kind not in ('linear', 'relu', 'lrelu') or self._fp32_needed(n):
@@ -724,8 +723,8 @@ class NetPlan:
                 if self._pool_y_dropped(n):
                     y = None                # (pooled fp32 tensor not written: see _pool_y_dropped)
                 if form == 2 and xq is not None:
-                    q_direct = n.outq is not None and self.dtype != SPLIT
-                    prog.append(("convpool_fwd", lambda d=d, xq=xq, wsrc=wsrc, b=b, y=y, yq=n.outq if self.dtype != SPLIT else None, m=n.aux['mask'], a=a:
+                    q_direct = n.outq is not None
+                    prog.append(("convpool_fwd", lambda d=d, xq=xq, wsrc=wsrc, b=b, y=y, yq=n.outq, m=n.aux['mask'], a=a:
                                  ops.conv2d_fwd_pool_lp_q(d, xq, wsrc, b, y, yq, m, a.kind, a.alpha, self.dtype),
                                  conv_meta(ops, d, 0, dt, pooled=True)))
                 elif form == 1 and n.outq is not None and ops.thin_fwd_q_supported(d, a.kind, True, self.dtype):
@@ -1115,7 +1114,7 @@ class NetPlan:
                         xin.aux[('grad_is_pre', key)] = True
                         Gq = gradq_of(n, G) if form == 3 else None
                         if Gq is not None and (ops.lp_q_direct(d2, 1, self.dtype) or self.dtype == SPLIT):
-                            giq = fused_gq(xin, gi, acc) if self.dtype != SPLIT else None
+                            giq = fused_gq(xin, gi, acc) if ops.lp_q_direct(d2, 1, self.dtype) else None
                             prog.append(("conv_dgrad", lambda d=d2, Gq=Gq, wsel=wsel, gi=gi, giq=giq, x=x, xa=xa:
                                          ops.conv2d_dgrad_dact_lp_q(d, Gq, wsel, gi, giq, x, xa.kind, xa.alpha, self.dtype),
                                          conv_meta(ops, d2, 3, dt)))

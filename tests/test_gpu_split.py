@@ -224,6 +224,85 @@ def test_thin_first_layers_write_the_split_q_copy(gpu, case):
     assert not full[:, :8].any() and not full[:, 8 + K:].any()
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64, 5, 1, 2), (2, 48, 32, 32, 160, 3, 1, 1), (2, 32, 64, 64, 128, 3, 2, 1),
+                                  (2, 64, 16, 16, 128, 3, 1, 1), (16, 64, 16, 16, 512, 3, 1, 1)])
+def test_split_products_write_their_split_q_copy(gpu, case):
+    """yq / dxq of ghm_conv2d_fwd_split / ghm_conv2d_dgrad_split (and the stride-2 data gradient with the producer's
+    activation backward): the three pieces the epilogue writes sum to the fp32 result bit for bit, inside a channel slice of a
+    wider split q tensor; with the fp32 pointer NULL the q result is unchanged"""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(sum(case) + 5)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    dy = rng.randn(N, K, d.Ho, d.Wo).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    wp = dev.tensor(D.pack_conv_w(Wt).ravel())
+    wq, wqT = dev.alloc(ops.split_weight_bytes(d, False)), dev.alloc(ops.split_weight_bytes(d, True))
+    ops.split_pack_weights(d, wp, wq, False)
+    ops.split_pack_weights(d, wp, wqT, True)
+    xd, dyd, bd = dev.tensor(x), dev.tensor(dy), dev.tensor(b)
+
+    def wide_q(shape):
+        wide = D.QTensor.empty(dev, (shape[0], shape[1] + 16, shape[2], shape[3]), 'bf16x3')
+        dev.memset_zero(wide.ptr, 3 * wide.nbytes)
+        return wide, wide.channels(8, 8 + shape[1])
+
+    if not ops.lp_q_direct(d, 0, 'bf16x3'):
+        pytest.skip("split-K plan on this device: the q copy is then made by ghm_split_pack")
+    y = dev.empty((N, K, d.Ho, d.Wo))
+    wide, yq = wide_q(y.shape)
+    ops.conv2d_fwd_split(d, xd, wq, bd, y, 'lrelu', 0.2, yq=yq)
+    assert np.array_equal(yq.numpy(), y.numpy())
+    full = wide.numpy()
+    assert not full[:, :8].any() and not full[:, 8 + K:].any()
+    only = D.QTensor.empty(dev, y.shape, 'bf16x3')
+    ops.conv2d_fwd_split(d, xd, wq, bd, None, 'lrelu', 0.2, yq=only)
+    assert np.array_equal(only.numpy(), y.numpy())
+    if ops.lp_q_direct(d, 1, 'bf16x3'):
+        dx = dev.empty((N, C, H, W))
+        widex, dxq = wide_q(dx.shape)
+        ops.conv2d_dgrad_split(d, dyd, wqT, dx, dxq=dxq)
+        assert np.array_equal(dxq.numpy(), dx.numpy())
+        fullx = widex.numpy()
+        assert not fullx[:, :8].any() and not fullx[:, 8 + C:].any()
+        if ops.dgrad_dact_supported(d, 'bf16x3') == 3:
+            dyq = D.QTensor.empty(dev, dy.shape, 'bf16x3')
+            ops.q_pack(dyd, dyq)
+            yact = dev.tensor(rng.randn(N, C, H, W).astype(np.float32))
+            out, outq = dev.empty((N, C, H, W)), D.QTensor.empty(dev, (N, C, H, W), 'bf16x3')
+            ops.conv2d_dgrad_dact_lp_q(d, dyq, wqT, out, outq, yact, 'lrelu', 0.2, 'bf16x3')
+            assert np.array_equal(outq.numpy(), out.numpy())
+
+
+def test_split_pooled_forward_writes_its_split_q_copy(gpu):
+    """ghm_conv2d_fwd_pool_split with pooledq: the pooled result as three exact pieces (also with the fp32 pointer NULL), the
+    mask unchanged"""
+    dev, ops, D = gpu
+    N, C, H, W, K, k = 2, 32, 64, 64, 64, 5
+    rng = np.random.RandomState(11)
+    d = D.conv_desc(N, C, H, W, K, k, k, 1, 2)
+    assert ops.conv_pool_supported(d, 'lrelu', 'bf16x3') == 2
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    wp, xd, bd = dev.tensor(D.pack_conv_w(Wt).ravel()), dev.tensor(x), dev.tensor(rng.randn(K).astype(np.float32))
+    wq = dev.alloc(ops.split_weight_bytes(d, False))
+    ops.split_pack_weights(d, wp, wq, False)
+    xq = D.QTensor.empty(dev, x.shape, 'bf16x3')
+    ops.q_pack(xd, xq)
+    n = N * K * (H // 2) * (W // 2)
+    y, yq, m1, m2 = dev.empty((N, K, H // 2, W // 2)), D.QTensor.empty(dev, (N, K, H // 2, W // 2), 'bf16x3'), dev.alloc(n), dev.alloc(n)
+    ops.conv2d_fwd_pool_lp_q(d, xq, wq, bd, y, yq, m1, 'lrelu', 0.2, 'bf16x3')
+    assert np.array_equal(yq.numpy(), y.numpy())
+    only = D.QTensor.empty(dev, y.shape, 'bf16x3')
+    ops.conv2d_fwd_pool_lp_q(d, xq, wq, bd, None, only, m2, 'lrelu', 0.2, 'bf16x3')
+    a, b = np.empty(n, np.uint8), np.empty(n, np.uint8)
+    dev.d2h(a, m1, n)
+    dev.d2h(b, m2, n)
+    assert np.array_equal(only.numpy(), y.numpy()) and np.array_equal(a, b)
+
+
 WGRAD_CASES = [
     # N, C, H, W, K, k, s, pad
     (2, 64, 32, 32, 64, 3, 1, 1),      # 3x3 stride 1: 12 waves, one strip
