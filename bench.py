@@ -96,6 +96,9 @@ SECONDARY = [
     ("config2_dcgan_512_b4_f32", dict(mode="dcgan")),
     ("config3_p2p_512_b4_f32", dict(mode="p2p")),
     ("config1_dcgan64_b16_f32", dict(config1=True)),
+    # configs 2 / 3 with the fp32 products by operand splitting (as the first line: opt-in arithmetic, fp32-accurate)
+    ("config2_dcgan_512_b4_fp32_by_bf16x3_splitting", dict(mode="dcgan", dtype="bf16x3")),
+    ("config3_p2p_512_b4_fp32_by_bf16x3_splitting", dict(mode="p2p", dtype="bf16x3")),
 ]
 
 
