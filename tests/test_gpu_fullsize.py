@@ -416,8 +416,10 @@ def test_full_size_batch4_step_properties(gpu):
     assert np.array_equal(runs[0], runs[1])
 
 
-def test_full_size_step_against_the_reference_executed_fixture(gpu):
-    """tests/golden/reference_step_fullsize.npz: the reference's experiments.py -> Pix2Pix.__init__ -> its own 512x512
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3"])
+def test_full_size_step_against_the_reference_executed_fixture(gpu, dtype):
+    """(dtype 'bf16x3': the split-fp32 mode, csrc/conv_split.hip, held to the same bounds as the fp32 path.)
+    tests/golden/reference_step_fullsize.npz: the reference's experiments.py -> Pix2Pix.__init__ -> its own 512x512
     architecture files, executed on the oracle's ops in float64 (tests/golden/make_reference_step_fullsize.py), one
     train_fn call at batch 2.  The HIP step must start from the same parameters (same RNG draws in the same order),
     return the same five losses and move every parameter tensor the same way."""
@@ -428,7 +430,7 @@ def test_full_size_step_against_the_reference_executed_fixture(gpu):
     fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_step_fullsize.npz"))
     seed, batch, dseed = (int(v) for v in fix["meta"])
     cfg = ostep.default_cfg()
-    model = make_model('test1_nobn_bilin_both', device=dev, seed=seed, verbose=False)
+    model = make_model('test1_nobn_bilin_both', device=dev, seed=seed, verbose=False, dtype=dtype)
     Z, X, Y = ostep.synthetic_batch(batch, cfg, seed=dseed)
 
     def summaries():
