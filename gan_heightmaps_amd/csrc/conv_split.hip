@@ -929,7 +929,11 @@ SpPlan sp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
     // one block per CU (three pieces of both operands, double-buffered, fill the LDS): 3x3 stride 1 takes 128 filters x 8 rows
     // with eight waves; 5x5 and stride 2 take 64 filters with four
     p.tw = W % 32 == 0 ? 32 : (W % 16 == 0 ? 16 : 8);
-    if (p.tw != 32 && GHM_OPT("GHM_SPLIT_NO_NARROW")) return p;
+    if (p.tw != 32)
+        if (const char* f = GHM_OPT("GHM_SPLIT_NO_NARROW")) {       // 1: all narrow maps; 3 / 5: those of that filter size only (tuning)
+            const int v = atoi(f);
+            if (v == 1 || v == ks) return p;
+        }
     if (p.tw == 32) {
         if (ks == 3 && st == 1) { p.bm = (R >= 96 && !GHM_OPT("GHM_SPLIT_BM64")) ? 128 : 64; p.rt = 8; p.wm = p.bm == 128 ? 2 : 1; p.wn = 4; }
         else if (ks == 5) { p.bm = 64; p.rt = 8; p.wm = 1; p.wn = 4; }
