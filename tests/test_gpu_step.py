@@ -244,7 +244,8 @@ def test_data_parallel_code_path_with_one_rank(dev, mode):
 
 
 @pytest.mark.parametrize("issue", [False, "recorded"])
-def test_sharded_update_code_path_with_one_rank(dev, issue):
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3"])
+def test_sharded_update_code_path_with_one_rank(dev, issue, dtype):
     """exchange_mode='rs_ag' on a world-1 RCCL communicator: ncclReduceScatter per sub-bucket inside the stage programs, the
     (whole, at one rank) optimiser update and ncclAllGather on the communication stream -- the N-rank program, which at one
     rank must reproduce the single-process step bit for bit, eager and as a recorded step (the collectives replay inside
@@ -252,13 +253,14 @@ def test_sharded_update_code_path_with_one_rank(dev, issue):
     from gan_heightmaps_amd import device, dist
     cfg = ostep.default_cfg(**SMALL)
     Zs = [ostep.synthetic_batch(4, cfg, seed=40 + i) for i in range(4)]
-    ref_model = build_model(cfg, 7, dev)
+    ref_model = build_model(cfg, 7, dev, dtype=dtype)       # ('bf16x3': the split weight packs follow the sharded update too)
     ref = [ref_model.train_fn(*b) for b in Zs]
     ref_params = model_params(ref_model)
     cdev = device.Device(dev.index)
     comm = dist.Comm(cdev, 0, 1, channels=(2, 4))
     try:
-        m = build_model(cfg, 7, dev, comm=comm, force_exchange=True, use_graph=issue, exchange_mode='rs_ag', bucket_mb=2048.0 / 2 ** 20)
+        m = build_model(cfg, 7, dev, comm=comm, force_exchange=True, use_graph=issue, exchange_mode='rs_ag', bucket_mb=2048.0 / 2 ** 20,
+                        dtype=dtype)
         b = m.engine.built(4)
         assert m.engine.sharded
         inside = [e[0] for lane in b.train_compute for e in lane if e[0].startswith("reducescatter_")]
