@@ -449,6 +449,16 @@ def measure(args, secondary_name=None):
             pmc = os.path.join(ROOT, "profiles", pmc)
             if traffic is None and os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get(dominant, {}).get("hbm_bytes_per_launch")
+        if traffic is None and dominant.startswith("sp_"):
+            # split kernels: the PMC file names the template instantiations; the wide-tile ones of this family, launch-weighted
+            pmc = os.path.join(ROOT, "profiles", "r04_pmc_traffic_3stream_bf16x3.json")
+            if os.path.exists(pmc):
+                fam = dominant.split(">")[0] + ","            # "sp_conv_kernel<3, 1" + ","
+                rows = [v for k, v in json.load(open(pmc)).items()
+                        if k.startswith(fam) and k.rstrip(">").endswith((", 32", ", 64")) and v.get("hbm_bytes_per_launch")]
+                n = sum(v["launches_sampled"] for v in rows)
+                if n:
+                    traffic = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in rows) / n
         iso = flops_per_launch / (isolated_ms * 1e-3) / 1e12
         # the dominant kernel is priced against the peak of the arithmetic IT runs in (a thin / small-map kernel that
         # stays fp32 in a bf16 step is an fp32 kernel)
