@@ -20,6 +20,8 @@ OUT = os.path.join(os.path.dirname(HERE), "libghm.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Rpass-analysis=kernel-resource-usage"]
+# GHM_BUILD_DEFINES="-DGHM_SPLIT_ABLATION ...": extra defines for tuning builds (ablation instantiations; never the shipped build)
+FLAGS += os.environ.get("GHM_BUILD_DEFINES", "").split()
 
 
 def _stale(obj, deps):
@@ -86,7 +88,7 @@ def kernel_resources():
 # scratch use that is known and outside every hot loop (bytes per lane): the 36-tap fan-out variant spills in its
 # prologue; the pooled fan-out variants, which hold two rows of accumulators, reload 11 spilled weight fragments per
 # 104-MFMA pixel group
-BENIGN_SCRATCH = {"fanout_kernelILi18ELi2ELi4ELb0ELb0": 52, "fanout_kernelILi13ELi2ELi2ELb0ELb1": 96,
+BENIGN_SCRATCH = {"sp_conv2_kernelILi3ELi1ELi128ELi8ELi1ELi4E": 24, "sp_conv2_kernelILi3ELi1ELi128ELi8ELi2ELi4E": 24, "fanout_kernelILi18ELi2ELi4ELb0ELb0": 52, "fanout_kernelILi13ELi2ELi2ELb0ELb1": 96,
                   "fanout_kernelILi18ELi2ELi2ELb0ELb1": 160}
 
 

@@ -180,6 +180,128 @@ struct SpConvArgs {
 
 constexpr int NP = 3;
 
+// the epilogue of the forward-form kernels: fp32 NCHW and / or the split q copy, split-K partials, or the pooled form
+template <int BM, int RT, int WM, int WN, bool POOL, int TW, int TM, int TN>
+__device__ __forceinline__ void sp_conv_epilogue(const SpConvArgs& a, f32x16 (&acc)[TM][TN], f32x16 (&accc)[TM][TN], u32x4* sp_smem,
+                                                 int tid, int wm, int wn, int kg, int li, int lx, int ly, int n, int r0, int y0,
+                                                 int x0, int HW) {
+    constexpr int RPF = 32 / TW;
+    // ---- epilogue (fp32): lanes along pixels; row of element e of tile i: i*32 + (e&3) + 8*(e>>2) + 4*kg ----
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] += accc[i][j][e];
+    const long P = (long)a.N * HW;
+    const int ru = r0 + wm * (BM / WM);
+    const int rl = ru + 4 * kg;
+    if (a.partial) {
+        float* const pb = a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HW + (long)(y0 + wn * TN * RPF) * a.W + x0;
+        const unsigned lo = 4u * kg * (unsigned)P + ly * a.W + lx;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    float* rowp = pb + (long)k * P + j * RPF * a.W;
+                    if (rl + k < a.R) rowp[lo] = acc[i][j][e];
+                }
+        return;
+    }
+    float* const sb = reinterpret_cast<float*>(sp_smem);          // bias through LDS (free after the last barrier)
+    if (tid < BM) sb[tid] = (a.bias && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
+    __syncthreads();
+    const float* const lb = sb + wm * (BM / WM) + 4 * kg;
+    const float slope = a.act == GHM_ACT_LINEAR ? 1.f : (a.act == GHM_ACT_RELU ? 0.f : a.alpha);
+    const bool pwl = a.act == GHM_ACT_LINEAR || a.act == GHM_ACT_RELU || a.act == GHM_ACT_LRELU;
+    if constexpr (POOL) {
+        // 2x2 max-pool of act(conv + bias): the row pair of a window is in one lane, the column pair in lanes (2t, 2t+1)
+        static_assert(!POOL || (TN % 2 == 0 && TW == 32), "pooled epilogue: row pairs inside a wave, 32-column tiles (stride 1)");
+        const int Wp = a.W / 2;
+        const long HWp = (long)(a.H / 2) * Wp;
+        const long pix = (long)((y0 + wn * TN) / 2) * Wp + (x0 + li) / 2;
+        const long base = ((long)n * a.R + rl) * HWp + pix;
+        const bool even = (li & 1) == 0;
+        uint2* const qb = a.out_q ? a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(ru / 8) * HWp + pix) + kg : nullptr;
+        const long ps2 = 2 * (long)a.N * a.out_q_nstride;
+#pragma unroll
+        for (int j2 = 0; j2 < TN / 2; ++j2)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float mq[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int e = 4 * g + t, k = i * 32 + t + 8 * g;
+                        float v0 = acc[i][2 * j2][e] + lb[k], v1 = acc[i][2 * j2 + 1][e] + lb[k];
+                        v0 = v0 > 0.f ? v0 : slope * v0;
+                        v1 = v1 > 0.f ? v1 : slope * v1;
+                        const float w0 = __shfl_xor(v0, 1, 64), w1 = __shfl_xor(v1, 1, 64);
+                        const float m = fmaxf(fmaxf(v0, v1), fmaxf(w0, w1));
+                        const unsigned mk = (v0 == m ? 1u : 0u) | (w0 == m ? 2u : 0u) | (v1 == m ? 4u : 0u) | (w1 == m ? 8u : 0u) |
+                                            (m > 0.f ? GHM_POOL_SIGN : 0u);
+                        mq[t] = m;
+                        if (even && rl + k < a.R) {
+                            const long o = base + (long)k * HWp + j2 * Wp;
+                            if (a.pool_out) a.pool_out[o] = m;
+                            a.pool_mask[o] = (unsigned char)mk;
+                        }
+                    }
+                    if (qb && even && rl + i * 32 + 8 * g < a.R)
+                        sp_qstore4(qb + 2 * ((long)(i * 4 + g) * HWp + j2 * Wp), mq[0], mq[1], mq[2], mq[3], ps2);
+                }
+        return;
+    }
+    float* const ub = a.out ? a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN * RPF) * a.W + x0 : nullptr;
+    const unsigned lo = 4u * kg * (unsigned)HW + ly * a.W + lx;
+    const bool full = r0 + BM <= a.R;
+    uint2* const qb = a.out_q ? a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(ru / 8) * HW +
+                                                 (long)(y0 + wn * TN * RPF + ly) * a.W + x0 + lx) + kg : nullptr;
+    const long ps2 = 2 * (long)a.N * a.out_q_nstride;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                v[e] = acc[i][j][e] + lb[k];
+            }
+            if (a.accumulate) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    if (full || rl + k < a.R) v[e] += (ub + (long)k * HW + j * RPF * a.W)[lo];
+                }
+            }
+            if (pwl) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = ghm_act(v[e], a.act, a.alpha);
+            }
+            if (ub) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    if (full || rl + k < a.R) (ub + (long)k * HW + j * RPF * a.W)[lo] = v[e];
+                }
+            }
+            if (qb) {       // e = 4g .. 4g+3: four consecutive channels of this lane's pixel = half a q unit (kg picks the half)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (full || rl + i * 32 + 8 * g < a.R)
+                        sp_qstore4(qb + 2 * ((long)(i * 4 + g) * HW + j * RPF * a.W), v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], ps2);
+            }
+        }
+}
+
 template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL = false, int TW = 32>
 __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvArgs a) {
     // TW = columns of the pixel tile (32, or 16 / 8 for narrow maps): the 32 pixel lanes of a fragment cover RPF = 32 / TW
@@ -340,122 +462,272 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
         }
     }
 
-    // ---- epilogue (fp32): lanes along pixels; row of element e of tile i: i*32 + (e&3) + 8*(e>>2) + 4*kg ----
+    sp_conv_epilogue<BM, RT, WM, WN, POOL, TW, TM, TN>(a, acc, accc, sp_smem, tid, wm, wn, kg, li, lx, ly, n, r0, y0, x0, HW);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sp_conv2_kernel (round 5): the tile, the LDS images and the arithmetic of sp_conv_kernel with a BRANCH-FREE, software-
+// pipelined K loop.  What the ISA of the first form showed (one wave per SIMD, so nothing hides a wave's own bubbles): every
+// iteration began with ~440 scalar / vector instructions in 75 basic blocks -- each exec-masked LDS-DMA instruction sat behind
+// its own branch -- issued with the matrix pipe idle, and the first filter column's fragments were read behind serial
+// ``s_waitcnt lgkmcnt(0)``: together the 40 % of the cycles in which SQ_VALU_MFMA_BUSY_CYCLES did not count.  Here
+//   * every wave issues the SAME number of DMA instructions per iteration, unconditionally: a lane outside the image reads the
+//     zero unit, a chunk outside the patch / weight tile lands in a 1 KB scratch chunk of LDS -- no exec masks, no branches;
+//     addresses are a uniform base + a per-lane 32-bit offset fixed at kernel start (weights) or a per-lane pointer walked by
+//     per-lane increments (patch: 0 for padding lanes);
+//   * the whole slab (KS filter rows x KS columns) is one basic block; the DMA of iteration it + 2 and the fragment reads of
+//     the next k-step are placed between the MFMAs of the current one (sched_group_barrier);
+//   * the barrier of an iteration sits at the end of its second-last column: behind it the last column's MFMAs run while the
+//     first fragments of the next iteration are read and the weights two iterations ahead are requested, so a DMA has a full
+//     iteration to land and no fragment read is exposed;
+//   * past the end of the contraction the pipeline keeps issuing (clamped to valid addresses): no peeled tail.
+// ------------------------------------------------------------------------------------------------
+template <int KS, int ST, int BM, int RT, int WM, int WN, int TW>
+struct SpGeo2 {
+    static constexpr int RPF = 32 / TW, ROWS = RT * RPF;
+    static constexpr int PH = (ROWS - 1) * ST + KS, PW = (TW - 1) * ST + KS;
+    static constexpr int PU1 = 2 * PH * PW, PCH = (PU1 + 63) / 64, PUP = PCH * 64;   // patch units / 64-unit chunks / padded
+    static constexpr int WU1 = 2 * KS * BM, NI = WU1 / 64;
+    static constexpr int NW = WM * WN;
+    static constexpr int NQ = (PCH + NW - 1) / NW;                 // patch DMA instructions per wave and piece
+    static constexpr int NIW = (NP * NI + NW - 1) / NW;            // weight DMA instructions per wave and iteration
+    static constexpr int WUNITS = NP * WU1, PUNITS = NP * PUP;
+    static constexpr int SCR = 2 * WUNITS + 2 * PUNITS;            // the scratch chunk
+    static constexpr int LDS_BYTES = (SCR + 64) * 16;
+};
+
+struct SpFragDummy {};
+
+// ABL (tuning only, wrong results): 1 = no DMA inside the loop, 2 = no waits / barriers inside the loop, 4 = no fragment reads
+// inside the loop -- what each costs beside the MFMA stream itself
+template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL = false, int TW = 32, int ABL = 0>
+__global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvArgs a) {
+    typedef SpGeo2<KS, ST, BM, RT, WM, WN, TW> G;
+    constexpr int T = KS * KS;
+    constexpr int RPF = G::RPF, ROWS = G::ROWS;
+    constexpr int TM = BM / (WM * 32), TN = RT / WN;
+    constexpr int PH = G::PH, PW = G::PW, PU1 = G::PU1, PCH = G::PCH, PUP = G::PUP;
+    constexpr int WU1 = G::WU1, NI = G::NI, NW = G::NW, NQ = G::NQ, NIW = G::NIW;
+    constexpr int WUNITS = G::WUNITS, PUNITS = G::PUNITS, SCR = G::SCR;
+    constexpr int NMF = 6 * TM * TN;                 // MFMAs per k-step
+    constexpr int NRD = NP * (TM + TN);              // fragment reads per k-step
+    static_assert(TM >= 1 && TN >= 1 && KS >= 3, "tile / pipeline shape");
+    extern __shared__ __attribute__((aligned(16))) u32x4 sp_smem[];
+    u32x4* const Wl = sp_smem;                         // [2 buffers][piece][2 ch-blocks][KS][BM]
+    u32x4* const Pl = sp_smem + 2 * WUNITS;            // [2 buffers][piece][PUP: 2 ch-blocks x PH x PW, padded to whole chunks]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int kg = lane >> 5, li = lane & 31;
+    const int ntr = (a.R + BM - 1) / BM;
+    const int tiles_x = a.W / TW, tiles_y = a.H / ROWS;
+    int L = sp_xcd_remap(blockIdx.x, gridDim.x);
+    const int r0 = (L % ntr) * BM;
+    L /= ntr;
+    const int tx = L % tiles_x;
+    L /= tiles_x;
+    const int ty = L % tiles_y;
+    const int n = L / tiles_y;
+    const int y0 = ty * ROWS, x0 = tx * TW;
+    const int lx = li % TW, ly = li / TW;
+    const int HW = a.H * a.W, HWin = a.Hin * a.Win;
+    const int nslabs = a.CH / 16;
+    const int s_begin = blockIdx.y * a.slabs_per_split;
+    const int s_end = min(nslabs, s_begin + a.slabs_per_split);
+
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    // ---- weight DMA: instruction i of this wave copies chunk j = wave + i * NW of the NP * NI chunks of a filter row ----
+    // address = (filter row base + wave-uniform chunk offset: scalar registers) + lane * 16
+    const unsigned lane16 = lane * 16;
+    unsigned wu[NIW];            // chunk's byte offset from the filter row's base (wave-uniform)
+    int wl[NIW];                 // LDS unit offset inside a weight buffer
+    bool wreal[NIW];
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+        const int j = wave + i * NW;
+        wreal[i] = j < NP * NI;
+        const int jj = wreal[i] ? j : 0;
+        const int p = jj / NI, w = jj - p * NI;
+        const int ci = w / (BM / 64), h = w - ci * (BM / 64);
+        const int cb = ci / KS, b = ci - cb * KS;
+        wu[i] = (unsigned)(((long)p * a.wq_pstride + ((long)cb * T + b) * a.Rpad + h * 64) * 16);
+        wl[i] = p * WU1 + w * 64;
+    }
+    const char* const wbase = (const char*)(a.wq + r0);
+    const long wrow = (long)KS * a.Rpad * 16;             // bytes between filter rows of a slab
+    const long wslab = (long)2 * T * a.Rpad * 16;         // ... between slabs
+    // filter row ``fa`` of slab ``s`` -> weight buffer at unit offset ``tog``
+    auto dma_w = [&](int s, int fa, int tog) {
+        const char* const src = wbase + (long)s * wslab + fa * wrow;
+#pragma unroll
+        for (int i = 0; i < NIW; ++i)
+            if (ABL & 16)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + wu[i] + lane16), (lptr_t)(sp_smem + (wreal[i] ? wl[i] + tog : SCR)), 4, 0, 0);
+            else if (ABL & 8)
+                __builtin_amdgcn_global_load_lds((gptr_t)a.zeros, (lptr_t)(sp_smem + (wreal[i] ? wl[i] + tog : SCR)), 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + wu[i] + lane16), (lptr_t)(sp_smem + (wreal[i] ? wl[i] + tog : SCR)), 16, 0, 0);
+    };
+
+    // ---- patch DMA: instruction q of this wave and piece copies chunk c = wave + q * NW of the PCH chunks ----
+    const char* pp[NQ];          // this lane's unit of the slab staged last, piece 0 (the zero unit for padding lanes)
+    unsigned pok = 0;            // bit q: the lane's unit of chunk q is inside the image (else it stays on the zero unit)
+    int pl[NQ];
+    bool preal[NQ];
+    {
+        const u32x4* const ibase = a.in_q + (long)n * a.in_q_nstride + (long)s_begin * 2 * HWin;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = wave + q * NW;
+            preal[q] = c < PCH;
+            const int e = c * 64 + lane;
+            const int cb = e / (PH * PW), rem = e - cb * (PH * PW);
+            const int py = rem / PW, px = rem - py * PW;
+            const int y = y0 * ST + py - a.pad, x = x0 * ST + px - a.pad;
+            const bool ok = e < PU1 && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
+            pp[q] = ok ? (const char*)(ibase + (long)cb * HWin + y * a.Win + x) : (const char*)a.zeros;
+            pok |= ok ? 1u << q : 0u;
+            pl[q] = c * 64;
+        }
+    }
+    const long pstep = a.in_q_pstride * 16;       // bytes between the pieces of a q tensor
+    const long sstep = (long)2 * HWin * 16;       // ... between slabs
+    auto dma_p = [&](int tog, bool advance) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const bool ok = (pok >> q) & 1u;
+            pp[q] += (advance && ok) ? sstep : 0;
+            const char* g = pp[q];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (ABL & 16)
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(sp_smem + (preal[q] ? 2 * WUNITS + tog + p * PUP + pl[q] : SCR)), 4, 0, 0);
+                else if (ABL & 8)
+                    __builtin_amdgcn_global_load_lds((gptr_t)a.zeros, (lptr_t)(sp_smem + (preal[q] ? 2 * WUNITS + tog + p * PUP + pl[q] : SCR)), 16, 0, 0);
+                else
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(sp_smem + (preal[q] ? 2 * WUNITS + tog + p * PUP + pl[q] : SCR)), 16, 0, 0);
+                g += ok ? pstep : 0;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN], accc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] += accc[i][j][e];
-    const long P = (long)a.N * HW;
-    const int ru = r0 + wm * (BM / WM);
-    const int rl = ru + 4 * kg;
-    if (a.partial) {
-        float* const pb = a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HW + (long)(y0 + wn * TN * RPF) * a.W + x0;
-        const unsigned lo = 4u * kg * (unsigned)P + ly * a.W + lx;
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = accc[i][j][e] = 0.f;
+
+    struct Frag {
+        u32x4 a[NP][TM], b[NP][TN];
+    };
+    const int wlane = kg * KS * BM + wm * (BM / WM) + li;
+    const int plane = kg * PH * PW + ((wn * TN * RPF + ly) * ST) * PW + lx * ST;
+    // fragments of (filter row fa, column b): weights from the buffer at Wb, patch from the buffer at Pb; in the order of
+    // their first use (the six products run small terms first: a2 b0, a1 b1, a0 b2, a1 b0, a0 b1, a0 b0)
+    auto rd = [&](Frag& f, const u32x4* Wb, const u32x4* Pb, int fa, int b) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) f.a[NP - 1 - p][i] = Wb[(NP - 1 - p) * WU1 + b * BM + i * 32];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                    float* rowp = pb + (long)k * P + j * RPF * a.W;
-                    if (rl + k < a.R) rowp[lo] = acc[i][j][e];
-                }
-        return;
-    }
-    float* const sb = reinterpret_cast<float*>(sp_smem);          // bias through LDS (free after the last barrier)
-    if (tid < BM) sb[tid] = (a.bias && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
-    __syncthreads();
-    const float* const lb = sb + wm * (BM / WM) + 4 * kg;
-    const float slope = a.act == GHM_ACT_LINEAR ? 1.f : (a.act == GHM_ACT_RELU ? 0.f : a.alpha);
-    const bool pwl = a.act == GHM_ACT_LINEAR || a.act == GHM_ACT_RELU || a.act == GHM_ACT_LRELU;
-    if constexpr (POOL) {
-        // 2x2 max-pool of act(conv + bias): the row pair of a window is in one lane, the column pair in lanes (2t, 2t+1)
-        static_assert(!POOL || (TN % 2 == 0 && ST == 1 && TW == 32), "pooled epilogue: row pairs inside a wave, 32-column tiles");
-        const int Wp = a.W / 2;
-        const long HWp = (long)(a.H / 2) * Wp;
-        const long pix = (long)((y0 + wn * TN) / 2) * Wp + (x0 + li) / 2;
-        const long base = ((long)n * a.R + rl) * HWp + pix;
-        const bool even = (li & 1) == 0;
-        uint2* const qb = a.out_q ? a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(ru / 8) * HWp + pix) + kg : nullptr;
-        const long ps2 = 2 * (long)a.N * a.out_q_nstride;
+            for (int j = 0; j < TN; ++j) f.b[p][j] = Pb[p * PUP + fa * PW + j * RPF * ST * PW + b];
+        }
+    };
+    auto mm = [&](const Frag& f) {
 #pragma unroll
-        for (int j2 = 0; j2 < TN / 2; ++j2)
+        for (int pr = 0; pr < 6; ++pr) {
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float mq[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int e = 4 * g + t, k = i * 32 + t + 8 * g;
-                        float v0 = acc[i][2 * j2][e] + lb[k], v1 = acc[i][2 * j2 + 1][e] + lb[k];
-                        v0 = v0 > 0.f ? v0 : slope * v0;
-                        v1 = v1 > 0.f ? v1 : slope * v1;
-                        const float w0 = __shfl_xor(v0, 1, 64), w1 = __shfl_xor(v1, 1, 64);
-                        const float m = fmaxf(fmaxf(v0, v1), fmaxf(w0, w1));
-                        const unsigned mk = (v0 == m ? 1u : 0u) | (w0 == m ? 2u : 0u) | (v1 == m ? 4u : 0u) | (w1 == m ? 8u : 0u) |
-                                            (m > 0.f ? GHM_POOL_SIGN : 0u);
-                        mq[t] = m;
-                        if (even && rl + k < a.R) {
-                            const long o = base + (long)k * HWp + j2 * Wp;
-                            if (a.pool_out) a.pool_out[o] = m;
-                            a.pool_mask[o] = (unsigned char)mk;
-                        }
-                    }
-                    if (qb && even && rl + i * 32 + 8 * g < a.R)
-                        sp_qstore4(qb + 2 * ((long)(i * 4 + g) * HWp + j2 * Wp), mq[0], mq[1], mq[2], mq[3], ps2);
+                for (int j = 0; j < TN; ++j) {
+                    if (pr < 5)
+                        accc[i][j] = sp_mfma(f.a[PA[pr]][i], f.b[PB[pr]][j], accc[i][j]);
+                    else
+                        acc[i][j] = sp_mfma(f.a[0][i], f.b[0][j], acc[i][j]);
                 }
-        return;
+        }
+    };
+
+    // ---- prologue: filter row 0 and the patch of the first slab, then filter row 1; the first fragments ----
+    const int s_last = s_end - 1;
+    if (s_begin < s_end) {
+        dma_w(s_begin, 0, 0);
+        dma_p(0, false);
     }
-    float* const ub = a.out ? a.out + (long)n * a.out_nstride + (long)ru * HW + (long)(y0 + wn * TN * RPF) * a.W + x0 : nullptr;
-    const unsigned lo = 4u * kg * (unsigned)HW + ly * a.W + lx;
-    const bool full = r0 + BM <= a.R;
-    uint2* const qb = a.out_q ? a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(ru / 8) * HW +
-                                                 (long)(y0 + wn * TN * RPF + ly) * a.W + x0 + lx) + kg : nullptr;
-    const long ps2 = 2 * (long)a.N * a.out_q_nstride;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (s_begin < s_end) dma_w(s_begin, 1, WUNITS);
+    int w0 = 0, p0 = 0;          // unit offsets of the weight buffer of the slab's filter row 0 / of the slab's patch buffer
+    Frag cur;
+    rd(cur, Wl + wlane, Pl + plane, 0, 0);
+
+    for (int s = s_begin; s < s_end; ++s) {
+        const int sn = s < s_last ? s + 1 : s;          // the slab staged from this one (itself at the end: harmless)
+        const u32x4* const Pc = Pl + p0 + plane;
+        const u32x4* const Pn = Pl + (PUNITS - p0) + plane;
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+        for (int fa = 0; fa < KS; ++fa) {
+            const int wc = (fa & 1) ? WUNITS - w0 : w0;         // this filter row's weight buffer
+            const u32x4* const Wc = Wl + wc + wlane;
+            const u32x4* const Wn = Wl + (WUNITS - wc) + wlane;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float v[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                v[e] = acc[i][j][e] + lb[k];
-            }
-            if (a.accumulate) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                    if (full || rl + k < a.R) v[e] += (ub + (long)k * HW + j * RPF * a.W)[lo];
+            for (int b = 0; b < KS; ++b) {
+                Frag nx;
+                int ndma = 0;
+                if (ABL & 4) {
+                    nx = cur;
+                } else if (b + 1 < KS) {
+                    rd(nx, Wc, Pc, fa, b + 1);
+                } else {                                         // the next iteration's first column
+                    rd(nx, Wn, fa + 1 < KS ? Pc : Pn, fa + 1 < KS ? fa + 1 : 0, 0);
                 }
-            }
-            if (pwl) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = ghm_act(v[e], a.act, a.alpha);
-            }
-            if (ub) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                    if (full || rl + k < a.R) (ub + (long)k * HW + j * RPF * a.W)[lo] = v[e];
+                if (b + 1 == KS && !(ABL & 1)) {
+                    // the filter row two iterations ahead replaces this one's (all of its fragments were read before the barrier)
+                    if (fa + 2 < KS)
+                        dma_w(s, fa + 2, wc);
+                    else
+                        dma_w(sn, fa + 2 - KS, wc);
+                    ndma = NIW;
                 }
-            }
-            if (qb) {       // e = 4g .. 4g+3: four consecutive channels of this lane's pixel = half a q unit (kg picks the half)
+                if (fa == 0 && b == 0 && !(ABL & 1)) {           // the next slab's patch
+                    dma_p(PUNITS - p0, s < s_last);
+                    ndma = NP * NQ;
+                }
+                mm(cur);
+                // fragment reads, then DMA, one behind each MFMA, front-loaded: the next k-step starts on fragments read long ago
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (full || rl + i * 32 + 8 * g < a.R)
-                        sp_qstore4(qb + 2 * ((long)(i * 4 + g) * HW + j * RPF * a.W), v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], ps2);
+                for (int m_ = 0; m_ < NRD; ++m_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int m_ = 0; m_ < ndma; ++m_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+                if (b == KS - 2 && !(ABL & 2)) {
+                    // everything but the patch requested in this iteration has landed; all reads of this filter row are done
+                    if (fa == 0)
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NP * NQ) : "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nx;
             }
         }
-}
+        if (KS & 1) w0 = WUNITS - w0;
+        p0 = PUNITS - p0;
+    }
+    // DMA still in flight targets LDS the epilogue reuses
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
+    sp_conv_epilogue<BM, RT, WM, WN, POOL, TW, TM, TN>(a, acc, accc, sp_smem, tid, wm, wn, kg, li, lx, ly, n, r0, y0, x0, HW);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Weight gradient (3x3 stride 1 / 2, 5x5 stride 1; 'same') from split q tensors: dwp[(c, tap)][k] = sum over pixels of
@@ -493,7 +765,31 @@ __device__ __forceinline__ u32x4 sp_tr_read8(const char* lds_lo, const char* lds
     return r;
 }
 
-template <int KS, int ST, int CHT, int CT, int SPX>
+// The same transposing read as inline assembly (round 5).  The compiler orders an LDS read it cannot disambiguate behind every
+// LDS-DMA in flight: with the builtin above it put ``s_waitcnt vmcnt(0)`` in front of the first fragment read of every output row
+// -- directly behind the DMA requests of the next row, whose whole latency was exposed once per row.  As assembly the read is
+// invisible to that pass; the kernel waits for its own fragments (sp_tr_wait: ``s_waitcnt lgkmcnt(0)`` tied to the registers).
+typedef unsigned long long sp_u64;
+struct SpTrFrag {
+    sp_u64 lo, hi;
+};
+__device__ __forceinline__ void sp_tr_issue(SpTrFrag& f, unsigned lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:256" : "=&v"(f.lo), "=&v"(f.hi) : "v"(lds_addr));
+}
+__device__ __forceinline__ u32x4 sp_tr_bits(const SpTrFrag& f) {
+    return u32x4{(unsigned)f.lo, (unsigned)(f.lo >> 32), (unsigned)f.hi, (unsigned)(f.hi >> 32)};
+}
+template <int N>
+__device__ __forceinline__ void sp_tr_wait(SpTrFrag (&f)[N]) {
+    static_assert(N == 3 || N == 5, "fragment sets of 3 or 5");
+    if constexpr (N == 3)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi),
+                     "+v"(f[3].lo), "+v"(f[3].hi), "+v"(f[4].lo), "+v"(f[4].hi));
+}
+
+template <int KS, int ST, int CHT, int CT, int SPX, bool ASMRD = true>
 __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const SpWgradArgs a) {
     static_assert((ST == 1 || (ST == 2 && KS == 3)) && (SPX == 64 || SPX == 32 || SPX == 16) && (KS == 3 || KS == 5), "variants");
     constexpr int T = KS * KS, PADK = KS / 2;
@@ -585,6 +881,59 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
     const char* const ylane = Yl + ww * YTB + lane_off;
     const char* const xlane = Xl + hh * NPAR * PLB + lane_off;
 
+    if constexpr (ASMRD) {
+        const unsigned lds0 = (unsigned)(size_t)(lptr_t)sp_wsmem;
+        const unsigned xl0 = lds0 + hh * NPAR * PLB + lane_off;
+        const unsigned yl0 = lds0 + NR * NP * ROWB + ww * YTB + lane_off;
+        for (int i = i_begin; i < i_end; ++i) {
+            const int buf = (i - i_begin) & 1;
+            if (i + 1 < i_end) {
+#pragma unroll
+                for (int r = 0; r < ST; ++r) stage_xrow(i * ST - PADK + KS + r);        // the rows the next output row adds
+                stage_dy(i + 1, buf ^ 1);
+            }
+            const unsigned xr = xl0 + (((i * ST + wr - PADK + NR) % NR) * NP) * ROWB;
+            const unsigned yb = yl0 + buf * NP * YB;
+            SpTrFrag af[2][KS], bf[2][NP];
+            auto read_x = [&](int ks, int p, int slot) {
+#pragma unroll
+                for (int fb = 0; fb < KS; ++fb) {
+                    const int par = ST == 2 ? (fb & 1) : 0;
+                    const int shift = ST == 2 ? (fb >> 1) : fb;
+                    sp_tr_issue(af[slot][fb], xr + p * ROWB + par * PLB + (ks * 16 + shift) * 64);
+                }
+            };
+            auto read_dy = [&](int ks, int slot) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) sp_tr_issue(bf[slot][q], yb + q * YB + ks * 1024);
+            };
+            read_dy(0, 0);
+            read_x(0, 2, 0);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+                for (int pi = 0; pi < NP; ++pi) {
+                    const int p = 2 - pi, ph = ks * NP + pi;
+                    // this phase's fragments have arrived (requested one phase ago) ...
+                    sp_tr_wait(af[ph & 1]);
+                    if (pi == 0) sp_tr_wait(bf[ks & 1]);
+                    // ... the next phase's are requested behind them
+                    if (pi + 1 < NP) {
+                        read_x(ks, p - 1, (ph + 1) & 1);
+                    } else if (ks + 1 < KSTEPS) {
+                        read_dy(ks + 1, (ks + 1) & 1);
+                        read_x(ks + 1, 2, (ph + 1) & 1);
+                    }
+#pragma unroll
+                    for (int q = 0; q <= 2 - p; ++q)
+#pragma unroll
+                        for (int t = 0; t < KS; ++t) acc[t] = sp_mfma(sp_tr_bits(af[ph & 1][t]), sp_tr_bits(bf[ks & 1][q]), acc[t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    } else
     for (int i = i_begin; i < i_end; ++i) {
         const int buf = (i - i_begin) & 1;
         if (i + 1 < i_end) {
@@ -914,10 +1263,14 @@ struct SpPlan {
 int sp_rpad(int r) { return (r + 127) / 128 * 128; }
 int sp_nblk(int red) { return (red + 15) / 16 * 2; }      // channel blocks of a pack (as the low-precision packs: whole slabs)
 
+// GHM_SPLIT_V1: the round-4 K loop (sp_conv_kernel) instead of the pipelined one (sp_conv2_kernel) -- A/B only
+bool sp_v1() { return GHM_OPT("GHM_SPLIT_V1") != nullptr; }
+
 size_t sp_lds_bytes(int ks, int st, int bm, int rt, int tw = 32) {
     const int rows = rt * (32 / tw);
     const int ph = (rows - 1) * st + ks, pw = (tw - 1) * st + ks;
-    return (size_t)2 * NP * (2 * ks * bm + 2 * ph * pw) * 16;
+    if (sp_v1()) return (size_t)2 * NP * (2 * ks * bm + 2 * ph * pw) * 16;
+    return ((size_t)2 * NP * (2 * ks * bm + (2 * ph * pw + 63) / 64 * 64) + 64) * 16;      // SpGeo2::LDS_BYTES
 }
 
 // forward form: CH reduction channels, R output channels, (H, W) output grid
@@ -935,6 +1288,8 @@ SpPlan sp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
             if (v == 1 || v == ks) return p;
         }
     if (p.tw == 32) {
+        // 3x3 stride 1, 128 filters: eight waves of 2 x 2 tiles (four waves of 4 x 2 tiles -- a quarter fewer fragment reads per
+        // MFMA -- measured 0-19 % slower alone: 212 against 231 TFLOP/s on the N4 C128 128^2 K256 data gradient)
         if (ks == 3 && st == 1) { p.bm = (R >= 96 && !GHM_OPT("GHM_SPLIT_BM64")) ? 128 : 64; p.rt = 8; p.wm = p.bm == 128 ? 2 : 1; p.wn = 4; }
         else if (ks == 5) { p.bm = 64; p.rt = 8; p.wm = 1; p.wn = 4; }
         else { p.bm = 64; p.rt = 4; p.wm = 2; p.wn = 2; }
@@ -985,6 +1340,41 @@ int sp_set_lds(K kernel, size_t lds) {
     return 0;
 }
 
+// one tile shape: the pipelined kernel (four-wave shapes) or, under GHM_SPLIT_V1, the round-4 kernel
+template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL, int TW>
+int sp_launch_variant(ghm_ctx* ctx, dim3 g, size_t lds, const SpConvArgs& a, bool v1) {
+    if (v1) {
+        if constexpr (!(BM == 128 && WM == 1)) {       // (the 4 x 2-tile shape is the pipelined kernel's)
+            if (int e = sp_set_lds(sp_conv_kernel<KS, ST, BM, RT, WM, WN, POOL, TW>, lds)) return e;
+            hipLaunchKernelGGL((sp_conv_kernel<KS, ST, BM, RT, WM, WN, POOL, TW>), g, dim3(WM * WN * 64), lds, ctx->stream, a);
+        }
+    } else if constexpr (true) {
+        static_assert(SpGeo2<KS, ST, BM, RT, WM, WN, TW>::LDS_BYTES <= 160 * 1024, "LDS");
+#ifdef GHM_SPLIT_ABLATION
+        if constexpr (KS == 5 && BM == 64 && RT == 8 && !POOL && TW == 32) {
+            const char* f = GHM_OPT("GHM_SPLIT_ABLATE");
+            const int abl = f ? atoi(f) : 0;
+#define GHM_ABL_CASE(A_)                                                                                              \
+            if (abl == A_) {                                                                                          \
+                if (int e = sp_set_lds(sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, A_>, lds)) return e;          \
+                hipLaunchKernelGGL((sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, A_>), g, dim3(WM * WN * 64), lds, ctx->stream, a); \
+                GHM_LAUNCH_CHECK();                                                                                   \
+                return 0;                                                                                             \
+            }
+            GHM_ABL_CASE(1) GHM_ABL_CASE(4) GHM_ABL_CASE(5) GHM_ABL_CASE(7) GHM_ABL_CASE(8) GHM_ABL_CASE(16)
+#undef GHM_ABL_CASE
+        }
+#endif
+        if (int e = sp_set_lds(sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW>, lds)) return e;
+        hipLaunchKernelGGL((sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW>), g, dim3(WM * WN * 64), lds, ctx->stream, a);
+    } else {
+        ghm_set_error("split-fp32 convolution: the eight-wave shape exists in the GHM_SPLIT_V1 form only");
+        return -3;
+    }
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
 // in32 != null: the fp32 operand is split into the launch's workspace first
 int sp_launch_conv(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, int ks, int st, const float* in32, long in32_nstride, bool pool) {
     a.slabs_per_split = pl.slabs_per_split;
@@ -1011,12 +1401,10 @@ int sp_launch_conv(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, int ks, int st,
     GHM_CHECK(!a.out_q || (a.R % 8 == 0 && ((uintptr_t)a.out_q & 15) == 0), "q output: a multiple of 8 channels, 16-byte aligned");
     const dim3 g(pl.grid, pl.splits);
 #define GHM_SP_CASE(KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_)                                                    \
-    if (ks == KS_ && st == ST_ && pl.bm == BM_ && pl.rt == RT_ && pool == POOL_ && pl.tw == TW_) {               \
-        if (int e = sp_set_lds(sp_conv_kernel<KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_>, pl.lds)) return e;      \
-        hipLaunchKernelGGL((sp_conv_kernel<KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_>), g, dim3(WM_ * WN_ * 64), pl.lds, \
-                           ctx->stream, a);                                                                      \
-        GHM_LAUNCH_CHECK();                                                                                      \
+    if (ks == KS_ && st == ST_ && pl.bm == BM_ && pl.rt == RT_ && pl.wm == WM_ && pool == POOL_ && pl.tw == TW_) {  \
+        if (int e = sp_launch_variant<KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_>(ctx, g, pl.lds, a, v1)) return e;  \
     } else
+    const bool v1 = sp_v1();
     GHM_SP_CASE(5, 1, 64, 8, 1, 4, false, 32)
     GHM_SP_CASE(5, 1, 64, 8, 1, 4, true, 32)
     GHM_SP_CASE(3, 1, 128, 8, 2, 4, false, 32)
@@ -1108,11 +1496,18 @@ int sp_launch_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const SpWPlan& v, cons
     const dim3 grid(d->C / (32 * v.cht), d->K / (32 * v.ct), splits);
 #define GHM_SPW_CASE(KS_, ST_, CHT_, CT_, SPX_)                                                                     \
     if (d->kh == KS_ && d->stride == ST_ && v.cht == CHT_ && v.ct == CT_ && v.spx == SPX_) {                       \
-        if (int e = sp_set_lds(sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_>, v.lds)) return e;                        \
-        hipLaunchKernelGGL((sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_>), grid, dim3(CHT_ * CT_ * KS_ * 64), v.lds, \
-                           ctx->stream, a);                                                                       \
+        if (v1w) {                                                                                                  \
+            if (int e = sp_set_lds(sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, false>, v.lds)) return e;             \
+            hipLaunchKernelGGL((sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, false>), grid, dim3(CHT_ * CT_ * KS_ * 64), v.lds, \
+                               ctx->stream, a);                                                                   \
+        } else {                                                                                                  \
+            if (int e = sp_set_lds(sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, true>, v.lds)) return e;              \
+            hipLaunchKernelGGL((sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, true>), grid, dim3(CHT_ * CT_ * KS_ * 64), v.lds, \
+                               ctx->stream, a);                                                                   \
+        }                                                                                                         \
         GHM_LAUNCH_CHECK();                                                                                       \
     } else
+    const bool v1w = GHM_OPT("GHM_SPLIT_WGRAD_V1") != nullptr;
     GHM_SPW_CASE(3, 1, 2, 2, 32)
     GHM_SPW_CASE(3, 2, 1, 4, 32)
     GHM_SPW_CASE(5, 1, 1, 2, 64)
