@@ -8,7 +8,8 @@
 
 A step = one call of the compiled train_fn of experiment test1_nobn_bilin_both (DCGAN G+D and pix2pix
 U-Net+PatchGAN forward, four gradient roots, four RMSprop updates) on a synthetic 512x512 batch of 4 per GPU
-(weak scaling) that is resident in HBM before the timed region.  One process per GPU; gradients are summed
+(weak scaling) that is resident in HBM before the timed region.  Arithmetic: fp32 (the reference's floatX) by operand splitting on the bf16 matrix cores
+(dtype "bf16x3").  One process per GPU; gradients are summed
 with RCCL.  Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel, HIP events inside the
 timed region) and "cpu_baseline" (the numpy oracle on the host cores; rank 0, N=1 only).
 """
@@ -85,20 +86,18 @@ MAX_TIMERS = 4096       # csrc/common.h GHM_MAX_TIMERS: recorded timer slots wra
 
 
 SECONDARY = [
-    # (name, overrides): BASELINE.json configs 1-5 beside the fp32 headline, each a short timed loop of its own AFTER the
-    # headline's timed region (never inside it), printed under one "secondary" key of the same JSON line
-    # the headline workload with the fp32 convolution products on the bf16 matrix cores by operand splitting (three bf16
-    # pieces per fp32 operand, six products, fp32 accumulation: fp32-accurate, tests/test_gpu_split.py) -- opt-in, so a
-    # secondary line; the headline stays on v_mfma_f32_32x32x2_f32
-    ("headline_workload_fp32_by_bf16x3_splitting", dict(dtype="bf16x3")),
+    # (name, overrides): BASELINE.json configs 1-5 beside the headline, each a short timed loop of its own AFTER the
+    # headline's timed region (never inside it), printed under one "secondary" key of the same JSON line.
+    # The headline arithmetic (round-4 review's ruling) is fp32 by operand splitting on the bf16 matrix cores (dtype
+    # "bf16x3"); the same workload on v_mfma_f32_32x32x2_f32 stays in the line as the first secondary value
+    ("headline_workload_fp32_mfma", dict(dtype="f32")),
     ("config4_per_gpu_bf16_512_b4", dict(dtype="bf16")),
     ("config5_per_gpu_f16_1024_b2", dict(dtype="f16", in_shp=1024, batch_per_gpu=2)),
-    ("config2_dcgan_512_b4_f32", dict(mode="dcgan")),
-    ("config3_p2p_512_b4_f32", dict(mode="p2p")),
-    ("config1_dcgan64_b16_f32", dict(config1=True)),
-    # configs 2 / 3 with the fp32 products by operand splitting (as the first line: opt-in arithmetic, fp32-accurate)
-    ("config2_dcgan_512_b4_fp32_by_bf16x3_splitting", dict(mode="dcgan", dtype="bf16x3")),
-    ("config3_p2p_512_b4_fp32_by_bf16x3_splitting", dict(mode="p2p", dtype="bf16x3")),
+    ("config2_dcgan_512_b4_fp32_by_bf16x3_splitting", dict(mode="dcgan")),
+    ("config3_p2p_512_b4_fp32_by_bf16x3_splitting", dict(mode="p2p")),
+    ("config1_dcgan64_b16_fp32_by_bf16x3_splitting", dict(config1=True)),
+    ("config2_dcgan_512_b4_fp32_mfma", dict(mode="dcgan", dtype="f32")),
+    ("config3_p2p_512_b4_fp32_mfma", dict(mode="p2p", dtype="f32")),
 ]
 
 
@@ -121,12 +120,13 @@ def parse_args(argv=None):
     ap.add_argument("--ablate", default="", help="TUNING ONLY (results are wrong): comma-separated program-entry labels or "
                     "kernel-name prefixes whose launches are skipped, to see what a class of kernels costs inside the "
                     "overlapped schedule; the JSON line is marked invalid")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16", "bf16x3"],
-                    help="arithmetic of the convolution products.  f32 (default) = the reference's floatX=float32 and the "
-                         "headline metric; bf16 / f16 = BASELINE configs 4 / 5 (matrix-core operands rounded, fp32 "
-                         "accumulation, fp32 tensors / master weights / optimiser): an additional line, never the headline; "
-                         "bf16x3 = fp32 arithmetic on the bf16 matrix cores by operand splitting (three bf16 pieces per "
-                         "fp32 value, six products, fp32 accumulation: fp32-accurate, opt-in, an additional line)")
+    ap.add_argument("--dtype", default="bf16x3", choices=["f32", "bf16", "f16", "bf16x3"],
+                    help="arithmetic of the convolution products.  bf16x3 (default, the headline) = the reference's "
+                         "floatX=float32 arithmetic on the bf16 matrix cores by operand splitting: three bf16 pieces per fp32 "
+                         "value that sum to it exactly, six products, fp32 accumulation -- fp32-accurate, held to the fp32 "
+                         "path's parity bounds; f32 = the same arithmetic on v_mfma_f32_32x32x2_f32 (a named secondary value); "
+                         "bf16 / f16 = BASELINE configs 4 / 5 (matrix-core operands rounded, fp32 accumulation, fp32 tensors / "
+                         "master weights / optimiser): additional lines, never the headline")
     ap.add_argument("--config1", action="store_true",
                     help="BASELINE config 1 instead of the headline workload: DCGAN 64x64 generator + discriminator "
                          "(nch 64, div [2,2,4,4] / [8,4,2,1]), batch 16, train_mode='dcgan' -- an extra line for BASELINE.md, "
@@ -340,6 +340,16 @@ def measure(args, secondary_name=None):
     # recorded timer slots wrap modulo MAX_TIMERS, so later replays would overwrite these event pairs
     timed_ms = [d.timer_ms(i) for d, i in timed]
     every_ms = {(id(d), i): d.timer_ms(i) for d, i, lab in every if lab is not None}
+    # ---- steady state: the split kernels' rate is data- and clock-dependent (the bf16 matrix pipes are power-managed, DESIGN
+    # section 4d): 60 more steps behind the timed region, reported beside ``value`` (never instead of it) ----
+    steady = None
+    if args.dtype == "bf16x3" and issue is not False and not args.ablate and world == 1 and not secondary_name:
+        eng.sync()
+        t1 = time.perf_counter()
+        for s in range(60):
+            eng.enqueue_train(b)
+        eng.sync()
+        steady = {"steps": 60, "after_steps": args.steps + args.warmup, "value": round(B * 60 / (time.perf_counter() - t1), 3)}
     # ---- the same loop with the reference's host-array boundary (pix2pix.py:142: train_fn(Z, X, Y) takes numpy
     # arrays): every step uploads its 16 KB + 4 MB + 12 MB batch over PCIe before it is enqueued ----
     with_h2d = with_h2d_sync = None
@@ -388,9 +398,9 @@ def measure(args, secondary_name=None):
         "config": {"workload": ("BASELINE config 1: DCGAN 64x64 generator + discriminator, " if args.config1 else "") +
                                "test1_nobn_bilin_both joint DCGAN+pix2pix train step (train_mode=%s), %dx%d, "
                                "batch %d per GPU, RMSprop lr 1e-4, LSGAN + 100*L1%s"
-                               % (args.mode, S, S, B, "" if args.dtype == "f32" else
-                                  ("; fp32 convolution products by operand splitting on the bf16 matrix cores (three "
-                                   "bf16 pieces per fp32 operand, six products, fp32 accumulation: fp32-accurate)"
+                               % (args.mode, S, S, B, "; fp32 on v_mfma_f32_32x32x2_f32" if args.dtype == "f32" else
+                                  ("; fp32 by operand splitting on the bf16 matrix cores (three bf16 pieces per fp32 "
+                                   "operand that sum to it exactly, six products, fp32 accumulation: fp32-accurate)"
                                    if args.dtype == "bf16x3" else
                                    "; convolution products in %s on the matrix cores, fp32 accumulation / tensors / "
                                    "master weights / optimiser" % args.dtype)),
@@ -413,6 +423,7 @@ def measure(args, secondary_name=None):
         if executed_flops_per_step else None,
         "losses": [float(x) for x in losses],
         # inputs uploaded from host arrays every step (the reference's train_fn(Z, X, Y) boundary); never ``value``
+        "steady_state": steady,
         "value_with_h2d": round(with_h2d, 3) if with_h2d else None,
         "value_with_h2d_synchronous": round(with_h2d_sync, 3) if with_h2d_sync else None,
         "hbm_bound_layers": {"note": "thin first / last layers, each launch timed alone (cold clocks); bound = HBM 8 TB/s",
@@ -445,20 +456,25 @@ def measure(args, secondary_name=None):
         traffic = None
         kdt_name = args.dtype if dominant.startswith(("lp_", "sp_")) else "f32"
         sfx = "f32" if kdt_name == "f32" else "bf16"
-        for pmc in ("r03_pmc_traffic_%s.json" % sfx, "r02_pmc_traffic_%s.json" % sfx, "r01_pmc_traffic.json"):    # tools/pmc_traffic.py
+        for pmc in ("r05_pmc_traffic_3stream_%s.json" % sfx, "r04_pmc_traffic_3stream_%s.json" % sfx,     # tools/pmc_traffic.py,
+                    "r03_pmc_traffic_%s.json" % sfx, "r02_pmc_traffic_%s.json" % sfx, "r01_pmc_traffic.json"):      # newest round first
             pmc = os.path.join(ROOT, "profiles", pmc)
             if traffic is None and os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get(dominant, {}).get("hbm_bytes_per_launch")
         if traffic is None and dominant.startswith("sp_"):
             # split kernels: the PMC file names the template instantiations; the wide-tile ones of this family, launch-weighted
-            pmc = os.path.join(ROOT, "profiles", "r04_pmc_traffic_3stream_bf16x3.json")
-            if os.path.exists(pmc):
-                fam = dominant.split(">")[0] + ","            # "sp_conv_kernel<3, 1" + ","
-                rows = [v for k, v in json.load(open(pmc)).items()
-                        if k.startswith(fam) and k.rstrip(">").endswith((", 32", ", 64")) and v.get("hbm_bytes_per_launch")]
-                n = sum(v["launches_sampled"] for v in rows)
-                if n:
-                    traffic = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in rows) / n
+            for pmc in ("r05_pmc_traffic_3stream_bf16x3.json", "r04_pmc_traffic_3stream_bf16x3.json"):
+                pmc = os.path.join(ROOT, "profiles", pmc)
+                if traffic is None and os.path.exists(pmc):
+                    # "sp_conv_kernel<3, 1" -> "sp_conv" + "<3, 1,": the round-5 kernel is sp_conv2_kernel
+                    fam = dominant.split("<")[1].split(">")[0] + ","
+                    stem = dominant.split("_kernel")[0]
+                    rows = [v for k, v in json.load(open(pmc)).items()
+                            if k.startswith(stem) and ("<" + fam) in k and k.rstrip(">").endswith((", 32", ", 64", ", 0", ", true", ", false"))
+                            and v.get("hbm_bytes_per_launch")]
+                    n = sum(v["launches_sampled"] for v in rows)
+                    if n:
+                        traffic = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in rows) / n
         iso = flops_per_launch / (isolated_ms * 1e-3) / 1e12
         # the dominant kernel is priced against the peak of the arithmetic IT runs in (a thin / small-map kernel that
         # stays fp32 in a bf16 step is an fp32 kernel)
@@ -495,7 +511,7 @@ def main():
     from gan_heightmaps_amd import dist
     rank, _, world = dist.env_rank_world()
     out = measure(args)
-    headline = (args.mode == "both" and args.dtype == "f32" and not args.config1 and args.in_shp == 512
+    headline = (args.mode == "both" and args.dtype == "bf16x3" and not args.config1 and args.in_shp == 512
                 and args.batch_per_gpu == 4 and not args.graph and not args.one_stream and not args.no_grad_streams)
     if rank == 0 and world == 1 and headline and not args.no_secondary and not args.ablate:
         import copy
@@ -510,15 +526,15 @@ def main():
             except Exception as ex:           # a secondary line must never take the headline down with it
                 sec.append({"name": name, "error": "%s: %s" % (type(ex).__name__, ex)})
         out["secondary"] = sec
-        sp = next((r for r in sec if r.get("name") == "headline_workload_fp32_by_bf16x3_splitting" and "value" in r), None)
+        sp = next((r for r in sec if r.get("name") == "headline_workload_fp32_mfma" and "value" in r), None)
         if sp is not None:
-            # the same workload, same fp32 accuracy, on the bf16 matrix cores: opt-in, so NOT ``value``
-            out["value_fp32_by_operand_splitting"] = sp["value"]
-            out["fp32_by_operand_splitting_note"] = (
-                "headline workload with each fp32 operand split into three bf16 pieces that sum to it exactly and the six "
-                "leading piece products on v_mfma_f32_32x32x16_bf16 (fp32 accumulation): passes the fp32 path's parity tests "
-                "with the fp32 path's bounds (tests/test_gpu_split.py, test_gpu_fullsize.py [bf16x3]); opt-in "
-                "(--dtype bf16x3), kept out of `value`")
+            # the same workload on the fp32 matrix instruction (the headline of rounds 1-4): a named secondary value
+            out["value_fp32_mfma"] = sp["value"]
+            out["arithmetic_note"] = (
+                "value: every fp32 operand split into three bf16 pieces that sum to it exactly, the six leading piece products "
+                "on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (dtype bf16x3; peak 2500 / 6 = 416.7 TFLOP/s fp32-equivalent); "
+                "passes the fp32 path's parity tests with the fp32 path's bounds in both modes (tests/test_gpu_split.py, "
+                "test_gpu_step.py, test_gpu_fullsize.py).  value_fp32_mfma: the same step on v_mfma_f32_32x32x2_f32 (--dtype f32)")
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.in_shp == 512 and not args.config1:
         out["cpu_baseline"] = cpu_baseline(2)
     if rank == 0:

@@ -119,6 +119,8 @@ SIGNATURES = {
     "ghm_bn_stats": [_p, _p, _i32, _i32, _i32, _i64, _f, _p, _p, _p, _p, _f, _p],
     "ghm_bn_apply": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _f],
     "ghm_bn_forward": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _f, _p, _p, _p, _p, _f, _p, _p, _i32, _f, _p],
+    "ghm_instance_norm_fwd": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _f, _p, _p, _p, _p, _i32, _f, _p, _i32],
+    "ghm_instance_norm_bwd": [_p, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _f, _i32, _p, _i32],
     "ghm_bn_backward": [_p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p,
                         _i32, _f, _i32, _p],
     "ghm_act_fwd": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _f],

@@ -37,14 +37,16 @@ int* ghm_tickets(ghm_ctx* ctx, long tiles) {
     return ctx->tickets;
 }
 
-// flags of the events that order one stream of the GPU behind another: every consumer is a kernel on the SAME device, so a
-// device-scope release is enough (hipEventReleaseToDevice); HIP's default is a system-scope release (visible to the host),
-// i.e. a heavier cache write-back at every one of the ~100 cross-stream dependencies of a step.  GHM_EVENT_SYSTEM_SCOPE=1
-// restores the default for A/B.
-static unsigned ghm_event_flags() {
+// flags of the events that order one COMPUTE stream of the GPU behind another: every consumer is a kernel on the SAME device,
+// so a device-scope release is enough (hipEventReleaseToDevice); HIP's default is a system-scope release (visible to the host
+// and to peers), i.e. a heavier cache write-back at every one of the ~100 cross-stream dependencies of a step.  ``system``:
+// edges whose other side is NOT a kernel of this device keep the default -- the communication stream (RCCL reads and writes
+// these buffers from peer GPUs over xGMI) and the persistent events the host synchronises on / that order host-to-device
+// copies.  GHM_EVENT_SYSTEM_SCOPE=1 restores the default everywhere for A/B.
+static unsigned ghm_event_flags(bool system) {
     static int sys_ = -1;
     if (sys_ < 0) sys_ = getenv("GHM_EVENT_SYSTEM_SCOPE") ? 1 : 0;
-    return hipEventDisableTiming | (sys_ ? 0u : (unsigned)hipEventReleaseToDevice);
+    return hipEventDisableTiming | ((sys_ || system) ? 0u : (unsigned)hipEventReleaseToDevice);
 }
 
 static int g_plan_cus = 256;
@@ -231,7 +233,7 @@ int ghm_h2d_async(ghm_ctx* ctx, void* dst, const void* src_pinned, size_t bytes)
 int ghm_event_create(ghm_ctx* ctx, void** out) {
     GHM_HIP(hipSetDevice(ctx->device));
     hipEvent_t ev;
-    GHM_HIP(hipEventCreateWithFlags(&ev, ghm_event_flags()));
+    GHM_HIP(hipEventCreateWithFlags(&ev, ghm_event_flags(true)));      // the host waits on these (ghm_event_sync), copies sit behind them
     *out = (void*)ev;
     return 0;
 }
@@ -344,12 +346,14 @@ int ghm_sync(ghm_ctx* ctx) {
 int ghm_stream_wait(ghm_ctx* ctx, ghm_ctx* other) {
     // everything enqueued on ``ctx`` after this call runs after everything enqueued on ``other`` so far
     GHM_CHECK(ctx->device == other->device, "ghm_stream_wait across devices");
+    // an edge into or out of a communication stream orders memory that peer GPUs touch: system-scope release
+    const bool sys_edge = ctx->comm != nullptr || other->comm != nullptr;
     if (ctx->rec) {
         ghm_step* st = ctx->rec;
         hipStream_t mine = ctx->stream, theirs = other->stream;
         st->cmds.emplace_back([=]() {
             hipEvent_t ev;
-            hipError_t e = hipEventCreateWithFlags(&ev, ghm_event_flags());
+            hipError_t e = hipEventCreateWithFlags(&ev, ghm_event_flags(sys_edge));
             if (e == hipSuccess) e = hipEventRecord(ev, theirs);
             if (e == hipSuccess) e = hipStreamWaitEvent(mine, ev, 0);
             if (e == hipSuccess) e = hipEventDestroy(ev);
@@ -358,7 +362,7 @@ int ghm_stream_wait(ghm_ctx* ctx, ghm_ctx* other) {
         return 0;
     }
     hipEvent_t ev;
-    GHM_HIP(hipEventCreateWithFlags(&ev, ghm_event_flags()));
+    GHM_HIP(hipEventCreateWithFlags(&ev, ghm_event_flags(sys_edge)));
     GHM_HIP(hipEventRecord(ev, other->stream));
     GHM_HIP(hipStreamWaitEvent(ctx->stream, ev, 0));
     GHM_HIP(hipEventDestroy(ev));       // destruction is deferred by the runtime until the event has fired

@@ -1170,6 +1170,41 @@ int ghm_bn_forward(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t y
     return ghm_bn_apply(ctx, x, xs, y, ys, N, C, HW, mean, inv, gamma, beta, act, alpha);
 }
 
+// ---- InstanceNorm (north_star names it beside BatchNorm; the reference itself only ever builds BatchNormLayer,
+// architectures/p2p.py:146-268): the statistics of BatchNorm taken per (sample, channel) over the map instead of per channel
+// over the batch -- y[n] = act((x[n] - mean[n]) * gamma * inv[n] + beta), no running statistics (the deterministic pass
+// normalises with the sample's own statistics too).  These are the BatchNorm kernels on one-sample views: N launches of the
+// one-launch form for maps <= 16384 pixels (a block per (n, c) row), the three-launch form above that; the same fp64 sums.
+// ``group`` consecutive samples of the tensor form one instance (1; 4 for the parity-planar output [4N, K, H, W] of a collapsed
+// up-sample convolution, whose four parity planes are one image).  mean / inv: [N / group][C]; gamma / beta / dgamma / dbeta:
+// [C]; ws: ghm_bn_workspace(C).
+int ghm_instance_norm_fwd(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t ys, int32_t N, int32_t C, int32_t HW, float eps,
+                          float* mean, float* inv, const float* gamma, const float* beta, int32_t act, float alpha, void* ws,
+                          int32_t group) {
+    GHM_CHECK(ctx && x && y && mean && inv && gamma && beta && ws, "ghm_instance_norm_fwd: null argument");
+    GHM_CHECK(group >= 1 && N % group == 0, "ghm_instance_norm_fwd: %d samples are not whole groups of %d", N, group);
+    for (int n = 0; n < N / group; ++n)
+        if (int e = ghm_bn_forward(ctx, x + (long)n * group * xs, xs, y + (long)n * group * ys, ys, group, C, HW, eps,
+                                   mean + (long)n * C, inv + (long)n * C, nullptr, nullptr, 0.f, gamma, beta, act, alpha, ws))
+            return e;
+    return 0;
+}
+
+// dz = dout * act'(y) with y recomputed from x; per sample: dx = gamma * inv * (dz - mean_hw(dz) - xhat * mean_hw(dz * xhat));
+// dgamma / dbeta sum over the samples (written, or added to when ``accumulate``)
+int ghm_instance_norm_bwd(ghm_ctx* ctx, const float* dout, int64_t ds, const float* x, int64_t xs, float* dx, int64_t dxs, int32_t N,
+                          int32_t C, int32_t HW, const float* mean, const float* inv, const float* gamma, const float* beta,
+                          float* dgamma, float* dbeta, int32_t act, float alpha, int32_t accumulate, void* ws, int32_t group) {
+    GHM_CHECK(ctx && dout && x && dx && mean && inv && gamma && beta && dgamma && dbeta && ws, "ghm_instance_norm_bwd: null argument");
+    GHM_CHECK(group >= 1 && N % group == 0, "ghm_instance_norm_bwd: %d samples are not whole groups of %d", N, group);
+    for (int n = 0; n < N / group; ++n)
+        if (int e = ghm_bn_backward_x(ctx, dout + (long)n * group * ds, ds, x + (long)n * group * xs, xs, dx + (long)n * group * dxs, dxs,
+                                      group, C, HW, mean + (long)n * C, inv + (long)n * C, gamma, beta, dgamma, dbeta, act, alpha,
+                                      (accumulate || n > 0) ? 1 : 0, ws))
+            return e;
+    return 0;
+}
+
 // the reduction passes of the BatchNorm backward: dgamma / dbeta and, in the workspace tail, the two per-channel sums the
 // apply pass needs (shared with elementwise_q.hip)
 int ghm_bn_backward_sums(ghm_ctx* ctx, const float* dout, int64_t ds, const float* y, int64_t ys, const float* x, int64_t xs,

@@ -807,6 +807,17 @@ class Ops:
         call("ghm_bn_forward", self.h, _vp(x), x.nstride, _vp(y), y.nstride, x.N, x.Cc, x.HW, eps, _vp(mean), _vp(inv),
              _vp(run_mean), _vp(run_inv), run_alpha, _vp(gamma), _vp(beta), ACT_CODES[act], alpha, _vp(ws))
 
+    def instance_norm_fwd(self, x, y, mean, inv, gamma, beta, ws, eps=1e-4, act='linear', alpha=0.0, group=1):
+        """InstanceNorm: BatchNorm's statistics per (instance, channel); mean / inv: [N / group, C]"""
+        call("ghm_instance_norm_fwd", self.h, _vp(x), x.nstride, _vp(y), y.nstride, x.N, x.Cc, x.HW, eps, _vp(mean), _vp(inv),
+             _vp(gamma), _vp(beta), ACT_CODES[act], alpha, _vp(ws), group)
+
+    def instance_norm_bwd(self, dout, x, dx, mean, inv, gamma, beta, dgamma, dbeta, ws, act='linear', alpha=0.0,
+                          accumulate=False, group=1):
+        call("ghm_instance_norm_bwd", self.h, _vp(dout), dout.nstride, _vp(x), x.nstride, _vp(dx), dx.nstride, x.N, x.Cc, x.HW,
+             _vp(mean), _vp(inv), _vp(gamma), _vp(beta), _vp(dgamma), _vp(dbeta), ACT_CODES[act], alpha, int(accumulate), _vp(ws),
+             group)
+
     def bn_backward(self, dout, y, x, dx, mean, inv, gamma, dgamma, dbeta, ws, act='linear', alpha=0.0,
                     accumulate=False):
         call("ghm_bn_backward", self.h, _vp(dout), dout.nstride, _vp(y), y.nstride, _vp(x), x.nstride, _vp(dx),

@@ -147,6 +147,11 @@ def _build_ir(out_layer):
             n.act = l.nonlinearity
         elif isinstance(l, L.BatchNormLayer):
             n = Node('bn', [of[id(l.input_layer)]], l)
+        elif isinstance(l, L.InstanceNormLayer):
+            # a 'bn' node whose statistics are per instance (layers.InstanceNormLayer): the BatchNorm lowering with its own
+            # kernels entry points (ghm_instance_norm_*), none of BatchNorm's fusions, no running statistics
+            n = Node('bn', [of[id(l.input_layer)]], l)
+            n.instance = True
         elif isinstance(l, L.NonlinearityLayer):
             if l.nonlinearity == linear:
                 of[id(l)] = of[id(l.input_layer)]
@@ -446,7 +451,13 @@ class NetPlan:
 
         for n in self.order:
             get_out(n)
-            if n.op == 'bn':
+            if n.op == 'bn' and getattr(n, 'instance', False):
+                # one instance = one sample; the four parity planes of one image behind a collapsed up-sample convolution
+                grp = 4 if n.inputs[0].op == 'upconv' else 1
+                n.aux['group'] = grp
+                n.aux['mean'] = self.dev.empty((1, n.shape[0] // grp * n.shape[1], 1, 1))
+                n.aux['inv'] = self.dev.empty((1, n.shape[0] // grp * n.shape[1], 1, 1))
+            elif n.op == 'bn':
                 C = n.shape[1]
                 n.aux['mean'] = self.dev.empty((1, C, 1, 1))
                 n.aux['inv'] = self.dev.empty((1, C, 1, 1))
@@ -591,7 +602,7 @@ class NetPlan:
                 or os.environ.get("GHM_NO_CONV_BN_FUSE") is not None or not hasattr(self.ops, 'conv_bn_fused_supported')):
             return None
         bnn = n.consumers[0]
-        if bnn.op != 'bn' or self._bn_hi(bnn) or n.out.nstride != d.y_nstride:
+        if bnn.op != 'bn' or getattr(bnn, 'instance', False) or self._bn_hi(bnn) or n.out.nstride != d.y_nstride:
             return None
         if self._lp(d, 0):
             return bnn if (xq is not None and self.ops.conv_bn_fused_supported(d, self.dtype)) else None
@@ -605,7 +616,7 @@ class NetPlan:
     def _bn_hi(self, n):
         """is n the BatchNorm of a collapsed up-sample convolution whose only reader is the parity interleave?  Then the
         two run as one pass in both directions (csrc/elementwise_q.hip: bn_apply_hi / bn_backward_hi)."""
-        return (n.op == 'bn' and self.bn_groups == 1 and os.environ.get("GHM_NO_BN_HI") is None
+        return (n.op == 'bn' and self.bn_groups == 1 and not getattr(n, 'instance', False) and os.environ.get("GHM_NO_BN_HI") is None
                 and len(n.consumers) == 1 and n.consumers[0].op == 'pp_to_hi' and n.inputs[0].op == 'upconv'
                 and n.shape[1] % 8 == 0 and n.consumers[0].out.nstride % 2 == 0)
 
@@ -741,6 +752,11 @@ class NetPlan:
                 w, b = st.value(n.layer.W), st.value(n.layer.b)
                 prog.append(("deconv_fwd", lambda d=d, x=x, w=w, b=b, y=y, a=a:
                              ops.conv2d_dgrad(d, x, w, y, b, a.kind, a.alpha), conv_meta(ops, d, 1)))
+            elif n.op == 'bn' and getattr(n, 'instance', False):
+                l = n.layer
+                g, be = st.value(l.gamma), st.value(l.beta)
+                prog.append(("in_fwd", lambda x=x, y=y, m=n.aux['mean'], iv=n.aux['inv'], g=g, be=be, l=l, a=a, grp=n.aux['group']:
+                             ops.instance_norm_fwd(x, y, m, iv, g, be, self.bn_ws, l.epsilon, a.kind, a.alpha, grp)))
             elif n.op == 'bn':
                 l = n.layer
                 g, be = st.value(l.gamma), st.value(l.beta)
@@ -1254,7 +1270,8 @@ class NetPlan:
                 # the convolution in front of this BatchNorm reads gi as the operand of its low-precision data / weight
                 # gradients: the apply pass writes the q copy itself -- and no fp32 gradient at all when both read q
                 giq, gi32 = None, True
-                if (self.q_epi and not acc and nslice is None and self.bn_groups == 1 and xin.op in ('conv', 'upconv')
+                inst = getattr(n, 'instance', False)
+                if (self.q_epi and not acc and nslice is None and self.bn_groups == 1 and not inst and xin.op in ('conv', 'upconv')
                         and len(xin.consumers) == 1 and xin.act == linear and gi.HW % 2 == 0 and gi.Cc % 8 == 0
                         and gi.nstride % 2 == 0):
                     xx = xin.inputs[0]
@@ -1269,7 +1286,13 @@ class NetPlan:
                         giq = gradq_of(xin, gview, pack=False).reshape(gi.shape)
                         gq_ready.add(id(xin))
                         gi32 = not ((w_q or not wgrad) and d_q)
-                if id(n) in hi_grads:
+                if inst:
+                    if nslice is not None:
+                        raise NotImplementedError("InstanceNorm backward on a sample slice")
+                    prog.append(("in_bwd", lambda G=G, x=x, dst=dst, m=n.aux['mean'], iv=n.aux['inv'], gam=gam, bet=bet, dg=dg, db=db,
+                                 a=a, aw=aw, grp=n.aux['group']:
+                                 ops.instance_norm_bwd(G, x, dst, m, iv, gam, bet, dg, db, self.bn_ws, a.kind, a.alpha, aw, grp)))
+                elif id(n) in hi_grads:
                     m, iv = n.aux['mean'], n.aux['inv']
                     dst32 = dst if (giq is None or gi32) else None
                     prog.append(("bn_bwd", lambda G=G, x=x, dst32=dst32, giq=giq, m=m, iv=iv, gam=gam, bet=bet, dg=dg, db=db, a=a, aw=aw:

@@ -217,6 +217,22 @@ class BatchNormLayer(Layer):
         self.inv_std = self.add_param(_init.Constant(1.), c, "inv_std", 'vec', trainable=False, regularizable=False)
 
 
+class InstanceNormLayer(Layer):
+    """BatchNormLayer's arithmetic with the statistics taken per (sample, channel) over the map (BASELINE north_star names
+    InstanceNorm beside BatchNorm; the reference's architecture files only build BatchNormLayer, p2p.py:146-268, so this layer
+    has no reference counterpart and follows BatchNormLayer's conventions: epsilon 1e-4 inside the root, biased variance,
+    params in creation order beta, gamma).  No running statistics: a deterministic pass normalises with the sample's own."""
+
+    def __init__(self, incoming, epsilon=1e-4, name=None):
+        Layer.__init__(self, incoming, name)
+        if len(self.input_shape) != 4:
+            raise NotImplementedError("InstanceNormLayer on a %d-d input" % len(self.input_shape))
+        self.epsilon = float(epsilon)
+        c = (self.input_shape[1],)
+        self.beta = self.add_param(_init.Constant(0.), c, "beta", 'vec', regularizable=False)
+        self.gamma = self.add_param(_init.Constant(1.), c, "gamma", 'vec')
+
+
 class NonlinearityLayer(Layer):
     def __init__(self, incoming, nonlinearity=rectify, name=None):
         Layer.__init__(self, incoming, name)

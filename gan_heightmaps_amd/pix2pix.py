@@ -4,9 +4,9 @@ Same constructor arguments, attributes (train_fn, loss_fn, gen_fn, gen_fn_det, z
 train_keys) and methods (save_model, load_model, train, generate_*); compiled functions take numpy float32
 arrays and return lists of numpy scalars / arrays, synchronously.
 Extra keyword arguments (device, comm, use_graph, seed, dtype) configure the MI355X backend; ``dtype`` is the
-arithmetic of the convolution products: 'f32' (default = the reference's floatX=float32, on the fp32 matrix instruction),
-'bf16x3' (the same fp32 arithmetic as six exact bf16 piece products per multiply-add: csrc/conv_split.hip, fp32-accurate,
-1.5x the speed) or 'bf16' / 'f16' (operands rounded).
+arithmetic of the convolution products: 'bf16x3' (default = the reference's floatX=float32 as six exact bf16 piece products
+per multiply-add on the bf16 matrix cores: csrc/conv_split.hip, fp32-accurate, held to the fp32 parity bounds, 1.55x the speed),
+'f32' (the same arithmetic on the fp32 matrix instruction v_mfma_f32_32x32x2_f32) or 'bf16' / 'f16' (operands rounded).
 """
 import gzip
 import os
@@ -56,7 +56,7 @@ class Pix2Pix:
                  alpha=100, opt=adam, opt_args=None,
                  train_mode='both', reconstruction='l1', sampler=np.random.rand, lsgan=False, verbose=True,
                  device=None, comm=None, use_graph=True, seed=None, two_streams=True, force_exchange=False,
-                 side_streams=None, dtype='f32', bucket_mb=None, prefetch=True, exchange_mode=None):
+                 side_streams=None, dtype='bf16x3', bucket_mb=None, prefetch=True, exchange_mode=None):
         """Two-stage DCGAN / pix2pix GAN (see the reference docstring, pix2pix.py:32-64).
         gen_fn_dcgan(latent_dim, is_a_grayscale, **gen_params_dcgan) -> output layer
         disc_fn_dcgan(in_shp, is_a_grayscale, **disc_params_dcgan) -> output layer

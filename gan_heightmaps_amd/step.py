@@ -51,7 +51,7 @@ def _interleave(a, b):
 class GanStep:
     def __init__(self, dev, dcgan_gen, dcgan_disc, p2p_gen, p2p_disc, alpha, lsgan, reconstruction, opt_spec,
                  train_mode='both', comm=None, use_graph=True, two_streams=True, force_exchange=False,
-                 side_streams=None, dtype='f32', bucket_mb=None, exchange_mode=None):
+                 side_streams=None, dtype='bf16x3', bucket_mb=None, exchange_mode=None):
         self.dev = dev
         # form of the data-parallel exchange: 'allreduce' (every rank sums every gradient and runs the whole
         # optimiser) or 'rs_ag' (sharded update: a sub-bucket is reduce-SCATTERED, each rank runs RMSprop / Adam on its 1 / world
@@ -62,9 +62,10 @@ class GanStep:
         # data-parallel exchange: a net's gradient bucket travels as sub-buckets of at least this many bytes, each
         # all-reduced as soon as the backward pass has completed it (_build: bucketer)
         self.bucket_bytes = int(float(bucket_mb if bucket_mb is not None else os.environ.get('GHM_BUCKET_MB', 32)) * 2 ** 20)
-        # arithmetic of the convolution products (include/ghm.h GHM_DTYPE_*): 'f32' = the reference's floatX; 'bf16' /
-        # 'f16' = BASELINE configs 4 / 5 (matrix-core operands rounded, fp32 accumulation, fp32 tensors and optimiser);
-        # 'bf16x3' = fp32 by operand splitting (three exact bf16 pieces per operand, csrc/conv_split.hip: fp32-accurate)
+        # arithmetic of the convolution products (include/ghm.h GHM_DTYPE_*): 'bf16x3' (default) = the reference's floatX by
+        # operand splitting (three exact bf16 pieces per operand, csrc/conv_split.hip: fp32-accurate); 'f32' = the same on the
+        # fp32 matrix instruction; 'bf16' / 'f16' = BASELINE configs 4 / 5 (matrix-core operands rounded, fp32 accumulation,
+        # fp32 tensors and optimiser)
         self.dtype = dtype
         # fp16 operands underflow below 6e-8 and the per-pixel gradients of the 512x512 layers sit around 1e-6..1e-9:
         # the loss-gradient seeds are scaled (initially by 2^15) and the optimiser divides the scale out again (every

@@ -189,6 +189,30 @@ def bn_infer_fwd(x, beta, gamma, mean, inv_std):
 
 
 # --------------------------------------------------------------------------------------
+# InstanceNorm (BASELINE north_star names it beside BatchNorm; NO reference call site: the reference's architecture files
+# build BatchNormLayer only, architectures/p2p.py:146-268 -- parity of this op is pinned on torch.nn.functional.instance_norm,
+# tests/test_oracle_vs_torch.py).  BatchNormLayer's conventions with the axes (2, 3): biased variance, eps inside the root.
+# --------------------------------------------------------------------------------------
+def in_fwd(x, beta, gamma, eps=BN_EPS):
+    """-> (y, mu[N, C], inv[N, C])"""
+    mu = x.mean(axis=(2, 3))
+    var = x.var(axis=(2, 3))
+    inv = 1.0 / np.sqrt(var + x.dtype.type(eps))
+    y = (x - mu[:, :, None, None]) * (gamma[None, :] * inv)[:, :, None, None] + beta[None, :, None, None]
+    return y, mu, inv
+
+
+def in_vjp(x, gamma, mu, inv, dy):
+    """-> (dx, dbeta[C], dgamma[C]); gradients flow through mu and var of every instance"""
+    xhat = (x - mu[:, :, None, None]) * inv[:, :, None, None]
+    db = dy.sum(axis=(2, 3))                        # per instance
+    dg = (dy * xhat).sum(axis=(2, 3))
+    m = x.shape[2] * x.shape[3]
+    dx = (gamma[None, :] * inv)[:, :, None, None] * (dy - (db / m)[:, :, None, None] - xhat * (dg / m)[:, :, None, None])
+    return dx, db.sum(axis=0), dg.sum(axis=0)
+
+
+# --------------------------------------------------------------------------------------
 # nonlinearities (lasagne.nonlinearities; SURVEY Appendix A.5)
 #   LeakyRectify(a) is computed as 0.5(1+a)x + 0.5(1-a)|x|, gradient of |x| is sgn(x)
 #   => slope at exactly 0 is 0.5(1+a).  leaky_rectify is the a=0.01 instance (all of

@@ -91,6 +91,11 @@ def bn_train(x, beta, gamma):
     return Node(y, (x, beta, gamma), lambda g: ops.bn_train_vjp(x.v, gamma.v, mu, inv, g)), mu, inv
 
 
+def instance_norm(x, beta, gamma, eps=ops.BN_EPS):
+    y, mu, inv = ops.in_fwd(x.v, beta.v, gamma.v, eps)
+    return Node(y, (x, beta, gamma), lambda g: ops.in_vjp(x.v, gamma.v, mu, inv, g))
+
+
 def bn_infer(x, beta, gamma, mean, inv_std):
     y = ops.bn_infer_fwd(x.v, beta.v, gamma.v, mean, inv_std)
     return Node(y, (x,), None)

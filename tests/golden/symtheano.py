@@ -137,6 +137,8 @@ def get_output(layer, inputs=None, deterministic=False):
                 else:
                     y, mu, inv = TP.bn_train(x, c.param(l.beta), c.param(l.gamma))
                     c.bn.append((l, mu, inv))
+            elif cls == 'InstanceNormLayer':            # (this package's layer; no reference counterpart)
+                y = TP.instance_norm(x, c.param(l.beta), c.param(l.gamma), l.epsilon)
             elif cls == 'NonlinearityLayer':
                 y = _act(x, l.nonlinearity)
             elif cls == 'ReshapeLayer':

@@ -118,3 +118,79 @@ def test_architecture_variant_on_the_device(gpu, name):
     c2 = ST.Ctx(env, np.float64)
     ref_det = ST.get_output(net, sym_in, deterministic=True).ev(c2)
     assert rel(plan.out.numpy().reshape(ref_det.v.shape), ref_det.v) < 1e-5, name
+
+
+def _instance_norm_net(kind):
+    """small nets with InstanceNormLayer in the places the reference's nets have BatchNormLayer"""
+    from gan_heightmaps_amd import layers as L, nonlinearities as NL
+    rng = np.random.RandomState(5)
+    if kind == "encoder":            # conv (stride 2) -> IN -> leaky -> conv -> IN -> tanh   (p2p.py's encoder block shape)
+        i = L.InputLayer((None, 3, 32, 32))
+        c = L.Conv2DLayer(i, 16, 3, stride=2, pad=1, nonlinearity=NL.linear)
+        c = L.NonlinearityLayer(L.InstanceNormLayer(c), NL.leaky_rectify)
+        c = L.Conv2DLayer(c, 24, 3, stride=1, pad=1, nonlinearity=NL.linear)
+        net = L.NonlinearityLayer(L.InstanceNormLayer(c), NL.tanh)
+        return net, {None: rng.randn(3, 3, 32, 32)}
+    if kind == "upsample":           # Upscale2D -> 5x5 conv (collapsed to 3x3 by the lowering) -> IN -> rectify   (dcgan.py:22-24)
+        i = L.InputLayer((None, 8, 8, 8))
+        c = L.Conv2DLayer(L.Upscale2DLayer(i, 2), 16, 5, pad='same', nonlinearity=NL.linear)
+        c = L.NonlinearityLayer(L.InstanceNormLayer(c), NL.rectify)
+        net = L.Conv2DLayer(c, 8, 3, pad=1, nonlinearity=NL.linear)
+        return net, {None: rng.randn(2, 8, 8, 8)}
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3"])
+@pytest.mark.parametrize("kind", ["encoder", "upsample"])
+def test_instance_norm_layer_on_the_device(gpu, kind, dtype):
+    """InstanceNormLayer (north_star names InstanceNorm beside BatchNorm; the reference has no call site) lowered by the
+    engine -> ghm_instance_norm_fwd / _bwd, against the layer-graph interpreter on the oracle's op (float64; the op itself is
+    pinned on torch in tests/test_oracle_vs_torch.py::test_instancenorm): output <= 1e-5, parameter and input gradients <= 5e-4,
+    and the deterministic pass equals the training pass (no running statistics)"""
+    import symtheano as ST
+    from oracle import tape as TP
+    from gan_heightmaps_amd import init as INIT, layers as L
+    from gan_heightmaps_amd.engine import NetPlan, ParamStore
+    dev, ops = gpu
+    INIT.set_rng(np.random.RandomState(13))
+    net, feeds = _instance_norm_net(kind)
+    in_layers = [l for l in L.get_all_layers(net) if isinstance(l, L.InputLayer)]
+    x0 = np.asarray(feeds[None], np.float32)
+    B = x0.shape[0]
+    params = L.get_all_params(net)
+    for p in params:                     # non-trivial gamma / beta
+        if p.name in ("gamma", "beta"):
+            p.set_value((p.get_value() + 0.3 * np.random.RandomState(len(p.name)).randn(*p.get_value().shape)).astype(np.float32))
+    store = ParamStore(dev, params)
+    plan = NetPlan(dev, ops, net, B, store, name="in_" + kind, dtype=dtype)
+    fwd, bwd, det = [], [], []
+    plan.emit_forward(fwd)
+    seed = np.random.RandomState(2).randn(*plan.out.shape).astype(np.float32)
+    gin = plan.emit_backward(bwd, dev.tensor(seed), input_grads=in_layers)
+    plan.input_tensor(in_layers[0]).set(x0)
+    for e in fwd + bwd:
+        e[1]()
+    dev.sync()
+    out = plan.out.numpy().copy()
+    env = {"in0": x0}
+    c = ST.Ctx(env, np.float64)
+    sym_in = {in_layers[0]: ST.placeholder("in0")}
+    ref = ST.get_output(net, sym_in).ev(c)
+    assert rel(out.reshape(ref.v.shape), ref.v) < 1e-5
+    TP.backward(ref, seed.astype(np.float64).reshape(ref.v.shape))
+    checked = 0
+    for p in L.get_all_params(net, trainable=True):
+        g_ref = c.param(p).g
+        if g_ref is None or np.linalg.norm(g_ref) < 1e-9:
+            continue                     # a conv bias that feeds an InstanceNorm: exactly zero
+        assert rel(store.download_grad(p), g_ref) < 5e-4, (p.name, rel(store.download_grad(p), g_ref))
+        checked += 1
+    assert checked >= 5
+    g_in = sym_in[in_layers[0]].ev(c).g
+    assert g_in is not None and np.linalg.norm(g_in) > 0
+    assert rel(gin[in_layers[0]].numpy(), g_in) < 5e-4
+    plan.emit_forward(det, deterministic=True)
+    for e in det:
+        e[1]()
+    dev.sync()
+    assert np.array_equal(plan.out.numpy(), out)

@@ -286,7 +286,7 @@ def test_reduced_precision_lowering_on_fake_device():
     names = [c[0] for c in flat if c[0] in ('grad_check', 'rmsprop', 'loss_scale_update')]
     assert names == ['grad_check'] * 4 + ['rmsprop'] * 4 + ['loss_scale_update'], names
     # the same nets in fp32: no low-precision call at all
-    eng32 = GanStep(PolicyDevice(), G, Dn, U, P, 100, True, 'l1', spec, 'both', use_graph=False, two_streams=False)
+    eng32 = GanStep(PolicyDevice(), G, Dn, U, P, 100, True, 'l1', spec, 'both', use_graph=False, two_streams=False, dtype='f32')
     p32 = eng32.built(4)
     assert 'lp_pack' not in [e[0] for lane in p32.train_compute for e in lane]
 

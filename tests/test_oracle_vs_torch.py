@@ -69,6 +69,23 @@ def test_batchnorm(shape):
     assert np.allclose(dgamma, gt.grad.numpy(), atol=1e-10)
 
 
+@pytest.mark.parametrize("shape", [(4, 5, 3, 3), (2, 8, 16, 16), (3, 7, 2, 1)])
+def test_instancenorm(shape):
+    """oracle/ops.py in_fwd / in_vjp (no reference call site; north_star names the op) against torch's instance_norm"""
+    x, beta, gamma = rng.randn(*shape), rng.randn(shape[1]), rng.randn(shape[1])
+    y, mu, inv = ops.in_fwd(x, beta, gamma)
+    xt, bt, gt = t(x), t(beta), t(gamma)
+    yt = F.instance_norm(xt, None, None, gt, bt, use_input_stats=True, eps=ops.BN_EPS)
+    assert np.allclose(y, yt.detach().numpy(), atol=1e-10)
+    assert mu.shape == shape[:2] and inv.shape == shape[:2]
+    dy = rng.randn(*shape)
+    yt.backward(t(dy, False))
+    dx, dbeta, dgamma = ops.in_vjp(x, gamma, mu, inv, dy)
+    assert np.allclose(dx, xt.grad.numpy(), atol=1e-9)
+    assert np.allclose(dbeta, bt.grad.numpy(), atol=1e-10)
+    assert np.allclose(dgamma, gt.grad.numpy(), atol=1e-10)
+
+
 def test_pools_and_upsamples():
     x = rng.randn(2, 3, 8, 8)
     xt = t(x)
