@@ -468,6 +468,10 @@ class Ops:
     def conv2d_dgrad_dact(self, d, dy, w, dx, y, act, alpha, dtype='f32'):
         """dx = conv^T(dy) * act'(y): the data gradient with the producer's activation backward in its epilogue"""
         assert y.shape == dx.shape
+        if dtype == SPLIT:
+            # a split weight pack has no fp32-operand form of this product: ghm_conv2d_dgrad_dact would read it as an fp32 /
+            # low-precision pack.  The split data gradient with the activation backward takes the q copy of dy
+            raise ValueError("conv2d_dgrad_dact(dtype='bf16x3'): use conv2d_dgrad_dact_lp_q with the split q tensor of dy")
         call("ghm_conv2d_dgrad_dact", self.h, C.byref(d), _vp(dy), _vp(w), _vp(dx), _vp(y), y.nstride, ACT_CODES[act], alpha,
              DTYPE_CODES[dtype])
 
@@ -653,13 +657,22 @@ class Ops:
              C.c_void_p(dxq.ptr if dxq is not None else 0), dxq.nstride if dxq is not None else 0, _vp(y), y.nstride,
              ACT_CODES[act], alpha, DTYPE_CODES[dtype])
 
+    @staticmethod
+    def _whole_planes(q):
+        """the q epilogues of the element-wise producers place the piece planes of a split q tensor N x nstride units apart: a
+        sample-sliced view (which keeps the allocation's pstride) would have pieces 1 and 2 written over other samples' data"""
+        assert q is None or q.dtype != SPLIT or q.pstride == q.N * q.nstride, \
+            "split q tensor: a sample slice cannot be the target of an element-wise q epilogue"
+
     def bn_apply_q(self, x, y, mean, inv, gamma, beta, yq, act='linear', alpha=0.0):
+        self._whole_planes(yq)
         call("ghm_bn_apply_q", self.h, _vp(x), x.nstride, _vp(y), y.nstride if y is not None else 0, x.N, x.Cc, x.HW, _vp(mean),
              _vp(inv), _vp(gamma), _vp(beta), ACT_CODES[act], alpha, C.c_void_p(yq.ptr), yq.nstride, DTYPE_CODES[yq.dtype])
 
     def bn_backward_q(self, dout, y, x, dx, mean, inv, gamma, dgamma, dbeta, ws, dxq, act='linear', alpha=0.0, accumulate=False,
                       beta=None):
         """y may be None when beta is given: the layer output is recomputed from x"""
+        self._whole_planes(dxq)
         call("ghm_bn_backward_q", self.h, _vp(dout), dout.nstride, _vp(y), y.nstride if y is not None else 0, _vp(x), x.nstride,
              _vp(dx), dx.nstride if dx is not None else 0, x.N, x.Cc, x.HW, _vp(mean), _vp(inv), _vp(gamma), _vp(beta),
              _vp(dgamma), _vp(dbeta), ACT_CODES[act], alpha, int(accumulate), _vp(ws), C.c_void_p(dxq.ptr), dxq.nstride,
@@ -672,16 +685,19 @@ class Ops:
 
     def upsample_bilinear2_fwd_q(self, x, y, yq):
         assert y is None or y.contiguous
+        self._whole_planes(yq)
         call("ghm_upsample_bilinear2_fwd_q", self.h, _vp(x), x.nstride, _vp(y), x.N, x.Cc, x.H, x.W, C.c_void_p(yq.ptr),
              yq.nstride, DTYPE_CODES[yq.dtype])
 
     def pp_to_hi_q(self, pp, hi, hiq):
+        self._whole_planes(hiq)
         assert pp.contiguous and pp.N == 4 * hiq.N
         call("ghm_pp_to_hi_q", self.h, _vp(pp), _vp(hi), hi.nstride if hi is not None else 0, hiq.N, pp.Cc, pp.H, pp.W,
              C.c_void_p(hiq.ptr), hiq.nstride, DTYPE_CODES[hiq.dtype])
 
     def bn_apply_hi(self, x_pp, hi, hiq, mean, inv, gamma, beta, act='linear', alpha=0.0):
         """BatchNorm + activation of a parity-planar tensor written straight in the interleaved layout (hi and / or hiq)"""
+        self._whole_planes(hiq)
         assert x_pp.contiguous and (hi is not None or hiq is not None)
         call("ghm_bn_apply_hi", self.h, _vp(x_pp), _vp(hi), hi.nstride if hi is not None else 0, x_pp.N // 4, x_pp.Cc, x_pp.H,
              x_pp.W, _vp(mean), _vp(inv), _vp(gamma), _vp(beta), ACT_CODES[act], alpha,
@@ -691,6 +707,7 @@ class Ops:
     def bn_backward_hi(self, dhi, x_pp, dx_pp, dxq, mean, inv, gamma, beta, dgamma, dbeta, ws, act='linear', alpha=0.0,
                        accumulate=False):
         """backward of bn_apply_hi: dhi in the interleaved layout, dx (fp32 and / or q) parity-planar"""
+        self._whole_planes(dxq)
         assert x_pp.contiguous and (dx_pp is None or dx_pp.contiguous) and (dx_pp is not None or dxq is not None)
         assert dxq is None or dxq.contiguous
         call("ghm_bn_backward_hi", self.h, _vp(dhi), dhi.nstride, _vp(x_pp), _vp(dx_pp), x_pp.N // 4, x_pp.Cc, x_pp.H, x_pp.W,
@@ -698,6 +715,7 @@ class Ops:
              C.c_void_p(dxq.ptr if dxq is not None else 0), DTYPE_CODES[dxq.dtype] if dxq is not None else 0)
 
     def maxpool2_mask_bwd_q(self, mask_ptr, y, dy, dx, dxq, act, alpha, dbias=None, accumulate=False):
+        self._whole_planes(dxq)
         N, Cc, H, W = dxq.shape
         call("ghm_maxpool2_mask_bwd_q", self.h, C.c_void_p(int(mask_ptr)), _vp(y), _vp(dy), _vp(dx), N, Cc, H, W,
              ACT_CODES[act], alpha, _vp(dbias), int(accumulate), C.c_void_p(dxq.ptr), dxq.nstride, DTYPE_CODES[dxq.dtype])

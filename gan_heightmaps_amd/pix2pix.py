@@ -110,6 +110,7 @@ class Pix2Pix:
         eng = self.engine
         eng.broadcast_parameters()          # replicas start from rank 0's (possibly unseeded) initial weights
         self.train_fn = lambda Z, X, Y: eng.train(floatX(Z), floatX(X), floatX(Y))
+        self._engine_train_fn = self.train_fn      # train() pipelines uploads only while train_fn is still the engine's own
         self.loss_fn = lambda Z, X, Y: eng.loss(floatX(Z), floatX(X), floatX(Y))
         self.gen_fn = lambda X: eng.generate('p2p_gen', X, False)
         self.gen_fn_det = lambda X: eng.generate('p2p_gen', X, True)
@@ -167,7 +168,8 @@ class Pix2Pix:
             rec = [[] for _ in self.train_keys]
             on_device = hasattr(src, 'next_into')          # gan_heightmaps_amd.data.Hdf5Iterator: batch stays in HBM
             eng = getattr(self, 'engine', None)
-            if (fn is getattr(self, 'train_fn', None) and not on_device and getattr(self, 'prefetch', False)
+            own = fn is getattr(self, 'train_fn', None) and fn is getattr(self, '_engine_train_fn', None)   # (a replaced / wrapped train_fn is called as it is)
+            if (own and not on_device and getattr(self, 'prefetch', False)
                     and hasattr(eng, 'train_pipelined')):
                 # host arrays: the same draws in the same order, but batch i+1 is drawn, sampled and uploaded (copy stream,
                 # page-locked staging) while step i runs; losses bit-identical to the call-by-call form
@@ -177,16 +179,24 @@ class Pix2Pix:
                         yield floatX(self.sampler(X_batch.shape[0], self.latent_dim)), floatX(X_batch), floatX(Y_batch)
                         if quick_run:
                             break
-                for results in eng.train_pipelined(batches()):
-                    for i, r in enumerate(results):
-                        rec[i].append(r)
+                try:
+                    for results in eng.train_pipelined(batches()):
+                        for i, r in enumerate(results):
+                            rec[i].append(r)
+                except BaseException:
+                    eng.close_pipeline()        # an abandoned loop must not leave an upload in flight on the copy stream
+                    raise
                 return tuple(np.mean(elem) for elem in rec)
-            if (fn is getattr(self, 'train_fn', None) and on_device and getattr(self, 'prefetch', False)
+            if (own and on_device and getattr(self, 'prefetch', False)
                     and hasattr(eng, 'train_pipelined_from_iterator')):
                 steps = 1 if quick_run else itr.N // batch_size
-                for results in eng.train_pipelined_from_iterator(src, lambda n: floatX(self.sampler(n, self.latent_dim)), steps):
-                    for i, r in enumerate(results):
-                        rec[i].append(r)
+                try:
+                    for results in eng.train_pipelined_from_iterator(src, lambda n: floatX(self.sampler(n, self.latent_dim)), steps):
+                        for i, r in enumerate(results):
+                            rec[i].append(r)
+                except BaseException:
+                    eng.close_pipeline()
+                    raise
                 return tuple(np.mean(elem) for elem in rec)
             for _ in range(itr.N // batch_size):
                 if on_device:

@@ -193,6 +193,8 @@ class GanStep:
             self.devs[1].sync()
         if self.cdev is not None and self.cdev is not self.devs[0]:
             self.cdev.sync()
+        if hasattr(self, '_pipe_state'):            # the copy stream of the input pipeline: no upload may outlive a sync()
+            self._pipe_state['dev'].sync()
 
     def broadcast_parameters(self, root=0):
         """Make every replica start from rank ``root``'s parameters, BatchNorm state and optimiser state (the
@@ -240,7 +242,12 @@ class GanStep:
     # ---- building -------------------------------------------------------------------------------------
     def _build(self, B, slot=0):
         b = _Built()
-        b0 = self._built.get(B) if slot else None        # (a second slot draws the same dropout masks: it shares the counters)
+        # dropout step counters live per (net, batch size) on the engine, whichever slot of that batch size is built first: both
+        # slots of a batch size advance ONE counter, so the pipelined loop draws the masks of the sequential loop (a ragged last
+        # batch first seen on an odd step builds slot 1 before slot 0)
+        if not hasattr(self, '_rng_counters'):
+            self._rng_counters = {}
+        rc = self._rng_counters
         dA, dB = self.devs
         oA, oB = self.ops
         G, D, U, P = (self.nets[k] for k in ('dcgan_gen', 'dcgan_disc', 'p2p_gen', 'p2p_disc'))
@@ -258,7 +265,7 @@ class GanStep:
         _side = lambda k, lane: self.side[lane] if k in _sn else None
         b.G = NetPlan(dA, oA, G, B, self.stores['dcgan_gen'], out_tensor=b.d_in.samples(B, 2 * B), name="G",
                       side=_side('G', 0), rng_seed=self.rank, dtype=self.dtype,       # replicas draw different dropout masks
-                      rng_counter=b0.G.rng_counter if b0 is not None else None)
+                      rng_counter=rc.get(('G', B)))
         b.D = NetPlan(dA, oA, D, 2 * B, self.stores['dcgan_disc'], inputs={d_in_layer: b.d_in}, name="D",
                       side=_side('D', 0), bn_groups=2 if _has_bn(D) else 1, dtype=self.dtype)
         b.P = NetPlan(dB, oB, P, 2 * B, self.stores['p2p_disc'], name="P", side=_side('P', 1),
@@ -266,7 +273,9 @@ class GanStep:
         pa, pb = b.P.input_tensor(i_a), b.P.input_tensor(i_b)
         b.U = NetPlan(dB, oB, U, B, self.stores['p2p_gen'], out_tensor=pb.samples(B, 2 * B), name="U",
                       side=_side('U', 1), rng_seed=self.rank, dtype=self.dtype,
-                      rng_counter=b0.U.rng_counter if b0 is not None else None)
+                      rng_counter=rc.get(('U', B)))
+        rc.setdefault(('G', B), b.G.rng_counter)
+        rc.setdefault(('U', B), b.U.rng_counter)
         b.z = b.G.input_nodes[0].out
         b.x = b.U.input_tensor(u_in_layer)
         b.y = dB.empty((B,) + tuple(pb.shape[1:]))

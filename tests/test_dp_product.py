@@ -305,3 +305,74 @@ def test_sharded_collective_sequence_and_stream_discipline(sharded):
     waits = [i for i, e in enumerate(log[:first_gather]) if e[0] == nm["comm"] and e[1] == "wait_for"]
     for lane in (nm["A"], nm["B"]):                                    # ... and the gathers wait for every reader of the old weights
         assert any(log[i][2] == lane for i in waits)
+
+
+# ---- world 8 (the node the step is built for): shard padding to world x 64 elements and the sub-bucket cuts have 8-way
+# geometry that two ranks never exercise --------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def world8(tmp_path_factory):
+    out = {}
+    for i, mode in enumerate(("allreduce", "rs_ag")):
+        d = tmp_path_factory.mktemp("dp_world8_" + mode)
+        world, port = 8, 37500 + (os.getpid() % 2000) + i
+        tmp_.spawn(_worker, args=(world, port, str(d), 2048.0 / 2 ** 20, mode), nprocs=world, join=True)
+        out[mode] = [pickle.load(open(os.path.join(str(d), "r%d.pkl" % r), "rb")) for r in range(world)]
+    return out
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+def test_eight_ranks_same_program_identical_replicas_mean_update(world8, mode):
+    rs = world8[mode]
+    assert len(rs) == 8
+    kinds = ("allreduce_sum", "reduce_scatter_sum", "all_gather")
+    seq0 = [e[1:] for e in rs[0]["log"] if e[1] in kinds]
+    for r in rs:
+        assert r["crc_before"][0] != r["crc_before"][1]              # eight different initialisations ...
+        assert r["crc_after"][0] == r["crc_after"][1]                # ... one after the broadcast ...
+        assert r["crc_end"][0] == r["crc_end"][1]                    # ... and still one after the step
+        # the collective sequence (kind, element offset inside its buffer, count) is the same program on every rank
+        seq = [e[1:] for e in r["log"] if e[1] in kinds]
+        assert [(e[0], e[2]) for e in seq] == [(e[0], e[2]) for e in seq0]
+        for k in KEYS:
+            assert np.array_equal(r["w"][k], rs[0]["w"][k])
+    # reduced buckets = the sum over the eight ranks of what each put in (fp32 sums in rank order differ from a float64 sum by
+    # rounding only); the all-reduce form keeps the reduced bucket in place on every rank
+    if mode == "allreduce":
+        for k in KEYS:
+            tot = np.sum([r["sent"][k].astype(np.float64) for r in rs], axis=0)
+            assert np.linalg.norm(rs[3]["g"][k] - tot) <= 1e-6 * np.linalg.norm(tot), k
+    # the PatchGAN-on-real-pairs bucket (no BatchNorm, no generator): mean over the eight shards == full-batch gradient
+    if mode == "allreduce":
+        A, B = _pairs(32)
+        full = _patchgan_real_grads(rs[0]["pvalues"], A, B)
+        for got, want in zip(rs[5]["pgrad_avg"], full):
+            assert got.shape == want.shape
+            assert np.linalg.norm(got - want) <= 4e-6 * np.linalg.norm(want) + 1e-12      # float32 buckets, eight-way sums
+
+
+def test_eight_rank_sharded_update_equals_the_allreduce_form(world8):
+    ar, sh = world8["allreduce"], world8["rs_ag"]
+    for k in KEYS:
+        assert np.array_equal(sh[0]["w0"][k], ar[0]["w0"][k])           # same seeds: same start
+        # every element updated once with the same arithmetic.  (Bit-identical at two ranks, where a + b has one order; an
+        # eight-way fp32 sum is ordered differently by a ring all-reduce and a reduce-scatter -- gloo here, RCCL on the node --
+        # so the two forms agree to rounding of the reduced gradient, amplified by RMSprop's g / sqrt(0.1 g^2) at step one)
+        d = np.abs(sh[0]["w"][k].astype(np.float64) - ar[0]["w"][k])
+        assert d.max() <= 1e-6 * (1 + np.abs(ar[0]["w"][k]).max()), (k, d.max())
+        assert not np.array_equal(sh[0]["w"][k], sh[0]["w0"][k])
+        # the optimiser state is held exactly once across the eight ranks
+        accs = np.stack([r["acc"][k] for r in sh])
+        assert np.all((accs != 0).sum(axis=0) <= 1)
+        assert np.abs(accs.sum(axis=0) - ar[0]["acc"][k]).max() <= 1e-5 * np.abs(ar[0]["acc"][k]).max()
+    r = sh[0]
+    seq = [e for e in r["log"] if e[1] in ("reduce_scatter_sum", "all_gather")]
+    rsx = [(e[2], e[3]) for e in seq if e[1] == "reduce_scatter_sum"]
+    for k in KEYS:
+        g0, _ = r["g_range"][k]
+        _, n_pad = r["w_range"][k]
+        rk = sorted((p - g0, n) for p, n in rsx if g0 <= p < g0 + 4 * n_pad)
+        # contiguous cover of the padded buffer; every sub-bucket is eight equal, 256-byte-aligned shards
+        assert rk and rk[0][0] == 0 and rk[-1][0] + 4 * rk[-1][1] == 4 * n_pad
+        assert all(a[0] + 4 * a[1] == b_[0] for a, b_ in zip(rk, rk[1:]))
+        assert all(n % (8 * 64) == 0 for _, n in rk), (k, rk)
+        assert n_pad % (8 * 64) == 0
