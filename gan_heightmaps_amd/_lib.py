@@ -100,16 +100,16 @@ SIGNATURES = {
     "ghm_conv2d_fwd_thin_q": [_p, _D, _p, _p, _p, _p, _i32, _f, _p, _i64, _i32],
     "ghm_conv2d_fwd_pool_thin_q": [_p, _D, _p, _p, _p, _p, _p, _i32, _f, _p, _i64, _i32],
     "ghm_thin_pool_lp_served": [_D, _i32, _f, _i32],
-    "ghm_split_weight_bytes": [_D, _i32, _p],
-    "ghm_split_pack_weights": [_p, _D, _p, _p, _i32],
-    "ghm_split_pack": [_p, _p, _i64, _i32, _i32, _i32, _p, _i64, _i64],
-    "ghm_split_pack_batched": [_p, _p, _i32, _i32],
-    "ghm_conv2d_dgrad_dact_split": [_p, _D, _p, _i64, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _f],
+    "ghm_split_weight_bytes": [_D, _i32, _p, _i32],
+    "ghm_split_pack_weights": [_p, _D, _p, _p, _i32, _i32],
+    "ghm_split_pack": [_p, _p, _i64, _i32, _i32, _i32, _p, _i64, _i64, _i32],
+    "ghm_split_pack_batched": [_p, _p, _i32, _i32, _i32],
+    "ghm_conv2d_dgrad_dact_split": [_p, _D, _p, _i64, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _f, _i32],
     "ghm_conv2d_wgrad_split_workspace": [_D, _p],
-    "ghm_conv2d_wgrad_split": [_p, _D, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i32],
-    "ghm_conv2d_fwd_pool_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _i32, _f],
-    "ghm_conv2d_fwd_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i32, _f, _i32],
-    "ghm_conv2d_dgrad_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i32, _f, _i32],
+    "ghm_conv2d_wgrad_split": [_p, _D, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i32, _i32],
+    "ghm_conv2d_fwd_pool_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _i32, _f, _i32],
+    "ghm_conv2d_fwd_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i32, _f, _i32, _i32],
+    "ghm_conv2d_dgrad_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i32, _f, _i32, _i32],
     "ghm_conv2d_pool_bwd_sparse_supported": [_D, _i32],
     "ghm_conv2d_pool_wgrad_sparse_workspace": [_D, C.POINTER(C.c_size_t)],
     "ghm_conv2d_pool_wgrad_sparse": [_p, _D, _p, _p, _p, _p, _p, _p, _i32, _f, _i32, _p],

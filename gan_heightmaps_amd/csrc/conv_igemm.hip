@@ -2313,7 +2313,7 @@ int ghm_conv2d_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, co
 // the thin (<= 4 input channels) forward kernels with a q copy of their result written by their own epilogue
 int ghm_thin_fwd_q_supported(const ghm_conv_desc* d, int32_t act, int32_t pooled, int32_t dtype) {
     // (dtype 3 = host-side 'bf16x3': the q copy as three exact bf16 pieces for the split-fp32 kernels)
-    if (!(dtype == GHM_DTYPE_BF16 || dtype == GHM_DTYPE_F16 || dtype == 3) || d->C > 4 || d->K % 8 || GHM_OPT("GHM_NO_THIN_Q")) return 0;
+    if (!(dtype == GHM_DTYPE_BF16 || dtype == GHM_DTYPE_F16 || dtype == 3 || dtype == 4) || d->C > 4 || d->K % 8 || GHM_OPT("GHM_NO_THIN_Q")) return 0;
     if (pooled) return (thin_fanout_fwd_pool_ok(d, act) && thin_fanout_pool_q_ok(d)) || thin_pool_lp_ok(d, act, 0.f, dtype) ? 1 : 0;
     return thin_fanout_fwd_ok(d, act) ? 1 : 0;
 }

@@ -53,15 +53,17 @@ __device__ __forceinline__ void sp_split8(const float* v, u32x4& q0, u32x4& q1, 
     q2 = u32x4{c[0], c[1], c[2], c[3]};
 }
 
-// a half unit (4 consecutive channels of one pixel) of a split q tensor: the three pieces of each value, three planes
-// ``ps2`` half-units apart (the producer writes whole tensors: plane stride = samples x sample stride)
+// a half unit (4 consecutive channels of one pixel) of a split q tensor: the NPC pieces of each value, NPC planes
+// ``ps2`` half-units apart (the producer writes whole tensors: plane stride = samples x sample stride).  NPC = 2 ('bf16x2'):
+// the first two pieces, x1 = bf16(x - x0) rounded to nearest -- x0 + x1 carries 16-17 significant bits
+template <int NPC>
 __device__ __forceinline__ void sp_qstore4(uint2* qo, float v0, float v1, float v2, float v3, long ps2) {
     unsigned a0, a1, a2, b0, b1, b2;
     sp_split2(v0, v1, a0, a1, a2);
     sp_split2(v2, v3, b0, b1, b2);
     qo[0] = make_uint2(a0, b0);
     qo[ps2] = make_uint2(a1, b1);
-    qo[2 * ps2] = make_uint2(a2, b2);
+    if (NPC == 3) qo[2 * ps2] = make_uint2(a2, b2);
 }
 
 __device__ __forceinline__ int sp_xcd_remap(int bid, int nb) {
@@ -71,6 +73,7 @@ __device__ __forceinline__ int sp_xcd_remap(int bid, int nb) {
 }
 
 // fp32 NCHW view -> split q tensor: one thread per 16-byte unit (8 channels of one pixel), three stores
+template <int NPC>
 __global__ __launch_bounds__(256) void sp_pack_kernel(const float* __restrict__ x, long x_nstride, int N, int C8, int HW,
                                                       u32x4* __restrict__ q, long q_nstride, long q_pstride) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -87,11 +90,12 @@ __global__ __launch_bounds__(256) void sp_pack_kernel(const float* __restrict__ 
     u32x4* o = q + (long)n * q_nstride + (long)cb * HW + p;
     o[0] = q0;
     o[q_pstride] = q1;
-    o[2 * q_pstride] = q2;
+    if (NPC == 3) o[2 * q_pstride] = q2;
 }
 
 // packed fp32 weights wp[c][tap][r] -> split pack (three planes of wq[c/8][tap][Rpad][8]); transposed: the data-gradient
 // operand wqT[k/8][T-1-tap][Cpad][8 k] = wp[c][tap][k] (conv_lp.hip, lp_pack_batched_kernel)
+template <int NPC>
 __global__ __launch_bounds__(256) void sp_pack_w_kernel(const float* __restrict__ wp, u32x4* __restrict__ wq, int red, int T,
                                                         int rows, int nblk, int rpad, int transposed, long pstride) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void sp_pack_w_kernel(const float* __restrict_
     sp_split8(v, q0, q1, q2);
     wq[idx] = q0;
     wq[idx + pstride] = q1;
-    wq[idx + 2 * pstride] = q2;
+    if (NPC == 3) wq[idx + 2 * pstride] = q2;
 }
 
 // every pack of a net in ONE launch: the device table of ghm_lp_pack_batched (48-byte items, include/ghm.h); an item's three
@@ -122,6 +126,7 @@ struct SpPackItem {
     int red, T, rows, nblk, rpad, transposed, block_begin, pad_;
 };
 
+template <int NPC>
 __global__ __launch_bounds__(256) void sp_pack_w_batched_kernel(const SpPackItem* __restrict__ items, int n) {
     int li = 0;
     while (li + 1 < n && (int)blockIdx.x >= items[li + 1].block_begin) ++li;
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256) void sp_pack_w_batched_kernel(const SpPackItem
     sp_split8(v, q0, q1, q2);
     it.wq[idx] = q0;
     it.wq[idx + plane] = q1;
-    it.wq[idx + 2 * plane] = q2;
+    if (NPC == 3) it.wq[idx + 2 * plane] = q2;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -178,10 +183,24 @@ struct SpConvArgs {
     unsigned char* pool_mask;   // ... and the arg-max mask of every window (bit 2*dr + dc; all ties set; bit 4: sign)
 };
 
-constexpr int NP = 3;
+// the piece products of one multiply-add, small terms first, the leading product x0 w0 last: all (i, j) with i + j < NPC.
+// NPC = 3 ('bf16x3'): six products, every term above 2^-24 of the product -- fp32-accurate.  NPC = 2 ('bf16x2'): x0 w0 + x1 w0 +
+// x0 w1, what is dropped is 2^-16 of the product: 16-bit operands at half the matrix-core time, BASELINE config 4's arithmetic
+template <int NPC>
+struct SpProd;
+template <>
+struct SpProd<3> {
+    static constexpr int N = 6;
+    static constexpr int A[6] = {2, 1, 0, 1, 0, 0}, B[6] = {0, 1, 2, 0, 1, 0};
+};
+template <>
+struct SpProd<2> {
+    static constexpr int N = 3;
+    static constexpr int A[3] = {1, 0, 0}, B[3] = {0, 1, 0};
+};
 
 // the epilogue of the forward-form kernels: fp32 NCHW and / or the split q copy, split-K partials, or the pooled form
-template <int BM, int RT, int WM, int WN, bool POOL, int TW, int TM, int TN>
+template <int BM, int RT, int WM, int WN, bool POOL, int TW, int TM, int TN, int NPC>
 __device__ __forceinline__ void sp_conv_epilogue(const SpConvArgs& a, f32x16 (&acc)[TM][TN], f32x16 (&accc)[TM][TN], u32x4* sp_smem,
                                                  int tid, int wm, int wn, int kg, int li, int lx, int ly, int n, int r0, int y0,
                                                  int x0, int HW) {
@@ -252,7 +271,7 @@ __device__ __forceinline__ void sp_conv_epilogue(const SpConvArgs& a, f32x16 (&a
                         }
                     }
                     if (qb && even && rl + i * 32 + 8 * g < a.R)
-                        sp_qstore4(qb + 2 * ((long)(i * 4 + g) * HWp + j2 * Wp), mq[0], mq[1], mq[2], mq[3], ps2);
+                        sp_qstore4<NPC>(qb + 2 * ((long)(i * 4 + g) * HWp + j2 * Wp), mq[0], mq[1], mq[2], mq[3], ps2);
                 }
         return;
     }
@@ -297,172 +316,9 @@ __device__ __forceinline__ void sp_conv_epilogue(const SpConvArgs& a, f32x16 (&a
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     if (full || rl + i * 32 + 8 * g < a.R)
-                        sp_qstore4(qb + 2 * ((long)(i * 4 + g) * HW + j * RPF * a.W), v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], ps2);
+                        sp_qstore4<NPC>(qb + 2 * ((long)(i * 4 + g) * HW + j * RPF * a.W), v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3], ps2);
             }
         }
-}
-
-template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL = false, int TW = 32>
-__global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvArgs a) {
-    // TW = columns of the pixel tile (32, or 16 / 8 for narrow maps): the 32 pixel lanes of a fragment cover RPF = 32 / TW
-    // consecutive rows of TW columns; the block's tile is (RT * RPF) rows x TW columns
-    constexpr int T = KS * KS;
-    constexpr int RPF = 32 / TW, ROWS = RT * RPF;
-    constexpr int TM = BM / (WM * 32), TN = RT / WN;
-    constexpr int PH = (ROWS - 1) * ST + KS, PW = (TW - 1) * ST + KS;
-    constexpr int PU1 = 2 * PH * PW, PUNITS = NP * PU1;          // one piece / all pieces of a slab's patch
-    constexpr int WU1 = 2 * KS * BM, WUNITS = NP * WU1;          // one piece / all pieces of a filter row's weights
-    constexpr int NW = WM * WN, NT = NW * 64;
-    constexpr int NQ = (PU1 + NT - 1) / NT;
-    constexpr int NI = WU1 / 64;                                  // DMA wave-instructions per weight tile and piece
-    static_assert((NW == 4 || NW == 8) && TM >= 1 && TN >= 1, "4 or 8 waves");
-    extern __shared__ __attribute__((aligned(16))) u32x4 sp_smem[];
-    u32x4* const Wl = sp_smem;                         // [2 buffers][piece][2 ch-blocks][KS][BM]
-    u32x4* const Pl = sp_smem + 2 * WUNITS;            // [2 buffers][piece][2 ch-blocks][PH][PW]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int kg = lane >> 5, li = lane & 31;
-    const int ntr = (a.R + BM - 1) / BM;
-    const int tiles_x = a.W / TW, tiles_y = a.H / ROWS;
-    int L = sp_xcd_remap(blockIdx.x, gridDim.x);
-    const int r0 = (L % ntr) * BM;
-    L /= ntr;
-    const int tx = L % tiles_x;
-    L /= tiles_x;
-    const int ty = L % tiles_y;
-    const int n = L / tiles_y;
-    const int y0 = ty * ROWS, x0 = tx * TW;
-    const int lx = li % TW, ly = li / TW;                 // this lane's pixel inside a fragment
-    const int HW = a.H * a.W, HWin = a.Hin * a.Win;
-    const int nslabs = a.CH / 16;
-    const int s_begin = blockIdx.y * a.slabs_per_split;
-    const int s_end = min(nslabs, s_begin + a.slabs_per_split);
-
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    int p_off[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int e = tid + q * NT;
-        const int cb = e / (PH * PW), rem = e - cb * (PH * PW);
-        const int py = rem / PW, px = rem - py * PW;
-        const int y = y0 * ST + py - a.pad, x = x0 * ST + px - a.pad;
-        const bool ok = e < PU1 && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
-        p_off[q] = ok ? cb * HWin + y * a.Win + x : -1;
-    }
-    const u32x4* ibase = a.in_q + (long)n * a.in_q_nstride + (long)s_begin * 2 * HWin;
-    auto stage_patch = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (q * NT + wave * 64 < PU1) {
-                    const u32x4* g = p_off[q] >= 0 ? ibase + p * a.in_q_pstride + p_off[q] : a.zeros;
-                    if (tid + q * NT < PU1)
-                        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Pl + buf * PUNITS + p * PU1 + q * NT + wave * 64), 16, 0, 0);
-                }
-            }
-        ibase += 2 * HWin;
-    };
-    auto stage_weights = [&](int s, int fa, int buf) {
-        const u32x4* src = a.wq + ((long)(2 * s) * T + fa * KS) * a.Rpad + r0 + lane;
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-            for (int w0 = 0; w0 < NI; w0 += NW) {
-                const int w = w0 + wave;
-                if (w < NI) {
-                    const int ci = w / (BM / 64), h = w - ci * (BM / 64);
-                    const int cb = ci / KS, b = ci - cb * KS;
-                    const u32x4* g = src + p * a.wq_pstride + ((long)cb * T + b) * a.Rpad + h * 64;
-                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(Wl + buf * WUNITS + p * WU1 + ci * BM + h * 64), 16, 0, 0);
-                }
-            }
-    };
-
-    // two accumulators per tile: the leading product x0 w0, and the five correction products (2^-8 ... 2^-16 of it).  Every
-    // MFMA rounds its sum to the magnitude of ITS accumulator: with one accumulator the five small products would each add a
-    // rounding error the size of the big sum's (measured 1.8x the fp32 MFMA kernel's error on the 5x5 layers)
-    f32x16 acc[TM][TN], accc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = accc[i][j][e] = 0.f;
-
-    if (s_begin < s_end) {
-        stage_weights(s_begin, 0, 0);
-        stage_patch(0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const int wlane = kg * KS * BM + wm * (BM / WM) + li;
-    const int plane = kg * PH * PW + ((wn * TN * RPF + ly) * ST) * PW + lx * ST;
-    int it = 0;
-    for (int s = s_begin; s < s_end; ++s) {
-        const int pbuf = (s - s_begin) & 1;
-        const bool next_slab = (s + 1) < s_end;
-        for (int fa = 0; fa < KS; ++fa, ++it) {
-            const int wbuf = it & 1;
-            if (fa + 1 < KS)
-                stage_weights(s, fa + 1, wbuf ^ 1);
-            else if (next_slab)
-                stage_weights(s + 1, 0, wbuf ^ 1);
-            if (fa == 0 && next_slab) stage_patch(pbuf ^ 1);
-            const u32x4* Wb = Wl + wbuf * WUNITS + wlane;
-            const u32x4* Pb = Pl + pbuf * PUNITS + plane + fa * PW;
-            // fragments of filter column b + 1 are read behind the MFMAs of column b
-            u32x4 af[2][NP][TM], bf[2][NP][TN];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[0][p][i] = Wb[p * WU1 + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[0][p][j] = Pb[p * PU1 + j * RPF * ST * PW];
-            }
-#pragma unroll
-            for (int b = 0; b < KS; ++b) {
-                if (b + 1 < KS) {
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) af[(b + 1) & 1][p][i] = Wb[p * WU1 + (b + 1) * BM + i * 32];
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) bf[(b + 1) & 1][p][j] = Pb[p * PU1 + j * RPF * ST * PW + b + 1];
-                    }
-                }
-                // the six products, small terms first; consecutive MFMAs go to different accumulators
-#pragma unroll
-                for (int pr = 0; pr < 6; ++pr) {
-                    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            if (pr < 5)
-                                accc[i][j] = sp_mfma(af[b & 1][PA[pr]][i], bf[b & 1][PB[pr]][j], accc[i][j]);
-                            else
-                                acc[i][j] = sp_mfma(af[b & 1][0][i], bf[b & 1][0][j], acc[i][j]);
-                        }
-                }
-                if (b + 1 < KS) {
-#pragma unroll
-                    for (int m_ = 0; m_ < NP * (TM + TN); ++m_) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    }
-
-    sp_conv_epilogue<BM, RT, WM, WN, POOL, TW, TM, TN>(a, acc, accc, sp_smem, tid, wm, wn, kg, li, lx, ly, n, r0, y0, x0, HW);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -482,7 +338,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv_kernel(const SpConvAr
 //     iteration to land and no fragment read is exposed;
 //   * past the end of the contraction the pipeline keeps issuing (clamped to valid addresses): no peeled tail.
 // ------------------------------------------------------------------------------------------------
-template <int KS, int ST, int BM, int RT, int WM, int WN, int TW>
+template <int KS, int ST, int BM, int RT, int WM, int WN, int TW, int NP>
 struct SpGeo2 {
     static constexpr int RPF = 32 / TW, ROWS = RT * RPF;
     static constexpr int PH = (ROWS - 1) * ST + KS, PW = (TW - 1) * ST + KS;
@@ -496,20 +352,19 @@ struct SpGeo2 {
     static constexpr int LDS_BYTES = (SCR + 64) * 16;
 };
 
-struct SpFragDummy {};
-
 // ABL (tuning only, wrong results): 1 = no DMA inside the loop, 2 = no waits / barriers inside the loop, 4 = no fragment reads
 // inside the loop -- what each costs beside the MFMA stream itself
-template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL = false, int TW = 32, int ABL = 0>
+template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL, int TW, int NP, int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvArgs a) {
-    typedef SpGeo2<KS, ST, BM, RT, WM, WN, TW> G;
+    typedef SpGeo2<KS, ST, BM, RT, WM, WN, TW, NP> G;
+    typedef SpProd<NP> PR;
     constexpr int T = KS * KS;
     constexpr int RPF = G::RPF, ROWS = G::ROWS;
     constexpr int TM = BM / (WM * 32), TN = RT / WN;
     constexpr int PH = G::PH, PW = G::PW, PU1 = G::PU1, PCH = G::PCH, PUP = G::PUP;
     constexpr int WU1 = G::WU1, NI = G::NI, NW = G::NW, NQ = G::NQ, NIW = G::NIW;
     constexpr int WUNITS = G::WUNITS, PUNITS = G::PUNITS, SCR = G::SCR;
-    constexpr int NMF = 6 * TM * TN;                 // MFMAs per k-step
+    constexpr int NMF = PR::N * TM * TN;             // MFMAs per k-step
     constexpr int NRD = NP * (TM + TN);              // fragment reads per k-step
     static_assert(TM >= 1 && TN >= 1 && KS >= 3, "tile / pipeline shape");
     extern __shared__ __attribute__((aligned(16))) u32x4 sp_smem[];
@@ -627,7 +482,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
     const int wlane = kg * KS * BM + wm * (BM / WM) + li;
     const int plane = kg * PH * PW + ((wn * TN * RPF + ly) * ST) * PW + lx * ST;
     // fragments of (filter row fa, column b): weights from the buffer at Wb, patch from the buffer at Pb; in the order of
-    // their first use (the six products run small terms first: a2 b0, a1 b1, a0 b2, a1 b0, a0 b1, a0 b0)
+    // their first use (the products run small terms first -- NP = 3: a2 b0, a1 b1, a0 b2, a1 b0, a0 b1, a0 b0)
     auto rd = [&](Frag& f, const u32x4* Wb, const u32x4* Pb, int fa, int b) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -639,14 +494,13 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
     };
     auto mm = [&](const Frag& f) {
 #pragma unroll
-        for (int pr = 0; pr < 6; ++pr) {
-            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+        for (int pr = 0; pr < PR::N; ++pr) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (pr < 5)
-                        accc[i][j] = sp_mfma(f.a[PA[pr]][i], f.b[PB[pr]][j], accc[i][j]);
+                    if (pr < PR::N - 1)
+                        accc[i][j] = sp_mfma(f.a[PR::A[pr]][i], f.b[PR::B[pr]][j], accc[i][j]);
                     else
                         acc[i][j] = sp_mfma(f.a[0][i], f.b[0][j], acc[i][j]);
                 }
@@ -726,7 +580,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
     // DMA still in flight targets LDS the epilogue reuses
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
-    sp_conv_epilogue<BM, RT, WM, WN, POOL, TW, TM, TN>(a, acc, accc, sp_smem, tid, wm, wn, kg, li, lx, ly, n, r0, y0, x0, HW);
+    sp_conv_epilogue<BM, RT, WM, WN, POOL, TW, TM, TN, NP>(a, acc, accc, sp_smem, tid, wm, wn, kg, li, lx, ly, n, r0, y0, x0, HW);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -753,20 +607,8 @@ struct SpWgradArgs {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ u32x4 sp_tr_read8(const char* lds_lo, const char* lds_hi) {
-    typedef s16x4 __attribute__((address_space(3))) * lp4_t;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4_t)lds_lo);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4_t)lds_hi);
-    u32x4 r;
-    r.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
-    r.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
-    r.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
-    r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
-    return r;
-}
-
-// The same transposing read as inline assembly (round 5).  The compiler orders an LDS read it cannot disambiguate behind every
-// LDS-DMA in flight: with the builtin above it put ``s_waitcnt vmcnt(0)`` in front of the first fragment read of every output row
+// The transposing LDS read ds_read_b64_tr_b16 as inline assembly (round 5).  The compiler orders an LDS read it cannot
+// disambiguate behind every LDS-DMA in flight: with __builtin_amdgcn_ds_read_tr16_b64_v4i16 it put ``s_waitcnt vmcnt(0)`` in front of the first fragment read of every output row
 // -- directly behind the DMA requests of the next row, whose whole latency was exposed once per row.  As assembly the read is
 // invisible to that pass; the kernel waits for its own fragments (sp_tr_wait: ``s_waitcnt lgkmcnt(0)`` tied to the registers).
 typedef unsigned long long sp_u64;
@@ -781,15 +623,17 @@ __device__ __forceinline__ u32x4 sp_tr_bits(const SpTrFrag& f) {
 }
 template <int N>
 __device__ __forceinline__ void sp_tr_wait(SpTrFrag (&f)[N]) {
-    static_assert(N == 3 || N == 5, "fragment sets of 3 or 5");
-    if constexpr (N == 3)
+    static_assert(N == 2 || N == 3 || N == 5, "fragment sets of 2, 3 or 5");
+    if constexpr (N == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi));
+    else if constexpr (N == 3)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi));
     else
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi),
                      "+v"(f[3].lo), "+v"(f[3].hi), "+v"(f[4].lo), "+v"(f[4].hi));
 }
 
-template <int KS, int ST, int CHT, int CT, int SPX, bool ASMRD = true>
+template <int KS, int ST, int CHT, int CT, int SPX, int NP>
 __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const SpWgradArgs a) {
     static_assert((ST == 1 || (ST == 2 && KS == 3)) && (SPX == 64 || SPX == 32 || SPX == 16) && (KS == 3 || KS == 5), "variants");
     constexpr int T = KS * KS, PADK = KS / 2;
@@ -881,7 +725,7 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
     const char* const ylane = Yl + ww * YTB + lane_off;
     const char* const xlane = Xl + hh * NPAR * PLB + lane_off;
 
-    if constexpr (ASMRD) {
+    {
         const unsigned lds0 = (unsigned)(size_t)(lptr_t)sp_wsmem;
         const unsigned xl0 = lds0 + hh * NPAR * PLB + lane_off;
         const unsigned yl0 = lds0 + NR * NP * ROWB + ww * YTB + lane_off;
@@ -908,12 +752,12 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
                 for (int q = 0; q < NP; ++q) sp_tr_issue(bf[slot][q], yb + q * YB + ks * 1024);
             };
             read_dy(0, 0);
-            read_x(0, 2, 0);
+            read_x(0, NP - 1, 0);
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
                 for (int pi = 0; pi < NP; ++pi) {
-                    const int p = 2 - pi, ph = ks * NP + pi;
+                    const int p = NP - 1 - pi, ph = ks * NP + pi;
                     // this phase's fragments have arrived (requested one phase ago) ...
                     sp_tr_wait(af[ph & 1]);
                     if (pi == 0) sp_tr_wait(bf[ks & 1]);
@@ -922,10 +766,10 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
                         read_x(ks, p - 1, (ph + 1) & 1);
                     } else if (ks + 1 < KSTEPS) {
                         read_dy(ks + 1, (ks + 1) & 1);
-                        read_x(ks + 1, 2, (ph + 1) & 1);
+                        read_x(ks + 1, NP - 1, (ph + 1) & 1);
                     }
 #pragma unroll
-                    for (int q = 0; q <= 2 - p; ++q)
+                    for (int q = 0; q <= NP - 1 - p; ++q)
 #pragma unroll
                         for (int t = 0; t < KS; ++t) acc[t] = sp_mfma(sp_tr_bits(af[ph & 1][t]), sp_tr_bits(bf[ks & 1][q]), acc[t]);
                     __builtin_amdgcn_sched_barrier(0);
@@ -933,64 +777,6 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
             }
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
-    } else
-    for (int i = i_begin; i < i_end; ++i) {
-        const int buf = (i - i_begin) & 1;
-        if (i + 1 < i_end) {
-#pragma unroll
-            for (int r = 0; r < ST; ++r) stage_xrow(i * ST - PADK + KS + r);        // the rows the next output row adds
-            stage_dy(i + 1, buf ^ 1);
-        }
-        const char* const xr = xlane + (((i * ST + wr - PADK + NR) % NR) * NP) * ROWB;
-        const char* const yb = ylane + buf * NP * YB;
-        // phases (k-step, x piece p = 2, 1, 0): the KS x fragments of piece p meet the dy pieces q <= 2 - p (small terms
-        // first); the next phase's fragments are read behind this phase's MFMAs
-        u32x4 af[2][KS], bf[2][NP];
-        auto read_x = [&](int ks, int p, int slot) {
-#pragma unroll
-            for (int fb = 0; fb < KS; ++fb) {
-                // local column of pixel t' and tap column fb: t' * ST + fb  ->  (parity plane, pixel in plane)
-                const int par = ST == 2 ? (fb & 1) : 0;
-                const int shift = ST == 2 ? (fb >> 1) : fb;
-                const char* pa = xr + p * ROWB + par * PLB + (ks * 16 + shift) * 64;
-                af[slot][fb] = sp_tr_read8(pa, pa + 256);
-            }
-        };
-        auto read_dy = [&](int ks, int slot) {
-#pragma unroll
-            for (int q = 0; q < NP; ++q) bf[slot][q] = sp_tr_read8(yb + q * YB + ks * 1024, yb + q * YB + ks * 1024 + 256);
-        };
-        read_dy(0, 0);
-        read_x(0, 2, 0);
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-#pragma unroll
-            for (int pi = 0; pi < NP; ++pi) {
-                const int p = 2 - pi, ph = ks * NP + pi;
-                int nreads = 0;
-                if (pi + 1 < NP) {
-                    read_x(ks, p - 1, (ph + 1) & 1);
-                    nreads = KS;
-                } else if (ks + 1 < KSTEPS) {
-                    read_dy(ks + 1, (ks + 1) & 1);
-                    read_x(ks + 1, 2, (ph + 1) & 1);
-                    nreads = KS + NP;
-                }
-#pragma unroll
-                for (int q = 0; q <= 2 - p; ++q)
-#pragma unroll
-                    for (int t = 0; t < KS; ++t) acc[t] = sp_mfma(af[ph & 1][t], bf[ks & 1][q], acc[t]);
-                // spread the next phase's reads (two transposing reads per fragment) behind this phase's MFMAs
-#pragma unroll
-                for (int m_ = 0; m_ < nreads; ++m_) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
 
     // ---- epilogue: lane = filter k0 + 32 ww + li; rows = channels c0 + 32 hh + (e & 3) + 8 (e >> 2) + 4 kg ----
@@ -1028,8 +814,9 @@ struct SpDgradS2Extra {
     float dact_alpha;
 };
 
-template <int BM, int RT>
+template <int BM, int RT, int NP>
 __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a, const SpDgradS2Extra x) {
+    typedef SpProd<NP> PR;
     // weights staged per filter ROW (3 taps x 2 channel blocks x BM rows x 3 pieces, double-buffered: 36 KB) and the dy patch
     // per slab (double-buffered): 68 KB in the 64 x 4 shape -- two blocks per CU, and room left for the other streams' kernels
     constexpr int T = 9, WM = 2, WN = 2;
@@ -1168,14 +955,13 @@ __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a,
                 const int cl = (ta == 1 ? 0 : 2) + (tb == 1 ? 0 : 1);
                 const int ro = ta == 0 ? 1 : 0, co = tb == 0 ? 1 : 0;
 #pragma unroll
-                for (int pr = 0; pr < 6; ++pr) {
-                    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+                for (int pr = 0; pr < PR::N; ++pr) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
-                            if (pr < 5)
-                                accc[cl][i][j] = sp_mfma(af[b & 1][PA[pr]][i], bf[PB[pr]][j + ro][co], accc[cl][i][j]);
+                            if (pr < PR::N - 1)
+                                accc[cl][i][j] = sp_mfma(af[b & 1][PR::A[pr]][i], bf[PR::B[pr]][j + ro][co], accc[cl][i][j]);
                             else
                                 acc[cl][i][j] = sp_mfma(af[b & 1][0][i], bf[0][j + ro][co], acc[cl][i][j]);
                         }
@@ -1243,8 +1029,8 @@ __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a,
                         qv[e & 3] = v;
                         if ((e & 3) == 3) {
                             uint2* qo = qrow + 2 * ((long)(i * 4 + (e >> 2)) * HWx + pu * a.W);
-                            sp_qstore4(qo, qv[0].x, qv[1].x, qv[2].x, qv[3].x, ps2);
-                            sp_qstore4(qo + 2, qv[0].y, qv[1].y, qv[2].y, qv[3].y, ps2);
+                            sp_qstore4<NP>(qo, qv[0].x, qv[1].x, qv[2].x, qv[3].x, ps2);
+                            sp_qstore4<NP>(qo + 2, qv[0].y, qv[1].y, qv[2].y, qv[3].y, ps2);
                         }
                     }
                 }
@@ -1256,6 +1042,7 @@ __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a,
 // ------------------------------------------------------------------------------------------------
 struct SpPlan {
     bool ok;
+    int np;            // pieces per operand: 3 ('bf16x3', six products) or 2 ('bf16x2', three products)
     int bm, rt, wm, wn, tw, splits, slabs_per_split, grid;
     size_t lds;
 };
@@ -1263,20 +1050,17 @@ struct SpPlan {
 int sp_rpad(int r) { return (r + 127) / 128 * 128; }
 int sp_nblk(int red) { return (red + 15) / 16 * 2; }      // channel blocks of a pack (as the low-precision packs: whole slabs)
 
-// GHM_SPLIT_V1: the round-4 K loop (sp_conv_kernel) instead of the pipelined one (sp_conv2_kernel) -- A/B only
-bool sp_v1() { return GHM_OPT("GHM_SPLIT_V1") != nullptr; }
-
-size_t sp_lds_bytes(int ks, int st, int bm, int rt, int tw = 32) {
+size_t sp_lds_bytes(int ks, int st, int bm, int rt, int tw, int np) {
     const int rows = rt * (32 / tw);
     const int ph = (rows - 1) * st + ks, pw = (tw - 1) * st + ks;
-    if (sp_v1()) return (size_t)2 * NP * (2 * ks * bm + 2 * ph * pw) * 16;
-    return ((size_t)2 * NP * (2 * ks * bm + (2 * ph * pw + 63) / 64 * 64) + 64) * 16;      // SpGeo2::LDS_BYTES
+    return ((size_t)2 * np * (2 * ks * bm + (2 * ph * pw + 63) / 64 * 64) + 64) * 16;      // SpGeo2::LDS_BYTES
 }
 
 // forward form: CH reduction channels, R output channels, (H, W) output grid
-SpPlan sp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
+SpPlan sp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu, int np = 3) {
     SpPlan p;
     memset(&p, 0, sizeof(p));
+    p.np = np;
     if (GHM_OPT("GHM_NO_SPLIT")) return p;
     if (!((ks == 3 && (st == 1 || st == 2)) || (ks == 5 && st == 1))) return p;
     // one block per CU (three pieces of both operands, double-buffered, fill the LDS): 3x3 stride 1 takes 128 filters x 8 rows
@@ -1298,7 +1082,7 @@ SpPlan sp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
     }
     const int rows = p.rt * (32 / p.tw);
     if (R < 32 || (W % p.tw) || (H % rows) || (CH % 16) || CH < 16) return p;
-    p.lds = sp_lds_bytes(ks, st, p.bm, p.rt, p.tw);
+    p.lds = sp_lds_bytes(ks, st, p.bm, p.rt, p.tw, np);
     if (p.lds > 160 * 1024) return p;
     const int ntr = (R + p.bm - 1) / p.bm;
     p.grid = ntr * (W / p.tw) * (H / rows) * N;
@@ -1318,14 +1102,20 @@ SpPlan sp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu) {
 
 static inline size_t align256(size_t n) { return (n + 255) / 256 * 256; }
 
-int sp_pack(ghm_ctx* ctx, const float* x, long x_nstride, int N, int C, int HW, void* q, long q_nstride, long q_pstride) {
+int sp_pack(ghm_ctx* ctx, const float* x, long x_nstride, int N, int C, int HW, void* q, long q_nstride, long q_pstride, int np) {
     const long total = (long)N * (C / 8) * HW;
     if (total == 0) return 0;
-    hipLaunchKernelGGL(sp_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, x, x_nstride, N, C / 8, HW,
-                       (u32x4*)q, q_nstride, q_pstride);
+    if (np == 3)
+        hipLaunchKernelGGL(sp_pack_kernel<3>, dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, x, x_nstride, N, C / 8, HW,
+                           (u32x4*)q, q_nstride, q_pstride);
+    else
+        hipLaunchKernelGGL(sp_pack_kernel<2>, dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, x, x_nstride, N, C / 8, HW,
+                           (u32x4*)q, q_nstride, q_pstride);
     GHM_LAUNCH_CHECK();
     return 0;
 }
+
+#define GHM_SP_PIECES_OK(np) GHM_CHECK((np) == 2 || (np) == 3, "split convolution: pieces must be 3 ('bf16x3') or 2 ('bf16x2')")
 
 // > 64 KB of dynamic LDS needs the attribute once per kernel (not per launch: it is a driver call on the step's issue path)
 template <typename K>
@@ -1340,36 +1130,31 @@ int sp_set_lds(K kernel, size_t lds) {
     return 0;
 }
 
-// one tile shape: the pipelined kernel (four-wave shapes) or, under GHM_SPLIT_V1, the round-4 kernel
+// one tile shape of the forward-form kernel, for 3 or 2 pieces per operand
 template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL, int TW>
-int sp_launch_variant(ghm_ctx* ctx, dim3 g, size_t lds, const SpConvArgs& a, bool v1) {
-    if (v1) {
-        if constexpr (!(BM == 128 && WM == 1)) {       // (the 4 x 2-tile shape is the pipelined kernel's)
-            if (int e = sp_set_lds(sp_conv_kernel<KS, ST, BM, RT, WM, WN, POOL, TW>, lds)) return e;
-            hipLaunchKernelGGL((sp_conv_kernel<KS, ST, BM, RT, WM, WN, POOL, TW>), g, dim3(WM * WN * 64), lds, ctx->stream, a);
-        }
-    } else if constexpr (true) {
-        static_assert(SpGeo2<KS, ST, BM, RT, WM, WN, TW>::LDS_BYTES <= 160 * 1024, "LDS");
+int sp_launch_variant(ghm_ctx* ctx, dim3 g, size_t lds, const SpConvArgs& a, int np) {
+    static_assert(SpGeo2<KS, ST, BM, RT, WM, WN, TW, 3>::LDS_BYTES <= 160 * 1024, "LDS");
 #ifdef GHM_SPLIT_ABLATION
-        if constexpr (KS == 5 && BM == 64 && RT == 8 && !POOL && TW == 32) {
-            const char* f = GHM_OPT("GHM_SPLIT_ABLATE");
-            const int abl = f ? atoi(f) : 0;
+    if constexpr (KS == 5 && BM == 64 && RT == 8 && !POOL && TW == 32) {
+        const char* f = GHM_OPT("GHM_SPLIT_ABLATE");
+        const int abl = f ? atoi(f) : 0;
 #define GHM_ABL_CASE(A_)                                                                                              \
-            if (abl == A_) {                                                                                          \
-                if (int e = sp_set_lds(sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, A_>, lds)) return e;          \
-                hipLaunchKernelGGL((sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, A_>), g, dim3(WM * WN * 64), lds, ctx->stream, a); \
-                GHM_LAUNCH_CHECK();                                                                                   \
-                return 0;                                                                                             \
-            }
-            GHM_ABL_CASE(1) GHM_ABL_CASE(4) GHM_ABL_CASE(5) GHM_ABL_CASE(7) GHM_ABL_CASE(8) GHM_ABL_CASE(16)
-#undef GHM_ABL_CASE
+        if (abl == A_ && np == 3) {                                                                                   \
+            if (int e = sp_set_lds(sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, 3, A_>, lds)) return e;           \
+            hipLaunchKernelGGL((sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, 3, A_>), g, dim3(WM * WN * 64), lds, ctx->stream, a); \
+            GHM_LAUNCH_CHECK();                                                                                       \
+            return 0;                                                                                                 \
         }
+        GHM_ABL_CASE(1) GHM_ABL_CASE(4) GHM_ABL_CASE(5) GHM_ABL_CASE(7) GHM_ABL_CASE(8) GHM_ABL_CASE(16)
+#undef GHM_ABL_CASE
+    }
 #endif
-        if (int e = sp_set_lds(sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW>, lds)) return e;
-        hipLaunchKernelGGL((sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW>), g, dim3(WM * WN * 64), lds, ctx->stream, a);
+    if (np == 3) {
+        if (int e = sp_set_lds(sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, 3>, lds)) return e;
+        hipLaunchKernelGGL((sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, 3>), g, dim3(WM * WN * 64), lds, ctx->stream, a);
     } else {
-        ghm_set_error("split-fp32 convolution: the eight-wave shape exists in the GHM_SPLIT_V1 form only");
-        return -3;
+        if (int e = sp_set_lds(sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, 2>, lds)) return e;
+        hipLaunchKernelGGL((sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, 2>), g, dim3(WM * WN * 64), lds, ctx->stream, a);
     }
     GHM_LAUNCH_CHECK();
     return 0;
@@ -1381,6 +1166,7 @@ int sp_launch_conv(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, int ks, int st,
     a.zeros = (const u32x4*)ctx->zeros;
     a.partial = nullptr;
     const long plane = (long)a.N * (a.CH / 8) * a.Hin * a.Win;
+    const int NP = pl.np;
     const size_t qbytes = in32 ? align256((size_t)NP * plane * 16) : 0;
     const size_t pbytes = pl.splits > 1 ? (size_t)pl.splits * a.R * a.N * a.H * a.W * sizeof(float) : 0;
     if (qbytes + pbytes) {
@@ -1390,7 +1176,7 @@ int sp_launch_conv(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, int ks, int st,
             a.in_q = (const u32x4*)ws;
             a.in_q_nstride = (long)(a.CH / 8) * a.Hin * a.Win;
             a.in_q_pstride = plane;
-            if (int e = sp_pack(ctx, in32, in32_nstride, a.N, a.CH, a.Hin * a.Win, ws, a.in_q_nstride, plane)) return e;
+            if (int e = sp_pack(ctx, in32, in32_nstride, a.N, a.CH, a.Hin * a.Win, ws, a.in_q_nstride, plane, NP)) return e;
         }
         if (pbytes) a.partial = (float*)((char*)ws + qbytes);
     }
@@ -1402,9 +1188,8 @@ int sp_launch_conv(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, int ks, int st,
     const dim3 g(pl.grid, pl.splits);
 #define GHM_SP_CASE(KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_)                                                    \
     if (ks == KS_ && st == ST_ && pl.bm == BM_ && pl.rt == RT_ && pl.wm == WM_ && pool == POOL_ && pl.tw == TW_) {  \
-        if (int e = sp_launch_variant<KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_>(ctx, g, pl.lds, a, v1)) return e;  \
+        if (int e = sp_launch_variant<KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_>(ctx, g, pl.lds, a, pl.np)) return e;  \
     } else
-    const bool v1 = sp_v1();
     GHM_SP_CASE(5, 1, 64, 8, 1, 4, false, 32)
     GHM_SP_CASE(5, 1, 64, 8, 1, 4, true, 32)
     GHM_SP_CASE(3, 1, 128, 8, 2, 4, false, 32)
@@ -1431,19 +1216,21 @@ int sp_launch_conv(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, int ks, int st,
 // ---- weight gradient plan: one round of resident blocks (a block per CU) ----
 struct SpWPlan {
     bool ok;
+    int np;
     int cht, ct, spx, splits_per_col, rows_per_split, ncols;
     size_t lds;
 };
 
-size_t sp_wgrad_lds(int ks, int st, int cht, int ct, int spx) {
+size_t sp_wgrad_lds(int ks, int st, int cht, int ct, int spx, int NP) {
     const int xpix = st == 1 ? spx + ks - 1 : spx + 1, xch = (xpix + 15) / 16;
     const size_t rowb = (size_t)cht * st * xch * 16 * 64, yb = (size_t)ct * spx * 64;
     return NP * ((ks + st) * rowb + 2 * yb);
 }
 
-SpWPlan sp_wplan(const ghm_conv_desc* d, int num_cu) {
+SpWPlan sp_wplan(const ghm_conv_desc* d, int num_cu, int np = 3) {
     SpWPlan v;
     memset(&v, 0, sizeof(v));
+    v.np = np;
     if (GHM_OPT("GHM_NO_SPLIT") || GHM_OPT("GHM_NO_SPLIT_WGRAD")) return v;
     const bool k3 = d->kh == 3 && d->kw == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2);
     const bool k5 = d->kh == 5 && d->kw == 5 && d->pad == 2 && d->stride == 1;
@@ -1461,7 +1248,7 @@ SpWPlan sp_wplan(const ghm_conv_desc* d, int num_cu) {
         if (d->K % 128 || d->C % 32) return v;
         v.cht = 1; v.ct = 4; v.spx = narrow;
     }
-    v.lds = sp_wgrad_lds(d->kh, d->stride, v.cht, v.ct, v.spx);
+    v.lds = sp_wgrad_lds(d->kh, d->stride, v.cht, v.ct, v.spx, np);
     if (v.lds > 160 * 1024) return v;
     v.ncols = d->N * (d->Wo / v.spx);
     const long tiles = (long)(d->C / (32 * v.cht)) * (d->K / (32 * v.ct)) * v.ncols;
@@ -1496,18 +1283,17 @@ int sp_launch_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const SpWPlan& v, cons
     const dim3 grid(d->C / (32 * v.cht), d->K / (32 * v.ct), splits);
 #define GHM_SPW_CASE(KS_, ST_, CHT_, CT_, SPX_)                                                                     \
     if (d->kh == KS_ && d->stride == ST_ && v.cht == CHT_ && v.ct == CT_ && v.spx == SPX_) {                       \
-        if (v1w) {                                                                                                  \
-            if (int e = sp_set_lds(sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, false>, v.lds)) return e;             \
-            hipLaunchKernelGGL((sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, false>), grid, dim3(CHT_ * CT_ * KS_ * 64), v.lds, \
+        if (v.np == 3) {                                                                                            \
+            if (int e = sp_set_lds(sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, 3>, v.lds)) return e;                 \
+            hipLaunchKernelGGL((sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, 3>), grid, dim3(CHT_ * CT_ * KS_ * 64), v.lds, \
                                ctx->stream, a);                                                                   \
         } else {                                                                                                  \
-            if (int e = sp_set_lds(sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, true>, v.lds)) return e;              \
-            hipLaunchKernelGGL((sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, true>), grid, dim3(CHT_ * CT_ * KS_ * 64), v.lds, \
+            if (int e = sp_set_lds(sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, 2>, v.lds)) return e;                 \
+            hipLaunchKernelGGL((sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, 2>), grid, dim3(CHT_ * CT_ * KS_ * 64), v.lds, \
                                ctx->stream, a);                                                                   \
         }                                                                                                         \
         GHM_LAUNCH_CHECK();                                                                                       \
     } else
-    const bool v1w = GHM_OPT("GHM_SPLIT_WGRAD_V1") != nullptr;
     GHM_SPW_CASE(3, 1, 2, 2, 32)
     GHM_SPW_CASE(3, 2, 1, 4, 32)
     GHM_SPW_CASE(5, 1, 1, 2, 64)
@@ -1524,9 +1310,10 @@ int sp_launch_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const SpWPlan& v, cons
 }
 
 // ---- 3x3 stride-2 data gradient ----
-SpPlan sp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu) {
+SpPlan sp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu, int np = 3) {
     SpPlan p;
     memset(&p, 0, sizeof(p));
+    p.np = np;
     // (a first form with all nine taps of a slab staged at once -- 142 KB of LDS, one block per CU -- was 2-25 % faster than
     // dgrad_s2_patch_kernel alone and 1.6 % SLOWER in the step: it shut the other streams' kernels out of its CU.  This one
     // stages a filter row at a time: 55 KB, two blocks per CU; alone 154-177 TFLOP/s fp32-equivalent against 107-115, joint
@@ -1537,7 +1324,7 @@ SpPlan sp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu) {
     p.bm = 64;
     p.rt = 2;           // 64 channels x 2 class rows: eight accumulator tiles per wave (leading + correction) -> two blocks per CU
     if (d->Ho % p.rt) return p;
-    p.lds = (size_t)2 * NP * (2 * 3 * p.bm + 2 * (p.rt + 1) * 33) * 16;
+    p.lds = (size_t)2 * np * (2 * 3 * p.bm + 2 * (p.rt + 1) * 33) * 16;
     p.grid = ((d->C + p.bm - 1) / p.bm) * (d->Wo / 32) * (d->Ho / p.rt) * d->N;
     const int nslabs = d->K / 16;
     p.splits = 1;
@@ -1557,6 +1344,7 @@ int sp_launch_dgrad_s2(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, const SpDgr
     a.zeros = (const u32x4*)ctx->zeros;
     a.partial = nullptr;
     const long plane = (long)a.N * (a.CH / 8) * a.Hin * a.Win;
+    const int NP = pl.np;
     const size_t qbytes = dy32 ? align256((size_t)NP * plane * 16) : 0;
     const size_t pbytes = pl.splits > 1 ? (size_t)pl.splits * a.R * a.N * a.H * a.W * sizeof(float) : 0;
     if (qbytes + pbytes) {
@@ -1566,7 +1354,7 @@ int sp_launch_dgrad_s2(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, const SpDgr
             a.in_q = (const u32x4*)ws;
             a.in_q_nstride = (long)(a.CH / 8) * a.Hin * a.Win;
             a.in_q_pstride = plane;
-            if (int e = sp_pack(ctx, dy32, dy32_nstride, a.N, a.CH, a.Hin * a.Win, ws, a.in_q_nstride, plane)) return e;
+            if (int e = sp_pack(ctx, dy32, dy32_nstride, a.N, a.CH, a.Hin * a.Win, ws, a.in_q_nstride, plane, NP)) return e;
         }
         if (pbytes) a.partial = (float*)((char*)ws + qbytes);
     }
@@ -1576,8 +1364,13 @@ int sp_launch_dgrad_s2(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, const SpDgr
     GHM_CHECK(!(a.accumulate && !a.out), "accumulate needs the fp32 output");
     GHM_CHECK(!a.out_q || (a.R % 8 == 0 && ((uintptr_t)a.out_q & 15) == 0), "q output: a multiple of 8 channels, 16-byte aligned");
     const dim3 g(pl.grid, pl.splits);
-    if (int e = sp_set_lds(sp_dgrad_s2_kernel<64, 2>, pl.lds)) return e;
-    hipLaunchKernelGGL((sp_dgrad_s2_kernel<64, 2>), g, dim3(256), pl.lds, ctx->stream, a, x);
+    if (NP == 3) {
+        if (int e = sp_set_lds(sp_dgrad_s2_kernel<64, 2, 3>, pl.lds)) return e;
+        hipLaunchKernelGGL((sp_dgrad_s2_kernel<64, 2, 3>), g, dim3(256), pl.lds, ctx->stream, a, x);
+    } else {
+        if (int e = sp_set_lds(sp_dgrad_s2_kernel<64, 2, 2>, pl.lds)) return e;
+        hipLaunchKernelGGL((sp_dgrad_s2_kernel<64, 2, 2>), g, dim3(256), pl.lds, ctx->stream, a, x);
+    }
     GHM_LAUNCH_CHECK();
     if (pl.splits > 1)
         return ghm_splitk_finish(ctx, a.partial, pl.splits, a.out, a.bias, a.N, a.R, a.H, a.W, a.out_nstride, a.act, a.alpha,
@@ -1593,8 +1386,8 @@ bool sp_fwd_geom(const ghm_conv_desc* d) {
 
 static int sp_dgrad_s2(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* dyq, long dyq_ns, long dyq_ps,
                        const void* wqT, const float* bias, float* dx, int act, float alpha, int accumulate, const float* dact_y,
-                       long dact_nstride, float dact_alpha, void* dxq = nullptr, long dxq_ns = 0) {
-    const SpPlan pl = sp_plan_dgrad_s2(d, ctx->num_cu);
+                       long dact_nstride, float dact_alpha, void* dxq, long dxq_ns, int np) {
+    const SpPlan pl = sp_plan_dgrad_s2(d, ctx->num_cu, np);
     GHM_CHECK(pl.ok, "split-fp32 stride-2 data gradient: geometry not served");
     SpConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -1650,45 +1443,57 @@ int ghm_conv2d_wgrad_split_workspace(const ghm_conv_desc* d, size_t* bytes) {
 // dwp (+)= the weight gradient in the packed layout wp[c][tap][k], from the split q tensors of x and dy
 int ghm_conv2d_wgrad_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void* xq, int64_t xq_nstride, int64_t xq_pstride,
                            const void* dyq, int64_t dyq_nstride, int64_t dyq_pstride, float* dwp, void* workspace,
-                           int32_t accumulate) {
+                           int32_t accumulate, int32_t pieces) {
     GHM_CHECK(ctx && d && xq && dyq && dwp, "null argument");
+    GHM_SP_PIECES_OK(pieces);
     GHM_CHECK(ghm_split_supported(d, 2), "ghm_conv2d_wgrad_split: geometry not served (ask ghm_split_supported)");
     GHM_CHECK((((uintptr_t)xq | (uintptr_t)dyq) & 15) == 0, "ghm_conv2d_wgrad_split: q tensors are 16-byte aligned");
-    const SpWPlan v = sp_wplan(d, ghm_plan_cus());
+    const SpWPlan v = sp_wplan(d, ghm_plan_cus(), pieces);
     return sp_launch_wgrad(ctx, d, v, xq, (long)xq_nstride, (long)xq_pstride, dyq, (long)dyq_nstride, (long)dyq_pstride, dwp,
                            workspace, accumulate);
 }
 
-int ghm_split_weight_bytes(const ghm_conv_desc* d, int32_t transposed, size_t* bytes) {
+int ghm_split_weight_bytes(const ghm_conv_desc* d, int32_t transposed, size_t* bytes, int32_t pieces) {
     GHM_CHECK(d && bytes, "null argument");
+    GHM_SP_PIECES_OK(pieces);
     const int red = transposed ? d->K : d->C, rows = transposed ? d->C : d->K;
-    *bytes = (size_t)NP * sp_nblk(red) * d->kh * d->kw * sp_rpad(rows) * 16;
+    *bytes = (size_t)pieces * sp_nblk(red) * d->kh * d->kw * sp_rpad(rows) * 16;
     return 0;
 }
 
-int ghm_split_pack_weights(ghm_ctx* ctx, const ghm_conv_desc* d, const float* wp, void* wq, int32_t transposed) {
+int ghm_split_pack_weights(ghm_ctx* ctx, const ghm_conv_desc* d, const float* wp, void* wq, int32_t transposed, int32_t pieces) {
     GHM_CHECK(ctx && d && wp && wq, "null argument");
+    GHM_SP_PIECES_OK(pieces);
     const int red = transposed ? d->K : d->C, rows = transposed ? d->C : d->K;
     const int T = d->kh * d->kw, nblk = sp_nblk(red), rpad = sp_rpad(rows);
     const long plane = (long)nblk * T * rpad;
-    hipLaunchKernelGGL(sp_pack_w_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0, ctx->stream, wp, (u32x4*)wq, red, T, rows,
-                       nblk, rpad, transposed ? 1 : 0, plane);
+    if (pieces == 3)
+        hipLaunchKernelGGL(sp_pack_w_kernel<3>, dim3(ceil_div(plane, 256)), dim3(256), 0, ctx->stream, wp, (u32x4*)wq, red, T, rows,
+                           nblk, rpad, transposed ? 1 : 0, plane);
+    else
+        hipLaunchKernelGGL(sp_pack_w_kernel<2>, dim3(ceil_div(plane, 256)), dim3(256), 0, ctx->stream, wp, (u32x4*)wq, red, T, rows,
+                           nblk, rpad, transposed ? 1 : 0, plane);
     GHM_LAUNCH_CHECK();
     return 0;
 }
 
-// fp32 NCHW view -> split q tensor (three planes of q_pstride units)
+// fp32 NCHW view -> split q tensor (``pieces`` planes of q_pstride units)
 int ghm_split_pack(ghm_ctx* ctx, const float* x, int64_t x_nstride, int32_t N, int32_t C, int32_t HW, void* q, int64_t q_nstride,
-                   int64_t q_pstride) {
+                   int64_t q_pstride, int32_t pieces) {
     GHM_CHECK(ctx && x && q && C % 8 == 0, "ghm_split_pack: null argument or channels not a multiple of 8");
-    return sp_pack(ctx, x, x_nstride, N, C, HW, q, q_nstride, q_pstride);
+    GHM_SP_PIECES_OK(pieces);
+    return sp_pack(ctx, x, x_nstride, N, C, HW, q, q_nstride, q_pstride, pieces);
 }
 
-int ghm_split_pack_batched(ghm_ctx* ctx, const void* table, int32_t n_items, int32_t total_blocks) {
+int ghm_split_pack_batched(ghm_ctx* ctx, const void* table, int32_t n_items, int32_t total_blocks, int32_t pieces) {
     static_assert(sizeof(SpPackItem) == 48, "table layout is part of the ABI (see ghm.h)");
     GHM_CHECK(ctx && table, "null argument");
+    GHM_SP_PIECES_OK(pieces);
     if (n_items <= 0 || total_blocks <= 0) return 0;
-    hipLaunchKernelGGL(sp_pack_w_batched_kernel, dim3(total_blocks), dim3(256), 0, ctx->stream, (const SpPackItem*)table, n_items);
+    if (pieces == 3)
+        hipLaunchKernelGGL(sp_pack_w_batched_kernel<3>, dim3(total_blocks), dim3(256), 0, ctx->stream, (const SpPackItem*)table, n_items);
+    else
+        hipLaunchKernelGGL(sp_pack_w_batched_kernel<2>, dim3(total_blocks), dim3(256), 0, ctx->stream, (const SpPackItem*)table, n_items);
     GHM_LAUNCH_CHECK();
     return 0;
 }
@@ -1704,10 +1509,11 @@ int ghm_split_pool_supported(const ghm_conv_desc* d, int32_t act) {
 
 int ghm_conv2d_fwd_pool_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* xq, int64_t xq_nstride,
                               int64_t xq_pstride, const void* wq, const float* bias, float* pooled, void* pooledq,
-                              int64_t pooledq_nstride, uint8_t* mask, int32_t act, float alpha) {
+                              int64_t pooledq_nstride, uint8_t* mask, int32_t act, float alpha, int32_t pieces) {
     GHM_CHECK(ctx && d && (x || xq) && wq && mask, "null argument");
+    GHM_SP_PIECES_OK(pieces);
     GHM_CHECK(ghm_split_pool_supported(d, act), "ghm_conv2d_fwd_pool_split: not served (ask ghm_split_pool_supported)");
-    const SpPlan pl = sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, ctx->num_cu);
+    const SpPlan pl = sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, 1, ctx->num_cu, pieces);
     SpConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in_q = (const u32x4*)xq; a.in_q_nstride = xq_nstride; a.in_q_pstride = xq_pstride;
@@ -1723,11 +1529,12 @@ int ghm_conv2d_fwd_pool_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float*
 // input as a split q tensor (ghm_split_pack) instead of x.
 int ghm_conv2d_fwd_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const void* xq, int64_t xq_nstride,
                          int64_t xq_pstride, const void* wq, const float* bias, float* y, void* yq, int64_t yq_nstride,
-                         int32_t act, float alpha, int32_t accumulate) {
+                         int32_t act, float alpha, int32_t accumulate, int32_t pieces) {
     GHM_CHECK(ctx && d && (x || xq) && wq && (y || yq), "null argument");
+    GHM_SP_PIECES_OK(pieces);
     GHM_CHECK(ghm_split_supported(d, 0), "ghm_conv2d_fwd_split: geometry not served (ask ghm_split_supported)");
     GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
-    const SpPlan pl = sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ctx->num_cu);
+    const SpPlan pl = sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, d->kh, d->stride, ctx->num_cu, pieces);
     SpConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in_q = (const u32x4*)xq; a.in_q_nstride = xq_nstride; a.in_q_pstride = xq_pstride;
@@ -1742,14 +1549,15 @@ int ghm_conv2d_fwd_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, c
 // dx = act(conv^T(dy, W) + b) of a stride-1 'same' convolution; wqT = ghm_split_pack_weights(transposed = 1)
 int ghm_conv2d_dgrad_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* dyq, int64_t dyq_nstride,
                            int64_t dyq_pstride, const void* wqT, const float* bias, float* dx, void* dxq, int64_t dxq_nstride,
-                           int32_t act, float alpha, int32_t accumulate) {
+                           int32_t act, float alpha, int32_t accumulate, int32_t pieces) {
     GHM_CHECK(ctx && d && (dy || dyq) && wqT && (dx || dxq), "null argument");
+    GHM_SP_PIECES_OK(pieces);
     GHM_CHECK(ghm_split_supported(d, 1), "ghm_conv2d_dgrad_split: geometry not served (ask ghm_split_supported)");
     GHM_CHECK(!(accumulate && act != GHM_ACT_LINEAR), "accumulate needs a linear epilogue");
     if (d->stride == 2)
         return sp_dgrad_s2(ctx, d, dy, dyq, dyq_nstride, dyq_pstride, wqT, bias, dx, act, alpha, accumulate, nullptr, 0, 0.f, dxq,
-                           (long)dxq_nstride);
-    const SpPlan pl = sp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ctx->num_cu);
+                           (long)dxq_nstride, pieces);
+    const SpPlan pl = sp_plan(d->N, d->K, d->H, d->W, d->C, d->kh, 1, ctx->num_cu, pieces);
     SpConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in_q = (const u32x4*)dyq; a.in_q_nstride = dyq_nstride; a.in_q_pstride = dyq_pstride;
@@ -1771,12 +1579,13 @@ int ghm_split_dgrad_dact_supported(const ghm_conv_desc* d) {
 
 int ghm_conv2d_dgrad_dact_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void* dyq, int64_t dyq_nstride, int64_t dyq_pstride,
                                 const void* wqT, float* dx, void* dxq, int64_t dxq_nstride, const float* y, int64_t y_nstride,
-                                int32_t act, float alpha) {
+                                int32_t act, float alpha, int32_t pieces) {
     GHM_CHECK(ctx && d && dyq && wqT && (dx || dxq) && y, "null argument");
+    GHM_SP_PIECES_OK(pieces);
     GHM_CHECK(ghm_split_dgrad_dact_supported(d), "ghm_conv2d_dgrad_dact_split: not served (ask ghm_split_dgrad_dact_supported)");
     GHM_CHECK(act == GHM_ACT_RELU || act == GHM_ACT_LRELU, "ghm_conv2d_dgrad_dact_split: relu / leaky relu");
     return sp_dgrad_s2(ctx, d, nullptr, dyq, (long)dyq_nstride, (long)dyq_pstride, wqT, nullptr, dx, GHM_ACT_LINEAR, 0.f, 0, y,
-                       (long)y_nstride, act == GHM_ACT_RELU ? 0.f : alpha, dxq, (long)dxq_nstride);
+                       (long)y_nstride, act == GHM_ACT_RELU ? 0.f : alpha, dxq, (long)dxq_nstride, pieces);
 }
 
 }  // extern "C"

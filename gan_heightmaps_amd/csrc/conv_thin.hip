@@ -66,7 +66,7 @@ __device__ __forceinline__ unsigned thin_pack2(float a, float b, int dt) {
 // a half unit (4 consecutive channels of one pixel) of a q tensor; dt == 3 ('bf16x3', the split-fp32 mode): the three bf16
 // pieces of each value in three planes ``ps2`` half-units apart (csrc/conv_split.hip, elementwise_q.hip q_store8)
 __device__ __forceinline__ void thin_qstore4(uint2* qo, float v0, float v1, float v2, float v3, int dt, long ps2) {
-    if (dt == 3) {
+    if (dt == 3 || dt == 4) {         // (4 = 'bf16x2': the first two pieces)
         unsigned p[2][3];
         const float in[2][2] = {{v0, v1}, {v2, v3}};
 #pragma unroll
@@ -80,7 +80,7 @@ __device__ __forceinline__ void thin_qstore4(uint2* qo, float v0, float v1, floa
         }
         qo[0] = make_uint2(p[0][0], p[1][0]);
         qo[ps2] = make_uint2(p[0][1], p[1][1]);
-        qo[2 * ps2] = make_uint2(p[0][2], p[1][2]);
+        if (dt == 3) qo[2 * ps2] = make_uint2(p[0][2], p[1][2]);
     } else {
         *qo = make_uint2(thin_pack2(v0, v1, dt), thin_pack2(v2, v3, dt));
     }
@@ -499,7 +499,7 @@ int thin_fanout_fwd(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, const 
     FanoutArgs a;
     memset(&a, 0, sizeof(a));
     const int T = d->kh * d->kw;
-    GHM_CHECK(!yq || (d->K % 8 == 0 && ((uintptr_t)yq & 15) == 0 && (q_dt == GHM_DTYPE_BF16 || q_dt == GHM_DTYPE_F16 || q_dt == 3)),
+    GHM_CHECK(!yq || (d->K % 8 == 0 && ((uintptr_t)yq & 15) == 0 && (q_dt == GHM_DTYPE_BF16 || q_dt == GHM_DTYPE_F16 || q_dt == 3 || q_dt == 4)),
               "thin forward with a q output: filters %% 8 == 0, 16-byte aligned q tensor, bf16 / f16");
     a.out_q = (uint2*)yq; a.out_q_nstride = yq_nstride; a.q_dt = q_dt;
     a.in = x; a.wp = wp; a.bias = bias; a.out = y; a.zeros = ctx->zeros;
@@ -530,7 +530,7 @@ int thin_fanout_fwd_pool(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, c
                          float* pooled, unsigned char* mask, int act, float alpha, void* yq, long yq_nstride, int q_dt) {
     FanoutArgs a;
     memset(&a, 0, sizeof(a));
-    GHM_CHECK(!yq || (((uintptr_t)yq & 15) == 0 && (q_dt == GHM_DTYPE_BF16 || q_dt == GHM_DTYPE_F16 || q_dt == 3)),
+    GHM_CHECK(!yq || (((uintptr_t)yq & 15) == 0 && (q_dt == GHM_DTYPE_BF16 || q_dt == GHM_DTYPE_F16 || q_dt == 3 || q_dt == 4)),
               "thin pooled forward with a q output: 16-byte aligned q tensor, bf16 / f16");
     a.out_q = (uint2*)yq; a.out_q_nstride = yq_nstride; a.q_dt = q_dt;
     const int T = d->kh * d->kw;

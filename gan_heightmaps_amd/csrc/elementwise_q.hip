@@ -38,14 +38,15 @@ __device__ __forceinline__ void q_split2(float a, float b, unsigned& p0, unsigne
     f32x2q r2 = {r[0] - __uint_as_float(p1 << 16), r[1] - __uint_as_float(p1 & 0xffff0000u)};
     p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2q));
 }
+// dt == 4 ('bf16x2'): the first two pieces only (x1 = bf16(x - x0), rounded to nearest)
 __device__ __forceinline__ void q_store8(u32x4q* o, const float* v, int dt, long ps) {
-    if (dt == 3) {
+    if (dt == 3 || dt == 4) {
         unsigned a[4], b[4], c[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) q_split2(v[2 * t], v[2 * t + 1], a[t], b[t], c[t]);
         o[0] = u32x4q{a[0], a[1], a[2], a[3]};
         o[ps] = u32x4q{b[0], b[1], b[2], b[3]};
-        o[2 * ps] = u32x4q{c[0], c[1], c[2], c[3]};
+        if (dt == 3) o[2 * ps] = u32x4q{c[0], c[1], c[2], c[3]};
     } else {
         *o = q_pack8(v, dt);
     }
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(64) void q_rows_sum_kernel(const float* __restrict_
     if (threadIdx.x == 0) out[c] = (accumulate ? out[c] : 0.f) + s;
 }
 
-inline bool q_dtype_ok(int dt) { return dt == GHM_DTYPE_BF16 || dt == GHM_DTYPE_F16 || dt == 3; }
+inline bool q_dtype_ok(int dt) { return dt == GHM_DTYPE_BF16 || dt == GHM_DTYPE_F16 || dt == 3 || dt == 4; }
 
 }  // namespace
 

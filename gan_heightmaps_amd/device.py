@@ -12,6 +12,11 @@ DTYPE_CODES = {'f32': 0, 'bf16': 1, 'f16': 2}       # GHM_DTYPE_* (include/ghm.h
 # routes the *_lp / *_lp_q calls made with it to the ghm_*_split entry points, and a QTensor of this dtype is three planes
 SPLIT = 'bf16x3'
 DTYPE_CODES[SPLIT] = 3     # understood by the q-epilogue producers (csrc/elementwise_q.hip) only
+# 'bf16x2': the same machinery with TWO pieces per operand and three products (x0 w0 + x1 w0 + x0 w1): 16-bit operands at half
+# the matrix-core time of 'bf16x3' -- BASELINE config 4's arithmetic (plain bf16 operands miss north_star's 1e-3 on the outputs)
+SPLIT2 = 'bf16x2'
+DTYPE_CODES[SPLIT2] = 4
+SPLITS = {SPLIT: 3, SPLIT2: 2}     # split dtypes -> pieces per operand (the ``pieces`` argument of the ghm_*_split entry points)
 
 
 def device_count():
@@ -105,7 +110,7 @@ class QTensor:
     @staticmethod
     def empty(dev, shape, dtype):
         shape = tuple(int(v) for v in shape)
-        planes = 3 if dtype == SPLIT else 1
+        planes = SPLITS.get(dtype, 1)
         return QTensor(dev, dev.alloc(planes * 16 * shape[0] * (shape[1] // 8) * shape[2] * shape[3]), shape, dtype)
 
     def channels(self, c0, c1):
@@ -128,14 +133,14 @@ class QTensor:
     def numpy(self, piece=None):
         """-> float32 [N, C, H, W] (the exact values of the stored halfwords); 'bf16x3': the sum of the three pieces (in
         float64, rounded once: the fp32 value that was split), or one piece"""
-        if self.dtype == SPLIT and piece is None:
-            return sum(self.numpy(p).astype(np.float64) for p in range(3)).astype(np.float32)
+        if self.dtype in SPLITS and piece is None:
+            return sum(self.numpy(p).astype(np.float64) for p in range(SPLITS[self.dtype])).astype(np.float32)
         raw = np.empty((self.N, self.Cc * self.HW), np.uint16)       # a sample's channel blocks are contiguous planes
         for n in range(self.N):
             self.dev.d2h(raw[n], self.ptr + 16 * ((piece or 0) * self.pstride + n * self.nstride), raw[n].nbytes)
         raw = raw.reshape(self.N, self.Cc // 8, self.HW, 8).transpose(0, 1, 3, 2)
         raw = np.ascontiguousarray(raw).reshape(self.shape)
-        if self.dtype in ('bf16', SPLIT):
+        if self.dtype == 'bf16' or self.dtype in SPLITS:
             return (raw.astype(np.uint32) << 16).view(np.float32)
         return raw.view(np.float16).astype(np.float32)
 
@@ -459,7 +464,7 @@ class Ops:
 
     def dgrad_dact_supported(self, d, dtype='f32'):
         """0: not served; 1 / 2 / 3: served, reading the fp32 packed wp / the fp32 wpT / the low-precision wqT"""
-        if dtype == SPLIT:
+        if dtype in SPLITS:
             if _lib.load().ghm_split_dgrad_dact_supported(C.byref(d)):
                 return 3
             dtype = 'f32'
@@ -468,7 +473,7 @@ class Ops:
     def conv2d_dgrad_dact(self, d, dy, w, dx, y, act, alpha, dtype='f32'):
         """dx = conv^T(dy) * act'(y): the data gradient with the producer's activation backward in its epilogue"""
         assert y.shape == dx.shape
-        if dtype == SPLIT:
+        if dtype in SPLITS:
             # a split weight pack has no fp32-operand form of this product: ghm_conv2d_dgrad_dact would read it as an fp32 /
             # low-precision pack.  The split data gradient with the activation backward takes the q copy of dy
             raise ValueError("conv2d_dgrad_dact(dtype='bf16x3'): use conv2d_dgrad_dact_lp_q with the split q tensor of dy")
@@ -485,7 +490,7 @@ class Ops:
 
     # ---- bf16 / fp16 matrix-core convolutions (fp32 tensors in HBM; include/ghm.h GHM_DTYPE_*) ----
     def lp_supported(self, d, kind, dtype):
-        if dtype == SPLIT:
+        if dtype in SPLITS:
             return self.split_supported(d, kind)
         return bool(_lib.load().ghm_lp_supported(C.byref(d), int(kind), DTYPE_CODES[dtype]))
 
@@ -493,50 +498,51 @@ class Ops:
     def split_supported(self, d, kind):
         return bool(_lib.load().ghm_split_supported(C.byref(d), int(kind)))
 
-    def split_weight_bytes(self, d, transposed=False):
+    def split_weight_bytes(self, d, transposed=False, pieces=3):
         n = C.c_size_t()
-        call("ghm_split_weight_bytes", C.byref(d), int(transposed), C.byref(n))
+        call("ghm_split_weight_bytes", C.byref(d), int(transposed), C.byref(n), pieces)
         return n.value
 
-    def split_pack_weights(self, d, wp, wq, transposed=False):
-        call("ghm_split_pack_weights", self.h, C.byref(d), _vp(wp), _vp(wq), int(transposed))
+    def split_pack_weights(self, d, wp, wq, transposed=False, pieces=3):
+        call("ghm_split_pack_weights", self.h, C.byref(d), _vp(wp), _vp(wq), int(transposed), pieces)
 
-    def split_pack(self, x, q_ptr, q_nstride=None, q_pstride=None):
-        """fp32 view -> split q tensor (three planes) at q_ptr; returns (nstride, pstride) in 16-byte units"""
+    def split_pack(self, x, q_ptr, q_nstride=None, q_pstride=None, pieces=3):
+        """fp32 view -> split q tensor (``pieces`` planes) at q_ptr; returns (nstride, pstride) in 16-byte units"""
         ns = (x.Cc // 8) * x.HW if q_nstride is None else q_nstride
         ps = x.N * ns if q_pstride is None else q_pstride
-        call("ghm_split_pack", self.h, _vp(x), x.nstride, x.N, x.Cc, x.HW, C.c_void_p(int(q_ptr)), ns, ps)
+        call("ghm_split_pack", self.h, _vp(x), x.nstride, x.N, x.Cc, x.HW, C.c_void_p(int(q_ptr)), ns, ps, pieces)
         return ns, ps
 
     def split_q_direct(self, d, kind):
         return bool(_lib.load().ghm_split_q_direct(C.byref(d), int(kind)))
 
-    def conv2d_fwd_split(self, d, x, wq, bias, y, act='linear', alpha=0.0, accumulate=False, xq=None, yq=None):
+    def conv2d_fwd_split(self, d, x, wq, bias, y, act='linear', alpha=0.0, accumulate=False, xq=None, yq=None, pieces=3):
         """xq = (ptr, nstride, pstride) of the input already split, or None (the entry point splits x); yq: a whole split
         QTensor (or a channel slice of one) that also receives the result; y may then be None"""
         q = xq or (None, 0, 0)
         assert yq is None or yq.pstride == yq.N * yq.nstride
         call("ghm_conv2d_fwd_split", self.h, C.byref(d), _vp(x), C.c_void_p(int(q[0])) if q[0] else None, q[1], q[2],
              _vp(wq), _vp(bias), _vp(y), C.c_void_p(yq.ptr) if yq is not None else None, yq.nstride if yq is not None else 0,
-             ACT_CODES[act], alpha, int(accumulate))
+             ACT_CODES[act], alpha, int(accumulate), pieces)
 
-    def conv2d_dgrad_split(self, d, dy, wqT, dx, bias=None, act='linear', alpha=0.0, accumulate=False, dyq=None, dxq=None):
+    def conv2d_dgrad_split(self, d, dy, wqT, dx, bias=None, act='linear', alpha=0.0, accumulate=False, dyq=None, dxq=None,
+                           pieces=3):
         q = dyq or (None, 0, 0)
         assert dxq is None or dxq.pstride == dxq.N * dxq.nstride
         call("ghm_conv2d_dgrad_split", self.h, C.byref(d), _vp(dy), C.c_void_p(int(q[0])) if q[0] else None, q[1], q[2],
              _vp(wqT), _vp(bias), _vp(dx), C.c_void_p(dxq.ptr) if dxq is not None else None,
-             dxq.nstride if dxq is not None else 0, ACT_CODES[act], alpha, int(accumulate))
+             dxq.nstride if dxq is not None else 0, ACT_CODES[act], alpha, int(accumulate), pieces)
 
     def lp_weight_bytes(self, d, transposed=False, dtype=None):
-        if dtype == SPLIT:
-            return self.split_weight_bytes(d, transposed)
+        if dtype in SPLITS:
+            return self.split_weight_bytes(d, transposed, SPLITS[dtype])
         n = C.c_size_t()
         call("ghm_lp_weight_bytes", C.byref(d), int(transposed), C.byref(n))
         return n.value
 
     def lp_pack_weights(self, d, wp, wq, dtype, transposed=False):
-        if dtype == SPLIT:
-            return self.split_pack_weights(d, wp, wq, transposed)
+        if dtype in SPLITS:
+            return self.split_pack_weights(d, wp, wq, transposed, SPLITS[dtype])
         call("ghm_lp_pack_weights", self.h, C.byref(d), _vp(wp), _vp(wq), DTYPE_CODES[dtype], int(transposed))
 
     def lp_pack_table(self, items):
@@ -555,19 +561,19 @@ class Ops:
 
     def lp_pack_batched(self, table, dtype):
         ptr, n, blocks = table
-        if dtype == SPLIT:
-            return call("ghm_split_pack_batched", self.h, C.c_void_p(ptr), n, blocks)
+        if dtype in SPLITS:
+            return call("ghm_split_pack_batched", self.h, C.c_void_p(ptr), n, blocks, SPLITS[dtype])
         call("ghm_lp_pack_batched", self.h, C.c_void_p(ptr), n, blocks, DTYPE_CODES[dtype])
 
     def conv2d_fwd_lp(self, d, x, wq, bias, y, dtype, act='linear', alpha=0.0, accumulate=False):
-        if dtype == SPLIT:
-            return self.conv2d_fwd_split(d, x, wq, bias, y, act, alpha, accumulate)
+        if dtype in SPLITS:
+            return self.conv2d_fwd_split(d, x, wq, bias, y, act, alpha, accumulate, pieces=SPLITS[dtype])
         call("ghm_conv2d_fwd_lp", self.h, C.byref(d), _vp(x), _vp(wq), _vp(bias), _vp(y), ACT_CODES[act], alpha,
              int(accumulate), DTYPE_CODES[dtype])
 
     def conv2d_dgrad_lp(self, d, dy, wqT, dx, dtype, bias=None, act='linear', alpha=0.0, accumulate=False):
-        if dtype == SPLIT:
-            return self.conv2d_dgrad_split(d, dy, wqT, dx, bias, act, alpha, accumulate)
+        if dtype in SPLITS:
+            return self.conv2d_dgrad_split(d, dy, wqT, dx, bias, act, alpha, accumulate, pieces=SPLITS[dtype])
         call("ghm_conv2d_dgrad_lp", self.h, C.byref(d), _vp(dy), _vp(wqT), _vp(bias), _vp(dx), ACT_CODES[act], alpha,
              int(accumulate), DTYPE_CODES[dtype])
 
@@ -584,8 +590,8 @@ class Ops:
     # ---- q tensors (include/ghm.h): low-precision products on operands rounded once at their producer ----
     def q_pack(self, x, q):
         assert x.shape == q.shape
-        if q.dtype == SPLIT:
-            return self.split_pack(x, q.ptr, q.nstride, q.pstride)
+        if q.dtype in SPLITS:
+            return self.split_pack(x, q.ptr, q.nstride, q.pstride, SPLITS[q.dtype])
         call("ghm_q_pack", self.h, _vp(x), x.nstride, x.N, x.Cc, x.HW, C.c_void_p(q.ptr), q.nstride, DTYPE_CODES[q.dtype])
 
     def q_unpack(self, q, x):
@@ -593,13 +599,13 @@ class Ops:
         call("ghm_q_unpack", self.h, C.c_void_p(q.ptr), q.nstride, q.N, q.Cc, q.HW, _vp(x), x.nstride, DTYPE_CODES[q.dtype])
 
     def lp_q_direct(self, d, kind, dtype):
-        if dtype == SPLIT:
+        if dtype in SPLITS:
             return self.split_q_direct(d, kind)
         return bool(_lib.load().ghm_lp_q_direct(C.byref(d), int(kind), DTYPE_CODES[dtype]))
 
     def conv_variant_lp(self, d, kind, dtype):
         """kernel family serving low-precision product ``kind`` (0 forward, 1 data gradient, 2 weight gradient)"""
-        if dtype == SPLIT:
+        if dtype in SPLITS:
             w = d.W if kind == 1 and d.stride == 1 else d.Wo          # width of the pixel grid the kernel tiles
             if kind == 1 and d.stride == 2:
                 return "sp_dgrad_s2_kernel"
@@ -610,7 +616,7 @@ class Ops:
         return out.value.decode()
 
     def conv_bn_fused_supported(self, d, dtype):
-        if dtype == SPLIT:
+        if dtype in SPLITS:
             return False
         if dtype == 'f32':
             return bool(_lib.load().ghm_conv_bn_fused_supported_f32(C.byref(d)))
@@ -633,26 +639,27 @@ class Ops:
              eps, run_alpha, ACT_CODES[act], alpha, DTYPE_CODES[dtype])
 
     def conv2d_fwd_lp_q(self, d, xq, wq, bias, y, yq, dtype, act='linear', alpha=0.0, accumulate=False):
-        if dtype == SPLIT:
-            return self.conv2d_fwd_split(d, None, wq, bias, y, act, alpha, accumulate, xq=(xq.ptr, xq.nstride, xq.pstride), yq=yq)
+        if dtype in SPLITS:
+            return self.conv2d_fwd_split(d, None, wq, bias, y, act, alpha, accumulate, xq=(xq.ptr, xq.nstride, xq.pstride), yq=yq,
+                                         pieces=SPLITS[dtype])
         call("ghm_conv2d_fwd_lp_q", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, _vp(wq), _vp(bias), _vp(y),
              C.c_void_p(yq.ptr if yq is not None else 0), yq.nstride if yq is not None else 0, ACT_CODES[act], alpha,
              int(accumulate), DTYPE_CODES[dtype])
 
     def conv2d_dgrad_lp_q(self, d, dyq, wqT, dx, dxq, dtype, bias=None, act='linear', alpha=0.0, accumulate=False):
-        if dtype == SPLIT:
+        if dtype in SPLITS:
             return self.conv2d_dgrad_split(d, None, wqT, dx, bias, act, alpha, accumulate,
-                                           dyq=(dyq.ptr, dyq.nstride, dyq.pstride), dxq=dxq)
+                                           dyq=(dyq.ptr, dyq.nstride, dyq.pstride), dxq=dxq, pieces=SPLITS[dtype])
         call("ghm_conv2d_dgrad_lp_q", self.h, C.byref(d), C.c_void_p(dyq.ptr), dyq.nstride, _vp(wqT), _vp(bias), _vp(dx),
              C.c_void_p(dxq.ptr if dxq is not None else 0), dxq.nstride if dxq is not None else 0, ACT_CODES[act], alpha,
              int(accumulate), DTYPE_CODES[dtype])
 
     def conv2d_dgrad_dact_lp_q(self, d, dyq, wqT, dx, dxq, y, act, alpha, dtype):
-        if dtype == SPLIT:
+        if dtype in SPLITS:
             assert dxq is None or dxq.pstride == dxq.N * dxq.nstride
             return call("ghm_conv2d_dgrad_dact_split", self.h, C.byref(d), C.c_void_p(dyq.ptr), dyq.nstride, dyq.pstride,
                         _vp(wqT), _vp(dx), C.c_void_p(dxq.ptr) if dxq is not None else None,
-                        dxq.nstride if dxq is not None else 0, _vp(y), y.nstride, ACT_CODES[act], alpha)
+                        dxq.nstride if dxq is not None else 0, _vp(y), y.nstride, ACT_CODES[act], alpha, SPLITS[dtype])
         call("ghm_conv2d_dgrad_dact_lp_q", self.h, C.byref(d), C.c_void_p(dyq.ptr), dyq.nstride, _vp(wqT), _vp(dx),
              C.c_void_p(dxq.ptr if dxq is not None else 0), dxq.nstride if dxq is not None else 0, _vp(y), y.nstride,
              ACT_CODES[act], alpha, DTYPE_CODES[dtype])
@@ -661,7 +668,7 @@ class Ops:
     def _whole_planes(q):
         """the q epilogues of the element-wise producers place the piece planes of a split q tensor N x nstride units apart: a
         sample-sliced view (which keeps the allocation's pstride) would have pieces 1 and 2 written over other samples' data"""
-        assert q is None or q.dtype != SPLIT or q.pstride == q.N * q.nstride, \
+        assert q is None or q.dtype not in SPLITS or q.pstride == q.N * q.nstride, \
             "split q tensor: a sample slice cannot be the target of an element-wise q epilogue"
 
     def bn_apply_q(self, x, y, mean, inv, gamma, beta, yq, act='linear', alpha=0.0):
@@ -721,23 +728,24 @@ class Ops:
              ACT_CODES[act], alpha, _vp(dbias), int(accumulate), C.c_void_p(dxq.ptr), dxq.nstride, DTYPE_CODES[dxq.dtype])
 
     def lp_wgrad_q_supported(self, d, dtype):
-        if dtype == SPLIT:
+        if dtype in SPLITS:
             return self.split_supported(d, 2)
         return bool(_lib.load().ghm_lp_wgrad_q_supported(C.byref(d), DTYPE_CODES[dtype]))
 
     def conv2d_wgrad_lp_q(self, d, xq, dyq, dwp, ws, dtype, accumulate=False):
-        if dtype == SPLIT:
+        if dtype in SPLITS:
             return call("ghm_conv2d_wgrad_split", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, xq.pstride,
-                        C.c_void_p(dyq.ptr), dyq.nstride, dyq.pstride, _vp(dwp), _vp(ws), int(accumulate))
+                        C.c_void_p(dyq.ptr), dyq.nstride, dyq.pstride, _vp(dwp), _vp(ws), int(accumulate), SPLITS[dtype])
         call("ghm_conv2d_wgrad_lp_q", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, C.c_void_p(dyq.ptr), dyq.nstride,
              _vp(dwp), _vp(ws), int(accumulate), DTYPE_CODES[dtype])
 
     def conv2d_fwd_pool_lp_q(self, d, xq, wq, bias, pooled, pooledq, mask_ptr, act, alpha, dtype):
-        if dtype == SPLIT:
+        if dtype in SPLITS:
             assert pooledq is None or pooledq.pstride == pooledq.N * pooledq.nstride
             return call("ghm_conv2d_fwd_pool_split", self.h, C.byref(d), None, C.c_void_p(xq.ptr), xq.nstride, xq.pstride,
                         _vp(wq), _vp(bias), _vp(pooled), C.c_void_p(pooledq.ptr) if pooledq is not None else None,
-                        pooledq.nstride if pooledq is not None else 0, C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha)
+                        pooledq.nstride if pooledq is not None else 0, C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha,
+                        SPLITS[dtype])
         call("ghm_conv2d_fwd_pool_lp_q", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, _vp(wq), _vp(bias), _vp(pooled),
              C.c_void_p(pooledq.ptr if pooledq is not None else 0), pooledq.nstride if pooledq is not None else 0,
              C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha, DTYPE_CODES[dtype])
@@ -745,7 +753,7 @@ class Ops:
     # ---- conv + activation + 2x2 max-pool fused (architectures/dcgan.py:42-47) ----
     def conv_pool_supported(self, d, act, dtype='f32'):
         """0: not served; 1: served with the fp32 packed weights; 2: served with the low-precision pack"""
-        if dtype == SPLIT:
+        if dtype in SPLITS:
             if d.C > 4 and _lib.load().ghm_split_pool_supported(C.byref(d), ACT_CODES[act]):
                 return 2
             dtype = 'f32'
@@ -753,9 +761,9 @@ class Ops:
 
     def conv2d_fwd_pool(self, d, x, w, bias, pooled, mask_ptr, act, alpha, dtype='f32'):
         assert pooled.contiguous
-        if dtype == SPLIT:
+        if dtype in SPLITS:
             return call("ghm_conv2d_fwd_pool_split", self.h, C.byref(d), _vp(x), None, 0, 0, _vp(w), _vp(bias), _vp(pooled),
-                        None, 0, C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha)
+                        None, 0, C.c_void_p(int(mask_ptr)), ACT_CODES[act], alpha, SPLITS[dtype])
         call("ghm_conv2d_fwd_pool", self.h, C.byref(d), _vp(x), _vp(w), _vp(bias), _vp(pooled), C.c_void_p(int(mask_ptr)),
              ACT_CODES[act], alpha, DTYPE_CODES[dtype])
 

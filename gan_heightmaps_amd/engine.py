@@ -20,7 +20,7 @@ import numpy as np
 
 from . import layers as L
 from .architectures.layers import BilinearUpsample2DLayer
-from .device import SPLIT, DevTensor, Ops, QTensor, conv_desc, pack_conv_w, unpack_conv_w
+from .device import SPLIT, SPLITS, DevTensor, Ops, QTensor, conv_desc, pack_conv_w, unpack_conv_w
 from .nonlinearities import linear
 
 ALIGN = 64      # elements; keeps every parameter 256-B aligned inside the flat buffers
@@ -295,7 +295,7 @@ class NetPlan:
         self.side = side
         # arithmetic of the convolution products: 'f32' (the reference's floatX) or 'bf16' / 'f16' on the matrix cores
         # for every geometry the low-precision kernels serve; tensors in HBM are fp32 either way (include/ghm.h)
-        assert dtype in ('f32', 'bf16', 'f16', SPLIT)
+        assert dtype in ('f32', 'bf16', 'f16') or dtype in SPLITS, dtype
         self.dtype = dtype
         # bn_groups=2: the batch is [real | fake] (two get_output calls of the reference, pix2pix.py:94-95,98-101):
         # every BatchNormLayer normalises each half with its own statistics
@@ -1129,7 +1129,7 @@ class NetPlan:
                         xa = xin.act
                         xin.aux[('grad_is_pre', key)] = True
                         Gq = gradq_of(n, G) if form == 3 else None
-                        if Gq is not None and (ops.lp_q_direct(d2, 1, self.dtype) or self.dtype == SPLIT):
+                        if Gq is not None and (ops.lp_q_direct(d2, 1, self.dtype) or self.dtype in SPLITS):
                             giq = fused_gq(xin, gi, acc) if ops.lp_q_direct(d2, 1, self.dtype) else None
                             prog.append(("conv_dgrad", lambda d=d2, Gq=Gq, wsel=wsel, gi=gi, giq=giq, x=x, xa=xa:
                                          ops.conv2d_dgrad_dact_lp_q(d, Gq, wsel, gi, giq, x, xa.kind, xa.alpha, self.dtype),
@@ -1382,7 +1382,7 @@ class NetPlan:
 def conv_meta(ops, d, kind, dtype='f32', pooled=False):
     """roofline metadata of one conv launch: kernel variant name and ALGORITHMIC flops (2 x MACs)."""
     if pooled:
-        name = ("sp_conv_kernel<%d, %d> fwd+pool" % (d.kh, d.stride)) if dtype == SPLIT else \
+        name = ("sp_conv_kernel<%d, %d> fwd+pool" % (d.kh, d.stride)) if dtype in SPLITS else \
             ("lp_conv_kernel<%s, %d, %d>" % (dtype, d.kh, d.stride)) if dtype != 'f32' else \
             ("fanout_kernel<fwd+pool>" if d.C <= 4 else ops.conv_variant(d, 0).split(" splits")[0])   # same kernel, pooled epilogue
     elif dtype != 'f32':

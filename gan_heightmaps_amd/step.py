@@ -95,6 +95,10 @@ class GanStep:
                 t = d.tensor(np.array([self.init_loss_scale, 1.0 / self.init_loss_scale, 0, 0, 0, 0, 0, 0], np.float32))
                 d.set_loss_scale_state(t)
                 self._ls_state.append((d, t))
+        elif hasattr(dev, 'set_loss_scale_state'):
+            # a caller-owned context may still carry the state of an earlier fp16 engine built on it: its loss kernels would
+            # scale this engine's seeds by 2^15 (found by running a bf16x2 model after an fp16 one on one Device)
+            dev.set_loss_scale_state(None)
         # optional GRADIENT stream for the weight / bias gradients of both stages (engine.NetPlan side=).  ONE stream for
         # the two stages, not one each: three MFMA-heavy kernels at a time (stage A, stage B, one weight gradient) is what
         # the chip runs best -- with a gradient stream per stage the two weight-gradient kernels share CUs with each other
@@ -261,7 +265,7 @@ class GanStep:
         # DPU 169.4 / 492.3 / 153.0 / 98.9, PU 169.3 / 498.8 / 150.5 / 97.2, GDPU 167.7 / 471.9 / 150.4 / 97.2,
         # none 164.5 / 467.1, GD 164.0).  GHM_SIDE_NETS overrides (tuning).
         # (reduced precision: +1 % with D inline too; the split-fp32 mode, whose kernels are as long as the fp32 ones: 253 -> 261 img/s with D on the side)
-        _sn = os.environ.get('GHM_SIDE_NETS', 'DPU' if self.dtype in ('f32', 'bf16x3') else 'PU')
+        _sn = os.environ.get('GHM_SIDE_NETS', 'DPU' if self.dtype in ('f32', 'bf16x3', 'bf16x2') else 'PU')
         _side = lambda k, lane: self.side[lane] if k in _sn else None
         b.G = NetPlan(dA, oA, G, B, self.stores['dcgan_gen'], out_tensor=b.d_in.samples(B, 2 * B), name="G",
                       side=_side('G', 0), rng_seed=self.rank, dtype=self.dtype,       # replicas draw different dropout masks

@@ -67,3 +67,38 @@ def split_product_terms():
     """the (operand-A piece, operand-B piece) pairs the kernels multiply: i + j <= 2; the three they drop are each below
     2^-24 |a b| (piece i is at most 2^-8i of the value, up to rounding)"""
     return [(i, j) for i in range(3) for j in range(3) if i + j <= 2]
+
+
+def split_bf16x2(a):
+    """float32 -> TWO bfloat16 pieces (as float32 arrays): p0 = bf16(a), p1 = bf16(a - p0), both round-to-nearest-even -- the
+    operand form of the 'bf16x2' mode (csrc/conv_split.hip with pieces = 2; BASELINE config 4's arithmetic).  p0 + p1 carries
+    16-17 significant bits: |a - p0 - p1| <= 2^-17 |a|."""
+    a = np.ascontiguousarray(a, np.float32)
+    p0 = round_bf16(a)
+    p1 = round_bf16((a - p0).astype(np.float32))
+    return p0, p1
+
+
+def split2_product_terms():
+    """the (operand-A piece, operand-B piece) pairs of the 'bf16x2' kernels: i + j <= 1 -- x0 w0 + x1 w0 + x0 w1; the dropped
+    x1 w1 is 2^-16 of the product, the same order as the operands' own truncation"""
+    return [(0, 0), (1, 0), (0, 1)]
+
+
+def conv2d_fwd_x2(x, W, b, stride, pad):
+    """what the 'bf16x2' forward kernel computes, in float64: the three piece products of the two-piece operands"""
+    px, pw = split_bf16x2(x), split_bf16x2(W)
+    out = 0.0
+    for i, j in split2_product_terms():
+        out = out + ops.conv2d_fwd(px[i].astype(np.float64), pw[j].astype(np.float64), np.zeros(W.shape[0]), stride, pad)
+    return out + np.asarray(b, np.float64)[None, :, None, None]
+
+
+def conv2d_vjp_x2(x, W, dy, stride, pad):
+    """-> (dx, dW) of the 'bf16x2' data- and weight-gradient kernels: the same three piece products of (dy, W) and (x, dy)"""
+    px, pw, pd = split_bf16x2(x), split_bf16x2(W), split_bf16x2(dy)
+    dx = dW = 0.0
+    for i, j in split2_product_terms():
+        dx = dx + ops.conv2d_vjp(px[0].astype(np.float64), pw[j].astype(np.float64), pd[i].astype(np.float64), stride, pad)[0]
+        dW = dW + ops.conv2d_vjp(px[i].astype(np.float64), pw[0].astype(np.float64), pd[j].astype(np.float64), stride, pad)[1]
+    return dx, dW

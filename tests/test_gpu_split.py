@@ -393,3 +393,68 @@ def test_split_train_step_meets_the_fp32_bounds(gpu):
     print("split step: worst rel-L2 -- losses %.2e (fp32 MFMA %.2e), gradients %.2e (fp32 MFMA %.2e); kernels %s"
           % (worst['loss'], worst['loss32'], worst['grad'], worst['grad32'], sorted(kinds)))
     assert worst['loss'] < 1e-5 and worst['grad'] < 1e-3 and worst['grad'] < 1.5 * worst['grad32'] + 1e-4, worst
+
+
+# ---- two pieces, three products ('bf16x2': BASELINE config 4's arithmetic; include/ghm.h ``pieces`` = 2) -----------------------
+X2_CASES = [(2, 32, 32, 32, 64, 5, 1, 2), (2, 48, 32, 32, 160, 3, 1, 1), (2, 64, 64, 64, 128, 3, 2, 1), (2, 64, 16, 16, 128, 3, 1, 1),
+            (4, 48, 8, 8, 64, 5, 1, 2), (4, 512, 16, 16, 512, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("case", X2_CASES)
+def test_two_piece_products_are_exact_given_the_pieces(gpu, case):
+    """the 'bf16x2' kernels (forward, data gradient incl. stride 2, weight gradient) compute the three products x0 w0 + x1 w0 +
+    x0 w1 of the two-piece operands exactly (fp32 accumulation: <= 4e-7 against oracle/lp.py's float64 statement of the same
+    products) and sit <= 2e-5 from the unrounded float64 convolution -- plain bf16 operands: 4e-3"""
+    from oracle import lp as LP
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(sum(case) + 11)
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    x = (rng.randn(N, C, H, W) * np.exp(rng.randn(N, C, 1, 1))).astype(np.float32)
+    dy = (rng.randn(N, K, d.Ho, d.Wo) * np.exp(rng.randn(N, K, 1, 1))).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    xd, dyd, bd = dev.tensor(x), dev.tensor(dy), dev.tensor(b)
+    wp = dev.tensor(D.pack_conv_w(Wt).ravel())
+    xq, dyq = D.QTensor.empty(dev, x.shape, 'bf16x2'), D.QTensor.empty(dev, dy.shape, 'bf16x2')
+    ops.q_pack(xd, xq)
+    ops.q_pack(dyd, dyq)
+    for got, want in zip((xq.numpy(0), xq.numpy(1)), LP.split_bf16x2(x)):       # the pieces are the oracle's, bit for bit
+        assert np.array_equal(got, want)
+    # forward (fp32 operand split by the entry point, and the pre-split q tensor), with the q copy of the result
+    assert ops.split_supported(d, 0)
+    wq = dev.alloc(ops.split_weight_bytes(d, False, 2))
+    ops.split_pack_weights(d, wp, wq, False, 2)
+    ref_x2 = LP.conv2d_fwd_x2(x, Wt, b, s, pad)
+    exact = O.conv2d_fwd(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), s, pad)
+    y = dev.empty((N, K, d.Ho, d.Wo))
+    ops.conv2d_fwd_split(d, xd, wq, bd, y, pieces=2)
+    assert rel(y.numpy(), ref_x2) < 4e-7 and rel(y.numpy(), exact) < 2e-5, (rel(y.numpy(), ref_x2), rel(y.numpy(), exact))
+    y2 = dev.empty((N, K, d.Ho, d.Wo))
+    yq = D.QTensor.empty(dev, y2.shape, 'bf16x2') if ops.lp_q_direct(d, 0, 'bf16x2') else None
+    ops.conv2d_fwd_lp_q(d, xq, wq, bd, y2, yq, 'bf16x2')
+    assert np.array_equal(y2.numpy(), y.numpy())
+    if yq is not None:
+        for got, want in zip((yq.numpy(0), yq.numpy(1)), LP.split_bf16x2(y2.numpy())):
+            assert np.array_equal(got, want)
+    # data gradient
+    if ops.split_supported(d, 1):
+        wqT = dev.alloc(ops.split_weight_bytes(d, True, 2))
+        ops.split_pack_weights(d, wp, wqT, True, 2)
+        dx = dev.empty((N, C, H, W))
+        ops.conv2d_dgrad_lp_q(d, dyq, wqT, dx, None, 'bf16x2')
+        dx_x2, dW_x2 = LP.conv2d_vjp_x2(x, Wt, dy, s, pad)
+        dx_exact = O.conv2d_vjp(np.zeros((N, C, H, W)), Wt.astype(np.float64), dy.astype(np.float64), s, pad)[0]
+        assert rel(dx.numpy(), dx_x2) < 4e-7 and rel(dx.numpy(), dx_exact) < 2e-5, (rel(dx.numpy(), dx_x2), rel(dx.numpy(), dx_exact))
+        dev.free(wqT)
+    # weight gradient
+    if ops.split_supported(d, 2):
+        ws = dev.alloc(max(ops.wgrad_lp_workspace(d), 16))
+        dw = dev.zeros((1, C * k * k * K, 1, 1))
+        ops.conv2d_wgrad_lp_q(d, xq, dyq, dw, ws, 'bf16x2')
+        got = D.unpack_conv_w(dw.numpy().ravel(), K, C, k, k)
+        dW_x2 = LP.conv2d_vjp_x2(x, Wt, dy, s, pad)[1]
+        dW_exact = O.conv2d_vjp(x.astype(np.float64), np.zeros((K, C, k, k)), dy.astype(np.float64), s, pad)[1]
+        assert rel(got, dW_x2) < 6e-7 and rel(got, dW_exact) < 2e-5, (rel(got, dW_x2), rel(got, dW_exact))
+        dev.free(ws)
+    dev.free(wq)

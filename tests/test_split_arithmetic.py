@@ -47,3 +47,22 @@ def test_six_products_are_the_product_to_fp32_accuracy():
     # and the bf16-rounded product the reduced-precision modes compute is 2^13 times further away
     lp_err = np.abs(LP.round_bf16(a).astype(np.float64) * LP.round_bf16(b).astype(np.float64) - exact) / np.abs(exact)
     assert np.median(lp_err) > 1000 * np.median(err[err > 0])
+
+
+def test_two_piece_operands_and_three_products():
+    """'bf16x2' (BASELINE config 4's arithmetic): two pieces carry >= 16 significant bits, the three kept products reproduce
+    a dot product to ~2^-16 per term -- three orders of magnitude below plain bf16 operands (2^-9)"""
+    rng = np.random.RandomState(3)
+    a = (rng.randn(4096) * np.exp2(rng.randint(-30, 30, 4096))).astype(np.float32)
+    p0, p1 = LP.split_bf16x2(a)
+    assert np.array_equal(p0, LP.round_bf16(a))
+    assert np.all(np.abs((a.astype(np.float64) - p0 - p1)) <= np.abs(a) * 2.0 ** -16)
+    x, w = rng.randn(64, 512).astype(np.float32), rng.randn(512, 32).astype(np.float32)
+    px, pw = LP.split_bf16x2(x), LP.split_bf16x2(w)
+    exact = x.astype(np.float64) @ w.astype(np.float64)
+    got = sum(px[i].astype(np.float64) @ pw[j].astype(np.float64) for i, j in LP.split2_product_terms())
+    one = LP.round_bf16(x).astype(np.float64) @ LP.round_bf16(w).astype(np.float64)
+    e2 = np.linalg.norm(got - exact) / np.linalg.norm(exact)
+    e1 = np.linalg.norm(one - exact) / np.linalg.norm(exact)
+    assert e2 < 1.5e-5 and e1 > 100 * e2, (e2, e1)
+    assert len(LP.split2_product_terms()) == 3

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--q", default="", choices=["", "f32", "q", "both"],
                     help="low-precision kinds through the *_q entry points: operands are pre-packed q tensors, the "
                          "result is written as fp32, as a q tensor, or both")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16", "split"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16", "split", "split2"],
                     help="bf16 / f16: the *_lp entry points (kinds fwd, dgrad_t, wgrad); split: fp32 on the bf16 matrix "
                          "cores by operand splitting (kinds fwd, dgrad_t, pack_x; --q q: operands already split)")
     args = ap.parse_args()
@@ -51,26 +51,28 @@ def main():
            "dgrad_t": lambda: ops.conv2d_dgrad_t(d, y, wT, dx),
            "dgrad": lambda: ops.conv2d_dgrad(d, y, w, dx),
            "wgrad": lambda: ops.conv2d_wgrad(d, x, y, dw, ws)}
-    if args.dtype == "split":
-        wq = dev.alloc(ops.split_weight_bytes(d, False))
-        wqT = dev.alloc(ops.split_weight_bytes(d, True))
-        ops.split_pack_weights(d, w, wq, False)
-        ops.split_pack_weights(d, w, wqT, True)
+    if args.dtype in ("split", "split2"):
+        npc = 3 if args.dtype == "split" else 2
+        qdt = "bf16x3" if npc == 3 else "bf16x2"
+        wq = dev.alloc(ops.split_weight_bytes(d, False, npc))
+        wqT = dev.alloc(ops.split_weight_bytes(d, True, npc))
+        ops.split_pack_weights(d, w, wq, False, npc)
+        ops.split_pack_weights(d, w, wqT, True, npc)
         xs = dev.alloc(3 * N * C * H * W * 2)
         ys = dev.alloc(3 * N * K * d.Ho * d.Wo * 2)
-        xq = (xs,) + ops.split_pack(x, xs)
-        yq = (ys,) + ops.split_pack(y, ys)
+        xq = (xs,) + ops.split_pack(x, xs, pieces=npc)
+        yq = (ys,) + ops.split_pack(y, ys, pieces=npc)
         pre = args.q == "q"
-        fns = {"pack_x": lambda: ops.split_pack(x, xs), "pack": lambda: ops.split_pack_weights(d, w, wq, False)}
+        fns = {"pack_x": lambda: ops.split_pack(x, xs, pieces=npc), "pack": lambda: ops.split_pack_weights(d, w, wq, False, npc)}
         if ops.split_supported(d, 0):
-            fns["fwd"] = lambda: ops.conv2d_fwd_split(d, x, wq, b, y, 'lrelu', 0.2, xq=xq if pre else None)
+            fns["fwd"] = lambda: ops.conv2d_fwd_split(d, x, wq, b, y, 'lrelu', 0.2, xq=xq if pre else None, pieces=npc)
         if ops.split_supported(d, 1):
-            fns["dgrad_t"] = lambda: ops.conv2d_dgrad_split(d, y, wqT, dx, dyq=yq if pre else None)
+            fns["dgrad_t"] = lambda: ops.conv2d_dgrad_split(d, y, wqT, dx, dyq=yq if pre else None, pieces=npc)
         if ops.split_supported(d, 2):
-            xQ = D.QTensor(dev, xs, x.shape, 'bf16x3')
-            yQ = D.QTensor(dev, ys, y.shape, 'bf16x3')
+            xQ = D.QTensor(dev, xs, x.shape, qdt)
+            yQ = D.QTensor(dev, ys, y.shape, qdt)
             ws_sp = dev.alloc(max(ops.wgrad_lp_workspace(d), 16))
-            fns["wgrad"] = lambda: ops.conv2d_wgrad_lp_q(d, xQ, yQ, dw, ws_sp, 'bf16x3')
+            fns["wgrad"] = lambda: ops.conv2d_wgrad_lp_q(d, xQ, yQ, dw, ws_sp, qdt)
     elif args.dtype != "f32":
         dt = args.dtype
         wq = dev.alloc(ops.lp_weight_bytes(d, False))
