@@ -34,6 +34,7 @@ struct ghm_step {
     ghm_graph* graph[8] = {};
     bool recorded = false, recording = false;
     std::vector<std::function<void()>> cmds;
+    std::vector<hipEvent_t> events;   // the cross-stream ordering events of the recorded waits: created once, re-recorded per replay
     long runs = 0;              // completed replays
     int timer_stride = 0;       // recorded timer slots advance by this much per replay (0: reuse the slots)
     hipError_t err = hipSuccess;

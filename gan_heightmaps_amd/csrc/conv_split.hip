@@ -362,6 +362,10 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
     constexpr int RPF = G::RPF, ROWS = G::ROWS;
     constexpr int TM = BM / (WM * 32), TN = RT / WN;
     constexpr int PH = G::PH, PW = G::PW, PU1 = G::PU1, PCH = G::PCH, PUP = G::PUP;
+    // stride 2: a patch row is staged de-interleaved -- its even columns first, then its odd ones -- so that the 32 pixel lanes
+    // of a fragment (image columns 2 lx + b) read CONSECUTIVE units of one parity plane: with the row as it lies in HBM the lanes
+    // are 32 bytes apart and every ds_read_b128 is a two-way bank conflict
+    constexpr int PWE = (PW + 1) / 2;
     constexpr int WU1 = G::WU1, NI = G::NI, NW = G::NW, NQ = G::NQ, NIW = G::NIW;
     constexpr int WUNITS = G::WUNITS, PUNITS = G::PUNITS, SCR = G::SCR;
     constexpr int NMF = PR::N * TM * TN;             // MFMAs per k-step
@@ -439,7 +443,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
             preal[q] = c < PCH;
             const int e = c * 64 + lane;
             const int cb = e / (PH * PW), rem = e - cb * (PH * PW);
-            const int py = rem / PW, px = rem - py * PW;
+            const int py = rem / PW, pxs = rem - py * PW;
+            const int px = ST == 2 ? (pxs < PWE ? 2 * pxs : 2 * (pxs - PWE) + 1) : pxs;      // LDS slot -> patch column
             const int y = y0 * ST + py - a.pad, x = x0 * ST + px - a.pad;
             const bool ok = e < PU1 && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
             pp[q] = ok ? (const char*)(ibase + (long)cb * HWin + y * a.Win + x) : (const char*)a.zeros;
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
         u32x4 a[NP][TM], b[NP][TN];
     };
     const int wlane = kg * KS * BM + wm * (BM / WM) + li;
-    const int plane = kg * PH * PW + ((wn * TN * RPF + ly) * ST) * PW + lx * ST;
+    const int plane = kg * PH * PW + ((wn * TN * RPF + ly) * ST) * PW + (ST == 2 ? lx : lx * ST);
     // fragments of (filter row fa, column b): weights from the buffer at Wb, patch from the buffer at Pb; in the order of
     // their first use (the products run small terms first -- NP = 3: a2 b0, a1 b1, a0 b2, a1 b0, a0 b1, a0 b0)
     auto rd = [&](Frag& f, const u32x4* Wb, const u32x4* Pb, int fa, int b) {
@@ -489,7 +494,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
 #pragma unroll
             for (int i = 0; i < TM; ++i) f.a[NP - 1 - p][i] = Wb[(NP - 1 - p) * WU1 + b * BM + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) f.b[p][j] = Pb[p * PUP + fa * PW + j * RPF * ST * PW + b];
+            for (int j = 0; j < TN; ++j)
+                f.b[p][j] = Pb[p * PUP + fa * PW + j * RPF * ST * PW + (ST == 2 ? (b & 1) * PWE + (b >> 1) : b)];
         }
     };
     auto mm = [&](const Frag& f) {

@@ -346,17 +346,33 @@ int ghm_sync(ghm_ctx* ctx) {
 int ghm_stream_wait(ghm_ctx* ctx, ghm_ctx* other) {
     // everything enqueued on ``ctx`` after this call runs after everything enqueued on ``other`` so far
     GHM_CHECK(ctx->device == other->device, "ghm_stream_wait across devices");
+    // TUNING ONLY (results are wrong: the streams race): no cross-stream ordering at all -- what the event machinery itself
+    // costs in the overlapped schedule
+    if (GHM_OPT("GHM_SKIP_STREAM_WAITS")) return 0;
     // an edge into or out of a communication stream orders memory that peer GPUs touch: system-scope release
     const bool sys_edge = ctx->comm != nullptr || other->comm != nullptr;
     if (ctx->rec) {
         ghm_step* st = ctx->rec;
         hipStream_t mine = ctx->stream, theirs = other->stream;
+        if (GHM_OPT("GHM_REC_EVENT_PER_REPLAY")) {          // the round 1-4 form (A/B): an event created and destroyed per replay
+            st->cmds.emplace_back([=]() {
+                hipEvent_t ev;
+                hipError_t e = hipEventCreateWithFlags(&ev, ghm_event_flags(sys_edge));
+                if (e == hipSuccess) e = hipEventRecord(ev, theirs);
+                if (e == hipSuccess) e = hipStreamWaitEvent(mine, ev, 0);
+                if (e == hipSuccess) e = hipEventDestroy(ev);
+                if (e != hipSuccess && st->err == hipSuccess) st->err = e;
+            });
+            return 0;
+        }
+        // one event per recorded wait, owned by the step: a replay re-records it (a wait holds the record it was given, so the
+        // next replay's record does not disturb a wait still pending) -- two runtime calls per edge instead of four
+        hipEvent_t ev;
+        GHM_HIP(hipEventCreateWithFlags(&ev, ghm_event_flags(sys_edge)));
+        st->events.push_back(ev);
         st->cmds.emplace_back([=]() {
-            hipEvent_t ev;
-            hipError_t e = hipEventCreateWithFlags(&ev, ghm_event_flags(sys_edge));
-            if (e == hipSuccess) e = hipEventRecord(ev, theirs);
+            hipError_t e = hipEventRecord(ev, theirs);
             if (e == hipSuccess) e = hipStreamWaitEvent(mine, ev, 0);
-            if (e == hipSuccess) e = hipEventDestroy(ev);
             if (e != hipSuccess && st->err == hipSuccess) st->err = e;
         });
         return 0;
@@ -488,6 +504,8 @@ int ghm_step_destroy(ghm_step* s) {
     if (s && s->recording) ghm_step_record_end(s);
     if (s && s->recorded)
         for (int i = 0; i < s->n; ++i) ghm_unpin(s->ctx[i]);
+    if (s)
+        for (hipEvent_t ev : s->events) (void)hipEventDestroy(ev);
     delete s;          // graphs stay owned by their creator (ghm_graph_destroy)
     return 0;
 }

@@ -33,3 +33,12 @@ t2 = time.perf_counter()
 seq = eng._sequence(b, 'train')
 print("%s: %d program entries per step; host issue %.3f ms/step, GPU step %.3f ms (issue / step = %.2f)"
       % (dtype, len(seq), 1e3 * (t1 - t0) / n, 1e3 * (t2 - t0) / n, (t1 - t0) / (t2 - t0)))
+# the same with empty queues: one step issued, then drained, five times -- the host's own cost of a replay
+ts = []
+for _ in range(5):
+    eng.sync()
+    t0 = time.perf_counter()
+    eng.enqueue_train(b)
+    ts.append(time.perf_counter() - t0)
+    eng.sync()
+print("%s: host issue of ONE step into empty queues: %s ms" % (dtype, " ".join("%.2f" % (1e3 * t) for t in ts)))
