@@ -143,6 +143,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true",
                     help="headline only: skip the short extra loops of BASELINE configs 1-5 (\"secondary\" key)")
     ap.add_argument("--secondary-steps", type=int, default=12)
+    ap.add_argument("--minimal", action="store_true",
+                    help="timed region only: no steady-state loop, no host-array loops (counter-collection runs, where every "
+                         "dispatch is serialised and a step takes seconds)")
     return ap.parse_args(argv)
 
 
@@ -347,7 +350,7 @@ def measure(args, secondary_name=None):
     # ---- steady state: the split kernels' rate is data- and clock-dependent (the bf16 matrix pipes are power-managed, DESIGN
     # section 4d): 60 more steps behind the timed region, reported beside ``value`` (never instead of it) ----
     steady = None
-    if args.dtype == "bf16x3" and issue is not False and not args.ablate and world == 1 and not secondary_name:
+    if args.dtype == "bf16x3" and issue is not False and not args.ablate and world == 1 and not secondary_name and not args.minimal:
         eng.sync()
         t1 = time.perf_counter()
         for s in range(60):
@@ -357,7 +360,7 @@ def measure(args, secondary_name=None):
     # ---- the same loop with the reference's host-array boundary (pix2pix.py:142: train_fn(Z, X, Y) takes numpy
     # arrays): every step uploads its 16 KB + 4 MB + 12 MB batch over PCIe before it is enqueued ----
     with_h2d = with_h2d_sync = None
-    if not args.ablate and world == 1:
+    if not args.ablate and world == 1 and not args.minimal:
         run = (lambda: eng.enqueue_train(b)) if issue is not False else (lambda: eng.enqueue_train(b, lambda lane, e: e[1]()))
         eng.sync()
         t1 = time.perf_counter()
@@ -476,9 +479,11 @@ def measure(args, secondary_name=None):
                     # "sp_conv_kernel<3, 1" -> "sp_conv" + "<3, 1,": the round-5 kernel is sp_conv2_kernel
                     fam = dominant.split("<")[1].split(">")[0] + ","
                     stem = dominant.split("_kernel")[0]
+                    import re
+                    # wide-tile instantiations only (32-column pixel tiles / 32- and 64-pixel strips), whatever trails them
+                    wide = re.compile(r"(, (true|false), 32(, \d+, \d+)?|, (32|64)(, \d+)?)>$")
                     rows = [v for k, v in json.load(open(pmc)).items()
-                            if k.startswith(stem) and ("<" + fam) in k and k.rstrip(">").endswith((", 32", ", 64", ", 0", ", true", ", false"))
-                            and v.get("hbm_bytes_per_launch")]
+                            if k.startswith(stem) and ("<" + fam) in k and wide.search(k) and v.get("hbm_bytes_per_launch")]
                     n = sum(v["launches_sampled"] for v in rows)
                     if n:
                         traffic = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in rows) / n

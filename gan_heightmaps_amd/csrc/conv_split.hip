@@ -1141,7 +1141,7 @@ template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL, int TW>
 int sp_launch_variant(ghm_ctx* ctx, dim3 g, size_t lds, const SpConvArgs& a, int np) {
     static_assert(SpGeo2<KS, ST, BM, RT, WM, WN, TW, 3>::LDS_BYTES <= 160 * 1024, "LDS");
 #ifdef GHM_SPLIT_ABLATION
-    if constexpr (KS == 5 && BM == 64 && RT == 8 && !POOL && TW == 32) {
+    if constexpr ((KS == 5 || (KS == 3 && ST == 1)) && BM == 64 && RT == 8 && !POOL && TW == 32) {
         const char* f = GHM_OPT("GHM_SPLIT_ABLATE");
         const int abl = f ? atoi(f) : 0;
 #define GHM_ABL_CASE(A_)                                                                                              \
@@ -1151,7 +1151,7 @@ int sp_launch_variant(ghm_ctx* ctx, dim3 g, size_t lds, const SpConvArgs& a, int
             GHM_LAUNCH_CHECK();                                                                                       \
             return 0;                                                                                                 \
         }
-        GHM_ABL_CASE(1) GHM_ABL_CASE(4) GHM_ABL_CASE(5) GHM_ABL_CASE(7) GHM_ABL_CASE(8) GHM_ABL_CASE(16)
+        GHM_ABL_CASE(1) GHM_ABL_CASE(2) GHM_ABL_CASE(4) GHM_ABL_CASE(7)
 #undef GHM_ABL_CASE
     }
 #endif

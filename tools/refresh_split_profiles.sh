@@ -1,4 +1,4 @@
-R=r04; O=gpurun_out/refresh; mkdir -p $O; export TMPDIR=/tmp
+R=${1:-r05}; O=gpurun_out/refresh; mkdir -p $O; export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 5 > $O/${R}_bench.json 2> $O/${R}_bench.err
 python bench.py --steps 30 --warmup 5 --dtype bf16x3 --no-cpu-baseline --no-secondary > $O/${R}_bench_bf16x3.json 2>> $O/${R}_bench.err
 GHM_PROFILE_ALL=1 python bench.py --steps 5 --profile --no-cpu-baseline --no-secondary --dtype bf16x3 > /dev/null 2> $O/${R}_kernel_table_bf16x3.txt

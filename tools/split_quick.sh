@@ -5,4 +5,5 @@ for g in "8 128 128 128 128 5 1 2" "8 64 256 256 64 5 1 2" "4 256 128 128 128 3 
   python tools/conv_bench.py $g --kinds fwd,dgrad_t,wgrad --reps 30 | tr '\n' '|'; echo
   python tools/conv_bench.py $g --kinds fwd,dgrad_t,pack_x --reps 30 --dtype split | tr '\n' '|'; echo
   python tools/conv_bench.py $g --kinds fwd,dgrad_t,wgrad --reps 30 --dtype split --q q | tr '\n' '|'; echo
+  python tools/conv_bench.py $g --kinds fwd,dgrad_t,wgrad --reps 30 --dtype split2 --q q | tr '\n' '|'; echo      # two pieces, three products (bf16x2)
 done
