@@ -820,6 +820,77 @@ struct SpDgradS2Extra {
     float dact_alpha;
 };
 
+// epilogue of the stride-2 data-gradient kernels: the four parity classes of a lane's class pixel interleaved into dx
+// (fp32 and / or the split q copy; bias, activation, the producer's activation backward; or split-K partials)
+template <int BM, int WM, int WN, int TM, int TN, int NP>
+__device__ __forceinline__ void sp_dgrad_s2_epilogue(const SpConvArgs& a, const SpDgradS2Extra& x, f32x16 (&acc)[4][TM][TN],
+                                                     f32x16 (&accc)[4][TM][TN], u32x4* sp_smem, int tid, int wm, int wn, int kg,
+                                                     int li, int n, int r0, int i0, int j0, int HWx) {
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[cl][i][j][e] += accc[cl][i][j][e];
+
+    // ---- epilogue: lane = class pixel (row i0 + wn*TN + j, column j0 + li); its two column parities are adjacent:
+    // one 8-byte store per (row parity, channel) ----
+    const long P = (long)a.N * HWx;
+    const int ru = r0 + wm * (BM / WM), rl = ru + 4 * kg;
+    float* const sb = reinterpret_cast<float*>(sp_smem);
+    if (tid < BM) sb[tid] = (a.bias && !a.partial && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
+    __syncthreads();
+    const float* const lb = sb + wm * (BM / WM) + 4 * kg;
+    const long rstride = a.partial ? P : (long)HWx;
+    const unsigned lo = 4u * kg * (unsigned)rstride + 2u * li;
+    const bool plain = a.partial != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const long rowpix = (long)(2 * (i0 + wn * TN + j)) * a.W + 2 * j0;
+        float* const ub = a.partial ? a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HWx + rowpix
+                                    : (a.out ? a.out + (long)n * a.out_nstride + (long)ru * HWx + rowpix : nullptr);
+        const float* const yb = x.dact_y ? x.dact_y + (long)n * x.dact_nstride + (long)ru * HWx + rowpix : nullptr;
+        // q output: unit (channel block ru/8 + 4i + g, pixel (2*(i0+..)+pu, 2*(j0+li) + {0, 1})), half kg
+        uint2* const qrow = (a.out_q && !a.partial) ? a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(ru / 8) * HWx + rowpix + 2 * li) + kg
+                                                     : nullptr;
+        const long ps2 = 2 * (long)a.N * a.out_q_nstride;
+        float2 qv[4];
+#pragma unroll
+        for (int pu = 0; pu < 2; ++pu)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    if (rl + k >= a.R) continue;
+                    float2 v = make_float2(acc[pu * 2 + 0][i][j][e], acc[pu * 2 + 1][i][j][e]);
+                    float2* o = ub ? reinterpret_cast<float2*>(ub + (long)k * rstride + pu * a.W + lo) : nullptr;
+                    if (!plain) {
+                        v.x += lb[k]; v.y += lb[k];
+                        if (a.accumulate) { const float2 old = *o; v.x += old.x; v.y += old.y; }      // (fp32 output present)
+                        v.x = ghm_act(v.x, a.act, a.alpha);
+                        v.y = ghm_act(v.y, a.act, a.alpha);
+                        if (yb) {                       // relu / leaky relu: the slope of the producer
+                            const float2 yy = *reinterpret_cast<const float2*>(yb + (long)k * HWx + pu * a.W + lo);
+                            v.x *= yy.x > 0.f ? 1.f : x.dact_alpha;
+                            v.y *= yy.y > 0.f ? 1.f : x.dact_alpha;
+                        }
+                    }
+                    if (ub) *o = v;
+                    if (qrow) {           // four consecutive channels (e = 4g .. 4g+3) of the lane's two pixels
+                        qv[e & 3] = v;
+                        if ((e & 3) == 3) {
+                            uint2* qo = qrow + 2 * ((long)(i * 4 + (e >> 2)) * HWx + pu * a.W);
+                            sp_qstore4<NP>(qo, qv[0].x, qv[1].x, qv[2].x, qv[3].x, ps2);
+                            sp_qstore4<NP>(qo + 2, qv[0].y, qv[1].y, qv[2].y, qv[3].y, ps2);
+                        }
+                    }
+                }
+    }
+}
+
 template <int BM, int RT, int NP>
 __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a, const SpDgradS2Extra x) {
     typedef SpProd<NP> PR;
@@ -978,69 +1049,7 @@ __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a,
             __syncthreads();
         }
     }
-#pragma unroll
-    for (int cl = 0; cl < 4; ++cl)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[cl][i][j][e] += accc[cl][i][j][e];
-
-    // ---- epilogue: lane = class pixel (row i0 + wn*TN + j, column j0 + li); its two column parities are adjacent:
-    // one 8-byte store per (row parity, channel) ----
-    const long P = (long)a.N * HWx;
-    const int ru = r0 + wm * (BM / WM), rl = ru + 4 * kg;
-    float* const sb = reinterpret_cast<float*>(sp_smem);
-    if (tid < BM) sb[tid] = (a.bias && !a.partial && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
-    __syncthreads();
-    const float* const lb = sb + wm * (BM / WM) + 4 * kg;
-    const long rstride = a.partial ? P : (long)HWx;
-    const unsigned lo = 4u * kg * (unsigned)rstride + 2u * li;
-    const bool plain = a.partial != nullptr;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const long rowpix = (long)(2 * (i0 + wn * TN + j)) * a.W + 2 * j0;
-        float* const ub = a.partial ? a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HWx + rowpix
-                                    : (a.out ? a.out + (long)n * a.out_nstride + (long)ru * HWx + rowpix : nullptr);
-        const float* const yb = x.dact_y ? x.dact_y + (long)n * x.dact_nstride + (long)ru * HWx + rowpix : nullptr;
-        // q output: unit (channel block ru/8 + 4i + g, pixel (2*(i0+..)+pu, 2*(j0+li) + {0, 1})), half kg
-        uint2* const qrow = (a.out_q && !a.partial) ? a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(ru / 8) * HWx + rowpix + 2 * li) + kg
-                                                     : nullptr;
-        const long ps2 = 2 * (long)a.N * a.out_q_nstride;
-        float2 qv[4];
-#pragma unroll
-        for (int pu = 0; pu < 2; ++pu)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
-                    if (rl + k >= a.R) continue;
-                    float2 v = make_float2(acc[pu * 2 + 0][i][j][e], acc[pu * 2 + 1][i][j][e]);
-                    float2* o = ub ? reinterpret_cast<float2*>(ub + (long)k * rstride + pu * a.W + lo) : nullptr;
-                    if (!plain) {
-                        v.x += lb[k]; v.y += lb[k];
-                        if (a.accumulate) { const float2 old = *o; v.x += old.x; v.y += old.y; }      // (fp32 output present)
-                        v.x = ghm_act(v.x, a.act, a.alpha);
-                        v.y = ghm_act(v.y, a.act, a.alpha);
-                        if (yb) {                       // relu / leaky relu: the slope of the producer
-                            const float2 yy = *reinterpret_cast<const float2*>(yb + (long)k * HWx + pu * a.W + lo);
-                            v.x *= yy.x > 0.f ? 1.f : x.dact_alpha;
-                            v.y *= yy.y > 0.f ? 1.f : x.dact_alpha;
-                        }
-                    }
-                    if (ub) *o = v;
-                    if (qrow) {           // four consecutive channels (e = 4g .. 4g+3) of the lane's two pixels
-                        qv[e & 3] = v;
-                        if ((e & 3) == 3) {
-                            uint2* qo = qrow + 2 * ((long)(i * 4 + (e >> 2)) * HWx + pu * a.W);
-                            sp_qstore4<NP>(qo, qv[0].x, qv[1].x, qv[2].x, qv[3].x, ps2);
-                            sp_qstore4<NP>(qo + 2, qv[0].y, qv[1].y, qv[2].y, qv[3].y, ps2);
-                        }
-                    }
-                }
-    }
+    sp_dgrad_s2_epilogue<BM, WM, WN, TM, TN, NP>(a, x, acc, accc, sp_smem, tid, wm, wn, kg, li, n, r0, i0, j0, HWx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1328,7 +1337,13 @@ SpPlan sp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu, int np = 3) {
     if (!(d->stride == 2 && d->kh == 3 && d->kw == 3 && d->pad == 1 && d->H == 2 * d->Ho && d->W == 2 * d->Wo)) return p;
     if (d->Wo % 32 || d->K % 16 || d->K < 16 || d->C < 32 || (d->x_nstride & 1) || ((d->H * d->W) & 1)) return p;
     p.bm = 64;
-    p.rt = 2;           // 64 channels x 2 class rows: eight accumulator tiles per wave (leading + correction) -> two blocks per CU
+    // 64 channels x 2 class rows: eight accumulator tiles per wave (leading + correction) -> two blocks per CU.  (Round 5 built
+    // the opposite trade -- 64 x 4 rows x 32 columns on four waves, one block per CU, the pipelined loop of sp_conv2_kernel with a
+    // slab of weights double-buffered, 170 instead of 300 bytes of staging per MFMA -- and measured it SLOWER: 98 / 137 / 168
+    // against 155 / 172 / 182 TFLOP/s on the N8 C64 256^2 / C128 128^2 / C256 64^2 layers, the step 262 against 270 img/s.  These
+    // layers contract over only 8-32 slabs and write four times the pixels they read: a block is 12-50 us of MFMAs between a
+    // prologue and a store-heavy epilogue, and with one block per CU nothing runs under those; two co-resident blocks hide them.)
+    p.rt = 2;
     if (d->Ho % p.rt) return p;
     p.lds = (size_t)2 * np * (2 * 3 * p.bm + 2 * (p.rt + 1) * 33) * 16;
     p.grid = ((d->C + p.bm - 1) / p.bm) * (d->Wo / 32) * (d->Ho / p.rt) * d->N;
