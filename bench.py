@@ -290,7 +290,7 @@ def measure(args, secondary_name=None):
 
     def is_comm(e):          # data-parallel runs: every (sub-)bucket all-reduce and each stage stream's wait for them
         return world > 1 and (e[0].startswith(("allreduce_", "reducescatter_", "allgather_", "rmsprop_shard_", "adam_shard_"))
-                              or e[0] == "wait_comm")
+                              or e[0] == "wait_comm" or e[0].startswith("wait_gather_"))
 
     slots = []          # device of every bracketed entry, in slot order
     slot_labels = []    # None = a launch of the dominant kernel, else the exchange entry's label
@@ -456,7 +456,8 @@ def measure(args, secondary_name=None):
             "buckets": [{"label": lab, "net": k, "MB": round(4 * n / 2 ** 20, 2),
                          "avg_ms": round(sum(per[lab]) / len(per[lab]), 4) if lab in per else None}
                         for lab, k, lo, n in b.xchg_order],
-            "exposed_wait_ms_per_step": {k[-1]: round(sum(v) / len(v), 4) for k, v in per.items() if k.startswith("wait_comm")},
+            "exposed_wait_ms_per_step": {(k[-1] if k.startswith("wait_comm") else k[len("wait_gather_"):]): round(sum(v) / len(v), 4)
+                                         for k, v in per.items() if k.startswith(("wait_comm", "wait_gather_"))},
         }
     if dominant and slot:
         tot_ms = sum(timed_ms)

@@ -940,6 +940,24 @@ __device__ __forceinline__ u32x4 lp_tr_read8(const char* lds_lo, const char* lds
     r.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
     return r;
 }
+// The transposing read as inline assembly (round 5; see sp_tr_issue in conv_split.hip): behind the builtin above the compiler
+// drains vmcnt in front of the first fragment read of every output row -- directly behind the DMA requests of the next row.
+// The kernel waits for its own fragments instead (s_waitcnt lgkmcnt(0) tied to the fragment registers).
+struct LpTrFrag {
+    unsigned long long lo, hi;
+};
+__device__ __forceinline__ void lp_tr_issue(LpTrFrag& f, unsigned lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:256" : "=&v"(f.lo), "=&v"(f.hi) : "v"(lds_addr));
+}
+__device__ __forceinline__ u32x4 lp_tr_bits(const LpTrFrag& f) {
+    return u32x4{(unsigned)f.lo, (unsigned)(f.lo >> 32), (unsigned)f.hi, (unsigned)(f.hi >> 32)};
+}
+template <int N>
+__device__ __forceinline__ void lp_tr_wait(LpTrFrag (&f)[N], LpTrFrag& g) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g.lo), "+v"(g.hi));
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i].lo), "+v"(f[i].hi));      // (volatile: stays behind the wait)
+}
 
 template <int DT, int KS, int ST, int CHT, int CT, bool RS, int SPX>
 __global__ __launch_bounds__(CHT * CT * (RS ? KS : 1) * 64, 1) void lp_wgrad_q_kernel(const LpWgradQArgs a) {
@@ -1032,8 +1050,9 @@ __global__ __launch_bounds__(CHT * CT * (RS ? KS : 1) * 64, 1) void lp_wgrad_q_k
     const int g16 = lane >> 4, lt = lane & 15;
     const int key = lt >> 2, quad = lt & 3;
     const int lane_off = (8 * kg + key) * 64 + (g16 & 1) * 32 + quad * 8;      // + 4 pixels (256 B) for the upper half
-    const char* const ylane = Yl + ww * YTB + lane_off;
-    const char* const xlane = Xl + hh * NPAR * PLB + lane_off;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)Xl;
+    const unsigned yl0 = lds0 + (unsigned)(Yl - Xl) + ww * YTB + lane_off;
+    const unsigned xl0 = lds0 + hh * NPAR * PLB + lane_off;
 
     for (int i = i_begin; i < i_end; ++i) {
         const int buf = (i - i_begin) & 1;
@@ -1042,18 +1061,16 @@ __global__ __launch_bounds__(CHT * CT * (RS ? KS : 1) * 64, 1) void lp_wgrad_q_k
             for (int r = 0; r < ST; ++r) stage_xrow(i * ST - PADK + KS + r);        // the rows the next slab adds
             stage_dy(i + 1, buf ^ 1);
         }
-        const char* xr[RS ? 1 : KS];
+        unsigned xr[RS ? 1 : KS];
 #pragma unroll
-        for (int fa = 0; fa < (RS ? 1 : KS); ++fa) xr[fa] = xlane + ((i * ST + (RS ? wr : fa) - PADK + NR) % NR) * ROWB;
-        const char* const yb = ylane + buf * YB;
+        for (int fa = 0; fa < (RS ? 1 : KS); ++fa) xr[fa] = xl0 + ((i * ST + (RS ? wr : fa) - PADK + NR) % NR) * ROWB;
+        const unsigned yb = yl0 + buf * YB;
         if (!(a.debug & 2)) {
-            // the fragments of k-step ks + 1 are read while the MFMAs of k-step ks run (two transposing reads behind each
-            // MFMA): left to the compiler every read sits right in front of its MFMA and the wave pays the LDS latency
-            // TPW times per k-step
+            // the fragments of k-step ks + 1 are requested behind the wait for those of k-step ks, in front of its MFMAs
             constexpr int NF = RS ? KS : T;               // A fragments per k-step and wave
-            u32x4 af[2][NF], bf[2];
+            LpTrFrag af[2][NF], bf[2];
             auto read_step = [&](int ks, int slot) {
-                bf[slot] = lp_tr_read8(yb + ks * 1024, yb + ks * 1024 + 256);
+                lp_tr_issue(bf[slot], yb + ks * 1024);
 #pragma unroll
                 for (int fa = 0; fa < (RS ? 1 : KS); ++fa)
 #pragma unroll
@@ -1061,23 +1078,16 @@ __global__ __launch_bounds__(CHT * CT * (RS ? KS : 1) * 64, 1) void lp_wgrad_q_k
                         // local column of pixel t' and tap column fb: t' * ST + fb  ->  (parity plane, pixel in plane)
                         const int par = ST == 2 ? (fb & 1) : 0;
                         const int shift = ST == 2 ? (fb >> 1) : fb;
-                        const char* pa = xr[fa] + par * PLB + (ks * 16 + shift) * 64;
-                        af[slot][fa * KS + fb] = lp_tr_read8(pa, pa + 256);
+                        lp_tr_issue(af[slot][fa * KS + fb], xr[fa] + par * PLB + (ks * 16 + shift) * 64);
                     }
             };
             read_step(0, 0);
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
+                lp_tr_wait(af[ks & 1], bf[ks & 1]);
                 if (ks + 1 < KSTEPS) read_step(ks + 1, (ks + 1) & 1);
 #pragma unroll
-                for (int t = 0; t < NF; ++t) acc[t] = Lp<DT>::mfma(af[ks & 1][t], bf[ks & 1], acc[t]);
-                if (ks + 1 < KSTEPS) {
-#pragma unroll
-                    for (int m_ = 0; m_ < NF + 1; ++m_) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    }
-                }
+                for (int t = 0; t < NF; ++t) acc[t] = Lp<DT>::mfma(lp_tr_bits(af[ks & 1][t]), lp_tr_bits(bf[ks & 1]), acc[t]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

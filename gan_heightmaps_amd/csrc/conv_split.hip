@@ -179,6 +179,7 @@ struct SpConvArgs {
     float alpha;
     int accumulate;
     int slabs_per_split;
+    int ntiles;                 // (filter tile, pixel tile, sample) tiles of the launch; a block walks blockIdx.x, + gridDim.x, ...
     float* pool_out;            // POOL: [N, R, H/2, W/2] maximum of act(conv + bias) over 2x2 windows ...
     unsigned char* pool_mask;   // ... and the arg-max mask of every window (bit 2*dr + dc; all ties set; bit 4: sign)
 };
@@ -349,7 +350,7 @@ struct SpGeo2 {
     static constexpr int NIW = (NP * NI + NW - 1) / NW;            // weight DMA instructions per wave and iteration
     static constexpr int WUNITS = NP * WU1, PUNITS = NP * PUP;
     static constexpr int SCR = 2 * WUNITS + 2 * PUNITS;            // the scratch chunk
-    static constexpr int LDS_BYTES = (SCR + 64) * 16;
+    static constexpr int LDS_BYTES = (SCR + 64 + 32) * 16;         // + 512 bytes: the epilogue's bias staging
 };
 
 // ABL (tuning only, wrong results): 1 = no DMA inside the loop, 2 = no waits / barriers inside the loop, 4 = no fragment reads
@@ -374,25 +375,42 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
     extern __shared__ __attribute__((aligned(16))) u32x4 sp_smem[];
     u32x4* const Wl = sp_smem;                         // [2 buffers][piece][2 ch-blocks][KS][BM]
     u32x4* const Pl = sp_smem + 2 * WUNITS;            // [2 buffers][piece][PUP: 2 ch-blocks x PH x PW, padded to whole chunks]
+    u32x4* const Bl = sp_smem + SCR + 64;              // the epilogue's bias staging (apart from every DMA target: a persistent
+                                                       // block's epilogue runs with the next tile's first requests in flight)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int kg = lane >> 5, li = lane & 31;
     const int ntr = (a.R + BM - 1) / BM;
     const int tiles_x = a.W / TW, tiles_y = a.H / ROWS;
-    int L = sp_xcd_remap(blockIdx.x, gridDim.x);
-    const int r0 = (L % ntr) * BM;
-    L /= ntr;
-    const int tx = L % tiles_x;
-    L /= tiles_x;
-    const int ty = L % tiles_y;
-    const int n = L / tiles_y;
-    const int y0 = ty * ROWS, x0 = tx * TW;
     const int lx = li % TW, ly = li / TW;
     const int HW = a.H * a.W, HWin = a.Hin * a.Win;
     const int nslabs = a.CH / 16;
     const int s_begin = blockIdx.y * a.slabs_per_split;
     const int s_end = min(nslabs, s_begin + a.slabs_per_split);
+    // PERSISTENT tiles: a block walks tiles v = blockIdx.x, + gridDim.x, ... < a.ntiles (grid = ntiles: one tile each, the
+    // split-K plans).  The K loop's pipeline flows across the tile boundary: during a tile's last slab the "next slab" it stages
+    // is the first slab of the block's next tile, so that tile starts on operands already in LDS -- the prologue (address
+    // set-up, a DMA round trip, a barrier, the first fragment reads: the larger part of ~7 us per 35-70 us tile) is paid once
+    // per block instead of once per tile
+    struct Tile {
+        int r0, n, y0, x0;
+    };
+    auto decode = [&](int v) {
+        int L = sp_xcd_remap(v, a.ntiles);
+        Tile t;
+        t.r0 = (L % ntr) * BM;
+        L /= ntr;
+        const int tx = L % tiles_x;
+        L /= tiles_x;
+        const int ty = L % tiles_y;
+        t.n = L / tiles_y;
+        t.y0 = ty * ROWS;
+        t.x0 = tx * TW;
+        return t;
+    };
+    int v = blockIdx.x;
+    Tile tc = decode(v);
 
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -414,12 +432,11 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
         wu[i] = (unsigned)(((long)p * a.wq_pstride + ((long)cb * T + b) * a.Rpad + h * 64) * 16);
         wl[i] = p * WU1 + w * 64;
     }
-    const char* const wbase = (const char*)(a.wq + r0);
     const long wrow = (long)KS * a.Rpad * 16;             // bytes between filter rows of a slab
     const long wslab = (long)2 * T * a.Rpad * 16;         // ... between slabs
-    // filter row ``fa`` of slab ``s`` -> weight buffer at unit offset ``tog``
-    auto dma_w = [&](int s, int fa, int tog) {
-        const char* const src = wbase + (long)s * wslab + fa * wrow;
+    // filter row ``fa`` of slab ``s`` of the filter tile at ``r0`` -> weight buffer at unit offset ``tog``
+    auto dma_w = [&](int r0, int s, int fa, int tog) {
+        const char* const src = (const char*)(a.wq + r0) + (long)s * wslab + fa * wrow;
 #pragma unroll
         for (int i = 0; i < NIW; ++i)
             if (ABL & 16)
@@ -433,25 +450,34 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
     // ---- patch DMA: instruction q of this wave and piece copies chunk c = wave + q * NW of the PCH chunks ----
     const char* pp[NQ];          // this lane's unit of the slab staged last, piece 0 (the zero unit for padding lanes)
     unsigned pok = 0;            // bit q: the lane's unit of chunk q is inside the image (else it stays on the zero unit)
+    int pcb[NQ], pyx[NQ];        // the unit's place in the patch: channel block, (row << 16 | column) -- the same for every tile
     int pl[NQ];
     bool preal[NQ];
-    {
-        const u32x4* const ibase = a.in_q + (long)n * a.in_q_nstride + (long)s_begin * 2 * HWin;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = wave + q * NW;
+        preal[q] = c < PCH;
+        const int e = c * 64 + lane;
+        const int cb = e / (PH * PW), rem = e - cb * (PH * PW);
+        const int py = rem / PW, pxs = rem - py * PW;
+        const int px = ST == 2 ? (pxs < PWE ? 2 * pxs : 2 * (pxs - PWE) + 1) : pxs;      // LDS slot -> patch column
+        pcb[q] = e < PU1 ? cb : -1;
+        pyx[q] = (py << 16) | px;
+        pl[q] = c * 64;
+    }
+    // this lane's patch pointers of tile t, slab s_begin
+    auto patch_of = [&](const Tile& t) {
+        const u32x4* const ibase = a.in_q + (long)t.n * a.in_q_nstride + (long)s_begin * 2 * HWin;
+        pok = 0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int c = wave + q * NW;
-            preal[q] = c < PCH;
-            const int e = c * 64 + lane;
-            const int cb = e / (PH * PW), rem = e - cb * (PH * PW);
-            const int py = rem / PW, pxs = rem - py * PW;
-            const int px = ST == 2 ? (pxs < PWE ? 2 * pxs : 2 * (pxs - PWE) + 1) : pxs;      // LDS slot -> patch column
-            const int y = y0 * ST + py - a.pad, x = x0 * ST + px - a.pad;
-            const bool ok = e < PU1 && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
-            pp[q] = ok ? (const char*)(ibase + (long)cb * HWin + y * a.Win + x) : (const char*)a.zeros;
+            const int y = t.y0 * ST + (pyx[q] >> 16) - a.pad, x = t.x0 * ST + (pyx[q] & 0xffff) - a.pad;
+            const bool ok = pcb[q] >= 0 && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
+            pp[q] = ok ? (const char*)(ibase + (long)pcb[q] * HWin + y * a.Win + x) : (const char*)a.zeros;
             pok |= ok ? 1u << q : 0u;
-            pl[q] = c * 64;
         }
-    }
+    };
+    patch_of(tc);
     const long pstep = a.in_q_pstride * 16;       // bytes between the pieces of a q tensor
     const long sstep = (long)2 * HWin * 16;       // ... between slabs
     auto dma_p = [&](int tog, bool advance) {
@@ -474,12 +500,6 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
     };
 
     f32x16 acc[TM][TN], accc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = accc[i][j][e] = 0.f;
 
     struct Frag {
         u32x4 a[NP][TM], b[NP][TN];
@@ -513,80 +533,102 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
         }
     };
 
-    // ---- prologue: filter row 0 and the patch of the first slab, then filter row 1; the first fragments ----
+    // ---- prologue (once per block): filter row 0 and the patch of the first slab, then filter row 1; the first fragments ----
     const int s_last = s_end - 1;
     if (s_begin < s_end) {
-        dma_w(s_begin, 0, 0);
+        dma_w(tc.r0, s_begin, 0, 0);
         dma_p(0, false);
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (s_begin < s_end) dma_w(s_begin, 1, WUNITS);
+    if (s_begin < s_end) dma_w(tc.r0, s_begin, 1, WUNITS);
     int w0 = 0, p0 = 0;          // unit offsets of the weight buffer of the slab's filter row 0 / of the slab's patch buffer
     Frag cur;
     rd(cur, Wl + wlane, Pl + plane, 0, 0);
 
-    for (int s = s_begin; s < s_end; ++s) {
-        const int sn = s < s_last ? s + 1 : s;          // the slab staged from this one (itself at the end: harmless)
-        const u32x4* const Pc = Pl + p0 + plane;
-        const u32x4* const Pn = Pl + (PUNITS - p0) + plane;
+    for (;;) {                   // tiles of this block
+        const int vn = v + gridDim.x;
+        // (the eight-wave shape -- 256 registers per wave -- has no room for the tile state: one tile per block)
+        const bool more = NW == 4 && vn < a.ntiles && s_begin < s_end;
+        const Tile tn = decode(more ? vn : v);
 #pragma unroll
-        for (int fa = 0; fa < KS; ++fa) {
-            const int wc = (fa & 1) ? WUNITS - w0 : w0;         // this filter row's weight buffer
-            const u32x4* const Wc = Wl + wc + wlane;
-            const u32x4* const Wn = Wl + (WUNITS - wc) + wlane;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int b = 0; b < KS; ++b) {
-                Frag nx;
-                int ndma = 0;
-                if (ABL & 4) {
-                    nx = cur;
-                } else if (b + 1 < KS) {
-                    rd(nx, Wc, Pc, fa, b + 1);
-                } else {                                         // the next iteration's first column
-                    rd(nx, Wn, fa + 1 < KS ? Pc : Pn, fa + 1 < KS ? fa + 1 : 0, 0);
-                }
-                if (b + 1 == KS && !(ABL & 1)) {
-                    // the filter row two iterations ahead replaces this one's (all of its fragments were read before the barrier)
-                    if (fa + 2 < KS)
-                        dma_w(s, fa + 2, wc);
-                    else
-                        dma_w(sn, fa + 2 - KS, wc);
-                    ndma = NIW;
-                }
-                if (fa == 0 && b == 0 && !(ABL & 1)) {           // the next slab's patch
-                    dma_p(PUNITS - p0, s < s_last);
-                    ndma = NP * NQ;
-                }
-                mm(cur);
-                // fragment reads, then DMA, one behind each MFMA, front-loaded: the next k-step starts on fragments read long ago
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int m_ = 0; m_ < NRD; ++m_) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-#pragma unroll
-                for (int m_ = 0; m_ < ndma; ++m_) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-                }
-                if (b == KS - 2 && !(ABL & 2)) {
-                    // everything but the patch requested in this iteration has landed; all reads of this filter row are done
-                    if (fa == 0)
-                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NP * NQ) : "memory");
-                    else
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                cur = nx;
-            }
-        }
-        if (KS & 1) w0 = WUNITS - w0;
-        p0 = PUNITS - p0;
-    }
-    // DMA still in flight targets LDS the epilogue reuses
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = accc[i][j][e] = 0.f;
 
-    sp_conv_epilogue<BM, RT, WM, WN, POOL, TW, TM, TN, NP>(a, acc, accc, sp_smem, tid, wm, wn, kg, li, lx, ly, n, r0, y0, x0, HW);
+        for (int s = s_begin; s < s_end; ++s) {
+            // what this slab stages ahead: the next slab of the tile -- or, in the tile's last slab, the first slab of the block's
+            // next tile (at the very end: itself again, harmless)
+            const bool last = s == s_last;
+            const int sn = last ? (more ? s_begin : s) : s + 1;
+            const int rn = (last && more) ? tn.r0 : tc.r0;
+            const u32x4* const Pc = Pl + p0 + plane;
+            const u32x4* const Pn = Pl + (PUNITS - p0) + plane;
+#pragma unroll
+            for (int fa = 0; fa < KS; ++fa) {
+                const int wc = (fa & 1) ? WUNITS - w0 : w0;         // this filter row's weight buffer
+                const u32x4* const Wc = Wl + wc + wlane;
+                const u32x4* const Wn = Wl + (WUNITS - wc) + wlane;
+#pragma unroll
+                for (int b = 0; b < KS; ++b) {
+                    Frag nx;
+                    int ndma = 0;
+                    if (ABL & 4) {
+                        nx = cur;
+                    } else if (b + 1 < KS) {
+                        rd(nx, Wc, Pc, fa, b + 1);
+                    } else {                                         // the next iteration's first column
+                        rd(nx, Wn, fa + 1 < KS ? Pc : Pn, fa + 1 < KS ? fa + 1 : 0, 0);
+                    }
+                    if (b + 1 == KS && !(ABL & 1)) {
+                        // the filter row two iterations ahead replaces this one's (all of its fragments were read before the barrier)
+                        if (fa + 2 < KS)
+                            dma_w(tc.r0, s, fa + 2, wc);
+                        else
+                            dma_w(rn, sn, fa + 2 - KS, wc);
+                        ndma = NIW;
+                    }
+                    if (fa == 0 && b == 0 && !(ABL & 1)) {           // the next slab's patch
+                        if (last && more)
+                            patch_of(tn);
+                        dma_p(PUNITS - p0, !last);
+                        ndma = NP * NQ;
+                    }
+                    mm(cur);
+                    // fragment reads, then DMA, one behind each MFMA, front-loaded: the next k-step starts on fragments read long ago
+#pragma unroll
+                    for (int m_ = 0; m_ < NRD; ++m_) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+#pragma unroll
+                    for (int m_ = 0; m_ < ndma; ++m_) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    }
+                    if (b == KS - 2 && !(ABL & 2)) {
+                        // everything but the patch requested in this iteration has landed; all reads of this filter row are done
+                        if (fa == 0)
+                            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NP * NQ) : "memory");
+                        else
+                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    cur = nx;
+                }
+            }
+            if (KS & 1) w0 = WUNITS - w0;
+            p0 = PUNITS - p0;
+        }
+
+        sp_conv_epilogue<BM, RT, WM, WN, POOL, TW, TM, TN, NP>(a, acc, accc, Bl, tid, wm, wn, kg, li, lx, ly, tc.n, tc.r0, tc.y0, tc.x0, HW);
+        if (!more) break;
+        v = vn;
+        tc = tn;
+    }
+    // DMA requested past the end of the last tile may still be in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1059,6 +1101,7 @@ struct SpPlan {
     bool ok;
     int np;            // pieces per operand: 3 ('bf16x3', six products) or 2 ('bf16x2', three products)
     int bm, rt, wm, wn, tw, splits, slabs_per_split, grid;
+    int blocks;        // blocks launched along x: grid (= tiles) or fewer, persistent ones (sp_conv2_kernel)
     size_t lds;
 };
 
@@ -1068,7 +1111,7 @@ int sp_nblk(int red) { return (red + 15) / 16 * 2; }      // channel blocks of a
 size_t sp_lds_bytes(int ks, int st, int bm, int rt, int tw, int np) {
     const int rows = rt * (32 / tw);
     const int ph = (rows - 1) * st + ks, pw = (tw - 1) * st + ks;
-    return ((size_t)2 * np * (2 * ks * bm + (2 * ph * pw + 63) / 64 * 64) + 64) * 16;      // SpGeo2::LDS_BYTES
+    return ((size_t)2 * np * (2 * ks * bm + (2 * ph * pw + 63) / 64 * 64) + 64 + 32) * 16;      // SpGeo2::LDS_BYTES
 }
 
 // forward form: CH reduction channels, R output channels, (H, W) output grid
@@ -1111,6 +1154,14 @@ SpPlan sp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu, i
     if (const char* f = GHM_OPT("GHM_SPLIT_SPLITS")) p.splits = atoi(f) < nslabs ? (atoi(f) > 0 ? atoi(f) : 1) : nslabs;
     p.slabs_per_split = (nslabs + p.splits - 1) / p.splits;
     p.splits = (nslabs + p.slabs_per_split - 1) / p.slabs_per_split;
+    // persistent blocks (single-pass plans): GHM_SPLIT_PERSIST = blocks as a fraction of the CUs (0: one block per tile)
+    p.blocks = p.grid;
+    if (p.splits == 1 && p.wm * p.wn == 4) {
+        const char* f = GHM_OPT("GHM_SPLIT_PERSIST");
+        const double frac = f ? atof(f) : 1.0;
+        int nb = (int)(frac * num_cu) / 8 * 8;
+        if (frac > 0 && nb >= 8 && nb < p.grid) p.blocks = nb;
+    }
     p.ok = true;
     return p;
 }
@@ -1200,7 +1251,8 @@ int sp_launch_conv(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, int ks, int st,
     GHM_CHECK(pool || a.out || a.out_q, "split-fp32 convolution: no output");
     GHM_CHECK(!(a.accumulate && !a.out), "accumulate needs the fp32 output");
     GHM_CHECK(!a.out_q || (a.R % 8 == 0 && ((uintptr_t)a.out_q & 15) == 0), "q output: a multiple of 8 channels, 16-byte aligned");
-    const dim3 g(pl.grid, pl.splits);
+    const dim3 g(pl.blocks, pl.splits);
+    a.ntiles = pl.grid;
 #define GHM_SP_CASE(KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_)                                                    \
     if (ks == KS_ && st == ST_ && pl.bm == BM_ && pl.rt == RT_ && pl.wm == WM_ && pool == POOL_ && pl.tw == TW_) {  \
         if (int e = sp_launch_variant<KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_>(ctx, g, pl.lds, a, pl.np)) return e;  \

@@ -243,15 +243,36 @@ int ghm_event_destroy(void* ev) {
     return 0;
 }
 
+// (inside a RECORDED step both are entries of the step: a replay records / waits again -- the per-net "parameters gathered"
+// events of the sharded update, which a step records at its end and the NEXT replay's forward waits for; not inside a HIP graph
+// capture)
 int ghm_event_record(ghm_ctx* ctx, void* ev) {
-    GHM_CHECK(!ctx->capturing && !ctx->rec, "ghm_event_record inside a capture / recording");
-    GHM_HIP(hipEventRecord((hipEvent_t)ev, ctx->stream));
+    GHM_CHECK(!ctx->capturing, "ghm_event_record inside a graph capture");
+    hipStream_t s = ctx->stream;
+    if (ctx->rec) {
+        ghm_step* st = ctx->rec;
+        st->cmds.emplace_back([=]() {
+            hipError_t e = hipEventRecord((hipEvent_t)ev, s);
+            if (e != hipSuccess && st->err == hipSuccess) st->err = e;
+        });
+        return 0;
+    }
+    GHM_HIP(hipEventRecord((hipEvent_t)ev, s));
     return 0;
 }
 
 int ghm_event_wait(ghm_ctx* ctx, void* ev) {
-    GHM_CHECK(!ctx->capturing && !ctx->rec, "ghm_event_wait inside a capture / recording");
-    GHM_HIP(hipStreamWaitEvent(ctx->stream, (hipEvent_t)ev, 0));
+    GHM_CHECK(!ctx->capturing, "ghm_event_wait inside a graph capture");
+    hipStream_t s = ctx->stream;
+    if (ctx->rec) {
+        ghm_step* st = ctx->rec;
+        st->cmds.emplace_back([=]() {
+            hipError_t e = hipStreamWaitEvent(s, (hipEvent_t)ev, 0);
+            if (e != hipSuccess && st->err == hipSuccess) st->err = e;
+        });
+        return 0;
+    }
+    GHM_HIP(hipStreamWaitEvent(s, (hipEvent_t)ev, 0));
     return 0;
 }
 

@@ -95,10 +95,7 @@ class GanStep:
                 t = d.tensor(np.array([self.init_loss_scale, 1.0 / self.init_loss_scale, 0, 0, 0, 0, 0, 0], np.float32))
                 d.set_loss_scale_state(t)
                 self._ls_state.append((d, t))
-        elif hasattr(dev, 'set_loss_scale_state'):
-            # a caller-owned context may still carry the state of an earlier fp16 engine built on it: its loss kernels would
-            # scale this engine's seeds by 2^15 (found by running a bf16x2 model after an fp16 one on one Device)
-            dev.set_loss_scale_state(None)
+
         # optional GRADIENT stream for the weight / bias gradients of both stages (engine.NetPlan side=).  ONE stream for
         # the two stages, not one each: three MFMA-heavy kernels at a time (stage A, stage B, one weight gradient) is what
         # the chip runs best -- with a gradient stream per stage the two weight-gradient kernels share CUs with each other
@@ -291,13 +288,26 @@ class GanStep:
         l2 = self.reconstruction == 'l2'
 
         # ---- shared forward (pix2pix.py:92-101), one list per stream ----
+        # sharded update: a net's parameters are all-gathered at the END of a step in forward order (G, U, D, P; within a net the
+        # first layers first) and the NEXT step's forward waits per net, right in front of the net's first weight read -- the
+        # discriminators' gathers run under the generators' forward passes instead of in front of the whole step
+        gev = self._gather_events() if self.sharded else {}
+
+        def gwait(prog, dev_, k):
+            if k in gev:
+                prog.append(("wait_gather_" + k, lambda dev_=dev_, ev=gev[k]: dev_.event_wait(ev), None, dev_))
+
         fa = [("x_to_d_in", lambda: oA.copy_view(b.x, b.d_in.samples(0, B)))]
+        gwait(fa, dA, 'dcgan_gen')
         b.G.emit_forward(fa)
+        gwait(fa, dA, 'dcgan_disc')
         b.D.emit_forward(fa)
         fb = [("x_to_p_in0", lambda: oB.copy_view(b.x, pa.samples(0, B))),
               ("x_to_p_in1", lambda: oB.copy_view(b.x, pa.samples(B, 2 * B))),
               ("y_to_p_in", lambda: oB.copy_view(b.y, pb.samples(0, B)))]
+        gwait(fb, dB, 'p2p_gen')
         b.U.emit_forward(fb)
+        gwait(fb, dB, 'p2p_disc')
         b.P.emit_forward(fb)
         d_out, p_out = b.D.out, b.P.out
         d_real, d_fake = d_out.samples(0, B), d_out.samples(B, 2 * B)
@@ -458,7 +468,12 @@ class GanStep:
                 # weights is behind it.)  Per sub-bucket, in the order it was reduced: this rank's shard of the optimiser
                 # update, then the all-gather of the updated parameter shards.
                 gs_, hp_ = 1.0 / self.world, self.opt_spec.hp
-                for label, k, blo, n in list(b.xchg_order):
+                # forward order: the nets as the next step reads them (the generators of both stages first), a net's
+                # sub-buckets by ascending offset = first layers first; a per-net event behind its last gather
+                fwd_rank = {'dcgan_gen': 0, 'p2p_gen': 1, 'dcgan_disc': 2, 'p2p_disc': 3}
+                order = sorted(b.xchg_order, key=lambda t: (fwd_rank[t[1]], t[2]))
+                last_of = {t[1]: i for i, t in enumerate(order)}
+                for idx, (label, k, blo, n) in enumerate(order):
                     st, hy, sh = self.stores[k], self.hyper[k], n // self.world
                     a0 = blo + self.rank * sh
                     wv, gv = st.w.channels(a0, a0 + sh), st.g.channels(a0, a0 + sh)
@@ -473,15 +488,19 @@ class GanStep:
                     full = st.w.channels(blo, blo + n)
                     b.exchange.append(("allgather_" + label[len("reducescatter_"):], lambda full=full, sh=sh: cops.all_gather(full, sh),
                                        None, cdev))
+                    if last_of[k] == idx:
+                        b.exchange.append(("gathered_" + k, lambda ev=gev[k]: cdev.event_record(ev), None, cdev))
                 if self.opt_spec.kind == 'adam':
                     for k in keys:
                         b.exchange.append(("adam_tick_" + k, lambda hy=self.hyper[k]: cops.adam_tick(hy), None, cdev))
 
             # one entry per stage stream, so that bench.py can bracket each with HIP events: the time a stage stream
             # spends in this wait is the EXPOSED part of the exchange
-            b.exchange.append(("wait_comm", lambda: dA.wait_for(cdev), None, dA))
-            if dB is not dA:
-                b.exchange.append(("wait_comm", lambda: dB.wait_for(cdev), None, dB))
+            # (sharded form: no wait here -- the next forward waits per net, ``wait_gather_*`` above)
+            if not self.sharded:
+                b.exchange.append(("wait_comm", lambda: dA.wait_for(cdev), None, dA))
+                if dB is not dA:
+                    b.exchange.append(("wait_comm", lambda: dB.wait_for(cdev), None, dB))
         gs = 1.0 / self.world          # (x 1 / loss scale inside the optimiser kernels, from the device state)
         hp = self.opt_spec.hp
         b.update = [[], []]
@@ -678,10 +697,27 @@ class GanStep:
             pipe['dev'].close()
             del self._pipe_state
 
+    def _gather_events(self):
+        """one persistent event per net on the communication stream: "this net's updated parameters are gathered" """
+        if not hasattr(self, '_gev'):
+            self._gev = {k: self.cdev.event_create() for k in ('dcgan_gen', 'dcgan_disc', 'p2p_gen', 'p2p_disc')}
+        return self._gev
+
+    def _bind_loss_scale(self):
+        """(re)attach this engine's dynamic loss-scale state to its contexts, or detach what another engine left there: the
+        contexts are the caller's and several engines may live on one (an fp16 engine's state on it would scale a later
+        engine's loss seeds by 2^15; found by running a bf16x2 model after an fp16 one on one Device).  The state pointer is
+        read when a launch is issued or recorded, so binding at every issue point is enough -- two host calls."""
+        mine = {id(d): t for d, t in self._ls_state}
+        for d in {id(d): d for d in self.devs}.values():
+            if hasattr(d, 'set_loss_scale_state'):
+                d.set_loss_scale_state(mine.get(id(d)))
+
     def _run_lanes(self, b, name, lanes, wrap=None):
         """Run one launch list per stream: eager (interleaved so both streams fill) on the first call,
         captured into one HIP graph per stream on the second, replayed afterwards.  ``wrap(lane, entry)``
         replaces the plain call (used by bench.py to bracket kernels with HIP events; implies eager)."""
+        self._bind_loss_scale()
         if wrap is not None or self.use_graph is not True:
             for lane, e in _interleave(lanes[0], lanes[1]):
                 if wrap is not None:
@@ -774,6 +810,7 @@ class GanStep:
     def _run_recorded(self, b, name, wrap=None):
         """call 0 eager (library workspaces take their size), call 1 records the sequence and replays it, later calls
         are ONE ghm_step_run each.  ``wrap(lane, entry)`` at record time brackets entries with recorded timers."""
+        self._bind_loss_scale()
         seq = self._sequence(b, name)
         n = b.calls.get(name, 0)
         b.calls[name] = n + 1

@@ -305,4 +305,14 @@ def host_device_class():
         def wait_for(self, other):
             Shared.log.append((self.name, "wait_for", other.name))
 
+        def event_create(self):
+            Shared.nev = getattr(Shared, "nev", 0) + 1
+            return "ev%d" % Shared.nev
+
+        def event_record(self, ev):
+            Shared.log.append((self.name, "event_record", ev))
+
+        def event_wait(self, ev):
+            Shared.log.append((self.name, "event_wait", ev))
+
     return HostDevice

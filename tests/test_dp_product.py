@@ -298,9 +298,32 @@ def test_sharded_collective_sequence_and_stream_discipline(sharded):
     log = r["log"]
     upd = [i for i, e in enumerate(log) if e[1] == "rmsprop"]
     assert upd and all(log[i][0] == nm["comm"] for i in upd)
-    last_gather = max(i for i, e in enumerate(log) if e[1] == "all_gather")
-    for lane in (nm["A"], nm["B"]):
-        assert any(i > last_gather and e == (lane, "wait_for", nm["comm"]) for i, e in enumerate(log))
+    # the gathers run in FORWARD order -- the generators of both stages, then the discriminators; inside a net by ascending
+    # offset (first layers first) -- and a per-net event is recorded on the communication stream right behind a net's last gather
+    gath = [(i, e) for i, e in enumerate(log) if e[1] == "all_gather"]
+    net_of = lambda ptr: next(k for k in KEYS if r["w_range"][k][0] <= ptr < r["w_range"][k][0] + 4 * r["w_range"][k][1])
+    nets_seq = [net_of(e[2]) for _, e in gath]
+    firsts = [k for j, k in enumerate(nets_seq) if k not in nets_seq[:j]]
+    assert firsts == ["dcgan_gen", "p2p_gen", "dcgan_disc", "p2p_disc"], firsts
+    recs = [(i, e[2]) for i, e in enumerate(log) if e[1] == "event_record"]
+    assert len(recs) == 4 and all(log[i][0] == nm["comm"] for i, _ in recs)
+    for k in KEYS:
+        idx = [i for (i, e), kk in zip(gath, nets_seq) if kk == k]
+        offs = [log[i][2] for i in idx]
+        assert offs == sorted(offs)                                     # ascending offsets: the net's first layers first
+        assert log[idx[-1] + 1][1] == "event_record"                    # the net's event directly behind its last gather
+    # ... which the stage streams wait for per net, in front of the net's forward, in THIS program (the next replay's waits
+    # see this step's records): generator before discriminator on both stage streams, every wait before the first collective;
+    # there is no wait for the whole communication stream at the end of the step any more
+    waits = [(i, e) for i, e in enumerate(log) if e[1] == "event_wait"]
+    assert len(waits) == 4
+    first_coll = min(i for i, e in enumerate(log) if e[1] in ("reduce_scatter_sum", "allreduce_sum"))
+    assert all(i < first_coll for i, _ in waits)
+    by_lane = {lane: [e[2] for _, e in waits if e[0] == lane] for lane in (nm["A"], nm["B"])}
+    rec_order = [ev for _, ev in recs]                                  # G, U, D, P
+    assert by_lane[nm["A"]] == [rec_order[0], rec_order[2]] and by_lane[nm["B"]] == [rec_order[1], rec_order[3]]
+    last_gather = max(i for i, _ in gath)
+    assert not any(i > last_gather and e[1] == "wait_for" and e[2] == nm["comm"] for i, e in enumerate(log))
     first_gather = min(i for i, e in enumerate(log) if e[1] == "all_gather")
     waits = [i for i, e in enumerate(log[:first_gather]) if e[0] == nm["comm"] and e[1] == "wait_for"]
     for lane in (nm["A"], nm["B"]):                                    # ... and the gathers wait for every reader of the old weights

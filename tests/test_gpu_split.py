@@ -458,3 +458,54 @@ def test_two_piece_products_are_exact_given_the_pieces(gpu, case):
         assert rel(got, dW_x2) < 6e-7 and rel(got, dW_exact) < 2e-5, (rel(got, dW_x2), rel(got, dW_exact))
         dev.free(ws)
     dev.free(wq)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 64, 64, 64, 5, 1, 2), (3, 48, 32, 64, 40, 3, 1, 1), (2, 32, 64, 64, 128, 3, 2, 1), (3, 64, 16, 32, 96, 5, 1, 2)])
+@pytest.mark.parametrize("pieces", [3, 2])
+def test_persistent_tiles_are_bit_identical_to_one_tile_per_block(gpu, case, pieces):
+    """sp_conv2_kernel walks several tiles per block when the launch has more tiles than blocks (GHM_SPLIT_PERSIST: blocks as a
+    fraction of the CUs), its pipeline flowing across the tile boundary: the results must be bit for bit those of one tile per
+    block -- forward with the q copy, data gradient, pooled forward; 8 blocks for 12-64 tiles here, uneven tile counts included"""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    rng = np.random.RandomState(sum(case) + 17 * pieces)
+    dt = 'bf16x3' if pieces == 3 else 'bf16x2'
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    dy = rng.randn(N, K, d.Ho, d.Wo).astype(np.float32)
+    Wt = (rng.randn(K, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    xd, dyd, bd = dev.tensor(x), dev.tensor(dy), dev.tensor(b)
+    wp = dev.tensor(D.pack_conv_w(Wt).ravel())
+    wq = dev.alloc(ops.split_weight_bytes(d, False, pieces))
+    wqT = dev.alloc(ops.split_weight_bytes(d, True, pieces))
+    ops.split_pack_weights(d, wp, wq, False, pieces)
+    ops.split_pack_weights(d, wp, wqT, True, pieces)
+    xq, dyq = D.QTensor.empty(dev, x.shape, dt), D.QTensor.empty(dev, dy.shape, dt)
+    ops.q_pack(xd, xq)
+    ops.q_pack(dyd, dyq)
+    res = {}
+    for frac in ("0", "0.04"):
+        with tuning_env(GHM_SPLIT_PERSIST=frac):
+            y = dev.empty((N, K, d.Ho, d.Wo))
+            yq = D.QTensor.empty(dev, y.shape, dt) if ops.lp_q_direct(d, 0, dt) else None
+            ops.conv2d_fwd_lp_q(d, xq, wq, bd, y, yq, dt, 'lrelu', 0.2)
+            out = [y.numpy()] + ([yq.numpy(p) for p in range(pieces)] if yq is not None else [])
+            if s == 1 and ops.split_supported(d, 1):
+                dx = dev.empty((N, C, H, W))
+                ops.conv2d_dgrad_lp_q(d, dyq, wqT, dx, None, dt)
+                out.append(dx.numpy())
+            if s == 1 and d.Ho % 2 == 0 and ops.conv_pool_supported(d, 'lrelu', dt) == 2:
+                pooled = dev.empty((N, K, d.Ho // 2, d.Wo // 2))
+                mask = dev.alloc(N * K * (d.Ho // 2) * (d.Wo // 2))
+                ops.conv2d_fwd_pool_lp_q(d, xq, wq, bd, pooled, None, mask, 'lrelu', 0.2, dt)
+                m = np.empty(N * K * (d.Ho // 2) * (d.Wo // 2), np.uint8)
+                dev.d2h(m, mask, m.nbytes)
+                out += [pooled.numpy(), m]
+                dev.free(mask)
+            res[frac] = out
+    assert len(res["0"]) == len(res["0.04"]) >= 2
+    for a_, b_ in zip(res["0"], res["0.04"]):
+        assert np.array_equal(a_, b_)
+    dev.free(wq)
+    dev.free(wqT)
