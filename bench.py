@@ -477,7 +477,7 @@ def measure(args, secondary_name=None):
             for pmc in ("r05_pmc_traffic_3stream_bf16x3.json", "r04_pmc_traffic_3stream_bf16x3.json"):
                 pmc = os.path.join(ROOT, "profiles", pmc)
                 if traffic is None and os.path.exists(pmc):
-                    # "sp_conv_kernel<3, 1" -> "sp_conv" + "<3, 1,": the round-5 kernel is sp_conv2_kernel
+                    # "sp_conv2_kernel<3, 1" -> "sp_conv2" + "<3, 1,"
                     fam = dominant.split("<")[1].split(">")[0] + ","
                     stem = dominant.split("_kernel")[0]
                     import re

@@ -937,7 +937,11 @@ template <int BM, int RT, int NP>
 __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a, const SpDgradS2Extra x) {
     typedef SpProd<NP> PR;
     // weights staged per filter ROW (3 taps x 2 channel blocks x BM rows x 3 pieces, double-buffered: 36 KB) and the dy patch
-    // per slab (double-buffered): 68 KB in the 64 x 4 shape -- two blocks per CU, and room left for the other streams' kernels
+    // per slab (double-buffered): 68 KB in the 64 x 4 shape -- two blocks per CU, and room left for the other streams' kernels.
+    // (Three weight buffers staged two rows ahead, the barrier waiting for the older row only: 146 / 167 / 140 TFLOP/s on the step's
+    // three geometries, the same as this form -- the L2 round trip per row is not what bounds it.  In the step the launch is as
+    // much epilogue as contraction: 14 bytes per output element -- producer's activation read, fp32 and split gradient written --
+    // against 576 flops, 0.213 ms where the bare product takes 0.133.)
     constexpr int T = 9, WM = 2, WN = 2;
     constexpr int TM = BM / (WM * 32), TN = RT / WN;
     constexpr int PH = RT + 1, PW = 33;
@@ -1132,7 +1136,19 @@ SpPlan sp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu, i
     if (p.tw == 32) {
         // 3x3 stride 1, 128 filters: eight waves of 2 x 2 tiles (four waves of 4 x 2 tiles -- a quarter fewer fragment reads per
         // MFMA -- measured 0-19 % slower alone: 212 against 231 TFLOP/s on the N4 C128 128^2 K256 data gradient)
-        if (ks == 3 && st == 1) { p.bm = (R >= 96 && !GHM_OPT("GHM_SPLIT_BM64")) ? 128 : 64; p.rt = 8; p.wm = p.bm == 128 ? 2 : 1; p.wn = 4; }
+        if (ks == 3 && st == 1) {
+            p.bm = (R >= 96 && !GHM_OPT("GHM_SPLIT_BM64")) ? 128 : 64;
+            if (p.bm == 128 && H % 8 == 0 && !GHM_OPT("GHM_SPLIT_BM128")) {
+                // a launch of 128 .. 255 tiles of 128 filters leaves half the CUs idle (the N4 C1024 64^2 K256 forward: 180
+                // TFLOP/s alone, 250 in 256 tiles of 64 filters; the N4 K512 -> C1024 32^2 data gradient 175 -> 239): whole
+                // rounds of blocks over the CUs, priced with the two shapes' rates alone (235 / 220 TFLOP/s) -- the 64-filter
+                // shape makes twice the tiles at half the work each
+                const long g128 = (long)((R + 127) / 128) * (W / 32) * (H / 8) * N, g64 = (long)((R + 63) / 64) * (W / 32) * (H / 8) * N;
+                const double t128 = (double)((g128 + num_cu - 1) / num_cu) / 235.0, t64 = 0.5 * (double)((g64 + num_cu - 1) / num_cu) / 220.0;
+                if (g128 >= num_cu / 2 && t64 < t128) p.bm = 64;
+            }
+            p.rt = 8; p.wm = p.bm == 128 ? 2 : 1; p.wn = 4;
+        }
         else if (ks == 5) { p.bm = 64; p.rt = 8; p.wm = 1; p.wn = 4; }
         else { p.bm = 64; p.rt = 4; p.wm = 2; p.wn = 2; }
     } else {        // narrow maps: 64 filters x (8 rows x 16 columns | 8 x 8): fragments of 2 x 16 / 4 x 8 pixels, four waves

@@ -247,7 +247,7 @@ int ghm_event_destroy(void* ev) {
 // events of the sharded update, which a step records at its end and the NEXT replay's forward waits for; not inside a HIP graph
 // capture)
 int ghm_event_record(ghm_ctx* ctx, void* ev) {
-    GHM_CHECK(!ctx->capturing, "ghm_event_record inside a graph capture");
+    GHM_CHECK(!ctx->capturing || ctx->rec, "ghm_event_record inside a graph capture");
     hipStream_t s = ctx->stream;
     if (ctx->rec) {
         ghm_step* st = ctx->rec;
@@ -262,7 +262,7 @@ int ghm_event_record(ghm_ctx* ctx, void* ev) {
 }
 
 int ghm_event_wait(ghm_ctx* ctx, void* ev) {
-    GHM_CHECK(!ctx->capturing, "ghm_event_wait inside a graph capture");
+    GHM_CHECK(!ctx->capturing || ctx->rec, "ghm_event_wait inside a graph capture");
     hipStream_t s = ctx->stream;
     if (ctx->rec) {
         ghm_step* st = ctx->rec;

@@ -609,7 +609,7 @@ class Ops:
             w = d.W if kind == 1 and d.stride == 1 else d.Wo          # width of the pixel grid the kernel tiles
             if kind == 1 and d.stride == 2:
                 return "sp_dgrad_s2_kernel"
-            return ("sp_wgrad_kernel<%d, %d>%s" if kind == 2 else "sp_conv_kernel<%d, %d>%s") % (
+            return ("sp_wgrad_kernel<%d, %d>%s" if kind == 2 else "sp_conv2_kernel<%d, %d>%s") % (
                 d.kh, d.stride, "" if w % 32 == 0 else " narrow")
         out = C.create_string_buffer(128)
         call("ghm_lp_variant", C.byref(d), int(kind), DTYPE_CODES[dtype], out, 128)

@@ -1382,7 +1382,7 @@ class NetPlan:
 def conv_meta(ops, d, kind, dtype='f32', pooled=False):
     """roofline metadata of one conv launch: kernel variant name and ALGORITHMIC flops (2 x MACs)."""
     if pooled:
-        name = ("sp_conv_kernel<%d, %d> fwd+pool" % (d.kh, d.stride)) if dtype in SPLITS else \
+        name = ("sp_conv2_kernel<%d, %d> fwd+pool" % (d.kh, d.stride)) if dtype in SPLITS else \
             ("lp_conv_kernel<%s, %d, %d>" % (dtype, d.kh, d.stride)) if dtype != 'f32' else \
             ("fanout_kernel<fwd+pool>" if d.C <= 4 else ops.conv_variant(d, 0).split(" splits")[0])   # same kernel, pooled epilogue
     elif dtype != 'f32':

@@ -210,7 +210,7 @@ def test_full_size_batch4_step_against_the_float64_fixture(gpu, dtype):
     b = model.engine.built(batch)
     if dtype != 'f32':          # the split kernels really are in the program
         names = {e[2]["kernel"] for lane in b.train_compute for e in lane if len(e) > 2 and e[2] is not None and e[2].get("dtype") == dtype}
-        assert any(n.startswith("sp_conv_kernel") for n in names) and any(n.startswith("sp_wgrad_kernel") for n in names), names
+        assert any(n.startswith("sp_conv2_kernel") for n in names) and any(n.startswith("sp_wgrad_kernel") for n in names), names
     for key, t in (("gz", b.G.out), ("ux", b.U.out)):          # the step's own forward outputs (pre-update parameters)
         a = t.numpy().astype(np.float64)
         lat = a[:, :, ::stride, ::stride]

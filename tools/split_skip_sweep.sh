@@ -5,7 +5,7 @@
 # over-state their class several times (1.36 / 0.92 ms in the sweep against 0.18 / 0.28 ms of kernels alone)
 run() { env $1 python bench.py --dtype bf16x3 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])"; }
 for k in "X=1" "X=2" \
-  "GHM_SKIP_KERNELS=sp_conv_kernel" \
+  "GHM_SKIP_KERNELS=sp_conv2_kernel" \
   "GHM_SKIP_KERNELS=sp_wgrad_kernel" \
   "GHM_SKIP_KERNELS=sp_dgrad_s2_kernel" \
   "GHM_SKIP_KERNELS=sp_pack_kernel" \
