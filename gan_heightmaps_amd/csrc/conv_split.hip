@@ -868,6 +868,38 @@ template <int BM, int WM, int WN, int TM, int TN, int NP>
 __device__ __forceinline__ void sp_dgrad_s2_epilogue(const SpConvArgs& a, const SpDgradS2Extra& x, f32x16 (&acc)[4][TM][TN],
                                                      f32x16 (&accc)[4][TM][TN], u32x4* sp_smem, int tid, int wm, int wn, int kg,
                                                      int li, int n, int r0, int i0, int j0, int HWx) {
+    // ---- epilogue: lane = class pixel (row i0 + wn*TN + j, column j0 + li); its two column parities are adjacent:
+    // one 8-byte store per (row parity, channel) ----
+    static_assert(TN == 1, "one class row per wave (the prefetched epilogue operand is sized for it)");
+    const long P = (long)a.N * HWx;
+    const int ru = r0 + wm * (BM / WM), rl = ru + 4 * kg;
+    const long rstride = a.partial ? P : (long)HWx;
+    const unsigned lo = 4u * kg * (unsigned)rstride + 2u * li;
+    const bool plain = a.partial != nullptr;
+    const long rowpix = (long)(2 * (i0 + wn * TN)) * a.W + 2 * j0;
+    float* const ub = a.partial ? a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HWx + rowpix
+                                : (a.out ? a.out + (long)n * a.out_nstride + (long)ru * HWx + rowpix : nullptr);
+    const float* const yb = x.dact_y ? x.dact_y + (long)n * x.dact_nstride + (long)ru * HWx + rowpix : nullptr;
+    // what the epilogue READS -- the gradient it accumulates into (U-Net skip connections) or the producer's activation (the
+    // PatchGAN's conv -> LeakyRectify -> conv chains), never both -- is fetched in ONE batch before anything else: 32 loads in
+    // flight per lane instead of a round trip per channel row (the launches with such an operand took 1.5x the bare product:
+    // 0.107 against 0.069 ms on N4 C64 256^2)
+    const bool do_acc = !plain && a.accumulate, do_y = !plain && yb != nullptr;
+    const float* const auxb = do_y ? yb : (do_acc ? ub : nullptr);
+    const long auxs = do_y ? (long)HWx : rstride;
+    float2 aux[2][TM][16];
+    if (auxb) {
+#pragma unroll
+        for (int pu = 0; pu < 2; ++pu)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i * 32 + (e & 3) + 8 * (e >> 2);
+                    aux[pu][i][e] = rl + k < a.R ? *reinterpret_cast<const float2*>(auxb + (long)k * auxs + pu * a.W + lo)
+                                                 : make_float2(0.f, 0.f);
+                }
+    }
 #pragma unroll
     for (int cl = 0; cl < 4; ++cl)
 #pragma unroll
@@ -877,23 +909,12 @@ __device__ __forceinline__ void sp_dgrad_s2_epilogue(const SpConvArgs& a, const 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[cl][i][j][e] += accc[cl][i][j][e];
 
-    // ---- epilogue: lane = class pixel (row i0 + wn*TN + j, column j0 + li); its two column parities are adjacent:
-    // one 8-byte store per (row parity, channel) ----
-    const long P = (long)a.N * HWx;
-    const int ru = r0 + wm * (BM / WM), rl = ru + 4 * kg;
     float* const sb = reinterpret_cast<float*>(sp_smem);
     if (tid < BM) sb[tid] = (a.bias && !a.partial && r0 + tid < a.R) ? a.bias[r0 + tid] : 0.f;
     __syncthreads();
     const float* const lb = sb + wm * (BM / WM) + 4 * kg;
-    const long rstride = a.partial ? P : (long)HWx;
-    const unsigned lo = 4u * kg * (unsigned)rstride + 2u * li;
-    const bool plain = a.partial != nullptr;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const long rowpix = (long)(2 * (i0 + wn * TN + j)) * a.W + 2 * j0;
-        float* const ub = a.partial ? a.partial + ((long)blockIdx.y * a.R + ru) * P + (long)n * HWx + rowpix
-                                    : (a.out ? a.out + (long)n * a.out_nstride + (long)ru * HWx + rowpix : nullptr);
-        const float* const yb = x.dact_y ? x.dact_y + (long)n * x.dact_nstride + (long)ru * HWx + rowpix : nullptr;
+    {
+        constexpr int j = 0;
         // q output: unit (channel block ru/8 + 4i + g, pixel (2*(i0+..)+pu, 2*(j0+li) + {0, 1})), half kg
         uint2* const qrow = (a.out_q && !a.partial) ? a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(ru / 8) * HWx + rowpix + 2 * li) + kg
                                                      : nullptr;
@@ -911,13 +932,12 @@ __device__ __forceinline__ void sp_dgrad_s2_epilogue(const SpConvArgs& a, const 
                     float2* o = ub ? reinterpret_cast<float2*>(ub + (long)k * rstride + pu * a.W + lo) : nullptr;
                     if (!plain) {
                         v.x += lb[k]; v.y += lb[k];
-                        if (a.accumulate) { const float2 old = *o; v.x += old.x; v.y += old.y; }      // (fp32 output present)
+                        if (do_acc) { v.x += aux[pu][i][e].x; v.y += aux[pu][i][e].y; }      // (fp32 output present)
                         v.x = ghm_act(v.x, a.act, a.alpha);
                         v.y = ghm_act(v.y, a.act, a.alpha);
-                        if (yb) {                       // relu / leaky relu: the slope of the producer
-                            const float2 yy = *reinterpret_cast<const float2*>(yb + (long)k * HWx + pu * a.W + lo);
-                            v.x *= yy.x > 0.f ? 1.f : x.dact_alpha;
-                            v.y *= yy.y > 0.f ? 1.f : x.dact_alpha;
+                        if (do_y) {                     // relu / leaky relu: the slope of the producer
+                            v.x *= aux[pu][i][e].x > 0.f ? 1.f : x.dact_alpha;
+                            v.y *= aux[pu][i][e].y > 0.f ? 1.f : x.dact_alpha;
                         }
                     }
                     if (ub) *o = v;
@@ -940,8 +960,9 @@ __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a,
     // per slab (double-buffered): 68 KB in the 64 x 4 shape -- two blocks per CU, and room left for the other streams' kernels.
     // (Three weight buffers staged two rows ahead, the barrier waiting for the older row only: 146 / 167 / 140 TFLOP/s on the step's
     // three geometries, the same as this form -- the L2 round trip per row is not what bounds it.  In the step the launch is as
-    // much epilogue as contraction: 14 bytes per output element -- producer's activation read, fp32 and split gradient written --
-    // against 576 flops, 0.213 ms where the bare product takes 0.133.)
+    // much epilogue as contraction: up to 14 bytes per output element -- producer's activation read, fp32 and split gradient
+    // written -- against 576 flops; what cost most was the round trip of the epilogue's READS, now one batch: the nine launches
+    // of the step 1.13 -> 0.97 ms, the bare products sum to 0.74.)
     constexpr int T = 9, WM = 2, WN = 2;
     constexpr int TM = BM / (WM * 32), TN = RT / WN;
     constexpr int PH = RT + 1, PW = 33;

@@ -1133,7 +1133,7 @@ class NetPlan:
                             giq = fused_gq(xin, gi, acc) if ops.lp_q_direct(d2, 1, self.dtype) else None
                             prog.append(("conv_dgrad", lambda d=d2, Gq=Gq, wsel=wsel, gi=gi, giq=giq, x=x, xa=xa:
                                          ops.conv2d_dgrad_dact_lp_q(d, Gq, wsel, gi, giq, x, xa.kind, xa.alpha, self.dtype),
-                                         conv_meta(ops, d2, 3, dt)))
+                                         conv_meta(ops, d2, 3, dt, extra=" +dact" + (" +q" if giq is not None else ""))))
                         else:
                             prog.append(("conv_dgrad", lambda d=d2, G=G, wsel=wsel, gi=gi, x=x, xa=xa, dt=dt:
                                          ops.conv2d_dgrad_dact(d, G, wsel, gi, x, xa.kind, xa.alpha, dt),
@@ -1152,7 +1152,8 @@ class NetPlan:
                                 gq_ready.discard(id(xin))
                             prog.append(("conv_dgrad", lambda d=d2, Gq=Gq, wqT=wqT, gi=gi, giq=giq, acc=acc:
                                          ops.conv2d_dgrad_lp_q(d, Gq, wqT, gi, giq, self.dtype, None, 'linear', 0.0, acc),
-                                         conv_meta(ops, d2, 3, self.dtype)))
+                                         conv_meta(ops, d2, 3, self.dtype,
+                                                   extra=(" +q" if giq is not None else "") + (" +acc" if acc else ""))))
                         else:
                             prog.append(("conv_dgrad", lambda d=d2, G=G, wqT=wqT, gi=gi, acc=acc:
                                          ops.conv2d_dgrad_lp(d, G, wqT, gi, self.dtype, None, 'linear', 0.0, acc),
@@ -1379,7 +1380,7 @@ class NetPlan:
                 for l in input_grads}
 
 
-def conv_meta(ops, d, kind, dtype='f32', pooled=False):
+def conv_meta(ops, d, kind, dtype='f32', pooled=False, extra=''):
     """roofline metadata of one conv launch: kernel variant name and ALGORITHMIC flops (2 x MACs)."""
     if pooled:
         name = ("sp_conv2_kernel<%d, %d> fwd+pool" % (d.kh, d.stride)) if dtype in SPLITS else \
@@ -1399,7 +1400,7 @@ def conv_meta(ops, d, kind, dtype='f32', pooled=False):
         yb = yb / 4 + yb / 16
     return {"kernel": name, "dtype": dtype, "bytes": xb + yb, "thin": min(d.C, d.K) <= 4,
             "flops": 2.0 * d.N * d.K * d.Ho * d.Wo * d.C * d.kh * d.kw,
-            "geom": "N%d C%d %dx%d K%d k%d s%d" % (d.N, d.C, d.H, d.W, d.K, d.kh, d.stride)}
+            "geom": "N%d C%d %dx%d K%d k%d s%d%s" % (d.N, d.C, d.H, d.W, d.K, d.kh, d.stride, extra)}
 
 
 def pack_meta(t):
