@@ -96,10 +96,12 @@ class Hdf5Iterator:
         return sl, perm, table
 
     # ---- device side ----
-    def _staging(self, name, nbytes):
+    def _staging(self, name, nbytes, via=None):
         cur = self._bufs.get(name)
         if cur is None or cur[1] < nbytes:
             if cur is not None:
+                # a copy or the augmentation kernel of the previous batch may still be reading it on the copy stream
+                (via if via is not None else self.dev).sync()
                 self.dev.free(cur[0])
             cur = (self.dev.alloc(nbytes), nbytes)
             self._bufs[name] = cur
@@ -119,8 +121,8 @@ class Hdf5Iterator:
             batch = np.ascontiguousarray(np.asarray(arr[sl])[perm])          # uint8 NHWC, permuted like flow()
             _, h, w, c = batch.shape
             assert dst.shape[1:] == (c, h, w) and dst.shape[0] >= n, (dst.shape, batch.shape)
-            src = self._staging(name, batch.nbytes)
-            xf = self._staging(name + "_xf", table.nbytes)
+            src = self._staging(name, batch.nbytes, via)
+            xf = self._staging(name + "_xf", table.nbytes, via)
             d = dev if dev is not None else dst.dev
             if dev is None:
                 d.h2d(src, batch)
