@@ -123,6 +123,10 @@ def parse_args(argv=None):
     ap.add_argument("--ablate", default="", help="TUNING ONLY (results are wrong): comma-separated program-entry labels or "
                     "kernel-name prefixes whose launches are skipped, to see what a class of kernels costs inside the "
                     "overlapped schedule; the JSON line is marked invalid")
+    ap.add_argument("--repeat", default="", help="TUNING ONLY: comma-separated program-entry labels or kernel-name prefixes whose "
+                    "launches are issued TWICE: the step's increase is what the class costs inside the overlapped schedule, on "
+                    "real data (skipping a producer leaves zeros in matrix-core operands, which run ~18 %% faster); the JSON line "
+                    "is marked invalid")
     ap.add_argument("--dtype", default="bf16x3", choices=["f32", "bf16", "f16", "bf16x3", "bf16x2"],
                     help="arithmetic of the convolution products.  bf16x3 (default, the headline) = the reference's "
                          "floatX=float32 arithmetic on the bf16 matrix cores by operand splitting: three bf16 pieces per fp32 "
@@ -238,6 +242,15 @@ def measure(args, secondary_name=None):
         for lanes in (b.train_compute, b.update):
             for i in (0, 1):
                 lanes[i][:] = [((e[0], (lambda: None)) + tuple(e[2:])) if dead(e) else e for e in lanes[i]]
+    if args.repeat:
+        rpats = [p for p in args.repeat.split(",") if p]
+
+        def twice(e):
+            k = e[2]["kernel"] if len(e) > 2 and e[2] else ""
+            return any(e[0] == p or (k and k.startswith(p)) for p in rpats)
+        for lanes in (b.train_compute, b.update):
+            for i in (0, 1):
+                lanes[i][:] = [x for e in lanes[i] for x in ((e, e) if twice(e) else (e,))]
     eng._upload(b, Z, X, Y)                      # inputs resident in HBM before the timed region
 
     for _ in range(max(args.warmup, 2 if issue == 'recorded' else 0)):     # recorded: call 0 eager, call 1 records
@@ -399,6 +412,7 @@ def measure(args, secondary_name=None):
         flops_source = "summed over the plan's convolution launches (bench.py nominal_flops_per_step)"
     out = {
         **({"INVALID": "ablation run (--ablate %s): kernels skipped, results wrong" % args.ablate} if args.ablate else {}),
+        **({"INVALID": "tuning run (--repeat %s): kernels issued twice" % args.repeat} if args.repeat else {}),
         "metric": "512px heightmap+texture train images/sec", "value": round(value, 3), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -526,7 +540,7 @@ def main():
     out = measure(args)
     headline = (args.mode == "both" and args.dtype == "bf16x3" and not args.config1 and args.in_shp == 512
                 and args.batch_per_gpu == 4 and not args.graph and not args.one_stream and not args.no_grad_streams)
-    if rank == 0 and world == 1 and headline and not args.no_secondary and not args.ablate:
+    if rank == 0 and world == 1 and headline and not args.no_secondary and not args.ablate and not args.repeat:
         import copy
         sec = []
         for name, ov in SECONDARY:

@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+bash tools/split_skip_sweep.sh > gpurun_out/r05_instep_skip_sweep_bf16x3.txt 2>&1
+cat gpurun_out/r05_instep_skip_sweep_bf16x3.txt
