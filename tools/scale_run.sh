@@ -6,7 +6,7 @@
 #   tools/scale_run.sh [dtype] [steps]          -> gpurun_out/scale_<dtype>_<N>.json
 set -u
 cd "$(dirname "$0")/.."
-DT=${1:-f32}; STEPS=${2:-30}
+DT=${1:-bf16x3}; STEPS=${2:-30}
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 mkdir -p gpurun_out
 NGPU=$(python -c "from gan_heightmaps_amd import device; print(device.device_count())")
