@@ -51,6 +51,10 @@ def main():
            "dgrad_t": lambda: ops.conv2d_dgrad_t(d, y, wT, dx),
            "dgrad": lambda: ops.conv2d_dgrad(d, y, w, dx),
            "wgrad": lambda: ops.conv2d_wgrad(d, x, y, dw, ws)}
+    if args.dtype == "f32" and min(C, K) <= 4 and ops.thin_fwd_q_supported(d, 'lrelu', False, 'bf16x3'):
+        # a first layer in the split step: fp32 result + the three-plane q copy in one pass (conv2d_fwd_thin_q)
+        yq3 = D.QTensor.empty(dev, y.shape, 'bf16x3')
+        fns["fwd_q"] = lambda: ops.conv2d_fwd_thin_q(d, x, w, b, y, yq3, 'lrelu', 0.2)
     if args.dtype in ("split", "split2"):
         npc = 3 if args.dtype == "split" else 2
         qdt = "bf16x3" if npc == 3 else "bf16x2"
@@ -120,7 +124,7 @@ def main():
         dev.timer_stop(0)
         ms = dev.timer_ms(0) / args.reps
         name = ("split" if args.dtype == "split" else "lp<%s>" % args.dtype) if args.dtype != "f32" else \
-            ops.conv_variant(d, ["fwd", "dgrad", "wgrad", "dgrad_t"].index(kind))
+            ops.conv_variant(d, ["fwd", "dgrad", "wgrad", "dgrad_t"].index(kind if kind != "fwd_q" else "fwd"))
         print("%-7s %-34s %8.3f ms  %7.1f TFLOP/s  (%.1f GFLOP)  N%d C%d %dx%d K%d k%d s%d" %
               (kind, name, ms, flops / ms / 1e9, flops / 1e9, N, C, H, W, K, k, s))
     dev.close()
