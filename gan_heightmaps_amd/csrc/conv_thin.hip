@@ -86,6 +86,31 @@ __device__ __forceinline__ void thin_qstore4(uint2* qo, float v0, float v1, floa
     }
 }
 
+// the three (two) bf16 pieces of four values as half units: p[piece] = {v0 v1, v2 v3}
+__device__ __forceinline__ void thin_split4(float v0, float v1, float v2, float v3, uint2 (&pc)[3]) {
+    unsigned p[2][3];
+    const float in[2][2] = {{v0, v1}, {v2, v3}};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        f32x2t v = {in[t][0], in[t][1]};
+        p[t][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2t));
+        f32x2t r = {v[0] - __uint_as_float(p[t][0] << 16), v[1] - __uint_as_float(p[t][0] & 0xffff0000u)};
+        p[t][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2t));
+        f32x2t r2 = {r[0] - __uint_as_float(p[t][1] << 16), r[1] - __uint_as_float(p[t][1] & 0xffff0000u)};
+        p[t][2] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2t));
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pc[q] = make_uint2(p[0][q], p[1][q]);
+}
+typedef unsigned thin_u2 __attribute__((ext_vector_type(2)));
+// lanes l and l + 32 hold the two halves of the q units of pixels a and b: after two lane swaps the lower lane holds the WHOLE
+// unit of pixel a and the upper lane the whole unit of pixel b -- one 16-byte store per lane instead of two 8-byte ones
+__device__ __forceinline__ uint4 thin_pair_units(uint2 pa, uint2 pb) {
+    const thin_u2 r0 = __builtin_amdgcn_permlane32_swap(pa.x, pb.x, false, false);
+    const thin_u2 r1 = __builtin_amdgcn_permlane32_swap(pa.y, pb.y, false, false);
+    return make_uint4(r0[0], r1[0], r0[1], r1[1]);
+}
+
 // LDS hand-over between the loader wave and the MFMA waves: wait for this wave's LDS traffic only.  A
 // __syncthreads() would also drain vmcnt, i.e. make every MFMA wave wait for its output stores to be
 // acknowledged once per iteration -- the stall this kernel is organised to avoid.
@@ -338,13 +363,34 @@ __global__ __launch_bounds__((4 * WS + 1) * 64, WS == 2 ? 1 : 2) void fanout_ker
                         *reinterpret_cast<vec_t*>(ob + (lo + row * plane)) = v;
                     }
                     if constexpr (QOUT) {   // rows 4g .. 4g+3 (+ 4h) of pixel NS*l + k: one half unit per (g, k)
-                        uint2* qb = a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(u0 + ri) * a.Wout + x0 + NS * l) + h;
+                        if ((a.q_dt == 3 || a.q_dt == 4) && NS % 2 == 0) {
+                            // split modes: the half units of pixels (k, k + NS/2) paired across the wave's halves (as 8-byte
+                            // stores of a lane's NS consecutive pixels the three planes were 60 of this kernel's 133 us on
+                            // N8 C4 512^2 K64: 16 bytes per 64-byte segment and instruction)
+                            uint4* qu = reinterpret_cast<uint4*>(a.out_q) + (long)n * a.out_q_nstride + (long)(u0 + ri) * a.Wout + x0 + NS * l;
+                            const long psu = (long)a.N * a.out_q_nstride;
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
+                            for (int g = 0; g < 4; ++g)
 #pragma unroll
-                            for (int k = 0; k < NS; ++k)
-                                thin_qstore4(qb + 2 * ((long)((rb + rbo) * 4 + g) * HWout + k), acc[k][rb][4 * g], acc[k][rb][4 * g + 1],
-                                             acc[k][rb][4 * g + 2], acc[k][rb][4 * g + 3], a.q_dt, 2 * (long)a.N * a.out_q_nstride);
+                                for (int k = 0; k < NS / 2; ++k) {
+                                    uint2 pa[3], pb[3];
+                                    thin_split4(acc[k][rb][4 * g], acc[k][rb][4 * g + 1], acc[k][rb][4 * g + 2], acc[k][rb][4 * g + 3], pa);
+                                    thin_split4(acc[k + NS / 2][rb][4 * g], acc[k + NS / 2][rb][4 * g + 1], acc[k + NS / 2][rb][4 * g + 2],
+                                                acc[k + NS / 2][rb][4 * g + 3], pb);
+                                    uint4* qo = qu + (long)((rb + rbo) * 4 + g) * HWout + k + (h ? NS / 2 : 0);
+                                    qo[0] = thin_pair_units(pa[0], pb[0]);
+                                    qo[psu] = thin_pair_units(pa[1], pb[1]);
+                                    if (a.q_dt == 3) qo[2 * psu] = thin_pair_units(pa[2], pb[2]);
+                                }
+                        } else {
+                            uint2* qb = a.out_q + 2 * ((long)n * a.out_q_nstride + (long)(u0 + ri) * a.Wout + x0 + NS * l) + h;
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                for (int k = 0; k < NS; ++k)
+                                    thin_qstore4(qb + 2 * ((long)((rb + rbo) * 4 + g) * HWout + k), acc[k][rb][4 * g], acc[k][rb][4 * g + 1],
+                                                 acc[k][rb][4 * g + 2], acc[k][rb][4 * g + 3], a.q_dt, 2 * (long)a.N * a.out_q_nstride);
+                        }
                     }
                 }
             }
