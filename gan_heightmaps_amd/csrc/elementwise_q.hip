@@ -62,32 +62,48 @@ __device__ __forceinline__ bool q_decode(long idx, int N, int C8, long items, in
     return true;
 }
 
-// y = act((x - mean) * (gamma * inv) + beta): thread = 8 channels x 2 consecutive pixels
+// y = act((x - mean) * (gamma * inv) + beta): thread = 8 channels x PX consecutive pixels.  PX = 1 (the default since round 5):
+// the 64 lanes of a wave write 64 consecutive q units, one kilobyte per store instruction; with two pixels per thread a
+// store instruction wrote 16 bytes of every 32 -- the q planes are most of what these passes move, and a pass that writes
+// partial segments pays for it (the pooling-mask backward: 0.62 -> 0.38 ms for the same bytes)
+template <int PX>
 __global__ __launch_bounds__(256) void bn_apply_q_kernel(const float* __restrict__ x, long xs, float* __restrict__ y, long ys,
                                                          int N, int C8, int HW, const float* __restrict__ mean,
                                                          const float* __restrict__ inv, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int act, float alpha,
                                                          u32x4q* __restrict__ q, long qns, int dt) {
     int n, cb;
-    long p2;
-    if (!q_decode((long)blockIdx.x * 256 + threadIdx.x, N, C8, HW / 2, n, cb, p2)) return;
-    float v0[8], v1[8];
+    long pp;
+    if (!q_decode((long)blockIdx.x * 256 + threadIdx.x, N, C8, HW / PX, n, cb, pp)) return;
+    float v[PX][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = cb * 8 + j;
         const float sc = gamma[c] * inv[c], m = mean[c], be = beta[c];
-        const float2 t = *reinterpret_cast<const float2*>(x + (long)n * xs + (long)c * HW + 2 * p2);
-        v0[j] = ghm_act(fmaf(t.x - m, sc, be), act, alpha);
-        v1[j] = ghm_act(fmaf(t.y - m, sc, be), act, alpha);
-        if (y) *reinterpret_cast<float2*>(y + (long)n * ys + (long)c * HW + 2 * p2) = make_float2(v0[j], v1[j]);
+        const float* xp = x + (long)n * xs + (long)c * HW + PX * pp;
+        float t[PX];
+        if constexpr (PX == 2) {
+            const float2 t2 = *reinterpret_cast<const float2*>(xp);
+            t[0] = t2.x; t[1] = t2.y;
+        } else {
+            t[0] = xp[0];
+        }
+#pragma unroll
+        for (int u = 0; u < PX; ++u) v[u][j] = ghm_act(fmaf(t[u] - m, sc, be), act, alpha);
+        if (y) {
+            float* yp = y + (long)n * ys + (long)c * HW + PX * pp;
+            if constexpr (PX == 2) *reinterpret_cast<float2*>(yp) = make_float2(v[0][j], v[1][j]);
+            else yp[0] = v[0][j];
+        }
     }
     const long ps = (long)N * qns;
-    u32x4q* o = q + (long)n * qns + (long)cb * HW + 2 * p2;
-    q_store8(o, v0, dt, ps);
-    q_store8(o + 1, v1, dt, ps);
+    u32x4q* o = q + (long)n * qns + (long)cb * HW + PX * pp;
+#pragma unroll
+    for (int u = 0; u < PX; ++u) q_store8(o + u, v[u], dt, ps);
 }
 
-// dx = gamma * inv * (dout * act'(y) - mean(dz) - xhat * mean(dz * xhat)): thread = 8 channels x 2 pixels
+// dx = gamma * inv * (dout * act'(y) - mean(dz) - xhat * mean(dz * xhat)): thread = 8 channels x PX pixels
+template <int PX>
 __global__ __launch_bounds__(256) void bn_bwd_apply_q_kernel(const float* __restrict__ dout, long ds, const float* __restrict__ y,
                                                              long ys, const float* __restrict__ x, long xs, float* __restrict__ dx,
                                                              long dxs, int N, int C8, int HW, const float* __restrict__ mean,
@@ -96,32 +112,48 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_q_kernel(const float* __rest
                                                              float alpha, u32x4q* __restrict__ q, long qns, int dt,
                                                              const float* __restrict__ beta) {
     int n, cb;
-    long p2;
-    if (!q_decode((long)blockIdx.x * 256 + threadIdx.x, N, C8, HW / 2, n, cb, p2)) return;
-    float v0[8], v1[8];
+    long pp;
+    if (!q_decode((long)blockIdx.x * 256 + threadIdx.x, N, C8, HW / PX, n, cb, pp)) return;
+    float v[PX][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = cb * 8 + j;
         const float m = mean[c], iv = inv[c], g = gamma[c] * iv;
         const float mb = sums[2 * c] * inv_count, mg = sums[2 * c + 1] * inv_count;
-        const long o = (long)c * HW + 2 * p2;
-        const float2 d = *reinterpret_cast<const float2*>(dout + (long)n * ds + o);
-        const float2 xx = *reinterpret_cast<const float2*>(x + (long)n * xs + o);
-        float2 yy;          // y == nullptr: recomputed from x with the forward pass's own expression (elementwise.hip bn_y)
+        const long o = (long)c * HW + PX * pp;
+        float d[PX], xx[PX], yy[PX];
+        if constexpr (PX == 2) {
+            const float2 d2 = *reinterpret_cast<const float2*>(dout + (long)n * ds + o);
+            const float2 x2 = *reinterpret_cast<const float2*>(x + (long)n * xs + o);
+            d[0] = d2.x; d[1] = d2.y; xx[0] = x2.x; xx[1] = x2.y;
+        } else {
+            d[0] = dout[(long)n * ds + o];
+            xx[0] = x[(long)n * xs + o];
+        }
+        // y == nullptr: recomputed from x with the forward pass's own expression (elementwise.hip bn_y)
         if (y) {
-            yy = *reinterpret_cast<const float2*>(y + (long)n * ys + o);
+            if constexpr (PX == 2) {
+                const float2 y2 = *reinterpret_cast<const float2*>(y + (long)n * ys + o);
+                yy[0] = y2.x; yy[1] = y2.y;
+            } else {
+                yy[0] = y[(long)n * ys + o];
+            }
         } else {
             const float be = beta[c];
-            yy = make_float2(ghm_act(fmaf(xx.x - m, g, be), act, alpha), ghm_act(fmaf(xx.y - m, g, be), act, alpha));
+#pragma unroll
+            for (int u = 0; u < PX; ++u) yy[u] = ghm_act(fmaf(xx[u] - m, g, be), act, alpha);
         }
-        v0[j] = g * (d.x * ghm_dact_from_out(yy.x, act, alpha) - mb - (xx.x - m) * iv * mg);
-        v1[j] = g * (d.y * ghm_dact_from_out(yy.y, act, alpha) - mb - (xx.y - m) * iv * mg);
-        if (dx) *reinterpret_cast<float2*>(dx + (long)n * dxs + o) = make_float2(v0[j], v1[j]);
+#pragma unroll
+        for (int u = 0; u < PX; ++u) v[u][j] = g * (d[u] * ghm_dact_from_out(yy[u], act, alpha) - mb - (xx[u] - m) * iv * mg);
+        if (dx) {
+            if constexpr (PX == 2) *reinterpret_cast<float2*>(dx + (long)n * dxs + o) = make_float2(v[0][j], v[1][j]);
+            else dx[(long)n * dxs + o] = v[0][j];
+        }
     }
     const long ps = (long)N * qns;
-    u32x4q* o = q + (long)n * qns + (long)cb * HW + 2 * p2;
-    q_store8(o, v0, dt, ps);
-    q_store8(o + 1, v1, dt, ps);
+    u32x4q* o = q + (long)n * qns + (long)cb * HW + PX * pp;
+#pragma unroll
+    for (int u = 0; u < PX; ++u) q_store8(o + u, v[u], dt, ps);
 }
 
 // Theano bilinear 2x (layers.py:13-26; elementwise.hip up_bilinear_fwd_kernel): thread = 8 channels x one coarse pixel,
@@ -380,6 +412,65 @@ __global__ __launch_bounds__(256) void maxpool2_mask_bwd_q_kernel(const unsigned
     }
 }
 
+// The same pass with a thread per FINE COLUMN (8 channels x the two rows of one window column): lanes along x write consecutive
+// 16-byte q units -- one kilobyte per store instruction.  The form above has a lane write four consecutive units (64 bytes), i.e.
+// 16 bytes per 64-byte segment and instruction over three planes x two rows: with the q tensor 6 bytes per element against
+// 1.25 read per element, the store pattern is what the pass costs.  Two neighbouring lanes read the same pooled element.
+template <bool BIAS>
+__global__ __launch_bounds__(256) void maxpool2_mask_bwd_qc_kernel(const unsigned char* __restrict__ mask,
+                                                                   const float* __restrict__ y, const float* __restrict__ dy,
+                                                                   float* __restrict__ dx, int N, int C8, int H, int W, int act,
+                                                                   float alpha, float* __restrict__ part, int bpp,
+                                                                   u32x4q* __restrict__ q, long qns, int dt) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long hwp = (long)Ho * Wo, hw = (long)H * W, items = (long)Ho * W;
+    const int blk = blockIdx.x % bpp;
+    const long ncb = blockIdx.x / bpp;
+    const int cb = (int)(ncb % C8), n = (int)(ncb / C8);
+    const long it = (long)blk * 256 + threadIdx.x;
+    const bool live = it < items;
+    const int i = live ? (int)(it / W) : 0, x = live ? (int)(it - (long)i * W) : 0;
+    const int c = x & 1;
+    float r0[8], r1[8], csum[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long pl = (long)n * C8 * 8 + cb * 8 + k;
+        const long po = pl * hwp + (long)i * Wo + (x >> 1);
+        const unsigned m = live ? mask[po] : 0u;
+        float g = live ? dy[po] : 0.f;
+        g *= y ? ghm_dact_from_out(live ? y[po] : 0.f, act, alpha) : ghm_dact_from_sign(m, act, alpha);
+        const bool b0 = (m >> c) & 1u, b1 = (m >> (2 + c)) & 1u;
+        r0[k] = b0 ? g : 0.f;
+        r1[k] = b1 ? g : 0.f;
+        csum[k] = g * (float)((int)b0 + (int)b1);
+        if (dx && live) {
+            float* o = dx + pl * hw + (long)(2 * i) * W + x;
+            o[0] = r0[k];
+            o[W] = r1[k];
+        }
+    }
+    if (live) {
+        const long ps = (long)N * qns;
+        u32x4q* o = q + (long)n * qns + (long)cb * hw + (long)(2 * i) * W + x;
+        q_store8(o, r0, dt, ps);
+        q_store8(o + W, r1, dt, ps);
+    }
+    if constexpr (BIAS) {
+        __shared__ float red[4][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float s = csum[k];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const int k = threadIdx.x;
+            part[(long)(cb * 8 + k) * ((long)N * bpp) + (long)n * bpp + blk] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        }
+    }
+}
+
 // out[c] (+)= fixed-order sum of part[c][0 .. S)
 __global__ __launch_bounds__(64) void q_rows_sum_kernel(const float* __restrict__ part, int C, int S, float* __restrict__ out,
                                                         int accumulate) {
@@ -404,8 +495,12 @@ int ghm_bn_apply_q(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t y
     GHM_CHECK(q_dtype_ok(dtype) && yq && C % 8 == 0 && HW % 2 == 0 && xs % 2 == 0 && ys % 2 == 0 &&
               (((uintptr_t)x | (uintptr_t)y) & 7) == 0 && ((uintptr_t)yq & 15) == 0,
               "ghm_bn_apply_q: bf16 / f16, C %% 8 == 0, even HW and strides, aligned tensors");
-    hipLaunchKernelGGL(bn_apply_q_kernel, EWQ_GRID((long)N * (C / 8) * (HW / 2)), x, (long)xs, y, (long)ys, N, C / 8, HW, mean,
-                       inv, gamma, beta, act, alpha, (u32x4q*)yq, (long)yq_nstride, dtype);
+    if (GHM_OPT("GHM_Q_TWO_PIXELS"))         // two pixels per thread (the form before round 5)
+        hipLaunchKernelGGL(bn_apply_q_kernel<2>, EWQ_GRID((long)N * (C / 8) * (HW / 2)), x, (long)xs, y, (long)ys, N, C / 8, HW, mean,
+                           inv, gamma, beta, act, alpha, (u32x4q*)yq, (long)yq_nstride, dtype);
+    else
+        hipLaunchKernelGGL(bn_apply_q_kernel<1>, EWQ_GRID((long)N * (C / 8) * HW), x, (long)xs, y, (long)ys, N, C / 8, HW, mean,
+                           inv, gamma, beta, act, alpha, (u32x4q*)yq, (long)yq_nstride, dtype);
     GHM_LAUNCH_CHECK();
     return 0;
 }
@@ -424,9 +519,14 @@ int ghm_bn_backward_q(ghm_ctx* ctx, const float* dout, int64_t ds, const float* 
                                      gamma, beta))
         return e;
     const float* sums = (const float*)((const char*)ws + ghm_bn_workspace(C) - (size_t)C * 2 * sizeof(float));
-    hipLaunchKernelGGL(bn_bwd_apply_q_kernel, EWQ_GRID((long)N * (C / 8) * (HW / 2)), dout, (long)ds, y, (long)ys, x, (long)xs,
-                       dx, (long)dxs, N, C / 8, HW, mean, inv, gamma, sums, 1.f / (float)((long)N * HW), act, alpha,
-                       (u32x4q*)dxq, (long)dxq_nstride, dtype, beta);
+    if (GHM_OPT("GHM_Q_TWO_PIXELS"))
+        hipLaunchKernelGGL(bn_bwd_apply_q_kernel<2>, EWQ_GRID((long)N * (C / 8) * (HW / 2)), dout, (long)ds, y, (long)ys, x, (long)xs,
+                           dx, (long)dxs, N, C / 8, HW, mean, inv, gamma, sums, 1.f / (float)((long)N * HW), act, alpha,
+                           (u32x4q*)dxq, (long)dxq_nstride, dtype, beta);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_q_kernel<1>, EWQ_GRID((long)N * (C / 8) * HW), dout, (long)ds, y, (long)ys, x, (long)xs,
+                           dx, (long)dxs, N, C / 8, HW, mean, inv, gamma, sums, 1.f / (float)((long)N * HW), act, alpha,
+                           (u32x4q*)dxq, (long)dxq_nstride, dtype, beta);
     GHM_LAUNCH_CHECK();
     return 0;
 }
@@ -491,6 +591,25 @@ int ghm_maxpool2_mask_bwd_q(ghm_ctx* ctx, const uint8_t* mask, const float* y, c
                             int64_t dxq_nstride, int32_t dtype) {
     GHM_CHECK(q_dtype_ok(dtype) && dxq && C % 8 == 0 && H % 2 == 0 && W % 4 == 0 && ((uintptr_t)dx & 15) == 0 &&
               ((uintptr_t)dxq & 15) == 0, "ghm_maxpool2_mask_bwd_q: bf16 / f16, C %% 8 == 0, even H, W %% 4 == 0, aligned tensors");
+    if (!GHM_OPT("GHM_POOLBWD_WINDOWS")) {        // a thread per fine column (see the kernel); the switch restores a thread per window pair
+        const long items = (long)(H / 2) * W;
+        const int bpp = (int)ceil_div(items, 256);
+        const long blocks = (long)N * (C / 8) * bpp;
+        if (dbias) {
+            const int S = N * bpp;
+            void* ws = nullptr;
+            if (int e = ghm_scratch(ctx, (size_t)C * S * sizeof(float), &ws)) return e;
+            hipLaunchKernelGGL((maxpool2_mask_bwd_qc_kernel<true>), dim3(blocks), dim3(256), 0, ctx->stream, mask, y, dy, dx, N, C / 8,
+                               H, W, act, alpha, (float*)ws, bpp, (u32x4q*)dxq, (long)dxq_nstride, dtype);
+            GHM_LAUNCH_CHECK();
+            hipLaunchKernelGGL(q_rows_sum_kernel, dim3(C), dim3(64), 0, ctx->stream, (const float*)ws, C, S, dbias, accumulate);
+        } else {
+            hipLaunchKernelGGL((maxpool2_mask_bwd_qc_kernel<false>), dim3(blocks), dim3(256), 0, ctx->stream, mask, y, dy, dx, N,
+                               C / 8, H, W, act, alpha, (float*)nullptr, bpp, (u32x4q*)dxq, (long)dxq_nstride, dtype);
+        }
+        GHM_LAUNCH_CHECK();
+        return 0;
+    }
     const long items = (long)(H / 2) * (W / 4);
     const int bpp = (int)ceil_div(items, 256);
     const long blocks = (long)N * (C / 8) * bpp;

@@ -245,7 +245,7 @@ def test_reduced_precision_train_step(gpu, dtype):
     dev, ops, D = gpu
     cfg = ostep.default_cfg(**LP_STEP)
     model = build_model(cfg, 7, dev, dtype=dtype, use_graph=False)
-    f32 = build_model(cfg, 7, dev, use_graph=False)
+    f32 = build_model(cfg, 7, dev, dtype='f32', use_graph=False)
     assert model.engine.loss_scale == (32768.0 if dtype == 'f16' else 1.0)
     # the low-precision kernels really are in the program
     b = model.engine.built(4)
