@@ -7,7 +7,7 @@ run() { python bench.py --dtype $DT --steps 30 --warmup 5 --no-cpu-baseline --no
 b1=$(run); b2=$(run)
 echo "plain: $b1 $b2"
 for k in \
-  "sp_conv2_kernel<5" "sp_conv2_kernel<3, 1>" "sp_conv2_kernel<3, 2>" "sp_wgrad_kernel" "sp_dgrad_s2_kernel" \
+  "sp_conv2_kernel<5" "sp_conv2_kernel<3" "sp_wgrad_kernel" "sp_dgrad_s2_kernel" \
   "fanout_kernel,thin_wgrad_kernel,pool_thin,fanin_s1_kernel,fanin_s2_kernel,taps_as_rows" \
   "igemm_kernel,wgrad_kernel,direct_smallr,smallk_dgrad,dense" \
   "bn_fwd" "bn_bwd" "maxpool_mask_bwd,maxpool_bwd,maxpool_fwd" "up_bilinear_fwd,up_bilinear_bwd" "q_pack,lp_pack" "bias_grad,act_bwd"; do
