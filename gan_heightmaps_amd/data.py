@@ -14,7 +14,6 @@ import ctypes as C
 import numpy as np
 
 from ._lib import call
-from .device import DevTensor
 
 
 class ImageDataGenerator:

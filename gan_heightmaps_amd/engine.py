@@ -20,7 +20,7 @@ import numpy as np
 
 from . import layers as L
 from .architectures.layers import BilinearUpsample2DLayer
-from .device import SPLIT, SPLITS, DevTensor, Ops, QTensor, conv_desc, pack_conv_w, unpack_conv_w
+from .device import SPLITS, DevTensor, QTensor, conv_desc, pack_conv_w, unpack_conv_w
 from .nonlinearities import linear
 
 ALIGN = 64      # elements; keeps every parameter 256-B aligned inside the flat buffers
