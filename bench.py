@@ -288,9 +288,30 @@ def measure(args, secondary_name=None):
                                                       meta["geom"] if meta else ""), file=sys.stderr)
         # the thin first / last layers (<= 4 channels on one side) are HBM-bound: reported against their byte floor
         # (input + output tensor once) and the 8 TB/s HBM peak, not against the MFMA peak
+        # ... timed WARM: ten launches back to back behind three untimed ones.  (One launch between two events behind a host
+        # synchronisation -- the table above -- charges a 20-100 us kernel its launch latency from an idle GPU: 78 against
+        # 21 us on the U-Net's first layer.)
+        warm = {}
+        for lane in (0, 1):
+            for e in b.train_compute[lane]:
+                if len(e) > 2 and e[2] and e[2].get("thin"):
+                    d_ = e[3] if len(e) > 3 and e[3] is not None else eng.devs[lane]
+                    eng.sync()
+                    for _ in range(3):
+                        e[1]()
+                    d_.timer_start(1)
+                    for _ in range(10):
+                        e[1]()
+                    d_.timer_stop(1)
+                    warm[id(e[2])] = d_.timer_ms(1) / 10
+        eng.sync()
+        table = [(label, warm.get(id(meta), ms), meta, lane_) for label, ms, meta, lane_ in table]
         thin_rows = [{"entry": label, "kernel": meta["kernel"].split(" splits")[0], "geom": meta["geom"], "ms": round(ms, 4),
                       "algorithmic_MB": round(meta["bytes"] / 1e6, 1), "GB/s": round(meta["bytes"] / ms / 1e6, 1),
-                      "frac_of_8TB/s": round(meta["bytes"] / ms / 1e6 / 8000.0, 3)}
+                      "frac_of_8TB/s": round(meta["bytes"] / ms / 1e6 / 8000.0, 3),
+                      # what the launch really moves (the q copy of its result on top of / instead of the fp32 tensor)
+                      "moved_MB": round(meta.get("moved_bytes", meta["bytes"]) / 1e6, 1),
+                      "moved_GB/s": round(meta.get("moved_bytes", meta["bytes"]) / ms / 1e6, 1)}
                      for label, ms, meta, _lane in table if meta and meta.get("thin") and ms > 0]
         dominant = max((k for k in by_kernel if by_kernel[k][2] > 0), key=lambda k: by_kernel[k][0])
         launches_per_step = by_kernel[dominant][1]
@@ -450,7 +471,8 @@ def measure(args, secondary_name=None):
         "steady_state": steady,
         "value_with_h2d": round(with_h2d, 3) if with_h2d else None,
         "value_with_h2d_synchronous": round(with_h2d_sync, 3) if with_h2d_sync else None,
-        "hbm_bound_layers": {"note": "thin first / last layers, each launch timed alone (cold clocks); bound = HBM 8 TB/s",
+        "hbm_bound_layers": {"note": "thin first / last layers, each timed alone and warm (ten launches back to back); bound = HBM 8 TB/s; "
+                                     "moved_* counts the q copy a first layer also writes",
                              "total_ms": round(sum(r["ms"] for r in thin_rows), 3), "launches": thin_rows} if thin_rows else None,
     }
     if world > 1:

@@ -596,6 +596,10 @@ class NetPlan:
                          self.ops.lp_pack_weights(d, w, wq, self.dtype, t)))
         return wq
 
+    def _q_bytes(self):
+        """bytes per element of a q tensor in this engine's arithmetic (2 per piece)"""
+        return 2.0 * SPLITS.get(self.dtype, 1)
+
     def _conv_bn_fusable(self, n, d, xq, deterministic):
         """-> the BatchNorm node behind convolution n when the pair runs as one product (ghm_conv2d_bn_fwd_lp_q), else None"""
         if (n.op != 'conv' or deterministic or self.bn_groups != 1 or n.act != linear or len(n.consumers) != 1
@@ -719,7 +723,8 @@ class NetPlan:
                 elif n.op == 'conv' and n.outq is not None and ops.thin_fwd_q_supported(d, a.kind, False, self.dtype):
                     q_direct = True         # a first layer (fp32 operands) whose epilogue also writes the q copy
                     prog.append(("conv_fwd", lambda d=d, x=x, w=w, b=b, y=y, yq=n.outq, a=a:
-                                 ops.conv2d_fwd_thin_q(d, x, w, b, y, yq, a.kind, a.alpha), conv_meta(ops, d, 0)))
+                                 ops.conv2d_fwd_thin_q(d, x, w, b, y, yq, a.kind, a.alpha),
+                                 conv_meta(ops, d, 0, moved=4.0 * d.N * d.C * d.H * d.W + (4.0 + self._q_bytes()) * d.N * d.K * d.Ho * d.Wo)))
                 else:
                     prog.append(("%s_fwd" % n.op, lambda d=d, x=x, w=w, b=b, y=y, a=a:
                                  ops.conv2d_fwd(d, x, w, b, y, a.kind, a.alpha), conv_meta(ops, d, 0)))
@@ -742,7 +747,9 @@ class NetPlan:
                     q_direct = True
                     prog.append(("convpool_fwd", lambda d=d, x=x, w=w, b=b, y=y, yq=n.outq, m=n.aux['mask'], a=a:
                                  ops.conv2d_fwd_pool_thin_q(d, x, w, b, y, m, yq, a.kind, a.alpha),
-                                 conv_meta(ops, d, 0, 'f32', pooled=True)))
+                                 conv_meta(ops, d, 0, 'f32', pooled=True,
+                                           moved=4.0 * d.N * d.C * d.H * d.W + ((0.0 if y is None else 4.0) + 1.0 + self._q_bytes())
+                                           * d.N * d.K * (d.Ho // 2) * (d.Wo // 2))))
                 else:
                     prog.append(("convpool_fwd", lambda d=d, x=x, wsrc=wsrc, b=b, y=y, m=n.aux['mask'], a=a, dt=dt:
                                  ops.conv2d_fwd_pool(d, x, wsrc, b, y, m, a.kind, a.alpha, dt),
@@ -1380,7 +1387,7 @@ class NetPlan:
                 for l in input_grads}
 
 
-def conv_meta(ops, d, kind, dtype='f32', pooled=False, extra=''):
+def conv_meta(ops, d, kind, dtype='f32', pooled=False, extra='', moved=None):
     """roofline metadata of one conv launch: kernel variant name and ALGORITHMIC flops (2 x MACs)."""
     if pooled:
         name = ("sp_conv2_kernel<%d, %d> fwd+pool" % (d.kh, d.stride)) if dtype in SPLITS else \
@@ -1398,7 +1405,10 @@ def conv_meta(ops, d, kind, dtype='f32', pooled=False, extra=''):
     xb, yb = 4.0 * d.N * d.C * d.H * d.W, 4.0 * d.N * d.K * d.Ho * d.Wo
     if pooled:
         yb = yb / 4 + yb / 16
-    return {"kernel": name, "dtype": dtype, "bytes": xb + yb, "thin": min(d.C, d.K) <= 4,
+    # ``moved``: the bytes the launch really moves where they differ from the algorithmic ones (a first layer that also writes
+    # the q copy of its result: 2 bytes per piece and element more; a pooled one whose fp32 tensor is not written: 4 less)
+    return {"kernel": name, "dtype": dtype, "bytes": xb + yb, "moved_bytes": (xb + yb) if moved is None else moved,
+            "thin": min(d.C, d.K) <= 4,
             "flops": 2.0 * d.N * d.K * d.Ho * d.Wo * d.C * d.kh * d.kw,
             "geom": "N%d C%d %dx%d K%d k%d s%d%s" % (d.N, d.C, d.H, d.W, d.K, d.kh, d.stride, extra)}
 
