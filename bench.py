@@ -466,6 +466,12 @@ def measure(args, secondary_name=None):
         # 3x3 form): this is what the matrix cores actually do per second
         "step_executed_tflops": round(executed_flops_per_step / (ms_per_step * 1e-3) / 1e12 * world, 2)
         if executed_flops_per_step else None,
+        "step_executed_frac_of_peak": round(executed_flops_per_step / (ms_per_step * 1e-3) / 1e12 / PEAK[args.dtype], 4)
+        if executed_flops_per_step else None,
+        # the reference's graph walks the DCGAN discriminator backward twice on the fake half (generator loss, discriminator
+        # loss); the step walks it once and takes the generator-loss gradient as a per-sample multiple: the
+        # algorithmic figure above still prices both passes, the executed one does not
+        "generator_gradient_from_discriminator_pass": any(e[0] == "per_sample_ratio" for e in b.train_compute[0]),
         "losses": [float(x) for x in losses],
         # inputs uploaded from host arrays every step (the reference's train_fn(Z, X, Y) boundary); never ``value``
         "steady_state": steady,

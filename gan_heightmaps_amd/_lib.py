@@ -143,6 +143,7 @@ SIGNATURES = {
     "ghm_upsample_bilinear2_fwd": [_p, _p, _i64, _p, _i32, _i32, _i32, _i32],
     "ghm_upsample_bilinear2_bwd": [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32],
     "ghm_copy_view": [_p, _p, _i64, _p, _i64, _i32, _i32, _i32, _i32],
+    "ghm_scale_samples": [_p, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _i64],
     "ghm_axpby": [_p, _f, _p, _f, _p, _i64],
     "ghm_image_batch": [_p, _p, _i32, _i32, _i32, _i32, _p, _i32, _p, _i64],
     "ghm_lsgan_loss": [_p, _p, _i64, _f, _p, _p, _f, _i32],

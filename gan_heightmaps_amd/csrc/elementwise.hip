@@ -312,6 +312,20 @@ __global__ __launch_bounds__(256) void copy_view_kernel(const float* __restrict_
     }
 }
 
+// x[n, ...] *= num[n] / den[n]  (0 where den[n] == 0): the per-sample factor between two backward passes through a net whose output
+// is ONE scalar per sample -- the pass is linear in that scalar's gradient (step.py, "rank-one" generator gradient)
+template <int VEC>
+__global__ __launch_bounds__(256) void scale_samples_kernel(float* __restrict__ x, long xs, View v, const float* __restrict__ num,
+                                                            long nums, const float* __restrict__ den, long dens) {
+    long n, c, i;
+    if (!decode<VEC>(v, n, c, i)) return;
+    const float d = den[n * dens];
+    const float r = d != 0.f ? num[n * nums] / d : 0.f;
+    float* p = x + n * xs + c * v.HW + i;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) p[k] *= r;
+}
+
 __global__ void axpby_kernel(float a, const float* __restrict__ x, float b, float* __restrict__ y, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = a * x[i] + (b != 0.f ? b * y[i] : 0.f);
@@ -1324,6 +1338,20 @@ int ghm_copy_view(ghm_ctx* ctx, const float* x, int64_t xs, float* y, int64_t ys
         hipLaunchKernelGGL((copy_view_kernel<4>), EW_GRID((long)N * C * (HW / 4)), x, (long)xs, y, (long)ys, v, accumulate);
     } else {
         hipLaunchKernelGGL((copy_view_kernel<1>), EW_GRID((long)N * C * HW), x, (long)xs, y, (long)ys, v, accumulate);
+    }
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+int ghm_scale_samples(ghm_ctx* ctx, float* x, int64_t xs, int32_t N, int32_t C, int32_t HW, const float* num, int64_t num_nstride,
+                      const float* den, int64_t den_nstride) {
+    const View v{N, C, HW};
+    if (HW % 4 == 0) {
+        hipLaunchKernelGGL((scale_samples_kernel<4>), EW_GRID((long)N * C * (HW / 4)), x, (long)xs, v, num, (long)num_nstride, den,
+                           (long)den_nstride);
+    } else {
+        hipLaunchKernelGGL((scale_samples_kernel<1>), EW_GRID((long)N * C * HW), x, (long)xs, v, num, (long)num_nstride, den,
+                           (long)den_nstride);
     }
     GHM_LAUNCH_CHECK();
     return 0;

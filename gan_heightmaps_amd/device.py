@@ -918,6 +918,11 @@ class Ops:
         assert x.shape == y.shape
         call("ghm_copy_view", self.h, _vp(x), x.nstride, _vp(y), y.nstride, x.N, x.Cc, x.HW, int(accumulate))
 
+    def scale_samples(self, x, num, den):
+        """x[n] *= num[n] / den[n] (0 where den[n] == 0); num, den: one value per sample"""
+        assert num.N == x.N and den.N == x.N and num.Cc * num.HW == 1 and den.Cc * den.HW == 1
+        call("ghm_scale_samples", self.h, _vp(x), x.nstride, x.N, x.Cc, x.HW, _vp(num), num.nstride, _vp(den), den.nstride)
+
     def axpby(self, a, x, b, y, n):
         call("ghm_axpby", self.h, a, _vp(x), b, _vp(y), int(n))
 

@@ -894,12 +894,15 @@ class NetPlan:
 
     # ---- backward --------------------------------------------------------------------------------
     def emit_backward(self, prog, seed, nslice=None, wgrad=True, input_grads=(), accumulate_wgrad=False, tag="bwd",
-                      transposed=None, on_grads=None):
+                      transposed=None, on_grads=None, resume=None):
         """Append the backward program.  ``seed``: DevTensor holding dLoss/d(output) (it may be modified in
         place).  ``nslice=(n0, n1)``: run on that sample range of the saved activations.  ``input_grads``:
         InputLayers whose gradient is wanted.  Returns {InputLayer: DevTensor grad}.
         ``on_grads(prog, params)``: called (with wgrad) right after the last launch that writes the gradients of
-        ``params`` has been appended -- the data-parallel exchange hangs its sub-bucket all-reduces there (step.py)."""
+        ``params`` has been appended -- the data-parallel exchange hangs its sub-bucket all-reduces there (step.py).
+        ``resume={node: gradient w.r.t. node.out}`` (instead of ``seed``): start from gradients an EARLIER emit of this plan
+        left behind (``grads_of``) and walk on from those nodes only -- the tail of a pass whose head another pass already
+        ran (step.py: the generator gradient of a per-sample-scalar discriminator)."""
         ops, st, dev = self.ops, self.store, self.dev
         n0, n1 = nslice if nslice is not None else (0, self.batch)
         nb = n1 - n0
@@ -955,9 +958,19 @@ class NetPlan:
                                           "ran (unsupported graph ordering)")
             return grad_of(n), id(n) in written
 
-        grads[id(self.out_node)] = seed
-        written.add(id(self.out_node))
-        mark_written(self.out_node)
+        if resume is None:
+            grads[id(self.out_node)] = seed
+            written.add(id(self.out_node))
+            mark_written(self.out_node)
+        else:
+            for rn, rg in resume.items():
+                grads[id(rn)] = rg
+                written.add(id(rn))
+                mark_written(rn)
+                # what the earlier pass left in the buffer of a layer with its own nonlinearity is the gradient in FRONT of it
+                # (act_bwd runs in place, or the consumer's data gradient applied it in its epilogue)
+                if rn.op in ('conv', 'deconv', 'dense') and rn.act != linear:
+                    rn.aux[('grad_is_pre', key)] = True
 
         def done(*params):
             if on_grads is not None and wgrad:
@@ -1383,8 +1396,13 @@ class NetPlan:
             prog.append(("expand_wgrad", lambda tab=tab, aw=accumulate_wgrad, wo=wo: wo.upconv_expand_batched(tab, aw),
                          None, wdev))
             done(*expand_params)
+        self._last_grads = dict(grads)
         return {l: (grad_of(self.node_of_layer[id(l)]) if id(self.node_of_layer[id(l)]) in written else None)
                 for l in input_grads}
+
+    def grads_of(self, node):
+        """the buffer the LAST emit_backward of this plan holds the gradient w.r.t. ``node.out`` in (None: never written)"""
+        return getattr(self, '_last_grads', {}).get(id(node))
 
 
 def conv_meta(ops, d, kind, dtype='f32', pooled=False, extra='', moved=None):

@@ -423,10 +423,27 @@ class GanStep:
             b.D.emit_transposes(ta, tdone)
             b.G.emit_transposes(ta, tdone)
             hook, flush = bucketer('dcgan_disc', 0, ta) if self.exchange else nohook
+            n1 = self._per_sample_scalar_head(b.D, d_in_layer)
+            if n1 is not None:
+                # the fake half of the discriminator-loss seed, kept aside (a backward pass may modify its seed in place)
+                b.seed_Df = dA.empty(d_fake.shape)
+                ta.append(("seed_copy", lambda: oA.copy_view(b.seed_D.samples(B, 2 * B), b.seed_Df)))
             b.D.emit_backward(ta, b.seed_D, wgrad=True, tag="dloss", transposed=tdone, on_grads=hook)
             flush()
-            gin = b.D.emit_backward(ta, b.seed_G, nslice=(B, 2 * B), wgrad=False, input_grads=[d_in_layer],
-                                    tag="gloss", transposed=tdone)
+            if n1 is not None:
+                # D returns ONE scalar per sample and no layer couples samples: its backward pass on sample n is linear in
+                # the single number dLoss/dD(G(z))_n, so the generator-loss gradient at every depth is the discriminator-loss
+                # gradient of the fake half times seed_G[n] / seed_D[n].  The dloss pass above already walked the fake half
+                # down to the first layer's output; only that layer's data gradient is left, then one per-sample factor
+                # (:107-108: both losses read the same D(G(z)); 12 -> 8 image-backward passes through D per step).
+                g1 = b.D.grads_of(n1).samples(B, 2 * B)
+                gin = b.D.emit_backward(ta, None, nslice=(B, 2 * B), wgrad=False, input_grads=[d_in_layer],
+                                        tag="gloss", transposed=tdone, resume={n1: g1})
+                gfake = gin[d_in_layer]
+                ta.append(("per_sample_ratio", lambda: oA.scale_samples(gfake, b.seed_G, b.seed_Df)))
+            else:
+                gin = b.D.emit_backward(ta, b.seed_G, nslice=(B, 2 * B), wgrad=False, input_grads=[d_in_layer],
+                                        tag="gloss", transposed=tdone)
             hook, flush = bucketer('dcgan_gen', 0, ta) if self.exchange else nohook
             b.G.emit_backward(ta, gin[d_in_layer], wgrad=True, transposed=tdone, on_grads=hook)
             flush()
@@ -532,6 +549,21 @@ class GanStep:
         b.graphs = {}
         b.calls = {}
         return b
+
+    @staticmethod
+    def _per_sample_scalar_head(plan, in_layer):
+        """-> the node that reads ``in_layer`` if the generator-loss gradient through this discriminator may be taken from its
+        discriminator-loss pass (see _build), else None: one scalar per sample out, no BatchNorm / InstanceNorm node (batch
+        statistics couple the samples; the normalisation backward is not sliced), one conv reader of the input.
+        GHM_NO_RANK_ONE=1 keeps the two separate passes (the A/B switch of tests/test_gpu_step.py)."""
+        if os.environ.get('GHM_NO_RANK_ONE'):
+            return None
+        if int(np.prod(plan.out.shape[1:])) != 1 or any(n.op == 'bn' for n in plan.order):
+            return None
+        node = plan.node_of_layer[id(in_layer)]
+        if len(node.consumers) != 1 or node.consumers[0].op not in ('conv', 'convpool'):
+            return None
+        return node.consumers[0]
 
     def built(self, B, slot=0):
         """the plan set of batch size B; slot 1 = a second, independent set (own activations and input buffers, the same

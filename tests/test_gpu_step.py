@@ -477,6 +477,48 @@ def test_gradient_side_streams_bitwise(dev):
     assert build_model(cfg, 11, dev).engine.side[0] is None
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3"])
+@pytest.mark.parametrize("lsgan", [True, False])
+def test_generator_gradient_from_the_discriminator_loss_pass(dev, monkeypatch, dtype, lsgan):
+    """The DCGAN discriminator returns one scalar per sample and (bn=False) couples no samples, so its backward pass on a fake
+    sample is linear in ONE number: the step takes dgen_loss/dG(z) as the discriminator-loss pass's fake half times
+    seed_G[n] / seed_D[n] (step.py, `per_sample_ratio`) instead of walking D a second time.  A/B against the two separate
+    passes (GHM_NO_RANK_ONE=1): same losses, generator gradients equal to fp32 rounding, every other net bit-identical; a
+    BatchNorm discriminator keeps the separate pass."""
+    over = dict(SMALL, lsgan=lsgan)
+    if not lsgan:
+        over.update(disc_dcgan=dict(nch=16, div=[4, 2, 2], nonlinearity='sigmoid'),
+                    disc_p2p=dict(nf=4, mul_factor=[1, 2], act='sigmoid'))
+    cfg = ostep.default_cfg(**over)
+    B = 4
+    labels = lambda m: [e[0] for e in m.engine.built(B).train_compute[0]]
+    one = build_model(cfg, 7, dev, dtype=dtype)
+    monkeypatch.setenv("GHM_NO_RANK_ONE", "1")
+    two = build_model(cfg, 7, dev, dtype=dtype)
+    two.engine.built(B)
+    monkeypatch.delenv("GHM_NO_RANK_ONE")
+    assert "per_sample_ratio" in labels(one) and "per_sample_ratio" not in labels(two)
+    assert len(labels(one)) < len(labels(two))
+    for it in range(3):          # step 0 eager, step 1 recorded, step 2 replayed
+        Z, X, Y = ostep.synthetic_batch(B, cfg, seed=300 + it)
+        la, lb = one.train_fn(Z, X, Y), two.train_fn(Z, X, Y)
+        ga, gb = model_grads(one), model_grads(two)
+        if it == 0:
+            assert la == lb                  # the losses are taken before either backward pass
+        else:                                # (the two generators have taken steps that differ by rounding since)
+            assert rel(la, lb) < 1e-5
+        for key in ga:
+            fa, fb = (np.concatenate([g.ravel() for g in x[key]]) for x in (ga, gb))
+            assert np.linalg.norm(fb) > 1e-6
+            if it == 0 and key != ('dcgan', 'gen'):
+                assert np.array_equal(fa, fb), key
+            else:
+                assert rel(fa, fb) < (2e-6 if it == 0 else 1e-4), (it, key, rel(fa, fb))
+    # a discriminator with BatchNorm couples its samples: the separate pass stays
+    bn = build_model(ostep.default_cfg(**dict(SMALL, disc_dcgan=dict(nch=16, div=[4, 2, 2], bn=True))), 7, dev, dtype=dtype)
+    assert "per_sample_ratio" not in labels(bn)
+
+
 @pytest.mark.parametrize("variant", ["plain", "adam_bn_disc", "one_rank_exchange", "one_rank_exchange_subbuckets"])
 def test_recorded_step_is_the_eager_schedule_in_one_call(dev, variant):
     """use_graph='recorded' (ghm_step_record_begin / ghm_step_run): the eager four-stream launch sequence -- gradient
