@@ -638,12 +638,16 @@ __global__ __launch_bounds__(256) void scalar_loss_kernel(const float* __restric
 }
 
 // fixed-order sum of the block partials: losses are bit-for-bit repeatable (no float atomics)
-__global__ void loss_final_kernel(const double* __restrict__ part, int nblocks, float* loss_out, int accumulate) {
+// (one wave: lane l sums partials l, l + 64, ... in order, then a butterfly -- a single thread walked up to 1024 dependent
+// loads, half of the 85 us the reconstruction loss took at 512^2)
+__global__ __launch_bounds__(64) void loss_final_kernel(const double* __restrict__ part, int nblocks, float* loss_out, int accumulate) {
     double s = 0.0;
-    for (int i = 0; i < nblocks; ++i) s += part[i];
-    loss_out[0] = (accumulate ? loss_out[0] : 0.f) + (float)s;
+    for (int i = threadIdx.x; i < nblocks; i += 64) s += part[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) loss_out[0] = (accumulate ? loss_out[0] : 0.f) + (float)s;
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict__ a, long as, const float* __restrict__ b,
                                                          long bs, View v, int l2, float* __restrict__ grad, long gs,
                                                          float gscale, int accumulate, double* __restrict__ part,
@@ -651,21 +655,37 @@ __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict
     const long chw = (long)v.C * v.HW, total = (long)v.N * chw;
     double acc = 0.0;
     if (ls) gscale *= ls[0];
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const long n = e / chw, o = e - n * chw;
-        const float dlt = a[n * as + o] - b[n * bs + o];
-        float g;
-        if (l2) {
-            acc += (double)dlt * dlt;
-            g = 2.f * dlt;
+    // VEC consecutive elements of one sample per thread and iteration (16-byte loads / stores where the views allow it)
+    const long per = chw / VEC, groups = (long)v.N * per;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < groups; e += (long)gridDim.x * 256) {
+        const long n = e / per, o = (e - n * per) * VEC;
+        float av[VEC], bv[VEC], pv[VEC];
+        if (VEC == 4) {
+            *reinterpret_cast<float4*>(av) = *reinterpret_cast<const float4*>(a + n * as + o);
+            *reinterpret_cast<float4*>(bv) = *reinterpret_cast<const float4*>(b + n * bs + o);
+            if (grad && accumulate) *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(grad + n * gs + o);
         } else {
-            acc += fabsf(dlt);
-            g = (dlt > 0.f) ? 1.f : (dlt < 0.f ? -1.f : 0.f);
+            av[0] = a[n * as + o];
+            bv[0] = b[n * bs + o];
+            if (grad && accumulate) pv[0] = grad[n * gs + o];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float dlt = av[k] - bv[k];
+            float g;
+            if (l2) {
+                acc += (double)dlt * dlt;
+                g = 2.f * dlt;
+            } else {
+                acc += fabsf(dlt);
+                g = (dlt > 0.f) ? 1.f : (dlt < 0.f ? -1.f : 0.f);
+            }
+            const float w = gscale * g / (float)total;
+            pv[k] = (grad && accumulate) ? pv[k] + w : w;
         }
         if (grad) {
-            float* p = grad + n * gs + o;
-            const float w = gscale * g / (float)total;
-            *p = accumulate ? *p + w : w;
+            if (VEC == 4) *reinterpret_cast<float4*>(grad + n * gs + o) = *reinterpret_cast<const float4*>(pv);
+            else grad[n * gs + o] = pv[0];
         }
     }
     __shared__ double red[4];
@@ -1530,7 +1550,7 @@ static int scalar_loss(ghm_ctx* ctx, const float* d, int64_t n, float target, in
     hipLaunchKernelGGL(scalar_loss_kernel, dim3(g), dim3(256), 0, ctx->stream, d, (long)n, target, kind, grad, grad_scale,
                        (double*)ws, (const float*)ctx->ls_state);
     GHM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1), 0, ctx->stream, (const double*)ws, g, loss_out,
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)ws, g, loss_out,
                        accumulate_loss);
     GHM_LAUNCH_CHECK();
     return 0;
@@ -1552,10 +1572,16 @@ int ghm_recon_loss(ghm_ctx* ctx, const float* a, int64_t as, const float* b, int
     const int g = loss_grid((long)N * C * HW);
     void* ws = nullptr;
     if (int e = ghm_scratch(ctx, (size_t)g * sizeof(double), &ws)) return e;
-    hipLaunchKernelGGL(recon_loss_kernel, dim3(g), dim3(256), 0, ctx->stream, a, (long)as, b, (long)bs, v, l2, grad, (long)gs,
-                       grad_scale, accumulate_grad, (double*)ws, (const float*)ctx->ls_state);
+    const bool v4 = ((long)C * HW) % 4 == 0 && as % 4 == 0 && bs % 4 == 0 && (grad == nullptr || gs % 4 == 0) && aligned16(a) &&
+                    aligned16(b) && aligned16(grad);
+    if (v4)
+        hipLaunchKernelGGL((recon_loss_kernel<4>), dim3(g), dim3(256), 0, ctx->stream, a, (long)as, b, (long)bs, v, l2, grad, (long)gs,
+                           grad_scale, accumulate_grad, (double*)ws, (const float*)ctx->ls_state);
+    else
+        hipLaunchKernelGGL((recon_loss_kernel<1>), dim3(g), dim3(256), 0, ctx->stream, a, (long)as, b, (long)bs, v, l2, grad, (long)gs,
+                           grad_scale, accumulate_grad, (double*)ws, (const float*)ctx->ls_state);
     GHM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1), 0, ctx->stream, (const double*)ws, g, loss_out, 0);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)ws, g, loss_out, 0);
     GHM_LAUNCH_CHECK();
     return 0;
 }
