@@ -618,7 +618,8 @@ __global__ __launch_bounds__(256) void image_batch_kernel(const unsigned char* _
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scalar_loss_kernel(const float* __restrict__ d, long n, float target, int kind,
                                                           float* __restrict__ grad, float gscale, double* __restrict__ part,
-                                                          const float* __restrict__ ls) {
+                                                          const float* __restrict__ ls, float* __restrict__ loss_out,
+                                                          int accumulate) {
     double acc = 0.0;
     if (ls) gscale *= ls[0];            // dynamic loss scale (fp16 products): a device scalar, so replays see it change
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -634,7 +635,12 @@ __global__ __launch_bounds__(256) void scalar_loss_kernel(const float* __restric
     }
     __shared__ double red[4];
     acc = block_sum(acc, red);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc / (double)n;
+    if (threadIdx.x == 0) {
+        // a single block (the discriminators' outputs: 8 .. 2048 values) finishes the loss itself: the same value
+        // loss_final_kernel would produce from one partial, one launch less on the stage stream's turn-around
+        if (gridDim.x == 1) loss_out[0] = (accumulate ? loss_out[0] : 0.f) + (float)(acc / (double)n);
+        else part[blockIdx.x] = acc / (double)n;
+    }
 }
 
 // fixed-order sum of the block partials: losses are bit-for-bit repeatable (no float atomics)
@@ -1548,11 +1554,13 @@ static int scalar_loss(ghm_ctx* ctx, const float* d, int64_t n, float target, in
     void* ws = nullptr;
     if (int e = ghm_scratch(ctx, (size_t)g * sizeof(double), &ws)) return e;
     hipLaunchKernelGGL(scalar_loss_kernel, dim3(g), dim3(256), 0, ctx->stream, d, (long)n, target, kind, grad, grad_scale,
-                       (double*)ws, (const float*)ctx->ls_state);
+                       (double*)ws, (const float*)ctx->ls_state, loss_out, accumulate_loss);
     GHM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)ws, g, loss_out,
-                       accumulate_loss);
-    GHM_LAUNCH_CHECK();
+    if (g > 1) {
+        hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)ws, g, loss_out,
+                           accumulate_loss);
+        GHM_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -114,6 +114,35 @@ def test_thin_layer_kernels(gpu, case, variants):
     assert rel(y1.numpy(), y2.numpy()) < 1e-5 and rel(dx1.numpy(), dx2.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("case", [(4, 64, 32, 32, 1, 3, 2, 1),      # pd_out (p2p.py:289): one filter, 3x3 stride 2
+                                  (3, 40, 4, 4, 1, 5, 1, 2),        # d_out (dcgan.py:50): one filter, 5x5 on the last 4x4 map
+                                  (2, 19, 10, 6, 1, 3, 1, 1)])      # ragged channel group, rectangular
+def test_one_filter_data_gradient_kernel(gpu, case):
+    """K == 1: a thread owns a pixel and eight channels (smallk1_dgrad_kernel) -- the same products in the same order as the
+    one-thread-per-element kernel it replaces (GHM_NO_SMALLK1=1): bit-identical, with and without the producer's
+    LeakyRectify backward in the epilogue."""
+    dev, ops, D = gpu
+    N, C, H, W, K, k, s, pad = case
+    d = D.conv_desc(N, C, H, W, K, k, k, s, pad)
+    assert ops.conv_variant(d, 1) == "smallk_dgrad_kernel"
+    _check_conv(gpu, case)
+    rng = np.random.RandomState(5)
+    dy = dev.tensor(rng.randn(N, K, d.Ho, d.Wo).astype(np.float32))
+    w = dev.tensor((rng.randn(C * k * k * K) / np.sqrt(C * k * k)).astype(np.float32))
+    xa = dev.tensor(rng.randn(N, C, H, W).astype(np.float32))
+    outs = []
+    for env in ({}, {"GHM_NO_SMALLK1": "1"}):
+        with tuning_env(**env):
+            a, b = dev.empty((N, C, H, W)), dev.empty((N, C, H, W))
+            ops.conv2d_dgrad(d, dy, w, a)
+            if ops.dgrad_dact_supported(d, 'f32') == 1:          # (form 1: reads the packed weights as they are)
+                ops.conv2d_dgrad_dact(d, dy, w, b, xa, 'lrelu', 0.2, 'f32')
+            else:
+                ops.conv2d_dgrad(d, dy, w, b)
+            outs.append((a.numpy(), b.numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def _check_conv(gpu, case):
     dev, ops, D = gpu
     N, C, H, W, K, k, s, pad = case
