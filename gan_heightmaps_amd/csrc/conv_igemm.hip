@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void smallk_dgrad_kernel(const SmallKDgradArgs
 // and CG consecutive channels (blockIdx.y = channel group: the weights are wave-uniform scalar loads): the tap decode and
 // the dy loads are paid once per CG outputs instead of once per output.  Same products in the same order as
 // smallk_dgrad_kernel (taps row-major, fmaf chain from the bias): bit-identical.  pd_out at 512^2, batch 8 (C512 32x32 k3
-// s2): 55 -> 17 us; it sits at the turn-around of the pix2pix stage stream, where nothing of that stage runs beside it.
+// s2): 55 -> 18 us; it sits at the turn-around of the pix2pix stage stream, where nothing of that stage runs beside it.
 template <int KS, int CG>
 __global__ __launch_bounds__(256) void smallk1_dgrad_kernel(const SmallKDgradArgs a) {
     const int HW = a.H * a.W;
