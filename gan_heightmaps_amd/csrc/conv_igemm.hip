@@ -1653,11 +1653,22 @@ __global__ __launch_bounds__(256) void channel_sum_partial(const float* __restri
     const long lo = sidx * chunk, hi = min(lo + chunk, total);
     float s = 0.f;
     if ((HW & 3) == 0 && (nstride & 3) == 0) {
-        for (long e = lo + threadIdx.x * 4; e < hi; e += 1024) {
-            const long n = e / HW, i = e - n * HW;
-            const float4 v = *reinterpret_cast<const float4*>(x + n * nstride + (long)c * HW + i);
-            s += (v.x + v.y) + (v.z + v.w);
+        // four 16-byte loads in flight per thread (one per iteration left a wave a single load deep: 2.4 TB/s on the 67 MB
+        // gradients of the 256^2 layers); the four partial sums are added in a fixed order
+        const float* xc = x + (long)c * HW;
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (long e = lo + threadIdx.x * 4; e < hi; e += 4096) {
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long ek = e + k * 1024;
+                const long n = ek / HW, i = ek - n * HW;
+                v[k] = ek < hi ? *reinterpret_cast<const float4*>(xc + n * nstride + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s4[k] += (v[k].x + v[k].y) + (v[k].z + v[k].w);
         }
+        s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     } else {
         for (long e = lo + threadIdx.x; e < hi; e += 256) {
             const long n = e / HW, i = e - n * HW;
