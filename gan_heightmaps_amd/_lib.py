@@ -105,6 +105,7 @@ SIGNATURES = {
     "ghm_split_pack": [_p, _p, _i64, _i32, _i32, _i32, _p, _i64, _i64, _i32],
     "ghm_split_pack_batched": [_p, _p, _i32, _i32, _i32],
     "ghm_conv2d_dgrad_dact_split": [_p, _D, _p, _i64, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _f, _i32],
+    "ghm_conv2d_dgrad_dact_split_q": [_p, _D, _p, _i64, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _f, _i32],
     "ghm_conv2d_wgrad_split_workspace": [_D, _p],
     "ghm_conv2d_wgrad_split": [_p, _D, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i32, _i32],
     "ghm_conv2d_fwd_pool_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _i32, _f, _i32],

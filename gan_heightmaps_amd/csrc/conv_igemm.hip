@@ -2384,6 +2384,7 @@ int ghm_conv2d_fwd_thin_q(ghm_ctx* ctx, const ghm_conv_desc* d, const float* x, 
                           int32_t act, float alpha, void* yq, int64_t yq_nstride, int32_t dtype) {
     if (int e = check_desc(d)) return e;
     GHM_CHECK(yq && ghm_thin_fwd_q_supported(d, act, 0, dtype), "ghm_conv2d_fwd_thin_q: not served (ask ghm_thin_fwd_q_supported)");
+    // (y == NULL: only the q copy is written)
     return thin_fanout_fwd(ctx, d, x, wp, bias, y, act, alpha, 0, yq, (long)yq_nstride, dtype);
 }
 

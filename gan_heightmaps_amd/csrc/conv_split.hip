@@ -860,6 +860,8 @@ struct SpDgradS2Extra {
     const float* dact_y;      // out *= act'(dact_y): the backward of the producer's nonlinearity in this epilogue (or null)
     long dact_nstride;
     float dact_alpha;
+    const uint2* dact_q;      // ... or the same slope from the SIGN of the first piece of the producer's q copy (half units of 4
+    long dact_q_nstride;      // channels; units between samples): 2 bytes per element in this epilogue's own register layout
 };
 
 // epilogue of the stride-2 data-gradient kernels: the four parity classes of a lane's class pixel interleaved into dx
@@ -884,7 +886,7 @@ __device__ __forceinline__ void sp_dgrad_s2_epilogue(const SpConvArgs& a, const 
     // PatchGAN's conv -> LeakyRectify -> conv chains), never both -- is fetched in ONE batch before anything else: 32 loads in
     // flight per lane instead of a round trip per channel row (the launches with such an operand took 1.5x the bare product:
     // 0.107 against 0.069 ms on N4 C64 256^2)
-    const bool do_acc = !plain && a.accumulate, do_y = !plain && yb != nullptr;
+    const bool do_acc = !plain && a.accumulate, do_y = !plain && yb != nullptr, do_yq = !plain && x.dact_q != nullptr;
     const float* const auxb = do_y ? yb : (do_acc ? ub : nullptr);
     const long auxs = do_y ? (long)HWx : rstride;
     float2 aux[2][TM][16];
@@ -898,6 +900,23 @@ __device__ __forceinline__ void sp_dgrad_s2_epilogue(const SpConvArgs& a, const 
                     const int k = i * 32 + (e & 3) + 8 * (e >> 2);
                     aux[pu][i][e] = rl + k < a.R ? *reinterpret_cast<const float2*>(auxb + (long)k * auxs + pu * a.W + lo)
                                                  : make_float2(0.f, 0.f);
+                }
+    }
+    if (do_yq) {
+        // the producer's q copy, piece 0: the half unit (channel block ru/8 + 4i + g, half kg) of the lane's two pixels per row
+        // parity -- 16 loads of 8 bytes instead of 32 (kept in the slots of ``aux``: the two operands never come together)
+        const uint2* const qd = x.dact_q + 2 * ((long)n * x.dact_q_nstride + (long)(ru / 8) * HWx + rowpix + 2 * li) + kg;
+#pragma unroll
+        for (int pu = 0; pu < 2; ++pu)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint2* q = qd + 2 * ((long)(i * 4 + g) * HWx + pu * a.W);
+                    const bool ok = rl + i * 32 + 8 * g < a.R;
+                    const uint2 h0 = ok ? q[0] : make_uint2(0u, 0u), h1 = ok ? q[2] : make_uint2(0u, 0u);
+                    aux[pu][i][2 * g] = make_float2(__uint_as_float(h0.x), __uint_as_float(h0.y));
+                    aux[pu][i][2 * g + 1] = make_float2(__uint_as_float(h1.x), __uint_as_float(h1.y));
                 }
     }
 #pragma unroll
@@ -938,6 +957,14 @@ __device__ __forceinline__ void sp_dgrad_s2_epilogue(const SpConvArgs& a, const 
                         if (do_y) {                     // relu / leaky relu: the slope of the producer
                             v.x *= aux[pu][i][e].x > 0.f ? 1.f : x.dact_alpha;
                             v.y *= aux[pu][i][e].y > 0.f ? 1.f : x.dact_alpha;
+                        }
+                        if (do_yq) {                    // the same from the bf16 first piece: x > 0 <=> its int16 pattern > 0
+                            const float2 h0 = aux[pu][i][2 * (e >> 2)], h1 = aux[pu][i][2 * (e >> 2) + 1];
+                            const unsigned w0 = __float_as_uint((e & 2) ? h0.y : h0.x), w1 = __float_as_uint((e & 2) ? h1.y : h1.x);
+                            const int s0 = (e & 1) ? ((int)w0 >> 16) : (int)(short)(w0 & 0xffffu);
+                            const int s1 = (e & 1) ? ((int)w1 >> 16) : (int)(short)(w1 & 0xffffu);
+                            v.x *= s0 > 0 ? 1.f : x.dact_alpha;
+                            v.y *= s1 > 0 ? 1.f : x.dact_alpha;
                         }
                     }
                     if (ub) *o = v;
@@ -1468,7 +1495,7 @@ int sp_launch_dgrad_s2(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, const SpDgr
         }
         if (pbytes) a.partial = (float*)((char*)ws + qbytes);
     }
-    GHM_CHECK(!(x.dact_y && pl.splits > 1), "split-fp32 stride-2 data gradient + activation derivative needs a single-pass plan");
+    GHM_CHECK(!((x.dact_y || x.dact_q) && pl.splits > 1), "split-fp32 stride-2 data gradient + activation derivative needs a single-pass plan");
     GHM_CHECK(!(a.out_q && pl.splits > 1), "split-fp32 stride-2 data gradient: a q output needs a single-pass plan");
     GHM_CHECK(a.out || a.out_q, "split-fp32 stride-2 data gradient: no output");
     GHM_CHECK(!(a.accumulate && !a.out), "accumulate needs the fp32 output");
@@ -1496,7 +1523,8 @@ bool sp_fwd_geom(const ghm_conv_desc* d) {
 
 static int sp_dgrad_s2(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, const void* dyq, long dyq_ns, long dyq_ps,
                        const void* wqT, const float* bias, float* dx, int act, float alpha, int accumulate, const float* dact_y,
-                       long dact_nstride, float dact_alpha, void* dxq, long dxq_ns, int np) {
+                       long dact_nstride, float dact_alpha, void* dxq, long dxq_ns, int np, const void* dact_q = nullptr,
+                       long dact_q_ns = 0) {
     const SpPlan pl = sp_plan_dgrad_s2(d, ctx->num_cu, np);
     GHM_CHECK(pl.ok, "split-fp32 stride-2 data gradient: geometry not served");
     SpConvArgs a;
@@ -1507,7 +1535,9 @@ static int sp_dgrad_s2(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy, co
     a.R = d->C; a.Rpad = sp_rpad(d->C); a.wq_pstride = (long)sp_nblk(d->K) * 9 * a.Rpad;
     a.out_nstride = d->x_nstride; a.pad = d->pad;
     a.act = act; a.alpha = alpha; a.accumulate = accumulate;
-    const SpDgradS2Extra x{dact_y, dact_nstride, dact_alpha};
+    const SpDgradS2Extra x{dact_y, dact_nstride, dact_alpha, (const uint2*)dact_q, dact_q_ns};
+    GHM_CHECK(!(dact_q && (dact_y || accumulate || d->C % 8)), "split-fp32 stride-2 data gradient: the slope from a q copy excludes "
+              "the fp32 operand and accumulation, and needs whole 8-channel blocks");
     return sp_launch_dgrad_s2(ctx, pl, a, x, dyq ? nullptr : dy, d->y_nstride);
 }
 
@@ -1696,6 +1726,20 @@ int ghm_conv2d_dgrad_dact_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void
     GHM_CHECK(act == GHM_ACT_RELU || act == GHM_ACT_LRELU, "ghm_conv2d_dgrad_dact_split: relu / leaky relu");
     return sp_dgrad_s2(ctx, d, nullptr, dyq, (long)dyq_nstride, (long)dyq_pstride, wqT, nullptr, dx, GHM_ACT_LINEAR, 0.f, 0, y,
                        (long)y_nstride, act == GHM_ACT_RELU ? 0.f : alpha, dxq, (long)dxq_nstride, pieces);
+}
+
+// the same with the slope taken from the producer's q copy (first piece plane at ``yq``, ``yq_nstride`` units between samples):
+// the producer's fp32 activation need not exist (engine.py: a conv -> LeakyRectify -> conv chain whose every reader takes q)
+int ghm_conv2d_dgrad_dact_split_q(ghm_ctx* ctx, const ghm_conv_desc* d, const void* dyq, int64_t dyq_nstride, int64_t dyq_pstride,
+                                  const void* wqT, float* dx, void* dxq, int64_t dxq_nstride, const void* yq, int64_t yq_nstride,
+                                  int32_t act, float alpha, int32_t pieces) {
+    GHM_CHECK(ctx && d && dyq && wqT && (dx || dxq) && yq, "null argument");
+    GHM_SP_PIECES_OK(pieces);
+    GHM_CHECK(ghm_split_dgrad_dact_supported(d) && d->C % 8 == 0,
+              "ghm_conv2d_dgrad_dact_split_q: not served (ask ghm_split_dgrad_dact_supported; C % 8 == 0)");
+    GHM_CHECK(act == GHM_ACT_RELU || act == GHM_ACT_LRELU, "ghm_conv2d_dgrad_dact_split_q: relu / leaky relu");
+    return sp_dgrad_s2(ctx, d, nullptr, dyq, (long)dyq_nstride, (long)dyq_pstride, wqT, nullptr, dx, GHM_ACT_LINEAR, 0.f, 0, nullptr,
+                       0, act == GHM_ACT_RELU ? 0.f : alpha, dxq, (long)dxq_nstride, pieces, yq, (long)yq_nstride);
 }
 
 }  // extern "C"

@@ -353,14 +353,16 @@ __global__ __launch_bounds__((4 * WS + 1) * 64, WS == 2 ? 1 : 2) void fanout_ker
 #pragma unroll
                         for (int e = 0; e < 16; ++e) acc[k][rb][e] = vals[e] > 0.f ? vals[e] : slope * vals[e];
                     }
+                    if (!QOUT || a.out != nullptr) {        // (a q-only launch: every reader of the result takes the q copy)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const unsigned row = (rb + rbo) * 32 + (e & 3) + 8 * (e >> 2);
-                        vec_t v;
-                        float* vp = reinterpret_cast<float*>(&v);
+                        for (int e = 0; e < 16; ++e) {
+                            const unsigned row = (rb + rbo) * 32 + (e & 3) + 8 * (e >> 2);
+                            vec_t v;
+                            float* vp = reinterpret_cast<float*>(&v);
 #pragma unroll
-                        for (int k = 0; k < NS; ++k) vp[k] = acc[k][rb][e];
-                        *reinterpret_cast<vec_t*>(ob + (lo + row * plane)) = v;
+                            for (int k = 0; k < NS; ++k) vp[k] = acc[k][rb][e];
+                            *reinterpret_cast<vec_t*>(ob + (lo + row * plane)) = v;
+                        }
                     }
                     if constexpr (QOUT) {   // rows 4g .. 4g+3 (+ 4h) of pixel NS*l + k: one half unit per (g, k)
                         if ((a.q_dt == 3 || a.q_dt == 4) && NS % 2 == 0) {

@@ -657,6 +657,12 @@ class Ops:
     def conv2d_dgrad_dact_lp_q(self, d, dyq, wqT, dx, dxq, y, act, alpha, dtype):
         if dtype in SPLITS:
             assert dxq is None or dxq.pstride == dxq.N * dxq.nstride
+            if isinstance(y, QTensor):          # the slope from the sign of the producer's q copy (its first piece plane)
+                assert y.dtype == dtype and y.shape[1:] == (d.C, d.H, d.W)
+                return call("ghm_conv2d_dgrad_dact_split_q", self.h, C.byref(d), C.c_void_p(dyq.ptr), dyq.nstride, dyq.pstride,
+                            _vp(wqT), _vp(dx), C.c_void_p(dxq.ptr) if dxq is not None else None,
+                            dxq.nstride if dxq is not None else 0, C.c_void_p(y.ptr), y.nstride, ACT_CODES[act], alpha,
+                            SPLITS[dtype])
             return call("ghm_conv2d_dgrad_dact_split", self.h, C.byref(d), C.c_void_p(dyq.ptr), dyq.nstride, dyq.pstride,
                         _vp(wqT), _vp(dx), C.c_void_p(dxq.ptr) if dxq is not None else None,
                         dxq.nstride if dxq is not None else 0, _vp(y), y.nstride, ACT_CODES[act], alpha, SPLITS[dtype])

@@ -527,6 +527,23 @@ class NetPlan:
                 return True
         return False
 
+    def _act_fp32_dropped(self, n):
+        """conv -> relu / leaky relu -> conv (the PatchGAN's chain, p2p.py:278-292) in the split modes: is the fp32 tensor of this
+        conv's activated output never read?  Its one consumer is a convolution whose forward and weight gradient read the q
+        copy and whose data gradient differentiates this layer's nonlinearity in its own epilogue from the SIGN of that q copy
+        (emit_backward, form 3 with ``ysrc`` = the q tensor).  GHM_KEEP_ACT_FP32=1 / GHM_DACT_FP32=1 keep the fp32 tensor."""
+        if (n.op != 'conv' or self.dtype not in SPLITS or not self.q_epi or not self.use_q or n.act.kind not in ('relu', 'lrelu')
+                or os.environ.get("GHM_KEEP_ACT_FP32") or os.environ.get("GHM_DACT_FP32")):
+            return False
+        if n is self.out_node or n.outq is None or n.alias is not None or len(n.consumers) != 1 or n.shape[1] % 8:
+            return False
+        c = n.consumers[0]
+        if c.op not in ('conv', 'convpool') or c.inputs[0] is not n or c.shape[1] % 8 or self._fp32_needed(n):
+            return False
+        # the consumer's data gradient must take the fused form that reads the q copy (the same tests as emit_backward)
+        dc = self._desc(c, n.out, self._full(c) if c.op == 'convpool' else c.out)
+        return self.ops.dgrad_dact_supported(dc, self.dtype) == 3
+
     def _pool_y_dropped(self, n):
         """fused conv + activation + max-pool node whose pooled fp32 tensor is never written: every consumer reads the q
         copy, and the backward pass takes the activation slope from the sign bit the forward kernel leaves in the mask"""
@@ -713,7 +730,8 @@ class NetPlan:
                     if xq is not None:
                         q_direct = n.outq is not None and ops.lp_q_direct(d, 0, self.dtype)
                         yq = n.outq if q_direct else None
-                        prog.append(("conv_fwd", lambda d=d, xq=xq, wq=wq, b=b, y=y, yq=yq, a=a:
+                        y32 = None if (q_direct and self._act_fp32_dropped(n)) else y
+                        prog.append(("conv_fwd", lambda d=d, xq=xq, wq=wq, b=b, y=y32, yq=yq, a=a:
                                      ops.conv2d_fwd_lp_q(d, xq, wq, b, y, yq, self.dtype, a.kind, a.alpha),
                                      conv_meta(ops, d, 0, self.dtype)))
                     else:
@@ -722,9 +740,11 @@ class NetPlan:
                                      conv_meta(ops, d, 0, self.dtype)))
                 elif n.op == 'conv' and n.outq is not None and ops.thin_fwd_q_supported(d, a.kind, False, self.dtype):
                     q_direct = True         # a first layer (fp32 operands) whose epilogue also writes the q copy
-                    prog.append(("conv_fwd", lambda d=d, x=x, w=w, b=b, y=y, yq=n.outq, a=a:
+                    y32 = None if self._act_fp32_dropped(n) else y
+                    prog.append(("conv_fwd", lambda d=d, x=x, w=w, b=b, y=y32, yq=n.outq, a=a:
                                  ops.conv2d_fwd_thin_q(d, x, w, b, y, yq, a.kind, a.alpha),
-                                 conv_meta(ops, d, 0, moved=4.0 * d.N * d.C * d.H * d.W + (4.0 + self._q_bytes()) * d.N * d.K * d.Ho * d.Wo)))
+                                 conv_meta(ops, d, 0, moved=4.0 * d.N * d.C * d.H * d.W
+                                           + ((0.0 if y32 is None else 4.0) + self._q_bytes()) * d.N * d.K * d.Ho * d.Wo)))
                 else:
                     prog.append(("%s_fwd" % n.op, lambda d=d, x=x, w=w, b=b, y=y, a=a:
                                  ops.conv2d_fwd(d, x, w, b, y, a.kind, a.alpha), conv_meta(ops, d, 0)))
@@ -1151,7 +1171,12 @@ class NetPlan:
                         Gq = gradq_of(n, G) if form == 3 else None
                         if Gq is not None and (ops.lp_q_direct(d2, 1, self.dtype) or self.dtype in SPLITS):
                             giq = fused_gq(xin, gi, acc) if ops.lp_q_direct(d2, 1, self.dtype) else None
-                            prog.append(("conv_dgrad", lambda d=d2, Gq=Gq, wsel=wsel, gi=gi, giq=giq, x=x, xa=xa:
+                            # split modes: the slope from the sign of the producer's q copy (2 bytes per element, and the
+                            # producer's fp32 activation need not exist: _act_fp32_dropped)
+                            ysrc = x
+                            if self.dtype in SPLITS and xin.outq is not None and gi.Cc % 8 == 0 and not os.environ.get("GHM_DACT_FP32"):
+                                ysrc = xin.outq if nslice is None else xin.outq.samples(n0, n1)
+                            prog.append(("conv_dgrad", lambda d=d2, Gq=Gq, wsel=wsel, gi=gi, giq=giq, x=ysrc, xa=xa:
                                          ops.conv2d_dgrad_dact_lp_q(d, Gq, wsel, gi, giq, x, xa.kind, xa.alpha, self.dtype),
                                          conv_meta(ops, d2, 3, dt, extra=" +dact" + (" +q" if giq is not None else ""))))
                         else:

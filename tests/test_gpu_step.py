@@ -519,6 +519,33 @@ def test_generator_gradient_from_the_discriminator_loss_pass(dev, monkeypatch, d
     assert "per_sample_ratio" not in labels(bn)
 
 
+def test_patchgan_chain_without_fp32_activations(dev, monkeypatch):
+    """Split modes: in the PatchGAN's conv -> LeakyRectify -> conv chain (p2p.py:278-292) every reader of an activation takes its q
+    copy, and the consumer's data gradient takes the LeakyRectify slope from the SIGN of that copy's first piece
+    (ghm_conv2d_dgrad_dact_split_q) -- the fp32 activations are never written.  Same bits as the step that writes and reads
+    them (GHM_DACT_FP32=1): bf16(x) has the sign of x."""
+    # (256^2: the first-layer kernel with a q epilogue wants 128 output columns, the stride-2 data gradient 32 columns of dy)
+    cfg = ostep.default_cfg(in_shp=256, latent_dim=16, train_mode='p2p', gen_dcgan=dict(nch=16, div=[1, 1, 2, 2, 2, 2]),
+                            disc_dcgan=dict(nch=16, div=[2, 2, 2, 2]), gen_p2p=dict(nf=8),
+                            disc_p2p=dict(nf=64, mul_factor=[1, 2, 4]))
+    B = 4
+    q = build_model(cfg, 7, dev, dtype='bf16x3')
+    plan = q.engine.built(B).P
+    assert any(plan._act_fp32_dropped(n) for n in plan.order), "no layer of this PatchGAN takes the q-only form: vacuous test"
+    monkeypatch.setenv("GHM_DACT_FP32", "1")
+    f = build_model(cfg, 7, dev, dtype='bf16x3')
+    planf = f.engine.built(B).P
+    assert not any(planf._act_fp32_dropped(n) for n in planf.order)
+    monkeypatch.delenv("GHM_DACT_FP32")
+    for it in range(3):          # eager, recorded, replayed
+        Z, X, Y = ostep.synthetic_batch(B, cfg, seed=400 + it)
+        assert q.train_fn(Z, X, Y) == f.train_fn(Z, X, Y)
+        gq, gf = model_grads(q), model_grads(f)
+        for key in gq:
+            for a, b in zip(gq[key], gf[key]):
+                assert np.array_equal(a, b), (it, key)
+
+
 @pytest.mark.parametrize("variant", ["plain", "adam_bn_disc", "one_rank_exchange", "one_rank_exchange_subbuckets"])
 def test_recorded_step_is_the_eager_schedule_in_one_call(dev, variant):
     """use_graph='recorded' (ghm_step_record_begin / ghm_step_run): the eager four-stream launch sequence -- gradient
