@@ -478,8 +478,8 @@ def test_gradient_side_streams_bitwise(dev):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16x3"])
-@pytest.mark.parametrize("lsgan", [True, False])
-def test_generator_gradient_from_the_discriminator_loss_pass(dev, monkeypatch, dtype, lsgan):
+@pytest.mark.parametrize("lsgan,pool", [(True, 'max'), (False, 'max'), (True, 'average_inc_pad')])
+def test_generator_gradient_from_the_discriminator_loss_pass(dev, monkeypatch, dtype, lsgan, pool):
     """The DCGAN discriminator returns one scalar per sample and (bn=False) couples no samples, so its backward pass on a fake
     sample is linear in ONE number: the step takes dgen_loss/dG(z) as the discriminator-loss pass's fake half times
     seed_G[n] / seed_D[n] (step.py, `per_sample_ratio`) instead of walking D a second time.  A/B against the two separate
@@ -489,6 +489,8 @@ def test_generator_gradient_from_the_discriminator_loss_pass(dev, monkeypatch, d
     if not lsgan:
         over.update(disc_dcgan=dict(nch=16, div=[4, 2, 2], nonlinearity='sigmoid'),
                     disc_p2p=dict(nf=4, mul_factor=[1, 2], act='sigmoid'))
+    if pool != 'max':       # (dcgan.py:48-49: the first layer is then a plain conv -> LeakyRectify, its gradient buffer holds the
+        over.update(disc_dcgan=dict(nch=16, div=[4, 2, 2], pool_mode=pool))      # gradient in FRONT of the nonlinearity)
     cfg = ostep.default_cfg(**over)
     B = 4
     labels = lambda m: [e[0] for e in m.engine.built(B).train_compute[0]]
