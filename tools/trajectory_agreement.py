@@ -3,7 +3,10 @@
 noise and dropout masks; the five losses of every step side by side.  Training is chaotic, so the runs separate eventually --
 what the table shows is WHEN and how fast: fp32 on the fp32 matrix instruction against fp32 by operand splitting (bf16x3, the
 default) should separate like two fp32 implementations do (summation order), not like a reduced-precision run.
-    python tools/trajectory_agreement.py [steps] [modeA] [modeB]        (default 40 f32 bf16x3)"""
+    python tools/trajectory_agreement.py [steps] [modeA] [modeB]        (default 40 f32 bf16x3)
+A mode is a dtype, optionally followed by +NAME=VALUE tuning switches set for that run only, e.g.
+    python tools/trajectory_agreement.py 40 bf16x3 bf16x3+GHM_NO_RANK_ONE=1
+(the DCGAN generator's gradient as a per-sample multiple of the discriminator-loss pass, DESIGN 4e, against the two separate passes)."""
 import os
 import sys
 
@@ -17,7 +20,18 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 modes = (sys.argv[2] if len(sys.argv) > 2 else 'f32', sys.argv[3] if len(sys.argv) > 3 else 'bf16x3')
 
 
-def run(dtype):
+def run(mode):
+    dtype, *switches = mode.split('+')
+    for sw in switches:
+        os.environ[sw.split('=')[0]] = sw.split('=', 1)[1]
+    try:
+        return _run(dtype)
+    finally:
+        for sw in switches:
+            os.environ.pop(sw.split('=')[0], None)
+
+
+def _run(dtype):
     dev = device.Device(0)
     model = make_model('test1_nobn_bilin_both', device=dev, seed=0, verbose=False, dtype=dtype, use_graph='recorded')
     X, Y = synthetic_arrays(64, 512, True, False, 0)
