@@ -320,10 +320,12 @@ __global__ __launch_bounds__(256) void scale_samples_kernel(float* __restrict__ 
     long n, c, i;
     if (!decode<VEC>(v, n, c, i)) return;
     const float d = den[n * dens];
-    const float r = d != 0.f ? num[n * nums] / d : 0.f;
+    // the ratio and the product in fp64: a denominator near the bottom of the fp32 range (a discriminator output of 1e-40) would
+    // push the fp32 ratio to inf and inf * 0 to NaN; the gradient it multiplies is that small too, and the product is ordinary
+    const double r = d != 0.f ? (double)num[n * nums] / (double)d : 0.0;
     float* p = x + n * xs + c * v.HW + i;
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) p[k] *= r;
+    for (int k = 0; k < VEC; ++k) p[k] = (float)((double)p[k] * r);
 }
 
 __global__ void axpby_kernel(float a, const float* __restrict__ x, float b, float* __restrict__ y, long n) {

@@ -143,6 +143,30 @@ def test_one_filter_data_gradient_kernel(gpu, case):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+def test_scale_samples(gpu):
+    """ghm_scale_samples: x[n] *= num[n] / den[n], 0 where den[n] == 0, on a strided view -- the per-sample factor of the DCGAN
+    generator's gradient (step.py).  A denominator at the bottom of the fp32 range must not make inf * 0."""
+    dev, ops, D = gpu
+    rng = np.random.RandomState(4)
+    N, C, H, W = 5, 3, 6, 10
+    big = rng.randn(N, C + 2, H, W).astype(np.float32)
+    num = np.array([0.5, -0.25, 3.0, 0.7, 0.5], np.float32)
+    den = np.array([2.0, 0.125, 0.0, -1.5, 1e-42], np.float32)        # [2]: dead sample, [4]: denormal
+    big[4] *= np.float32(1e-40)                                         # the gradient behind a tiny seed is that small too
+    t = dev.tensor(big)
+    view = t.channels(1, 1 + C)
+    ops.scale_samples(view, dev.tensor(num.reshape(N, 1, 1, 1)), dev.tensor(den.reshape(N, 1, 1, 1)))
+    got = t.numpy()
+    want = big.astype(np.float64)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        r = np.where(den != 0, num.astype(np.float64) / den.astype(np.float64), 0.0)
+    want[:, 1:1 + C] *= r.reshape(N, 1, 1, 1)
+    assert np.all(np.isfinite(got))
+    assert np.array_equal(got[:, 0], big[:, 0]) and np.array_equal(got[:, -1], big[:, -1])      # outside the view: untouched
+    assert np.all(got[2, 1:1 + C] == 0)
+    assert np.allclose(got[:, 1:1 + C], want[:, 1:1 + C].astype(np.float32), rtol=1e-6, atol=0)
+
+
 def _check_conv(gpu, case):
     dev, ops, D = gpu
     N, C, H, W, K, k, s, pad = case
