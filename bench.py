@@ -147,6 +147,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true",
                     help="headline only: skip the short extra loops of BASELINE configs 1-5 (\"secondary\" key)")
     ap.add_argument("--secondary-steps", type=int, default=12)
+    ap.add_argument("--batches", type=int, default=8,
+                    help="distinct synthetic batches resident in HBM that the timed steps rotate through (device-to-device "
+                         "into the step's input buffers on a copy stream while the previous step runs); 1 = the same batch "
+                         "every step (rounds 1-5; reported as value_single_batch)")
+    ap.add_argument("--side-file", default=os.path.join("gpurun_out", "bench_secondary.json"),
+                    help="where the secondary configurations / thin-layer table / notes go (the stdout line stays < 4 KB)")
     ap.add_argument("--minimal", action="store_true",
                     help="timed region only: no steady-state loop, no host-array loops (counter-collection runs, where every "
                          "dispatch is serialised and a step takes seconds)")
@@ -233,28 +239,60 @@ def measure(args, secondary_name=None):
     eng = model.engine
     Z, X, Y = synthetic_batch(B, 100 if args.config1 else 1000, S, seed=1000 + rank)
     b = eng.built(B)
-    if args.ablate:
-        pats = [p for p in args.ablate.split(",") if p]
+    latent = 100 if args.config1 else 1000
+    # the timed steps ROTATE through ``args.batches`` distinct synthetic batches that lie in HBM before the timed region: a
+    # second plan of the same batch size (own activations and inputs, shared parameters: the product's input pipeline,
+    # step.py) takes batch k+1 by device-to-device copies on the copy stream while step k runs on the other plan.  (Rounds
+    # 1-5 re-trained ONE batch 85+ times: the discriminator over-fits it, and the split kernels' rate is data-dependent.)
+    rotate = args.batches > 1 and issue is not False
+    plans = [b] + ([eng.built(B, 1)] if rotate else [])
+    for p_ in plans:
+        if args.ablate:
+            pats = [p for p in args.ablate.split(",") if p]
 
-        def dead(e):
-            k = e[2]["kernel"] if len(e) > 2 and e[2] else ""
-            return any(e[0] == p or (k and k.startswith(p)) for p in pats)
-        for lanes in (b.train_compute, b.update):
-            for i in (0, 1):
-                lanes[i][:] = [((e[0], (lambda: None)) + tuple(e[2:])) if dead(e) else e for e in lanes[i]]
-    if args.repeat:
-        rpats = [p for p in args.repeat.split(",") if p]
+            def dead(e):
+                k = e[2]["kernel"] if len(e) > 2 and e[2] else ""
+                return any(e[0] == p or (k and k.startswith(p)) for p in pats)
+            for lanes in (p_.train_compute, p_.update):
+                for i in (0, 1):
+                    lanes[i][:] = [((e[0], (lambda: None)) + tuple(e[2:])) if dead(e) else e for e in lanes[i]]
+        if args.repeat:
+            rpats = [p for p in args.repeat.split(",") if p]
 
-        def twice(e):
-            k = e[2]["kernel"] if len(e) > 2 and e[2] else ""
-            return any(e[0] == p or (k and k.startswith(p)) for p in rpats)
-        for lanes in (b.train_compute, b.update):
-            for i in (0, 1):
-                lanes[i][:] = [x for e in lanes[i] for x in ((e, e) if twice(e) else (e,))]
-    eng._upload(b, Z, X, Y)                      # inputs resident in HBM before the timed region
+            def twice(e):
+                k = e[2]["kernel"] if len(e) > 2 and e[2] else ""
+                return any(e[0] == p or (k and k.startswith(p)) for p in rpats)
+            for lanes in (p_.train_compute, p_.update):
+                for i in (0, 1):
+                    lanes[i][:] = [x for e in lanes[i] for x in ((e, e) if twice(e) else (e,))]
+    kstep = [0]                 # steps issued so far: step k runs on plans[k & 1] with batch k % len(pool)
+    if rotate:
+        pool = [tuple(dev.tensor(a) for a in synthetic_batch(B, latent, S, seed=1000 + 1000 * rank + 3 * i))
+                for i in range(args.batches)]           # inputs resident in HBM before the timed region
+        eng.upload_resident_async(plans[0], *pool[0])
 
-    for _ in range(max(args.warmup, 2 if issue == 'recorded' else 0)):     # recorded: call 0 eager, call 1 records
-        eng.enqueue_train(b)
+        def cur_plan():
+            return kstep[0] & 1
+
+        def run_steps(n, wrap=None):
+            for _ in range(n):
+                k = kstep[0]
+                eng.enqueue_train_uploaded(plans[k & 1], wrap)
+                kstep[0] = k + 1
+                eng.upload_resident_async(plans[(k + 1) & 1], *pool[(k + 1) % len(pool)])
+    else:
+        eng._upload(b, Z, X, Y)                      # inputs resident in HBM before the timed region
+
+        def cur_plan():
+            return 0
+
+        def run_steps(n, wrap=None):
+            for _ in range(n):
+                eng.enqueue_train(b, wrap)
+                kstep[0] += 1
+
+    # recorded: call 0 of a plan is eager, call 1 records
+    run_steps(max(args.warmup, 2 * len(plans) if issue == 'recorded' else len(plans)))
     eng.sync()
 
     # ---- pick the dominant kernel from one instrumented (untimed) step ----
@@ -340,14 +378,24 @@ def measure(args, secondary_name=None):
         else:
             e[1]()
 
+    base, nslot, runs_of, stride = {}, {}, {}, 0
     if issue == 'recorded' and dominant:
-        # re-record the step with HIP-event brackets around every launch of the dominant kernel; the recorded timer
-        # slots advance by ``launches_per_step`` per replay, so every launch of the timed region has its own events
-        b.steps.pop('train', None)
-        eng.enqueue_train(b, wrap)              # records (with the brackets) and replays once: untimed
-        type(dev).step_timer_stride(b.steps['train'], len(slots))
-        rec_devs, inst_steps = list(slots), min(args.steps, 4000 // max(len(slots), 1) - 1)
+        # re-record the step of every plan with HIP-event brackets around every launch of the dominant kernel; the recorded
+        # timer slots advance by ``stride`` (= the brackets of all plans) per replay, so every launch of the timed region has
+        # its own events
+        for _ in plans:
+            p = cur_plan()
+            base[p] = len(slots)
+            plans[p].steps.pop('train', None)
+            run_steps(1, wrap)                  # records (with the brackets) and replays once: untimed
+            nslot[p] = len(slots) - base[p]
+            runs_of[p] = 1                      # the recording call was replay 0 of this plan's step
+        stride = len(slots)
+        for p in base:
+            type(dev).step_timer_stride(plans[p].steps['train'], stride)
+        rec_devs = list(slots)
         eng.sync()
+        inst_steps = args.steps
     else:
         inst_steps = min(args.steps, 4000 // max(launches_per_step + 24 * (world > 1), 1)) if dominant else 0
 
@@ -355,12 +403,16 @@ def measure(args, secondary_name=None):
     if comm is not None:
         comm.barrier()
     eng.sync()
+    order = []                  # (plan, replay number of that plan's recorded step) of every timed step
     t0 = time.perf_counter()
     for s in range(args.steps):
         if issue is not False:
-            eng.enqueue_train(b)                # ONE ghm_step_run (recorded) / two graph launches (--graph)
+            p = cur_plan()
+            order.append((p, runs_of.get(p, 0)))
+            runs_of[p] = runs_of.get(p, 0) + 1
+            run_steps(1)                        # ONE ghm_step_run (recorded) / two graph launches (--graph)
         else:
-            eng.enqueue_train(b, wrap if s < inst_steps else (lambda lane, e: e[1]()))
+            run_steps(1, wrap if s < inst_steps else (lambda lane, e: e[1]()))
     eng.sync()
     if comm is not None:
         comm.barrier()
@@ -369,28 +421,54 @@ def measure(args, secondary_name=None):
         elapsed = comm.max_scalar(elapsed)
     losses = eng._read_losses()
     if issue == 'recorded' and dominant:
-        # replay r (1-based; replay 0 was the recording call) used slots [r * L, (r + 1) * L)
-        L_ = len(rec_devs)
-        first = args.steps - inst_steps + 1
-        every = [(d, (i + r * L_) % MAX_TIMERS, slot_labels[i]) for r in range(first, args.steps + 1) for i, d in enumerate(rec_devs)]
+        # replay r of plan p used slots base[p] + i + r * stride; the slots wrap modulo MAX_TIMERS: the last ``keep`` replays
+        # of a plan still hold their events
+        keep = MAX_TIMERS // max(stride, 1) - 1
+        every = [(rec_devs[i], (i + r * stride) % MAX_TIMERS, slot_labels[i])
+                 for p, r in order if runs_of[p] - r <= keep for i in range(base[p], base[p] + nslot[p])]
     else:
         every = [(d, i, slot_labels[i]) for i, d in enumerate(slots)]
     timed = [(d, i) for d, i, lab in every if lab is None]
     slot = len(timed)
-    # read every bracket of the timed region NOW: the host-boundary loop below replays the bracketed step and the
-    # recorded timer slots wrap modulo MAX_TIMERS, so later replays would overwrite these event pairs
+    # read every bracket of the timed region NOW: the loops below replay the bracketed steps and the recorded timer slots
+    # wrap modulo MAX_TIMERS, so later replays would overwrite these event pairs
     timed_ms = [d.timer_ms(i) for d, i in timed]
     every_ms = {(id(d), i): d.timer_ms(i) for d, i, lab in every if lab is not None}
+    extras = (issue is not False and not args.ablate and not args.repeat and world == 1 and not secondary_name
+              and not args.minimal)
     # ---- steady state: the split kernels' rate is data- and clock-dependent (the bf16 matrix pipes are power-managed, DESIGN
     # section 4d): 60 more steps behind the timed region, reported beside ``value`` (never instead of it) ----
     steady = None
-    if args.dtype == "bf16x3" and issue is not False and not args.ablate and world == 1 and not secondary_name and not args.minimal:
+    if args.dtype == "bf16x3" and extras:
         eng.sync()
         t1 = time.perf_counter()
-        for s in range(60):
-            eng.enqueue_train(b)
+        run_steps(60)
         eng.sync()
         steady = {"steps": 60, "after_steps": args.steps + args.warmup, "value": round(B * 60 / (time.perf_counter() - t1), 3)}
+    # ---- the same steps with lr = 0 (parameters frozen: what the kernels do on a FIXED state of the nets; the timed region
+    # above trains, so its activations drift with the parameters) and, as rounds 1-5 measured, on ONE batch repeated ----
+    value_lr0 = value_single = None
+    if extras:
+        eng.sync()
+        lr_saved = float(eng.hyper['dcgan_gen'].numpy().ravel()[0])
+        eng.set_lr(0.0)
+        run_steps(2)
+        eng.sync()
+        t1 = time.perf_counter()
+        run_steps(args.steps)
+        eng.sync()
+        value_lr0 = B * args.steps / (time.perf_counter() - t1)
+        eng.set_lr(lr_saved)
+        if rotate:
+            eng._upload(b, Z, X, Y)
+            for _ in range(2):
+                eng.enqueue_train(b)
+            eng.sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.enqueue_train(b)
+            eng.sync()
+            value_single = B * args.steps / (time.perf_counter() - t1)
     # ---- the same loop with the reference's host-array boundary (pix2pix.py:142: train_fn(Z, X, Y) takes numpy
     # arrays): every step uploads its 16 KB + 4 MB + 12 MB batch over PCIe before it is enqueued ----
     with_h2d = with_h2d_sync = None
@@ -407,16 +485,16 @@ def measure(args, secondary_name=None):
             # the product's path for host arrays (Pix2Pix.train -> GanStep.train_pipelined): the upload of batch i+1 on a
             # copy stream from page-locked staging while step i runs
             b1 = eng.built(B, 1)
-            slots = [b, b1]
+            pslots = [b, b1]
             for w_ in range(6):                  # both slots record their step (call 0 eager, call 1 records)
-                eng.upload_async(slots[w_ & 1], Z, X, Y)
-                eng.enqueue_train_uploaded(slots[w_ & 1])
+                eng.upload_async(pslots[w_ & 1], Z, X, Y)
+                eng.enqueue_train_uploaded(pslots[w_ & 1])
             eng.sync()
-            eng.upload_async(slots[0], Z, X, Y)
+            eng.upload_async(pslots[0], Z, X, Y)
             t1 = time.perf_counter()
             for s in range(args.steps):
-                eng.enqueue_train_uploaded(slots[s & 1])
-                eng.upload_async(slots[(s + 1) & 1], Z, X, Y)
+                eng.enqueue_train_uploaded(pslots[s & 1])
+                eng.upload_async(pslots[(s + 1) & 1], Z, X, Y)
             eng.sync()
             with_h2d = B * args.steps / (time.perf_counter() - t1)
         else:
@@ -439,16 +517,14 @@ def measure(args, secondary_name=None):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("BASELINE config 1: DCGAN 64x64 generator + discriminator, " if args.config1 else "") +
                                "test1_nobn_bilin_both joint DCGAN+pix2pix train step (train_mode=%s), %dx%d, "
-                               "batch %d per GPU, RMSprop lr 1e-4, LSGAN + 100*L1%s"
+                               "batch %d per GPU, RMSprop lr 1e-4, LSGAN+100*L1%s"
                                % (args.mode, S, S, B, "; fp32 on v_mfma_f32_32x32x2_f32" if args.dtype == "f32" else
-                                  ("; fp32 by operand splitting on the bf16 matrix cores (three bf16 pieces per fp32 "
-                                   "operand that sum to it exactly, six products, fp32 accumulation: fp32-accurate)"
-                                   if args.dtype == "bf16x3" else
-                                   "; convolution operands as two bf16 pieces (16-17 significant bits), three products x0 w0 + "
-                                   "x1 w0 + x0 w1 on the bf16 matrix cores, fp32 accumulation / tensors / master weights / optimiser"
-                                   if args.dtype == "bf16x2" else
-                                   "; convolution products in %s on the matrix cores, fp32 accumulation / tensors / "
-                                   "master weights / optimiser" % args.dtype)),
+                                  ("; fp32 by operand splitting on the bf16 matrix cores (3 exact bf16 pieces per operand, "
+                                   "6 products, fp32 accumulation)" if args.dtype == "bf16x3" else
+                                   "; operands as 2 bf16 pieces (16-17 bits), 3 products on the bf16 matrix cores, fp32 "
+                                   "accumulation / tensors / master weights" if args.dtype == "bf16x2" else
+                                   "; products in %s on the matrix cores, fp32 accumulation / tensors / master weights"
+                                   % args.dtype)),
                    "global_batch": B * world, "in_shp": S, "parallelism": "dp%d" % world,
                    "hip_graph": bool(args.graph), "issue": "graph" if args.graph else args.issue,
                    "host_calls_per_step": 1 if issue == 'recorded' else None,
@@ -475,6 +551,11 @@ def measure(args, secondary_name=None):
         "losses": [float(x) for x in losses],
         # inputs uploaded from host arrays every step (the reference's train_fn(Z, X, Y) boundary); never ``value``
         "steady_state": steady,
+        # the rotation: ``value`` is measured over ``resident_batches`` distinct batches; value_lr0 = the same steps with the
+        # learning rate at 0 (frozen parameters); value_single_batch = ONE batch repeated (what rounds 1-5 reported)
+        "resident_batches": len(pool) if rotate else 1,
+        "value_lr0": round(value_lr0, 3) if value_lr0 else None,
+        "value_single_batch": round(value_single, 3) if value_single else None,
         "value_with_h2d": round(with_h2d, 3) if with_h2d else None,
         "value_with_h2d_synchronous": round(with_h2d_sync, 3) if with_h2d_sync else None,
         "hbm_bound_layers": {"note": "thin first / last layers, each timed alone and warm (ten launches back to back); bound = HBM 8 TB/s; "
@@ -549,7 +630,7 @@ def measure(args, secondary_name=None):
         out = {"name": secondary_name, **{k: out[k] for k in (
             "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "step_algorithmic_tflops",
             "step_algorithmic_gflop_per_img", "step_flops_source", "step_frac_of_peak", "step_peak_tflops", "step_executed_tflops",
-            "losses", "value_with_h2d", "value_with_h2d_synchronous", "roofline")}}
+            "step_executed_frac_of_peak", "resident_batches", "losses", "value_with_h2d", "value_with_h2d_synchronous", "roofline")}}
     eng.close_pipeline()
     if comm is not None:
         comm.close()
@@ -559,6 +640,48 @@ def measure(args, secondary_name=None):
             d.close()
     dev.close()
     return out
+
+
+LINE_LIMIT = 4096       # the driver keeps the tail of stdout: the ONE JSON line must fit (round 5's 20.8 KB line did not parse)
+
+HEADLINE_KEYS = ("INVALID", "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_fp32_mfma", "value_lr0",
+                 "value_single_batch", "resident_batches", "steady_state", "step_frac_of_peak", "step_executed_frac_of_peak",
+                 "step_algorithmic_gflop_per_img", "step_peak_tflops", "generator_gradient_from_discriminator_pass", "losses",
+                 "exchange", "side_file")
+# dropped first when the line would still be too long (never the contract's keys)
+OPTIONAL_KEYS = ("exchange", "losses", "generator_gradient_from_discriminator_pass", "step_peak_tflops",
+                 "step_algorithmic_gflop_per_img", "steady_state", "resident_batches", "value_single_batch")
+
+
+def headline_line(out):
+    """the ONE stdout line: the contract's keys + roofline + cpu_baseline, shortened to stay below LINE_LIMIT bytes.
+    Everything else (secondary configurations, the thin-layer table, notes) is in the side file."""
+    line = {k: out[k] for k in HEADLINE_KEYS if k in out}
+    if isinstance(line.get("config"), dict):
+        c = dict(line["config"])
+        if isinstance(c.get("workload"), str) and len(c["workload"]) > 260:
+            c["workload"] = c["workload"][:257] + "..."
+        line["config"] = c
+    if isinstance(line.get("cpu_baseline"), dict):
+        cb = dict(line["cpu_baseline"])
+        if isinstance(cb.get("sample"), str) and len(cb["sample"]) > 200:
+            cb["sample"] = cb["sample"][:197] + "..."
+        if isinstance(cb.get("config1"), dict):
+            cb["config1"] = {k: v for k, v in cb["config1"].items() if k != "sample"}
+        line["cpu_baseline"] = cb
+    if isinstance(line.get("exchange"), dict):
+        line["exchange"] = {k: v for k, v in line["exchange"].items() if k != "buckets"}
+    if isinstance(line.get("losses"), list):
+        line["losses"] = [round(x, 6) for x in line["losses"]]
+    txt = json.dumps(line)
+    for k in OPTIONAL_KEYS:
+        if len(txt) < LINE_LIMIT - 64:
+            break
+        line.pop(k, None)
+        txt = json.dumps(line)
+    assert len(txt) < LINE_LIMIT, len(txt)
+    return txt
 
 
 def main():
@@ -580,6 +703,10 @@ def main():
                 sec.append(measure(a2, name))
             except Exception as ex:           # a secondary line must never take the headline down with it
                 sec.append({"name": name, "error": "%s: %s" % (type(ex).__name__, ex)})
+            r_ = sec[-1]
+            # one short line per configuration on STDERR (stdout carries exactly one JSON line)
+            print("secondary %-48s %s" % (name, ("%.1f img/s, %.2f ms, %s" % (r_["value"], r_["ms_per_step"], r_["dtype"]))
+                                          if "value" in r_ else r_.get("error")), file=sys.stderr, flush=True)
         out["secondary"] = sec
         sp = next((r for r in sec if r.get("name") == "headline_workload_fp32_mfma" and "value" in r), None)
         if sp is not None:
@@ -593,7 +720,17 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.in_shp == 512 and not args.config1:
         out["cpu_baseline"] = cpu_baseline(2)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        # the complete record (secondary configurations, thin-layer table, notes) goes to a side file ...
+        try:
+            side = args.side_file if os.path.isabs(args.side_file) else os.path.join(ROOT, args.side_file)
+            os.makedirs(os.path.dirname(side), exist_ok=True)
+            with open(side, "w") as f:
+                json.dump(out, f, indent=1)
+            out["side_file"] = args.side_file
+        except OSError as ex:
+            sys.stderr.write("bench.py: side file not written: %s\n" % ex)
+        # ... and stdout carries ONE short JSON line
+        print(headline_line(out), flush=True)
 
 
 if __name__ == "__main__":

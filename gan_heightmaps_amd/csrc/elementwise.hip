@@ -312,8 +312,11 @@ __global__ __launch_bounds__(256) void copy_view_kernel(const float* __restrict_
     }
 }
 
-// x[n, ...] *= num[n] / den[n]  (0 where den[n] == 0): the per-sample factor between two backward passes through a net whose output
-// is ONE scalar per sample -- the pass is linear in that scalar's gradient (step.py, "rank-one" generator gradient)
+// x[n, ...] *= num[n] / den[n]: the per-sample factor between two backward passes through a net whose output is ONE scalar per
+// sample -- the pass is linear in that scalar's gradient (step.py, "rank-one" generator gradient).  den[n] == 0: the element
+// stays 0 where it is exactly 0 (a dead final ReLU: both passes are exactly zero there) and becomes NaN where it is not --
+// a head whose output is exactly 0 WITHOUT a dead ReLU in front has a non-zero generator-loss gradient that no factor recovers
+// from a zero discriminator-loss seed; that must fail loudly (finite checks of every parity test), not train on zeros
 template <int VEC>
 __global__ __launch_bounds__(256) void scale_samples_kernel(float* __restrict__ x, long xs, View v, const float* __restrict__ num,
                                                             long nums, const float* __restrict__ den, long dens) {
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256) void scale_samples_kernel(float* __restrict__ 
     const double r = d != 0.f ? (double)num[n * nums] / (double)d : 0.0;
     float* p = x + n * xs + c * v.HW + i;
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) p[k] = (float)((double)p[k] * r);
+    for (int k = 0; k < VEC; ++k) p[k] = (d != 0.f || p[k] == 0.f) ? (float)((double)p[k] * r) : __builtin_nanf("");
 }
 
 __global__ void axpby_kernel(float a, const float* __restrict__ x, float b, float* __restrict__ y, long n) {

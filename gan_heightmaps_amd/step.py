@@ -291,20 +291,33 @@ class GanStep:
         # sharded update: a net's parameters are all-gathered at the END of a step in forward order (G, U, D, P; within a net the
         # first layers first) and the NEXT step's forward waits per net, right in front of the net's first weight read -- the
         # discriminators' gathers run under the generators' forward passes instead of in front of the whole step
-        gev = self._gather_events() if self.sharded else {}
+        # (captured HIP graphs, use_graph=True: an event wait cannot sit inside a capture -- ghm_event_wait refuses -- so that
+        # form keeps one wait for the communication stream at the end of the step, as the all-reduce form does)
+        per_net_waits = self.sharded and self.use_graph is not True
+        gev = self._gather_events() if per_net_waits else {}
 
         def gwait(prog, dev_, k):
             if k in gev:
                 prog.append(("wait_gather_" + k, lambda dev_=dev_, ev=gev[k]: dev_.event_wait(ev), None, dev_))
 
         fa = [("x_to_d_in", lambda: oA.copy_view(b.x, b.d_in.samples(0, B)))]
+        fb = []
+        if per_net_waits:
+            # nothing waits for the communication stream at the end of a sharded step, and a stage whose nets were not
+            # exchanged (train_mode 'dcgan' / 'p2p') never meets a gather event: its loss kernels of the NEXT step write
+            # losses_dev, which the previous step's loss all-reduce may still be reading -- both stage streams wait for the
+            # event recorded behind that all-reduce (unrecorded on the first step: the wait is a no-op)
+            lev = self._losses_event()
+            fa.append(("wait_losses_reduced", lambda: dA.event_wait(lev), None, dA))
+            if dB is not dA:
+                fb.append(("wait_losses_reduced", lambda: dB.event_wait(lev), None, dB))
         gwait(fa, dA, 'dcgan_gen')
         b.G.emit_forward(fa)
         gwait(fa, dA, 'dcgan_disc')
         b.D.emit_forward(fa)
-        fb = [("x_to_p_in0", lambda: oB.copy_view(b.x, pa.samples(0, B))),
-              ("x_to_p_in1", lambda: oB.copy_view(b.x, pa.samples(B, 2 * B))),
-              ("y_to_p_in", lambda: oB.copy_view(b.y, pb.samples(0, B)))]
+        fb += [("x_to_p_in0", lambda: oB.copy_view(b.x, pa.samples(0, B))),
+               ("x_to_p_in1", lambda: oB.copy_view(b.x, pa.samples(B, 2 * B))),
+               ("y_to_p_in", lambda: oB.copy_view(b.y, pb.samples(0, B)))]
         gwait(fb, dB, 'p2p_gen')
         b.U.emit_forward(fb)
         gwait(fb, dB, 'p2p_disc')
@@ -423,7 +436,7 @@ class GanStep:
             b.D.emit_transposes(ta, tdone)
             b.G.emit_transposes(ta, tdone)
             hook, flush = bucketer('dcgan_disc', 0, ta) if self.exchange else nohook
-            n1 = self._per_sample_scalar_head(b.D, d_in_layer)
+            n1 = self._per_sample_scalar_head(b.D, d_in_layer, self.dtype)
             if n1 is not None:
                 # the fake half of the discriminator-loss seed, kept aside (a backward pass may modify its seed in place)
                 b.seed_Df = dA.empty(d_fake.shape)
@@ -480,6 +493,8 @@ class GanStep:
                     cdev.wait_for(dB)
                 cops.allreduce_sum(lo, 8)
             b.exchange.append(("allreduce_losses", reduce_losses, None, cdev))
+            if per_net_waits:
+                b.exchange.append(("losses_reduced", lambda ev=self._losses_event(): cdev.event_record(ev), None, cdev))
             if self.sharded:
                 # (the communication stream has just waited for both stage streams: every kernel that reads the pre-update
                 # weights is behind it.)  Per sub-bucket, in the order it was reduced: this rank's shard of the optimiser
@@ -505,7 +520,7 @@ class GanStep:
                     full = st.w.channels(blo, blo + n)
                     b.exchange.append(("allgather_" + label[len("reducescatter_"):], lambda full=full, sh=sh: cops.all_gather(full, sh),
                                        None, cdev))
-                    if last_of[k] == idx:
+                    if last_of[k] == idx and k in gev:
                         b.exchange.append(("gathered_" + k, lambda ev=gev[k]: cdev.event_record(ev), None, cdev))
                 if self.opt_spec.kind == 'adam':
                     for k in keys:
@@ -513,8 +528,9 @@ class GanStep:
 
             # one entry per stage stream, so that bench.py can bracket each with HIP events: the time a stage stream
             # spends in this wait is the EXPOSED part of the exchange
-            # (sharded form: no wait here -- the next forward waits per net, ``wait_gather_*`` above)
-            if not self.sharded:
+            # (sharded form: no wait here -- the next forward waits per net, ``wait_gather_*`` above; except under captured
+            # HIP graphs, where the waits cannot sit inside the graphs)
+            if not per_net_waits:
                 b.exchange.append(("wait_comm", lambda: dA.wait_for(cdev), None, dA))
                 if dB is not dA:
                     b.exchange.append(("wait_comm", lambda: dB.wait_for(cdev), None, dB))
@@ -551,12 +567,18 @@ class GanStep:
         return b
 
     @staticmethod
-    def _per_sample_scalar_head(plan, in_layer):
+    def _per_sample_scalar_head(plan, in_layer, dtype='bf16x3'):
         """-> the node that reads ``in_layer`` if the generator-loss gradient through this discriminator may be taken from its
         discriminator-loss pass (see _build), else None: one scalar per sample out, no BatchNorm / InstanceNorm node (batch
         statistics couple the samples; the normalisation backward is not sliced), one conv reader of the input.
-        GHM_NO_RANK_ONE=1 keeps the two separate passes (the A/B switch of tests/test_gpu_step.py)."""
-        if os.environ.get('GHM_NO_RANK_ONE'):
+        GHM_NO_RANK_ONE=1 keeps the two separate passes (the A/B switch of tests/test_gpu_step.py).
+        Not in 'f16': the identity is exact, but the shared pass carries the fake half at the DISCRIMINATOR-loss seed, which is
+        smaller than the generator-loss seed by d / (1 - d) (LSGAN; p / (1 - p) with BCE) -- 1e-2 .. 1e-5 once the discriminator
+        is winning (pix2pix.py:107-108; results.txt of the reference's run: dcgan_disc 0.0119) -- and fp16 gradient operands
+        (range 6e-8 .. 65504 behind the 2^15 loss scale) flush per-pixel gradients that small to zero before the per-sample
+        factor multiplies them back up.  fp32 / bf16 pieces have fp32's exponent range: there the error stays relative
+        (tests/test_gpu_step.py::test_generator_gradient_shortcut_with_a_confident_discriminator)."""
+        if os.environ.get('GHM_NO_RANK_ONE') or dtype == 'f16':
             return None
         if int(np.prod(plan.out.shape[1:])) != 1 or any(n.op == 'bn' for n in plan.order):
             return None
@@ -653,6 +675,20 @@ class GanStep:
         cp.event_record(sl['landed'])
         sl['uploads'] += 1
 
+    def upload_resident_async(self, b, zt, xt, yt):
+        """upload_async for a batch that already lies in HBM (three contiguous DevTensors): device-to-device copies into plan
+        ``b``'s input buffers on the copy stream, same orderings (bench.py rotates resident synthetic batches through its timed
+        steps this way, so that no step re-trains the batch of the step before it)"""
+        cp = self._pipe()['dev']
+        sl = self._pipe_slot(b)
+        if sl['used']:
+            for d, ev in sl['done']:
+                d.event_sync(ev)                # the step that last read these input buffers has finished
+        for src, dst in ((zt, b.z), (xt, b.x), (yt, b.y)):
+            assert src.contiguous and dst.contiguous and src.size == dst.size
+            cp.d2d(dst.ptr, src.ptr, 4 * dst.size)
+        cp.event_record(sl['landed'])
+
     def produce_async(self, b, it, Z_sampler):
         """like upload_async, with the (A, B) batch made on the device by a data.Hdf5Iterator: uint8 rows from page-locked
         staging + ghm_image_batch straight into plan ``b``'s inputs, all on the copy stream"""
@@ -728,6 +764,12 @@ class GanStep:
                     d.event_destroy(ev)
             pipe['dev'].close()
             del self._pipe_state
+
+    def _losses_event(self):
+        """persistent event on the communication stream: "the loss all-reduce of the last step has read losses_dev" """
+        if not hasattr(self, '_lev'):
+            self._lev = self.cdev.event_create()
+        return self._lev
 
     def _gather_events(self):
         """one persistent event per net on the communication stream: "this net's updated parameters are gathered" """

@@ -88,6 +88,9 @@ class FakeDevice:
     def h2d_async(self, ptr, pinned):
         FakeDevice.pipe_log.append(("h2d_async", int(ptr), float(np.asarray(pinned.array).ravel()[0]), self.name()))
 
+    def d2d(self, dst, src, nbytes):
+        FakeDevice.pipe_log.append(("d2d", int(dst), int(src), int(nbytes), self.name()))
+
     def name(self):
         return "dev%x" % (id(self) & 0xffff)
 

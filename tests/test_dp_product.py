@@ -306,7 +306,12 @@ def test_sharded_collective_sequence_and_stream_discipline(sharded):
     firsts = [k for j, k in enumerate(nets_seq) if k not in nets_seq[:j]]
     assert firsts == ["dcgan_gen", "p2p_gen", "dcgan_disc", "p2p_disc"], firsts
     recs = [(i, e[2]) for i, e in enumerate(log) if e[1] == "event_record"]
-    assert len(recs) == 4 and all(log[i][0] == nm["comm"] for i, _ in recs)
+    assert len(recs) == 5 and all(log[i][0] == nm["comm"] for i, _ in recs)
+    # the first record sits directly behind the loss all-reduce ("losses_dev has been read": the next step's loss kernels of
+    # BOTH stage streams wait for it, whichever nets were exchanged); the other four are the nets' gather events
+    i_lr = next(i for i, e in enumerate(log) if e[1] == "allreduce_sum")
+    assert recs[0][0] == i_lr + 1
+    loss_ev, recs = recs[0][1], recs[1:]
     for k in KEYS:
         idx = [i for (i, e), kk in zip(gath, nets_seq) if kk == k]
         offs = [log[i][2] for i in idx]
@@ -316,6 +321,10 @@ def test_sharded_collective_sequence_and_stream_discipline(sharded):
     # see this step's records): generator before discriminator on both stage streams, every wait before the first collective;
     # there is no wait for the whole communication stream at the end of the step any more
     waits = [(i, e) for i, e in enumerate(log) if e[1] == "event_wait"]
+    lw = [(i, e) for i, e in waits if e[2] == loss_ev]
+    assert sorted(e[0] for _, e in lw) == sorted([nm["A"], nm["B"]])       # one wait per stage stream, ahead of its forward
+    assert all(i < min(j for j, e in waits if e[2] != loss_ev and e[0] == lane) for (i, e_), lane in ((w, w[1][0]) for w in lw))
+    waits = [(i, e) for i, e in waits if e[2] != loss_ev]
     assert len(waits) == 4
     first_coll = min(i for i, e in enumerate(log) if e[1] in ("reduce_scatter_sum", "allreduce_sum"))
     assert all(i < first_coll for i, _ in waits)

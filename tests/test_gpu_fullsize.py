@@ -249,9 +249,11 @@ def test_full_size_batch4_step_against_the_float64_fixture(gpu, dtype):
     del model
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3"])
 @pytest.mark.parametrize("mode", ["dcgan", "p2p"])
-def test_full_size_batch4_single_stage_modes_against_the_fixture(gpu, mode):
-    """BASELINE configs 2 / 3: the same 512x512 nets with ``train_mode='dcgan'`` / ``'p2p'`` (pix2pix.py:136-141) given
+def test_full_size_batch4_single_stage_modes_against_the_fixture(gpu, mode, dtype):
+    """(both fp32 arithmetic forms: bench.py reports configs 2 / 3 on the fp32 matrix instruction AND by operand splitting.)
+    BASELINE configs 2 / 3: the same 512x512 nets with ``train_mode='dcgan'`` / ``'p2p'`` (pix2pix.py:136-141) given
     to the constructor, as bench.py --mode does.  Every loss and gradient root of the reference's step is evaluated at the
     pre-update parameters, so the trained stage's half of tests/golden/reference_step_fullsize_b4.npz (the JOINT step)
     is this mode's answer: all five losses, the trained stage's outputs, gradients and post-step parameters equal the
@@ -264,8 +266,9 @@ def test_full_size_batch4_single_stage_modes_against_the_fixture(gpu, mode):
     fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_step_fullsize_b4.npz"))
     seed, batch, dseed, stride, win = (int(v) for v in fix["meta"])
     cfg = ostep.default_cfg()
-    model = make_model('test1_nobn_bilin_both', device=dev, seed=seed, verbose=False, use_graph=False, train_mode=mode)
-    assert model.engine.train_mode == mode
+    model = make_model('test1_nobn_bilin_both', device=dev, seed=seed, verbose=False, use_graph=False, train_mode=mode,
+                       dtype=dtype)
+    assert model.engine.train_mode == mode and model.engine.dtype == dtype
     Z, X, Y = ostep.synthetic_batch(batch, cfg, seed=dseed)
     frozen = ('p2p', 'dcgan')[mode == 'p2p']
     before = {(frozen, h): [v.copy() for v in L.get_all_param_values(getattr(model, frozen)[h])] for h in ('gen', 'disc')}

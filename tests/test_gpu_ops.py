@@ -144,15 +144,18 @@ def test_one_filter_data_gradient_kernel(gpu, case):
 
 
 def test_scale_samples(gpu):
-    """ghm_scale_samples: x[n] *= num[n] / den[n], 0 where den[n] == 0, on a strided view -- the per-sample factor of the DCGAN
-    generator's gradient (step.py).  A denominator at the bottom of the fp32 range must not make inf * 0."""
+    """ghm_scale_samples: x[n] *= num[n] / den[n] on a strided view -- the per-sample factor of the DCGAN generator's gradient
+    (step.py).  den[n] == 0 behind a dead final ReLU means the gradient is exactly 0 as well and stays 0; a NON-zero gradient
+    behind a zero denominator (a head that is exactly 0 without a dead ReLU) cannot be recovered by any factor and must come out
+    NaN, not silently 0.  A denominator at the bottom of the fp32 range must not make inf * 0."""
     dev, ops, D = gpu
     rng = np.random.RandomState(4)
-    N, C, H, W = 5, 3, 6, 10
+    N, C, H, W = 6, 3, 6, 10
     big = rng.randn(N, C + 2, H, W).astype(np.float32)
-    num = np.array([0.5, -0.25, 3.0, 0.7, 0.5], np.float32)
-    den = np.array([2.0, 0.125, 0.0, -1.5, 1e-42], np.float32)        # [2]: dead sample, [4]: denormal
+    num = np.array([0.5, -0.25, 3.0, 0.7, 0.5, -0.5], np.float32)
+    den = np.array([2.0, 0.125, 0.0, -1.5, 1e-42, 0.0], np.float32)   # [2]: dead sample, [4]: denormal, [5]: zero seed, live gradient
     big[4] *= np.float32(1e-40)                                         # the gradient behind a tiny seed is that small too
+    big[2, 1:1 + C] = 0.0                                               # dead final ReLU: the gradient is exactly zero
     t = dev.tensor(big)
     view = t.channels(1, 1 + C)
     ops.scale_samples(view, dev.tensor(num.reshape(N, 1, 1, 1)), dev.tensor(den.reshape(N, 1, 1, 1)))
@@ -161,10 +164,11 @@ def test_scale_samples(gpu):
     with np.errstate(divide='ignore', invalid='ignore'):
         r = np.where(den != 0, num.astype(np.float64) / den.astype(np.float64), 0.0)
     want[:, 1:1 + C] *= r.reshape(N, 1, 1, 1)
-    assert np.all(np.isfinite(got))
+    assert np.all(np.isfinite(got[:5]))
     assert np.array_equal(got[:, 0], big[:, 0]) and np.array_equal(got[:, -1], big[:, -1])      # outside the view: untouched
     assert np.all(got[2, 1:1 + C] == 0)
-    assert np.allclose(got[:, 1:1 + C], want[:, 1:1 + C].astype(np.float32), rtol=1e-6, atol=0)
+    assert np.all(np.isnan(got[5, 1:1 + C]))                            # loud, not zero
+    assert np.allclose(got[:5, 1:1 + C], want[:5, 1:1 + C].astype(np.float32), rtol=1e-6, atol=0)
 
 
 def _check_conv(gpu, case):

@@ -190,6 +190,89 @@ def test_input_pipeline_protocol_on_fake_device():
     eng.close_pipeline()
 
 
+def test_resident_batches_rotate_through_two_plans_on_fake_device():
+    """bench.py's timed loop (no reference counterpart; the contract is "inputs resident in HBM, every step a different
+    batch"): GanStep.upload_resident_async copies batch k+1 device-to-device into the OTHER plan's inputs on the copy stream
+    while step k runs; the stage stream of step k waits for the event behind ITS batch's three copies, and a plan's inputs
+    are overwritten only after a host-side wait for the step that last used them."""
+    dev = FakeDevice()
+    G = dcgan.default_generator(24, True, nch=16, div=[2, 2, 4])
+    Dn = dcgan.default_discriminator(32, True, nch=16, div=[4, 2, 2], nonlinearity=linear)
+    U = p2p.g_unet(32, True, False, nf=4, act=tanh, bilinear_upsample=True)
+    P = p2p.discriminator(32, True, False, nf=4, act=linear, mul_factor=[1, 2])
+    spec = updates.rmsprop(learning_rate=updates.shared(1e-4))
+    import gan_heightmaps_amd.step as step_mod
+    orig = step_mod.Ops
+    step_mod.Ops = RecordingOps
+    try:
+        eng = GanStep(dev, G, Dn, U, P, 100, True, 'l1', spec, 'both', use_graph=False, two_streams=False)
+        plans = [eng.built(4, 0), eng.built(4, 1)]
+        pool = [(dev.empty((4, 24)), dev.empty((4, 1, 32, 32)), dev.empty((4, 3, 32, 32))) for _ in range(3)]
+        FakeDevice.pipe_log.clear()
+        eng.upload_resident_async(plans[0], *pool[0])
+        for k in range(5):
+            eng.enqueue_train_uploaded(plans[k & 1])
+            eng.upload_resident_async(plans[(k + 1) & 1], *pool[(k + 1) % 3])
+    finally:
+        step_mod.Ops = orig
+    log = FakeDevice.pipe_log
+    cps = [e for e in log if e[0] == "d2d"]
+    assert len(cps) == 3 * 6
+    # z of batch k: from pool[k % 3] into plans[k & 1], whole tensor
+    for k in range(6):
+        z = cps[3 * k]
+        assert z[1] == plans[k & 1].z.ptr and z[2] == pool[k % 3][0].ptr and z[3] == 4 * 4 * 24
+        assert cps[3 * k + 1][1] == plans[k & 1].x.ptr and cps[3 * k + 2][1] == plans[k & 1].y.ptr
+    # every step's stage stream waits for an event recorded after that batch's three copies
+    waits = [i for i, e in enumerate(log) if e[0] == "wait"]
+    assert len(waits) == 5
+    for k, wi in enumerate(waits):
+        ri = max(i for i, e in enumerate(log[:wi]) if e[0] == "record" and e[1] == log[wi][1])
+        assert sum(1 for e in log[:ri] if e[0] == "d2d") == 3 * (k + 1)
+    # before the third copy set (plan 0 again) the host waited for the events recorded behind step 0 on that plan
+    i3 = log.index(cps[6])
+    syncs = [e for e in log[:i3] if e[0] == "host_sync"]
+    recs0 = [e[1] for e in log[:i3] if e[0] == "record"]
+    assert syncs and all(e[1] in recs0 for e in syncs)
+    eng.close_pipeline()
+
+
+def test_bench_stdout_line_is_short_strict_json():
+    """the driver keeps only the tail of bench.py's stdout: the ONE JSON line must stay below 4096 bytes whatever the side
+    record holds (round 5's 20.8 KB line was not parsed), be strict JSON, and keep the contract's keys + roofline + cpu_baseline"""
+    import json
+    import bench
+    thin = [{"entry": "conv_fwd", "kernel": "fanout_kernel<18, 2, 4>", "geom": "N8 C4 512x512 K64 5x5", "ms": 0.1,
+             "algorithmic_MB": 537.0, "GB/s": 3400.0, "frac_of_8TB/s": 0.42, "moved_MB": 700.0, "moved_GB/s": 4400.0}] * 21
+    roof = {"bound": "mfma", "achieved": 109.8, "peak": 416.67, "kernel_dtype": "bf16x3", "unit": "TFLOP/s", "frac": 0.2635,
+            "traffic": 211000000.0, "concurrent_streams": 3, "achieved_isolated": 206.4, "frac_isolated": 0.495,
+            "kernel": "sp_conv2_kernel<3, 1", "launches_per_step": 14, "avg_launch_ms": 0.3867,
+            "algorithmic_gflop_per_launch": 42.451, "share_of_step_time": 0.379}
+    sec = {"name": "x" * 48, "metric": "m", "value": 1.0, "config": {"workload": "w" * 400}, "roofline": roof, "losses": [0.1] * 5}
+    out = {"metric": "512px heightmap+texture train images/sec", "value": 280.3, "unit": "images/s", "n_gpus": 1, "steps": 20,
+           "warmup": 5, "ms_per_step": 14.27, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3",
+           "data": "synthetic", "config": {"workload": "w" * 600, "global_batch": 4, "in_shp": 512, "parallelism": "dp1",
+                                           "hip_graph": False, "issue": "recorded", "host_calls_per_step": 1, "streams": 3},
+           "step_frac_of_peak": 0.4596, "step_executed_frac_of_peak": 0.4004, "losses": [0.123456789] * 5,
+           "steady_state": {"steps": 60, "after_steps": 25, "value": 285.4}, "value_lr0": 275.0, "value_single_batch": 281.0,
+           "resident_batches": 8, "hbm_bound_layers": {"note": "n" * 200, "total_ms": 1.0, "launches": thin}, "roofline": roof,
+           "secondary": [sec] * 9, "value_fp32_mfma": 180.2, "arithmetic_note": "a" * 500,
+           "cpu_baseline": {"value": 0.0719, "unit": "images/s", "cores": 64, "kind": "port", "sample": "s" * 400,
+                            "config1": {"value": 24.0, "unit": "images/s", "sample": "t" * 300}},
+           "exchange": {"rccl_nranks": 8, "buckets": [{"label": "allreduce_p2p_gen_%d" % i, "MB": 32.0, "avg_ms": 0.5}
+                                                      for i in range(40)], "exposed_wait_ms_per_step": {"A": 0.1, "B": 0.2}},
+           "side_file": "gpurun_out/bench_secondary.json"}
+    assert len(json.dumps(out)) > 12000
+    txt = bench.headline_line(out)
+    assert len(txt.encode()) < 4096 and "\n" not in txt
+    line = json.loads(txt, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))     # no NaN / Infinity
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "value_fp32_mfma", "value_lr0", "step_executed_frac_of_peak"):
+        assert k in line, k
+    assert "secondary" not in line and "hbm_bound_layers" not in line and "arithmetic_note" not in line
+    assert line["roofline"]["frac"] == 0.2635 and line["cpu_baseline"]["cores"] == 64 and line["config"]["workload"].endswith("...")
+
+
 def test_discriminator_conv_lrelu_maxpool_is_fused_when_the_library_serves_it():
     """Conv2DLayer -> LeakyRectify -> MaxPool2DLayer (dcgan.py:42-47) becomes one 'convpool' node: pooled output, a
     byte mask, and in the backward the mask pass (which also sums the bias gradient) in front of an ordinary conv
