@@ -14,7 +14,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["ctx.hip", "conv_igemm.hip", "conv_lp.hip", "conv_small.hip", "conv_thin.hip", "conv_thin_lp.hip", "conv_split.hip", "conv_pool_bwd.hip", "elementwise.hip", "elementwise_q.hip", "comm.hip"]
+SOURCES = ["ctx.hip", "conv_igemm.hip", "conv_lp.hip", "conv_small.hip", "conv_thin.hip", "conv_thin_lp.hip", "conv_split.hip", "conv_pool_bwd.hip", "conv_bilinear.hip", "elementwise.hip", "elementwise_q.hip", "comm.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "ghm.h")]
 OUT = os.path.join(os.path.dirname(HERE), "libghm.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

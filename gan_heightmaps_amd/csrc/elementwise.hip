@@ -869,8 +869,17 @@ struct CollapseItem {
     const float* bias;
     float* wpc;
     float* bias4;
-    int C, K, block_begin, pad;
+    int C, K, block_begin, mode;      // mode 0: Upscale2D (nearest) -> 5x5; 1: BilinearUpsample2D -> 3x3 (conv_bilinear.hip)
 };
+
+// BilinearUpsample2DLayer(2) -> 3x3 'same' convolution on the zero-extended coarse grid (conv_bilinear.hip: the U0 operator):
+// coefficient of fine correlation tap a (offset a - 1) in coarse tap r (offset r - 1) for output parity p
+//   p = 0 (u[2m-1], u[2m], u[2m+1] = (x[m-1] + x[m]) / 2, x[m], (x[m] + x[m+1]) / 2):  r = 0: (1/2, 0, 0)  1: (1/2, 1, 1/2)  2: (0, 0, 1/2)
+//   p = 1 (u[2m], u[2m+1], u[2m+2] = x[m], (x[m] + x[m+1]) / 2, x[m+1]):              r = 0: none         1: (1, 1/2, 0)    2: (0, 1/2, 1)
+__device__ __forceinline__ float blconv_coef(int p, int r, int a) {
+    if (p == 0) return r == 1 ? (a == 1 ? 1.f : 0.5f) : ((r == 0 && a == 0) || (r == 2 && a == 2) ? 0.5f : 0.f);
+    return r == 0 ? 0.f : (a == 1 ? 0.5f : ((r == 1 && a == 0) || (r == 2 && a == 2) ? 1.f : 0.f));
+}
 
 __global__ __launch_bounds__(256) void upconv_collapse_batched_kernel(const CollapseItem* __restrict__ items, int n) {
     int li = 0;
@@ -888,10 +897,18 @@ __global__ __launch_bounds__(256) void upconv_collapse_batched_kernel(const Coll
         const int c = (int)(t / 9);
         const int p = pq >> 1, q = pq & 1, r = rs / 3, s_ = rs % 3;
         float v = 0.f;
-        for (int a = 0; a < 5; ++a) {
-            if (upconv_group(p, a) != r) continue;
-            for (int b = 0; b < 5; ++b)
-                if (upconv_group(q, b) == s_) v += it.wp5[((long)c * 25 + a * 5 + b) * K + k];
+        if (it.mode == 1) {
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    const float cf = blconv_coef(p, r, a) * blconv_coef(q, s_, b);
+                    if (cf != 0.f) v += cf * it.wp5[((long)c * 9 + a * 3 + b) * K + k];
+                }
+        } else {
+            for (int a = 0; a < 5; ++a) {
+                if (upconv_group(p, a) != r) continue;
+                for (int b = 0; b < 5; ++b)
+                    if (upconv_group(q, b) == s_) v += it.wp5[((long)c * 25 + a * 5 + b) * K + k];
+            }
         }
         it.wpc[i] = v;
     } else if (it.bias && it.bias4 && i < total + 4L * it.K) {
@@ -903,7 +920,7 @@ __global__ __launch_bounds__(256) void upconv_collapse_batched_kernel(const Coll
 struct ExpandItem {
     const float* dwpc;
     float* dwp5;
-    int C, K, block_begin, pad;
+    int C, K, block_begin, mode;      // as CollapseItem
 };
 
 __global__ __launch_bounds__(256) void upconv_expand_batched_kernel(const ExpandItem* __restrict__ items, int n, int accumulate) {
@@ -911,12 +928,25 @@ __global__ __launch_bounds__(256) void upconv_expand_batched_kernel(const Expand
     for (int i = 1; i < n; ++i)
         if ((int)blockIdx.x >= items[i].block_begin) li = i;
     const ExpandItem it = items[li];
-    const long total = (long)it.C * 25 * it.K;
+    const long total = (long)it.C * (it.mode == 1 ? 9 : 25) * it.K;
     const long i = (long)(blockIdx.x - it.block_begin) * 256 + threadIdx.x;
     if (i >= total) return;
     const int K = it.K;
     const int k = (int)(i % K);
     long t = i / K;
+    if (it.mode == 1) {                 // the transposed tap map of the bilinear collapse
+        const int ab = (int)(t % 9);
+        const int c = (int)(t / 9);
+        const int a = ab / 3, b = ab % 3;
+        float v = 0.f;
+        for (int pq = 0; pq < 4; ++pq)
+            for (int rs = 0; rs < 9; ++rs) {
+                const float cf = blconv_coef(pq >> 1, rs / 3, a) * blconv_coef(pq & 1, rs % 3, b);
+                if (cf != 0.f) v += cf * it.dwpc[(((long)c * 9 + rs) * 4 + pq) * K + k];
+            }
+        it.dwp5[i] = accumulate ? it.dwp5[i] + v : v;
+        return;
+    }
     const int ab = (int)(t % 25);
     const int c = (int)(t / 25);
     const int a = ab / 5, b = ab % 5;

@@ -409,13 +409,13 @@ class Ops:
         call("ghm_conv2d_transpose_weights", self.h, C.byref(d), _vp(wp), _vp(wpT))
 
     def collapse_table(self, items):
-        """items: [(wp5, bias, wpc, bias4 DevTensors, C, K)] -> (device table ptr, n, total blocks) for
-        upconv_collapse_batched (uploaded once: the pointers are fixed for the life of a plan)"""
+        """items: [(wp5, bias, wpc, bias4 DevTensors, C, K[, mode])] -> (device table ptr, n, total blocks) for
+        upconv_collapse_batched (uploaded once: the pointers are fixed for the life of a plan); mode 1 = the bilinear form"""
         rec = np.zeros(len(items), dtype=[('wp5', '<u8'), ('bias', '<u8'), ('wpc', '<u8'), ('b4', '<u8'), ('C', '<i4'),
                                           ('K', '<i4'), ('b0', '<i4'), ('pad', '<i4')])
         b0 = 0
-        for i, (w5, b, wpc, b4, Cc, K) in enumerate(items):
-            rec[i] = (w5.ptr, b.ptr if b is not None else 0, wpc.ptr, b4.ptr if b4 is not None else 0, Cc, K, b0, 0)
+        for i, (w5, b, wpc, b4, Cc, K, *mode) in enumerate(items):
+            rec[i] = (w5.ptr, b.ptr if b is not None else 0, wpc.ptr, b4.ptr if b4 is not None else 0, Cc, K, b0, mode[0] if mode else 0)
             b0 += (36 * Cc * K + 4 * K + 255) // 256
         ptr = self.dev.alloc(max(rec.nbytes, 40))
         self.dev.h2d(ptr, rec.view(np.uint8))
@@ -430,8 +430,8 @@ class Ops:
         rec = np.zeros(len(items), dtype=[('dwpc', '<u8'), ('dwp5', '<u8'), ('C', '<i4'), ('K', '<i4'), ('b0', '<i4'),
                                           ('pad', '<i4')])
         b0 = 0
-        for i, (dwpc, dwp5, Cc, K) in enumerate(items):
-            rec[i] = (dwpc.ptr, dwp5.ptr, Cc, K, b0, 0)
+        for i, (dwpc, dwp5, Cc, K, *mode) in enumerate(items):
+            rec[i] = (dwpc.ptr, dwp5.ptr, Cc, K, b0, mode[0] if mode else 0)
             b0 += (25 * Cc * K + 255) // 256
         ptr = self.dev.alloc(max(rec.nbytes, 32))
         self.dev.h2d(ptr, rec.view(np.uint8))
@@ -440,6 +440,28 @@ class Ops:
     def upconv_expand_batched(self, table, accumulate=False):
         ptr, n, blocks = table
         call("ghm_upconv_expand_batched", self.h, C.c_void_p(ptr), n, blocks, int(accumulate))
+
+    # ---- BilinearUpsample2DLayer(2) -> 3x3 conv: the frame the collapsed convolution leaves out (csrc/conv_bilinear.hip) ----
+    def blconv_supported(self, N, Cc, K, n1, n2):
+        return bool(_lib.load().ghm_blconv_supported(int(N), int(Cc), int(K), int(n1), int(n2)))
+
+    def blconv_frame_sizes(self, N, Cc, K, n1, n2):
+        a, b = C.c_int64(), C.c_int64()
+        call("ghm_blconv_frame_sizes", int(N), int(Cc), int(K), int(n1), int(n2), C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def blconv_frame_fwd(self, x, wp, y_pp, K, FL):
+        """y_pp [N, 4K, n1, n2] += conv3x3(frame of x); x: the coarse fp32 input; wp: the layer's packed 3x3 weights"""
+        call("ghm_blconv_frame_fwd", self.h, _vp(x), x.nstride, _vp(wp), _vp(y_pp), y_pp.nstride, x.N, x.Cc, int(K), x.H, x.W, _vp(FL))
+
+    def blconv_frame_gather(self, dy_pp, Cc, K, DYL):
+        call("ghm_blconv_frame_gather", self.h, _vp(dy_pp), dy_pp.nstride, dy_pp.N, int(Cc), int(K), dy_pp.H, dy_pp.W, _vp(DYL))
+
+    def blconv_frame_dgrad(self, DYL, wp, dx, K):
+        call("ghm_blconv_frame_dgrad", self.h, _vp(DYL), _vp(wp), _vp(dx), dx.nstride, dx.N, dx.Cc, int(K), dx.H, dx.W)
+
+    def blconv_frame_wgrad(self, DYL, FL, dwp, N, Cc, K, n1, n2):
+        call("ghm_blconv_frame_wgrad", self.h, _vp(DYL), _vp(FL), _vp(dwp), int(N), int(Cc), int(K), int(n1), int(n2))
 
     def transpose_table(self, items):
         """items: [(wp DevTensor, wpT DevTensor, C, T, K)] -> (device table ptr, n, total blocks) for

@@ -313,6 +313,58 @@ def bilinear_up2_vjp(g):
     return _bilin_axis_vjp(_bilin_axis_vjp(g, 3), 2)
 
 
+# ---- BilinearUpsample2DLayer(2) -> 3x3 'same' Conv2DLayer on the COARSE grid (architectures/p2p.py:204-267 with
+# architectures/layers.py:13-26).  Test infrastructure for csrc/conv_bilinear.hip; the algebra, per axis, fine index -1 .. 2n:
+#   U  = Theano's operator (above) with the convolution's ring of zeros,
+#   U0 = the natural operator on x extended by zeros: u0[2m] = x[m], u0[2m+1] = (x[m] + x[m+1]) / 2 for m = -1 .. n,
+#   U x = U0 x + D x,  (D x)[-1] = -x[0] / 2,  (D x)[2n-1] = +x[n-1] / 2, zero elsewhere
+# so that  conv(U x U^T) = conv(U0 x U0^T) + conv(F),  F = (D x) U^T + U0 (x D^T): four zero-padded coarse convolutions with
+# collapsed taps (one per output parity) plus a frame of two fine rows and two fine columns.
+_BL_COEF = (np.array([[.5, 0, 0], [.5, 1, .5], [0, 0, .5]]),      # even outputs: [coarse tap r][fine tap a]
+            np.array([[0, 0, 0], [1, .5, 0], [0, .5, 1]]))        # odd outputs: coarse offsets 0, +1
+
+
+def bilinear_conv_collapse(Wcorr):
+    """correlation taps [K, C, 3, 3] of the fine convolution -> [4][K, C, 3, 3] coarse correlation taps, class = 2 p + q
+    (25 of the 36 non-zero)"""
+    return [np.einsum('ra,sb,kcab->kcrs', _BL_COEF[p], _BL_COEF[q], Wcorr) for p in (0, 1) for q in (0, 1)]
+
+
+def bilinear_conv_expand(dWc):
+    """the transposed tap map: gradients of the four collapsed tap sets -> gradient of the fine correlation taps"""
+    return sum(np.einsum('ra,sb,kcrs->kcab', _BL_COEF[pq >> 1], _BL_COEF[pq & 1], dWc[pq]) for pq in range(4))
+
+
+def _bl_u0_axis(v, axis):
+    """U0 along ``axis``: n samples -> fine positions -1 .. 2n (2n + 2 values)"""
+    v = np.moveaxis(v, axis, -1)
+    n = v.shape[-1]
+    z = np.zeros_like(v[..., :1])
+    vp = np.concatenate([z, v, z], -1)
+    out = np.zeros(v.shape[:-1] + (2 * n + 2,), v.dtype)
+    out[..., 1::2] = vp[..., 1:]
+    out[..., 0::2] = 0.5 * (vp[..., :-1] + vp[..., 1:])
+    return np.moveaxis(out, -1, axis)
+
+
+def _bl_u_axis(v, axis):
+    """U along ``axis``: Theano's operator embedded in -1 .. 2n (zero ring)"""
+    pad = [(0, 0)] * v.ndim
+    pad[axis] = (1, 1)
+    return np.pad(_bilin_axis_fwd(v, axis), pad)
+
+
+def bilinear_conv_frame(x):
+    """F [N, C, 2 n1 + 2, 2 n2 + 2]: U x U^T - U0 x U0^T, non-zero on fine rows -1, 2 n1 - 1 and columns -1, 2 n2 - 1"""
+    return _bl_u_axis(_bl_u_axis(x, 2) - _bl_u0_axis(x, 2), 3) + _bl_u0_axis(_bl_u_axis(x, 3) - _bl_u0_axis(x, 3), 2)
+
+
+def bilinear_conv_main(x, W):
+    """conv3x3(U0 x U0^T) as the four collapsed coarse convolutions, parity-planar [N, 4, K, n1, n2] (no bias)"""
+    Wc = bilinear_conv_collapse(_flip(W))
+    return np.stack([corr2d_fwd(x, Wc[pq], 1, 1) for pq in range(4)], 1)
+
+
 def bilinear_theano_literal(x, ratio=2):
     """Literal transcription of theano.tensor.nnet.abstract_conv.bilinear_upsampling
     (use_1D_kernel=True): replicate the border once, transposed-conv each axis with the

@@ -629,6 +629,72 @@ def test_upscale_conv5_collapsed_to_four_3x3(gpu, case):
     assert rel(dbd.numpy().ravel(), db_ref) < TOL
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 5, 7), (1, 32, 64, 2, 2), (2, 64, 32, 8, 16), (1, 96, 32, 16, 16), (3, 32, 32, 2, 9),
+                                  (4, 64, 64, 32, 32)])
+def test_bilinear_conv3_collapsed_onto_the_coarse_grid(gpu, case):
+    """BilinearUpsample2DLayer(2) -> Conv2DLayer(3x3, 'same') (p2p.py:204-267, layers.py:13-26) without the up-sampled tensor:
+    the collapsed 3x3 convolution with 4K filters on the coarse input (ghm_upconv_collapse_batched mode 1) + the frame the
+    zero extension leaves out (ghm_blconv_frame_*): forward, data gradient and weight gradient against the oracle's literal
+    bilinear up-sampling + convolution -- odd sizes, 2 x 2 maps, rectangular maps, both borders."""
+    dev, ops, D = gpu
+    N, C, K, n1, n2 = case
+    assert ops.blconv_supported(N, C, K, n1, n2)
+    rng = np.random.RandomState(sum(case))
+    x = rng.randn(N, C, n1, n2).astype(np.float32)
+    Wt = (rng.randn(K, C, 3, 3) / np.sqrt(C * 9)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    xu = O.bilinear_up2_fwd(x.astype(np.float64))
+    y_ref = O.conv2d_fwd(xu, Wt.astype(np.float64), b.astype(np.float64), 1, 1)
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    dxu, dW_ref, _ = O.conv2d_vjp(xu, Wt.astype(np.float64), dy.astype(np.float64), 1, 1)
+    dx_ref = O.bilinear_up2_vjp(dxu)
+
+    wp3 = dev.tensor(D.pack_conv_w(Wt).ravel())
+    bd = dev.tensor(b)
+    wpc, b4 = dev.empty((1, C * 9 * 4 * K, 1, 1)), dev.empty((1, 4 * K, 1, 1))
+    ops.upconv_collapse_batched(ops.collapse_table([(wp3, bd, wpc, b4, C, K, 1)]))
+    assert np.array_equal(b4.numpy().ravel(), np.tile(b, 4))
+    # the collapsed taps against the oracle's: [c][rs][pq][k]
+    Wc = O.bilinear_conv_collapse(O._flip(Wt.astype(np.float64)))
+    want = np.stack([w.reshape(K, C, 9) for w in Wc], 0).transpose(2, 3, 0, 1)       # [c][rs][pq][k]
+    assert rel(wpc.numpy().ravel(), want.ravel()) < 1e-6
+    d = D.conv_desc(N, C, n1, n2, 4 * K, 3, 3, 1, 1)
+    xd = dev.tensor(x)
+    pp = dev.empty((4 * N, K, n1, n2))
+    y4 = pp.reshape((N, 4 * K, n1, n2))
+    ops.conv2d_fwd(d, xd, wpc, b4, y4)
+    main = O.bilinear_conv_main(x.astype(np.float64), Wt.astype(np.float64)) + np.tile(b, 4).reshape(1, 4, K, 1, 1)
+    assert rel(y4.numpy().reshape(N, 4, K, n1, n2), main) < TOL
+    nfl, ndyl = ops.blconv_frame_sizes(N, C, K, n1, n2)
+    FL, DYL = dev.empty((1, nfl, 1, 1)), dev.empty((1, ndyl, 1, 1))
+    ops.blconv_frame_fwd(xd, wp3, y4, K, FL)
+    hi = dev.empty((N, K, 2 * n1, 2 * n2))
+    ops.pp_to_hi(pp, hi)
+    assert rel(hi.numpy(), y_ref) < TOL
+    # backward
+    dpp = dev.empty((4 * N, K, n1, n2))
+    ops.hi_to_pp(dev.tensor(dy), dpp)
+    g4 = dpp.reshape((N, 4 * K, n1, n2))
+    dxd = dev.empty((N, C, n1, n2))
+    ops.conv2d_dgrad(d, g4, wpc, dxd)
+    ops.blconv_frame_gather(g4, C, K, DYL)
+    ops.blconv_frame_dgrad(DYL, wp3, dxd, K)
+    assert rel(dxd.numpy(), dx_ref) < TOL
+    dwc = dev.zeros((1, C * 9 * 4 * K, 1, 1))
+    ops.conv2d_wgrad(d, xd, g4, dwc, dev.alloc(ops.wgrad_workspace(d)))
+    dw3 = dev.zeros((1, C * 9 * K, 1, 1))
+    ops.upconv_expand_batched(ops.expand_table([(dwc, dw3, C, K, 1)]))
+    ops.blconv_frame_wgrad(DYL, FL, dw3, N, C, K, n1, n2)
+    assert rel(D.unpack_conv_w(dw3.numpy().ravel(), K, C, 3, 3), dW_ref) < TOL
+    # into a wider destination (the decoder's output is a channel slice of a ConcatLayer buffer): dx with a sample stride
+    wide = dev.zeros((N, C + 32, n1, n2))
+    view = wide.channels(32, 32 + C)
+    ops.conv2d_dgrad(D.conv_desc(N, C, n1, n2, 4 * K, 3, 3, 1, 1, view.nstride, g4.nstride), g4, wpc, view)
+    ops.blconv_frame_dgrad(DYL, wp3, view, K)
+    got = wide.numpy()
+    assert rel(got[:, 32:], dx_ref) < TOL and not got[:, :32].any()
+
+
 def test_dropout_hash_mask_and_backward(gpu):
     """DropoutLayer(p): the device mask is bit-identical to oracle.ops.dropout_mask for the same (key, step); the
     backward is the same call on dy; a tick of the device counter changes the mask"""

@@ -121,6 +121,48 @@ def test_bilinear_closed_form_equals_theano_algorithm(hw):
     assert np.isclose((a * g).sum(), (x * ops.bilinear_up2_vjp(g)).sum())
 
 
+@pytest.mark.parametrize("case", [(2, 3, 4, 5, 7), (1, 2, 3, 2, 2), (1, 2, 2, 2, 3), (2, 4, 5, 8, 6), (1, 3, 2, 16, 16)])
+def test_bilinear_conv_on_the_coarse_grid(case):
+    """BilinearUpsample2DLayer(2) -> 3x3 'same' Conv2DLayer (p2p.py:204-267) == four collapsed coarse convolutions of the
+    zero-extended input + the convolution of a frame of two fine rows and two fine columns (oracle/ops.py
+    bilinear_conv_*; the statement csrc/conv_bilinear.hip is tested against): forward, and both gradients through the
+    decomposition, against the literal up-sample + convolution -- odd sizes, 2 x 2 maps, both borders."""
+    N, C, K, n1, n2 = case
+    rng = np.random.RandomState(sum(case))
+    x, W, b = rng.randn(N, C, n1, n2), rng.randn(K, C, 3, 3), rng.randn(K)
+    ref = ops.conv2d_fwd(ops.bilinear_up2_fwd(x), W, b, 1, 1)
+    main = ops.bilinear_conv_main(x, W)                         # [N, 4, K, n1, n2]
+    Fr = ops.bilinear_conv_frame(x)
+    assert np.count_nonzero(np.abs(Fr[:, :, 1:-2, 1:-2]).sum((0, 1))) == 0          # only the frame lines
+    y = np.zeros_like(ref)
+    for pq in range(4):
+        y[:, :, (pq >> 1)::2, (pq & 1)::2] = main[:, pq]
+    yF = ops.corr2d_fwd(Fr, ops._flip(W), 1, 0)
+    touched = np.abs(yF).sum((0, 1)) > 1e-13
+    edge = np.zeros_like(touched)
+    edge[[0, -2, -1], :] = True
+    edge[:, [0, -2, -1]] = True
+    assert not np.any(touched & ~edge)                          # the frame reaches rows / columns 0, 2n-2, 2n-1 only
+    assert np.allclose(y + yF + b.reshape(1, -1, 1, 1), ref, atol=1e-12)
+    # collapsed taps: 9 / 6 / 6 / 4 non-zero
+    Wc = ops.bilinear_conv_collapse(ops._flip(W))
+    assert [int(np.count_nonzero(np.abs(w).sum((0, 1)))) for w in Wc] == [9, 6, 6, 4]
+    # gradients through the decomposition == gradients of the literal form
+    dy = rng.randn(*ref.shape)
+    dxu, dW_ref, _ = ops.conv2d_vjp(ops.bilinear_up2_fwd(x), W, dy, 1, 1)
+    dx_ref = ops.bilinear_up2_vjp(dxu)
+    dWc = [ops.corr2d_bwd_weight(x, dy[:, :, (pq >> 1)::2, (pq & 1)::2], 1, 1, 3, 3) for pq in range(4)]
+    dW_main = ops._flip(ops.bilinear_conv_expand(dWc))
+    dW_frame = ops._flip(ops.corr2d_bwd_weight(Fr, dy, 1, 0, 3, 3))
+    assert np.allclose(dW_main + dW_frame, dW_ref, atol=1e-10)
+    dx_main = sum(ops.corr2d_bwd_input(dy[:, :, (pq >> 1)::2, (pq & 1)::2], Wc[pq], 1, 1, n1, n2) for pq in range(4))
+    eps = 1e-6                                                  # the frame is linear in x: its vjp by a directional probe
+    v = rng.randn(*x.shape)
+    lhs = ((dx_ref - dx_main) * v).sum()
+    rhs = (ops.corr2d_fwd(ops.bilinear_conv_frame(v), ops._flip(W), 1, 0) * dy).sum()
+    assert abs(lhs - rhs) <= 1e-9 * (1 + abs(rhs))
+
+
 def test_optimizers_against_torch_formulas():
     p, g = rng.randn(50), rng.randn(50)
     acc = np.abs(rng.randn(50))
