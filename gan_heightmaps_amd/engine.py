@@ -213,7 +213,25 @@ def _replace(order, old, new):
         n.inputs = [new if i is old else i for i in n.inputs]
 
 
-def _rewrite(out_node):
+def _blconv_wanted(conv_layer, up_layer, dtype):
+    """BilinearUpsample2DLayer(2) -> 3x3 'same' stride-1 conv evaluated on the coarse grid (csrc/conv_bilinear.hip)?  Served
+    geometries: channels and filters multiples of 32, coarse maps of at least 16 x 16 (below that the layer is microseconds of
+    work either way and keeps the literal form).  In the split arithmetic modes only (the fp32-MFMA mode stays the literal
+    bit-reference of the layer); GHM_NO_BLCONV=1 keeps the literal form everywhere, GHM_BLCONV=all extends it to every mode."""
+    if os.environ.get("GHM_NO_BLCONV") is not None:
+        return False
+    if dtype not in SPLITS and os.environ.get("GHM_BLCONV") != 'all':
+        return False
+    l = conv_layer
+    if l.filter_size != (3, 3) or l.stride != (1, 1) or l.pad != (1, 1) or getattr(up_layer, 'factor', 2) != 2:
+        return False
+    cs = up_layer.input_layer.output_shape
+    nmin = int(os.environ.get("GHM_BLCONV_MIN", 16))
+    return (len(cs) == 4 and cs[1] % 32 == 0 and l.num_filters % 32 == 0 and cs[2] >= nmin and cs[3] >= nmin
+            and cs[2] % 8 == 0 and cs[3] % 8 == 0)
+
+
+def _rewrite(out_node, dtype='f32'):
     # R1: act(concat(..)) -> concat(act(..)..) with CSE
     changed = True
     while changed:
@@ -261,12 +279,21 @@ def _rewrite(out_node):
             changed = False
             order = _toposort(out_node)
             for n in order:
-                if n.op != 'conv' or n.inputs[0].op != 'up_nearest' or len(n.inputs[0].consumers) != 1:
+                if n.op != 'conv' or n.inputs[0].op not in ('up_nearest', 'up_bilinear') or len(n.inputs[0].consumers) != 1:
                     continue
                 l = n.layer
-                if l.filter_size != (5, 5) or l.stride != (1, 1) or l.pad != (2, 2):
-                    continue
-                uc = Node('upconv', [n.inputs[0].inputs[0]], l)
+                if n.inputs[0].op == 'up_nearest':
+                    if l.filter_size != (5, 5) or l.stride != (1, 1) or l.pad != (2, 2):
+                        continue
+                    mode = 0
+                else:
+                    # R3b: BilinearUpsample2DLayer(2) -> 3x3 'same' conv (p2p.py:204-267) the same way: a packed 3x3 conv with
+                    # 4K filters on the coarse input (25 of its 36 collapsed taps non-zero) + the frame Theano's border
+                    # handling adds (csrc/conv_bilinear.hip); mode 1 of the same node
+                    if not _blconv_wanted(l, n.inputs[0].layer, dtype):
+                        continue
+                    mode = 1
+                uc = Node('upconv', [n.inputs[0].inputs[0]], l, mode=mode)
                 uc.act = n.act
                 tail_old, tail_new = n, uc
                 if len(n.consumers) == 1 and n.consumers[0].op == 'bn':
@@ -301,7 +328,7 @@ class NetPlan:
         # every BatchNormLayer normalises each half with its own statistics
         self.bn_groups = bn_groups
         nodes, of = _build_ir(out_layer)
-        self.out_node = _rewrite(of[id(out_layer)])
+        self.out_node = _rewrite(of[id(out_layer)], dtype)
         self.order = _toposort(self.out_node)
         self.node_of_layer = of
         self.input_nodes = [n for n in self.order if n.op == 'input']
@@ -423,7 +450,7 @@ class NetPlan:
             if n.op == 'concat':
                 c0 = 0
                 for i in n.inputs:
-                    if i.alias is None and i.op in ('conv', 'deconv', 'dense', 'bn', 'act', 'input') and i.out is None:
+                    if i.alias is None and i.op in ('conv', 'deconv', 'dense', 'bn', 'act', 'input', 'pp_to_hi') and i.out is None:
                         i.alias = (n, c0)
                     c0 += i.shape[1]
         if out_tensor is not None:
@@ -471,6 +498,12 @@ class NetPlan:
                 for name in ('wpc', 'wpcT', 'dwpc'):
                     n.aux[name] = self.dev.empty((1, C * 9 * 4 * K, 1, 1))
                 n.aux['b4'] = self.dev.empty((1, 4 * K, 1, 1))
+                if n.attrs.get('mode') == 1:
+                    xs = n.inputs[0].shape
+                    if not self.ops.blconv_supported(xs[0], C, K, xs[2], xs[3]):
+                        raise NotImplementedError("bilinear up-sample convolution %r: geometry not served by the library" % (n,))
+                    nfl, ndyl = self.ops.blconv_frame_sizes(xs[0], C, K, xs[2], xs[3])
+                    n.aux['fl'], n.aux['dyl'] = self.dev.empty((1, nfl, 1, 1)), self.dev.empty((1, ndyl, 1, 1))
 
     def _place_q(self):
         """allocate the q copy of every node output that a low-precision forward product reads (the conv's input): the
@@ -520,6 +553,8 @@ class NetPlan:
             if c.op in ('conv', 'convpool') and c.inputs[0] is n:
                 d = self._desc(c, n.out, self._full(c))
             elif c.op == 'upconv' and c.inputs[0] is n:
+                if c.attrs.get('mode') == 1:
+                    return True             # the frame kernels (conv_bilinear.hip) read the coarse fp32 border rows / columns
                 d = self._upconv_desc(c, n.out)
             else:
                 return True
@@ -669,8 +704,8 @@ class NetPlan:
         if ups:
             if getattr(self, '_collapse_tab', None) is None:
                 self._collapse_tab = ops.collapse_table(
-                    [(st.value(n.layer.W), st.value(n.layer.b), n.aux['wpc'], n.aux['b4'], n.inputs[0].shape[1], n.shape[1])
-                     for n in ups])
+                    [(st.value(n.layer.W), st.value(n.layer.b), n.aux['wpc'], n.aux['b4'], n.inputs[0].shape[1], n.shape[1],
+                      n.attrs.get('mode', 0)) for n in ups])
             prog.append(("collapse_w", lambda t=self._collapse_tab: ops.upconv_collapse_batched(t)))
         if self._lp_table is not None:
             prog.append(("lp_pack", lambda t=self._lp_table: ops.lp_pack_batched(t, self.dtype)))
@@ -837,20 +872,26 @@ class NetPlan:
                 w5, b = st.value(n.layer.W), st.value(n.layer.b)
                 wpc, b4 = n.aux['wpc'], n.aux['b4']
                 C, K = x.Cc, n.shape[1]
+                ulab = 'blconv' if n.attrs.get('mode') == 1 else 'upconv'     # (bench.py prices 'upconv' launches at 25 / 9)
                 y4 = y.reshape((x.N, 4 * K, x.H, x.W))
                 if self._lp(d, 0):
                     wq = self._lp_pack_entry(prog, d, wpc, ('c', id(n.layer.W)), False, None)    # after collapse_w
                     if xq is not None:
-                        prog.append(("upconv_fwd", lambda d=d, xq=xq, wq=wq, b4=b4, y4=y4, a=a:
+                        prog.append((ulab + "_fwd", lambda d=d, xq=xq, wq=wq, b4=b4, y4=y4, a=a:
                                      ops.conv2d_fwd_lp_q(d, xq, wq, b4, y4, None, self.dtype, a.kind, a.alpha),
                                      conv_meta(ops, d, 0, self.dtype)))
                     else:
-                        prog.append(("upconv_fwd", lambda d=d, x=x, wq=wq, b4=b4, y4=y4, a=a:
+                        prog.append((ulab + "_fwd", lambda d=d, x=x, wq=wq, b4=b4, y4=y4, a=a:
                                      ops.conv2d_fwd_lp(d, x, wq, b4, y4, self.dtype, a.kind, a.alpha),
                                      conv_meta(ops, d, 0, self.dtype)))
                 else:
-                    prog.append(("upconv_fwd", lambda d=d, x=x, wpc=wpc, b4=b4, y4=y4, a=a:
+                    prog.append((ulab + "_fwd", lambda d=d, x=x, wpc=wpc, b4=b4, y4=y4, a=a:
                                  ops.conv2d_fwd(d, x, wpc, b4, y4, a.kind, a.alpha), conv_meta(ops, d, 0)))
+                if n.attrs.get('mode') == 1:
+                    if a != linear:
+                        raise NotImplementedError("bilinear up-sample convolution with its own nonlinearity")
+                    # what the zero-extended coarse convolution leaves out: Theano's border rows / columns (conv_bilinear.hip)
+                    prog.append(("blconv_frame_fwd", lambda x=x, w5=w5, y4=y4, K=K, fl=n.aux['fl']: ops.blconv_frame_fwd(x, w5, y4, K, fl)))
             elif n.op == 'pp_to_hi':
                 if id(n) in fused_hi:
                     q_direct = self.q_epi                          # written by the BatchNorm in front of it
@@ -939,7 +980,7 @@ class NetPlan:
             has_p = wgrad and n.op in ('conv', 'convpool', 'deconv', 'dense', 'bn', 'upconv')
             req[id(n)] = has_p or any(req[id(i)] for i in n.inputs) or id(n) in want_in
         grads, written = {}, set()
-        expands, expand_params = [], []
+        expands, expand_params, frames = [], [], []
         key = (tag, n0, n1)
         cache = self._scratch.setdefault(key, {})
         for n in self.order:                # flags of an earlier emit of the same (tag, slice): every emit decides afresh
@@ -1229,6 +1270,10 @@ class NetPlan:
                 wpc, wpcT, dwpc = n.aux['wpc'], n.aux['wpcT'], n.aux['dwpc']
                 xq = xin.outq
                 G4q_w = gradq_of(n, G4) if (wgrad and xq is not None and self._wq(d)) else None
+                bl = n.attrs.get('mode') == 1
+                ulab = 'blconv' if bl else 'upconv'
+                if bl:      # the six border lines of the fine gradient, for both frame gradients (before the gradient stream forks)
+                    prog.append(("blconv_frame_gather", lambda G4=G4, C=C, K=K, dyl=n.aux['dyl']: ops.blconv_frame_gather(G4, C, K, dyl)))
                 if wgrad:
                     self._need_wgrad_ws(d)
                     gw, gb = st.grad(l.W), st.grad(l.b)
@@ -1238,17 +1283,19 @@ class NetPlan:
                         wdev, wo = self.side
                         prog.append(("fork", lambda wdev=wdev: wdev.wait_for(dev), None, wdev))
                     if G4q_w is not None:
-                        prog.append(("upconv_wgrad", lambda d=d, xq=xq, G4q=G4q_w, dwpc=dwpc, wo=wo:
+                        prog.append((ulab + "_wgrad", lambda d=d, xq=xq, G4q=G4q_w, dwpc=dwpc, wo=wo:
                                      wo.conv2d_wgrad_lp_q(d, xq, G4q, dwpc, self.wgrad_ws, self.dtype, False),
                                      conv_meta(ops, d, 2, self.dtype), wdev))
                     elif self._lp(d, 2):
-                        prog.append(("upconv_wgrad", lambda d=d, x=x, G4=G4, dwpc=dwpc, wo=wo:
+                        prog.append((ulab + "_wgrad", lambda d=d, x=x, G4=G4, dwpc=dwpc, wo=wo:
                                      wo.conv2d_wgrad_lp(d, x, G4, dwpc, self.wgrad_ws, self.dtype, False),
                                      conv_meta(ops, d, 2, self.dtype), wdev))
                     else:
-                        prog.append(("upconv_wgrad", lambda d=d, x=x, G4=G4, dwpc=dwpc, wo=wo:
+                        prog.append((ulab + "_wgrad", lambda d=d, x=x, G4=G4, dwpc=dwpc, wo=wo:
                                      wo.conv2d_wgrad(d, x, G4, dwpc, self.wgrad_ws, False), conv_meta(ops, d, 2), wdev))
-                    expands.append((dwpc, gw, C, K))      # 3x3 -> 5x5 gradient expansion: one launch for all layers, below
+                    expands.append((dwpc, gw, C, K, n.attrs.get('mode', 0)))      # 3x3 -> 5x5 (-> fine 3x3) gradient expansion: one launch for all layers, below
+                    if bl:
+                        frames.append((n.aux['dyl'], n.aux['fl'], gw, x.N, C, K, x.H, x.W))
                     bn_fed = len(n.consumers) == 1 and n.consumers[0].op == 'bn' and n.act == linear
                     if not bn_fed:
                         prog.append(("bias_grad", lambda G=G, gb=gb, aw=aw, wo=wo: wo.channel_sum(G, gb, aw), None, wdev))
@@ -1260,22 +1307,25 @@ class NetPlan:
                         wqT = self._lp_pack_entry(prog, d, wpc, ('c', id(l.W)), True, transposed)
                         G4q = gradq_of(n, G4)
                         if G4q is not None:
-                            prog.append(("upconv_dgrad", lambda d=d, G4q=G4q, wqT=wqT, gi=gi, acc=acc:
+                            prog.append((ulab + "_dgrad", lambda d=d, G4q=G4q, wqT=wqT, gi=gi, acc=acc:
                                          ops.conv2d_dgrad_lp_q(d, G4q, wqT, gi, None, self.dtype, None, 'linear', 0.0, acc),
                                          conv_meta(ops, d, 3, self.dtype)))
                         else:
-                            prog.append(("upconv_dgrad", lambda d=d, G4=G4, wqT=wqT, gi=gi, acc=acc:
+                            prog.append((ulab + "_dgrad", lambda d=d, G4=G4, wqT=wqT, gi=gi, acc=acc:
                                          ops.conv2d_dgrad_lp(d, G4, wqT, gi, self.dtype, None, 'linear', 0.0, acc),
                                          conv_meta(ops, d, 3, self.dtype)))
                     elif C > 4 and ops.dgrad_t_supported(d):
                         if ('c', id(l.W)) not in transposed:
                             transposed.add(('c', id(l.W)))
                             prog.append(("transpose_w", lambda d=d, wpc=wpc, wpcT=wpcT: ops.transpose_weights(d, wpc, wpcT)))
-                        prog.append(("upconv_dgrad", lambda d=d, G4=G4, wpcT=wpcT, gi=gi, acc=acc:
+                        prog.append((ulab + "_dgrad", lambda d=d, G4=G4, wpcT=wpcT, gi=gi, acc=acc:
                                      ops.conv2d_dgrad_t(d, G4, wpcT, gi, None, 'linear', 0.0, acc), conv_meta(ops, d, 3)))
                     else:
-                        prog.append(("upconv_dgrad", lambda d=d, G4=G4, wpc=wpc, gi=gi, acc=acc:
+                        prog.append((ulab + "_dgrad", lambda d=d, G4=G4, wpc=wpc, gi=gi, acc=acc:
                                      ops.conv2d_dgrad(d, G4, wpc, gi, None, 'linear', 0.0, acc), conv_meta(ops, d, 1)))
+                    if bl:
+                        prog.append(("blconv_frame_dgrad", lambda dyl=n.aux['dyl'], w3=st.value(l.W), gi=gi, K=K:
+                                     ops.blconv_frame_dgrad(dyl, w3, gi, K)))
                     mark_written(xin)
             elif n.op == 'dropout':
                 if need_dx:
@@ -1331,7 +1381,7 @@ class NetPlan:
                     if (w_q or not wgrad) and (self._lp(dq, 1) or w_q):
                         giq = gradq_of(xin, gview, pack=False).reshape(gi.shape)
                         gq_ready.add(id(xin))
-                        gi32 = not ((w_q or not wgrad) and d_q)
+                        gi32 = not ((w_q or not wgrad) and d_q) or xin.attrs.get('mode') == 1     # (the frame reads its border lines)
                 if inst:
                     if nslice is not None:
                         raise NotImplementedError("InstanceNorm backward on a sample slice")
@@ -1420,6 +1470,9 @@ class NetPlan:
                 tab = self._scratch['tables'][tkey] = wo.expand_table(expands)
             prog.append(("expand_wgrad", lambda tab=tab, aw=accumulate_wgrad, wo=wo: wo.upconv_expand_batched(tab, aw),
                          None, wdev))
+            for dyl, fl, gw, N_, C_, K_, h_, w_ in frames:       # the frame's share of the fine weight gradients, on top
+                prog.append(("blconv_frame_wgrad", lambda dyl=dyl, fl=fl, gw=gw, N_=N_, C_=C_, K_=K_, h_=h_, w_=w_, wo=wo:
+                             wo.blconv_frame_wgrad(dyl, fl, gw, N_, C_, K_, h_, w_), None, wdev))
             done(*expand_params)
         self._last_grads = dict(grads)
         return {l: (grad_of(self.node_of_layer[id(l)]) if id(self.node_of_layer[id(l)]) in written else None)

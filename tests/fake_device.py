@@ -118,6 +118,13 @@ class RecordingOps:
     def conv_variant(self, d, kind):
         return "fake<%d>" % kind
 
+    def blconv_supported(self, N, Cc, K, n1, n2):
+        return Cc % 32 == 0 and K % 32 == 0 and n1 >= 2 and n2 >= 2
+
+    def blconv_frame_sizes(self, N, Cc, K, n1, n2):
+        lp = (2 * max(n1, n2) + 4 + 31) // 32 * 32
+        return N * 4 * Cc * lp + 64, 6 * N * K * (lp + 32)
+
     def __getattr__(self, name):
         def rec(*args, **kw):
             self.calls.append((name, args, kw))
@@ -199,7 +206,7 @@ def host_device_class():
             return (0, len(items), 0)
 
         def expand_table(self, items):
-            return [int(dwp5.ptr) for _, dwp5, _, _ in items]
+            return [int(it[1].ptr) for it in items]
 
         def upconv_expand_batched(self, table, accumulate=False):
             Shared.log.append((self.dev.name, "upconv_expand_batched") + tuple(table))     # the 5x5 gradients it writes

@@ -609,6 +609,49 @@ def test_generator_gradient_shortcut_with_a_confident_discriminator(dev, monkeyp
         assert rel(g1[('dcgan', 'gen')], g2[('dcgan', 'gen')]) < 5e-6
 
 
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16x2"])
+def test_bilinear_decoder_on_the_coarse_grid(dev, monkeypatch, dtype):
+    """p2p.g_unet(bilinear_upsample=True): every decoder stage is BilinearUpsample2DLayer(2) -> 3x3 'same' conv (p2p.py:204-267).
+    In the split modes the engine evaluates the pair on the COARSE grid (engine.py R3b, csrc/conv_bilinear.hip: collapsed 3x3
+    with 4K filters + the border frame) wherever the library serves the geometry; the up-sampled tensor is never written.
+    A/B against the literal form (GHM_NO_BLCONV=1) and the float64 oracle over three steps (eager, recorded, replayed):
+    same losses, gradients no further from the oracle than the literal form's (+ fp32 rounding), parameters after the steps."""
+    cfg = ostep.default_cfg(in_shp=128, latent_dim=16, train_mode='p2p', gen_dcgan=dict(nch=16, div=[1, 1, 2, 2, 2]),
+                            disc_dcgan=dict(nch=16, div=[2, 2, 2]), gen_p2p=dict(nf=32), disc_p2p=dict(nf=8, mul_factor=[1, 2]))
+    B, seed = 4, 7
+    a = build_model(cfg, seed, dev, dtype=dtype)
+    monkeypatch.setenv("GHM_NO_BLCONV", "1")
+    lit = build_model(cfg, seed, dev, dtype=dtype)
+    lit.engine.built(B)
+    monkeypatch.delenv("GHM_NO_BLCONV")
+    la = [e[0] for e in a.engine.built(B).train_compute[1]]
+    ll = [e[0] for e in lit.engine.built(B).train_compute[1]]
+    # decoder levels with coarse maps of 32 and 16 pixels take the coarse-grid form; the inner ones (8 .. 2) stay literal
+    assert la.count("blconv_fwd") == 2 and la.count("blconv_frame_fwd") == 2 and la.count("blconv_frame_dgrad") == 2
+    assert la.count("blconv_frame_wgrad") == 2 and "blconv_fwd" not in ll
+    assert la.count("up_bilinear_fwd") == ll.count("up_bilinear_fwd") - 2
+    state = ostep.init_state(cfg, seed, np.float32)
+    tol = 2e-4 if dtype == "bf16x3" else 2e-3
+    for it in range(3):
+        Z, X, Y = ostep.synthetic_batch(B, cfg, seed=500 + it)
+        ref = ostep.train_step(state, Z, X, Y, dtype=np.float64)
+        ga_l, gl_l = a.train_fn(Z, X, Y), lit.train_fn(Z, X, Y)
+        assert rel(ga_l, ref['losses']) < (1e-5 if dtype == "bf16x3" else 1e-4), (it, ga_l, ref['losses'])
+        assert rel(ga_l, gl_l) < (1e-5 if dtype == "bf16x3" else 1e-4)
+        ga, gl = model_grads(a), model_grads(lit)
+        for key in ref['grads']:
+            fr = np.concatenate([g.ravel() for g in ref['grads'][key]])
+            fa, fl = (np.concatenate([g.ravel() for g in x[key]]) for x in (ga, gl))
+            ea, el = rel(fa, fr), rel(fl, fr)
+            assert ea < max(tol, 2 * el + 1e-6), (it, key, ea, el)
+        # both device models and the oracle continue from the coarse-grid model's parameters
+        mp = model_params(a)
+        from gan_heightmaps_amd import layers as L
+        for key in ostep.NET_ORDER:
+            state['params'][key[0]][key[1]] = [v.copy() for v in mp[key]]
+            L.set_all_param_values(getattr(lit, key[0])[key[1]], mp[key])
+
+
 def test_patchgan_chain_without_fp32_activations(dev, monkeypatch):
     """Split modes: in the PatchGAN's conv -> LeakyRectify -> conv chain (p2p.py:278-292) every reader of an activation takes its q
     copy, and the consumer's data gradient takes the LeakyRectify slope from the SIGN of that copy's first piece
