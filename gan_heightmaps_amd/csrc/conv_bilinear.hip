@@ -47,7 +47,8 @@ struct BlGeo {
 };
 
 // ---- frame lines from the coarse tensor -------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bl_lines_kernel(const float* __restrict__ x, long xs, BlGeo g, float* __restrict__ FL) {
+__global__ __launch_bounds__(256) void bl_lines_kernel(const float* __restrict__ x, long xs, BlGeo g, float* __restrict__ FL,
+                                                       float* __restrict__ FLt) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)g.N * 4 * g.C * g.LP;
     if (idx >= total) return;
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256) void bl_lines_kernel(const float* __restrict__
         }
     }
     FL[idx] = v;
+    FLt[(((long)n * 4 + line) * g.LP + ai) * g.C + c] = v;         // [n][line][ai][c]: the weight gradient's operand (lanes along c)
 }
 
 // ---- the three line GEMMs: D[i][j] = sum_kk A[i][kk] B[kk][j] on v_mfma_f32_32x32x2_f32 -----------------------------------
@@ -138,7 +140,16 @@ __global__ __launch_bounds__(256) void bl_gemm_fwd_kernel(const float* __restric
 
 // data gradient: dFL[split][n][line][c][ai] = sum over the jobs of the line, t, k of wp[c][tap(job, t)][k] * DYL[job][n][k][ai - t + 2]
 // (DYL array index = pos + 2: two zero entries in front).  grid (C / 32, LP / 32, splits * 4 * N)
-__global__ __launch_bounds__(256) void bl_gemm_dgrad_kernel(const float* __restrict__ wp, const float* __restrict__ DYL, BlGeo g,
+__global__ __launch_bounds__(256) void bl_wt_kernel(const float* __restrict__ wp, int C, int K, float* __restrict__ wT) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;       // wT[tap][k][c] = wp[c][tap][k]
+    if (idx >= (long)9 * K * C) return;
+    const int c = (int)(idx % C);
+    const long r = idx / C;
+    const int k = (int)(r % K), tap = (int)(r / K);
+    wT[idx] = wp[((long)c * 9 + tap) * K + k];
+}
+
+__global__ __launch_bounds__(256) void bl_gemm_dgrad_kernel(const float* __restrict__ wT, const float* __restrict__ DYL, BlGeo g,
                                                             int splits, float* __restrict__ dFL) {
     __shared__ float smem[4 * 32 * 33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kg = lane >> 5;
@@ -158,12 +169,14 @@ __global__ __launch_bounds__(256) void bl_gemm_dgrad_kernel(const float* __restr
     for (int jj = 0; jj < njobs; ++jj) {
         const int job = job_lo + jj;
         const float* dy = DYL + (((long)job * g.N + n) * g.K) * LD + ai + 2;
-        const float* wc = wp + (long)c * 9 * g.K;
-        const int t0 = bl_job_tap(job, 0), t1 = bl_job_tap(job, 1), t2 = bl_job_tap(job, 2);
+        const long KC = (long)g.K * g.C;
+        const float* w0 = wT + bl_job_tap(job, 0) * KC + c;
+        const float* w1 = wT + bl_job_tap(job, 1) * KC + c;
+        const float* w2 = wT + bl_job_tap(job, 2) * KC + c;
 #pragma unroll 4
         for (int k0 = k_lo + 2 * wave; k0 < k_hi; k0 += 8) {
             const int k = k0 + kg;
-            const float a0 = wc[(long)t0 * g.K + k], a1 = wc[(long)t1 * g.K + k], a2 = wc[(long)t2 * g.K + k];
+            const float a0 = w0[(long)k * g.C], a1 = w1[(long)k * g.C], a2 = w2[(long)k * g.C];
             const float* d = dy + (long)k * LD;
             const float b0 = d[0], b1 = d[-1], b2 = d[-2];
             acc = bl_mfma(a0, b0, acc);
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(256) void bl_gemm_dgrad_kernel(const float* __restr
 // weight gradient: dWp[split][tap (A, B)][c][k] = sum over n of
 //     sum_pos DYL[rowjob(A)][n][k][pos] * FL[n][rowline(A)][c][pos + B]  +  sum_pos DYL[coljob(B)][n][k][pos] * FL[n][colline(B)][c][pos + A]
 // grid (K / 32, C / 32, splits * 9); the split deals the samples x position pairs
-__global__ __launch_bounds__(256) void bl_gemm_wgrad_kernel(const float* __restrict__ DYL, const float* __restrict__ FL, BlGeo g,
+__global__ __launch_bounds__(256) void bl_gemm_wgrad_kernel(const float* __restrict__ DYLt, const float* __restrict__ FLt, BlGeo g,
                                                             int splits, float* __restrict__ dWp) {
     __shared__ float smem[4 * 32 * 33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kg = lane >> 5;
@@ -201,8 +214,8 @@ __global__ __launch_bounds__(256) void bl_gemm_wgrad_kernel(const float* __restr
         const int n = (int)(r % g.N), part = (int)(r / g.N);
         const int pos = 2 * pp + kg;
         const int job = part ? coljob : rowjob, line = part ? colline : rowline, sh = part ? A : B;
-        const float a = DYL[(((long)job * g.N + n) * g.K + k) * LD + pos + 2];
-        const float b = (pos + sh < g.LP) ? FL[(((long)n * 4 + line) * g.C + c) * g.LP + pos + sh] : 0.f;
+        const float a = DYLt[(((long)job * g.N + n) * LD + pos + 2) * g.K + k];
+        const float b = (pos + sh < g.LP) ? FLt[(((long)n * 4 + line) * g.LP + pos + sh) * g.C + c] : 0.f;
         acc = bl_mfma(a, b, acc);
     }
     // D[i = k][j = c] -> dWp[split][tap][c][k]
@@ -245,7 +258,8 @@ __global__ __launch_bounds__(256) void bl_scatter_fwd_kernel(const float* __rest
 }
 
 // DYL[job][n][k][2 + pos] = dy (fine, from the parity-planar tensor) on the job's output line; zeros elsewhere in the row
-__global__ __launch_bounds__(256) void bl_gather_dy_kernel(const float* __restrict__ dy, long dys, BlGeo g, float* __restrict__ DYL) {
+__global__ __launch_bounds__(256) void bl_gather_dy_kernel(const float* __restrict__ dy, long dys, BlGeo g, float* __restrict__ DYL,
+                                                           float* __restrict__ DYLt) {
     const int LD = g.LP + 32;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)6 * g.N * g.K * LD) return;
@@ -269,6 +283,7 @@ __global__ __launch_bounds__(256) void bl_gather_dy_kernel(const float* __restri
         v = dy[(long)n * dys + ((long)((i & 1) * 2 + (j & 1)) * g.K + k) * g.n1 * g.n2 + (long)(i >> 1) * g.n2 + (j >> 1)];
     }
     DYL[idx] = v;
+    DYLt[(((long)job * g.N + n) * LD + ai) * g.K + k] = v;          // [job][n][ai][k]: the weight gradient's operand (lanes along k)
 }
 
 // dx[n][c][border] += the adjoint of bl_lines_kernel applied to sum over splits of dFL; one thread per (n, c, coarse border pixel)
@@ -340,8 +355,9 @@ extern "C" {
 int ghm_blconv_frame_sizes(int32_t N, int32_t C, int32_t K, int32_t n1, int32_t n2, int64_t* fl_floats, int64_t* dyl_floats) {
     GHM_CHECK(bl_ok(N, C, K, n1, n2), "ghm_blconv_frame_sizes: C and K must be multiples of 32, maps at least 2 x 2");
     const int LP = bl_lp(n1, n2);
-    *fl_floats = (int64_t)N * 4 * C * LP + 64;          // (the forward GEMM's last tile reads two entries past a row)
-    *dyl_floats = (int64_t)6 * N * K * (LP + 32);
+    *fl_floats = 2 * ((int64_t)N * 4 * C * LP + 64);    // [n][line][c][LP] and [n][line][LP][c] (the forward GEMM's last tile reads
+                                                        // two entries past a row)
+    *dyl_floats = 2 * ((int64_t)6 * N * K * (LP + 32)); // [job][n][k][LD] and [job][n][LD][k]
     return 0;
 }
 
@@ -363,7 +379,8 @@ int ghm_blconv_frame_fwd(ghm_ctx* ctx, const float* x, int64_t x_nstride, const 
                          int32_t C, int32_t K, int32_t n1, int32_t n2, float* FL) {
     GHM_CHECK(bl_ok(N, C, K, n1, n2), "ghm_blconv_frame_fwd: geometry not served");
     const BlGeo g{N, C, K, n1, n2, bl_lp(n1, n2)};
-    hipLaunchKernelGGL(bl_lines_kernel, dim3(ceil_div((long)N * 4 * C * g.LP, 256)), dim3(256), 0, ctx->stream, x, (long)x_nstride, g, FL);
+    hipLaunchKernelGGL(bl_lines_kernel, dim3(ceil_div((long)N * 4 * C * g.LP, 256)), dim3(256), 0, ctx->stream, x, (long)x_nstride, g, FL,
+                       FL + ((long)N * 4 * C * g.LP + 64));
     GHM_LAUNCH_CHECK();
     const int used = (2 * (n1 > n2 ? n1 : n2) + 31) / 32;                    // position tiles that hold output pixels
     const int splits = bl_splits(3L * C, (long)(K / 32) * used * 6 * N, ctx->num_cu);
@@ -385,7 +402,7 @@ int ghm_blconv_frame_gather(ghm_ctx* ctx, const float* dy, int64_t dy_nstride, i
     GHM_CHECK(bl_ok(N, C, K, n1, n2), "ghm_blconv_frame_gather: geometry not served");
     const BlGeo g{N, C, K, n1, n2, bl_lp(n1, n2)};
     hipLaunchKernelGGL(bl_gather_dy_kernel, dim3(ceil_div((long)6 * N * K * (g.LP + 32), 256)), dim3(256), 0, ctx->stream, dy,
-                       (long)dy_nstride, g, DYL);
+                       (long)dy_nstride, g, DYL, DYL + (long)6 * N * K * (g.LP + 32));
     GHM_LAUNCH_CHECK();
     return 0;
 }
@@ -398,9 +415,14 @@ int ghm_blconv_frame_dgrad(ghm_ctx* ctx, const float* DYL, const float* wp, floa
     const int used = (2 * (n1 > n2 ? n1 : n2) + 2 + 31) / 32;                // array indices 0 .. 2 n + 1
     const int splits = bl_splits(6L * K, (long)(C / 32) * used * 4 * N, ctx->num_cu);
     void* ws;
-    if (ghm_scratch(ctx, (size_t)splits * N * 4 * C * g.LP * 4, &ws)) return -1;
+    const size_t part_bytes = (size_t)splits * N * 4 * C * g.LP * 4;
+    if (ghm_scratch(ctx, part_bytes + (size_t)9 * K * C * 4, &ws)) return -1;
+    float* const wT = (float*)((char*)ws + part_bytes);      // wT[tap][k][c]: the GEMM's lanes run along c
+    hipLaunchKernelGGL(bl_wt_kernel, dim3(ceil_div((long)9 * K * C, 256)), dim3(256), 0, ctx->stream, wp, C, K, wT);
+    GHM_LAUNCH_CHECK();
     // (the fold reads array indices <= 2 n + 1 only: position tiles beyond ``used`` are neither written nor read)
-    hipLaunchKernelGGL(bl_gemm_dgrad_kernel, dim3(C / 32, used, splits * 4 * N), dim3(256), 0, ctx->stream, wp, DYL, g, splits, (float*)ws);
+    hipLaunchKernelGGL(bl_gemm_dgrad_kernel, dim3(C / 32, used, splits * 4 * N), dim3(256), 0, ctx->stream, (const float*)wT, DYL, g, splits,
+                       (float*)ws);
     GHM_LAUNCH_CHECK();
     const long nb = (long)(n1 >= 2 ? 2 : 1) * n2 + (long)(n2 >= 2 ? 2 : 1) * (n1 > 2 ? n1 - 2 : 0);
     hipLaunchKernelGGL(bl_fold_kernel, dim3(ceil_div((long)N * C * nb, 256)), dim3(256), 0, ctx->stream, (const float*)ws, g, splits, dx,
@@ -419,7 +441,8 @@ int ghm_blconv_frame_wgrad(ghm_ctx* ctx, const float* DYL, const float* FL, floa
     if (splits > items / 4) splits = (int)(items / 4 > 0 ? items / 4 : 1);
     void* ws;
     if (ghm_scratch(ctx, (size_t)splits * 9 * C * K * 4, &ws)) return -1;
-    hipLaunchKernelGGL(bl_gemm_wgrad_kernel, dim3(K / 32, C / 32, splits * 9), dim3(256), 0, ctx->stream, DYL, FL, g, splits, (float*)ws);
+    hipLaunchKernelGGL(bl_gemm_wgrad_kernel, dim3(K / 32, C / 32, splits * 9), dim3(256), 0, ctx->stream,
+                       DYL + (long)6 * N * K * (g.LP + 32), FL + ((long)N * 4 * C * g.LP + 64), g, splits, (float*)ws);
     GHM_LAUNCH_CHECK();
     hipLaunchKernelGGL(bl_wgrad_add_kernel, dim3(ceil_div((long)C * 9 * K, 256)), dim3(256), 0, ctx->stream, (const float*)ws, C, K, splits,
                        dwp);

@@ -215,8 +215,8 @@ def _replace(order, old, new):
 
 def _blconv_wanted(conv_layer, up_layer, dtype):
     """BilinearUpsample2DLayer(2) -> 3x3 'same' stride-1 conv evaluated on the coarse grid (csrc/conv_bilinear.hip)?  Served
-    geometries: channels and filters multiples of 32, coarse maps of at least 16 x 16 (below that the layer is microseconds of
-    work either way and keeps the literal form).  In the split arithmetic modes only (the fp32-MFMA mode stays the literal
+    geometries: channels and filters multiples of 32, coarse maps of at least 32 x 32 (GHM_BLCONV_MIN; on 16-wide coarse maps
+    the narrow-map kernels run the 4K-filter form slower than the literal 32-wide one).  In the split arithmetic modes only (the fp32-MFMA mode stays the literal
     bit-reference of the layer); GHM_NO_BLCONV=1 keeps the literal form everywhere, GHM_BLCONV=all extends it to every mode."""
     if os.environ.get("GHM_NO_BLCONV") is not None:
         return False
@@ -226,7 +226,7 @@ def _blconv_wanted(conv_layer, up_layer, dtype):
     if l.filter_size != (3, 3) or l.stride != (1, 1) or l.pad != (1, 1) or getattr(up_layer, 'factor', 2) != 2:
         return False
     cs = up_layer.input_layer.output_shape
-    nmin = int(os.environ.get("GHM_BLCONV_MIN", 16))
+    nmin = int(os.environ.get("GHM_BLCONV_MIN", 32))
     return (len(cs) == 4 and cs[1] % 32 == 0 and l.num_filters % 32 == 0 and cs[2] >= nmin and cs[3] >= nmin
             and cs[2] % 8 == 0 and cs[3] % 8 == 0)
 

@@ -123,7 +123,7 @@ class RecordingOps:
 
     def blconv_frame_sizes(self, N, Cc, K, n1, n2):
         lp = (2 * max(n1, n2) + 4 + 31) // 32 * 32
-        return N * 4 * Cc * lp + 64, 6 * N * K * (lp + 32)
+        return 2 * (N * 4 * Cc * lp + 64), 2 * 6 * N * K * (lp + 32)
 
     def __getattr__(self, name):
         def rec(*args, **kw):

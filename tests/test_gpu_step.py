@@ -619,7 +619,10 @@ def test_bilinear_decoder_on_the_coarse_grid(dev, monkeypatch, dtype):
     cfg = ostep.default_cfg(in_shp=128, latent_dim=16, train_mode='p2p', gen_dcgan=dict(nch=16, div=[1, 1, 2, 2, 2]),
                             disc_dcgan=dict(nch=16, div=[2, 2, 2]), gen_p2p=dict(nf=32), disc_p2p=dict(nf=8, mul_factor=[1, 2]))
     B, seed = 4, 7
+    monkeypatch.setenv("GHM_BLCONV_MIN", "16")      # (default 32: this 128-pixel net then has one such stage, here two)
     a = build_model(cfg, seed, dev, dtype=dtype)
+    a.engine.built(B)
+    monkeypatch.delenv("GHM_BLCONV_MIN")
     monkeypatch.setenv("GHM_NO_BLCONV", "1")
     lit = build_model(cfg, seed, dev, dtype=dtype)
     lit.engine.built(B)
