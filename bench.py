@@ -170,7 +170,7 @@ def nominal_flops_per_step(b):
             meta = e[2] if len(e) > 2 else None
             if not meta or not meta.get("flops"):
                 continue
-            f = meta["flops"]
+            f = meta.get("nominal_flops", meta["flops"])     # (a collapsed bilinear convolution executes 25 of its 36 taps)
             if e[0].startswith("upconv"):
                 f *= 25.0 / 9.0
             if meta["kernel"].startswith("pool_thin"):

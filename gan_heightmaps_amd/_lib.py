@@ -141,6 +141,9 @@ SIGNATURES = {
     "ghm_blconv_frame_gather": [_p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p],
     "ghm_blconv_frame_dgrad": [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32],
     "ghm_blconv_frame_wgrad": [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32],
+    "ghm_blconv_fwd_split": [_p, _D, _p, _i64, _i64, _p, _p, _p, _i32],
+    "ghm_blconv_dgrad_split": [_p, _D, _p, _i64, _i64, _p, _p, _i32, _i32],
+    "ghm_blconv_wgrad_split": [_p, _D, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i32, _i32],
     "ghm_upconv_expand_wgrad": [_p, _p, _p, _i32, _i32, _i32],
     "ghm_pp_to_hi": [_p, _p, _p, _i64, _i32, _i32, _i32, _i32],
     "ghm_hi_to_pp": [_p, _p, _i64, _p, _i32, _i32, _i32, _i32],
@@ -176,6 +179,7 @@ _SPECIAL = {"ghm_last_error": ([], C.c_char_p), "ghm_bn_workspace": ([_i32], C.c
             "ghm_conv2d_pool_supported": ([_D, _i32, _i32], C.c_int),
             "ghm_dgrad_dact_supported": ([_D, _i32], C.c_int),
             "ghm_blconv_supported": ([_i32, _i32, _i32, _i32, _i32], C.c_int),
+            "ghm_blconv_split_supported": ([_D, _i32], C.c_int),
             "ghm_lp_q_direct": ([_D, _i32, _i32], C.c_int),
             "ghm_conv_bn_fused_supported": ([_D, _i32], C.c_int),
             "ghm_conv_bn_fused_supported_f32": ([_D], C.c_int),

@@ -182,6 +182,7 @@ struct SpConvArgs {
     int ntiles;                 // (filter tile, pixel tile, sample) tiles of the launch; a block walks blockIdx.x, + gridDim.x, ...
     float* pool_out;            // POOL: [N, R, H/2, W/2] maximum of act(conv + bias) over 2x2 windows ...
     unsigned char* pool_mask;   // ... and the arg-max mask of every window (bit 2*dr + dc; all ties set; bit 4: sign)
+    int cls_k;                  // CLS forms: filters (forward) / reduction channels (data gradient) per parity class
 };
 
 // the piece products of one multiply-add, small terms first, the leading product x0 w0 last: all (i, j) with i + j < NPC.
@@ -355,8 +356,23 @@ struct SpGeo2 {
 
 // ABL (tuning only, wrong results): 1 = no DMA inside the loop, 2 = no waits / barriers inside the loop, 4 = no fragment reads
 // inside the loop -- what each costs beside the MFMA stream itself
-template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL, int TW, int NP, int ABL = 0>
+// CLS (3x3 stride 1 only): the collapsed form of BilinearUpsample2DLayer(2) -> 3x3 conv (conv_bilinear.hip) is a 3x3 convolution
+// with 4K filters ordered (parity class p q, k) in which class (p, q) has no taps in filter row 0 when p = 1 and none in filter
+// column 0 when q = 1 (9 / 6 / 6 / 4 of the 9 taps): the structural zeros are SKIPPED, k-step by k-step.
+//   CLS = 1 (forward): the class is a property of the block's filter tile (a.cls_k filters per class, a multiple of BM): its
+//     slabs run filter rows p .. 2 and columns q .. 2;
+//   CLS = 2 (data gradient on the transposed pack, whose taps are flipped): the class is a property of the SLAB (a.cls_k
+//     reduction channels per class): a slab of class (p, q) runs filter rows 0 .. 2 - p and columns 0 .. 2 - q.
+// Same pipeline, same products in the same order as the full kernel minus the k-steps whose weights are all zero: results are
+// bit-identical to CLS = 0 (tests/test_gpu_split.py).
+template <int V>
+struct SpIC {
+    static constexpr int value = V;
+};
+
+template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL, int TW, int NP, int ABL = 0, int CLS = 0>
 __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvArgs a) {
+    static_assert(CLS == 0 || (KS == 3 && ST == 1 && !POOL && ABL == 0), "class forms: 3x3 stride 1");
     typedef SpGeo2<KS, ST, BM, RT, WM, WN, TW, NP> G;
     typedef SpProd<NP> PR;
     constexpr int T = KS * KS;
@@ -397,10 +413,19 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
         int r0, n, y0, x0;
     };
     auto decode = [&](int v) {
-        int L = sp_xcd_remap(v, a.ntiles);
+        // CLS = 1: the classes' tiles cost 9 : 6 : 6 : 4 -- filter tiles slowest, i.e. the launch is dispatched class by class,
+        // heaviest first, so that the CUs that finish a 9-tap tile late pick up the 4-tap ones (and no XCD remap: it would hand
+        // whole classes to single XCDs)
+        int L = CLS == 1 ? v : sp_xcd_remap(v, a.ntiles);
         Tile t;
-        t.r0 = (L % ntr) * BM;
-        L /= ntr;
+        if (CLS == 1) {
+            const int per = a.ntiles / ntr;
+            t.r0 = (L / per) * BM;
+            L %= per;
+        } else {
+            t.r0 = (L % ntr) * BM;
+            L /= ntr;
+        }
         const int tx = L % tiles_x;
         L /= tiles_x;
         const int ty = L % tiles_y;
@@ -411,6 +436,9 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
     };
     int v = blockIdx.x;
     Tile tc = decode(v);
+    // CLS = 1: first filter row / column of this block's class (one tile per block in the class forms)
+    const int cls1 = CLS == 1 ? tc.r0 / a.cls_k : 0;
+    const int fa0 = CLS == 1 ? (cls1 >> 1) : 0, b0 = CLS == 1 ? (cls1 & 1) : 0;
 
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -504,8 +532,9 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
     struct Frag {
         u32x4 a[NP][TM], b[NP][TN];
     };
-    const int wlane = kg * KS * BM + wm * (BM / WM) + li;
-    const int plane = kg * PH * PW + ((wn * TN * RPF + ly) * ST) * PW + (ST == 2 ? lx : lx * ST);
+    // (class forms: the block's first filter row / column folded into the fragment bases; rd() takes indices relative to them)
+    const int wlane = kg * KS * BM + wm * (BM / WM) + li + b0 * BM;
+    const int plane = kg * PH * PW + ((wn * TN * RPF + ly) * ST) * PW + (ST == 2 ? lx : lx * ST) + fa0 * PW + b0;
     // fragments of (filter row fa, column b): weights from the buffer at Wb, patch from the buffer at Pb; in the order of
     // their first use (the products run small terms first -- NP = 3: a2 b0, a1 b1, a0 b2, a1 b0, a0 b1, a0 b0)
     auto rd = [&](Frag& f, const u32x4* Wb, const u32x4* Pb, int fa, int b) {
@@ -536,19 +565,20 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
     // ---- prologue (once per block): filter row 0 and the patch of the first slab, then filter row 1; the first fragments ----
     const int s_last = s_end - 1;
     if (s_begin < s_end) {
-        dma_w(tc.r0, s_begin, 0, 0);
+        dma_w(tc.r0, s_begin, fa0, 0);
         dma_p(0, false);
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (s_begin < s_end) dma_w(tc.r0, s_begin, 1, WUNITS);
+    if (s_begin < s_end) dma_w(tc.r0, s_begin, fa0 + 1, WUNITS);
     int w0 = 0, p0 = 0;          // unit offsets of the weight buffer of the slab's filter row 0 / of the slab's patch buffer
     Frag cur;
     rd(cur, Wl + wlane, Pl + plane, 0, 0);
 
     for (;;) {                   // tiles of this block
         const int vn = v + gridDim.x;
-        // (the eight-wave shape -- 256 registers per wave -- has no room for the tile state: one tile per block)
-        const bool more = NW == 4 && vn < a.ntiles && s_begin < s_end;
+        // (the eight-wave shape -- 256 registers per wave -- has no room for the tile state: one tile per block; so have the
+        // class forms, whose next tile may be of another class)
+        const bool more = NW == 4 && CLS == 0 && vn < a.ntiles && s_begin < s_end;
         const Tile tn = decode(more ? vn : v);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -557,69 +587,91 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = accc[i][j][e] = 0.f;
 
-        for (int s = s_begin; s < s_end; ++s) {
-            // what this slab stages ahead: the next slab of the tile -- or, in the tile's last slab, the first slab of the block's
-            // next tile (at the very end: itself again, harmless)
-            const bool last = s == s_last;
-            const int sn = last ? (more ? s_begin : s) : s + 1;
-            const int rn = (last && more) ? tn.r0 : tc.r0;
-            const u32x4* const Pc = Pl + p0 + plane;
-            const u32x4* const Pn = Pl + (PUNITS - p0) + plane;
+        // slabs [s_lo, s_hi) with NR filter rows x NC filter columns each (the full kernel: KS x KS); rows / columns relative to
+        // (fa0, b0).  Whatever (NR, NC) the NEXT slab has, its first two filter rows are relative rows 0 and 1 (NR >= 2)
+        auto run = [&](auto NR_, auto NC_, int s_lo, int s_hi) {
+            constexpr int NR = decltype(NR_)::value, NC = decltype(NC_)::value;
+            static_assert(NR >= 2 && NC >= 2, "at least two filter rows / columns per slab");
+            for (int s = s_lo; s < s_hi; ++s) {
+                // what this slab stages ahead: the next slab of the tile -- or, in the tile's last slab, the first slab of the
+                // block's next tile (at the very end: itself again, harmless)
+                const bool last = s == s_last;
+                const int sn = last ? (more ? s_begin : s) : s + 1;
+                const int rn = (last && more) ? tn.r0 : tc.r0;
+                const u32x4* const Pc = Pl + p0 + plane;
+                const u32x4* const Pn = Pl + (PUNITS - p0) + plane;
 #pragma unroll
-            for (int fa = 0; fa < KS; ++fa) {
-                const int wc = (fa & 1) ? WUNITS - w0 : w0;         // this filter row's weight buffer
-                const u32x4* const Wc = Wl + wc + wlane;
-                const u32x4* const Wn = Wl + (WUNITS - wc) + wlane;
+                for (int fa = 0; fa < NR; ++fa) {
+                    const int wc = (fa & 1) ? WUNITS - w0 : w0;         // this filter row's weight buffer
+                    const u32x4* const Wc = Wl + wc + wlane;
+                    const u32x4* const Wn = Wl + (WUNITS - wc) + wlane;
 #pragma unroll
-                for (int b = 0; b < KS; ++b) {
-                    Frag nx;
-                    int ndma = 0;
-                    if (ABL & 4) {
-                        nx = cur;
-                    } else if (b + 1 < KS) {
-                        rd(nx, Wc, Pc, fa, b + 1);
-                    } else {                                         // the next iteration's first column
-                        rd(nx, Wn, fa + 1 < KS ? Pc : Pn, fa + 1 < KS ? fa + 1 : 0, 0);
-                    }
-                    if (b + 1 == KS && !(ABL & 1)) {
-                        // the filter row two iterations ahead replaces this one's (all of its fragments were read before the barrier)
-                        if (fa + 2 < KS)
-                            dma_w(tc.r0, s, fa + 2, wc);
-                        else
-                            dma_w(rn, sn, fa + 2 - KS, wc);
-                        ndma = NIW;
-                    }
-                    if (fa == 0 && b == 0 && !(ABL & 1)) {           // the next slab's patch
-                        if (last && more)
-                            patch_of(tn);
-                        dma_p(PUNITS - p0, !last);
-                        ndma = NP * NQ;
-                    }
-                    mm(cur);
-                    // fragment reads, then DMA, one behind each MFMA, front-loaded: the next k-step starts on fragments read long ago
+                    for (int b = 0; b < NC; ++b) {
+                        Frag nx;
+                        int ndma = 0;
+                        if (ABL & 4) {
+                            nx = cur;
+                        } else if (b + 1 < NC) {
+                            rd(nx, Wc, Pc, fa, b + 1);
+                        } else {                                         // the next iteration's first column
+                            rd(nx, Wn, fa + 1 < NR ? Pc : Pn, fa + 1 < NR ? fa + 1 : 0, 0);
+                        }
+                        if (b + 1 == NC && !(ABL & 1)) {
+                            // the filter row two iterations ahead replaces this one's (all of its fragments were read before the barrier)
+                            if (fa + 2 < NR)
+                                dma_w(tc.r0, s, fa0 + fa + 2, wc);
+                            else
+                                dma_w(rn, sn, fa0 + fa + 2 - NR, wc);
+                            ndma = NIW;
+                        }
+                        if (fa == 0 && b == 0 && !(ABL & 1)) {           // the next slab's patch
+                            if (last && more)
+                                patch_of(tn);
+                            dma_p(PUNITS - p0, !last);
+                            ndma = NP * NQ;
+                        }
+                        mm(cur);
+                        // fragment reads, then DMA, one behind each MFMA, front-loaded: the next k-step starts on fragments read long ago
 #pragma unroll
-                    for (int m_ = 0; m_ < NRD; ++m_) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
+                        for (int m_ = 0; m_ < NRD; ++m_) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
 #pragma unroll
-                    for (int m_ = 0; m_ < ndma; ++m_) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                        for (int m_ = 0; m_ < ndma; ++m_) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                        }
+                        if (b == NC - 2 && !(ABL & 2)) {
+                            // everything but the patch requested in this iteration has landed; all reads of this filter row are done
+                            if (fa == 0)
+                                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NP * NQ) : "memory");
+                            else
+                                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        cur = nx;
                     }
-                    if (b == KS - 2 && !(ABL & 2)) {
-                        // everything but the patch requested in this iteration has landed; all reads of this filter row are done
-                        if (fa == 0)
-                            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NP * NQ) : "memory");
-                        else
-                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    cur = nx;
                 }
+                if (NR & 1) w0 = WUNITS - w0;
+                p0 = PUNITS - p0;
             }
-            if (KS & 1) w0 = WUNITS - w0;
-            p0 = PUNITS - p0;
+        };
+        if constexpr (CLS == 0) {
+            run(SpIC<KS>{}, SpIC<KS>{}, s_begin, s_end);
+        } else if constexpr (CLS == 1) {
+            switch (cls1) {
+                case 0: run(SpIC<3>{}, SpIC<3>{}, s_begin, s_end); break;
+                case 1: run(SpIC<3>{}, SpIC<2>{}, s_begin, s_end); break;
+                case 2: run(SpIC<2>{}, SpIC<3>{}, s_begin, s_end); break;
+                default: run(SpIC<2>{}, SpIC<2>{}, s_begin, s_end); break;
+            }
+        } else {
+            const int spc = a.cls_k / 16;                  // slabs per class
+            run(SpIC<3>{}, SpIC<3>{}, max(s_begin, 0), min(s_end, spc));
+            run(SpIC<3>{}, SpIC<2>{}, max(s_begin, spc), min(s_end, 2 * spc));
+            run(SpIC<2>{}, SpIC<3>{}, max(s_begin, 2 * spc), min(s_end, 3 * spc));
+            run(SpIC<2>{}, SpIC<2>{}, max(s_begin, 3 * spc), min(s_end, 4 * spc));
         }
 
         sp_conv_epilogue<BM, RT, WM, WN, POOL, TW, TM, TN, NP>(a, acc, accc, Bl, tid, wm, wn, kg, li, lx, ly, tc.n, tc.r0, tc.y0, tc.x0, HW);
@@ -651,6 +703,7 @@ struct SpWgradArgs {
     int rows_per_split, splits_per_col;
     long split_stride;
     int accumulate;
+    int cls_k;             // CLS form: filters per parity class (the collapsed bilinear convolution, sp_conv2_kernel)
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -681,9 +734,14 @@ __device__ __forceinline__ void sp_tr_wait(SpTrFrag (&f)[N]) {
                      "+v"(f[3].lo), "+v"(f[3].hi), "+v"(f[4].lo), "+v"(f[4].hi));
 }
 
-template <int KS, int ST, int CHT, int CT, int SPX, int NP>
+// CLS = 1 (3x3 stride 1): the filters are 4 parity classes of a.cls_k (class (p, q) of the collapsed bilinear convolution has no
+// taps in filter row 0 when p = 1, none in filter column 0 when q = 1): a block's filter tile lies in ONE class; the waves of a
+// structurally-zero filter row only help staging, and every wave skips the zero column -- fragment reads and MFMAs.  The
+// skipped taps leave their zero accumulators in dwp (the expansion multiplies them by zero coefficients anyway).
+template <int KS, int ST, int CHT, int CT, int SPX, int NP, int CLS = 0>
 __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const SpWgradArgs a) {
     static_assert((ST == 1 || (ST == 2 && KS == 3)) && (SPX == 64 || SPX == 32 || SPX == 16) && (KS == 3 || KS == 5), "variants");
+    static_assert(CLS == 0 || (KS == 3 && ST == 1), "class form: 3x3 stride 1");
     constexpr int T = KS * KS, PADK = KS / 2;
     constexpr int NWAVES = CHT * CT * KS;
     constexpr int NPAR = ST;                          // column-parity planes of an x row
@@ -777,53 +835,75 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
         const unsigned lds0 = (unsigned)(size_t)(lptr_t)sp_wsmem;
         const unsigned xl0 = lds0 + hh * NPAR * PLB + lane_off;
         const unsigned yl0 = lds0 + NR * NP * ROWB + ww * YTB + lane_off;
-        for (int i = i_begin; i < i_end; ++i) {
-            const int buf = (i - i_begin) & 1;
-            if (i + 1 < i_end) {
+        // T0: first active filter column of this block's class; ACT: does this wave's filter row have any taps?
+        auto rows = [&](auto T0_, auto ACT_) {
+            constexpr int T0 = decltype(T0_)::value;
+            constexpr bool ACT = decltype(ACT_)::value != 0;
+            for (int i = i_begin; i < i_end; ++i) {
+                const int buf = (i - i_begin) & 1;
+                if (i + 1 < i_end) {
 #pragma unroll
-                for (int r = 0; r < ST; ++r) stage_xrow(i * ST - PADK + KS + r);        // the rows the next output row adds
-                stage_dy(i + 1, buf ^ 1);
-            }
-            const unsigned xr = xl0 + (((i * ST + wr - PADK + NR) % NR) * NP) * ROWB;
-            const unsigned yb = yl0 + buf * NP * YB;
-            SpTrFrag af[2][KS], bf[2][NP];
-            auto read_x = [&](int ks, int p, int slot) {
-#pragma unroll
-                for (int fb = 0; fb < KS; ++fb) {
-                    const int par = ST == 2 ? (fb & 1) : 0;
-                    const int shift = ST == 2 ? (fb >> 1) : fb;
-                    sp_tr_issue(af[slot][fb], xr + p * ROWB + par * PLB + (ks * 16 + shift) * 64);
+                    for (int r = 0; r < ST; ++r) stage_xrow(i * ST - PADK + KS + r);        // the rows the next output row adds
+                    stage_dy(i + 1, buf ^ 1);
                 }
-            };
-            auto read_dy = [&](int ks, int slot) {
+                if constexpr (ACT) {
+                    const unsigned xr = xl0 + (((i * ST + wr - PADK + NR) % NR) * NP) * ROWB;
+                    const unsigned yb = yl0 + buf * NP * YB;
+                    SpTrFrag af[2][KS], bf[2][NP];
+                    auto read_x = [&](int ks, int p, int slot) {
 #pragma unroll
-                for (int q = 0; q < NP; ++q) sp_tr_issue(bf[slot][q], yb + q * YB + ks * 1024);
-            };
-            read_dy(0, 0);
-            read_x(0, NP - 1, 0);
+                        for (int fb = T0; fb < KS; ++fb) {
+                            const int par = ST == 2 ? (fb & 1) : 0;
+                            const int shift = ST == 2 ? (fb >> 1) : fb;
+                            sp_tr_issue(af[slot][fb], xr + p * ROWB + par * PLB + (ks * 16 + shift) * 64);
+                        }
+                    };
+                    auto read_dy = [&](int ks, int slot) {
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
+                        for (int q = 0; q < NP; ++q) sp_tr_issue(bf[slot][q], yb + q * YB + ks * 1024);
+                    };
+                    read_dy(0, 0);
+                    read_x(0, NP - 1, 0);
 #pragma unroll
-                for (int pi = 0; pi < NP; ++pi) {
-                    const int p = NP - 1 - pi, ph = ks * NP + pi;
-                    // this phase's fragments have arrived (requested one phase ago) ...
-                    sp_tr_wait(af[ph & 1]);
-                    if (pi == 0) sp_tr_wait(bf[ks & 1]);
-                    // ... the next phase's are requested behind them
-                    if (pi + 1 < NP) {
-                        read_x(ks, p - 1, (ph + 1) & 1);
-                    } else if (ks + 1 < KSTEPS) {
-                        read_dy(ks + 1, (ks + 1) & 1);
-                        read_x(ks + 1, NP - 1, (ph + 1) & 1);
+                    for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+                        for (int pi = 0; pi < NP; ++pi) {
+                            const int p = NP - 1 - pi, ph = ks * NP + pi;
+                            // this phase's fragments have arrived (requested one phase ago) ...
+                            if constexpr (T0 == 0)
+                                sp_tr_wait(af[ph & 1]);
+                            else
+                                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[ph & 1][1].lo), "+v"(af[ph & 1][1].hi), "+v"(af[ph & 1][2].lo),
+                                             "+v"(af[ph & 1][2].hi));
+                            if (pi == 0) sp_tr_wait(bf[ks & 1]);
+                            // ... the next phase's are requested behind them
+                            if (pi + 1 < NP) {
+                                read_x(ks, p - 1, (ph + 1) & 1);
+                            } else if (ks + 1 < KSTEPS) {
+                                read_dy(ks + 1, (ks + 1) & 1);
+                                read_x(ks + 1, NP - 1, (ph + 1) & 1);
+                            }
+#pragma unroll
+                            for (int q = 0; q <= NP - 1 - p; ++q)
+#pragma unroll
+                                for (int t = T0; t < KS; ++t) acc[t] = sp_mfma(sp_tr_bits(af[ph & 1][t]), sp_tr_bits(bf[ks & 1][q]), acc[t]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
-#pragma unroll
-                    for (int q = 0; q <= NP - 1 - p; ++q)
-#pragma unroll
-                        for (int t = 0; t < KS; ++t) acc[t] = sp_mfma(sp_tr_bits(af[ph & 1][t]), sp_tr_bits(bf[ks & 1][q]), acc[t]);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             }
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        if constexpr (CLS == 0) {
+            rows(SpIC<0>{}, SpIC<1>{});
+        } else {
+            const int cls = k0 / a.cls_k;                  // (p, q) of this block's filter tile
+            if (wr < (cls >> 1))
+                rows(SpIC<0>{}, SpIC<0>{});
+            else if (cls & 1)
+                rows(SpIC<1>{}, SpIC<1>{});
+            else
+                rows(SpIC<0>{}, SpIC<1>{});
         }
     }
 
@@ -1167,7 +1247,7 @@ size_t sp_lds_bytes(int ks, int st, int bm, int rt, int tw, int np) {
 }
 
 // forward form: CH reduction channels, R output channels, (H, W) output grid
-SpPlan sp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu, int np = 3) {
+SpPlan sp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu, int np = 3, bool bm64 = false) {
     SpPlan p;
     memset(&p, 0, sizeof(p));
     p.np = np;
@@ -1185,7 +1265,7 @@ SpPlan sp_plan(int N, int CH, int H, int W, int R, int ks, int st, int num_cu, i
         // 3x3 stride 1, 128 filters: eight waves of 2 x 2 tiles (four waves of 4 x 2 tiles -- a quarter fewer fragment reads per
         // MFMA -- measured 0-19 % slower alone: 212 against 231 TFLOP/s on the N4 C128 128^2 K256 data gradient)
         if (ks == 3 && st == 1) {
-            p.bm = (R >= 96 && !GHM_OPT("GHM_SPLIT_BM64")) ? 128 : 64;
+            p.bm = (R >= 96 && !bm64 && !GHM_OPT("GHM_SPLIT_BM64")) ? 128 : 64;
             if (p.bm == 128 && H % 8 == 0 && !GHM_OPT("GHM_SPLIT_BM128")) {
                 // a launch of 128 .. 255 tiles of 128 filters leaves half the CUs idle (the N4 C1024 64^2 K256 forward: 180
                 // TFLOP/s alone, 250 in 256 tiles of 64 filters; the N4 K512 -> C1024 32^2 data gradient 175 -> 239): whole
@@ -1262,8 +1342,24 @@ int sp_set_lds(K kernel, size_t lds) {
 
 // one tile shape of the forward-form kernel, for 3 or 2 pieces per operand
 template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL, int TW>
-int sp_launch_variant(ghm_ctx* ctx, dim3 g, size_t lds, const SpConvArgs& a, int np) {
+int sp_launch_variant(ghm_ctx* ctx, dim3 g, size_t lds, const SpConvArgs& a, int np, int cls = 0) {
     static_assert(SpGeo2<KS, ST, BM, RT, WM, WN, TW, 3>::LDS_BYTES <= 160 * 1024, "LDS");
+    if (cls) {          // the class forms of the collapsed bilinear convolution (structural zero taps skipped)
+        if constexpr (KS == 3 && ST == 1 && !POOL && TW == 32 && BM == 64) {      // (the eight-wave 128-filter shape has no registers to spare)
+#define GHM_CLS_CASE(NP_, C_)                                                                                                     \
+            if (np == NP_ && cls == C_) {                                                                                         \
+                if (int e = sp_set_lds(sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, NP_, 0, C_>, lds)) return e;             \
+                hipLaunchKernelGGL((sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, NP_, 0, C_>), g, dim3(WM * WN * 64), lds,   \
+                                   ctx->stream, a);                                                                               \
+                GHM_LAUNCH_CHECK();                                                                                               \
+                return 0;                                                                                                         \
+            }
+            GHM_CLS_CASE(3, 1) GHM_CLS_CASE(3, 2) GHM_CLS_CASE(2, 1) GHM_CLS_CASE(2, 2)
+#undef GHM_CLS_CASE
+        }
+        ghm_set_error("split-fp32 convolution: no class form for this tile shape");
+        return -3;
+    }
 #ifdef GHM_SPLIT_ABLATION
     if constexpr ((KS == 5 || (KS == 3 && ST == 1)) && BM == 64 && RT == 8 && !POOL && TW == 32) {
         const char* f = GHM_OPT("GHM_SPLIT_ABLATE");
@@ -1291,7 +1387,8 @@ int sp_launch_variant(ghm_ctx* ctx, dim3 g, size_t lds, const SpConvArgs& a, int
 }
 
 // in32 != null: the fp32 operand is split into the launch's workspace first
-int sp_launch_conv(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, int ks, int st, const float* in32, long in32_nstride, bool pool) {
+int sp_launch_conv(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, int ks, int st, const float* in32, long in32_nstride, bool pool,
+                   int cls = 0) {
     a.slabs_per_split = pl.slabs_per_split;
     a.zeros = (const u32x4*)ctx->zeros;
     a.partial = nullptr;
@@ -1315,11 +1412,11 @@ int sp_launch_conv(ghm_ctx* ctx, const SpPlan& pl, SpConvArgs a, int ks, int st,
     GHM_CHECK(pool || a.out || a.out_q, "split-fp32 convolution: no output");
     GHM_CHECK(!(a.accumulate && !a.out), "accumulate needs the fp32 output");
     GHM_CHECK(!a.out_q || (a.R % 8 == 0 && ((uintptr_t)a.out_q & 15) == 0), "q output: a multiple of 8 channels, 16-byte aligned");
-    const dim3 g(pl.blocks, pl.splits);
+    const dim3 g(cls ? pl.grid : pl.blocks, pl.splits);       // (the class forms run one tile per block)
     a.ntiles = pl.grid;
 #define GHM_SP_CASE(KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_)                                                    \
     if (ks == KS_ && st == ST_ && pl.bm == BM_ && pl.rt == RT_ && pl.wm == WM_ && pool == POOL_ && pl.tw == TW_) {  \
-        if (int e = sp_launch_variant<KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_>(ctx, g, pl.lds, a, pl.np)) return e;  \
+        if (int e = sp_launch_variant<KS_, ST_, BM_, RT_, WM_, WN_, POOL_, TW_>(ctx, g, pl.lds, a, pl.np, cls)) return e;  \
     } else
     GHM_SP_CASE(5, 1, 64, 8, 1, 4, false, 32)
     GHM_SP_CASE(5, 1, 64, 8, 1, 4, true, 32)
@@ -1396,9 +1493,10 @@ SpWPlan sp_wplan(const ghm_conv_desc* d, int num_cu, int np = 3) {
 }
 
 int sp_launch_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const SpWPlan& v, const void* xq, long xq_ns, long xq_ps,
-                    const void* dyq, long dyq_ns, long dyq_ps, float* dwp, void* workspace, int accumulate) {
+                    const void* dyq, long dyq_ns, long dyq_ps, float* dwp, void* workspace, int accumulate, int cls_k = 0) {
     SpWgradArgs a;
     memset(&a, 0, sizeof(a));
+    a.cls_k = cls_k;
     a.xq = (const u32x4*)xq; a.xq_ns = xq_ns; a.xq_ps = xq_ps; a.dyq = (const u32x4*)dyq; a.dyq_ns = dyq_ns; a.dyq_ps = dyq_ps;
     a.zeros = (const u32x4*)ctx->zeros;
     a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.K = d->K; a.Ho = d->Ho; a.Wo = d->Wo;
@@ -1412,6 +1510,20 @@ int sp_launch_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const SpWPlan& v, cons
         a.out = dwp; a.split_stride = 0; a.accumulate = accumulate;
     }
     const dim3 grid(d->C / (32 * v.cht), d->K / (32 * v.ct), splits);
+    if (cls_k) {        // the class form of the collapsed bilinear convolution: 3x3 stride 1, 32-pixel strips
+        GHM_CHECK(d->kh == 3 && d->stride == 1 && v.cht == 2 && v.ct == 2 && v.spx == 32 && cls_k % 64 == 0 && d->K == 4 * cls_k,
+                  "split-fp32 weight gradient: no class form for this geometry");
+        if (v.np == 3) {
+            if (int e = sp_set_lds(sp_wgrad_kernel<3, 1, 2, 2, 32, 3, 1>, v.lds)) return e;
+            hipLaunchKernelGGL((sp_wgrad_kernel<3, 1, 2, 2, 32, 3, 1>), grid, dim3(2 * 2 * 3 * 64), v.lds, ctx->stream, a);
+        } else {
+            if (int e = sp_set_lds(sp_wgrad_kernel<3, 1, 2, 2, 32, 2, 1>, v.lds)) return e;
+            hipLaunchKernelGGL((sp_wgrad_kernel<3, 1, 2, 2, 32, 2, 1>), grid, dim3(2 * 2 * 3 * 64), v.lds, ctx->stream, a);
+        }
+        GHM_LAUNCH_CHECK();
+        if (splits > 1) return ghm_reduce_splits(ctx, (const float*)workspace, splits, n, n, dwp, accumulate);
+        return 0;
+    }
 #define GHM_SPW_CASE(KS_, ST_, CHT_, CT_, SPX_)                                                                     \
     if (d->kh == KS_ && d->stride == ST_ && v.cht == CHT_ && v.ct == CT_ && v.spx == SPX_) {                       \
         if (v.np == 3) {                                                                                            \
@@ -1707,6 +1819,75 @@ int ghm_conv2d_dgrad_split(ghm_ctx* ctx, const ghm_conv_desc* d, const float* dy
     a.out_nstride = d->x_nstride; a.pad = d->kh - 1 - d->pad;
     a.act = act; a.alpha = alpha; a.accumulate = accumulate;
     return sp_launch_conv(ctx, pl, a, d->kh, 1, dyq ? nullptr : dy, d->y_nstride, false);
+}
+
+// ---- the collapsed form of BilinearUpsample2DLayer(2) -> 3x3 conv (conv_bilinear.hip; d: the 3x3 'same' stride-1 descriptor on
+// the coarse grid with d->K = 4 x the layer's filters, ordered (parity class, k)) with the structurally zero taps of the classes
+// skipped: the same products in the same order as ghm_conv2d_{fwd, dgrad, wgrad}_split on the zero-padded collapsed weights.
+// kind 0 forward, 1 data gradient, 2 weight gradient
+int ghm_blconv_split_supported(const ghm_conv_desc* d, int32_t kind) {
+    if (!d || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->K % 4 || GHM_OPT("GHM_BLCONV_NO_SKIP")) return 0;
+    const int ck = d->K / 4;
+    if (ck % 64) return 0;
+    if (kind == 0) {
+        const SpPlan pl = sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, 3, 1, ghm_plan_cus(), 3, true);
+        return sp_fwd_geom(d) && pl.ok && pl.tw == 32 && pl.bm == 64;
+    }
+    if (kind == 1) {
+        const SpPlan pl = sp_plan(d->N, d->K, d->H, d->W, d->C, 3, 1, ghm_plan_cus(), 3, true);
+        return sp_fwd_geom(d) && pl.ok && pl.tw == 32 && pl.bm == 64;
+    }
+    if (kind == 2) {
+        const SpWPlan v = sp_wplan(d, ghm_plan_cus());
+        return v.ok && v.cht == 2 && v.ct == 2 && v.spx == 32;
+    }
+    return 0;
+}
+
+int ghm_blconv_fwd_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void* xq, int64_t xq_nstride, int64_t xq_pstride, const void* wq,
+                         const float* bias, float* y, int32_t pieces) {
+    GHM_CHECK(ctx && d && xq && wq && y, "null argument");
+    GHM_SP_PIECES_OK(pieces);
+    GHM_CHECK(ghm_blconv_split_supported(d, 0), "ghm_blconv_fwd_split: geometry not served (ask ghm_blconv_split_supported)");
+    const int ck = d->K / 4;
+    const SpPlan pl = sp_plan(d->N, d->C, d->Ho, d->Wo, d->K, 3, 1, ctx->num_cu, pieces, true);
+    SpConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in_q = (const u32x4*)xq; a.in_q_nstride = xq_nstride; a.in_q_pstride = xq_pstride;
+    a.wq = (const u32x4*)wq; a.bias = bias; a.out = y;
+    a.N = d->N; a.CH = d->C; a.H = d->Ho; a.W = d->Wo; a.Hin = d->H; a.Win = d->W;
+    a.R = d->K; a.Rpad = sp_rpad(d->K); a.wq_pstride = (long)sp_nblk(d->C) * 9 * a.Rpad;
+    a.out_nstride = d->y_nstride; a.pad = 1;
+    a.act = GHM_ACT_LINEAR; a.cls_k = ck;
+    return sp_launch_conv(ctx, pl, a, 3, 1, nullptr, 0, false, 1);
+}
+
+int ghm_blconv_dgrad_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void* dyq, int64_t dyq_nstride, int64_t dyq_pstride,
+                           const void* wqT, float* dx, int32_t accumulate, int32_t pieces) {
+    GHM_CHECK(ctx && d && dyq && wqT && dx, "null argument");
+    GHM_SP_PIECES_OK(pieces);
+    GHM_CHECK(ghm_blconv_split_supported(d, 1), "ghm_blconv_dgrad_split: geometry not served (ask ghm_blconv_split_supported)");
+    const SpPlan pl = sp_plan(d->N, d->K, d->H, d->W, d->C, 3, 1, ctx->num_cu, pieces, true);
+    SpConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in_q = (const u32x4*)dyq; a.in_q_nstride = dyq_nstride; a.in_q_pstride = dyq_pstride;
+    a.wq = (const u32x4*)wqT; a.out = dx;
+    a.N = d->N; a.CH = d->K; a.H = d->H; a.W = d->W; a.Hin = d->H; a.Win = d->W;
+    a.R = d->C; a.Rpad = sp_rpad(d->C); a.wq_pstride = (long)sp_nblk(d->K) * 9 * a.Rpad;
+    a.out_nstride = d->x_nstride; a.pad = 1;
+    a.act = GHM_ACT_LINEAR; a.accumulate = accumulate; a.cls_k = d->K / 4;
+    return sp_launch_conv(ctx, pl, a, 3, 1, nullptr, 0, false, 2);
+}
+
+int ghm_blconv_wgrad_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void* xq, int64_t xq_nstride, int64_t xq_pstride,
+                           const void* dyq, int64_t dyq_nstride, int64_t dyq_pstride, float* dwp, void* workspace,
+                           int32_t accumulate, int32_t pieces) {
+    GHM_CHECK(ctx && d && xq && dyq && dwp, "null argument");
+    GHM_SP_PIECES_OK(pieces);
+    GHM_CHECK(ghm_blconv_split_supported(d, 2), "ghm_blconv_wgrad_split: geometry not served (ask ghm_blconv_split_supported)");
+    const SpWPlan v = sp_wplan(d, ghm_plan_cus(), pieces);
+    return sp_launch_wgrad(ctx, d, v, xq, (long)xq_nstride, (long)xq_pstride, dyq, (long)dyq_nstride, (long)dyq_pstride, dwp,
+                           workspace, accumulate, d->K / 4);
 }
 
 // dx = conv^T(dy, W) * act'(y) of a 3x3 stride-2 convolution: the producer's relu / leaky-relu backward in the epilogue (the

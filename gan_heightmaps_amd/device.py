@@ -463,6 +463,22 @@ class Ops:
     def blconv_frame_wgrad(self, DYL, FL, dwp, N, Cc, K, n1, n2):
         call("ghm_blconv_frame_wgrad", self.h, _vp(DYL), _vp(FL), _vp(dwp), int(N), int(Cc), int(K), int(n1), int(n2))
 
+    def blconv_split_supported(self, d, kind, dtype):
+        """may the collapsed bilinear convolution ``d`` (4K filters) run with its structural zero taps skipped?"""
+        return dtype in SPLITS and bool(_lib.load().ghm_blconv_split_supported(C.byref(d), int(kind)))
+
+    def blconv_fwd_split(self, d, xq, wq, bias, y, dtype):
+        call("ghm_blconv_fwd_split", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, xq.pstride, _vp(wq), _vp(bias), _vp(y),
+             SPLITS[dtype])
+
+    def blconv_dgrad_split(self, d, dyq, wqT, dx, dtype, accumulate=False):
+        call("ghm_blconv_dgrad_split", self.h, C.byref(d), C.c_void_p(dyq.ptr), dyq.nstride, dyq.pstride, _vp(wqT), _vp(dx),
+             int(accumulate), SPLITS[dtype])
+
+    def blconv_wgrad_split(self, d, xq, dyq, dwp, ws, dtype, accumulate=False):
+        call("ghm_blconv_wgrad_split", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, xq.pstride, C.c_void_p(dyq.ptr),
+             dyq.nstride, dyq.pstride, _vp(dwp), _vp(ws), int(accumulate), SPLITS[dtype])
+
     def transpose_table(self, items):
         """items: [(wp DevTensor, wpT DevTensor, C, T, K)] -> (device table ptr, n, total blocks) for
         transpose_weights_batched (uploaded once: the pointers are fixed for the life of a plan)"""

@@ -626,6 +626,11 @@ class NetPlan:
         K = n.shape[1]
         return conv_desc(x_t.N, x_t.Cc, x_t.H, x_t.W, 4 * K, 3, 3, 1, 1, x_t.nstride, 4 * K * x_t.H * x_t.W)
 
+    def _bl_skip(self, n, d, kind):
+        """does the collapsed bilinear convolution of node n run with its structurally zero taps skipped (split modes)?"""
+        return (n.attrs.get('mode') == 1 and self.dtype in SPLITS and hasattr(self.ops, 'blconv_split_supported')
+                and bool(self.ops.blconv_split_supported(d, kind, self.dtype)))
+
     def _use_dgrad_t(self, d, W):
         """data gradient through the transposed weight copy (forward-form kernels)?  Not for <= 4 filters unless the
         thin fan-out kernel serves them: their reduction is element-wise work (smallk_dgrad_kernel)"""
@@ -876,7 +881,11 @@ class NetPlan:
                 y4 = y.reshape((x.N, 4 * K, x.H, x.W))
                 if self._lp(d, 0):
                     wq = self._lp_pack_entry(prog, d, wpc, ('c', id(n.layer.W)), False, None)    # after collapse_w
-                    if xq is not None:
+                    if xq is not None and self._bl_skip(n, d, 0) and a == linear:
+                        # the bilinear form's structurally zero taps skipped (25 of 36 k-steps): bit-identical to the full kernel
+                        prog.append((ulab + "_fwd", lambda d=d, xq=xq, wq=wq, b4=b4, y4=y4:
+                                     ops.blconv_fwd_split(d, xq, wq, b4, y4, self.dtype), bl_meta(conv_meta(ops, d, 0, self.dtype))))
+                    elif xq is not None:
                         prog.append((ulab + "_fwd", lambda d=d, xq=xq, wq=wq, b4=b4, y4=y4, a=a:
                                      ops.conv2d_fwd_lp_q(d, xq, wq, b4, y4, None, self.dtype, a.kind, a.alpha),
                                      conv_meta(ops, d, 0, self.dtype)))
@@ -1282,7 +1291,11 @@ class NetPlan:
                     if self.side is not None:
                         wdev, wo = self.side
                         prog.append(("fork", lambda wdev=wdev: wdev.wait_for(dev), None, wdev))
-                    if G4q_w is not None:
+                    if G4q_w is not None and self._bl_skip(n, d, 2):
+                        prog.append((ulab + "_wgrad", lambda d=d, xq=xq, G4q=G4q_w, dwpc=dwpc, wo=wo:
+                                     wo.blconv_wgrad_split(d, xq, G4q, dwpc, self.wgrad_ws, self.dtype, False),
+                                     bl_meta(conv_meta(ops, d, 2, self.dtype)), wdev))
+                    elif G4q_w is not None:
                         prog.append((ulab + "_wgrad", lambda d=d, xq=xq, G4q=G4q_w, dwpc=dwpc, wo=wo:
                                      wo.conv2d_wgrad_lp_q(d, xq, G4q, dwpc, self.wgrad_ws, self.dtype, False),
                                      conv_meta(ops, d, 2, self.dtype), wdev))
@@ -1306,7 +1319,11 @@ class NetPlan:
                     if self._lp(d, 1):
                         wqT = self._lp_pack_entry(prog, d, wpc, ('c', id(l.W)), True, transposed)
                         G4q = gradq_of(n, G4)
-                        if G4q is not None:
+                        if G4q is not None and self._bl_skip(n, d, 1):
+                            prog.append((ulab + "_dgrad", lambda d=d, G4q=G4q, wqT=wqT, gi=gi, acc=acc:
+                                         ops.blconv_dgrad_split(d, G4q, wqT, gi, self.dtype, acc),
+                                         bl_meta(conv_meta(ops, d, 3, self.dtype))))
+                        elif G4q is not None:
                             prog.append((ulab + "_dgrad", lambda d=d, G4q=G4q, wqT=wqT, gi=gi, acc=acc:
                                          ops.conv2d_dgrad_lp_q(d, G4q, wqT, gi, None, self.dtype, None, 'linear', 0.0, acc),
                                          conv_meta(ops, d, 3, self.dtype)))
@@ -1507,6 +1524,16 @@ def conv_meta(ops, d, kind, dtype='f32', pooled=False, extra='', moved=None):
             "thin": min(d.C, d.K) <= 4,
             "flops": 2.0 * d.N * d.K * d.Ho * d.Wo * d.C * d.kh * d.kw,
             "geom": "N%d C%d %dx%d K%d k%d s%d%s" % (d.N, d.C, d.H, d.W, d.K, d.kh, d.stride, extra)}
+
+
+def bl_meta(meta):
+    """a collapsed bilinear convolution whose structurally zero taps are skipped: 25 of the 36 collapsed products execute (bench.py
+    prices the launch at the reference's 36 = the fine 3x3 convolution's count; ``flops`` is what the matrix cores do)"""
+    m = dict(meta)
+    m["flops"] = meta["flops"] * 25.0 / 36.0
+    m["nominal_flops"] = meta["flops"]
+    m["kernel"] = meta["kernel"] + " cls"
+    return m
 
 
 def pack_meta(t):

@@ -518,3 +518,64 @@ def test_persistent_tiles_are_bit_identical_to_one_tile_per_block(gpu, case, pie
         assert np.array_equal(a_, b_)
     dev.free(wq)
     dev.free(wqT)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 32, 32), (1, 128, 128, 32, 64), (4, 256, 64, 128, 128), (2, 64, 64, 8, 32)])
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16x2"])
+def test_collapsed_bilinear_convolution_skips_its_structural_zeros(gpu, case, dtype):
+    """The coarse-grid form of BilinearUpsample2DLayer(2) -> 3x3 conv (p2p.py:204-267; csrc/conv_bilinear.hip) is a 3x3
+    convolution with 4K filters in which 11 of the 36 collapsed taps are zero by construction.  ghm_blconv_{fwd,dgrad,wgrad}_split
+    run the same kernels without the k-steps of those taps: the results must equal ghm_conv2d_*_split on the same zero-padded
+    collapsed weights BIT FOR BIT (same products, same order), forward, data gradient (also accumulating, into a channel slice)
+    and weight gradient, in both split arithmetic modes."""
+    dev, ops, D = gpu
+    N, C, K, n1, n2 = case
+    rng = np.random.RandomState(sum(case))
+    x = (rng.randn(N, C, n1, n2) * np.exp(rng.randn(N, C, 1, 1))).astype(np.float32)
+    Wt = (rng.randn(K, C, 3, 3) / np.sqrt(C * 9)).astype(np.float32)
+    b = rng.randn(K).astype(np.float32)
+    g = (rng.randn(N, 4 * K, n1, n2) * np.exp(rng.randn(N, 4 * K, 1, 1))).astype(np.float32)
+    d = D.conv_desc(N, C, n1, n2, 4 * K, 3, 3, 1, 1)
+    for kind in (0, 1, 2):
+        assert ops.blconv_split_supported(d, kind, dtype), kind
+    wp3, bd = dev.tensor(D.pack_conv_w(Wt).ravel()), dev.tensor(b)
+    wpc, b4 = dev.empty((1, C * 9 * 4 * K, 1, 1)), dev.empty((1, 4 * K, 1, 1))
+    ops.upconv_collapse_batched(ops.collapse_table([(wp3, bd, wpc, b4, C, K, 1)]))
+    w = wpc.numpy().reshape(C, 9, 4, K)
+    zero = [(rs, pq) for rs in range(9) for pq in range(4) if not w[:, rs, pq].any()]
+    assert len(zero) == 11                                      # 36 - (9 + 6 + 6 + 4)
+    pieces = D.SPLITS[dtype]
+    wq, wqT = dev.alloc(ops.split_weight_bytes(d, False, pieces)), dev.alloc(ops.split_weight_bytes(d, True, pieces))
+    ops.split_pack_weights(d, wpc, wq, False, pieces)
+    ops.split_pack_weights(d, wpc, wqT, True, pieces)
+    xq, gq = D.QTensor.empty(dev, x.shape, dtype), D.QTensor.empty(dev, g.shape, dtype)
+    ops.q_pack(dev.tensor(x), xq)
+    ops.q_pack(dev.tensor(g), gq)
+    # forward
+    y0, y1 = dev.empty(g.shape), dev.empty(g.shape)
+    ops.conv2d_fwd_lp_q(d, xq, wq, b4, y0, None, dtype)
+    ops.blconv_fwd_split(d, xq, wq, b4, y1, dtype)
+    assert np.array_equal(y0.numpy(), y1.numpy())
+    # data gradient, plain and accumulating into a channel slice of a wider tensor
+    dx0, dx1 = dev.empty(x.shape), dev.empty(x.shape)
+    ops.conv2d_dgrad_lp_q(d, gq, wqT, dx0, None, dtype)
+    ops.blconv_dgrad_split(d, gq, wqT, dx1, dtype)
+    assert np.array_equal(dx0.numpy(), dx1.numpy())
+    wide0, wide1 = dev.tensor(rng.randn(N, C + 16, n1, n2).astype(np.float32)), None
+    wide1 = dev.tensor(wide0.numpy())
+    dv = D.conv_desc(N, C, n1, n2, 4 * K, 3, 3, 1, 1, wide0.nstride, gq.shape[1] * n1 * n2)
+    ops.conv2d_dgrad_lp_q(dv, gq, wqT, wide0.channels(16, 16 + C), None, dtype, accumulate=True)
+    ops.blconv_dgrad_split(dv, gq, wqT, wide1.channels(16, 16 + C), dtype, accumulate=True)
+    assert np.array_equal(wide0.numpy(), wide1.numpy())
+    # weight gradient
+    ws = dev.alloc(max(ops.wgrad_lp_workspace(d), 16))
+    dw0, dw1 = dev.zeros((1, C * 9 * 4 * K, 1, 1)), dev.zeros((1, C * 9 * 4 * K, 1, 1))
+    ops.conv2d_wgrad_lp_q(d, xq, gq, dw0, ws, dtype)
+    ops.blconv_wgrad_split(d, xq, gq, dw1, ws, dtype)
+    a0, a1 = dw0.numpy().reshape(C, 9, 4, K), dw1.numpy().reshape(C, 9, 4, K)
+    for rs in range(9):
+        for pq in range(4):
+            if (rs, pq) in zero:
+                assert not a1[:, rs, pq].any()                  # skipped taps leave zeros (the expansion ignores them)
+            else:
+                assert np.array_equal(a0[:, rs, pq], a1[:, rs, pq]), (rs, pq)
