@@ -204,19 +204,17 @@ __global__ __launch_bounds__(256) void bl_gemm_wgrad_kernel(const float* __restr
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    // work items: (part, n, position pair); this block takes items sp, sp + splits, ...; its waves alternate
-    const int P2 = g.LP / 2;                               // position pairs per line (the padding holds zeros)
-    const long items = (long)2 * g.N * P2;
-#pragma unroll 4
-    for (long it = (long)sp * 4 + wave; it < items; it += (long)splits * 4) {
-        const int pp = (int)(it % P2);
-        const long r = it / P2;
-        const int n = (int)(r % g.N), part = (int)(r / g.N);
-        const int pos = 2 * pp + kg;
+    // contraction: (part, n, position pair); the block's waves take the pairs sp * 4 + wave, + splits * 4, ... of every (part, n)
+    for (int part = 0; part < 2; ++part) {
         const int job = part ? coljob : rowjob, line = part ? colline : rowline, sh = part ? A : B;
-        const float a = DYLt[(((long)job * g.N + n) * LD + pos + 2) * g.K + k];
-        const float b = (pos + sh < g.LP) ? FLt[(((long)n * 4 + line) * g.LP + pos + sh) * g.C + c] : 0.f;
-        acc = bl_mfma(a, b, acc);
+        const int np2 = part ? g.n1 : g.n2;                 // fine positions 0 .. 2 n - 1 of the output line, in pairs
+        for (int n = 0; n < g.N; ++n) {
+            const float* ap = DYLt + ((((long)job * g.N + n) * LD + 2 + kg) * g.K + k);
+            const float* bp = FLt + ((((long)n * 4 + line) * g.LP + sh + kg) * g.C + c);
+#pragma unroll 8
+            for (int pp = sp * 4 + wave; pp < np2; pp += splits * 4)
+                acc = bl_mfma(ap[(long)(2 * pp) * g.K], bp[(long)(2 * pp) * g.C], acc);
+        }
     }
     // D[i = k][j = c] -> dWp[split][tap][c][k]
     float* dst = dWp + (((long)sp * 9 + tap) * g.C + blockIdx.y * 32) * g.K + blockIdx.x * 32;
@@ -436,9 +434,9 @@ int ghm_blconv_frame_wgrad(ghm_ctx* ctx, const float* DYL, const float* FL, floa
                            int32_t n2) {
     GHM_CHECK(bl_ok(N, C, K, n1, n2), "ghm_blconv_frame_wgrad: geometry not served");
     const BlGeo g{N, C, K, n1, n2, bl_lp(n1, n2)};
-    const long items = (long)2 * N * (g.LP / 2);
-    int splits = bl_splits(items * 2, (long)(K / 32) * (C / 32) * 9, ctx->num_cu);
-    if (splits > items / 4) splits = (int)(items / 4 > 0 ? items / 4 : 1);
+    const int npmin = n1 < n2 ? n1 : n2;                    // position pairs per (part, n): every split must own some of them
+    int splits = bl_splits((long)2 * N * (n1 + n2), (long)(K / 32) * (C / 32) * 9, ctx->num_cu);
+    if (splits > npmin / 4) splits = npmin / 4 > 0 ? npmin / 4 : 1;
     void* ws;
     if (ghm_scratch(ctx, (size_t)splits * 9 * C * K * 4, &ws)) return -1;
     hipLaunchKernelGGL(bl_gemm_wgrad_kernel, dim3(K / 32, C / 32, splits * 9), dim3(256), 0, ctx->stream,

@@ -449,6 +449,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
     unsigned wu[NIW];            // chunk's byte offset from the filter row's base (wave-uniform)
     int wl[NIW];                 // LDS unit offset inside a weight buffer
     bool wreal[NIW];
+    int wcol[NIW];               // the chunk's filter column (class forms: structurally zero columns are not fetched)
 #pragma unroll
     for (int i = 0; i < NIW; ++i) {
         const int j = wave + i * NW;
@@ -459,15 +460,22 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
         const int cb = ci / KS, b = ci - cb * KS;
         wu[i] = (unsigned)(((long)p * a.wq_pstride + ((long)cb * T + b) * a.Rpad + h * 64) * 16);
         wl[i] = p * WU1 + w * 64;
+        wcol[i] = b;
+        if (CLS == 1 && b < b0) wreal[i] = false;          // forward class with q = 1: column 0 is all zeros
     }
     const long wrow = (long)KS * a.Rpad * 16;             // bytes between filter rows of a slab
     const long wslab = (long)2 * T * a.Rpad * 16;         // ... between slabs
     // filter row ``fa`` of slab ``s`` of the filter tile at ``r0`` -> weight buffer at unit offset ``tog``
-    auto dma_w = [&](int r0, int s, int fa, int tog) {
+    auto dma_w = [&](int r0, int s, int fa, int tog, int nc = KS) {
         const char* const src = (const char*)(a.wq + r0) + (long)s * wslab + fa * wrow;
 #pragma unroll
         for (int i = 0; i < NIW; ++i)
-            if (ABL & 16)
+            if (CLS != 0) {
+                // a chunk of a structurally zero column (or a surplus instruction) reads the zero unit into the scratch chunk
+                const bool real = wreal[i] && (CLS != 2 || wcol[i] < nc);
+                __builtin_amdgcn_global_load_lds(real ? (gptr_t)(src + wu[i] + lane16) : (gptr_t)a.zeros,
+                                                 (lptr_t)(sp_smem + (real ? wl[i] + tog : SCR)), 16, 0, 0);
+            } else if (ABL & 16)
                 __builtin_amdgcn_global_load_lds((gptr_t)(src + wu[i] + lane16), (lptr_t)(sp_smem + (wreal[i] ? wl[i] + tog : SCR)), 4, 0, 0);
             else if (ABL & 8)
                 __builtin_amdgcn_global_load_lds((gptr_t)a.zeros, (lptr_t)(sp_smem + (wreal[i] ? wl[i] + tog : SCR)), 16, 0, 0);
@@ -564,12 +572,14 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
 
     // ---- prologue (once per block): filter row 0 and the patch of the first slab, then filter row 1; the first fragments ----
     const int s_last = s_end - 1;
+    // (CLS = 2: filter columns a slab of class (p, q) has = 3 - q)
+    auto ncols_of = [&](int s) { return CLS == 2 ? 3 - ((s / (a.cls_k / 16)) & 1) : KS; };
     if (s_begin < s_end) {
-        dma_w(tc.r0, s_begin, fa0, 0);
+        dma_w(tc.r0, s_begin, fa0, 0, ncols_of(s_begin));
         dma_p(0, false);
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (s_begin < s_end) dma_w(tc.r0, s_begin, fa0 + 1, WUNITS);
+    if (s_begin < s_end) dma_w(tc.r0, s_begin, fa0 + 1, WUNITS, ncols_of(s_begin));
     int w0 = 0, p0 = 0;          // unit offsets of the weight buffer of the slab's filter row 0 / of the slab's patch buffer
     Frag cur;
     rd(cur, Wl + wlane, Pl + plane, 0, 0);
@@ -619,9 +629,9 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
                         if (b + 1 == NC && !(ABL & 1)) {
                             // the filter row two iterations ahead replaces this one's (all of its fragments were read before the barrier)
                             if (fa + 2 < NR)
-                                dma_w(tc.r0, s, fa0 + fa + 2, wc);
+                                dma_w(tc.r0, s, fa0 + fa + 2, wc, NC);
                             else
-                                dma_w(rn, sn, fa0 + fa + 2 - NR, wc);
+                                dma_w(rn, sn, fa0 + fa + 2 - NR, wc, ncols_of(sn));
                             ndma = NIW;
                         }
                         if (fa == 0 && b == 0 && !(ABL & 1)) {           // the next slab's patch
@@ -1859,7 +1869,15 @@ int ghm_blconv_fwd_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void* xq, i
     a.R = d->K; a.Rpad = sp_rpad(d->K); a.wq_pstride = (long)sp_nblk(d->C) * 9 * a.Rpad;
     a.out_nstride = d->y_nstride; a.pad = 1;
     a.act = GHM_ACT_LINEAR; a.cls_k = ck;
-    return sp_launch_conv(ctx, pl, a, 3, 1, nullptr, 0, false, 1);
+    // the classes' tiles cost 9 : 6 : 6 : 4: a launch of at most one block per CU ends with its 9-tap tiles while the CUs of
+    // the 4-tap ones idle -- two halves of the contraction per tile give every CU a heavy and a light block
+    SpPlan p2 = pl;
+    const int nslabs = d->C / 16;
+    if (p2.splits == 1 && p2.grid <= ctx->num_cu && nslabs >= 16 && !GHM_OPT("GHM_BLCONV_NO_SPLITK")) {
+        p2.splits = 2;
+        p2.slabs_per_split = (nslabs + 1) / 2;
+    }
+    return sp_launch_conv(ctx, p2, a, 3, 1, nullptr, 0, false, 1);
 }
 
 int ghm_blconv_dgrad_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void* dyq, int64_t dyq_nstride, int64_t dyq_pstride,

@@ -520,7 +520,8 @@ def test_persistent_tiles_are_bit_identical_to_one_tile_per_block(gpu, case, pie
     dev.free(wqT)
 
 
-@pytest.mark.parametrize("case", [(2, 64, 64, 32, 32), (1, 128, 128, 32, 64), (4, 256, 64, 128, 128), (2, 64, 64, 8, 32)])
+@pytest.mark.parametrize("case", [(2, 64, 64, 32, 32), (1, 128, 128, 32, 64), (4, 256, 64, 128, 128), (2, 64, 64, 8, 32),
+                                  (4, 256, 256, 32, 32)])
 @pytest.mark.parametrize("dtype", ["bf16x3", "bf16x2"])
 def test_collapsed_bilinear_convolution_skips_its_structural_zeros(gpu, case, dtype):
     """The coarse-grid form of BilinearUpsample2DLayer(2) -> 3x3 conv (p2p.py:204-267; csrc/conv_bilinear.hip) is a 3x3
@@ -555,18 +556,23 @@ def test_collapsed_bilinear_convolution_skips_its_structural_zeros(gpu, case, dt
     y0, y1 = dev.empty(g.shape), dev.empty(g.shape)
     ops.conv2d_fwd_lp_q(d, xq, wq, b4, y0, None, dtype)
     ops.blconv_fwd_split(d, xq, wq, b4, y1, dtype)
-    assert np.array_equal(y0.numpy(), y1.numpy())
+    # (4, 256, 256, 32, 32): few tiles -- the class forms (64-filter tiles; a forward launch of one block per CU halves every tile's
+    # contraction so that each CU gets a heavy and a light block) cut the contraction into other split-K ranges than the plain
+    # plans: the same products, fp32 sums in another order -- equal to rounding there, bit for bit everywhere else
+    exact = case != (4, 256, 256, 32, 32)
+    same = (lambda u, v: np.array_equal(u, v)) if exact else (lambda u, v: rel(u, v) < 1e-6)
+    assert same(y0.numpy(), y1.numpy())
     # data gradient, plain and accumulating into a channel slice of a wider tensor
     dx0, dx1 = dev.empty(x.shape), dev.empty(x.shape)
     ops.conv2d_dgrad_lp_q(d, gq, wqT, dx0, None, dtype)
     ops.blconv_dgrad_split(d, gq, wqT, dx1, dtype)
-    assert np.array_equal(dx0.numpy(), dx1.numpy())
+    assert same(dx0.numpy(), dx1.numpy())
     wide0, wide1 = dev.tensor(rng.randn(N, C + 16, n1, n2).astype(np.float32)), None
     wide1 = dev.tensor(wide0.numpy())
     dv = D.conv_desc(N, C, n1, n2, 4 * K, 3, 3, 1, 1, wide0.nstride, gq.shape[1] * n1 * n2)
     ops.conv2d_dgrad_lp_q(dv, gq, wqT, wide0.channels(16, 16 + C), None, dtype, accumulate=True)
     ops.blconv_dgrad_split(dv, gq, wqT, wide1.channels(16, 16 + C), dtype, accumulate=True)
-    assert np.array_equal(wide0.numpy(), wide1.numpy())
+    assert same(wide0.numpy(), wide1.numpy())
     # weight gradient
     ws = dev.alloc(max(ops.wgrad_lp_workspace(d), 16))
     dw0, dw1 = dev.zeros((1, C * 9 * 4 * K, 1, 1)), dev.zeros((1, C * 9 * 4 * K, 1, 1))
