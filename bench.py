@@ -590,24 +590,36 @@ def measure(args, secondary_name=None):
         traffic = None
         kdt_name = args.dtype if dominant.startswith(("lp_", "sp_")) else "f32"
         sfx = "f32" if kdt_name == "f32" else "bf16"
-        for pmc in ("r05_pmc_traffic_3stream_%s.json" % sfx, "r04_pmc_traffic_3stream_%s.json" % sfx,     # tools/pmc_traffic.py,
-                    "r03_pmc_traffic_%s.json" % sfx, "r02_pmc_traffic_%s.json" % sfx, "r01_pmc_traffic.json"):      # newest round first
+        rounds = ("r06", "r05", "r04")                                      # tools/pmc_mfma.sh; newest round first
+        for pmc in ["%s_pmc_traffic_3stream_%s.json" % (r, sfx) for r in rounds] + ["r03_pmc_traffic_%s.json" % sfx,
+                                                                                     "r02_pmc_traffic_%s.json" % sfx, "r01_pmc_traffic.json"]:
             pmc = os.path.join(ROOT, "profiles", pmc)
             if traffic is None and os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get(dominant, {}).get("hbm_bytes_per_launch")
         if traffic is None and dominant.startswith("sp_"):
-            # split kernels: the PMC file names the template instantiations; the wide-tile ones of this family, launch-weighted
-            for pmc in ("r05_pmc_traffic_3stream_bf16x3.json", "r04_pmc_traffic_3stream_bf16x3.json"):
+            # split kernels: the PMC file names the template instantiations <KS, ST, BM, RT, WM, WN, POOL, TW, NP, ABL, CLS>; the
+            # wide-tile ones of this family (pooled or not, class forms or not, as the label says), launch-weighted
+            import re
+            for pmc in ["%s_pmc_traffic_3stream_%s.json" % (r, args.dtype) for r in rounds]:
                 pmc = os.path.join(ROOT, "profiles", pmc)
                 if traffic is None and os.path.exists(pmc):
-                    # "sp_conv2_kernel<3, 1" -> "sp_conv2" + "<3, 1,"
-                    fam = dominant.split("<")[1].split(">")[0] + ","
+                    fam = dominant.split("<")[1].split(">")[0] + ","             # "sp_conv2_kernel<3, 1> cls" -> "3, 1,"
                     stem = dominant.split("_kernel")[0]
-                    import re
-                    # wide-tile instantiations only (32-column pixel tiles / 32- and 64-pixel strips), whatever trails them
-                    wide = re.compile(r"(, (true|false), 32(, \d+, \d+)?|, (32|64)(, \d+)?)>$")
-                    rows = [v for k, v in json.load(open(pmc)).items()
-                            if k.startswith(stem) and ("<" + fam) in k and wide.search(k) and v.get("hbm_bytes_per_launch")]
+                    pooled, cls = "fwd+pool" in dominant, dominant.endswith(" cls")
+                    rows = []
+                    for k, v in json.load(open(pmc)).items():
+                        if not (k.startswith(stem) and ("<" + fam) in k and v.get("hbm_bytes_per_launch")):
+                            continue
+                        targs = [t.strip() for t in k.split("<", 1)[1].rstrip(">").split(",")]
+                        if stem == "sp_conv2":
+                            if targs[7] != "32" or (targs[6] == "true") != pooled:
+                                continue
+                            if (len(targs) > 10 and targs[10] != "0") != cls:
+                                continue
+                        elif stem == "sp_wgrad":
+                            if targs[4] not in ("32", "64") or (len(targs) > 6 and targs[6] != "0") != cls:
+                                continue
+                        rows.append(v)
                     n = sum(v["launches_sampled"] for v in rows)
                     if n:
                         traffic = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] for v in rows) / n

@@ -2,7 +2,7 @@
 # MFMA-utilisation counters per kernel of the THREE-STREAM RECORDED step (the form bench.py times), f32 and bf16, and
 # FETCH / WRITE traffic re-taken in the same form.  Counters only (--pmc with --kernel-trace).
 #   gpurun --timeout 1500 -- 'tools/pmc_mfma.sh r04'   then copy gpurun_out/pmc/* into profiles/
-R=${1:-r05}
+R=${1:-r06}
 O=$GRAFT_REPO_ROOT/gpurun_out/pmc
 mkdir -p $O
 export TMPDIR=/tmp

@@ -2,7 +2,7 @@
 # Regenerates the files under profiles/ for the current round (run through gpurun from the repo root, then copy
 # gpurun_out/refresh/* into profiles/):   gpurun --timeout 2400 -- 'tools/refresh_profiles.sh r05'
 # Round 5: the headline arithmetic is bf16x3 (python bench.py with no --dtype); f32 = the same step on v_mfma_f32_32x32x2_f32.
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out/refresh
 mkdir -p $O
 export TMPDIR=/tmp
