@@ -748,10 +748,16 @@ __device__ __forceinline__ void sp_tr_wait(SpTrFrag (&f)[N]) {
 // taps in filter row 0 when p = 1, none in filter column 0 when q = 1): a block's filter tile lies in ONE class; the waves of a
 // structurally-zero filter row only help staging, and every wave skips the zero column -- fragment reads and MFMAs.  The
 // skipped taps leave their zero accumulators in dwp (the expansion multiplies them by zero coefficients anyway).
-template <int KS, int ST, int CHT, int CT, int SPX, int NP, int CLS = 0>
+// LA = 2 (round 6; 3x3 stride 1, where it fits the LDS): the operands of output row i + 2 are requested while row i is
+// multiplied -- an output row of a 32-pixel strip is ~1.5 us of MFMAs (1 us in the class forms), the order of the DMA latency it
+// had to hide with one row of lookahead.  Ring of KS + 2 ST rows, three dy buffers; every wave issues the SAME number of DMA
+// instructions per row (surplus ones copy the zero unit into a scratch chunk), so the end-of-row wait is a compile-time
+// ``vmcnt(instructions of this row)``: row i + 1 has landed, row i + 2 stays in flight.  Same products, same order.
+template <int KS, int ST, int CHT, int CT, int SPX, int NP, int CLS = 0, int LA = 1>
 __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const SpWgradArgs a) {
     static_assert((ST == 1 || (ST == 2 && KS == 3)) && (SPX == 64 || SPX == 32 || SPX == 16) && (KS == 3 || KS == 5), "variants");
     static_assert(CLS == 0 || (KS == 3 && ST == 1), "class form: 3x3 stride 1");
+    static_assert(LA == 1 || LA == 2, "rows of lookahead");
     constexpr int T = KS * KS, PADK = KS / 2;
     constexpr int NWAVES = CHT * CT * KS;
     constexpr int NPAR = ST;                          // column-parity planes of an x row
@@ -759,13 +765,17 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
     constexpr int XCH = (XPIX + 15) / 16;             // 16-pixel DMA pieces per plane
     constexpr int PLB = XCH * 16 * 64;                // bytes per plane
     constexpr int ROWB = CHT * NPAR * PLB;            // bytes per ring row and piece
-    constexpr int NR = KS + ST;                       // ring rows: KS live + ST arriving
+    constexpr int NR = KS + LA * ST;                  // ring rows: KS live + LA x ST arriving
+    constexpr int NYB = LA + 1;                       // dy buffers
     constexpr int YTB = SPX * 64;                     // bytes per dy filter tile
     constexpr int YB = CT * YTB;                      // bytes per dy buffer and piece
     constexpr int KSTEPS = SPX / 16;
+    constexpr int XTOT = NP * CHT * NPAR * XCH, YTOT = NP * CT * (SPX / 16);      // DMA instructions per x row / dy strip
+    constexpr int NX = (XTOT + NWAVES - 1) / NWAVES, NY = (YTOT + NWAVES - 1) / NWAVES;   // ... per wave
     extern __shared__ __attribute__((aligned(16))) char sp_wsmem[];
     char* const Xl = sp_wsmem;                        // [ring slot][piece][ROWB]
     char* const Yl = sp_wsmem + NR * NP * ROWB;       // [buffer][piece][YB]
+    char* const Sl = Yl + NYB * NP * YB;              // LA = 2: 1 KB scratch, the target of the surplus DMA instructions
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -803,6 +813,8 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
                 const u32x4* src = ok ? xbase + piece * a.xq_ps + (long)(g * 4) * HWx + (long)y * a.W + x : a.zeros;
                 if (pp < XPIX)
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xl + (slot * NP + piece) * ROWB + pl * PLB + ch * 1024), 16, 0, 0);
+            } else if (LA == 2) {
+                __builtin_amdgcn_global_load_lds((gptr_t)a.zeros, (lptr_t)Sl, 16, 0, 0);
             }
         }
     };
@@ -815,6 +827,8 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
                 const int ct = p / (SPX / 16), ch = p - ct * (SPX / 16);
                 const u32x4* src = ybase + piece * a.dyq_ps + (long)(ct * 4) * HWy + (long)i * a.Wo + j0 + ch * 16 + pxi;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Yl + (buf * NP + piece) * YB + ct * YTB + ch * 1024), 16, 0, 0);
+            } else if (LA == 2) {
+                __builtin_amdgcn_global_load_lds((gptr_t)a.zeros, (lptr_t)Sl, 16, 0, 0);
             }
         }
     };
@@ -829,6 +843,11 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
 #pragma unroll
         for (int fa = 0; fa < KS; ++fa) stage_xrow(i_begin * ST + fa - PADK);
         stage_dy(i_begin, 0);
+        if (LA == 2 && i_begin + 1 < i_end) {
+#pragma unroll
+            for (int r = 0; r < ST; ++r) stage_xrow(i_begin * ST - PADK + KS + r);
+            stage_dy(i_begin + 1, 1);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -850,11 +869,12 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
             constexpr int T0 = decltype(T0_)::value;
             constexpr bool ACT = decltype(ACT_)::value != 0;
             for (int i = i_begin; i < i_end; ++i) {
-                const int buf = (i - i_begin) & 1;
-                if (i + 1 < i_end) {
+                const int buf = (i - i_begin) % NYB;
+                const bool ahead = i + LA < i_end;
+                if (ahead) {
 #pragma unroll
-                    for (int r = 0; r < ST; ++r) stage_xrow(i * ST - PADK + KS + r);        // the rows the next output row adds
-                    stage_dy(i + 1, buf ^ 1);
+                    for (int r = 0; r < ST; ++r) stage_xrow((i + LA - 1) * ST - PADK + KS + r);     // the rows output row i + LA adds
+                    stage_dy(i + LA, (i + LA - i_begin) % NYB);
                 }
                 if constexpr (ACT) {
                     const unsigned xr = xl0 + (((i * ST + wr - PADK + NR) % NR) * NP) * ROWB;
@@ -901,7 +921,11 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
                         }
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                // row i + 1 has landed (LA = 2: what this row requested, row i + 2, may stay in flight); everybody is done with row i
+                if (LA == 2 && ahead)
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(ST * NX + NY) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             }
         };
         if constexpr (CLS == 0) {
@@ -1456,13 +1480,14 @@ struct SpWPlan {
     bool ok;
     int np;
     int cht, ct, spx, splits_per_col, rows_per_split, ncols;
+    int la;            // rows of DMA lookahead (2: 3x3 stride 1 on 32-pixel strips)
     size_t lds;
 };
 
-size_t sp_wgrad_lds(int ks, int st, int cht, int ct, int spx, int NP) {
+size_t sp_wgrad_lds(int ks, int st, int cht, int ct, int spx, int NP, int la = 1) {
     const int xpix = st == 1 ? spx + ks - 1 : spx + 1, xch = (xpix + 15) / 16;
     const size_t rowb = (size_t)cht * st * xch * 16 * 64, yb = (size_t)ct * spx * 64;
-    return NP * ((ks + st) * rowb + 2 * yb);
+    return NP * ((ks + la * st) * rowb + (la + 1) * yb) + (la == 2 ? 1024 : 0);
 }
 
 SpWPlan sp_wplan(const ghm_conv_desc* d, int num_cu, int np = 3) {
@@ -1486,7 +1511,8 @@ SpWPlan sp_wplan(const ghm_conv_desc* d, int num_cu, int np = 3) {
         if (d->K % 128 || d->C % 32) return v;
         v.cht = 1; v.ct = 4; v.spx = narrow;
     }
-    v.lds = sp_wgrad_lds(d->kh, d->stride, v.cht, v.ct, v.spx, np);
+    v.la = (k3 && d->stride == 1 && v.spx == 32 && !GHM_OPT("GHM_SPLIT_WGRAD_LA1")) ? 2 : 1;
+    v.lds = sp_wgrad_lds(d->kh, d->stride, v.cht, v.ct, v.spx, np, v.la);
     if (v.lds > 160 * 1024) return v;
     v.ncols = d->N * (d->Wo / v.spx);
     const long tiles = (long)(d->C / (32 * v.cht)) * (d->K / (32 * v.ct)) * v.ncols;
@@ -1523,37 +1549,38 @@ int sp_launch_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const SpWPlan& v, cons
     if (cls_k) {        // the class form of the collapsed bilinear convolution: 3x3 stride 1, 32-pixel strips
         GHM_CHECK(d->kh == 3 && d->stride == 1 && v.cht == 2 && v.ct == 2 && v.spx == 32 && cls_k % 64 == 0 && d->K == 4 * cls_k,
                   "split-fp32 weight gradient: no class form for this geometry");
-        if (v.np == 3) {
-            if (int e = sp_set_lds(sp_wgrad_kernel<3, 1, 2, 2, 32, 3, 1>, v.lds)) return e;
-            hipLaunchKernelGGL((sp_wgrad_kernel<3, 1, 2, 2, 32, 3, 1>), grid, dim3(2 * 2 * 3 * 64), v.lds, ctx->stream, a);
-        } else {
-            if (int e = sp_set_lds(sp_wgrad_kernel<3, 1, 2, 2, 32, 2, 1>, v.lds)) return e;
-            hipLaunchKernelGGL((sp_wgrad_kernel<3, 1, 2, 2, 32, 2, 1>), grid, dim3(2 * 2 * 3 * 64), v.lds, ctx->stream, a);
+#define GHM_SPW_CLS(NP_, LA_)                                                                                           \
+        if (v.np == NP_ && v.la == LA_) {                                                                               \
+            if (int e = sp_set_lds(sp_wgrad_kernel<3, 1, 2, 2, 32, NP_, 1, LA_>, v.lds)) return e;                      \
+            hipLaunchKernelGGL((sp_wgrad_kernel<3, 1, 2, 2, 32, NP_, 1, LA_>), grid, dim3(2 * 2 * 3 * 64), v.lds, ctx->stream, a); \
         }
+        GHM_SPW_CLS(3, 1) GHM_SPW_CLS(3, 2) GHM_SPW_CLS(2, 1) GHM_SPW_CLS(2, 2)
+#undef GHM_SPW_CLS
         GHM_LAUNCH_CHECK();
         if (splits > 1) return ghm_reduce_splits(ctx, (const float*)workspace, splits, n, n, dwp, accumulate);
         return 0;
     }
-#define GHM_SPW_CASE(KS_, ST_, CHT_, CT_, SPX_)                                                                     \
-    if (d->kh == KS_ && d->stride == ST_ && v.cht == CHT_ && v.ct == CT_ && v.spx == SPX_) {                       \
+#define GHM_SPW_CASE(KS_, ST_, CHT_, CT_, SPX_, LA_)                                                                \
+    if (d->kh == KS_ && d->stride == ST_ && v.cht == CHT_ && v.ct == CT_ && v.spx == SPX_ && v.la == LA_) {        \
         if (v.np == 3) {                                                                                            \
-            if (int e = sp_set_lds(sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, 3>, v.lds)) return e;                 \
-            hipLaunchKernelGGL((sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, 3>), grid, dim3(CHT_ * CT_ * KS_ * 64), v.lds, \
+            if (int e = sp_set_lds(sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, 3, 0, LA_>, v.lds)) return e;         \
+            hipLaunchKernelGGL((sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, 3, 0, LA_>), grid, dim3(CHT_ * CT_ * KS_ * 64), v.lds, \
                                ctx->stream, a);                                                                   \
         } else {                                                                                                  \
-            if (int e = sp_set_lds(sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, 2>, v.lds)) return e;                 \
-            hipLaunchKernelGGL((sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, 2>), grid, dim3(CHT_ * CT_ * KS_ * 64), v.lds, \
+            if (int e = sp_set_lds(sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, 2, 0, LA_>, v.lds)) return e;         \
+            hipLaunchKernelGGL((sp_wgrad_kernel<KS_, ST_, CHT_, CT_, SPX_, 2, 0, LA_>), grid, dim3(CHT_ * CT_ * KS_ * 64), v.lds, \
                                ctx->stream, a);                                                                   \
         }                                                                                                         \
         GHM_LAUNCH_CHECK();                                                                                       \
     } else
-    GHM_SPW_CASE(3, 1, 2, 2, 32)
-    GHM_SPW_CASE(3, 2, 1, 4, 32)
-    GHM_SPW_CASE(5, 1, 1, 2, 64)
-    GHM_SPW_CASE(5, 1, 1, 2, 32)
-    GHM_SPW_CASE(3, 1, 2, 2, 16)
-    GHM_SPW_CASE(3, 2, 1, 4, 16)
-    GHM_SPW_CASE(5, 1, 1, 2, 16) {
+    GHM_SPW_CASE(3, 1, 2, 2, 32, 2)
+    GHM_SPW_CASE(3, 1, 2, 2, 32, 1)
+    GHM_SPW_CASE(3, 2, 1, 4, 32, 1)
+    GHM_SPW_CASE(5, 1, 1, 2, 64, 1)
+    GHM_SPW_CASE(5, 1, 1, 2, 32, 1)
+    GHM_SPW_CASE(3, 1, 2, 2, 16, 1)
+    GHM_SPW_CASE(3, 2, 1, 4, 16, 1)
+    GHM_SPW_CASE(5, 1, 1, 2, 16, 1) {
         ghm_set_error("no split-fp32 weight gradient variant for k=%d s=%d cht=%d ct=%d spx=%d", d->kh, d->stride, v.cht, v.ct, v.spx);
         return -3;
     }
