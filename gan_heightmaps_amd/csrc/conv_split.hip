@@ -183,6 +183,7 @@ struct SpConvArgs {
     float* pool_out;            // POOL: [N, R, H/2, W/2] maximum of act(conv + bias) over 2x2 windows ...
     unsigned char* pool_mask;   // ... and the arg-max mask of every window (bit 2*dr + dc; all ties set; bit 4: sign)
     int cls_k;                  // CLS forms: filters (forward) / reduction channels (data gradient) per parity class
+    int cls_group;              // CLS = 1: pixel tiles per dispatch group (see decode)
 };
 
 // the piece products of one multiply-add, small terms first, the leading product x0 w0 last: all (i, j) with i + j < NPC.
@@ -413,15 +414,19 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void sp_conv2_kernel(const SpConvA
         int r0, n, y0, x0;
     };
     auto decode = [&](int v) {
-        // CLS = 1: the classes' tiles cost 9 : 6 : 6 : 4 -- filter tiles slowest, i.e. the launch is dispatched class by class,
-        // heaviest first, so that the CUs that finish a 9-tap tile late pick up the 4-tap ones (and no XCD remap: it would hand
-        // whole classes to single XCDs)
+        // CLS = 1: the classes' tiles cost 9 : 6 : 6 : 4.  Dispatch order = groups of a.cls_group pixel tiles; inside a group the
+        // filter tiles slowest, i.e. class by class, heaviest first, so that the CUs that finish a 9-tap tile late pick up the
+        // 4-tap ones -- and the blocks that read one input patch (one pixel tile, every filter tile) stay within a couple of
+        // rounds of each other and, the group size being a multiple of 8, on ONE XCD's L2 (blocks go round-robin over the XCDs;
+        // no remap).  (Filter tiles slowest over the WHOLE launch re-read the input once per filter tile from HBM: 515 MB per
+        // launch on the decoder layers against 117 for the plain kernel, profiles/r06_pmc_traffic_3stream_bf16x3.json.)
         int L = CLS == 1 ? v : sp_xcd_remap(v, a.ntiles);
         Tile t;
         if (CLS == 1) {
-            const int per = a.ntiles / ntr;
-            t.r0 = (L / per) * BM;
-            L %= per;
+            const int gs = a.cls_group, span = ntr * gs;
+            const int g = L / span, rem = L - g * span;
+            t.r0 = (rem / gs) * BM;
+            L = g * gs + rem % gs;
         } else {
             t.r0 = (L % ntr) * BM;
             L /= ntr;
@@ -1511,7 +1516,10 @@ SpWPlan sp_wplan(const ghm_conv_desc* d, int num_cu, int np = 3) {
         if (d->K % 128 || d->C % 32) return v;
         v.cht = 1; v.ct = 4; v.spx = narrow;
     }
-    v.la = (k3 && d->stride == 1 && v.spx == 32 && !GHM_OPT("GHM_SPLIT_WGRAD_LA1")) ? 2 : 1;
+    // (two rows of lookahead: built and measured in round 6, NOT the default -- the joint step 300.1 / 299.5 / 296.5 img/s with it
+    // against 299.8 / 301.0 / 298.3 without, the class-form launches 0.96 against 0.92 ms alone: the end-of-row wait is not what
+    // holds this kernel.  GHM_SPLIT_WGRAD_LA2=1 turns it on; tests/test_gpu_split.py covers both.)
+    v.la = (k3 && d->stride == 1 && v.spx == 32 && GHM_OPT("GHM_SPLIT_WGRAD_LA2")) ? 2 : 1;
     v.lds = sp_wgrad_lds(d->kh, d->stride, v.cht, v.ct, v.spx, np, v.la);
     if (v.lds > 160 * 1024) return v;
     v.ncols = d->N * (d->Wo / v.spx);
@@ -1896,6 +1904,14 @@ int ghm_blconv_fwd_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void* xq, i
     a.R = d->K; a.Rpad = sp_rpad(d->K); a.wq_pstride = (long)sp_nblk(d->C) * 9 * a.Rpad;
     a.out_nstride = d->y_nstride; a.pad = 1;
     a.act = GHM_ACT_LINEAR; a.cls_k = ck;
+    {   // dispatch groups of about two rounds of blocks: a power-of-two number of pixel tiles, a multiple of 8 where possible
+        const int per = pl.grid / ((d->K + pl.bm - 1) / pl.bm), ntr = (d->K + pl.bm - 1) / pl.bm;
+        int gs = 8;
+        while (gs * 2 * ntr <= 2 * ctx->num_cu && per % (gs * 2) == 0) gs *= 2;
+        if (per % gs) gs = per;
+        if (const char* f = GHM_OPT("GHM_BLCONV_GROUP")) gs = (atoi(f) > 0 && per % atoi(f) == 0) ? atoi(f) : per;
+        a.cls_group = gs;
+    }
     // the classes' tiles cost 9 : 6 : 6 : 4: a launch of at most one block per CU ends with its 9-tap tiles while the CUs of
     // the 4-tap ones idle -- two halves of the contraction per tile give every CU a heavy and a light block
     SpPlan p2 = pl;

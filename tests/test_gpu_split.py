@@ -585,3 +585,30 @@ def test_collapsed_bilinear_convolution_skips_its_structural_zeros(gpu, case, dt
                 assert not a1[:, rs, pq].any()                  # skipped taps leave zeros (the expansion ignores them)
             else:
                 assert np.array_equal(a0[:, rs, pq], a1[:, rs, pq]), (rs, pq)
+
+
+@pytest.mark.parametrize("pieces", [3, 2])
+def test_weight_gradient_with_two_rows_of_lookahead_is_bit_identical(gpu, pieces):
+    """GHM_SPLIT_WGRAD_LA2=1 (3x3 stride 1, 32-pixel strips: the operands of output row i + 2 requested while row i is multiplied;
+    built and measured in round 6, not the default): the same products in the same order as the one-row form -- plain and class
+    form."""
+    dev, ops, D = gpu
+    dtype = {3: 'bf16x3', 2: 'bf16x2'}[pieces]
+    N, C, K, n1, n2 = 2, 64, 64, 16, 64
+    rng = np.random.RandomState(5)
+    x = rng.randn(N, C, n1, n2).astype(np.float32)
+    g = rng.randn(N, 4 * K, n1, n2).astype(np.float32)
+    d = D.conv_desc(N, C, n1, n2, 4 * K, 3, 3, 1, 1)
+    xq, gq = D.QTensor.empty(dev, x.shape, dtype), D.QTensor.empty(dev, g.shape, dtype)
+    ops.q_pack(dev.tensor(x), xq)
+    ops.q_pack(dev.tensor(g), gq)
+    ws = dev.alloc(max(ops.wgrad_lp_workspace(d), 16))
+    out = {}
+    for la2 in (False, True):
+        with tuning_env(**({"GHM_SPLIT_WGRAD_LA2": "1"} if la2 else {})):
+            a, b = dev.zeros((1, C * 9 * 4 * K, 1, 1)), dev.zeros((1, C * 9 * 4 * K, 1, 1))
+            ops.conv2d_wgrad_lp_q(d, xq, gq, a, ws, dtype)
+            ops.blconv_wgrad_split(d, xq, gq, b, ws, dtype)
+            out[la2] = (a.numpy(), b.numpy())
+    assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
+    assert np.abs(out[True][0]).max() > 0
