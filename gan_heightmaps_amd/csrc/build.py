@@ -87,8 +87,9 @@ def kernel_resources():
 
 # scratch use that is known and outside every hot loop (bytes per lane): the 36-tap fan-out variant spills in its
 # prologue; the pooled fan-out variants, which hold two rows of accumulators, reload 11 spilled weight fragments per
-# 104-MFMA pixel group
-BENIGN_SCRATCH = {"sp_conv2_kernelILi3ELi1ELi128ELi8ELi1ELi4E": 24, "sp_conv2_kernelILi3ELi1ELi128ELi8ELi2ELi4E": 24, "fanout_kernelILi18ELi2ELi4ELb0ELb0": 52, "fanout_kernelILi13ELi2ELi2ELb0ELb1": 96,
+# 104-MFMA pixel group; the 128-filter data-gradient class form (conv_split.hip CLS = 2) keeps 32 bytes outside its slab loop
+BENIGN_SCRATCH = {"sp_conv2_kernelILi3ELi1ELi128ELi8ELi1ELi4E": 24, "sp_conv2_kernelILi3ELi1ELi128ELi8ELi2ELi4E": 24,
+                  "sp_conv2_kernelILi3ELi1ELi128ELi8ELi2ELi4ELb0ELi32ELi3ELi0ELi2E": 32, "sp_conv2_kernelILi3ELi1ELi128ELi8ELi2ELi4ELb0ELi32ELi2ELi0ELi2E": 32, "fanout_kernelILi18ELi2ELi4ELb0ELb0": 52, "fanout_kernelILi13ELi2ELi2ELb0ELb1": 96,
                   "fanout_kernelILi18ELi2ELi2ELb0ELb1": 160}
 
 

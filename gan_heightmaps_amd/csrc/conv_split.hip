@@ -1384,15 +1384,18 @@ template <int KS, int ST, int BM, int RT, int WM, int WN, bool POOL, int TW>
 int sp_launch_variant(ghm_ctx* ctx, dim3 g, size_t lds, const SpConvArgs& a, int np, int cls = 0) {
     static_assert(SpGeo2<KS, ST, BM, RT, WM, WN, TW, 3>::LDS_BYTES <= 160 * 1024, "LDS");
     if (cls) {          // the class forms of the collapsed bilinear convolution (structural zero taps skipped)
-        if constexpr (KS == 3 && ST == 1 && !POOL && TW == 32 && BM == 64) {      // (the eight-wave 128-filter shape has no registers to spare)
+        if constexpr (KS == 3 && ST == 1 && !POOL && TW == 32) {
+            // (forward class form: 64-filter tiles only -- the eight-wave 128-filter shape spills 232 bytes per lane with it;
+            // the data-gradient form fits it with 20)
 #define GHM_CLS_CASE(NP_, C_)                                                                                                     \
-            if (np == NP_ && cls == C_) {                                                                                         \
-                if (int e = sp_set_lds(sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, NP_, 0, C_>, lds)) return e;             \
-                hipLaunchKernelGGL((sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, NP_, 0, C_>), g, dim3(WM * WN * 64), lds,   \
-                                   ctx->stream, a);                                                                               \
-                GHM_LAUNCH_CHECK();                                                                                               \
-                return 0;                                                                                                         \
-            }
+            if constexpr (BM == 64 || C_ == 2)                                                                                    \
+                if (np == NP_ && cls == C_) {                                                                                     \
+                    if (int e = sp_set_lds(sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, NP_, 0, C_>, lds)) return e;         \
+                    hipLaunchKernelGGL((sp_conv2_kernel<KS, ST, BM, RT, WM, WN, POOL, TW, NP_, 0, C_>), g, dim3(WM * WN * 64), lds, \
+                                       ctx->stream, a);                                                                           \
+                    GHM_LAUNCH_CHECK();                                                                                           \
+                    return 0;                                                                                                     \
+                }
             GHM_CLS_CASE(3, 1) GHM_CLS_CASE(3, 2) GHM_CLS_CASE(2, 1) GHM_CLS_CASE(2, 2)
 #undef GHM_CLS_CASE
         }
@@ -1879,8 +1882,8 @@ int ghm_blconv_split_supported(const ghm_conv_desc* d, int32_t kind) {
         return sp_fwd_geom(d) && pl.ok && pl.tw == 32 && pl.bm == 64;
     }
     if (kind == 1) {
-        const SpPlan pl = sp_plan(d->N, d->K, d->H, d->W, d->C, 3, 1, ghm_plan_cus(), 3, true);
-        return sp_fwd_geom(d) && pl.ok && pl.tw == 32 && pl.bm == 64;
+        const SpPlan pl = sp_plan(d->N, d->K, d->H, d->W, d->C, 3, 1, ghm_plan_cus(), 3, GHM_OPT("GHM_BLCONV_DGRAD_BM64") != nullptr);
+        return sp_fwd_geom(d) && pl.ok && pl.tw == 32;
     }
     if (kind == 2) {
         const SpWPlan v = sp_wplan(d, ghm_plan_cus());
@@ -1928,7 +1931,7 @@ int ghm_blconv_dgrad_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void* dyq
     GHM_CHECK(ctx && d && dyq && wqT && dx, "null argument");
     GHM_SP_PIECES_OK(pieces);
     GHM_CHECK(ghm_blconv_split_supported(d, 1), "ghm_blconv_dgrad_split: geometry not served (ask ghm_blconv_split_supported)");
-    const SpPlan pl = sp_plan(d->N, d->K, d->H, d->W, d->C, 3, 1, ctx->num_cu, pieces, true);
+    const SpPlan pl = sp_plan(d->N, d->K, d->H, d->W, d->C, 3, 1, ctx->num_cu, pieces, GHM_OPT("GHM_BLCONV_DGRAD_BM64") != nullptr);
     SpConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in_q = (const u32x4*)dyq; a.in_q_nstride = dyq_nstride; a.in_q_pstride = dyq_pstride;
