@@ -466,3 +466,54 @@ def test_unique_id_rendezvous_two_processes(tmp_path, leftovers):
     for p in ps:
         p.join(30)
     assert got[0] == got[1] == bytes(range(128))
+
+
+def test_bilinear_decoder_stages_are_lowered_onto_the_coarse_grid(monkeypatch):
+    """engine.py R3b without a GPU: BilinearUpsample2DLayer(2) -> Conv2DLayer(3x3, 'same') pairs of p2p.g_unet (p2p.py:204-267)
+    become mode-1 ``upconv`` nodes in the split arithmetic modes where the geometry is served (channels / filters multiples of 32,
+    coarse maps >= GHM_BLCONV_MIN): collapsed-weight table in mode 1, the frame launch behind the collapsed convolution, the
+    BatchNorm written straight into the next ConcatLayer buffer (no concat copy), gather / frame launches in the backward pass,
+    the frame weight gradients behind the batched expansion; the literal form in 'f32' and under GHM_NO_BLCONV."""
+    from tests.fake_device import PolicyDevice, PolicyOps
+    U = p2p.g_unet(128, True, False, nf=32, act=tanh, bilinear_upsample=True)
+
+    def plan_of(dtype):
+        dev = PolicyDevice()
+        ops = PolicyOps(dev)
+        return NetPlan(dev, ops, U, 4, ParamStore(dev, L.get_all_params(U)), dtype=dtype), ops
+
+    monkeypatch.setenv("GHM_BLCONV_MIN", "16")
+    plan, ops = plan_of('bf16x3')
+    ups = [n for n in plan.order if n.op == 'upconv']
+    assert [n.attrs.get('mode') for n in ups] == [1, 1]                     # coarse 16x16 (C 256 -> K 64) and 32x32 (C 128 -> K 32)
+    assert [tuple(n.shape) for n in ups] == [(16, 64, 16, 16), (16, 32, 32, 32)]
+    assert sum(n.op == 'up_bilinear' for n in plan.order) == 3              # the inner stages (8x8 .. 2x2 coarse) stay literal
+    for n in ups:
+        sh = n.consumers[0].consumers[0]
+        assert n.consumers[0].op == 'bn' and sh.op == 'pp_to_hi' and sh.alias is not None       # lives inside the concat buffer
+        assert 'fl' in n.aux and 'dyl' in n.aux
+    fwd = []
+    plan.emit_forward(fwd)
+    labels = [e[0] for e in fwd]
+    assert labels.count('blconv_fwd') == 2 and labels.count('blconv_frame_fwd') == 2 and 'concat_copy' not in labels
+    for i, lab in enumerate(labels):
+        if lab == 'blconv_fwd':
+            assert labels[i + 1] == 'blconv_frame_fwd'                      # the frame before anything reads the convolution's output
+    for e in fwd:
+        e[1]()
+    tab = [c for c in ops.calls if c[0] == 'collapse_table'][0][1][0]
+    assert [it[6] for it in tab] == [1, 1]                                  # mode 1: the bilinear tap map
+    seed = plan.dev.empty(plan.out.shape)
+    bwd = []
+    plan.emit_backward(bwd, seed, wgrad=True)
+    lb = [e[0] for e in bwd]
+    assert lb.count('blconv_frame_gather') == 2 and lb.count('blconv_frame_dgrad') == 2 and lb.count('blconv_frame_wgrad') == 2
+    assert lb.index('expand_wgrad') < min(i for i, x in enumerate(lb) if x == 'blconv_frame_wgrad')
+    for i, x in enumerate(lb):
+        if x == 'blconv_dgrad':
+            assert lb[i + 1] == 'blconv_frame_dgrad'
+    monkeypatch.delenv("GHM_BLCONV_MIN")
+    assert sum(n.op == 'upconv' for n in plan_of('bf16x3')[0].order) == 1   # default: coarse maps of at least 32 x 32
+    assert not any(n.op == 'upconv' for n in plan_of('f32')[0].order)       # the fp32-MFMA mode keeps the literal form
+    monkeypatch.setenv("GHM_NO_BLCONV", "1")
+    assert not any(n.op == 'upconv' for n in plan_of('bf16x3')[0].order)
