@@ -325,4 +325,31 @@ def host_device_class():
         def event_wait(self, ev):
             Shared.log.append((self.name, "event_wait", ev))
 
+        # ---- the input pipeline's surface (step.py upload_async / upload_resident_async): synchronous here, logged ----
+        class pinned_array:
+            def __init__(self, shape, dtype=np.float32):
+                self.shape, self.array, self.ptr = tuple(shape), np.zeros(shape, dtype), 1
+
+            def close(self):
+                self.array = None
+
+        @staticmethod
+        def event_sync(ev):
+            Shared.log.append(("host", "event_sync", ev))
+
+        @staticmethod
+        def event_destroy(ev):
+            pass
+
+        def h2d_async(self, ptr, pinned):
+            self.h2d(ptr, pinned.array)
+            Shared.log.append((self.name, "h2d_async", int(ptr)))
+
+        def d2d(self, dst, src, nbytes):
+            self.view(dst, nbytes // 4)[:] = self.view(src, nbytes // 4)
+            Shared.log.append((self.name, "d2d", int(dst), int(src), int(nbytes)))
+
+        def close(self):
+            pass
+
     return HostDevice

@@ -408,3 +408,72 @@ def test_eight_rank_sharded_update_equals_the_allreduce_form(world8):
         assert all(a[0] + 4 * a[1] == b_[0] for a, b_ in zip(rk, rk[1:]))
         assert all(n % (8 * 64) == 0 for _, n in rk), (k, rk)
         assert n_pad % (8 * 64) == 0
+
+
+# ---- bench.py's timed loop at N > 1: resident batches rotating through two plans (step.py upload_resident_async +
+# ---- enqueue_train_uploaded) with the exchange program inside every step -------------------------------------------------------
+def _worker_rotating(rank, world, port, out_dir, exchange_mode):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    from gan_heightmaps_amd import updates
+    from gan_heightmaps_amd.step import GanStep
+    from tests.fake_device import host_device_class
+    HostDevice = host_device_class()
+    dev, cdev = HostDevice(0), HostDevice(0)
+
+    class GlooComm:
+        def __init__(self):
+            self.dev, self.rank, self.world = cdev, rank, world
+
+        def max_scalar(self, v):
+            t = torch.tensor([float(v)], dtype=torch.float64)
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+            return float(t[0])
+
+    G, D, U, P = _nets(seed=7 if rank == 0 else 1000 + rank)
+    spec = updates.rmsprop(learning_rate=updates.shared(1e-2))
+    eng = GanStep(dev, G, D, U, P, 100, True, 'l1', spec, 'both', comm=GlooComm(), use_graph=False, two_streams=True,
+                  side_streams=True, bucket_mb=2048.0 / 2 ** 20, exchange_mode=exchange_mode)
+    eng.broadcast_parameters()
+    plans = [eng.built(4, 0), eng.built(4, 1)]
+    rng = np.random.RandomState(3 + rank)
+    pool = [(dev.tensor(rng.rand(4, 24)), dev.tensor(rng.rand(4, 1, 32, 32)), dev.tensor(rng.randn(4, 3, 32, 32))) for _ in range(3)]
+    # (the compute kernels are no-ops: give every step's gradient buckets rank-dependent contents so that the updates move)
+    log0 = len(HostDevice.shared.log)
+    eng.upload_resident_async(plans[0], *pool[0])
+    for k in range(4):
+        for key in KEYS:
+            st = eng.stores[key]
+            st.g.set(np.random.RandomState(100 * k + rank).randn(st.n_pad).astype(np.float32))
+        eng.enqueue_train_uploaded(plans[k & 1])
+        eng.upload_resident_async(plans[(k + 1) & 1], *pool[(k + 1) % 3])
+    eng.sync()
+    x_seen = [plans[k & 1].x.numpy().copy() for k in (0, 1)]
+    out = {"rank": rank, "crc": eng.replica_checksums(), "log": HostDevice.shared.log[log0:], "comm": cdev.name,
+           "x": x_seen, "pool_x": [p[1].numpy().copy() for p in pool]}
+    eng.close_pipeline()
+    with open(os.path.join(out_dir, "r%d.pkl" % rank), "wb") as f:
+        pickle.dump(out, f)
+    tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+def test_rotating_resident_batches_with_the_exchange_inside_every_step(tmp_path, mode):
+    """What ``bench.py --gpus N`` times since round 6: step k runs on plan k & 1 with batch k % len(pool), copied device-to-device
+    on the copy stream while step k - 1 runs.  Two gloo ranks, both exchange forms: identical collective sequences on both ranks
+    over four steps, replicas bit-identical at the end, every plan holding the batch the rotation says."""
+    world, port = 2, 35500 + (os.getpid() % 2000) + (0 if mode == "allreduce" else 1)
+    tmp_.spawn(_worker_rotating, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
+    out = [pickle.load(open(os.path.join(str(tmp_path), "r%d.pkl" % r), "rb")) for r in range(world)]
+    coll = ("allreduce_sum", "reduce_scatter_sum", "all_gather")
+    seqs = [[(e[1],) + tuple(e[3:]) for e in r["log"] if e[1] in coll] for r in out]      # (sizes; pointers differ per process)
+    assert seqs[0] == seqs[1] and len(seqs[0]) >= 4 * 5
+    assert all(e[0] == r["comm"] for r in out for e in r["log"] if e[1] in coll)
+    assert out[0]["crc"] == out[1]["crc"] and out[0]["crc"][0] == out[0]["crc"][1]
+    for r in out:
+        # after steps 0..3 and the staging of batch 4: plan 0 holds batch 4 % 3 = 1, plan 1 holds batch 3 % 3 = 0
+        assert np.array_equal(r["x"][0], r["pool_x"][1]) and np.array_equal(r["x"][1], r["pool_x"][0])
+        copies = [e for e in r["log"] if e[1] == "d2d"]
+        assert len(copies) == 3 * 5
