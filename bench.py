@@ -141,9 +141,10 @@ def parse_args(argv=None):
                          "never the headline")
     ap.add_argument("--in-shp", type=int, default=512, choices=[512, 1024],
                     help="1024 = BASELINE config 5 geometry (one more U-Net level and DCGAN stage; beyond the reference)")
-    ap.add_argument("--exchange", default=None, choices=["allreduce", "rs_ag"],
+    ap.add_argument("--exchange", default=None, choices=["allreduce", "rs_ag", "allreduce_bf16"],
                     help="N > 1: form of the gradient exchange (default allreduce; rs_ag = reduce-scatter, sharded optimiser "
-                         "update, all-gather of the updated parameters)")
+                         "update, all-gather of the updated parameters; allreduce_bf16 = the all-reduce through a bf16 exchange "
+                         "buffer: half the bytes, REDUCED precision -- the JSON line says so in config.exchange)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="headline only: skip the short extra loops of BASELINE configs 1-5 (\"secondary\" key)")
     ap.add_argument("--secondary-steps", type=int, default=12)
@@ -526,6 +527,7 @@ def measure(args, secondary_name=None):
                                    "; products in %s on the matrix cores, fp32 accumulation / tensors / master weights"
                                    % args.dtype)),
                    "global_batch": B * world, "in_shp": S, "parallelism": "dp%d" % world,
+                   **({"exchange": eng.exchange_mode} if world > 1 else {}),
                    "hip_graph": bool(args.graph), "issue": "graph" if args.graph else args.issue,
                    "host_calls_per_step": 1 if issue == 'recorded' else None,
                    "streams": len({id(d) for d in list(eng.devs) + [sd[0] for sd in eng.side if sd is not None]})},

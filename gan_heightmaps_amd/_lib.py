@@ -169,6 +169,7 @@ SIGNATURES = {
     "ghm_comm_destroy": [_p],
     "ghm_comm_count": [_p, C.POINTER(_i32)],
     "ghm_allreduce_sum": [_p, _p, _i64],
+    "ghm_allreduce_sum_bf16": [_p, _p, _i64, _p],
     "ghm_allreduce_max": [_p, _p, _i64],
     "ghm_reduce_scatter_sum": [_p, _p, _i64],
     "ghm_all_gather": [_p, _p, _i64],

@@ -12,7 +12,7 @@ namespace {
 // minimal RCCL surface (nccl.h ABI): ncclUniqueId is 128 opaque bytes
 typedef struct { char internal[128]; } rccl_uid;
 typedef void* rccl_comm;
-enum { RCCL_FLOAT32 = 7 };
+enum { RCCL_FLOAT32 = 7, RCCL_BFLOAT16 = 9 };
 enum { RCCL_SUM = 0, RCCL_MAX = 2 };
 
 struct RcclApi {
@@ -81,6 +81,21 @@ int load_rccl() {
             return -4;                                                                        \
         }                                                                                     \
     } while (0)
+
+// fp32 <-> bf16 (round to nearest even) over a contiguous range: the reduced-precision exchange buffer
+__global__ __launch_bounds__(256) void comm_f32_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned u = __float_as_uint(x[i]);
+    unsigned r = u + 0x7fffu + ((u >> 16) & 1u);
+    if ((u & 0x7f800000u) == 0x7f800000u) r = u;          // inf / nan keep their class (a nan stays a nan: the quiet bit is in the top half)
+    y[i] = (unsigned short)(r >> 16);
+}
+
+__global__ __launch_bounds__(256) void comm_bf16_to_f32_kernel(const unsigned short* __restrict__ y, float* __restrict__ x, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = __uint_as_float((unsigned)y[i] << 16);
+}
 
 }  // namespace
 
@@ -151,6 +166,31 @@ int ghm_allreduce_sum(ghm_ctx* ctx, float* buf, int64_t n) {
         return 0;
     }
     GHM_RCCL(g_api.AllReduce(buf, buf, (size_t)n, RCCL_FLOAT32, RCCL_SUM, (rccl_comm)ctx->comm, ctx->stream));
+    return 0;
+}
+
+// The same sum with HALF the bytes on the links (opt-in, GanStep(exchange_mode='allreduce_bf16')): the fp32 range is rounded to
+// bf16 into ``scratch`` (n halfwords), summed by RCCL in bf16 and widened back into ``buf`` -- a REDUCED-PRECISION exchange (8
+// significant bits per contribution, rounded again per reduction hop), for configurations where the 226 MB of fp32 gradients
+// per step are exposed on the xGMI links (BASELINE config 4: bf16 compute at 6 ms per step).  Recordable like the fp32 form.
+int ghm_allreduce_sum_bf16(ghm_ctx* ctx, float* buf, int64_t n, void* scratch) {
+    GHM_CHECK(ctx->comm != nullptr, "ghm_allreduce_sum_bf16 on a context without a communicator (ghm_comm_init)");
+    GHM_CHECK(buf && scratch && n > 0, "ghm_allreduce_sum_bf16: null argument");
+    unsigned short* const h = (unsigned short*)scratch;
+    hipLaunchKernelGGL(comm_f32_to_bf16_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, (const float*)buf, h, (long)n);
+    GHM_LAUNCH_CHECK();
+    rccl_comm comm = (rccl_comm)ctx->comm;
+    if (ctx->rec) {
+        ghm_step* st = ctx->rec;
+        hipStream_t s = ctx->stream;
+        st->cmds.emplace_back([=]() {
+            if (g_api.AllReduce(h, h, (size_t)n, RCCL_BFLOAT16, RCCL_SUM, comm, s) != 0 && st->err == hipSuccess) st->err = hipErrorUnknown;
+        });
+    } else {
+        GHM_RCCL(g_api.AllReduce(h, h, (size_t)n, RCCL_BFLOAT16, RCCL_SUM, comm, ctx->stream));
+    }
+    hipLaunchKernelGGL(comm_bf16_to_f32_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, (const unsigned short*)h, buf, (long)n);
+    GHM_LAUNCH_CHECK();
     return 0;
 }
 

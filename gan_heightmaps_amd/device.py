@@ -1006,6 +1006,10 @@ class Ops:
     def allreduce_sum(self, buf, n):
         call("ghm_allreduce_sum", self.h, _vp(buf), int(n))
 
+    def allreduce_sum_bf16(self, buf, n, scratch_ptr):
+        """the sum through a bf16 exchange buffer (``scratch_ptr``: n halfwords of device memory): half the bytes, reduced precision"""
+        call("ghm_allreduce_sum_bf16", self.h, _vp(buf), int(n), C.c_void_p(int(scratch_ptr)))
+
     def reduce_scatter_sum(self, buf, shard):
         """buf = world x shard elements: this rank's shard receives the sum over the ranks (in place)"""
         call("ghm_reduce_scatter_sum", self.h, _vp(buf), int(shard))

@@ -54,11 +54,13 @@ class GanStep:
                  side_streams=None, dtype='bf16x3', bucket_mb=None, exchange_mode=None):
         self.dev = dev
         # form of the data-parallel exchange: 'allreduce' (every rank sums every gradient and runs the whole
-        # optimiser) or 'rs_ag' (sharded update: a sub-bucket is reduce-SCATTERED, each rank runs RMSprop / Adam on its 1 / world
+        # optimiser), 'allreduce_bf16' (the same program with every gradient sub-bucket rounded to bf16 for the trip: half the
+        # bytes on the xGMI links, a REDUCED-PRECISION exchange, opt-in; for the first multi-GPU node to A/B) or 'rs_ag'
+        # (sharded update: a sub-bucket is reduce-SCATTERED, each rank runs RMSprop / Adam on its 1 / world
         # slice of parameters + state, and the updated slices are all-gathered -- the same bytes on the links, 1 / world of
         # the optimiser's 1.13 GB / step per rank)
         self.exchange_mode = exchange_mode or os.environ.get('GHM_EXCHANGE', 'allreduce')
-        assert self.exchange_mode in ('allreduce', 'rs_ag'), self.exchange_mode
+        assert self.exchange_mode in ('allreduce', 'allreduce_bf16', 'rs_ag'), self.exchange_mode
         # data-parallel exchange: a net's gradient bucket travels as sub-buckets of at least this many bytes, each
         # all-reduced as soon as the backward pass has completed it (_build: bucketer)
         self.bucket_bytes = int(float(bucket_mb if bucket_mb is not None else os.environ.get('GHM_BUCKET_MB', 32)) * 2 ** 20)
@@ -398,6 +400,10 @@ class GanStep:
             b.net_buckets = getattr(b, 'net_buckets', {})
             b.net_buckets[k] = buckets
 
+            half = self.exchange_mode == 'allreduce_bf16'
+            if half and not hasattr(st, 'xchg_bf16'):
+                st.xchg_bf16 = cdev.alloc(2 * st.n_pad + 256)          # the net's bf16 exchange buffer (one halfword per gradient)
+
             def send(bk):
                 bk['sent'] = True
                 lo, n = bk['lo'], bk['hi'] - bk['lo']
@@ -411,6 +417,8 @@ class GanStep:
                         cdev.wait_for(d)
                     if sharded:
                         cops.reduce_scatter_sum(view, n // self.world)
+                    elif half:
+                        cops.allreduce_sum_bf16(view, n, st.xchg_bf16 + 2 * lo)
                     else:
                         cops.allreduce_sum(view, n)
                 e = (label, fn, None, cdev)

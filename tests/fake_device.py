@@ -219,6 +219,22 @@ def host_device_class():
             tdist.all_reduce(t)
             Shared.log.append((self.dev.name, "allreduce_sum", int(buf.ptr), int(n)))
 
+        def allreduce_sum_bf16(self, buf, n, scratch_ptr):
+            """the bf16 exchange buffer on the host: contributions rounded to bf16 (nearest even), summed, the sum rounded again
+            (RCCL rounds per reduction hop; the program under test is what matters here, not the last bit)"""
+            import torch
+            import torch.distributed as tdist
+
+            def bf16(a):
+                u = a.view(np.uint32).astype(np.uint64)
+                r = ((u + 0x7fff + ((u >> 16) & 1)) >> 16) << 16
+                return r.astype(np.uint32).view(np.float32)
+            v = self.dev.view(buf.ptr, n)
+            t = torch.from_numpy(bf16(v.copy()))
+            tdist.all_reduce(t)
+            v[:] = bf16(t.numpy())
+            Shared.log.append((self.dev.name, "allreduce_sum_bf16", int(buf.ptr), int(n)))
+
         def reduce_scatter_sum(self, buf, shard):
             # gloo has no reduce-scatter: all-reduce a copy and keep this rank's shard (the other shards stay as they were,
             # like RCCL's in-place form leaves them unspecified)

@@ -459,19 +459,22 @@ def _worker_rotating(rank, world, port, out_dir, exchange_mode):
     tdist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag", "allreduce_bf16"])
 def test_rotating_resident_batches_with_the_exchange_inside_every_step(tmp_path, mode):
     """What ``bench.py --gpus N`` times since round 6: step k runs on plan k & 1 with batch k % len(pool), copied device-to-device
     on the copy stream while step k - 1 runs.  Two gloo ranks, both exchange forms: identical collective sequences on both ranks
     over four steps, replicas bit-identical at the end, every plan holding the batch the rotation says."""
-    world, port = 2, 35500 + (os.getpid() % 2000) + (0 if mode == "allreduce" else 1)
+    world, port = 2, 35500 + (os.getpid() % 2000) + ["allreduce", "rs_ag", "allreduce_bf16"].index(mode)
     tmp_.spawn(_worker_rotating, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     out = [pickle.load(open(os.path.join(str(tmp_path), "r%d.pkl" % r), "rb")) for r in range(world)]
-    coll = ("allreduce_sum", "reduce_scatter_sum", "all_gather")
+    coll = ("allreduce_sum", "allreduce_sum_bf16", "reduce_scatter_sum", "all_gather")
     seqs = [[(e[1],) + tuple(e[3:]) for e in r["log"] if e[1] in coll] for r in out]      # (sizes; pointers differ per process)
     assert seqs[0] == seqs[1] and len(seqs[0]) >= 4 * 5
     assert all(e[0] == r["comm"] for r in out for e in r["log"] if e[1] in coll)
     assert out[0]["crc"] == out[1]["crc"] and out[0]["crc"][0] == out[0]["crc"][1]
+    if mode == "allreduce_bf16":            # every gradient sub-bucket travels as bf16, the losses in fp32
+        names = [e[0] for e in seqs[0]]
+        assert names.count("allreduce_sum") == 4 and names.count("allreduce_sum_bf16") >= 4 * 4
     for r in out:
         # after steps 0..3 and the staging of batch 4: plan 0 holds batch 4 % 3 = 1, plan 1 holds batch 3 % 3 = 0
         assert np.array_equal(r["x"][0], r["pool_x"][1]) and np.array_equal(r["x"][1], r["pool_x"][0])

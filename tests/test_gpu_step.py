@@ -294,6 +294,40 @@ def test_data_parallel_code_path_with_one_rank(dev, mode):
             cdev.close()
 
 
+@pytest.mark.parametrize("issue", [False, "recorded"])
+def test_bf16_exchange_buffer_with_one_rank(dev, issue):
+    """exchange_mode='allreduce_bf16' (opt-in, reduced precision: every gradient sub-bucket rounded to bf16 for the trip, summed
+    by RCCL in bf16, widened back) on a world-1 communicator: ncclAllReduce on ncclBfloat16 runs -- eager and replayed inside
+    ghm_step_run --, the losses stay fp32 and bit-identical, and what reaches the optimiser is the gradient rounded to bf16
+    (nearest even): every element within 2^-8 of the single-process step's, most of them changed."""
+    from gan_heightmaps_amd import device, dist
+    cfg = ostep.default_cfg(**SMALL)
+    batches = [ostep.synthetic_batch(4, cfg, seed=60 + i) for i in range(3)]
+    ref_model = build_model(cfg, 7, dev, use_graph=issue)
+    cdev = device.Device(dev.index)
+    comm = dist.Comm(cdev, 0, 1)
+    try:
+        m = build_model(cfg, 7, dev, comm=comm, force_exchange=True, use_graph=issue, exchange_mode='allreduce_bf16',
+                        bucket_mb=2048.0 / 2 ** 20)
+        assert m.engine.exchange_mode == 'allreduce_bf16' and not m.engine.sharded
+        for it, b_ in enumerate(batches):
+            from gan_heightmaps_amd import layers as L
+            for a_, h_, _ in NETS:          # same parameters on both sides before every step (the updates differ by the rounding)
+                L.set_all_param_values(getattr(m, a_)[h_], L.get_all_param_values(getattr(ref_model, a_)[h_]))
+            want, got = ref_model.train_fn(*b_), m.train_fn(*b_)
+            assert want == got                                   # the losses are reduced in fp32
+            gr, gm = model_grads(ref_model), model_grads(m)
+            for key in gr:
+                fr, fm = (np.concatenate([g.ravel() for g in x[key]]) for x in (gr, gm))
+                nz = fr != 0
+                assert np.all(np.abs(fm[nz] - fr[nz]) <= np.abs(fr[nz]) * 2.0 ** -8), (it, key)
+                assert np.array_equal(fm, fm.view(np.uint32).__and__(0xffff0000).view(np.float32))     # bf16 values
+                assert (fm != fr).mean() > 0.5
+    finally:
+        comm.close()
+        cdev.close()
+
+
 @pytest.mark.parametrize("issue", [False, "recorded", True])
 @pytest.mark.parametrize("dtype", ["f32", "bf16x3"])
 def test_sharded_update_code_path_with_one_rank(dev, issue, dtype):
