@@ -7,6 +7,7 @@ O=gpurun_out/refresh
 mkdir -p $O
 export TMPDIR=/tmp
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${R}_bench.json 2> $O/${R}_bench.err          # the driver's command: headline + secondary lines
+cp gpurun_out/bench_secondary.json $O/${R}_bench_secondary.json                                     # (its side file: the later runs overwrite it)
 for dt in f32 bf16 bf16x2 f16; do
   python bench.py --steps 30 --warmup 5 --dtype $dt --no-cpu-baseline --no-secondary > $O/${R}_bench_$dt.json 2>> $O/${R}_bench.err
 done
