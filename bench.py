@@ -292,8 +292,8 @@ def measure(args, secondary_name=None):
                 eng.enqueue_train(b, wrap)
                 kstep[0] += 1
 
-    # recorded: call 0 of a plan is eager, call 1 records
-    run_steps(max(args.warmup, 2 * len(plans) if issue == 'recorded' else len(plans)))
+    # set-up steps (untimed, not the warm-up): call 0 of a plan is eager (library workspaces take their size), call 1 records
+    run_steps(2 * len(plans) if issue == 'recorded' else len(plans))
     eng.sync()
 
     # ---- pick the dominant kernel from one instrumented (untimed) step ----
@@ -400,6 +400,12 @@ def measure(args, secondary_name=None):
     else:
         inst_steps = min(args.steps, 4000 // max(launches_per_step + 24 * (world > 1), 1)) if dominant else 0
 
+    # ---- the W untimed warm-up steps, immediately in front of the timed region (the instrumented per-entry steps above leave
+    # the GPU idle between launches: clocks and caches are those of an idle chip behind them) ----
+    for _ in range(args.warmup):
+        if issue is not False:
+            runs_of[cur_plan()] = runs_of.get(cur_plan(), 0) + 1       # (a replay: the recorded timer slots advance)
+        run_steps(1)
     # ---- timed region ----
     if comm is not None:
         comm.barrier()
