@@ -586,7 +586,7 @@ class GanStep:
         (range 6e-8 .. 65504 behind the 2^15 loss scale) flush per-pixel gradients that small to zero before the per-sample
         factor multiplies them back up.  fp32 / bf16 pieces have fp32's exponent range: there the error stays relative
         (tests/test_gpu_step.py::test_generator_gradient_shortcut_with_a_confident_discriminator)."""
-        if os.environ.get('GHM_NO_RANK_ONE') or dtype == 'f16':
+        if os.environ.get('GHM_NO_RANK_ONE') or (dtype == 'f16' and not os.environ.get('GHM_RANK_ONE_F16')):      # (GHM_RANK_ONE_F16=1: measurement only)
             return None
         if int(np.prod(plan.out.shape[1:])) != 1 or any(n.op == 'bn' for n in plan.order):
             return None
