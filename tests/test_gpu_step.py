@@ -687,6 +687,11 @@ def test_bilinear_decoder_on_the_coarse_grid(dev, monkeypatch, dtype):
         for key in ostep.NET_ORDER:
             state['params'][key[0]][key[1]] = [v.copy() for v in mp[key]]
             L.set_all_param_values(getattr(lit, key[0])[key[1]], mp[key])
+    # the forward-only entry points (pix2pix.py:144-147) through the same lowering: batch statistics and running statistics
+    X = ostep.synthetic_batch(B, cfg, seed=510)[1]
+    for fn in ("gen_fn", "gen_fn_det"):
+        ya, yl = getattr(a, fn)(X), getattr(lit, fn)(X)
+        assert ya.shape == (B, 3, 128, 128) and rel(ya, yl) < (1e-5 if dtype == "bf16x3" else 1e-3), (fn, rel(ya, yl))
 
 
 def test_patchgan_chain_without_fp32_activations(dev, monkeypatch):
