@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void bl_lines_kernel(const float* __restrict__
 __device__ __forceinline__ f32x16 bl_mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ void bl_reduce_store(f32x16 acc, float* dst, long row_stride, long col_stride, float* smem, int rows_ok,
-                                                int cols_ok) {
+                                                int cols_ok, bool accumulate = false) {
     // dst[i * row_stride + j * col_stride] = sum over the four waves; lane: j = lane & 31, rows (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, kg = lane >> 5;
@@ -100,7 +100,10 @@ __device__ __forceinline__ void bl_reduce_store(f32x16 acc, float* dst, long row
     for (int o = tid; o < 1024; o += 256) {
         const int i = o >> 5, jj = o & 31;
         const float v = ((smem[i * 33 + jj] + smem[(32 + i) * 33 + jj]) + smem[(64 + i) * 33 + jj]) + smem[(96 + i) * 33 + jj];
-        if (i < rows_ok && jj < cols_ok) dst[(long)i * row_stride + (long)jj * col_stride] = v;
+        if (i < rows_ok && jj < cols_ok) {
+            float* const q = dst + (long)i * row_stride + (long)jj * col_stride;
+            *q = accumulate ? *q + v : v;
+        }
     }
 }
 
@@ -149,8 +152,9 @@ __global__ __launch_bounds__(256) void bl_wt_kernel(const float* __restrict__ wp
     wT[idx] = wp[((long)c * 9 + tap) * K + k];
 }
 
+// (``wp_direct``: wT is the packed layout wp[c][tap][k] itself -- no transposed copy; each lane then walks its own cache lines)
 __global__ __launch_bounds__(256) void bl_gemm_dgrad_kernel(const float* __restrict__ wT, const float* __restrict__ DYL, BlGeo g,
-                                                            int splits, float* __restrict__ dFL) {
+                                                            int splits, float* __restrict__ dFL, int wp_direct) {
     __shared__ float smem[4 * 32 * 33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kg = lane >> 5;
     int z = blockIdx.z;
@@ -170,13 +174,14 @@ __global__ __launch_bounds__(256) void bl_gemm_dgrad_kernel(const float* __restr
         const int job = job_lo + jj;
         const float* dy = DYL + (((long)job * g.N + n) * g.K) * LD + ai + 2;
         const long KC = (long)g.K * g.C;
-        const float* w0 = wT + bl_job_tap(job, 0) * KC + c;
-        const float* w1 = wT + bl_job_tap(job, 1) * KC + c;
-        const float* w2 = wT + bl_job_tap(job, 2) * KC + c;
+        const long ks = wp_direct ? 1 : g.C;                 // stride of k in the weight operand
+        const float* w0 = wp_direct ? wT + ((long)c * 9 + bl_job_tap(job, 0)) * g.K : wT + bl_job_tap(job, 0) * KC + c;
+        const float* w1 = wp_direct ? wT + ((long)c * 9 + bl_job_tap(job, 1)) * g.K : wT + bl_job_tap(job, 1) * KC + c;
+        const float* w2 = wp_direct ? wT + ((long)c * 9 + bl_job_tap(job, 2)) * g.K : wT + bl_job_tap(job, 2) * KC + c;
 #pragma unroll 4
         for (int k0 = k_lo + 2 * wave; k0 < k_hi; k0 += 8) {
             const int k = k0 + kg;
-            const float a0 = w0[(long)k * g.C], a1 = w1[(long)k * g.C], a2 = w2[(long)k * g.C];
+            const float a0 = w0[k * ks], a1 = w1[k * ks], a2 = w2[k * ks];
             const float* d = dy + (long)k * LD;
             const float b0 = d[0], b1 = d[-1], b2 = d[-2];
             acc = bl_mfma(a0, b0, acc);
@@ -191,8 +196,9 @@ __global__ __launch_bounds__(256) void bl_gemm_dgrad_kernel(const float* __restr
 // weight gradient: dWp[split][tap (A, B)][c][k] = sum over n of
 //     sum_pos DYL[rowjob(A)][n][k][pos] * FL[n][rowline(A)][c][pos + B]  +  sum_pos DYL[coljob(B)][n][k][pos] * FL[n][colline(B)][c][pos + A]
 // grid (K / 32, C / 32, splits * 9); the split deals the samples x position pairs
+// (``direct`` != null, one split: the tile is added straight into the fine packed weight gradient dwp[c][tap][k])
 __global__ __launch_bounds__(256) void bl_gemm_wgrad_kernel(const float* __restrict__ DYLt, const float* __restrict__ FLt, BlGeo g,
-                                                            int splits, float* __restrict__ dWp) {
+                                                            int splits, float* __restrict__ dWp, float* __restrict__ direct) {
     __shared__ float smem[4 * 32 * 33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kg = lane >> 5;
     const int tap = blockIdx.z % 9, sp = blockIdx.z / 9;
@@ -216,7 +222,11 @@ __global__ __launch_bounds__(256) void bl_gemm_wgrad_kernel(const float* __restr
                 acc = bl_mfma(ap[(long)(2 * pp) * g.K], bp[(long)(2 * pp) * g.C], acc);
         }
     }
-    // D[i = k][j = c] -> dWp[split][tap][c][k]
+    // D[i = k][j = c] -> dWp[split][tap][c][k], or += into dwp[c][tap][k]
+    if (direct) {
+        bl_reduce_store(acc, direct + ((long)(blockIdx.y * 32) * 9 + tap) * g.K + blockIdx.x * 32, 1, (long)9 * g.K, smem, 32, 32, true);
+        return;
+    }
     float* dst = dWp + (((long)sp * 9 + tap) * g.C + blockIdx.y * 32) * g.K + blockIdx.x * 32;
     bl_reduce_store(acc, dst, 1, g.K, smem, 32, 32);
 }
@@ -416,11 +426,14 @@ int ghm_blconv_frame_dgrad(ghm_ctx* ctx, const float* DYL, const float* wp, floa
     const size_t part_bytes = (size_t)splits * N * 4 * C * g.LP * 4;
     if (ghm_scratch(ctx, part_bytes + (size_t)9 * K * C * 4, &ws)) return -1;
     float* const wT = (float*)((char*)ws + part_bytes);      // wT[tap][k][c]: the GEMM's lanes run along c
-    hipLaunchKernelGGL(bl_wt_kernel, dim3(ceil_div((long)9 * K * C, 256)), dim3(256), 0, ctx->stream, wp, C, K, wT);
-    GHM_LAUNCH_CHECK();
+    const int direct = GHM_OPT("GHM_BLCONV_NO_WT") ? 1 : 0;  // (tuning: read the packed weights as they lie, no transposed copy)
+    if (!direct) {
+        hipLaunchKernelGGL(bl_wt_kernel, dim3(ceil_div((long)9 * K * C, 256)), dim3(256), 0, ctx->stream, wp, C, K, wT);
+        GHM_LAUNCH_CHECK();
+    }
     // (the fold reads array indices <= 2 n + 1 only: position tiles beyond ``used`` are neither written nor read)
-    hipLaunchKernelGGL(bl_gemm_dgrad_kernel, dim3(C / 32, used, splits * 4 * N), dim3(256), 0, ctx->stream, (const float*)wT, DYL, g, splits,
-                       (float*)ws);
+    hipLaunchKernelGGL(bl_gemm_dgrad_kernel, dim3(C / 32, used, splits * 4 * N), dim3(256), 0, ctx->stream,
+                       direct ? wp : (const float*)wT, DYL, g, splits, (float*)ws, direct);
     GHM_LAUNCH_CHECK();
     const long nb = (long)(n1 >= 2 ? 2 : 1) * n2 + (long)(n2 >= 2 ? 2 : 1) * (n1 > 2 ? n1 - 2 : 0);
     hipLaunchKernelGGL(bl_fold_kernel, dim3(ceil_div((long)N * C * nb, 256)), dim3(256), 0, ctx->stream, (const float*)ws, g, splits, dx,
@@ -437,10 +450,16 @@ int ghm_blconv_frame_wgrad(ghm_ctx* ctx, const float* DYL, const float* FL, floa
     const int npmin = n1 < n2 ? n1 : n2;                    // position pairs per (part, n): every split must own some of them
     int splits = bl_splits((long)2 * N * (n1 + n2), (long)(K / 32) * (C / 32) * 9, ctx->num_cu);
     if (splits > npmin / 4) splits = npmin / 4 > 0 ? npmin / 4 : 1;
+    if (splits == 1) {          // enough tiles to fill the chip: one launch, the tiles added straight into dwp
+        hipLaunchKernelGGL(bl_gemm_wgrad_kernel, dim3(K / 32, C / 32, 9), dim3(256), 0, ctx->stream,
+                           DYL + (long)6 * N * K * (g.LP + 32), FL + ((long)N * 4 * C * g.LP + 64), g, 1, (float*)nullptr, dwp);
+        GHM_LAUNCH_CHECK();
+        return 0;
+    }
     void* ws;
     if (ghm_scratch(ctx, (size_t)splits * 9 * C * K * 4, &ws)) return -1;
     hipLaunchKernelGGL(bl_gemm_wgrad_kernel, dim3(K / 32, C / 32, splits * 9), dim3(256), 0, ctx->stream,
-                       DYL + (long)6 * N * K * (g.LP + 32), FL + ((long)N * 4 * C * g.LP + 64), g, splits, (float*)ws);
+                       DYL + (long)6 * N * K * (g.LP + 32), FL + ((long)N * 4 * C * g.LP + 64), g, splits, (float*)ws, (float*)nullptr);
     GHM_LAUNCH_CHECK();
     hipLaunchKernelGGL(bl_wgrad_add_kernel, dim3(ceil_div((long)C * 9 * K, 256)), dim3(256), 0, ctx->stream, (const float*)ws, C, K, splits,
                        dwp);
