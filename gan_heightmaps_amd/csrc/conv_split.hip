@@ -873,8 +873,25 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
         auto rows = [&](auto T0_, auto ACT_) {
             constexpr int T0 = decltype(T0_)::value;
             constexpr bool ACT = decltype(ACT_)::value != 0;
+            // (LA = 2: the operands of row i + 1 landed a whole row ago, so its FIRST fragments are read under row i's last MFMAs --
+            // with one row of lookahead every row starts with an exposed LDS round trip)
+            SpTrFrag af[2][KS], bf[2][NP];
+            auto read_x = [&](unsigned xr, int ks, int p, int slot) {
+#pragma unroll
+                for (int fb = T0; fb < KS; ++fb) {
+                    const int par = ST == 2 ? (fb & 1) : 0;
+                    const int shift = ST == 2 ? (fb >> 1) : fb;
+                    sp_tr_issue(af[slot][fb], xr + p * ROWB + par * PLB + (ks * 16 + shift) * 64);
+                }
+            };
+            auto read_dy = [&](unsigned yb, int ks, int slot) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) sp_tr_issue(bf[slot][q], yb + q * YB + ks * 1024);
+            };
+            auto xr_of = [&](int i) { return xl0 + (((i * ST + wr - PADK + NR) % NR) * NP) * ROWB; };
+            auto yb_of = [&](int i) { return yl0 + ((i - i_begin) % NYB) * NP * YB; };
+            constexpr bool CARRY = LA == 2 && ((KSTEPS * NP) % 2 == 0) && (KSTEPS % 2 == 0);     // slot parities line up across rows
             for (int i = i_begin; i < i_end; ++i) {
-                const int buf = (i - i_begin) % NYB;
                 const bool ahead = i + LA < i_end;
                 if (ahead) {
 #pragma unroll
@@ -882,23 +899,11 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
                     stage_dy(i + LA, (i + LA - i_begin) % NYB);
                 }
                 if constexpr (ACT) {
-                    const unsigned xr = xl0 + (((i * ST + wr - PADK + NR) % NR) * NP) * ROWB;
-                    const unsigned yb = yl0 + buf * NP * YB;
-                    SpTrFrag af[2][KS], bf[2][NP];
-                    auto read_x = [&](int ks, int p, int slot) {
-#pragma unroll
-                        for (int fb = T0; fb < KS; ++fb) {
-                            const int par = ST == 2 ? (fb & 1) : 0;
-                            const int shift = ST == 2 ? (fb >> 1) : fb;
-                            sp_tr_issue(af[slot][fb], xr + p * ROWB + par * PLB + (ks * 16 + shift) * 64);
-                        }
-                    };
-                    auto read_dy = [&](int ks, int slot) {
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) sp_tr_issue(bf[slot][q], yb + q * YB + ks * 1024);
-                    };
-                    read_dy(0, 0);
-                    read_x(0, NP - 1, 0);
+                    const unsigned xr = xr_of(i), yb = yb_of(i);
+                    if (!CARRY || i == i_begin) {
+                        read_dy(yb, 0, 0);
+                        read_x(xr, 0, NP - 1, 0);
+                    }
 #pragma unroll
                     for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
@@ -913,24 +918,44 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
                             if (pi == 0) sp_tr_wait(bf[ks & 1]);
                             // ... the next phase's are requested behind them
                             if (pi + 1 < NP) {
-                                read_x(ks, p - 1, (ph + 1) & 1);
+                                read_x(xr, ks, p - 1, (ph + 1) & 1);
                             } else if (ks + 1 < KSTEPS) {
-                                read_dy(ks + 1, (ks + 1) & 1);
-                                read_x(ks + 1, NP - 1, (ph + 1) & 1);
+                                read_dy(yb, ks + 1, (ks + 1) & 1);
+                                read_x(xr, ks + 1, NP - 1, (ph + 1) & 1);
+                            } else if (CARRY && i + 1 < i_end) {        // the next row's first fragments
+                                read_dy(yb_of(i + 1), 0, 0);
+                                read_x(xr_of(i + 1), 0, NP - 1, 0);
                             }
 #pragma unroll
                             for (int q = 0; q <= NP - 1 - p; ++q)
 #pragma unroll
                                 for (int t = T0; t < KS; ++t) acc[t] = sp_mfma(sp_tr_bits(af[ph & 1][t]), sp_tr_bits(bf[ks & 1][q]), acc[t]);
                             __builtin_amdgcn_sched_barrier(0);
+                            if (CARRY && ph == KSTEPS * NP - 2) {
+                                // the row's barrier, one phase early: every LDS read of row i has been issued (the last phase's
+                                // fragments are in registers behind lgkmcnt(0)) and row i + 1 has landed for every wave -- behind it
+                                // the last phase's MFMAs run while row i + 1's first fragments are read
+                                if (ahead)
+                                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ST * NX + NY) : "memory");
+                                else
+                                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                            }
                         }
                     }
                 }
                 // row i + 1 has landed (LA = 2: what this row requested, row i + 2, may stay in flight); everybody is done with row i
-                if (LA == 2 && ahead)
+                if (CARRY) {
+                    if constexpr (!ACT) {           // (a wave that only stages meets the same barrier)
+                        if (ahead)
+                            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(ST * NX + NY) : "memory");
+                        else
+                            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                    }
+                } else if (LA == 2 && ahead) {
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(ST * NX + NY) : "memory");
-                else
+                } else {
                     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                }
             }
         };
         if constexpr (CLS == 0) {
