@@ -719,9 +719,17 @@ struct SpWgradArgs {
     long split_stride;
     int accumulate;
     int cls_k;             // CLS form: filters per parity class (the collapsed bilinear convolution, sp_conv2_kernel)
+    int xcd;               // 1: the (channel tile, filter tile) blocks of one strip run on ONE XCD (they share its x and dy rows)
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// TUNING ONLY (results wrong): -DGHM_WGRAD_ABLATE=<bits> compiles parts of sp_wgrad_kernel's row loop out: 1 = no DMA inside the
+// loop, 2 = no fragment reads inside the loop (the first row's fragments are reused), 4 = no waits / barriers inside the loop,
+// 16 = every DMA instruction of the loop copies the (cache-resident) zero unit: the instructions and LDS writes without the memory traffic
+#ifndef GHM_WGRAD_ABLATE
+#define GHM_WGRAD_ABLATE 0
+#endif
 
 // The transposing LDS read ds_read_b64_tr_b16 as inline assembly (round 5).  The compiler orders an LDS read it cannot
 // disambiguate behind every LDS-DMA in flight: with __builtin_amdgcn_ds_read_tr16_b64_v4i16 it put ``s_waitcnt vmcnt(0)`` in front of the first fragment read of every output row
@@ -789,9 +797,21 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
     const int wrem = wave % (CHT * CT);
     const int hh = wrem / CT, ww = wrem % CT;         // this wave's channel group / filter tile
     const int kg = lane >> 5, li = lane & 31;
-    const int c0 = blockIdx.x * (32 * CHT), k0 = blockIdx.y * (32 * CT);
+    // Blocks are handed to the eight XCDs round-robin in launch order: as launched, the blocks that share a strip's x rows
+    // (same channel tile) and dy rows (same filter tile) sit on different XCDs and every L2 fetches them again.  Re-numbered
+    // so that an XCD walks whole strips: all (channel tile, filter tile) blocks of a strip behind one L2.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (a.xcd) {
+        const int gxy = gridDim.x * gridDim.y;
+        int L = sp_xcd_remap(bx + gridDim.x * by + gxy * bz, gxy * gridDim.z);
+        bz = L / gxy;
+        L -= bz * gxy;
+        by = L / gridDim.x;
+        bx = L - by * gridDim.x;
+    }
+    const int c0 = bx * (32 * CHT), k0 = by * (32 * CT);
     const int strips = a.Wo / SPX;
-    const int col = blockIdx.z / a.splits_per_col, sp = blockIdx.z - col * a.splits_per_col;
+    const int col = bz / a.splits_per_col, sp = bz - col * a.splits_per_col;
     const int n = col / strips, j0 = (col - n * strips) * SPX;
     const int i_begin = sp * a.rows_per_split, i_end = min(a.Ho, i_begin + a.rows_per_split);
     const int HWx = a.H * a.W, HWy = a.Ho * a.Wo;
@@ -815,7 +835,7 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
                 const int pp = ch * 16 + pxi;                        // pixel inside the plane
                 const int x = xs0 + (ST == 2 ? 2 * pp + par : pp);
                 const bool ok = rok && (unsigned)x < (unsigned)a.W;
-                const u32x4* src = ok ? xbase + piece * a.xq_ps + (long)(g * 4) * HWx + (long)y * a.W + x : a.zeros;
+                const u32x4* src = (ok && !(GHM_WGRAD_ABLATE & 16)) ? xbase + piece * a.xq_ps + (long)(g * 4) * HWx + (long)y * a.W + x : a.zeros;
                 if (pp < XPIX)
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xl + (slot * NP + piece) * ROWB + pl * PLB + ch * 1024), 16, 0, 0);
             } else if (LA == 2) {
@@ -830,7 +850,7 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
             if (pq < NP * CT * (SPX / 16)) {
                 const int piece = pq / (CT * (SPX / 16)), p = pq - piece * (CT * (SPX / 16));
                 const int ct = p / (SPX / 16), ch = p - ct * (SPX / 16);
-                const u32x4* src = ybase + piece * a.dyq_ps + (long)(ct * 4) * HWy + (long)i * a.Wo + j0 + ch * 16 + pxi;
+                const u32x4* src = (GHM_WGRAD_ABLATE & 16) ? a.zeros : ybase + piece * a.dyq_ps + (long)(ct * 4) * HWy + (long)i * a.Wo + j0 + ch * 16 + pxi;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Yl + (buf * NP + piece) * YB + ct * YTB + ch * 1024), 16, 0, 0);
             } else if (LA == 2) {
                 __builtin_amdgcn_global_load_lds((gptr_t)a.zeros, (lptr_t)Sl, 16, 0, 0);
@@ -893,16 +913,20 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
             constexpr bool CARRY = LA == 2 && ((KSTEPS * NP) % 2 == 0) && (KSTEPS % 2 == 0);     // slot parities line up across rows
             for (int i = i_begin; i < i_end; ++i) {
                 const bool ahead = i + LA < i_end;
-                if (ahead) {
+                if (ahead && !(GHM_WGRAD_ABLATE & 1)) {
 #pragma unroll
                     for (int r = 0; r < ST; ++r) stage_xrow((i + LA - 1) * ST - PADK + KS + r);     // the rows output row i + LA adds
                     stage_dy(i + LA, (i + LA - i_begin) % NYB);
                 }
                 if constexpr (ACT) {
                     const unsigned xr = xr_of(i), yb = yb_of(i);
-                    if (!CARRY || i == i_begin) {
+                    if ((!CARRY && !(GHM_WGRAD_ABLATE & 2)) || i == i_begin) {
                         read_dy(yb, 0, 0);
                         read_x(xr, 0, NP - 1, 0);
+                        if (GHM_WGRAD_ABLATE & 2) {
+                            read_dy(yb, 0, 1);
+                            read_x(xr, 0, NP - 1, 1);
+                        }
                     }
 #pragma unroll
                     for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -917,7 +941,8 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
                                              "+v"(af[ph & 1][2].hi));
                             if (pi == 0) sp_tr_wait(bf[ks & 1]);
                             // ... the next phase's are requested behind them
-                            if (pi + 1 < NP) {
+                            if (GHM_WGRAD_ABLATE & 2) {
+                            } else if (pi + 1 < NP) {
                                 read_x(xr, ks, p - 1, (ph + 1) & 1);
                             } else if (ks + 1 < KSTEPS) {
                                 read_dy(yb, ks + 1, (ks + 1) & 1);
@@ -951,6 +976,7 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
                         else
                             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                     }
+                } else if (GHM_WGRAD_ABLATE & 4) {
                 } else if (LA == 2 && ahead) {
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(ST * NX + NY) : "memory");
                 } else {
@@ -972,7 +998,7 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
     }
 
     // ---- epilogue: lane = filter k0 + 32 ww + li; rows = channels c0 + 32 hh + (e & 3) + 8 (e >> 2) + 4 kg ----
-    float* const ob = a.out + (long)blockIdx.z * a.split_stride;
+    float* const ob = a.out + (long)bz * a.split_stride;
     const int kcol = k0 + ww * 32 + li;
     if (kcol >= a.K) return;
 #pragma unroll
@@ -1124,6 +1150,11 @@ __device__ __forceinline__ void sp_dgrad_s2_epilogue(const SpConvArgs& a, const 
     }
 }
 
+// TUNING ONLY (results wrong): -DGHM_DGS2_ABLATE=<bits>: 1 = no weight DMA inside the loop, 2 = no patch DMA inside the loop,
+// 4 = weight fragments read once per filter row only, 8 = no waits / barriers inside the loop
+#ifndef GHM_DGS2_ABLATE
+#define GHM_DGS2_ABLATE 0
+#endif
 template <int BM, int RT, int NP>
 __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a, const SpDgradS2Extra x) {
     typedef SpProd<NP> PR;
@@ -1244,11 +1275,12 @@ __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a,
 #pragma unroll
         for (int fa = 0; fa < 3; ++fa, ++it) {
             const int wbuf = it & 1;
-            if (fa + 1 < 3)
+            if (GHM_DGS2_ABLATE & 1) {
+            } else if (fa + 1 < 3)
                 stage_weights(s, fa + 1, wbuf ^ 1);
             else if (more)
                 stage_weights(s + 1, 0, wbuf ^ 1);
-            if (fa == 0 && more) stage_patch(pbuf ^ 1);
+            if (fa == 0 && more && !(GHM_DGS2_ABLATE & 2)) stage_patch(pbuf ^ 1);
             const u32x4* Wb = Wl + wbuf * WUNITS + wlane;
             u32x4 af[2][NP][TM];
 #pragma unroll
@@ -1259,11 +1291,16 @@ __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a,
             // (ta != 1, tb != 1) from dy[i + (ta == 0)][j + (tb == 0)].  Weight fragments are read one tap ahead.
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
-                if (b + 1 < 3) {
+                if (b + 1 < 3 && !(GHM_DGS2_ABLATE & 4)) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
 #pragma unroll
                         for (int i = 0; i < TM; ++i) af[(b + 1) & 1][p][i] = Wb[p * WU1 + (b + 1) * BM + i * 32];
+                } else if (b + 1 < 3) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) af[(b + 1) & 1][p][i] = af[b & 1][p][i];
                 }
                 const int tw = 3 * fa + b;
                 const int ta = (8 - tw) / 3, tb = (8 - tw) % 3;
@@ -1283,8 +1320,10 @@ __global__ __launch_bounds__(256, 2) void sp_dgrad_s2_kernel(const SpConvArgs a,
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (!(GHM_DGS2_ABLATE & 8)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
         }
     }
     sp_dgrad_s2_epilogue<BM, WM, WN, TM, TN, NP>(a, x, acc, accc, sp_smem, tid, wm, wn, kg, li, n, r0, i0, j0, HWx);
@@ -1578,6 +1617,7 @@ int sp_launch_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const SpWPlan& v, cons
     a.zeros = (const u32x4*)ctx->zeros;
     a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.K = d->K; a.Ho = d->Ho; a.Wo = d->Wo;
     a.rows_per_split = v.rows_per_split; a.splits_per_col = v.splits_per_col;
+    a.xcd = GHM_OPT("GHM_SPLIT_WGRAD_NO_XCD") ? 0 : 1;
     const long n = (long)d->C * d->kh * d->kw * d->K;
     const int splits = v.ncols * v.splits_per_col;
     if (splits > 1) {
