@@ -612,3 +612,29 @@ def test_weight_gradient_with_two_rows_of_lookahead_is_bit_identical(gpu, pieces
             out[la2] = (a.numpy(), b.numpy())
     assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
     assert np.abs(out[True][0]).max() > 0
+
+
+@pytest.mark.parametrize("case", [(2, 64, 128, 32, 64, 3, 1), (2, 64, 128, 32, 64, 3, 2), (2, 32, 64, 16, 128, 5, 1), (3, 128, 64, 16, 32, 3, 1)])
+def test_weight_gradient_blocks_renumbered_onto_one_xcd_are_the_same_blocks(gpu, case):
+    """The (channel tile, filter tile) blocks of one strip are re-numbered so that one XCD's L2 serves all of them (round 6;
+    GHM_SPLIT_WGRAD_NO_XCD=1 launches them as numbered by the grid): a permutation of WHICH block computes which tile --
+    every tile computed once, bit-identical results, split-K partial slices included."""
+    dev, ops, D = gpu
+    N, C, K, H, W, ks, st = case
+    rng = np.random.RandomState(11)
+    Ho, Wo = (H + st - 1) // st, (W + st - 1) // st
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    g = rng.randn(N, K, Ho, Wo).astype(np.float32)
+    d = D.conv_desc(N, C, H, W, K, ks, ks, st, ks // 2)
+    xq, gq = D.QTensor.empty(dev, x.shape, 'bf16x3'), D.QTensor.empty(dev, g.shape, 'bf16x3')
+    ops.q_pack(dev.tensor(x), xq)
+    ops.q_pack(dev.tensor(g), gq)
+    ws = dev.alloc(max(ops.wgrad_lp_workspace(d), 16))
+    out = {}
+    for plain in (False, True):
+        with tuning_env(**({"GHM_SPLIT_WGRAD_NO_XCD": "1"} if plain else {})):
+            a = dev.zeros((1, C * ks * ks * K, 1, 1))
+            ops.conv2d_wgrad_lp_q(d, xq, gq, a, ws, 'bf16x3')
+            out[plain] = a.numpy()
+    assert np.array_equal(out[False], out[True])
+    assert np.abs(out[True]).max() > 0
