@@ -757,6 +757,34 @@ __device__ __forceinline__ void sp_tr_wait(SpTrFrag (&f)[N]) {
                      "+v"(f[3].lo), "+v"(f[3].hi), "+v"(f[4].lo), "+v"(f[4].hi));
 }
 
+// The KS tap fragments of an x row are windows of ONE 12-pixel span shifted by a pixel each (stride 1: a lane's 8 pixels start
+// at tap t): the span is read once (three transposing reads instead of 2 KS) and the windows are cut from its registers -- even
+// taps are register pairs as they lie, odd taps one v_alignbit per register.  Same operand bits, same MFMA order.
+#ifndef GHM_WGRAD_SPAN
+#define GHM_WGRAD_SPAN 1
+#endif
+struct SpTrSpan {
+    sp_u64 s0, s1, s2;
+};
+__device__ __forceinline__ void sp_span_issue(SpTrSpan& f, unsigned lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %3\n\tds_read_b64_tr_b16 %1, %3 offset:256\n\tds_read_b64_tr_b16 %2, %3 offset:512"
+                 : "=&v"(f.s0), "=&v"(f.s1), "=&v"(f.s2)
+                 : "v"(lds_addr));
+}
+__device__ __forceinline__ void sp_span_wait(SpTrSpan& f) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.s0), "+v"(f.s1), "+v"(f.s2)); }
+template <int T>
+__device__ __forceinline__ u32x4 sp_span_tap(const SpTrSpan& f) {
+    static_assert(T >= 0 && T <= 4, "taps 0 .. 4 of a 12-pixel span");
+    const unsigned v[6] = {(unsigned)f.s0, (unsigned)(f.s0 >> 32), (unsigned)f.s1, (unsigned)(f.s1 >> 32), (unsigned)f.s2, (unsigned)(f.s2 >> 32)};
+    if constexpr (T % 2 == 0) {
+        return u32x4{v[T / 2], v[T / 2 + 1], v[T / 2 + 2], v[T / 2 + 3]};
+    } else {
+        constexpr int b = (T - 1) / 2;
+        return u32x4{__builtin_amdgcn_alignbit(v[b + 1], v[b], 16), __builtin_amdgcn_alignbit(v[b + 2], v[b + 1], 16),
+                     __builtin_amdgcn_alignbit(v[b + 3], v[b + 2], 16), __builtin_amdgcn_alignbit(v[b + 4], v[b + 3], 16)};
+    }
+}
+
 // CLS = 1 (3x3 stride 1): the filters are 4 parity classes of a.cls_k (class (p, q) of the collapsed bilinear convolution has no
 // taps in filter row 0 when p = 1, none in filter column 0 when q = 1): a block's filter tile lies in ONE class; the waves of a
 // structurally-zero filter row only help staging, and every wave skips the zero column -- fragment reads and MFMAs.  The
@@ -895,14 +923,27 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
             constexpr bool ACT = decltype(ACT_)::value != 0;
             // (LA = 2: the operands of row i + 1 landed a whole row ago, so its FIRST fragments are read under row i's last MFMAs --
             // with one row of lookahead every row starts with an exposed LDS round trip)
-            SpTrFrag af[2][KS], bf[2][NP];
+            constexpr bool SPAN = GHM_WGRAD_SPAN && ST == 1;
+            SpTrFrag af[2][SPAN ? 1 : KS], bf[2][NP];
+            SpTrSpan as[2];
             auto read_x = [&](unsigned xr, int ks, int p, int slot) {
+                if constexpr (SPAN) {
+                    sp_span_issue(as[slot], xr + p * ROWB + (ks * 16) * 64);
+                } else {
 #pragma unroll
-                for (int fb = T0; fb < KS; ++fb) {
-                    const int par = ST == 2 ? (fb & 1) : 0;
-                    const int shift = ST == 2 ? (fb >> 1) : fb;
-                    sp_tr_issue(af[slot][fb], xr + p * ROWB + par * PLB + (ks * 16 + shift) * 64);
+                    for (int fb = T0; fb < KS; ++fb) {
+                        const int par = ST == 2 ? (fb & 1) : 0;
+                        const int shift = ST == 2 ? (fb >> 1) : fb;
+                        sp_tr_issue(af[slot][fb], xr + p * ROWB + par * PLB + (ks * 16 + shift) * 64);
+                    }
                 }
+            };
+            auto x_tap = [&](int slot, auto t_) -> u32x4 {
+                constexpr int t = decltype(t_)::value;
+                if constexpr (SPAN)
+                    return sp_span_tap<t>(as[slot]);
+                else
+                    return sp_tr_bits(af[slot][t]);
             };
             auto read_dy = [&](unsigned yb, int ks, int slot) {
 #pragma unroll
@@ -934,7 +975,9 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
                         for (int pi = 0; pi < NP; ++pi) {
                             const int p = NP - 1 - pi, ph = ks * NP + pi;
                             // this phase's fragments have arrived (requested one phase ago) ...
-                            if constexpr (T0 == 0)
+                            if constexpr (SPAN)
+                                sp_span_wait(as[ph & 1]);
+                            else if constexpr (T0 == 0)
                                 sp_tr_wait(af[ph & 1]);
                             else
                                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[ph & 1][1].lo), "+v"(af[ph & 1][1].hi), "+v"(af[ph & 1][2].lo),
@@ -951,10 +994,20 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
                                 read_dy(yb_of(i + 1), 0, 0);
                                 read_x(xr_of(i + 1), 0, NP - 1, 0);
                             }
+                            {
+                                u32x4 xt[KS];
+                                if constexpr (T0 == 0) xt[0] = x_tap(ph & 1, SpIC<0>{});
+                                xt[1] = x_tap(ph & 1, SpIC<1>{});
+                                xt[2] = x_tap(ph & 1, SpIC<2>{});
+                                if constexpr (KS == 5) {
+                                    xt[3] = x_tap(ph & 1, SpIC<3>{});
+                                    xt[4] = x_tap(ph & 1, SpIC<4>{});
+                                }
 #pragma unroll
-                            for (int q = 0; q <= NP - 1 - p; ++q)
+                                for (int q = 0; q <= NP - 1 - p; ++q)
 #pragma unroll
-                                for (int t = T0; t < KS; ++t) acc[t] = sp_mfma(sp_tr_bits(af[ph & 1][t]), sp_tr_bits(bf[ks & 1][q]), acc[t]);
+                                    for (int t = T0; t < KS; ++t) acc[t] = sp_mfma(xt[t], sp_tr_bits(bf[ks & 1][q]), acc[t]);
+                            }
                             __builtin_amdgcn_sched_barrier(0);
                             if (CARRY && ph == KSTEPS * NP - 2) {
                                 // the row's barrier, one phase early: every LDS read of row i has been issued (the last phase's
