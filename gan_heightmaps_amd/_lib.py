@@ -108,6 +108,8 @@ SIGNATURES = {
     "ghm_conv2d_dgrad_dact_split_q": [_p, _D, _p, _i64, _i64, _p, _p, _p, _i64, _p, _i64, _i32, _f, _i32],
     "ghm_conv2d_wgrad_split_workspace": [_D, _p],
     "ghm_conv2d_wgrad_split": [_p, _D, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i32, _i32],
+    "ghm_conv2d_wgrad_pooled_split": [_p, _D, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _i32, _i32],
+    "ghm_maxpool2_mask_bwd_compress_q": [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f, _p, _i64, _p, _p, _i32],
     "ghm_conv2d_fwd_pool_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _i32, _f, _i32],
     "ghm_conv2d_fwd_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i32, _f, _i32, _i32],
     "ghm_conv2d_dgrad_split": [_p, _D, _p, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i32, _f, _i32, _i32],
@@ -186,6 +188,7 @@ _SPECIAL = {"ghm_last_error": ([], C.c_char_p), "ghm_bn_workspace": ([_i32], C.c
             "ghm_conv_bn_fused_supported_f32": ([_D], C.c_int),
             "ghm_lp_wgrad_q_supported": ([_D, _i32], C.c_int),
             "ghm_split_supported": ([_D, _i32], C.c_int),
+            "ghm_conv2d_wgrad_pooled_split_supported": ([_D], C.c_int),
             "ghm_split_pool_supported": ([_D, _i32], C.c_int),
             "ghm_split_q_direct": ([_D, _i32], C.c_int),
             "ghm_split_dgrad_dact_supported": ([_D], C.c_int)}

@@ -90,7 +90,7 @@ def kernel_resources():
 # 104-MFMA pixel group; the 128-filter data-gradient class form (conv_split.hip CLS = 2) keeps 32 bytes outside its slab loop
 BENIGN_SCRATCH = {"sp_conv2_kernelILi3ELi1ELi128ELi8ELi1ELi4E": 24, "sp_conv2_kernelILi3ELi1ELi128ELi8ELi2ELi4E": 24,
                   "sp_conv2_kernelILi3ELi1ELi128ELi8ELi2ELi4ELb0ELi32ELi3ELi0ELi2E": 32, "sp_conv2_kernelILi3ELi1ELi128ELi8ELi2ELi4ELb0ELi32ELi2ELi0ELi2E": 32, "fanout_kernelILi18ELi2ELi4ELb0ELb0": 52, "fanout_kernelILi13ELi2ELi2ELb0ELb1": 96,
-                  "fanout_kernelILi18ELi2ELi2ELb0ELb1": 160}
+                  "fanout_kernelILi18ELi2ELi2ELb0ELb1": 160, "sp_wgrad_pooled_kernelILi64ELi3E": 36}
 
 
 def check_no_spills():

@@ -720,6 +720,11 @@ struct SpWgradArgs {
     int accumulate;
     int cls_k;             // CLS form: filters per parity class (the collapsed bilinear convolution, sp_conv2_kernel)
     int xcd;               // 1: the (channel tile, filter tile) blocks of one strip run on ONE XCD (they share its x and dy rows)
+    // sp_wgrad_pooled_kernel: dy in the sparse-instruction operand form (ghm_maxpool2_mask_bwd_compress_q)
+    const u32x4* cq;       // [piece][N][K/8][Ho][Wo/2] half-width rows
+    long cq_ns, cq_ps;
+    const u32x4* cidx;     // [N][K/8][Ho][Wo/32] units of 8 x u16 column bits
+    const int* cflags;     // [N * Ho]: the row has a tied window row -> take it from the dense dyq
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -1069,6 +1074,296 @@ __global__ __launch_bounds__(CHT * CT * KS * 64, 1) void sp_wgrad_kernel(const S
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 5x5 weight gradient of a conv -> LeakyRectify -> MaxPool2D(2) layer (DCGAN discriminator, architectures/dcgan.py:42-60) on the
+// SPARSE matrix instruction.  The gradient of the conv's output is the max-pool backward of the pooled gradient: one non-zero
+// per window row at most (ties aside), i.e. two values in any four consecutive pixels of a row -- v_smfmac_f32_32x32x32_bf16's
+// 2:4 operand with the PIXELS as contraction index, 32 pixels per instruction at the dense instruction's issue cost
+// (tools/smfmac_probe.hip, profiles/r06_smfmac_probe.txt).  A = dy (rows = filters): a lane's 8 compressed values are half-pixels
+// 4 kg .. + 3 and 8 + 4 kg .. + 3 of a 16-half-pixel chunk, two transposing reads of the half-width row cq; its index word puts
+// value j of a group at pixel 2 j + (column bit).  B = x (columns = channels): a lane's 16 pixels 16 kg .. + 15 shifted by the
+// tap, cut from one 20-pixel span (five transposing reads).  The three pieces of a value share the pattern: the same six
+// products as the dense kernel, in its order.  A row with a tied window row (cflags) is taken from the dense q tensor with the
+// dense instruction in the same operand roles, into the same accumulators.  Block = 32 channels x 64 filters, 10 waves
+// (5 filter rows x 2 filter tiles), staging and split-K as sp_wgrad_kernel<5, 1, 1, 2, SPX, NP>.
+// ------------------------------------------------------------------------------------------------
+struct SpTrSpan5 {
+    sp_u64 s0, s1, s2, s3, s4;
+};
+__device__ __forceinline__ void sp_span5_issue(SpTrSpan5& f, unsigned lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %5\n\tds_read_b64_tr_b16 %1, %5 offset:256\n\tds_read_b64_tr_b16 %2, %5 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %3, %5 offset:768\n\tds_read_b64_tr_b16 %4, %5 offset:1024"
+                 : "=&v"(f.s0), "=&v"(f.s1), "=&v"(f.s2), "=&v"(f.s3), "=&v"(f.s4)
+                 : "v"(lds_addr));
+}
+__device__ __forceinline__ void sp_span5_wait(SpTrSpan5& f) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.s0), "+v"(f.s1), "+v"(f.s2), "+v"(f.s3), "+v"(f.s4));
+}
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x16 __attribute__((ext_vector_type(16)));
+template <int T>
+__device__ __forceinline__ u32x8 sp_span5_tap(const SpTrSpan5& f) {
+    static_assert(T >= 0 && T <= 4, "taps 0 .. 4 of a 20-pixel span");
+    const unsigned v[10] = {(unsigned)f.s0, (unsigned)(f.s0 >> 32), (unsigned)f.s1, (unsigned)(f.s1 >> 32), (unsigned)f.s2,
+                            (unsigned)(f.s2 >> 32), (unsigned)f.s3, (unsigned)(f.s3 >> 32), (unsigned)f.s4, (unsigned)(f.s4 >> 32)};
+    u32x8 r;
+    if constexpr (T % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = v[T / 2 + j];
+    } else {
+        constexpr int b = (T - 1) / 2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = __builtin_amdgcn_alignbit(v[b + 1 + j], v[b + j], 16);
+    }
+    return r;
+}
+__device__ __forceinline__ f32x16 sp_smfmac(u32x4 a, u32x8 b, f32x16 c, int idx) {
+    return __builtin_amdgcn_smfmac_f32_32x32x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x16, b), c, idx, 0, 0);
+}
+
+template <int SPX, int NP>
+__global__ __launch_bounds__(640, 1) void sp_wgrad_pooled_kernel(const SpWgradArgs a) {
+    static_assert(SPX == 64 || SPX == 32, "strips of 64 or 32 pixels");
+    constexpr int KS = 5, T = 25, PADK = 2, CT = 2, NWAVES = CT * KS;
+    constexpr int XPIX = SPX + KS - 1, XCH = (XPIX + 15) / 16;
+    constexpr int ROWB = XCH * 16 * 64;              // bytes per ring row and piece (one 32-channel group)
+    constexpr int NR = KS + 1, NYB = 2;
+    constexpr int YTB = SPX * 64, YB = CT * YTB;      // dy buffer sized for a DENSE row; a compressed row uses half of every tile
+    constexpr int KSTEPS = SPX / 16, K2 = SPX / 32, NCH = SPX / 32;
+    constexpr int IB = 1024;                          // index words of a row: CT x 4 units x NCH chunks x 16 bytes <= 256
+    extern __shared__ __attribute__((aligned(16))) char sp_wsmem[];
+    char* const Xl = sp_wsmem;
+    char* const Yl = sp_wsmem + NR * NP * ROWB;
+    char* const Il = Yl + NYB * NP * YB;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / CT, ww = wave % CT;
+    const int kg = lane >> 5, li = lane & 31;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (a.xcd) {
+        const int gxy = gridDim.x * gridDim.y;
+        int L = sp_xcd_remap(bx + gridDim.x * by + gxy * bz, gxy * gridDim.z);
+        bz = L / gxy;
+        L -= bz * gxy;
+        by = L / gridDim.x;
+        bx = L - by * gridDim.x;
+    }
+    const int c0 = bx * 32, k0 = by * (32 * CT);
+    const int strips = a.Wo / SPX;
+    const int col = bz / a.splits_per_col, sp = bz - col * a.splits_per_col;
+    const int n = col / strips, j0 = (col - n * strips) * SPX;
+    const int i_begin = sp * a.rows_per_split, i_end = min(a.Ho, i_begin + a.rows_per_split);
+    const int HWx = a.H * a.W, HWy = a.Ho * a.Wo, HWc = a.Ho * (a.Wo / 2), Wc = a.Wo / 2, Wi = a.Wo / 32;
+    const int xs0 = j0 - PADK;
+
+    const int pxi = lane >> 2, cb4 = lane & 3;
+    const u32x4* const xbase = a.xq + (long)n * a.xq_ns + (long)(c0 / 8 + cb4) * HWx;
+    const u32x4* const ybase = a.dyq + (long)n * a.dyq_ns + (long)(k0 / 8 + cb4) * HWy;
+    const u32x4* const cbase = a.cq + (long)n * a.cq_ns + (long)(k0 / 8 + cb4) * HWc;
+    const int* const fl = a.cflags + (long)n * a.Ho;
+
+    auto stage_xrow = [&](int y) {
+        const int slot = (y + NR) % NR;
+        const bool rok = (unsigned)y < (unsigned)a.H;
+#pragma unroll
+        for (int p0 = 0; p0 < NP * XCH; p0 += NWAVES) {
+            const int pq = p0 + wave;
+            if (pq < NP * XCH) {
+                const int piece = pq / XCH, ch = pq - piece * XCH;
+                const int pp = ch * 16 + pxi;
+                const int x = xs0 + pp;
+                const bool ok = rok && (unsigned)x < (unsigned)a.W;
+                const u32x4* src = ok ? xbase + piece * a.xq_ps + (long)y * a.W + x : a.zeros;
+                if (pp < XPIX) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xl + (slot * NP + piece) * ROWB + ch * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // dy row i into buffer buf: dense (the row has a tie) or half-width + its index words
+    auto stage_dy = [&](int i, int buf, bool dense) {
+        if (dense) {
+#pragma unroll
+            for (int p0 = 0; p0 < NP * CT * (SPX / 16); p0 += NWAVES) {
+                const int pq = p0 + wave;
+                if (pq < NP * CT * (SPX / 16)) {
+                    const int piece = pq / (CT * (SPX / 16)), p = pq - piece * (CT * (SPX / 16));
+                    const int ct = p / (SPX / 16), ch = p - ct * (SPX / 16);
+                    const u32x4* src = ybase + piece * a.dyq_ps + (long)(ct * 4) * HWy + (long)i * a.Wo + j0 + ch * 16 + pxi;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Yl + (buf * NP + piece) * YB + ct * YTB + ch * 1024), 16, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int p0 = 0; p0 < NP * CT * (SPX / 32); p0 += NWAVES) {
+                const int pq = p0 + wave;
+                if (pq < NP * CT * (SPX / 32)) {
+                    const int piece = pq / (CT * (SPX / 32)), p = pq - piece * (CT * (SPX / 32));
+                    const int ct = p / (SPX / 32), ch = p - ct * (SPX / 32);
+                    const u32x4* src = cbase + piece * a.cq_ps + (long)(ct * 4) * HWc + (long)i * Wc + j0 / 2 + ch * 16 + pxi;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Yl + (buf * NP + piece) * YB + ct * YTB + ch * 1024), 16, 0, 0);
+                }
+            }
+            if (wave == NWAVES - 1 && lane < CT * 4 * NCH) {       // lane = (filter tile, 8-filter unit, chunk)
+                const int ct = lane / (4 * NCH), u = (lane / NCH) & 3, ch = lane % NCH;
+                const u32x4* src = a.cidx + (((long)n * (a.K / 8) + k0 / 8 + ct * 4 + u) * a.Ho + i) * Wi + j0 / 32 + ch;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Il + buf * IB), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[KS];
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    bool cur_dense = false;
+    if (i_begin < i_end) {
+        cur_dense = fl[i_begin] != 0;
+#pragma unroll
+        for (int fa = 0; fa < KS; ++fa) stage_xrow(i_begin + fa - PADK);
+        stage_dy(i_begin, 0, cur_dense);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int g16 = lane >> 4, lt = lane & 15;
+    const int key = lt >> 2, quad = lt & 3;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)sp_wsmem;
+    const unsigned sub = (g16 & 1) * 32 + quad * 8;
+    // dense fragments: a lane's 8 pixels 8 kg .. + 7 of a 16-pixel step; sparse: x 16 kg .. + 15 (+ tap) of a 32-pixel step,
+    // compressed dy half-pixels 4 kg .. + 3 and 8 + 4 kg .. + 3 of its 16
+    const unsigned xd0 = lds0 + (8 * kg + key) * 64 + sub, xs_0 = lds0 + (16 * kg + key) * 64 + sub;
+    const unsigned yd0 = lds0 + NR * NP * ROWB + ww * YTB + (8 * kg + key) * 64 + sub;
+    const unsigned yc0 = lds0 + NR * NP * ROWB + ww * YTB + (4 * kg + key) * 64 + sub;
+    const unsigned il0 = lds0 + NR * NP * ROWB + NYB * NP * YB + ((ww * 4 + (li >> 3)) * NCH) * 16 + (li & 7) * 2;
+
+    for (int i = i_begin; i < i_end; ++i) {
+        const bool ahead = i + 1 < i_end;
+        const bool next_dense = ahead && fl[i + 1] != 0;
+        if (ahead) {
+            stage_xrow(i + 1 - PADK + KS - 1);
+            stage_dy(i + 1, (i + 1 - i_begin) & 1, next_dense);
+        }
+        const unsigned xrow = (((i + wr - PADK + NR) % NR) * NP) * ROWB;
+        const unsigned ybuf = (((i - i_begin) & 1) * NP) * YB;
+        if (!cur_dense) {
+            // ---- sparse row: K2 steps of 32 pixels ----
+            SpTrSpan5 as[2];
+            SpTrFrag bf[2][NP];
+            unsigned iw[2];
+            auto read_dy = [&](int ks2, int slot) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512"
+                                 : "=&v"(bf[slot][q].lo), "=&v"(bf[slot][q].hi)
+                                 : "v"(yc0 + ybuf + q * YB + ks2 * 1024));
+                // (assembly like the fragment reads: a read the compiler sees waits for every LDS-DMA in flight)
+                asm volatile("ds_read_u16 %0, %1" : "=&v"(iw[slot]) : "v"(il0 + ((i - i_begin) & 1) * IB + ks2 * 16));
+            };
+            // index word of the instruction: value j of a group sits at pixel 2 j + (its column bit)
+            auto index_of = [&](unsigned w) {
+                unsigned b8 = ((w >> (4 * kg)) & 0xfu) | (((w >> (8 + 4 * kg)) & 0xfu) << 4);
+                b8 = (b8 | (b8 << 4)) & 0x0f0fu;
+                b8 = (b8 | (b8 << 2)) & 0x3333u;
+                b8 = (b8 | (b8 << 1)) & 0x5555u;
+                return (int)(0x8888u | b8);
+            };
+            auto read_x = [&](int ks2, int p, int slot) { sp_span5_issue(as[slot], xs_0 + xrow + p * ROWB + ks2 * 2048); };
+            read_dy(0, 0);
+            read_x(0, NP - 1, 0);
+#pragma unroll
+            for (int ks2 = 0; ks2 < K2; ++ks2) {
+#pragma unroll
+                for (int pi = 0; pi < NP; ++pi) {
+                    const int p = NP - 1 - pi, ph = ks2 * NP + pi;
+                    sp_span5_wait(as[ph & 1]);
+                    if (pi == 0) {
+                        sp_tr_wait(bf[ks2 & 1]);
+                        asm volatile("" : "+v"(iw[ks2 & 1]));
+                    }
+                    const int ixw = index_of(iw[ks2 & 1]);
+                    if (pi + 1 < NP) {
+                        read_x(ks2, p - 1, (ph + 1) & 1);
+                    } else if (ks2 + 1 < K2) {
+                        read_dy(ks2 + 1, (ks2 + 1) & 1);
+                        read_x(ks2 + 1, NP - 1, (ph + 1) & 1);
+                    }
+                    // tap by tap (one 8-register window of the span live at a time: the kernel sits at the 168 registers of three
+                    // waves per SIMD); the products of a tap go to ITS accumulator, in the dense kernel's order
+                    auto tap = [&](auto t_) {
+                        constexpr int t = decltype(t_)::value;
+                        const u32x8 xt = sp_span5_tap<t>(as[ph & 1]);
+#pragma unroll
+                        for (int q = 0; q <= NP - 1 - p; ++q) acc[t] = sp_smfmac(sp_tr_bits(bf[ks2 & 1][q]), xt, acc[t], ixw);
+                    };
+                    tap(SpIC<0>{}); tap(SpIC<1>{}); tap(SpIC<2>{}); tap(SpIC<3>{}); tap(SpIC<4>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            // ---- a row with a tied window row: the dense q tensor, dense instruction, same roles (A = dy, B = x) ----
+            SpTrSpan as[2];
+            SpTrFrag bf[2][NP];
+            auto read_dy = [&](int ks, int slot) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) sp_tr_issue(bf[slot][q], yd0 + ybuf + q * YB + ks * 1024);
+            };
+            auto read_x = [&](int ks, int p, int slot) { sp_span_issue(as[slot], xd0 + xrow + p * ROWB + ks * 1024); };
+            read_dy(0, 0);
+            read_x(0, NP - 1, 0);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+                for (int pi = 0; pi < NP; ++pi) {
+                    const int p = NP - 1 - pi, ph = ks * NP + pi;
+                    sp_span_wait(as[ph & 1]);
+                    if (pi == 0) sp_tr_wait(bf[ks & 1]);
+                    if (pi + 1 < NP) {
+                        read_x(ks, p - 1, (ph + 1) & 1);
+                    } else if (ks + 1 < KSTEPS) {
+                        read_dy(ks + 1, (ks + 1) & 1);
+                        read_x(ks + 1, NP - 1, (ph + 1) & 1);
+                    }
+                    u32x4 xt[KS];
+                    xt[0] = sp_span_tap<0>(as[ph & 1]);
+                    xt[1] = sp_span_tap<1>(as[ph & 1]);
+                    xt[2] = sp_span_tap<2>(as[ph & 1]);
+                    xt[3] = sp_span_tap<3>(as[ph & 1]);
+                    xt[4] = sp_span_tap<4>(as[ph & 1]);
+#pragma unroll
+                    for (int q = 0; q <= NP - 1 - p; ++q)
+#pragma unroll
+                        for (int t = 0; t < KS; ++t) acc[t] = sp_mfma(sp_tr_bits(bf[ks & 1][q]), xt[t], acc[t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        cur_dense = next_dense;
+    }
+
+    // ---- epilogue: lane = channel c0 + li; rows = filters k0 + 32 ww + (e & 3) + 8 (e >> 2) + 4 kg: four consecutive filters ----
+    float* const ob = a.out + (long)bz * a.split_stride;
+    const int c = c0 + li;
+    if (c >= a.C) return;
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int kf = k0 + ww * 32 + 8 * g + 4 * kg;
+            if (kf >= a.K) continue;
+            float4* o = reinterpret_cast<float4*>(ob + ((long)c * T + wr * KS + t) * a.K + kf);
+            float4 v = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+            if (a.accumulate) {
+                const float4 w = *o;
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            *o = v;
+        }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Data gradient of a 3x3 / stride-2 / pad-1 convolution (U-Net encoder, PatchGAN; architectures/p2p.py:20-21) from the split
@@ -1723,6 +2018,45 @@ int sp_launch_wgrad(ghm_ctx* ctx, const ghm_conv_desc* d, const SpWPlan& v, cons
     return 0;
 }
 
+// the pooled-gradient form (sp_wgrad_pooled_kernel): 5x5 stride 1, 32 channels x 64 filters, strips of 64 or 32 pixels
+bool sp_wgrad_pooled_ok(const ghm_conv_desc* d, const SpWPlan& v) {
+    return v.ok && d->kh == 5 && d->kw == 5 && d->stride == 1 && v.cht == 1 && v.ct == 2 && (v.spx == 64 || v.spx == 32) && d->Wo % 32 == 0 &&
+           d->Ho % 2 == 0 && d->K % 64 == 0 && !GHM_OPT("GHM_NO_SPARSE_WGRAD");
+}
+
+int sp_launch_wgrad_pooled(ghm_ctx* ctx, const ghm_conv_desc* d, const SpWPlan& v, const void* xq, long xq_ns, long xq_ps,
+                           const void* dyq, long dyq_ns, long dyq_ps, const void* cq, long cq_ns, long cq_ps, const void* cidx,
+                           const int* cflags, float* dwp, void* workspace, int accumulate) {
+    SpWgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xq = (const u32x4*)xq; a.xq_ns = xq_ns; a.xq_ps = xq_ps; a.dyq = (const u32x4*)dyq; a.dyq_ns = dyq_ns; a.dyq_ps = dyq_ps;
+    a.cq = (const u32x4*)cq; a.cq_ns = cq_ns; a.cq_ps = cq_ps; a.cidx = (const u32x4*)cidx; a.cflags = cflags;
+    a.zeros = (const u32x4*)ctx->zeros;
+    a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.K = d->K; a.Ho = d->Ho; a.Wo = d->Wo;
+    a.rows_per_split = v.rows_per_split; a.splits_per_col = v.splits_per_col;
+    a.xcd = GHM_OPT("GHM_SPLIT_WGRAD_NO_XCD") ? 0 : 1;
+    const long n = (long)d->C * d->kh * d->kw * d->K;
+    const int splits = v.ncols * v.splits_per_col;
+    if (splits > 1) {
+        GHM_CHECK(workspace != nullptr, "split-fp32 weight gradient needs a workspace for %d splits", splits);
+        a.out = (float*)workspace; a.split_stride = n; a.accumulate = 0;
+    } else {
+        a.out = dwp; a.split_stride = 0; a.accumulate = accumulate;
+    }
+    const dim3 grid(d->C / 32, d->K / 64, splits);
+    const size_t lds = v.lds + 2 * 1024;
+#define GHM_SPWP_CASE(SPX_, NP_)                                                                              \
+    if (v.spx == SPX_ && v.np == NP_) {                                                                       \
+        if (int e = sp_set_lds(sp_wgrad_pooled_kernel<SPX_, NP_>, lds)) return e;                             \
+        hipLaunchKernelGGL((sp_wgrad_pooled_kernel<SPX_, NP_>), grid, dim3(640), lds, ctx->stream, a);        \
+    }
+    GHM_SPWP_CASE(64, 3) GHM_SPWP_CASE(32, 3) GHM_SPWP_CASE(64, 2) GHM_SPWP_CASE(32, 2)
+#undef GHM_SPWP_CASE
+    GHM_LAUNCH_CHECK();
+    if (splits > 1) return ghm_reduce_splits(ctx, (const float*)workspace, splits, n, n, dwp, accumulate);
+    return 0;
+}
+
 // ---- 3x3 stride-2 data gradient ----
 SpPlan sp_plan_dgrad_s2(const ghm_conv_desc* d, int num_cu, int np = 3) {
     SpPlan p;
@@ -1874,6 +2208,30 @@ int ghm_conv2d_wgrad_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void* xq,
     const SpWPlan v = sp_wplan(d, ghm_plan_cus(), pieces);
     return sp_launch_wgrad(ctx, d, v, xq, (long)xq_nstride, (long)xq_pstride, dyq, (long)dyq_nstride, (long)dyq_pstride, dwp,
                            workspace, accumulate);
+}
+
+// can the weight gradient of this conv -> activation -> MaxPool2D(2) layer take the pooled gradient in the sparse-instruction
+// operand form (ghm_maxpool2_mask_bwd_compress_q)?
+int ghm_conv2d_wgrad_pooled_split_supported(const ghm_conv_desc* d) {
+    if (!d || !ghm_split_supported(d, 2)) return 0;
+    const SpWPlan v = sp_wplan(d, ghm_plan_cus());
+    return sp_wgrad_pooled_ok(d, v) ? 1 : 0;
+}
+
+// ghm_conv2d_wgrad_split for a layer whose dy is the max-pool backward of a pooled gradient: rows without a tied window row
+// are contracted on the sparse matrix instruction from cq / cidx, the others (cflags) from the dense dyq -- same products
+int ghm_conv2d_wgrad_pooled_split(ghm_ctx* ctx, const ghm_conv_desc* d, const void* xq, int64_t xq_nstride, int64_t xq_pstride,
+                                  const void* dyq, int64_t dyq_nstride, int64_t dyq_pstride, const void* cq, int64_t cq_nstride,
+                                  int64_t cq_pstride, const void* cidx, const int32_t* cflags, float* dwp, void* workspace,
+                                  int32_t accumulate, int32_t pieces) {
+    GHM_CHECK(ctx && d && xq && dyq && cq && cidx && cflags && dwp, "null argument");
+    GHM_SP_PIECES_OK(pieces);
+    GHM_CHECK((((uintptr_t)xq | (uintptr_t)dyq | (uintptr_t)cq | (uintptr_t)cidx) & 15) == 0, "ghm_conv2d_wgrad_pooled_split: 16-byte aligned tensors");
+    const SpWPlan v = sp_wplan(d, ghm_plan_cus(), pieces);
+    GHM_CHECK(ghm_split_supported(d, 2) && sp_wgrad_pooled_ok(d, v),
+              "ghm_conv2d_wgrad_pooled_split: geometry not served (ask ghm_conv2d_wgrad_pooled_split_supported)");
+    return sp_launch_wgrad_pooled(ctx, d, v, xq, (long)xq_nstride, (long)xq_pstride, dyq, (long)dyq_nstride, (long)dyq_pstride, cq,
+                                  (long)cq_nstride, (long)cq_pstride, cidx, cflags, dwp, workspace, accumulate);
 }
 
 int ghm_split_weight_bytes(const ghm_conv_desc* d, int32_t transposed, size_t* bytes, int32_t pieces) {

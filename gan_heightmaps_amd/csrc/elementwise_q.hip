@@ -471,6 +471,56 @@ __global__ __launch_bounds__(256) void maxpool2_mask_bwd_qc_kernel(const unsigne
     }
 }
 
+// The same gradient in the operand form of the SPARSE matrix instruction (round 6; sp_wgrad_pooled_kernel, conv_split.hip): the
+// max-pool backward leaves at most one non-zero per 2x2 window and row unless two columns of a window row tie, so fine row
+// 2 i + r is its HALF-WIDTH row cq[.., 2 i + r, j] = (arg-max of window (i, j) in row r ? g : 0) plus one column bit per
+// half-pixel -- two values in every four consecutive pixels, v_smfmac_f32_32x32x32_bf16's 2:4 pattern with the pixels as
+// contraction index.  idx[n][cb][y][j / 16] holds the column bits of 16 half-pixels of 8 channels (8 x u16 = one 16-byte unit).
+// A tie inside a window row (Theano sends the gradient to both columns) cannot be written this way: flags[n * H + y] is set
+// and the weight gradient takes that row from the dense q tensor.  Thread = one window, 8 channels, both rows.
+__global__ __launch_bounds__(256) void maxpool2_mask_bwd_compress_kernel(const unsigned char* __restrict__ mask, const float* __restrict__ y,
+                                                                         const float* __restrict__ dy, int N, int C8, int H, int W,
+                                                                         int act, float alpha, u32x4q* __restrict__ cq, long cqns,
+                                                                         u32x4q* __restrict__ idx, int* __restrict__ flags, int dt) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long hwp = (long)Ho * Wo;
+    const int bpp = (int)((hwp + 255) / 256);
+    const int blk = blockIdx.x % bpp;
+    const long ncb = blockIdx.x / bpp;
+    const int cb = (int)(ncb % C8), n = (int)(ncb / C8);
+    const long it = (long)blk * 256 + threadIdx.x;
+    const bool live = it < hwp;
+    const int i = live ? (int)(it / Wo) : 0, j = live ? (int)(it - (long)i * Wo) : 0;
+    float v[2][8];
+    unsigned ax[2] = {0u, 0u}, tie[2] = {0u, 0u};        // bit k = channel k
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long po = ((long)n * C8 * 8 + cb * 8 + k) * hwp + it;
+        const unsigned m = live ? mask[po] : 0u;
+        float g = live ? dy[po] : 0.f;
+        g *= y ? ghm_dact_from_out(live ? y[po] : 0.f, act, alpha) : ghm_dact_from_sign(m, act, alpha);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const unsigned b0 = (m >> (2 * r)) & 1u, b1 = (m >> (2 * r + 1)) & 1u;
+            v[r][k] = (b0 | b1) ? g : 0.f;
+            ax[r] |= (b1 & ~b0 & 1u) << k;
+            tie[r] |= (b0 & b1) << k;
+        }
+    }
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (live) q_store8(cq + (long)n * cqns + ((long)cb * H + 2 * i + r) * Wo + j, v[r], dt, (long)N * cqns);
+        unsigned w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = (unsigned)((__ballot((ax[r] >> k) & 1u) >> (lane & 48)) & 0xffffull);
+        if (live && (lane & 15) == 0)
+            idx[(((long)n * C8 + cb) * H + 2 * i + r) * (Wo / 16) + j / 16] =
+                u32x4q{w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16)};
+        if (live && tie[r]) atomicOr(flags + (long)n * H + 2 * i + r, 1);
+    }
+}
+
 // out[c] (+)= fixed-order sum of part[c][0 .. S)
 __global__ __launch_bounds__(64) void q_rows_sum_kernel(const float* __restrict__ part, int C, int S, float* __restrict__ out,
                                                         int accumulate) {
@@ -625,6 +675,22 @@ int ghm_maxpool2_mask_bwd_q(ghm_ctx* ctx, const uint8_t* mask, const float* y, c
         hipLaunchKernelGGL((maxpool2_mask_bwd_q_kernel<false>), dim3(blocks), dim3(256), 0, ctx->stream, mask, y, dy, dx, N,
                            C / 8, H, W, act, alpha, (float*)nullptr, bpp, (u32x4q*)dxq, (long)dxq_nstride, dtype);
     }
+    GHM_LAUNCH_CHECK();
+    return 0;
+}
+
+// the pooled gradient in the sparse-instruction operand form (see maxpool2_mask_bwd_compress_kernel): cq [pieces][N][C/8][H][W/2]
+// units, idx [N][C/8][H][W/32] units of 8 x u16 column bits, flags [N * H] ints (zeroed here, set where a window row ties)
+int ghm_maxpool2_mask_bwd_compress_q(ghm_ctx* ctx, const uint8_t* mask, const float* y, const float* dy, int32_t N, int32_t C, int32_t H,
+                                     int32_t W, int32_t act, float alpha, void* cq, int64_t cq_nstride, void* idx, int32_t* flags,
+                                     int32_t dtype) {
+    GHM_CHECK((dtype == 3 || dtype == 4) && cq && idx && flags && C % 8 == 0 && H % 2 == 0 && W % 32 == 0 && ((uintptr_t)cq & 15) == 0 &&
+              ((uintptr_t)idx & 15) == 0, "ghm_maxpool2_mask_bwd_compress_q: split dtypes, C %% 8 == 0, even H, W %% 32 == 0, aligned tensors");
+    if (int e = ghm_memset_zero(ctx, flags, (size_t)N * H * sizeof(int32_t))) return e;
+    const long hwp = (long)(H / 2) * (W / 2);
+    const long blocks = (long)N * (C / 8) * ceil_div(hwp, 256);
+    hipLaunchKernelGGL(maxpool2_mask_bwd_compress_kernel, dim3(blocks), dim3(256), 0, ctx->stream, mask, y, dy, N, C / 8, H, W, act, alpha,
+                       (u32x4q*)cq, (long)cq_nstride, (u32x4q*)idx, flags, dtype);
     GHM_LAUNCH_CHECK();
     return 0;
 }

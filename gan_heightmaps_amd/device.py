@@ -771,6 +771,21 @@ class Ops:
         call("ghm_maxpool2_mask_bwd_q", self.h, C.c_void_p(int(mask_ptr)), _vp(y), _vp(dy), _vp(dx), N, Cc, H, W,
              ACT_CODES[act], alpha, _vp(dbias), int(accumulate), C.c_void_p(dxq.ptr), dxq.nstride, DTYPE_CODES[dxq.dtype])
 
+    def maxpool2_mask_bwd_compress_q(self, mask_ptr, y, dy, cq, idx, flags, act, alpha):
+        """the same gradient as half-width rows + column bits (the sparse matrix instruction's operand; ghm.h); ``cq`` is a
+        QTensor of shape (N, C, H, W / 2), ``idx`` (N * C / 8 * H * W / 32 units of 16 bytes) and ``flags`` (N * H int32) raw"""
+        N, Cc, H, Wh = cq.shape
+        call("ghm_maxpool2_mask_bwd_compress_q", self.h, C.c_void_p(int(mask_ptr)), _vp(y), _vp(dy), N, Cc, H, 2 * Wh,
+             ACT_CODES[act], alpha, C.c_void_p(cq.ptr), cq.nstride, _vp(idx), _vp(flags), DTYPE_CODES[cq.dtype])
+
+    def wgrad_pooled_split_supported(self, d, dtype):
+        return dtype in SPLITS and bool(_lib.load().ghm_conv2d_wgrad_pooled_split_supported(C.byref(d)))
+
+    def conv2d_wgrad_pooled_split(self, d, xq, dyq, cq, idx, flags, dwp, ws, dtype, accumulate=False):
+        call("ghm_conv2d_wgrad_pooled_split", self.h, C.byref(d), C.c_void_p(xq.ptr), xq.nstride, xq.pstride, C.c_void_p(dyq.ptr),
+             dyq.nstride, dyq.pstride, C.c_void_p(cq.ptr), cq.nstride, cq.pstride, _vp(idx), _vp(flags), _vp(dwp), _vp(ws),
+             int(accumulate), SPLITS[dtype])
+
     def lp_wgrad_q_supported(self, d, dtype):
         if dtype in SPLITS:
             return self.split_supported(d, 2)

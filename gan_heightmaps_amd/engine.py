@@ -1048,6 +1048,7 @@ class NetPlan:
 
         hi_grads = set()        # BatchNorm nodes whose output gradient is held in the interleaved layout of their pp_to_hi reader
         gq_ready = set()        # nodes whose output-gradient q tensor was written by the kernel that produced the gradient
+        pooled_c = {}           # convpool nodes whose gradient also exists in the sparse instruction's operand form
 
         def gradq_of(n, G, pack=True):
             """q copy of the (final) output gradient G of node n: the operand of its low-precision data / weight
@@ -1149,6 +1150,17 @@ class NetPlan:
                     Gf32 = None if ((w_q or not wgrad) and (d_lp or not need_dx)) else Gf
                     prog.append(("maxpool_mask_bwd", lambda m=mptr, y=y, G=G, Gf32=Gf32, Gfq=Gfq, a=a, gb=gb_fused, aw=accumulate_wgrad:
                                  ops.maxpool2_mask_bwd_q(m, y, G, Gf32, Gfq, a.kind, a.alpha, gb, aw)))
+                    # the same gradient once more as half-width rows + column bits: the operand of the sparse matrix
+                    # instruction, for the 5x5 weight gradient (rows with a tied window row stay on the dense q copy)
+                    if wgrad and w_q and ops.wgrad_pooled_split_supported(dF, self.dtype):
+                        pc = cache.get(('pooled_c', id(n), nb))
+                        if pc is None:
+                            Kp, Hf, Wf = Gf.Cc, Gf.H, Gf.W
+                            pc = cache[('pooled_c', id(n), nb)] = (
+                                QTensor.empty(dev, (nb, Kp, Hf, Wf // 2), self.dtype),
+                                dev.alloc(nb * (Kp // 8) * Hf * (Wf // 32) * 16 + 256), dev.alloc(nb * Hf * 4 + 256))
+                        # (written by the stream that runs the weight gradient, its only reader: see conv_wgrad below)
+                        pooled_c[id(n)] = pc + (mptr, y, G, a)
                 else:
                     prog.append(("maxpool_mask_bwd", lambda m=mptr, y=y, G=G, Gf=Gf, a=a, gb=gb_fused, aw=accumulate_wgrad:
                                  ops.maxpool2_mask_bwd(m, y, G, Gf, a.kind, a.alpha, gb, aw)))
@@ -1175,7 +1187,15 @@ class NetPlan:
                     if self.side is not None:
                         wdev, wo = self.side
                         prog.append(("fork", lambda wdev=wdev: wdev.wait_for(dev), None, wdev))
-                    if Gq_w is not None:
+                    if Gq_w is not None and id(n) in pooled_c:
+                        pc = pooled_c[id(n)]
+                        prog.append(("maxpool_mask_compress", lambda pc=pc, wo=wo:
+                                     wo.maxpool2_mask_bwd_compress_q(pc[3], pc[4], pc[5], pc[0], pc[1], pc[2], pc[6].kind, pc[6].alpha),
+                                     None, wdev))
+                        prog.append(("conv_wgrad", lambda d=d, xq=xq, Gq=Gq_w, pc=pc, gw=gw, aw=aw, wo=wo:
+                                     wo.conv2d_wgrad_pooled_split(d, xq, Gq, pc[0], pc[1], pc[2], gw, self.wgrad_ws, self.dtype, aw),
+                                     sparse_meta(conv_meta(ops, d, 2, self.dtype)), wdev))
+                    elif Gq_w is not None:
                         prog.append(("conv_wgrad", lambda d=d, xq=xq, Gq=Gq_w, gw=gw, aw=aw, wo=wo:
                                      wo.conv2d_wgrad_lp_q(d, xq, Gq, gw, self.wgrad_ws, self.dtype, aw),
                                      conv_meta(ops, d, 2, self.dtype), wdev))
@@ -1533,6 +1553,16 @@ def bl_meta(meta):
     m["flops"] = meta["flops"] * 25.0 / 36.0
     m["nominal_flops"] = meta["flops"]
     m["kernel"] = meta["kernel"] + " cls"
+    return m
+
+
+def sparse_meta(meta):
+    """a weight gradient contracted on the sparse matrix instruction: the operand's structural zeros (three of four pixels of a
+    max-pool backward) are skipped in pairs -- half the multiplications of the dense count execute"""
+    m = dict(meta)
+    m["flops"] = meta["flops"] / 2.0
+    m["nominal_flops"] = meta["flops"]
+    m["kernel"] = meta["kernel"] + " 2:4"
     return m
 
 

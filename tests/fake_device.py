@@ -125,6 +125,9 @@ class RecordingOps:
         lp = (2 * max(n1, n2) + 4 + 31) // 32 * 32
         return 2 * (N * 4 * Cc * lp + 64), 2 * 6 * N * K * (lp + 32)
 
+    def wgrad_pooled_split_supported(self, d, dtype):        # (the sparse-instruction weight gradient: GPU tests only)
+        return False
+
     def __getattr__(self, name):
         def rec(*args, **kw):
             self.calls.append((name, args, kw))

@@ -638,3 +638,64 @@ def test_weight_gradient_blocks_renumbered_onto_one_xcd_are_the_same_blocks(gpu,
             out[plain] = a.numpy()
     assert np.array_equal(out[False], out[True])
     assert np.abs(out[True]).max() > 0
+
+
+@pytest.mark.parametrize("case", [(2, 32, 64, 16, 64, 'bf16x3', False), (2, 32, 64, 16, 64, 'bf16x3', True), (2, 64, 128, 32, 32, 'bf16x3', True),
+                                  (1, 32, 64, 8, 128, 'bf16x2', True), (3, 64, 64, 20, 96, 'bf16x3', True), (2, 32, 128, 64, 64, 'bf16x2', False)])
+def test_pooled_weight_gradient_on_the_sparse_matrix_instruction(gpu, case):
+    """5x5 conv -> activation -> MaxPool2D(2) (architectures/dcgan.py:42-60): the weight gradient contracts x with the max-pool
+    backward of the pooled gradient -- one non-zero per window row unless two columns tie.  ghm_maxpool2_mask_bwd_compress_q writes
+    it as half-width rows + column bits + tie flags, ghm_conv2d_wgrad_pooled_split contracts tie-free rows on
+    v_smfmac_f32_32x32x32_bf16 and flagged rows densely.  Against the dense split kernel (same products; the instruction's own
+    summation order differs) and a float64 contraction of the dense gradient; the flags against the mask."""
+    dev, ops, D = gpu
+    N, C, K, H, W, dtype, ties = case
+    rng = np.random.RandomState(sum(case[:5]))
+    Ho, Wo = H // 2, W // 2
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    gp = rng.randn(N, K, Ho, Wo).astype(np.float32)
+    mask = (1 << rng.randint(0, 4, size=(N, K, Ho, Wo))).astype(np.uint8)          # bit 2 r + c: one arg-max per window
+    if ties:        # tied window rows and whole tied windows (flat terrain) in three pooled rows
+        for (n, i) in [(0, 1), (N - 1, Ho - 1), (0, Ho // 2)]:
+            mask[n, ::3, i, ::5] = 0b0011
+            mask[n, 1::3, i, 1::7] = 0b1111
+    d = D.conv_desc(N, C, H, W, K, 5, 5, 1, 2)
+    assert ops.wgrad_pooled_split_supported(d, dtype)
+    xq = D.QTensor.empty(dev, x.shape, dtype)
+    ops.q_pack(dev.tensor(x), xq)
+    mptr = dev.alloc(mask.size)
+    dev.h2d(mptr, mask)
+    gpt = dev.tensor(gp)
+    dyq, dx = D.QTensor.empty(dev, (N, K, H, W), dtype), dev.empty((N, K, H, W))
+    ops.maxpool2_mask_bwd_q(mptr, None, gpt, dx, dyq, 'linear', 0.0)
+    cq = D.QTensor.empty(dev, (N, K, H, W // 2), dtype)
+    idx, flags = dev.alloc(N * (K // 8) * H * (W // 32) * 16 + 256), dev.alloc(N * H * 4 + 256)
+    ops.maxpool2_mask_bwd_compress_q(mptr, None, gpt, cq, idx, flags, 'linear', 0.0)
+    fl = np.zeros(N * H, np.int32)
+    dev.sync()
+    dev.d2h(fl, flags, fl.nbytes)
+    want = np.zeros((N, H), bool)
+    want[:, 0::2] = ((mask & 3) == 3).any(axis=(1, 3))
+    want[:, 1::2] = (((mask >> 2) & 3) == 3).any(axis=(1, 3))
+    assert np.array_equal(fl.reshape(N, H) != 0, want)
+    assert want.any() == ties
+    dyd = dx.numpy()
+    ws = dev.alloc(max(ops.wgrad_lp_workspace(d), 16))
+    a, b = dev.zeros((1, C * 25 * K, 1, 1)), dev.zeros((1, C * 25 * K, 1, 1))
+    ops.conv2d_wgrad_lp_q(d, xq, dyq, a, ws, dtype)
+    ops.conv2d_wgrad_pooled_split(d, xq, dyq, cq, idx, flags, b, ws, dtype)
+    A, B = a.numpy().ravel(), b.numpy().ravel()
+    xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (2, 2), (2, 2)))
+    ref = np.zeros((C, 25, K))
+    for ta in range(5):
+        for tb in range(5):
+            ref[:, ta * 5 + tb, :] = np.einsum('nchw,nkhw->ck', xp[:, :, ta:ta + H, tb:tb + W], dyd.astype(np.float64))
+    ref = ref.ravel()
+    sc = np.abs(ref).max()
+    bound = 2e-6 if dtype == 'bf16x3' else 3e-5          # the dense kernel's own distance from float64: 4e-7 / 5e-6 here
+    assert np.abs(A - ref).max() / sc < bound
+    assert np.abs(B - ref).max() / sc < bound
+    assert np.abs(A - B).max() / sc < bound
+    # accumulate into an existing gradient
+    ops.conv2d_wgrad_pooled_split(d, xq, dyq, cq, idx, flags, b, ws, dtype, accumulate=True)
+    assert np.abs(b.numpy().ravel() - 2 * B).max() / sc < 1e-6
