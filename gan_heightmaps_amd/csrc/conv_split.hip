@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(640, 1) void sp_wgrad_pooled_kernel(const SpWgradAr
     for (int i = i_begin; i < i_end; ++i) {
         const bool ahead = i + 1 < i_end;
         const bool next_dense = ahead && fl[i + 1] != 0;
-        if (ahead) {
+        if (ahead && !(GHM_WGRAD_ABLATE & 1)) {
             stage_xrow(i + 1 - PADK + KS - 1);
             stage_dy(i + 1, (i + 1 - i_begin) & 1, next_dense);
         }
@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(640, 1) void sp_wgrad_pooled_kernel(const SpWgradAr
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!(GHM_WGRAD_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         cur_dense = next_dense;
     }
 

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void maxpool2_mask_bwd_compress_kernel(const u
         if (live && (lane & 15) == 0)
             idx[(((long)n * C8 + cb) * H + 2 * i + r) * (Wo / 16) + j / 16] =
                 u32x4q{w[0] | (w[1] << 16), w[2] | (w[3] << 16), w[4] | (w[5] << 16), w[6] | (w[7] << 16)};
-        if (live && tie[r]) atomicOr(flags + (long)n * H + 2 * i + r, 1);
+        if (live && tie[r]) flags[(long)n * H + 2 * i + r] = 1;      // (every writer stores the same value: no atomic needed)
     }
 }
 
