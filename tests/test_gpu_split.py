@@ -641,7 +641,8 @@ def test_weight_gradient_blocks_renumbered_onto_one_xcd_are_the_same_blocks(gpu,
 
 
 @pytest.mark.parametrize("case", [(2, 32, 64, 16, 64, 'bf16x3', False), (2, 32, 64, 16, 64, 'bf16x3', True), (2, 64, 128, 32, 32, 'bf16x3', True),
-                                  (1, 32, 64, 8, 128, 'bf16x2', True), (3, 64, 64, 20, 96, 'bf16x3', True), (2, 32, 128, 64, 64, 'bf16x2', False)])
+                                  (1, 32, 64, 8, 128, 'bf16x2', True), (3, 64, 64, 20, 96, 'bf16x3', True), (2, 32, 128, 64, 64, 'bf16x2', False),
+                                  (2, 96, 192, 16, 64, 'bf16x3', True), (1, 32, 64, 4, 32, 'bf16x3', 'all')])
 def test_pooled_weight_gradient_on_the_sparse_matrix_instruction(gpu, case):
     """5x5 conv -> activation -> MaxPool2D(2) (architectures/dcgan.py:42-60): the weight gradient contracts x with the max-pool
     backward of the pooled gradient -- one non-zero per window row unless two columns tie.  ghm_maxpool2_mask_bwd_compress_q writes
@@ -655,7 +656,9 @@ def test_pooled_weight_gradient_on_the_sparse_matrix_instruction(gpu, case):
     x = rng.randn(N, C, H, W).astype(np.float32)
     gp = rng.randn(N, K, Ho, Wo).astype(np.float32)
     mask = (1 << rng.randint(0, 4, size=(N, K, Ho, Wo))).astype(np.uint8)          # bit 2 r + c: one arg-max per window
-    if ties:        # tied window rows and whole tied windows (flat terrain) in three pooled rows
+    if ties == 'all':       # flat terrain everywhere: every window ties, every row runs densely
+        mask[:] = 0b1111
+    elif ties:      # tied window rows and whole tied windows in three pooled rows
         for (n, i) in [(0, 1), (N - 1, Ho - 1), (0, Ho // 2)]:
             mask[n, ::3, i, ::5] = 0b0011
             mask[n, 1::3, i, 1::7] = 0b1111
@@ -678,7 +681,7 @@ def test_pooled_weight_gradient_on_the_sparse_matrix_instruction(gpu, case):
     want[:, 0::2] = ((mask & 3) == 3).any(axis=(1, 3))
     want[:, 1::2] = (((mask >> 2) & 3) == 3).any(axis=(1, 3))
     assert np.array_equal(fl.reshape(N, H) != 0, want)
-    assert want.any() == ties
+    assert want.any() == bool(ties) and (ties != 'all' or want.all())
     dyd = dx.numpy()
     ws = dev.alloc(max(ops.wgrad_lp_workspace(d), 16))
     a, b = dev.zeros((1, C * 25 * K, 1, 1)), dev.zeros((1, C * 25 * K, 1, 1))
